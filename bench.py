@@ -1,0 +1,149 @@
+#!/usr/bin/env python3
+"""bench.py -- assembled+flushed nnz/s on the 256^3 7-point stencil (BASELINE.json config 2).
+
+A "step" is one fresh assembly of fdrand(Float64,n,n,n; matrixtype=ExtendableSparseMatrix)
+(src/matrix/sprand.jl:226-256): the update stream is produced on the device straight into the COO
+append buffer (inputs resident in HBM, no PCIe in the timed region), then flush! builds the CSC.
+value = nnz of the resulting CSC x steps x ranks / wall time (max over ranks).
+
+Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, hipEvent-timed on the
+library's stream), "pipeline" (whole step against the compulsory bytes of SURVEY.md section 8d),
+"cpu_baseline" (the C oracle timed on this box's host, bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def fd_counts(n):
+    E = 12 * n * n * (n - 1) + 6 * n * n
+    Z = n ** 3 + 6 * n * n * (n - 1)
+    return E, Z
+
+
+def cpu_baseline(sample_n):
+    """Reference algorithm (LNK insert via updateindex! + lnk+csc flush) on the host, 1 thread."""
+    from oracle import oracle as orc
+    z, ti, tf = orc.bench_fdrand(sample_n, sample_n, sample_n, orc.KIND_UPDATE)
+    return {"value": z / (ti + tf), "unit": "nnz/s", "cores": 1, "kind": "port",
+            "sample": "fdrand %d^3 fresh assemble+flush!, updateindex! style, C restatement of "
+                      "SparseMatrixLNK (oracle/), insert %.2fs + flush %.2fs; host has %d cores"
+                      % (sample_n, ti, tf, os.cpu_count())}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--n", type=int, default=int(os.environ.get("ESP_BENCH_N", "256")))
+    ap.add_argument("--cpu-sample-n", type=int, default=int(os.environ.get("ESP_BENCH_CPU_N", "160")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    torch.cuda.set_device(local)
+
+    from esparse_loader import load
+    esp = load()
+    n = args.n
+    N = n ** 3
+    E, Z = fd_counts(n)
+    A = esp.ExtendableSparseMatrix(N, N, device=local, capacity_hint=E)
+    A.timing_enable(True)
+
+    def step():
+        A.reset()
+        A.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1, kind=esp.ESP_UPDATE)
+        A.flush()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    A.timing(clear=True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert A.nnz() == Z, (A.nnz(), Z)
+    tm = A.timing(clear=True)
+
+    if rank == 0:
+        # dominant kernel = the stage with the largest summed device time
+        stage_ms = {k: v[0] for k, v in tm.items() if isinstance(v, tuple)}
+        dom = max(stage_ms, key=stage_ms.get)
+        dom_ms, dom_launches = tm[dom]
+        per_launch_bytes = {
+            # algorithmic bytes of ONE launch of the stage's kernel over the E appended entries
+            "scatter": 32.0 * E,          # read 16 B (key+value), write 16 B per entry
+            "hist": 8.0 * E,              # read the keys
+            "append": 16.0 * E,           # write key+value
+            "local": 16.0 * E + 16.0 * Z + 8.0 * (N + 1),
+            "fold": 16.0 * E + 16.0 * Z,
+        }.get(dom, 16.0 * E)
+        avg_ms = dom_ms / max(dom_launches, 1)
+        achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
+        algo_bytes = 2 * 16.0 * E + 16.0 * Z + 8.0 * (N + 1)   # 72.08 B per final nnz
+        ms_step = dt / args.steps * 1e3
+        out = {
+            "metric": "assembled+flushed nnz/sec, 256^3 7-pt stencil (fdrand) fresh CSC",
+            "value": Z * args.steps * world / dt,
+            "unit": "nnz/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms_step,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "fdrand %d^3 Float64/Int64 fresh build: device COO append -> stable radix "
+                                   "partition -> ordered fold -> CSC (BASELINE.json configs[1])" % n,
+                       "n": n, "appended_entries": E, "final_nnz": Z,
+                       "parallelism": "replicas x%d (no exchange)" % world if world > 1 else "1 GPU"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "avg_launch_ms": avg_ms, "launches": dom_launches,
+                         "algorithmic_bytes_per_launch": per_launch_bytes},
+            "pipeline": {"algorithmic_bytes_per_step": algo_bytes, "bytes_per_final_nnz": algo_bytes / Z,
+                         "achieved_GBs": algo_bytes / (ms_step * 1e-3) / 1e9,
+                         "frac_of_hbm_peak": algo_bytes / (ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "stage_ms_per_step": {k: v / args.steps for k, v in stage_ms.items()},
+                         "flush_ms_per_step": tm["flush_ms"] / max(tm["flushes"], 1)},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n)
+        print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,53 @@
+// common.hpp -- shared declarations of libesparse_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "../../include/esparse_hip.h"
+
+typedef int64_t i64;
+typedef uint64_t u64;
+typedef uint32_t u32;
+
+#define ESP_WAVE 64
+
+// Packed key of an appended entry:  ((col0 << rb) | row0) << 2 | kind.
+// The two kind bits never take part in any sort; (col0,row0) are 0-based.
+#define ESP_TAG_BITS 2
+#define ESP_TAG_MASK 3ull
+
+struct KeyLayout {
+    int rb;  // bits of a 0-based row index
+    int cb;  // bits of a 0-based column index
+    __host__ __device__ int sort_bits() const { return rb + cb; }
+    __host__ __device__ u64 rowmask() const { return (1ull << rb) - 1ull; }
+};
+
+__host__ __device__ inline u64 esp_pack(const KeyLayout &L, i64 row1, i64 col1, int kind) {
+    return ((((u64)(col1 - 1) << L.rb) | (u64)(row1 - 1)) << ESP_TAG_BITS) | (u64)kind;
+}
+
+__host__ __device__ inline u64 esp_mix64(u64 z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+// counter-based uniform in [0,1): same formula as oracle/esparse_oracle.c:orc_uniform
+__host__ __device__ inline double esp_uniform(u64 seed, u64 counter) {
+    u64 z = esp_mix64(seed + (counter + 1) * 0x9E3779B97F4A7C15ull);
+    return (double)(z >> 11) * 0x1.0p-53;
+}
+
+static inline int bits_for(i64 extent) {  // bits needed for 0..extent-1, at least 1
+    int b = 1;
+    while (b < 62 && ((i64)1 << b) < extent) b++;
+    return b;
+}
+
+template <typename T>
+static inline T ceil_div(T a, T b) {
+    return (a + b - 1) / b;
+}

@@ -1,0 +1,900 @@
+// esparse_hip.hip -- C ABI of libesparse_hip.so (see include/esparse_hip.h) and the host
+// orchestration of the flush pipeline.  gfx950 only; no CPU fallback of any kind: without
+// a GPU every entry point that needs one returns ESP_ERR_NODEVICE.
+#include <stdio.h>
+#include <string.h>
+
+#include <algorithm>
+
+#include "common.hpp"
+#include "fold.hpp"
+#include "generators.hpp"
+#include "merge.hpp"
+#include "radix.hpp"
+#include "scan.hpp"
+
+// ------------------------------------------------------------------------ handle
+struct DevBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+};
+
+struct TimedSpan {
+    int stage;
+    hipEvent_t a, b;
+    int launches;
+};
+
+struct esp_handle {
+    i64 m = 0, n = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    KeyLayout L{1, 1};
+    std::string err;
+
+    // COO append buffer
+    DevBuf keys, vals;
+    i64 cap = 0, count = 0;
+    // ping-pong / scratch
+    DevBuf keys2, vals2, hist, segs, colend, newkey, newval, heads, misc;
+    // device CSC (Julia layout) + spare set for rebuilds
+    DevBuf colptr, rowval, nzval, rowval2, nzval2;
+    i64 nnz = 0;
+    bool csc_valid = false;  // colptr initialised
+    // host staging (pinned) + device staging
+    i64 stage_cap = 0;
+    i64 *st_rows = nullptr, *st_cols = nullptr;
+    double *st_vals = nullptr;
+    uint8_t *st_kinds = nullptr;
+    DevBuf d_st_rows, d_st_cols, d_st_vals, d_st_kinds;
+    unsigned long long *pin_scalar = nullptr;  // pinned, 8 slots
+    // shard cache
+    bool shard_valid = false;
+    int shard_P = 0;
+    // timing
+    bool timing = false;
+    std::vector<hipEvent_t> ev_pool;
+    std::vector<TimedSpan> spans;
+    esp_timing_t acc;
+    hipEvent_t flush_a = nullptr, flush_b = nullptr;
+};
+
+static thread_local std::string g_err;
+
+#define FAIL(h, code, ...)                                   \
+    do {                                                     \
+        char _b[512];                                        \
+        snprintf(_b, sizeof _b, __VA_ARGS__);                \
+        if (h) (h)->err = _b;                                \
+        g_err = _b;                                          \
+        return (code);                                       \
+    } while (0)
+
+#define HIPCK(h, call)                                                                          \
+    do {                                                                                        \
+        hipError_t _e = (call);                                                                 \
+        if (_e != hipSuccess)                                                                   \
+            FAIL(h, _e == hipErrorOutOfMemory ? ESP_ERR_NOMEM : ESP_ERR_HIP, "%s failed: %s",   \
+                 #call, hipGetErrorString(_e));                                                 \
+    } while (0)
+
+#define CK(...)                       \
+    do {                              \
+        int32_t _s = (__VA_ARGS__);   \
+        if (_s != ESP_OK) return _s;  \
+    } while (0)
+
+static int32_t ensure(esp_handle *h, DevBuf &b, size_t need, bool keep = false) {
+    if (b.bytes >= need && b.p) return ESP_OK;
+    size_t want = need;
+    if (keep && b.bytes) want = std::max(need, b.bytes + b.bytes / 2);
+    want = (want + 255) & ~(size_t)255;
+    void *np = nullptr;
+    HIPCK(h, hipMalloc(&np, want));
+    if (keep && b.p && b.bytes) {
+        HIPCK(h, hipMemcpyAsync(np, b.p, b.bytes, hipMemcpyDeviceToDevice, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+    }
+    if (b.p) (void)hipFree(b.p);
+    b.p = np;
+    b.bytes = want;
+    return ESP_OK;
+}
+static void release(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+// ------------------------------------------------------------------------ timing
+static hipEvent_t ev_get(esp_handle *h) {
+    if (!h->ev_pool.empty()) {
+        hipEvent_t e = h->ev_pool.back();
+        h->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+static void timing_collect(esp_handle *h) {
+    if (h->spans.empty()) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (auto &s : h->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            if (s.stage >= 0) {
+                h->acc.ms[s.stage] += ms;
+                h->acc.launches[s.stage] += s.launches;
+            } else {
+                h->acc.flush_ms += ms;
+                h->acc.flushes += 1;
+            }
+        }
+        h->ev_pool.push_back(s.a);
+        h->ev_pool.push_back(s.b);
+    }
+    h->spans.clear();
+}
+struct Span {
+    esp_handle *h;
+    int stage;
+    hipEvent_t a = nullptr;
+    int launches = 0;
+    Span(esp_handle *hh, int st) : h(hh), stage(st) {
+        if (h->timing) {
+            a = ev_get(h);
+            (void)hipEventRecord(a, h->stream);
+        }
+    }
+    void add(int l) { launches += l; }
+    ~Span() {
+        if (h->timing && a) {
+            hipEvent_t b = ev_get(h);
+            (void)hipEventRecord(b, h->stream);
+            h->spans.push_back({stage, a, b, launches});
+            if (h->spans.size() > 2048) timing_collect(h);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------ small kernels
+__global__ void set_i64_k(i64 *p, i64 a, i64 b, i64 c, i64 d) {
+    p[0] = a;
+    p[1] = b;
+    p[2] = c;
+    p[3] = d;
+}
+__global__ void fill_i64_k(i64 *p, i64 n, i64 v) {
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) p[g] = v;
+}
+
+static inline unsigned grid_for(i64 n, int threads) { return (unsigned)std::max<i64>(1, ceil_div<i64>(n, threads)); }
+
+// ------------------------------------------------------------------------ lifetime
+extern "C" const char *esp_version(void) { return "esparse-hip 0.1 (gfx950)"; }
+
+extern "C" const char *esp_last_error(const esp_handle *h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+static int32_t init_empty_csc(esp_handle *h) {
+    CK(ensure(h, h->colptr, sizeof(i64) * (size_t)(h->n + 1)));
+    hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(h->n + 1, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p,
+                       h->n + 1, (i64)1);
+    h->nnz = 0;
+    h->csc_valid = true;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_create(int64_t m, int64_t n, int32_t device, int64_t capacity_hint, esp_handle **out) {
+    if (!out) FAIL((esp_handle *)nullptr, ESP_ERR_INVALID, "esp_create: out is NULL");
+    *out = nullptr;
+    if (m < 0 || n < 0) FAIL((esp_handle *)nullptr, ESP_ERR_INVALID, "esp_create: negative dimension");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        FAIL((esp_handle *)nullptr, ESP_ERR_NODEVICE, "esp_create: no HIP device available (libesparse_hip has no CPU path)");
+    if (device < 0 || device >= ndev)
+        FAIL((esp_handle *)nullptr, ESP_ERR_INVALID, "esp_create: device %d out of range (0..%d)", device, ndev - 1);
+    const int rb = bits_for(m), cb = bits_for(n);
+    if (rb + cb + ESP_TAG_BITS > 64)
+        FAIL((esp_handle *)nullptr, ESP_ERR_UNSUPPORTED, "esp_create: %lld x %lld needs %d key bits (max 62)",
+             (long long)m, (long long)n, rb + cb);
+    esp_handle *h = new esp_handle();
+    h->m = m;
+    h->n = n;
+    h->device = device;
+    h->L = KeyLayout{rb, cb};
+    memset(&h->acc, 0, sizeof h->acc);
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        FAIL((esp_handle *)nullptr, ESP_ERR_HIP, "esp_create: cannot create a stream on device %d", device);
+    }
+    h->own_stream = true;
+    if (hipHostMalloc((void **)&h->pin_scalar, 64, hipHostMallocDefault) != hipSuccess) {
+        (void)hipStreamDestroy(h->stream);
+        delete h;
+        FAIL((esp_handle *)nullptr, ESP_ERR_NOMEM, "esp_create: pinned scalar allocation failed");
+    }
+    int32_t st = init_empty_csc(h);
+    if (st == ESP_OK && capacity_hint > 0) {
+        st = ensure(h, h->keys, sizeof(u64) * (size_t)capacity_hint);
+        if (st == ESP_OK) st = ensure(h, h->vals, sizeof(double) * (size_t)capacity_hint);
+        if (st == ESP_OK) h->cap = capacity_hint;
+    }
+    if (st != ESP_OK) {
+        g_err = h->err;
+        esp_destroy(h);
+        return st;
+    }
+    *out = h;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_destroy(esp_handle *h) {
+    if (!h) return ESP_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    for (DevBuf *b : {&h->keys, &h->vals, &h->keys2, &h->vals2, &h->hist, &h->segs, &h->colend, &h->newkey,
+                      &h->newval, &h->heads, &h->misc, &h->colptr, &h->rowval, &h->nzval, &h->rowval2,
+                      &h->nzval2, &h->d_st_rows, &h->d_st_cols, &h->d_st_vals, &h->d_st_kinds})
+        release(*b);
+    if (h->st_rows) (void)hipHostFree(h->st_rows);
+    if (h->st_cols) (void)hipHostFree(h->st_cols);
+    if (h->st_vals) (void)hipHostFree(h->st_vals);
+    if (h->st_kinds) (void)hipHostFree(h->st_kinds);
+    if (h->pin_scalar) (void)hipHostFree(h->pin_scalar);
+    for (auto &s : h->spans) {
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_set_stream(esp_handle *h, void *hip_stream) {
+    if (!h) return ESP_ERR_INVALID;
+    (void)hipStreamSynchronize(h->stream);
+    timing_collect(h);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    return ESP_OK;
+}
+extern "C" int32_t esp_synchronize(esp_handle *h) {
+    if (!h) return ESP_ERR_INVALID;
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return ESP_OK;
+}
+extern "C" int32_t esp_size(const esp_handle *h, int64_t *m, int64_t *n) {
+    if (!h) return ESP_ERR_INVALID;
+    if (m) *m = h->m;
+    if (n) *n = h->n;
+    return ESP_OK;
+}
+extern "C" int32_t esp_key_layout(const esp_handle *h, int32_t *row_bits, int32_t *col_bits) {
+    if (!h) return ESP_ERR_INVALID;
+    if (row_bits) *row_bits = h->L.rb;
+    if (col_bits) *col_bits = h->L.cb;
+    return ESP_OK;
+}
+extern "C" int32_t esp_pending(const esp_handle *h, int64_t *count) {
+    if (!h || !count) return ESP_ERR_INVALID;
+    *count = h->count;
+    return ESP_OK;
+}
+extern "C" int32_t esp_nnz(const esp_handle *h, int64_t *nnz) {
+    if (!h || !nnz) return ESP_ERR_INVALID;
+    *nnz = h->nnz;
+    return ESP_OK;
+}
+
+// ------------------------------------------------------------------------ append
+static int32_t reserve_append(esp_handle *h, i64 add) {
+    const i64 need = h->count + add;
+    if (need <= h->cap) return ESP_OK;
+    i64 ncap = std::max<i64>(need, h->cap + h->cap / 2);
+    ncap = std::max<i64>(ncap, 1024);
+    // keep contents: only the first count entries matter
+    DevBuf nk, nv;
+    CK(ensure(h, nk, sizeof(u64) * (size_t)ncap));
+    CK(ensure(h, nv, sizeof(double) * (size_t)ncap));
+    if (h->count > 0) {
+        HIPCK(h, hipMemcpyAsync(nk.p, h->keys.p, sizeof(u64) * (size_t)h->count, hipMemcpyDeviceToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(nv.p, h->vals.p, sizeof(double) * (size_t)h->count, hipMemcpyDeviceToDevice, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+    }
+    release(h->keys);
+    release(h->vals);
+    h->keys = nk;
+    h->vals = nv;
+    h->cap = ncap;
+    return ESP_OK;
+}
+
+// pack count triples that already sit in device memory; checks bounds before committing
+static int32_t pack_device(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const double *d_vals,
+                           const uint8_t *d_kinds, int kind_all, int op, i64 count) {
+    if (count == 0) return ESP_OK;
+    if (!d_kinds && (kind_all < 0 || kind_all > 2)) FAIL(h, ESP_ERR_INVALID, "append: kind %d invalid", kind_all);
+    if (op != ESP_OP_ADD && op != ESP_OP_SUB) FAIL(h, ESP_ERR_UNSUPPORTED, "append: op %d not supported on the device path", op);
+    CK(reserve_append(h, count));
+    h->pin_scalar[0] = ~0ull;
+    CK(ensure(h, h->misc, 256));
+    unsigned long long *d_err = (unsigned long long *)h->misc.p;
+    HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 8, hipMemcpyHostToDevice, h->stream));
+    {
+        Span sp(h, ESP_ST_APPEND);
+        hipLaunchKernelGGL(espgen::pack_k, dim3(grid_for(count, espgen::THREADS)), dim3(espgen::THREADS), 0, h->stream,
+                           d_rows, d_cols, d_vals, d_kinds, kind_all, op == ESP_OP_SUB ? 1 : 0, count, h->m, h->n, h->L,
+                           (u64 *)h->keys.p + h->count, (double *)h->vals.p + h->count, d_err);
+        sp.add(1);
+    }
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (h->pin_scalar[0] != ~0ull)
+        FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
+             (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
+    h->count += count;
+    h->shard_valid = false;
+    return ESP_OK;
+}
+
+static int32_t ensure_stage(esp_handle *h, i64 want) {
+    if (want <= h->stage_cap) return ESP_OK;
+    i64 cap = std::max<i64>(want, 1 << 16);
+    if (h->st_rows) (void)hipHostFree(h->st_rows);
+    if (h->st_cols) (void)hipHostFree(h->st_cols);
+    if (h->st_vals) (void)hipHostFree(h->st_vals);
+    if (h->st_kinds) (void)hipHostFree(h->st_kinds);
+    h->st_rows = h->st_cols = nullptr;
+    h->st_vals = nullptr;
+    h->st_kinds = nullptr;
+    h->stage_cap = 0;
+    HIPCK(h, hipHostMalloc((void **)&h->st_rows, sizeof(i64) * (size_t)cap, hipHostMallocDefault));
+    HIPCK(h, hipHostMalloc((void **)&h->st_cols, sizeof(i64) * (size_t)cap, hipHostMallocDefault));
+    HIPCK(h, hipHostMalloc((void **)&h->st_vals, sizeof(double) * (size_t)cap, hipHostMallocDefault));
+    HIPCK(h, hipHostMalloc((void **)&h->st_kinds, (size_t)cap, hipHostMallocDefault));
+    CK(ensure(h, h->d_st_rows, sizeof(i64) * (size_t)cap));
+    CK(ensure(h, h->d_st_cols, sizeof(i64) * (size_t)cap));
+    CK(ensure(h, h->d_st_vals, sizeof(double) * (size_t)cap));
+    CK(ensure(h, h->d_st_kinds, (size_t)cap));
+    h->stage_cap = cap;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_stage_begin(esp_handle *h, int64_t want, int64_t **rows, int64_t **cols, double **vals,
+                                   uint8_t **kinds, int64_t *got) {
+    if (!h || !rows || !cols || !vals || !got) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    if (want <= 0) want = 1 << 20;
+    want = std::min<i64>(want, (i64)1 << 26);
+    CK(ensure_stage(h, want));
+    *rows = h->st_rows;
+    *cols = h->st_cols;
+    *vals = h->st_vals;
+    if (kinds) *kinds = h->st_kinds;
+    *got = h->stage_cap;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_commit(esp_handle *h, int64_t count, int32_t kind_all, int32_t op) {
+    if (!h) return ESP_ERR_INVALID;
+    if (count < 0 || count > h->stage_cap) FAIL(h, ESP_ERR_INVALID, "esp_commit: count %lld exceeds the staged chunk", (long long)count);
+    if (count == 0) return ESP_OK;
+    (void)hipSetDevice(h->device);
+    {
+        Span sp(h, ESP_ST_COPY);
+        HIPCK(h, hipMemcpyAsync(h->d_st_rows.p, h->st_rows, sizeof(i64) * (size_t)count, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(h->d_st_cols.p, h->st_cols, sizeof(i64) * (size_t)count, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(h->d_st_vals.p, h->st_vals, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, h->stream));
+        sp.add(3);
+        if (kind_all < 0) {
+            HIPCK(h, hipMemcpyAsync(h->d_st_kinds.p, h->st_kinds, (size_t)count, hipMemcpyHostToDevice, h->stream));
+            sp.add(1);
+        }
+    }
+    return pack_device(h, (const i64 *)h->d_st_rows.p, (const i64 *)h->d_st_cols.p, (const double *)h->d_st_vals.p,
+                       kind_all < 0 ? (const uint8_t *)h->d_st_kinds.p : nullptr, kind_all, op, count);
+}
+
+extern "C" int32_t esp_append_host(esp_handle *h, const int64_t *rows, const int64_t *cols, const double *vals,
+                                   const uint8_t *kinds, int32_t kind_all, int32_t op, int64_t count) {
+    if (!h || count < 0 || (count > 0 && (!rows || !cols || !vals))) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    const i64 chunk = (i64)1 << 22;
+    const i64 start_count = h->count;
+    for (i64 off = 0; off < count; off += chunk) {
+        const i64 c = std::min<i64>(chunk, count - off);
+        int64_t *r, *cc;
+        double *v;
+        uint8_t *k;
+        int64_t got;
+        CK(esp_stage_begin(h, c, &r, &cc, &v, &k, &got));
+        memcpy(r, rows + off, sizeof(i64) * (size_t)c);
+        memcpy(cc, cols + off, sizeof(i64) * (size_t)c);
+        memcpy(v, vals + off, sizeof(double) * (size_t)c);
+        if (kinds) memcpy(k, kinds + off, (size_t)c);
+        int32_t st = esp_commit(h, c, kinds ? -1 : kind_all, op);
+        if (st != ESP_OK) {
+            h->count = start_count;  // the whole call is one batch: nothing is committed
+            return st;
+        }
+    }
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_append_device(esp_handle *h, const int64_t *d_rows, const int64_t *d_cols, const double *d_vals,
+                                     const uint8_t *d_kinds, int32_t kind_all, int32_t op, int64_t count) {
+    if (!h || count < 0 || (count > 0 && (!d_rows || !d_cols || !d_vals))) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    return pack_device(h, d_rows, d_cols, d_vals, d_kinds, kind_all, op, count);
+}
+
+extern "C" int32_t esp_append_packed(esp_handle *h, const uint64_t *d_keys, const double *d_vals, int64_t count) {
+    if (!h || count < 0 || (count > 0 && (!d_keys || !d_vals))) return ESP_ERR_INVALID;
+    if (count == 0) return ESP_OK;
+    (void)hipSetDevice(h->device);
+    CK(reserve_append(h, count));
+    Span sp(h, ESP_ST_COPY);
+    HIPCK(h, hipMemcpyAsync((u64 *)h->keys.p + h->count, d_keys, sizeof(u64) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync((double *)h->vals.p + h->count, d_vals, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
+    sp.add(2);
+    h->count += count;
+    h->shard_valid = false;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_generate_fdrand(esp_handle *h, int64_t nx, int64_t ny, int64_t nz, uint64_t seed,
+                                       int32_t rand_mode, int32_t kind) {
+    if (!h) return ESP_ERR_INVALID;
+    if (nx < 1 || ny < 1 || nz < 1) FAIL(h, ESP_ERR_INVALID, "fdrand: bad grid");
+    const i64 N = nx * ny * nz;
+    if (h->m != N || h->n != N) FAIL(h, ESP_ERR_INVALID, "Matrix size mismatch");  // sprand.jl:66-68
+    if (kind != ESP_UPDATE && kind != ESP_RAWUPDATE) FAIL(h, ESP_ERR_INVALID, "fdrand: kind must be UPDATE or RAWUPDATE");
+    if (rand_mode < 0 || rand_mode > 2) FAIL(h, ESP_ERR_INVALID, "fdrand: rand_mode");
+    (void)hipSetDevice(h->device);
+    i64 E = 4 * (nx - 1) * ny * nz + (nx == 1 ? 1 : 2) * ny * nz;
+    E += 4 * nx * (ny - 1) * nz + (ny > 2 ? 2 * nx * nz : 0);
+    E += 4 * nx * ny * (nz - 1) + (nz > 2 ? 2 * nx * ny : 0);
+    CK(reserve_append(h, E));
+    espgen::FdArgs a;
+    a.nx = nx;
+    a.ny = ny;
+    a.nz = nz;
+    a.hx = 1.0 / (double)nx;
+    a.hy = 1.0 / (double)ny;
+    a.hz = 1.0 / (double)nz;
+    a.seed = seed;
+    a.rand_mode = rand_mode;
+    a.kind = kind;
+    a.L = h->L;
+    a.keys = (u64 *)h->keys.p + h->count;
+    a.vals = (double *)h->vals.p + h->count;
+    {
+        Span sp(h, ESP_ST_APPEND);
+        hipLaunchKernelGGL(espgen::fdrand_k, dim3(grid_for(N, espgen::THREADS)), dim3(espgen::THREADS), 0, h->stream, a);
+        sp.add(1);
+    }
+    HIPCK(h, hipGetLastError());
+    h->count += E;
+    h->shard_valid = false;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_generate_fem(esp_handle *h, int32_t dim, int64_t npd, uint64_t seed, int32_t order_mode) {
+    if (!h) return ESP_ERR_INVALID;
+    if ((dim != 2 && dim != 3) || npd < 2) FAIL(h, ESP_ERR_INVALID, "fem: dim must be 2 or 3 and npd >= 2");
+    const i64 nn = dim == 2 ? npd * npd : npd * npd * npd;
+    if (h->m != nn || h->n != nn) FAIL(h, ESP_ERR_INVALID, "Matrix size mismatch");
+    (void)hipSetDevice(h->device);
+    const i64 q = npd - 1;
+    const i64 nc = dim == 2 ? 2 * q * q : 6 * q * q * q;
+    const i64 E = nc * (dim + 1) * (dim + 2);
+    CK(reserve_append(h, E));
+    espgen::FemArgs a;
+    a.dim = dim;
+    a.npd = npd;
+    a.ncells = nc;
+    a.seed = seed;
+    a.order_mode = order_mode;
+    int bits = 2;
+    while (((u64)1 << bits) < (u64)nc) bits += 2;
+    a.bits = bits;
+    a.h = 1.0 / (double)(npd - 1);
+    a.L = h->L;
+    a.keys = (u64 *)h->keys.p + h->count;
+    a.vals = (double *)h->vals.p + h->count;
+    {
+        Span sp(h, ESP_ST_APPEND);
+        hipLaunchKernelGGL(espgen::fem_k, dim3(grid_for(nc, espgen::THREADS)), dim3(espgen::THREADS), 0, h->stream, a);
+        sp.add(1);
+    }
+    HIPCK(h, hipGetLastError());
+    h->count += E;
+    h->shard_valid = false;
+    return ESP_OK;
+}
+
+// ------------------------------------------------------------------------ CSC side
+extern "C" int32_t esp_set_csc(esp_handle *h, const int64_t *colptr, const int64_t *rowval, const double *nzval, int64_t nnz) {
+    if (!h || !colptr || nnz < 0 || (nnz > 0 && (!rowval || !nzval))) return ESP_ERR_INVALID;
+    if (colptr[0] != 1 || colptr[h->n] != nnz + 1) FAIL(h, ESP_ERR_INVALID, "esp_set_csc: colptr[1]=%lld colptr[n+1]=%lld nnz=%lld violate the CSC invariants", (long long)colptr[0], (long long)colptr[h->n], (long long)nnz);
+    (void)hipSetDevice(h->device);
+    CK(ensure(h, h->colptr, sizeof(i64) * (size_t)(h->n + 1)));
+    CK(ensure(h, h->rowval, sizeof(i64) * (size_t)std::max<i64>(nnz, 1)));
+    CK(ensure(h, h->nzval, sizeof(double) * (size_t)std::max<i64>(nnz, 1)));
+    Span sp(h, ESP_ST_COPY);
+    HIPCK(h, hipMemcpyAsync(h->colptr.p, colptr, sizeof(i64) * (size_t)(h->n + 1), hipMemcpyHostToDevice, h->stream));
+    if (nnz > 0) {
+        HIPCK(h, hipMemcpyAsync(h->rowval.p, rowval, sizeof(i64) * (size_t)nnz, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(h->nzval.p, nzval, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, h->stream));
+    }
+    sp.add(3);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    h->nnz = nnz;
+    h->csc_valid = true;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_get_csc(esp_handle *h, int64_t *colptr, int64_t *rowval, double *nzval) {
+    if (!h || !colptr) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    {
+        Span sp(h, ESP_ST_COPY);
+        HIPCK(h, hipMemcpyAsync(colptr, h->colptr.p, sizeof(i64) * (size_t)(h->n + 1), hipMemcpyDeviceToHost, h->stream));
+        if (h->nnz > 0) {
+            if (!rowval || !nzval) FAIL(h, ESP_ERR_INVALID, "esp_get_csc: rowval/nzval NULL with nnz>0");
+            HIPCK(h, hipMemcpyAsync(rowval, h->rowval.p, sizeof(i64) * (size_t)h->nnz, hipMemcpyDeviceToHost, h->stream));
+            HIPCK(h, hipMemcpyAsync(nzval, h->nzval.p, sizeof(double) * (size_t)h->nnz, hipMemcpyDeviceToHost, h->stream));
+        }
+        sp.add(3);
+    }
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_get_nzval(esp_handle *h, double *nzval) {
+    if (!h) return ESP_ERR_INVALID;
+    if (h->nnz == 0) return ESP_OK;
+    if (!nzval) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    HIPCK(h, hipMemcpyAsync(nzval, h->nzval.p, sizeof(double) * (size_t)h->nnz, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_csc_device(esp_handle *h, const int64_t **d_colptr, const int64_t **d_rowval, const double **d_nzval) {
+    if (!h) return ESP_ERR_INVALID;
+    if (d_colptr) *d_colptr = (const i64 *)h->colptr.p;
+    if (d_rowval) *d_rowval = (const i64 *)h->rowval.p;
+    if (d_nzval) *d_nzval = (const double *)h->nzval.p;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_clear_pending(esp_handle *h) {
+    if (!h) return ESP_ERR_INVALID;
+    h->count = 0;
+    h->shard_valid = false;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_reset(esp_handle *h) {
+    if (!h) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    h->count = 0;
+    h->shard_valid = false;
+    return init_empty_csc(h);
+}
+
+extern "C" int32_t esp_zero_values(esp_handle *h) {
+    if (!h) return ESP_ERR_INVALID;
+    if (h->nnz == 0) return ESP_OK;
+    (void)hipSetDevice(h->device);
+    HIPCK(h, hipMemsetAsync(h->nzval.p, 0, sizeof(double) * (size_t)h->nnz, h->stream));
+    return ESP_OK;
+}
+
+// exclusive scan helpers with scratch carved from h->misc
+template <typename T, bool MAX>
+static int32_t scan_inplace(esp_handle *h, T *data, i64 n, DevBuf &ws, int *launches) {
+    CK(ensure(h, ws, sizeof(T) * (size_t)espscan::workspace_elems(n)));
+    *launches += espscan::exclusive<T, MAX>(h->stream, data, data, n, (T *)ws.p);
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_dropzeros(esp_handle *h, int64_t *new_nnz) {
+    if (!h) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    const i64 Z = h->nnz;
+    if (Z == 0) {
+        if (new_nnz) *new_nnz = 0;
+        return ESP_OK;
+    }
+    if (Z >= 0xFFFFFFF0ll) FAIL(h, ESP_ERR_UNSUPPORTED, "dropzeros: nnz too large");
+    CK(ensure(h, h->vals2, sizeof(u32) * (size_t)(Z + 1)));
+    u32 *flag = (u32 *)h->vals2.p;
+    hipLaunchKernelGGL(espfold::nonzero_flags_k, dim3(grid_for(Z + 1, 256)), dim3(256), 0, h->stream, (const double *)h->nzval.p, Z, flag);
+    int l = 0;
+    CK(scan_inplace<u32, false>(h, flag, Z + 1, h->hist, &l));
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, flag + Z, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    const i64 Zk = (i64) * (u32 *)h->pin_scalar;
+    if (Zk != Z) {
+        CK(ensure(h, h->rowval2, sizeof(i64) * (size_t)std::max<i64>(Zk, 1)));
+        CK(ensure(h, h->nzval2, sizeof(double) * (size_t)std::max<i64>(Zk, 1)));
+        hipLaunchKernelGGL(espfold::dropzeros_compact_k, dim3(grid_for(Z, 256)), dim3(256), 0, h->stream, (const i64 *)h->rowval.p,
+                           (const double *)h->nzval.p, Z, flag, (i64 *)h->rowval2.p, (double *)h->nzval2.p);
+        CK(ensure(h, h->colend, sizeof(i64) * (size_t)(h->n + 1)));
+        hipLaunchKernelGGL(espfold::dropzeros_colptr_k, dim3(grid_for(h->n + 1, 256)), dim3(256), 0, h->stream, (const i64 *)h->colptr.p,
+                           h->n + 1, flag, (i64 *)h->colend.p);
+        std::swap(h->colptr, h->colend);
+        std::swap(h->rowval, h->rowval2);
+        std::swap(h->nzval, h->nzval2);
+        h->nnz = Zk;
+    }
+    if (new_nnz) *new_nnz = h->nnz;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_getindex(esp_handle *h, int64_t i, int64_t j, double *value, int32_t *found) {
+    if (!h || !value) return ESP_ERR_INVALID;
+    if (!(1 <= i && i <= h->m && 1 <= j && j <= h->n)) FAIL(h, ESP_ERR_BOUNDS, "BoundsError: (%lld,%lld) outside %lld x %lld", (long long)i, (long long)j, (long long)h->m, (long long)h->n);
+    (void)hipSetDevice(h->device);
+    CK(ensure(h, h->misc, 256));
+    espfold::Csc c{(const i64 *)h->colptr.p, (const i64 *)h->rowval.p, (double *)h->nzval.p, h->nnz};
+    double *d_out = (double *)h->misc.p + 8;
+    hipLaunchKernelGGL(espfold::getindex_k, dim3(1), dim3(1), 0, h->stream, c, i - 1, j - 1, d_out);
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_out, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    const double *r = (const double *)h->pin_scalar;
+    *value = r[0];
+    if (found) *found = r[1] != 0.0;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_pattern_hash(esp_handle *h, uint64_t *hash) {
+    if (!h || !hash) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    CK(ensure(h, h->misc, 256));
+    unsigned long long *acc = (unsigned long long *)h->misc.p + 16;
+    HIPCK(h, hipMemsetAsync(acc, 0, 16, h->stream));
+    const i64 work = std::max<i64>(h->n + 1, h->nnz);
+    const unsigned grid = (unsigned)std::min<i64>(2048, std::max<i64>(1, ceil_div<i64>(work, espfold::THREADS)));
+    hipLaunchKernelGGL(espfold::pattern_hash_k, dim3(grid), dim3(espfold::THREADS), 0, h->stream, (const i64 *)h->colptr.p, h->n + 1,
+                       (const i64 *)h->rowval.p, h->nnz, acc);
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, acc, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    const u64 h1 = h->pin_scalar[0], h2 = h->pin_scalar[1];
+    *hash = esp_mix64(h1 ^ esp_mix64(h2 + 0xD1B54A32D192ED03ull));
+    return ESP_OK;
+}
+
+// ------------------------------------------------------------------------ sort
+// One stable partition pass over S segments (device arrays seg_start/tile_first).
+// max_tiles bounds the grid; the scanned histogram stays in h->hist.
+static int32_t partition_pass(esp_handle *h, espradix::Pass &p, i64 max_tiles) {
+    const int R = 1 << p.bits;
+    const i64 hn = max_tiles * R;
+    const size_t hist_bytes = sizeof(u64) * (size_t)(hn + espscan::workspace_elems(hn));
+    CK(ensure(h, h->hist, hist_bytes));
+    p.hist = (u64 *)h->hist.p;
+    if (p.S > 1) HIPCK(h, hipMemsetAsync(p.hist, 0, sizeof(u64) * (size_t)hn, h->stream));
+    {
+        Span sp(h, ESP_ST_HIST);
+        hipLaunchKernelGGL(espradix::tile_hist_k, dim3((unsigned)max_tiles), dim3(espradix::THREADS), 0, h->stream, p);
+        sp.add(1);
+    }
+    {
+        Span sp(h, ESP_ST_SCAN);
+        sp.add(espscan::exclusive<u64, false>(h->stream, p.hist, p.hist, hn, p.hist + hn));
+    }
+    {
+        Span sp(h, ESP_ST_SCATTER);
+        hipLaunchKernelGGL(espradix::scatter_k, dim3((unsigned)max_tiles), dim3(espradix::THREADS), 0, h->stream, p);
+        sp.add(1);
+    }
+    return ESP_OK;
+}
+
+// full stable LSD sort of the pending entries on their (col,row) bits.  Result in *sk/*sv.
+static int32_t sort_pending_lsd(esp_handle *h, const u64 **sk, const double **sv) {
+    const i64 E = h->count;
+    CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
+    CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
+    CK(ensure(h, h->segs, sizeof(i64) * 8));
+    const i64 T = ceil_div<i64>(E, espradix::TILE);
+    i64 *segs = (i64 *)h->segs.p;
+    hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, segs, (i64)0, E, (i64)0, T);
+    u64 *kin = (u64 *)h->keys.p, *kout = (u64 *)h->keys2.p;
+    double *vin = (double *)h->vals.p, *vout = (double *)h->vals2.p;
+    const int K = h->L.sort_bits();
+    for (int done = 0; done < K; done += 8) {
+        espradix::Pass p;
+        p.keys_in = kin;
+        p.vals_in = vin;
+        p.keys_out = kout;
+        p.vals_out = vout;
+        p.seg_start = segs;
+        p.tile_first = segs + 2;
+        p.S = 1;
+        p.shift = ESP_TAG_BITS + done;
+        p.bits = std::min(8, K - done);
+        CK(partition_pass(h, p, T));
+        std::swap(kin, kout);
+        std::swap(vin, vout);
+    }
+    HIPCK(h, hipGetLastError());
+    *sk = kin;
+    *sv = vin;
+    // make keys/vals the scratch pair for the caller: after an odd number of passes the sorted
+    // data lives in keys2/vals2
+    if (kin != (u64 *)h->keys.p) {
+        std::swap(h->keys, h->keys2);
+        std::swap(h->vals, h->vals2);
+        // capacities may differ: keep cap consistent with the smaller of the two
+        h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
+    }
+    return ESP_OK;
+}
+
+// ------------------------------------------------------------------------ flush
+extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int32_t *pattern_changed) {
+    if (!h) return ESP_ERR_INVALID;
+    if (mode != ESP_FLUSH_ROUTED && mode != ESP_FLUSH_PLUS) FAIL(h, ESP_ERR_INVALID, "esp_flush: mode");
+    (void)hipSetDevice(h->device);
+    if (pattern_changed) *pattern_changed = 0;
+    const i64 E = h->count;
+    if (E == 0) {
+        if (new_nnz) *new_nnz = h->nnz;
+        return ESP_OK;
+    }
+    if (E >= 0xFFFFFFF0ll) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_flush: %lld pending entries exceed the 2^32 limit of one flush", (long long)E);
+    hipEvent_t fa = nullptr;
+    if (h->timing) {
+        fa = ev_get(h);
+        (void)hipEventRecord(fa, h->stream);
+    }
+    const u64 *sk;
+    const double *sv;
+    CK(sort_pending_lsd(h, &sk, &sv));  // sorted data now in h->keys/h->vals; keys2/vals2 are scratch
+
+    const i64 Z0 = h->nnz;
+    const i64 N1 = h->n + 1;
+    u32 *flag = (u32 *)h->vals2.p;        // E+1 u32 fits in E doubles (E>=1)
+    double *fval = (double *)h->keys2.p;  // E doubles
+    espfold::Csc csc{(const i64 *)h->colptr.p, (const i64 *)h->rowval.p, (double *)h->nzval.p, Z0};
+    {
+        Span sp(h, ESP_ST_FOLD);
+        hipLaunchKernelGGL(espfold::fold_k, dim3(grid_for(E + 1, espfold::THREADS)), dim3(espfold::THREADS), 0, h->stream, sk, sv, E,
+                           csc, h->L.rb, mode, flag, fval);
+        sp.add(1);
+    }
+    {
+        Span sp(h, ESP_ST_SCAN);
+        int l = 0;
+        CK(scan_inplace<u32, false>(h, flag, E + 1, h->hist, &l));
+        sp.add(l);
+    }
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, flag + E, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    const i64 Zn = (i64) * (u32 *)h->pin_scalar;
+
+    if (Zn > 0) {
+        CK(ensure(h, h->colend, sizeof(u64) * (size_t)(N1 + espscan::workspace_elems(N1))));
+        u64 *colend = (u64 *)h->colend.p;
+        HIPCK(h, hipMemsetAsync(colend, 0, sizeof(u64) * (size_t)N1, h->stream));
+        if (Z0 == 0) {
+            CK(ensure(h, h->rowval, sizeof(i64) * (size_t)Zn));
+            CK(ensure(h, h->nzval, sizeof(double) * (size_t)Zn));
+            {
+                Span sp(h, ESP_ST_FOLD);
+                hipLaunchKernelGGL((espfold::compact_k<true>), dim3(grid_for(E, espfold::THREADS)), dim3(espfold::THREADS), 0, h->stream,
+                                   sk, (const double *)fval, E, (const u32 *)flag, h->L.rb, (i64 *)h->rowval.p, (u64 *)nullptr,
+                                   (double *)h->nzval.p, colend);
+                sp.add(1);
+            }
+            {
+                Span sp(h, ESP_ST_COLPTR);
+                sp.add(espscan::exclusive<u64, true>(h->stream, colend, colend, N1, colend + N1));
+                hipLaunchKernelGGL(espfold::colptr_finish_k, dim3(grid_for(N1, 256)), dim3(256), 0, h->stream, (const u64 *)colend,
+                                   (const i64 *)nullptr, N1, (i64 *)h->colptr.p);
+                sp.add(1);
+            }
+            h->nnz = Zn;
+        } else {
+            const i64 Zt = Z0 + Zn;
+            if (Z0 >= 0xFFFFFFF0ll) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_flush: CSC too large for the 32-bit column index");
+            CK(ensure(h, h->newkey, sizeof(u64) * (size_t)Zn));
+            CK(ensure(h, h->newval, sizeof(double) * (size_t)Zn));
+            {
+                Span sp(h, ESP_ST_FOLD);
+                hipLaunchKernelGGL((espfold::compact_k<false>), dim3(grid_for(E, espfold::THREADS)), dim3(espfold::THREADS), 0, h->stream,
+                                   sk, (const double *)fval, E, (const u32 *)flag, h->L.rb, (i64 *)nullptr, (u64 *)h->newkey.p,
+                                   (double *)h->newval.p, colend);
+                sp.add(1);
+            }
+            {
+                Span sp(h, ESP_ST_COLPTR);
+                sp.add(espscan::exclusive<u64, true>(h->stream, colend, colend, N1, colend + N1));
+                // column index of every stored entry
+                const i64 hn = Z0 + 1;
+                CK(ensure(h, h->heads, sizeof(u32) * (size_t)(hn + espscan::workspace_elems(hn))));
+                u32 *heads = (u32 *)h->heads.p;
+                HIPCK(h, hipMemsetAsync(heads, 0, sizeof(u32) * (size_t)hn, h->stream));
+                hipLaunchKernelGGL(espfold::col_heads_k, dim3(grid_for(h->n, 256)), dim3(256), 0, h->stream, (const i64 *)h->colptr.p, h->n, heads);
+                sp.add(1 + espscan::exclusive<u32, true>(h->stream, heads, heads, hn, heads + hn));
+            }
+            CK(ensure(h, h->rowval2, sizeof(i64) * (size_t)Zt));
+            CK(ensure(h, h->nzval2, sizeof(double) * (size_t)Zt));
+            {
+                Span sp(h, ESP_ST_MERGE);
+                espmerge::Args a;
+                a.old_col = (const u32 *)h->heads.p + 1;
+                a.old_row = (const i64 *)h->rowval.p;
+                a.old_val = (const double *)h->nzval.p;
+                a.Z0 = Z0;
+                a.new_key = (const u64 *)h->newkey.p;
+                a.new_val = (const double *)h->newval.p;
+                a.Zn = Zn;
+                a.rb = h->L.rb;
+                a.out_row = (i64 *)h->rowval2.p;
+                a.out_val = (double *)h->nzval2.p;
+                hipLaunchKernelGGL(espmerge::merge_k, dim3(grid_for(Zt, espmerge::TILE)), dim3(espmerge::THREADS), 0, h->stream, a);
+                sp.add(1);
+            }
+            {
+                Span sp(h, ESP_ST_COLPTR);
+                hipLaunchKernelGGL(espfold::colptr_finish_k, dim3(grid_for(N1, 256)), dim3(256), 0, h->stream, (const u64 *)colend,
+                                   (const i64 *)h->colptr.p, N1, (i64 *)h->colptr.p);
+                sp.add(1);
+            }
+            std::swap(h->rowval, h->rowval2);
+            std::swap(h->nzval, h->nzval2);
+            h->nnz = Zt;
+        }
+        if (pattern_changed) *pattern_changed = 1;
+    }
+    HIPCK(h, hipGetLastError());
+    h->count = 0;
+    h->shard_valid = false;
+    if (h->timing && fa) {
+        hipEvent_t fb = ev_get(h);
+        (void)hipEventRecord(fb, h->stream);
+        h->spans.push_back({-1, fa, fb, 0});
+    }
+    if (new_nnz) *new_nnz = h->nnz;
+    return ESP_OK;
+}
+
+// ------------------------------------------------------------------------ shards
+extern "C" int32_t esp_shard_counts(esp_handle *h, int32_t nshards, int64_t *counts) {
+    (void)h;
+    (void)nshards;
+    (void)counts;
+    FAIL(h, ESP_ERR_UNSUPPORTED, "esp_shard_counts: not built yet");
+}
+extern "C" int32_t esp_shard_export(esp_handle *h, int32_t nshards, uint64_t *d_keys, double *d_vals, int64_t *offsets) {
+    (void)nshards;
+    (void)d_keys;
+    (void)d_vals;
+    (void)offsets;
+    FAIL(h, ESP_ERR_UNSUPPORTED, "esp_shard_export: not built yet");
+}
+
+// ------------------------------------------------------------------------ measurement
+extern "C" int32_t esp_timing_enable(esp_handle *h, int32_t on) {
+    if (!h) return ESP_ERR_INVALID;
+    timing_collect(h);
+    h->timing = on != 0;
+    return ESP_OK;
+}
+extern "C" int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear) {
+    if (!h || !out) return ESP_ERR_INVALID;
+    timing_collect(h);
+    *out = h->acc;
+    if (clear) memset(&h->acc, 0, sizeof h->acc);
+    return ESP_OK;
+}

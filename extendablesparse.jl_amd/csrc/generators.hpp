@@ -1,0 +1,243 @@
+// generators.hpp -- append-path kernels (K1): pack host/device (i,j,v) triples into the
+// COO buffer, and on-device producers of the reference's update streams.
+// All of them write the buffer in the exact order of the sequential reference loop, so
+// the ordered fold reproduces the CPU accumulation order bit for bit.
+// Compiled with -ffp-contract=off: no FMA contraction, values match the oracle's bits.
+#pragma once
+#include "common.hpp"
+
+namespace espgen {
+
+constexpr int THREADS = 256;
+
+// (rows, cols, vals, kinds) -> packed keys.  Out-of-range indices raise *err (first bad
+// position + 1) and nothing of the batch is committed by the host side
+// (BoundsError, sparsematrixcsc.jl:8-10).
+__global__ __launch_bounds__(THREADS) void pack_k(const i64 *__restrict__ rows,
+                                                  const i64 *__restrict__ cols,
+                                                  const double *__restrict__ vals,
+                                                  const uint8_t *__restrict__ kinds, int kind_all,
+                                                  int negate, i64 count, i64 m, i64 n, KeyLayout L,
+                                                  u64 *__restrict__ keys, double *__restrict__ out,
+                                                  unsigned long long *__restrict__ err) {
+    const i64 g = (i64)blockIdx.x * THREADS + threadIdx.x;
+    if (g >= count) return;
+    const i64 r = rows[g], c = cols[g];
+    int kind = kinds ? (int)kinds[g] : kind_all;
+    if (!(1 <= r && r <= m && 1 <= c && c <= n) || kind < 0 || kind > 2) {
+        atomicMin(err, (unsigned long long)(g + 1));
+        return;
+    }
+    double v = vals[g];
+    if (negate && kind != ESP_SET) v = -v;
+    keys[g] = esp_pack(L, r, c, kind);
+    out[g] = v;
+}
+
+// ---- fdrand! stream (src/matrix/sprand.jl:87-124) -----------------------------------
+struct FdArgs {
+    i64 nx, ny, nz;
+    double hx, hy, hz;
+    u64 seed;
+    int rand_mode;
+    int kind;
+    KeyLayout L;
+    u64 *keys;
+    double *vals;
+};
+
+__device__ __forceinline__ double fd_rand(int mode, u64 seed, u64 ctr) {
+    if (mode == 0) return 1.0;
+    if (mode == 1) return 0.1 + esp_uniform(seed, ctr);
+    return esp_uniform(seed, ctr);
+}
+
+// number of update calls issued by nodes that precede node (i,j,k) (1-based) in the
+// k,j,i loop nest -- closed form, so every node writes at its exact stream position
+__device__ __forceinline__ i64 fd_offset(const FdArgs &a, i64 i, i64 j, i64 k, i64 *cy_out,
+                                         i64 *cz_out) {
+    const i64 nx = a.nx, ny = a.ny, nz = a.nz;
+    const i64 CX = 4 * (nx - 1) + (nx == 1 ? 1 : 2);
+    const i64 CY = 4 * (ny - 1) + (ny > 2 ? 2 : 0);
+    const i64 PX = 4 * (i - 1) + (i > 1 ? 1 : 0);
+    const i64 PY = 4 * (j - 1) + ((ny > 2 && j > 1) ? 1 : 0);
+    const i64 PZ = 4 * (k - 1) + ((nz > 2 && k > 1) ? 1 : 0);
+    const i64 cy = (j < ny ? 4 : 0) + ((ny > 2 && (j == 1 || j == ny)) ? 1 : 0);
+    const i64 cz = (k < nz ? 4 : 0) + ((nz > 2 && (k == 1 || k == nz)) ? 1 : 0);
+    *cy_out = cy;
+    *cz_out = cz;
+    return (k - 1) * (ny * CX + nx * CY) + nx * ny * PZ + (j - 1) * CX + nx * PY +
+           (j - 1) * nx * cz + PX + (i - 1) * (cy + cz);
+}
+
+__device__ __forceinline__ void fd_put(const FdArgs &a, i64 &o, double v, i64 row, i64 col) {
+    a.keys[o] = esp_pack(a.L, row, col, a.kind);
+    a.vals[o] = v;
+    o++;
+}
+__device__ __forceinline__ void fd_pair(const FdArgs &a, i64 &o, double v, i64 l, i64 l2) {
+    fd_put(a, o, -v, l, l2);  // update_pair: sprand.jl:87-92
+    fd_put(a, o, -v, l2, l);
+    fd_put(a, o, v, l, l);
+    fd_put(a, o, v, l2, l2);
+}
+
+__global__ __launch_bounds__(THREADS) void fdrand_k(FdArgs a) {
+    const i64 g = (i64)blockIdx.x * THREADS + threadIdx.x;  // node l-1
+    const i64 N = a.nx * a.ny * a.nz;
+    if (g >= N) return;
+    const i64 i = g % a.nx + 1, j = (g / a.nx) % a.ny + 1, k = g / (a.nx * a.ny) + 1;
+    i64 cy, cz;
+    i64 o = fd_offset(a, i, j, k, &cy, &cz);
+    const i64 l = g + 1;
+    const u64 c = 6ull * (u64)g;
+    if (i < a.nx) fd_pair(a, o, fd_rand(a.rand_mode, a.seed, c + 0) * a.hy * a.hz / a.hx, l, l + 1);
+    if (i == 1 || i == a.nx) fd_put(a, o, fd_rand(a.rand_mode, a.seed, c + 1) * a.hy * a.hz, l, l);
+    if (j < a.ny) fd_pair(a, o, fd_rand(a.rand_mode, a.seed, c + 2) * a.hx * a.hz / a.hy, l, l + a.nx);
+    if (a.ny > 2 && (j == 1 || j == a.ny))
+        fd_put(a, o, fd_rand(a.rand_mode, a.seed, c + 3) * a.hx * a.hz, l, l);
+    if (k < a.nz)
+        fd_pair(a, o, fd_rand(a.rand_mode, a.seed, c + 4) * a.hx * a.hy / a.hz, l, l + a.nx * a.ny);
+    if (a.nz > 2 && (k == 1 || k == a.nz))
+        fd_put(a, o, fd_rand(a.rand_mode, a.seed, c + 5) * a.hx * a.hy, l, l);
+}
+
+// ---- P1 FEM stream (test/femtools.jl:45-72) on a Kuhn-triangulated tensor grid --------
+struct FemArgs {
+    int dim;
+    i64 npd, ncells;
+    u64 seed;
+    int order_mode;
+    int bits;  // even bit count of the Feistel domain
+    double h;
+    KeyLayout L;
+    u64 *keys;
+    double *vals;
+};
+
+__device__ __forceinline__ u64 fem_cell_at(const FemArgs &a, i64 pos) {
+    if (a.order_mode == 0 || a.ncells < 2) return (u64)pos;
+    const int half = a.bits / 2;
+    const u64 mask = (1ull << half) - 1ull;
+    u64 x = (u64)pos;
+    do {
+        u64 Lh = x >> half, R = x & mask;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const u64 f = esp_mix64(R + a.seed + (u64)(r + 1) * 0x9E3779B97F4A7C15ull) & mask;
+            const u64 tt = Lh ^ f;
+            Lh = R;
+            R = tt;
+        }
+        x = (Lh << half) | R;
+    } while (x >= (u64)a.ncells);
+    return x;
+}
+
+__global__ __launch_bounds__(THREADS) void fem_k(FemArgs a) {
+    const i64 p = (i64)blockIdx.x * THREADS + threadIdx.x;
+    if (p >= a.ncells) return;
+    const i64 cell = (i64)fem_cell_at(a, p);
+    const int dim = a.dim;
+    const int K = dim == 2 ? 2 : 6;
+    const i64 q = a.npd - 1;
+    const i64 cube = cell / K;
+    const int s = (int)(cell % K);
+    i64 vx[4][3];
+    vx[0][0] = cube % q;
+    vx[0][1] = (cube / q) % q;
+    vx[0][2] = dim == 3 ? cube / (q * q) : 0;
+    // Kuhn simplices: vertex k+1 = vertex k + e_{perm[k]}
+    const int perm3[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+    const int perm2[2][2] = {{0, 1}, {1, 0}};
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        if (k < dim) {
+            const int ax = dim == 2 ? perm2[s][k & 1] : perm3[s][k];
+#pragma unroll
+            for (int d = 0; d < 3; d++) vx[k + 1][d] = vx[k][d] + (d == ax ? 1 : 0);
+        }
+    }
+    i64 nodes[4];
+    double X[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (k <= dim) {
+            nodes[k] = 1 + vx[k][0] + a.npd * (vx[k][1] + a.npd * vx[k][2]);
+#pragma unroll
+            for (int d = 0; d < 3; d++) X[k][d] = (double)vx[k][d] * a.h;
+        }
+    }
+    double G[4][3];
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+#pragma unroll
+        for (int d = 0; d < 3; d++) G[k][d] = 0.0;
+    double det;
+    if (dim == 2) {
+        const double aa = X[1][0] - X[0][0], bb = X[2][0] - X[0][0];
+        const double cc = X[1][1] - X[0][1], dd = X[2][1] - X[0][1];
+        det = aa * dd - bb * cc;
+        G[1][0] = dd / det;
+        G[1][1] = -bb / det;
+        G[2][0] = -cc / det;
+        G[2][1] = aa / det;
+        G[0][0] = -(G[1][0] + G[2][0]);
+        G[0][1] = -(G[1][1] + G[2][1]);
+    } else {
+        double J[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; r++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) J[r][k] = X[k + 1][r] - X[0][r];
+        const double c00 = J[1][1] * J[2][2] - J[1][2] * J[2][1];
+        const double c01 = J[1][0] * J[2][2] - J[1][2] * J[2][0];
+        const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
+        det = J[0][0] * c00 - J[0][1] * c01 + J[0][2] * c02;
+        G[1][0] = c00 / det;
+        G[1][1] = -(J[0][1] * J[2][2] - J[0][2] * J[2][1]) / det;
+        G[1][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
+        G[2][0] = -c01 / det;
+        G[2][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
+        G[2][2] = -(J[0][0] * J[1][2] - J[0][2] * J[1][0]) / det;
+        G[3][0] = c02 / det;
+        G[3][1] = -(J[0][0] * J[2][1] - J[0][1] * J[2][0]) / det;
+        G[3][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+#pragma unroll
+        for (int d = 0; d < 3; d++) G[0][d] = -((G[1][d] + G[2][d]) + G[3][d]);
+    }
+    const double vol = fabs(det) / (dim == 2 ? 2.0 : 6.0);
+    double S[4][4];
+#pragma unroll
+    for (int il = 0; il < 4; il++)
+#pragma unroll
+        for (int jl = 0; jl < 4; jl++) {
+            if (il <= dim && jl >= il && jl <= dim) {
+                double sacc = 0.0;
+#pragma unroll
+                for (int k = 0; k < 3; k++)
+                    if (k < dim) sacc += G[jl][k] * G[il][k];
+                S[il][jl] = sacc;
+                S[jl][il] = sacc;
+            }
+        }
+    i64 o = p * (i64)((dim + 1) * (dim + 2));
+#pragma unroll
+    for (int il = 0; il < 4; il++) {
+        if (il <= dim) {
+            a.keys[o] = esp_pack(a.L, nodes[il], nodes[il], ESP_RAWUPDATE);
+            a.vals[o] = 0.1 * vol / (double)(dim + 1);
+            o++;
+#pragma unroll
+            for (int jl = 0; jl < 4; jl++) {
+                if (jl <= dim) {
+                    a.keys[o] = esp_pack(a.L, nodes[il], nodes[jl], ESP_RAWUPDATE);
+                    a.vals[o] = vol * S[il][jl];
+                    o++;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace espgen

@@ -1,0 +1,207 @@
+// radix.hpp -- stable radix partition pass on packed (col,row) keys (K2).
+//
+// One pass splits every segment of the entry array by one digit of the key, keeping
+// the append order inside a digit (stable), which the ordered fold needs
+// (SET/ADD order, sparsematrixlnk.jl:192-195,219-221).  A pass is
+//   tile_hist_k  : per-tile digit counts            (reads 8 B/entry)
+//   scan         : exclusive scan in (segment, digit, tile) order
+//   scatter_k    : wave-match ranking, LDS reorder, coalesced run stores
+//                                                    (reads 16 B, writes 16 B/entry)
+// HBM-bound.  Tiles are 4096 entries (256 threads x 16): 64 KiB of LDS for the
+// reorder buffer, two workgroups per CU.  Wave64 throughout: ballots are 64-bit.
+#pragma once
+#include "common.hpp"
+#include "scan.hpp"
+
+namespace espradix {
+
+constexpr int THREADS = 256;
+constexpr int WAVES = THREADS / ESP_WAVE;
+constexpr int ITEMS = 16;
+constexpr int TILE = THREADS * ITEMS;
+constexpr int RADIX = 256;
+
+struct Pass {
+    const u64 *keys_in;
+    const double *vals_in;
+    u64 *keys_out;
+    double *vals_out;
+    const i64 *seg_start;   // S+1 entry offsets (device)
+    const i64 *tile_first;  // S+1 first tile of each segment (device)
+    int S;
+    int shift;  // digit = (key >> shift) & ((1<<bits)-1)
+    int bits;   // 1..8
+    u64 *hist;  // [tile_first[s]*R + d*ntiles_s + tile_in_seg]; scanned in place
+};
+
+// largest s with tile_first[s] <= tile, or -1 when tile is past the last segment
+__device__ __forceinline__ int find_segment(const i64 *__restrict__ tile_first, int S, i64 tile) {
+    if (tile >= tile_first[S]) return -1;
+    int lo = 0, hi = S;  // invariant tile_first[lo] <= tile < tile_first[hi]
+    while (hi - lo > 1) {
+        int mid = (lo + hi) >> 1;
+        if (tile_first[mid] <= tile)
+            lo = mid;
+        else
+            hi = mid;
+    }
+    return lo;
+}
+
+__global__ __launch_bounds__(THREADS) void tile_hist_k(Pass p) {
+    __shared__ u32 cnt[RADIX];
+    const int t = threadIdx.x;
+    const i64 tile = blockIdx.x;
+    const int s = p.S == 1 ? (tile < p.tile_first[1] ? 0 : -1) : find_segment(p.tile_first, p.S, tile);
+    if (s < 0) return;
+    const i64 tf = p.tile_first[s];
+    const i64 nts = p.tile_first[s + 1] - tf;
+    const i64 tin = tile - tf;
+    const i64 beg = p.seg_start[s] + tin * TILE;
+    const i64 end = min(p.seg_start[s + 1], beg + (i64)TILE);
+    cnt[t] = 0;
+    __syncthreads();
+    const u32 mask = (1u << p.bits) - 1u;
+#pragma unroll 4
+    for (int k = 0; k < ITEMS; k++) {
+        i64 idx = beg + k * THREADS + t;
+        if (idx < end) atomicAdd(&cnt[(u32)(p.keys_in[idx] >> p.shift) & mask], 1u);
+    }
+    __syncthreads();
+    const int R = 1 << p.bits;
+    if (t < R) p.hist[tf * R + (i64)t * nts + tin] = cnt[t];
+}
+
+__global__ __launch_bounds__(THREADS, 2) void scatter_k(Pass p) {
+    __shared__ u64 lkeys[TILE];
+    __shared__ double lvals[TILE];
+    __shared__ u32 cnt[WAVES][RADIX];
+    __shared__ u32 dstart[RADIX];
+    __shared__ i64 goff[RADIX];
+    __shared__ u32 lw[WAVES];
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const i64 tile = blockIdx.x;
+    const int s = p.S == 1 ? (tile < p.tile_first[1] ? 0 : -1) : find_segment(p.tile_first, p.S, tile);
+    if (s < 0) return;
+    const i64 tf = p.tile_first[s];
+    const i64 nts = p.tile_first[s + 1] - tf;
+    const i64 tin = tile - tf;
+    const i64 beg = p.seg_start[s] + tin * TILE;
+    const i64 end = min(p.seg_start[s + 1], beg + (i64)TILE);
+    const int ntile = (int)(end - beg);
+    const u32 mask = (1u << p.bits) - 1u;
+    const int R = 1 << p.bits;
+
+#pragma unroll
+    for (int i = 0; i < WAVES; i++) cnt[i][t] = 0;
+
+    // wave-striped arrangement: memory order == (wave, k, lane) order
+    u64 key[ITEMS];
+    const i64 wbase = beg + (i64)w * (ESP_WAVE * ITEMS) + lane;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        i64 idx = wbase + k * ESP_WAVE;
+        key[k] = idx < end ? p.keys_in[idx] : ~0ull;
+    }
+    __syncthreads();
+
+    // stable rank inside the wave by ballot matching
+    unsigned short rank[ITEMS];
+    const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const bool valid = (wbase + k * ESP_WAVE) < end;
+        const u32 d = (u32)(key[k] >> p.shift) & mask;
+        u64 m = __ballot(valid);
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const bool bit = (d >> b) & 1u;
+            const u64 bb = __ballot(bit);
+            m &= bit ? bb : ~bb;
+        }
+        u32 prev = 0;
+        if (valid) prev = cnt[w][d];
+        rank[k] = (unsigned short)(prev + (u32)__popcll(m & lt));
+        __builtin_amdgcn_wave_barrier();
+        if (valid && (m & lt) == 0) cnt[w][d] = prev + (u32)__popcll(m);
+        __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();
+
+    // per-digit: exclusive prefix over the waves, tile total, LDS start, global offset
+    u32 tot = 0;
+    {
+        u32 c[WAVES];
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) c[i] = cnt[i][t];
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) {
+            cnt[i][t] = tot;
+            tot += c[i];
+        }
+    }
+    u32 blocktot;
+    const u32 ds = espscan::block_exclusive<u32, false>(tot, lw, &blocktot);
+    dstart[t] = ds;
+    if (t < R) goff[t] = (i64)p.hist[tf * R + (i64)t * nts + tin] - (i64)ds;
+    __syncthreads();
+
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const i64 idx = wbase + k * ESP_WAVE;
+        if (idx < end) {
+            const u32 d = (u32)(key[k] >> p.shift) & mask;
+            const u32 slot = dstart[d] + cnt[w][d] + rank[k];
+            lkeys[slot] = key[k];
+            lvals[slot] = p.vals_in[idx];
+        }
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int j = 0; j < ITEMS; j++) {
+        const int slot = t + j * THREADS;
+        if (slot < ntile) {
+            const u64 kk = lkeys[slot];
+            const u32 d = (u32)(kk >> p.shift) & mask;
+            const i64 dst = goff[d] + slot;
+            p.keys_out[dst] = kk;
+            p.vals_out[dst] = lvals[slot];
+        }
+    }
+}
+
+// after the scan: start of segment (s,d) = hist[tile_first[s]*R + d*ntiles_s]
+__global__ void new_segments_k(const u64 *__restrict__ hist, const i64 *__restrict__ seg_start,
+                               const i64 *__restrict__ tile_first, int S, int bits,
+                               i64 *__restrict__ new_seg_start, i64 total) {
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const int R = 1 << bits;
+    const i64 NS = (i64)S * R;
+    if (g > NS) return;
+    if (g == NS) {
+        new_seg_start[g] = total;
+        return;
+    }
+    const int s = (int)(g >> bits);
+    const int d = (int)(g & (R - 1));
+    const i64 nts = tile_first[s + 1] - tile_first[s];
+    // empty segment: every (s,d) starts where the segment starts
+    new_seg_start[g] = nts == 0 ? seg_start[s] : (i64)hist[tile_first[s] * R + (i64)d * nts];
+}
+
+// tiles per segment -> tile_first by exclusive scan (caller scans); also max segment length
+__global__ void seg_tiles_k(const i64 *__restrict__ seg_start, i64 S, i64 tile, u64 *__restrict__ ntiles,
+                            unsigned long long *__restrict__ maxlen) {
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g > S) return;
+    if (g == S) {
+        ntiles[g] = 0;
+        return;
+    }
+    const i64 len = seg_start[g + 1] - seg_start[g];
+    ntiles[g] = (u64)((len + tile - 1) / tile);
+    if (maxlen) atomicMax(maxlen, (unsigned long long)len);
+}
+
+}  // namespace espradix

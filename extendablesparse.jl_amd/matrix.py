@@ -1,0 +1,546 @@
+"""Host-side mirror of the reference's operator interface for the assembly path.
+
+Same names, argument meaning and error behaviour as ExtendableSparse.jl (paths relative
+to the reference repository), backed by libesparse_hip.so through the C ABI only:
+
+  SparseMatrixCSC                  Julia's SparseArrays.SparseMatrixCSC{Float64,Int64} (host container)
+  SparseMatrixHIPCOO               the extension buffer replacing SparseMatrixLNK
+                                   (plugin contract: src/matrix/abstractsparsematrixextension.jl:6-14)
+  ExtendableSparseMatrix           src/matrix/extendable.jl with the buffer AND the CSC device-resident
+  GenericExtendableSparseMatrixCSC src/matrix/genericextendablesparsematrixcsc.jl (host CSC + buffer)
+  GenericMTExtendableSparseMatrixCSC src/matrix/genericmtextendablesparsematrixcsc.jl (one buffer per tid)
+
+Julia is not available in this image, so this Python layer plays the role the Julia shim of
+INTEGRATION.md plays in production; it contains no arithmetic of its own.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import (ESP_FLUSH_PLUS, ESP_FLUSH_ROUTED, ESP_OP_ADD, ESP_OP_SUB, ESP_RAWUPDATE, ESP_SET,
+                   ESP_UPDATE, BoundsError, check)
+
+_OPS = {"+": ESP_OP_ADD, "-": ESP_OP_SUB, ESP_OP_ADD: ESP_OP_ADD, ESP_OP_SUB: ESP_OP_SUB}
+try:  # operator.add / operator.sub are accepted like Julia's `+` / `-`
+    import operator as _operator
+    _OPS[_operator.add] = ESP_OP_ADD
+    _OPS[_operator.sub] = ESP_OP_SUB
+except Exception:  # pragma: no cover
+    pass
+
+
+def _op(op):
+    try:
+        return _OPS[op]
+    except (KeyError, TypeError):
+        raise NotImplementedError("op %r is not supported by the device buffer (only + and -); "
+                                  "use the CPU SparseMatrixLNK path for it" % (op,))
+
+
+def _vp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class SparseMatrixCSC:
+    """Host CSC container with Julia's layout: Int64 1-based colptr (n+1) / rowval, Float64 nzval."""
+
+    def __init__(self, m, n, colptr=None, rowval=None, nzval=None):
+        self.m, self.n = int(m), int(n)
+        if colptr is None:  # spzeros(m,n)
+            colptr = np.ones(self.n + 1, np.int64)
+            rowval = np.empty(0, np.int64)
+            nzval = np.empty(0, np.float64)
+        self.colptr = np.ascontiguousarray(colptr, np.int64)
+        self.rowval = np.ascontiguousarray(rowval, np.int64)
+        self.nzval = np.ascontiguousarray(nzval, np.float64)
+
+    @property
+    def shape(self):
+        return (self.m, self.n)
+
+    def nnz(self):
+        return int(self.colptr[-1] - 1)
+
+    def findindex(self, i, j):
+        """findindex(csc,i,j): src/matrix/sparsematrixcsc.jl:7-23 (1-based position or 0)."""
+        if not (1 <= i <= self.m and 1 <= j <= self.n):
+            raise BoundsError()
+        r1, r2 = int(self.colptr[j - 1]), int(self.colptr[j] - 1)
+        if r1 > r2:
+            return 0
+        k = r1 + int(np.searchsorted(self.rowval[r1 - 1:r2], i, side="left"))
+        if k > r2 or self.rowval[k - 1] != i:
+            return 0
+        return k
+
+    def __getitem__(self, ij):
+        k = self.findindex(*ij)
+        return float(self.nzval[k - 1]) if k else 0.0
+
+    def arrays(self):
+        return self.colptr, self.rowval, self.nzval
+
+    def findnz(self):
+        J = np.repeat(np.arange(1, self.n + 1, dtype=np.int64), np.diff(self.colptr))
+        return self.rowval.copy(), J, self.nzval.copy()
+
+    def copy(self):
+        return SparseMatrixCSC(self.m, self.n, self.colptr.copy(), self.rowval.copy(), self.nzval.copy())
+
+    def pattern_equal(self, other):
+        """pattern_equal: src/matrix/sparsematrixcsc.jl:83-85."""
+        return np.array_equal(self.colptr, other.colptr) and np.array_equal(self.rowval, other.rowval)
+
+    def __eq__(self, other):
+        return (isinstance(other, SparseMatrixCSC) and self.shape == other.shape and self.pattern_equal(other)
+                and np.array_equal(self.nzval, other.nzval))
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+        return sp.csc_matrix((self.nzval, self.rowval - 1, self.colptr - 1), shape=self.shape)
+
+
+class _Handle:
+    """Owns one esp_handle (one device, one stream) and its pinned staging chunk."""
+
+    def __init__(self, m, n, device=0, capacity_hint=0):
+        self.lib = L.load()
+        self.m, self.n = int(m), int(n)
+        h = C.c_void_p()
+        check(None, self.lib.esp_create(self.m, self.n, device, capacity_hint, C.byref(h)))
+        self.h = h
+        self._st = None
+        self._nst = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.esp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def ck(self, rc):
+        check(self.h, rc)
+
+    # -- staged per-entry appends (one ccall per chunk, not per entry)
+    def _stage(self):
+        if self._st is None:
+            r, c, v, k = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_void_p()
+            got = C.c_int64()
+            self.ck(self.lib.esp_stage_begin(self.h, 1 << 16, C.byref(r), C.byref(c), C.byref(v), C.byref(k),
+                                             C.byref(got)))
+            n = got.value
+            self._st = (np.ctypeslib.as_array(C.cast(r, C.POINTER(C.c_int64)), (n,)),
+                        np.ctypeslib.as_array(C.cast(c, C.POINTER(C.c_int64)), (n,)),
+                        np.ctypeslib.as_array(C.cast(v, C.POINTER(C.c_double)), (n,)),
+                        np.ctypeslib.as_array(C.cast(k, C.POINTER(C.c_uint8)), (n,)))
+        return self._st
+
+    def push(self, kind, v, i, j):
+        if not (1 <= i <= self.m and 1 <= j <= self.n):
+            raise BoundsError("(%d,%d) outside %d x %d" % (i, j, self.m, self.n))
+        r, c, vals, k = self._stage()
+        n = self._nst
+        r[n], c[n], vals[n], k[n] = i, j, v, kind
+        self._nst = n + 1
+        if self._nst == len(r):
+            self.commit()
+
+    def commit(self):
+        if self._nst:
+            n, self._nst = self._nst, 0
+            self.ck(self.lib.esp_commit(self.h, n, -1, ESP_OP_ADD))
+
+    def append(self, kind, I, J, V, op=ESP_OP_ADD, kinds=None):
+        self.commit()
+        I = np.ascontiguousarray(I, np.int64)
+        J = np.ascontiguousarray(J, np.int64)
+        V = np.ascontiguousarray(V, np.float64)
+        kp = None
+        if kinds is not None:
+            kinds = np.ascontiguousarray(kinds, np.uint8)
+            kp = _vp(kinds)
+        self.ck(self.lib.esp_append_host(self.h, _vp(I), _vp(J), _vp(V), kp, kind, op, len(I)))
+
+    def pending(self):
+        c = C.c_int64()
+        self.ck(self.lib.esp_pending(self.h, C.byref(c)))
+        return c.value + self._nst
+
+    def nnz(self):
+        c = C.c_int64()
+        self.ck(self.lib.esp_nnz(self.h, C.byref(c)))
+        return c.value
+
+    def set_csc(self, csc):
+        self.ck(self.lib.esp_set_csc(self.h, _vp(csc.colptr), _vp(csc.rowval), _vp(csc.nzval), csc.nnz()))
+
+    def flush(self, mode):
+        self.commit()
+        z, ch = C.c_int64(), C.c_int32()
+        self.ck(self.lib.esp_flush(self.h, mode, C.byref(z), C.byref(ch)))
+        return z.value, bool(ch.value)
+
+    def get_csc(self):
+        z = self.nnz()
+        cp = np.empty(self.n + 1, np.int64)
+        rv = np.empty(z, np.int64)
+        nz = np.empty(z, np.float64)
+        self.ck(self.lib.esp_get_csc(self.h, _vp(cp), _vp(rv), _vp(nz)))
+        return SparseMatrixCSC(self.m, self.n, cp, rv, nz)
+
+    def timing(self, clear=True):
+        t = L.esp_timing_t()
+        self.ck(self.lib.esp_timing(self.h, C.byref(t), 1 if clear else 0))
+        d = {name: (t.ms[i], t.launches[i]) for i, name in enumerate(L.STAGES)}
+        d["flush_ms"], d["flushes"] = t.flush_ms, t.flushes
+        return d
+
+
+class SparseMatrixHIPCOO:
+    """Device-resident COO append buffer: the `T_ext` of the reference's plugin contract
+    (abstractsparsematrixextension.jl:6-14), replacing SparseMatrixLNK (sparsematrixlnk.jl)."""
+
+    def __init__(self, m, n, device=0, capacity_hint=0):
+        self._d = _Handle(m, n, device, capacity_hint)
+        self.m, self.n = int(m), int(n)
+
+    def size(self):
+        return (self.m, self.n)
+
+    shape = property(size)
+
+    def nnz(self):
+        """>0 iff anything is pending (the flush! gate, genericextendablesparsematrixcsc.jl:32)."""
+        return self._d.pending()
+
+    def __setitem__(self, ij, v):  # setindex!: sparsematrixlnk.jl:178-201
+        self._d.push(ESP_SET, float(v), int(ij[0]), int(ij[1]))
+
+    def __getitem__(self, ij):
+        raise RuntimeError("getindex on pending device entries: flush! the matrix first "
+                           "(cf. genericmtextendablesparsematrixcsc.jl:80)")
+
+    def updateindex(self, op, v, i, j):  # updateindex!: sparsematrixlnk.jl:210-228
+        v = float(v)
+        self._d.push(ESP_UPDATE, -v if _op(op) == ESP_OP_SUB else v, int(i), int(j))
+
+    def rawupdateindex(self, op, v, i, j, tid=1):  # rawupdateindex!: sparsematrixlnk.jl:237-253
+        v = float(v)
+        self._d.push(ESP_RAWUPDATE, -v if _op(op) == ESP_OP_SUB else v, int(i), int(j))
+
+    def append(self, kind, I, J, V, op="+", kinds=None):
+        """Bulk form of the three calls above (one C call for the whole batch)."""
+        self._d.append(kind, I, J, V, _op(op), kinds)
+
+    def __add__(self, csc):
+        """Base.:+(ext, csc) -> SparseMatrixCSC (sparsematrixlnk.jl:294-383): THE flush."""
+        if (csc.m, csc.n) != (self.m, self.n):
+            raise AssertionError("size mismatch")
+        self._d.set_csc(csc)
+        self._d.flush(ESP_FLUSH_PLUS)
+        return self._d.get_csc()
+
+    __radd__ = __add__
+
+    @staticmethod
+    def sum(xs, csc):
+        """Base.sum(extmatrices, csc) (sparsematrixdilnkc.jl:397-435): csc + x1 + x2 + ... left to right."""
+        if sum(x.nnz() for x in xs) == 0:
+            return csc
+        out = csc
+        for x in xs:
+            if x.nnz() > 0:
+                out = x + out
+        return out
+
+
+class ExtendableSparseMatrix:
+    """ExtendableSparseMatrixCSC{Float64,Int64} (src/matrix/extendable.jl) with the extension buffer
+    AND the CSC resident on the GPU.  Every update is appended to the device buffer; flush! runs
+    the HIP pipeline in ROUTED mode, which applies updates of entries already in the CSC in call
+    order (extendable.jl:164-166) and merges the rest (extendable.jl:248-255)."""
+
+    def __init__(self, m, n=None, device=0, capacity_hint=0):
+        if isinstance(m, SparseMatrixCSC):  # extendable.jl:61-63
+            csc = m
+            self._d = _Handle(csc.m, csc.n, device, capacity_hint)
+            self._d.set_csc(csc)
+            self.m, self.n = csc.m, csc.n
+            self.phash = self._pattern_hash()
+        else:
+            self._d = _Handle(m, n, device, capacity_hint)
+            self.m, self.n = int(m), int(n)
+            self.phash = 0  # extendable.jl:40
+        self._host = None
+
+    @property
+    def shape(self):
+        return (self.m, self.n)
+
+    size = shape
+
+    def _pattern_hash(self):
+        hsh = C.c_uint64()
+        self._d.ck(self._d.lib.esp_pattern_hash(self._d.h, C.byref(hsh)))
+        return hsh.value
+
+    def _touch(self):
+        self._host = None
+
+    def __setitem__(self, ij, v):  # extendable.jl:205-218
+        self._touch()
+        self._d.push(ESP_SET, float(v), int(ij[0]), int(ij[1]))
+
+    def updateindex(self, op, v, i, j):  # extendable.jl:159-174
+        self._touch()
+        v = float(v)
+        self._d.push(ESP_UPDATE, -v if _op(op) == ESP_OP_SUB else v, int(i), int(j))
+
+    def rawupdateindex(self, op, v, i, j, part=1):  # extendable.jl:181-197
+        self._touch()
+        v = float(v)
+        self._d.push(ESP_RAWUPDATE, -v if _op(op) == ESP_OP_SUB else v, int(i), int(j))
+
+    def append(self, kind, I, J, V, op="+", kinds=None):
+        self._touch()
+        self._d.append(kind, I, J, V, _op(op), kinds)
+
+    def __getitem__(self, ij):
+        """getindex (extendable.jl:226-238).  Pending entries live on the device, so the lookup is
+        flush-then-findindex: correct, slow, documented (use updateindex! instead of A[i,j]+=v)."""
+        i, j = int(ij[0]), int(ij[1])
+        if not (1 <= i <= self.m and 1 <= j <= self.n):
+            raise BoundsError()
+        self.flush()
+        val, found = C.c_double(), C.c_int32()
+        self._d.ck(self._d.lib.esp_getindex(self._d.h, i, j, C.byref(val), C.byref(found)))
+        return val.value
+
+    def flush(self):  # flush!: extendable.jl:248-255
+        if self._d.pending() > 0:
+            self._touch()
+            _, changed = self._d.flush(ESP_FLUSH_ROUTED)
+            if changed:
+                self.phash = self._pattern_hash()  # extendable.jl:252
+        return self
+
+    def sparse(self):  # extendable.jl:258-261: host-visible SparseMatrixCSC
+        self.flush()
+        if self._host is None:
+            self._host = self._d.get_csc()
+        return self._host
+
+    def nnz(self):  # abstractextendablesparsematrixcsc.jl:80
+        self.flush()
+        return self._d.nnz()
+
+    def nnznew(self):
+        return self._d.pending()
+
+    def nonzeros(self):
+        return self.sparse().nzval
+
+    def rowvals(self):
+        return self.sparse().rowval
+
+    def getcolptr(self):
+        return self.sparse().colptr
+
+    def findnz(self):
+        return self.sparse().findnz()
+
+    def arrays(self):
+        return self.sparse().arrays()
+
+    def reset(self):  # reset!: extendable.jl:269-272 (phash kept)
+        self._touch()
+        self._d._nst = 0
+        self._d.ck(self._d.lib.esp_reset(self._d.h))
+
+    def zero_values(self):  # fdrand!'s zero!: sprand.jl:82
+        self.flush()
+        self._touch()
+        self._d.ck(self._d.lib.esp_zero_values(self._d.h))
+
+    def dropzeros(self):  # dropzeros!(ext): flush then dropzeros!(csc)
+        self.flush()
+        self._touch()
+        z = C.c_int64()
+        self._d.ck(self._d.lib.esp_dropzeros(self._d.h, C.byref(z)))
+        return self
+
+    def generate_fdrand(self, nx, ny=1, nz=1, seed=0x5EED0002, rand_mode=1, kind=ESP_UPDATE):
+        """The hot loop of fdrand! (sprand.jl:100-124) produced on the device."""
+        self._touch()
+        self._d.commit()
+        self._d.ck(self._d.lib.esp_generate_fdrand(self._d.h, nx, ny, nz, seed, rand_mode, kind))
+
+    def generate_fem(self, dim, npd, seed=0x5EED0004, order_mode=1):
+        """The update stream of testassemble! (test/femtools.jl:45-72) produced on the device."""
+        self._touch()
+        self._d.commit()
+        self._d.ck(self._d.lib.esp_generate_fem(self._d.h, dim, npd, seed, order_mode))
+
+    def timing_enable(self, on=True):
+        self._d.ck(self._d.lib.esp_timing_enable(self._d.h, 1 if on else 0))
+
+    def timing(self, clear=True):
+        return self._d.timing(clear)
+
+    def synchronize(self):
+        self._d.ck(self._d.lib.esp_synchronize(self._d.h))
+
+
+class GenericExtendableSparseMatrixCSC:
+    """src/matrix/genericextendablesparsematrixcsc.jl with Tm = SparseMatrixHIPCOO: host CSC,
+    host findindex routing, device buffer for the misses; flush! = xmatrix + cscmatrix (:31-37)."""
+
+    def __init__(self, m, n, Tm=SparseMatrixHIPCOO, **kw):
+        self.Tm, self._kw = Tm, kw
+        self.cscmatrix = SparseMatrixCSC(m, n)
+        self.xmatrix = Tm(m, n, **kw)
+
+    @property
+    def shape(self):
+        return self.cscmatrix.shape
+
+    def nnznew(self):  # :21
+        return self.xmatrix.nnz()
+
+    def reset(self):  # :23-28
+        m, n = self.cscmatrix.shape
+        self.cscmatrix = SparseMatrixCSC(m, n)
+        self.xmatrix = self.Tm(m, n, **self._kw)
+        return self
+
+    def flush(self):  # :31-37
+        if self.xmatrix.nnz() > 0:
+            self.cscmatrix = self.xmatrix + self.cscmatrix
+            m, n = self.cscmatrix.shape
+            self.xmatrix = self.Tm(m, n, **self._kw)
+        return self
+
+    def sparse(self):  # :39-42
+        self.flush()
+        return self.cscmatrix
+
+    def nnz(self):
+        return self.sparse().nnz()
+
+    def arrays(self):
+        return self.sparse().arrays()
+
+    def __setitem__(self, ij, v):  # :44-54
+        k = self.cscmatrix.findindex(*ij)
+        if k > 0:
+            self.cscmatrix.nzval[k - 1] = v
+        else:
+            self.xmatrix[ij] = v
+
+    def __getitem__(self, ij):  # :57-66 (pending entries: flush-then-lookup)
+        k = self.cscmatrix.findindex(*ij)
+        if k > 0:
+            return float(self.cscmatrix.nzval[k - 1])
+        if self.xmatrix.nnz() == 0:
+            return 0.0
+        self.flush()
+        return self.cscmatrix[ij]
+
+    def rawupdateindex(self, op, v, i, j):  # :68-79
+        k = self.cscmatrix.findindex(i, j)
+        if k > 0:
+            self.cscmatrix.nzval[k - 1] = _apply(op, self.cscmatrix.nzval[k - 1], v)
+        else:
+            self.xmatrix.rawupdateindex(op, v, i, j)
+
+    def updateindex(self, op, v, i, j):  # :81-92
+        k = self.cscmatrix.findindex(i, j)
+        if k > 0:
+            self.cscmatrix.nzval[k - 1] = _apply(op, self.cscmatrix.nzval[k - 1], v)
+        else:
+            self.xmatrix.updateindex(op, v, i, j)
+
+
+def _apply(op, a, b):
+    return a - b if _op(op) == ESP_OP_SUB else a + b
+
+
+class GenericMTExtendableSparseMatrixCSC:
+    """src/matrix/genericmtextendablesparsematrixcsc.jl with Tm = SparseMatrixHIPCOO: one device
+    buffer per partition `tid`; flush! = Base.sum(xmatrices, cscmatrix) (:45-51)."""
+
+    def __init__(self, n, m, p=1, Tm=SparseMatrixHIPCOO, **kw):
+        self.Tm, self._kw = Tm, kw
+        self.cscmatrix = SparseMatrixCSC(m, n)
+        self.xmatrices = [Tm(m, n, **kw) for _ in range(p)]
+        self.colparts = np.array([1, 2], np.int64)
+        self.partnodes = np.array([1, n + 1], np.int64)
+
+    @property
+    def shape(self):
+        return self.cscmatrix.shape
+
+    def partitioning(self, colparts, partnodes):  # partitioning!: :24-28
+        self.partnodes = np.asarray(partnodes, np.int64)
+        self.colparts = np.asarray(colparts, np.int64)
+        return self
+
+    def reset(self, p=None):  # :31-42
+        m, n = self.cscmatrix.shape
+        p = len(self.xmatrices) if p is None else p
+        self.cscmatrix = SparseMatrixCSC(m, n)
+        self.xmatrices = [self.Tm(m, n, **self._kw) for _ in range(p)]
+        self.colparts = np.array([1, 2], np.int64)
+        self.partnodes = np.array([1, n + 1], np.int64)
+        return self
+
+    def nnznew(self):  # :84
+        return sum(x.nnz() for x in self.xmatrices)
+
+    def flush(self):  # :45-51
+        self.cscmatrix = self.Tm.sum(self.xmatrices, self.cscmatrix)
+        m, n = self.cscmatrix.shape
+        self.xmatrices = [self.Tm(m, n, **self._kw) for _ in range(len(self.xmatrices))]
+        return self
+
+    def sparse(self):
+        self.flush()
+        return self.cscmatrix
+
+    def arrays(self):
+        return self.sparse().arrays()
+
+    def __setitem__(self, ij, v):  # :59-69
+        k = self.cscmatrix.findindex(*ij)
+        if k > 0:
+            self.cscmatrix.nzval[k - 1] = v
+        else:
+            raise RuntimeError("use rawupdateindex! for new entries into GenericMTExtendableSparseMatrixCSC")
+
+    def __getitem__(self, ij):  # :71-82
+        k = self.cscmatrix.findindex(*ij)
+        if k > 0:
+            return float(self.cscmatrix.nzval[k - 1])
+        if self.nnznew() == 0:
+            return 0.0
+        raise RuntimeError("flush! GenericMTExtendableSparseMatrixCSC before using getindex")
+
+    def rawupdateindex(self, op, v, i, j, tid=1):  # :87-99
+        k = self.cscmatrix.findindex(i, j)
+        if k > 0:
+            self.cscmatrix.nzval[k - 1] = _apply(op, self.cscmatrix.nzval[k - 1], v)
+        else:
+            self.xmatrices[tid - 1].rawupdateindex(op, v, i, j)
+
+    def updateindex(self, op, v, i, j, tid=1):  # :102-114
+        k = self.cscmatrix.findindex(i, j)
+        if k > 0:
+            self.cscmatrix.nzval[k - 1] = _apply(op, self.cscmatrix.nzval[k - 1], v)
+        else:
+            self.xmatrices[tid - 1].updateindex(op, v, i, j)

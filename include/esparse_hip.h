@@ -1,0 +1,176 @@
+/*
+ * esparse_hip.h -- C ABI of libesparse_hip.so, the MI355X (gfx950) sparse-assembly
+ * backend for ExtendableSparse.jl's ExtendableSparseMatrix.
+ *
+ * What it replaces (paths relative to the reference repository):
+ *   - the CPU insertion buffer SparseMatrixLNK  (src/matrix/sparsematrixlnk.jl:21-253)
+ *     becomes a device-resident COO append buffer (packed u64 key + f64 value);
+ *   - flush! / `lnk + csc`  (src/matrix/extendable.jl:248-255,
+ *     src/matrix/sparsematrixlnk.jl:294-383) becomes a HIP pipeline: stable radix
+ *     partition on (col,row) keys, LDS-staged ordered fold of duplicates,
+ *     merge-path join with the existing CSC.
+ * The entry points are what the reference's plugin slot for extension buffers
+ * (src/matrix/abstractsparsematrixextension.jl:6-14, used by
+ * src/matrix/genericextendablesparsematrixcsc.jl:14-92 and
+ * src/matrix/genericmtextendablesparsematrixcsc.jl:16-114) needs from a foreign
+ * buffer; INTEGRATION.md shows the Julia `ccall` shim that binds them.
+ *
+ * Conventions
+ *   - every function returns an int32 status (0 = ok, <0 = esp_status); nothing
+ *     throws or aborts across the boundary; esp_last_error() gives the message;
+ *   - all matrix indices are 1-based Int64, exactly as Julia passes them;
+ *   - output arrays are caller-allocated (Julia Vectors) after a size query;
+ *   - one handle = one device + one HIP stream; a handle is not thread-safe
+ *     (like one reference buffer per `tid`); distinct handles are independent;
+ *   - element types: Float64 values, Int64 indices (the reference's default
+ *     ExtendableSparseMatrix{Float64,Int64}); other Tv/Ti stay on the CPU path.
+ */
+#ifndef ESPARSE_HIP_H
+#define ESPARSE_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct esp_handle esp_handle;
+
+typedef enum {
+    ESP_OK = 0,
+    ESP_ERR_INVALID = -1,     /* bad argument / NULL handle                       */
+    ESP_ERR_BOUNDS = -2,      /* (i,j) outside 1..m x 1..n  -> Julia BoundsError  */
+    ESP_ERR_HIP = -3,         /* a HIP runtime call failed                         */
+    ESP_ERR_NOMEM = -4,       /* device or pinned allocation failed                */
+    ESP_ERR_UNSUPPORTED = -5, /* dimension / count outside the supported range     */
+    ESP_ERR_STATE = -6,       /* call not valid in the handle's current state      */
+    ESP_ERR_NODEVICE = -7     /* no usable GPU (the product never falls back)      */
+} esp_status;
+
+/* How an appended entry combines with what is already stored at (i,j).
+ * SET       = Base.setindex!      (sparsematrixlnk.jl:178-201, extendable.jl:205-218)
+ * UPDATE    = updateindex!(A,+..) (sparsematrixlnk.jl:210-228, extendable.jl:159-174)
+ * RAWUPDATE = rawupdateindex!     (sparsematrixlnk.jl:237-253, extendable.jl:181-197) */
+typedef enum { ESP_SET = 0, ESP_UPDATE = 1, ESP_RAWUPDATE = 2 } esp_kind;
+
+/* `op` of updateindex!/rawupdateindex!.  Every call site of the reference passes `+`;
+ * `-` is exact as `+` of the negated value.  Other functions stay on the CPU path. */
+typedef enum { ESP_OP_ADD = 0, ESP_OP_SUB = 1 } esp_op;
+
+/* Which reference operation esp_flush() evaluates:
+ * ROUTED = flush!(ExtendableSparseMatrixCSC): every appended update of an (i,j) that
+ *          is already in the CSC is applied to csc.nzval in call order
+ *          (extendable.jl:164-166,188-189,210-211), the others fold in the buffer and
+ *          are merged in (extendable.jl:248-255);
+ * PLUS   = Base.:+(buffer, csc) (sparsematrixlnk.jl:294-383): the buffer folds on its
+ *          own and equal positions give csc.nzval + buffer value (:363).            */
+typedef enum { ESP_FLUSH_ROUTED = 0, ESP_FLUSH_PLUS = 1 } esp_flush_mode;
+
+/* pipeline stages reported by esp_timing() */
+enum {
+    ESP_ST_APPEND = 0, /* pack / generator kernels (coalesced stores into the buffer) */
+    ESP_ST_HIST = 1,   /* digit histograms of the radix partition                      */
+    ESP_ST_SCAN = 2,   /* exclusive scans (offsets, colptr)                           */
+    ESP_ST_SCATTER = 3,/* stable radix partition passes (global)                      */
+    ESP_ST_LOCAL = 4,  /* LDS bucket sort + ordered fold + emit                       */
+    ESP_ST_FOLD = 5,   /* ordered segmented fold on globally sorted entries           */
+    ESP_ST_COLPTR = 6, /* column ends -> colptr                                       */
+    ESP_ST_MERGE = 7,  /* merge-path join with the existing CSC                       */
+    ESP_ST_COPY = 8,   /* H2D / D2H copies issued by this library                     */
+    ESP_ST_COUNT = 9
+};
+typedef struct {
+    double ms[ESP_ST_COUNT];        /* summed hipEvent time per stage since the last clear */
+    int64_t launches[ESP_ST_COUNT]; /* kernel launches (or copies) per stage               */
+    double flush_ms;                /* whole esp_flush calls (device time)                 */
+    int64_t flushes;
+} esp_timing_t;
+
+/* ---- lifetime -------------------------------------------------------------------
+ * esp_create: the constructor T_ext(m,n) of the plugin contract
+ * (abstractsparsematrixextension.jl:8; SparseMatrixLNK{Tv,Ti}(m,n),
+ * sparsematrixlnk.jl:75-77).  capacity_hint = expected number of appended entries. */
+int32_t esp_create(int64_t m, int64_t n, int32_t device, int64_t capacity_hint, esp_handle **out);
+int32_t esp_destroy(esp_handle *h);
+const char *esp_last_error(const esp_handle *h);
+const char *esp_version(void);
+/* use an external HIP stream (hipStream_t) instead of the handle's own */
+int32_t esp_set_stream(esp_handle *h, void *hip_stream);
+int32_t esp_synchronize(esp_handle *h);
+/* Base.size(ext) (abstractsparsematrixextension.jl:10) */
+int32_t esp_size(const esp_handle *h, int64_t *m, int64_t *n);
+/* packed key layout: key = ((col-1) << row_bits | (row-1)) << 2 | kind */
+int32_t esp_key_layout(const esp_handle *h, int32_t *row_bits, int32_t *col_bits);
+
+/* ---- append (replaces setindex!/updateindex!/rawupdateindex! on the buffer) -----
+ * Host-fed: Julia fills a pinned chunk obtained from esp_stage_begin and commits it;
+ * one ccall per chunk, not per entry.  kinds may be left untouched when kind_all>=0. */
+int32_t esp_stage_begin(esp_handle *h, int64_t want, int64_t **rows, int64_t **cols,
+                        double **vals, uint8_t **kinds, int64_t *got);
+int32_t esp_commit(esp_handle *h, int64_t count, int32_t kind_all, int32_t op);
+/* bulk host arrays (COO constructor path extendable.jl:92-104): kinds==NULL -> kind_all */
+int32_t esp_append_host(esp_handle *h, const int64_t *rows, const int64_t *cols,
+                        const double *vals, const uint8_t *kinds, int32_t kind_all, int32_t op,
+                        int64_t count);
+/* device-side producers: arrays already in HBM on this handle's device */
+int32_t esp_append_device(esp_handle *h, const int64_t *d_rows, const int64_t *d_cols,
+                          const double *d_vals, const uint8_t *d_kinds, int32_t kind_all,
+                          int32_t op, int64_t count);
+/* entries already packed in this handle's key layout (used by the shard exchange) */
+int32_t esp_append_packed(esp_handle *h, const uint64_t *d_keys, const double *d_vals,
+                          int64_t count);
+/* on-device update streams of the reference's workloads:
+ * fdrand!(A,nx,ny,nz;update,rand) hot loop (src/matrix/sprand.jl:87-124); rand_mode
+ * 0: ()->1, 1: 0.1+u (fdrand default, :232), 2: u; kind = ESP_UPDATE / ESP_RAWUPDATE;
+ * testassemble! (test/femtools.jl:45-72) on a Kuhn grid with npd points per axis.    */
+int32_t esp_generate_fdrand(esp_handle *h, int64_t nx, int64_t ny, int64_t nz, uint64_t seed,
+                            int32_t rand_mode, int32_t kind);
+int32_t esp_generate_fem(esp_handle *h, int32_t dim, int64_t npd, uint64_t seed,
+                         int32_t order_mode);
+/* number of appended, not yet flushed entries; >0 iff anything is pending
+ * (the flush! gate of genericextendablesparsematrixcsc.jl:32 / nnznew :21) */
+int32_t esp_pending(const esp_handle *h, int64_t *count);
+
+/* ---- the CSC side ---------------------------------------------------------------
+ * esp_set_csc: attach an existing SparseMatrixCSC (the `csc` operand of `ext + csc`). */
+int32_t esp_set_csc(esp_handle *h, const int64_t *colptr, const int64_t *rowval,
+                    const double *nzval, int64_t nnz);
+/* THE flush: sort + ordered fold + join, result stays device-resident.
+ * pattern_changed = 1 iff the CSC was rebuilt (the reference recomputes phash then). */
+int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int32_t *pattern_changed);
+/* SparseArrays.nnz of the device CSC (does not flush) */
+int32_t esp_nnz(const esp_handle *h, int64_t *nnz);
+/* D2H into caller arrays: colptr (n+1), rowval (nnz), nzval (nnz); Julia layout */
+int32_t esp_get_csc(esp_handle *h, int64_t *colptr, int64_t *rowval, double *nzval);
+/* D2H of nzval only (pattern unchanged since the caller's last esp_get_csc) */
+int32_t esp_get_nzval(esp_handle *h, double *nzval);
+/* device pointers of the resident CSC (Int64 1-based values), for device consumers */
+int32_t esp_csc_device(esp_handle *h, const int64_t **d_colptr, const int64_t **d_rowval,
+                       const double **d_nzval);
+/* reset!(ext) (extendable.jl:269-272): empty CSC, empty buffer */
+int32_t esp_reset(esp_handle *h);
+/* drop the buffer only (a fresh T_ext(m,n), genericextendablesparsematrixcsc.jl:34) */
+int32_t esp_clear_pending(esp_handle *h);
+/* fdrand!'s zero!(A): nonzeros(A) .= 0 (sprand.jl:82) on the device CSC */
+int32_t esp_zero_values(esp_handle *h);
+/* dropzeros!(A) on the device CSC (test/test_updates.jl:19,23) */
+int32_t esp_dropzeros(esp_handle *h, int64_t *new_nnz);
+/* findindex(csc,i,j)+nzval[k] (sparsematrixcsc.jl:7-23) on the device CSC; found=0 if absent */
+int32_t esp_getindex(esp_handle *h, int64_t i, int64_t j, double *value, int32_t *found);
+/* stand-in for phash(csc) (sparsematrixcsc.jl:74): a 64-bit function of colptr/rowval only */
+int32_t esp_pattern_hash(esp_handle *h, uint64_t *hash);
+
+/* ---- column-range shards (multi-GPU, one process per GPU) ------------------------
+ * owner(col) = floor((col-1)*nshards/n).  esp_shard_counts: pending entries per owner.
+ * esp_shard_export: stable partition of the pending entries by owner into the caller's
+ * device buffers (send buffer of the all-to-all); offsets has nshards+1 entries.       */
+int32_t esp_shard_counts(esp_handle *h, int32_t nshards, int64_t *counts);
+int32_t esp_shard_export(esp_handle *h, int32_t nshards, uint64_t *d_keys, double *d_vals,
+                         int64_t *offsets);
+
+/* ---- measurement ---------------------------------------------------------------- */
+int32_t esp_timing_enable(esp_handle *h, int32_t on);
+int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,397 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the golden fixtures.
+
+Integer structure (colptr/rowval) must match bit for bit; Float64 nzval must match BITWISE too:
+the sort is stable and the fold runs left to right, so the device reproduces the reference's
+accumulation order (the north star allows 2 ulp; the tests hold the stricter bar).
+"""
+import numpy as np
+import pytest
+
+import golden_util as gu
+from refmodel import assert_csc_equal, bits, check_julia_invariants
+
+pytestmark = pytest.mark.gpu
+
+SET, UPDATE, RAW = 0, 1, 2
+
+
+def hip_arrays(A):
+    return A.sparse().arrays()
+
+
+# ------------------------------------------------------------------ golden fixtures
+@pytest.mark.parametrize("name", gu.STREAMS)
+def test_golden_streams(esp, name):
+    fx = gu.load(name)
+    hashes = []
+    for q, got, want, rebuilt in gu.replay(
+            fx, esp.ExtendableSparseMatrix,
+            lambda A, k, I, J, V: A.append(0, I, J, V, kinds=k),
+            lambda A: (hashes.append(A.phash), A.flush(), hashes.append(A.phash)),
+            hip_arrays):
+        assert_csc_equal(got, want, "%s flush %d" % (name, q))
+        check_julia_invariants(int(fx["m"]), int(fx["n"]), *got)
+        # phash changes iff the CSC was rebuilt (extendable.jl:249-252)
+        assert (hashes[-1] != hashes[-2]) == bool(rebuilt)
+
+
+@pytest.mark.parametrize("dims", [(100, 1, 1), (10, 10, 1), (5, 5, 5)])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_golden_fdrand_small(esp, dims, mode):
+    fx = gu.load("fdrand_small")
+    tag = "fd_%dx%dx%d_m%d" % (*dims, mode)
+    want = (fx[tag + "_colptr"], fx[tag + "_rowval"], fx[tag + "_nzval"])
+    A = esp.fdrand(*dims, rand_mode=mode, seed=0x5EED0002)          # device generator
+    assert_csc_equal(hip_arrays(A), want, tag + " device")
+    for upd in (esp.fdrand_module.update_updateindex, esp.fdrand_module.update_rawupdateindex,
+                esp.fdrand_module.update_pluseq):                   # test_fdrand.jl:29-53
+        if upd is esp.fdrand_module.update_pluseq and dims != (5, 5, 5):
+            continue                                                # flush-per-getindex: keep it small
+        B = esp.fdrand(*dims, rand_mode=mode, seed=0x5EED0002, update=upd)
+        assert_csc_equal(hip_arrays(B), want, tag + " host loop")
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_golden_fdrand_30(esp, mode):
+    """BASELINE config 1 (30^3) on the device path vs the committed digest."""
+    d = gu.digests()["fd_30x30x30_m%d" % mode]
+    A = esp.fdrand(30, 30, 30, rand_mode=mode, seed=0x5EED0002)
+    arrs = hip_arrays(A)
+    assert len(arrs[1]) == 183600
+    assert gu.digest(*arrs) == d["csc"]
+
+
+@pytest.mark.parametrize("dim,npd", [(2, 32), (3, 10)])
+def test_golden_fem(esp, dim, npd):
+    fx = gu.load("fem_small")
+    tag = "fem%dd_%d" % (dim, npd)
+    nn = npd ** dim
+    A = esp.ExtendableSparseMatrix(nn, nn)
+    A.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
+    A.flush()
+    assert_csc_equal(hip_arrays(A), (fx[tag + "_colptr"], fx[tag + "_rowval"], fx[tag + "_nzval"]), tag)
+
+
+# ------------------------------------------------------------------ reference test-suite, on the device
+def test_updates_nnz_trace(esp):
+    """test/test_updates.jl:10-25."""
+    A = esp.ExtendableSparseMatrix(10, 10)
+    assert A.nnz() == 0
+    A[1, 3] = 5
+    A.updateindex("+", 6.0, 4, 5)
+    A.updateindex("+", 0.0, 2, 3)
+    assert A.nnz() == 2
+    A.rawupdateindex("+", 0.0, 2, 3)
+    assert A.nnz() == 3
+    A.dropzeros()
+    assert A.nnz() == 2
+    A.rawupdateindex("+", 0.1, 2, 3)
+    assert A.nnz() == 3
+    A.dropzeros()
+    assert A.nnz() == 3
+
+
+def _assembly(esp, orc, m, n, xnnz, nsplice, seed):
+    """test/test_assembly.jl:6-35 with updateindex! (== `+=`) on the device."""
+    rng = np.random.default_rng(seed)
+    A = esp.ExtendableSparseMatrix(m, n)
+    O = orc.ExtendableSparseMatrix(m, n)
+    for _ in range(nsplice):
+        I = rng.integers(1, m + 1, xnnz)
+        J = rng.integers(1, n + 1, xnnz)
+        a = 1.0 + rng.random(xnnz)
+        A.append(UPDATE, I, J, a)
+        O.apply(np.full(xnnz, orc.KIND_PLUSEQ, np.uint8), I, J, a)
+        A.flush()
+        O.flush()
+        got = hip_arrays(A)
+        check_julia_invariants(m, n, *got)
+        assert_csc_equal(got, O.arrays())
+
+
+@pytest.mark.parametrize("m,n,xnnz,nsplice", [
+    (10, 10, 5, 1), (100, 100, 500, 2), (1000, 1000, 5000, 3),
+    (20, 10, 5, 1), (200, 100, 500, 2), (2000, 1000, 5000, 3),
+    (10, 20, 5, 1), (100, 200, 500, 2), (1000, 2000, 5000, 3),
+])
+def test_assembly_fixed_shapes(esp, orc, m, n, xnnz, nsplice):
+    _assembly(esp, orc, m, n, xnnz, nsplice, seed=m * 7 + n)
+
+
+def test_assembly_random_shapes(esp, orc):
+    rng = np.random.default_rng(4321)
+    for _ in range(10):
+        m, n, z = (int(rng.integers(1, 10001)) for _ in range(3))
+        _assembly(esp, orc, m, n, z, int(rng.integers(1, 6)), seed=z)
+
+
+def test_pluseq_through_getindex(esp, orc):
+    """`A[i,j] += v` (getindex + setindex!, docs/src/example.md:166-177): flush-then-lookup path."""
+    rng = np.random.default_rng(3)
+    m, n = 12, 9
+    A = esp.ExtendableSparseMatrix(m, n)
+    O = orc.ExtendableSparseMatrix(m, n)
+    for _ in range(60):
+        i, j, v = int(rng.integers(1, m + 1)), int(rng.integers(1, n + 1)), float(rng.standard_normal())
+        A[i, j] = A[i, j] + v
+        O.apply(np.array([orc.KIND_PLUSEQ], np.uint8), [i], [j], [v])
+    assert_csc_equal(hip_arrays(A), O.arrays())
+
+
+def test_mixed_kinds_and_zeros(esp, orc):
+    rng = np.random.default_rng(7)
+    m, n = 37, 23
+    A = esp.ExtendableSparseMatrix(m, n)
+    O = orc.ExtendableSparseMatrix(m, n)
+    pool = np.array([0.0, -0.0, 1.5, -1.5, 1e-300, 3.25, -7.0])
+    for splice in range(5):
+        cnt = 700
+        kinds = rng.integers(0, 3, cnt).astype(np.uint8)
+        I = rng.integers(1, m + 1, cnt)
+        J = rng.integers(1, n + 1, cnt)
+        V = np.where(rng.random(cnt) < 0.4, rng.choice(pool, cnt), rng.standard_normal(cnt))
+        A.append(0, I, J, V, kinds=kinds)
+        O.apply(kinds, I, J, V)
+        if splice % 2 == 0:
+            A.flush()
+            O.flush()
+            assert_csc_equal(hip_arrays(A), O.arrays(), "splice %d" % splice)
+    assert_csc_equal(hip_arrays(A), O.arrays())
+
+
+def test_per_entry_calls_equal_batch(esp, orc):
+    rng = np.random.default_rng(11)
+    m, n = 40, 50
+    A = esp.ExtendableSparseMatrix(m, n)
+    O = orc.ExtendableSparseMatrix(m, n)
+    for _ in range(2000):
+        k = int(rng.integers(0, 4))
+        i, j = int(rng.integers(1, m + 1)), int(rng.integers(1, n + 1))
+        v = float(rng.choice([0.0, 1.0, -2.5, rng.standard_normal()]))
+        if k == 0:
+            A[i, j] = v
+            O[i, j] = v
+        elif k == 1:
+            A.updateindex("+", v, i, j)
+            O.updateindex(orc.OP_ADD, v, i, j)
+        elif k == 2:
+            A.rawupdateindex("+", v, i, j)
+            O.rawupdateindex(orc.OP_ADD, v, i, j)
+        else:
+            A.updateindex("-", v, i, j)
+            O.updateindex(orc.OP_SUB, v, i, j)
+    assert_csc_equal(hip_arrays(A), O.arrays())
+
+
+def test_bounds_error(esp):
+    A = esp.ExtendableSparseMatrix(5, 4)
+    for (i, j) in [(0, 1), (6, 1), (1, 0), (1, 5)]:
+        with pytest.raises(IndexError):
+            A.updateindex("+", 1.0, i, j)
+        with pytest.raises(IndexError):
+            A[i, j] = 1.0
+        with pytest.raises(IndexError):
+            A[i, j]
+        with pytest.raises(IndexError):   # device-side check of a bulk batch: nothing is committed
+            A.append(UPDATE, [1, i], [1, j], [1.0, 1.0])
+    assert A.nnznew() == 0 and A.nnz() == 0
+
+
+def test_flush_gate_and_phash(esp):
+    A = esp.ExtendableSparseMatrix(6, 6)
+    assert A.phash == 0
+    A.updateindex("+", 0.0, 2, 2)
+    A[3, 3] = 0.0
+    A.flush()
+    assert A.phash == 0 and A.nnz() == 0
+    A.rawupdateindex("+", 0.0, 2, 2)
+    A.flush()
+    h = A.phash
+    assert h != 0 and A.nnz() == 1
+    A.updateindex("+", 2.0, 2, 2)
+    A.flush()
+    assert A.phash == h and A[2, 2] == 2.0
+    A.reset()
+    assert A.nnz() == 0 and A.phash == h
+
+
+def test_pattern_hash_matches_oracle_formula(esp, orc):
+    A = esp.fdrand(6, 5, 4, rand_mode=1)
+    cp, rv, nz = hip_arrays(A)
+    assert A.phash == orc.CSC(120, 120, cp, rv, nz).pattern_hash()
+
+
+def _sprand(rng, m, n, d):
+    import scipy.sparse as sp
+    S = sp.random(m, n, density=d, format="csc", random_state=rng, dtype=np.float64)
+    S.sort_indices()
+    return S
+
+
+def test_csc_plus_buffer_is_2csc_and_round_trip(esp):
+    """test_operations.jl:8-13 and test_constructors.jl:26-31 with the device buffer."""
+    rng = np.random.default_rng(5)
+    for _ in range(6):
+        m, n = int(rng.integers(1, 600)), int(rng.integers(1, 600))
+        S = _sprand(rng, m, n, 0.3 * rng.random())
+        csc = esp.SparseMatrixCSC(m, n, S.indptr + 1, S.indices + 1, S.data)
+        I, J, V = csc.findnz()
+        x = esp.SparseMatrixHIPCOO(m, n)          # SparseMatrixLNK(csc): setindex! of every entry
+        x.append(SET, I, J, V)
+        two = csc + x
+        assert two.pattern_equal(csc) and np.array_equal(bits(two.nzval), bits(2 * csc.nzval))
+        y = esp.SparseMatrixHIPCOO(m, n)
+        y.append(SET, I, J, V)
+        back = y + esp.SparseMatrixCSC(m, n)
+        assert back == csc
+
+
+def test_generic_wrapper_vs_oracle(esp, orc):
+    """GenericExtendableSparseMatrixCSC{SparseMatrixHIPCOO} (host routing) == ExtendableSparseMatrix."""
+    rng = np.random.default_rng(17)
+    m, n = 30, 45
+    G = esp.GenericExtendableSparseMatrixCSC(m, n)
+    O = orc.ExtendableSparseMatrix(m, n)
+    for rnd in range(3):
+        for _ in range(400):
+            k = int(rng.integers(0, 3))
+            i, j = int(rng.integers(1, m + 1)), int(rng.integers(1, n + 1))
+            v = float(rng.choice([0.0, 2.0, rng.standard_normal()]))
+            if k == 0:
+                G[i, j] = v
+                O[i, j] = v
+            elif k == 1:
+                G.updateindex("+", v, i, j)
+                O.updateindex(orc.OP_ADD, v, i, j)
+            else:
+                G.rawupdateindex("+", v, i, j)
+                O.rawupdateindex(orc.OP_ADD, v, i, j)
+        G.flush()
+        O.flush()
+        assert_csc_equal(G.arrays(), O.arrays(), "round %d" % rnd)
+
+
+def test_mt_wrapper_vs_oracle(esp, orc):
+    """GenericMTExtendableSparseMatrixCSC{SparseMatrixHIPCOO}: test_parallel.jl:18-26 style."""
+    rng = np.random.default_rng(19)
+    n, p = 60, 3
+    M = esp.GenericMTExtendableSparseMatrixCSC(n, n, p)
+    O = orc.MTExtendableSparseMatrix(n, n, p)
+    with pytest.raises(RuntimeError):
+        M[1, 1] = 1.0
+    for rnd in range(2):
+        for _ in range(900):
+            i, j = int(rng.integers(1, n + 1)), int(rng.integers(1, n + 1))
+            tid = int(rng.integers(1, p + 1))
+            v = float(rng.standard_normal())
+            M.rawupdateindex("+", v, i, j, tid)
+            O.rawupdateindex(orc.OP_ADD, v, i, j, tid)
+        M.flush()
+        O.flush()
+        assert_csc_equal(M.arrays(), O.arrays(), "round %d" % rnd)
+
+
+def test_fdrand_stream_and_reassembly(esp, orc):
+    """SURVEY 3.2 / config 3 in the small: re-assembly hits the CSC in place, then +new entries."""
+    nx, ny, nz = 9, 8, 7
+    N = nx * ny * nz
+    A = esp.fdrand(nx, ny, nz, rand_mode=1, seed=5)
+    O = orc.fdrand(nx, ny, nz, rand_mode=1, seed=5, style=orc.KIND_UPDATE)
+    assert_csc_equal(hip_arrays(A), O.arrays())
+    h0 = A.phash
+    esp.fdrand_device_(A, nx, ny, nz, rand_mode=1, seed=6)          # all hits
+    O.fdrand(nx, ny, nz, rand_mode=1, seed=6, style=orc.KIND_UPDATE)
+    assert_csc_equal(hip_arrays(A), O.arrays())
+    assert A.phash == h0
+    # second-neighbour pairs in x: new positions, merged with the existing CSC
+    l = np.array([g + 1 for g in range(N) if g % nx < nx - 2], np.int64)
+    rng = np.random.default_rng(9)
+    v = rng.random(len(l))
+    I = np.concatenate([l, l + 2])
+    J = np.concatenate([l + 2, l])
+    V = np.concatenate([v, v])
+    A.generate_fdrand(nx, ny, nz, seed=7, rand_mode=1)
+    A.append(UPDATE, I, J, V)
+    Io, Jo, Vo = orc.fdrand_stream(nx, ny, nz, rand_mode=1, seed=7)
+    O.apply(np.full(len(Io), UPDATE, np.uint8), Io, Jo, Vo)
+    O.apply(np.full(len(I), UPDATE, np.uint8), I, J, V)
+    A.flush()
+    O.flush()
+    assert_csc_equal(hip_arrays(A), O.arrays())
+    assert A.phash != h0 and A.nnz() == orc.fdrand_nnz(nx, ny, nz) + len(I)
+
+
+def test_device_generator_stream_is_the_reference_stream(esp, orc):
+    """The on-device fdrand stream equals the sequential stream entry for entry (order included):
+    feed it through a 1-entry-per-key matrix so every value is observable."""
+    nx, ny, nz = 7, 6, 5
+    N = nx * ny * nz
+    I, J, V = orc.fdrand_stream(nx, ny, nz, rand_mode=1, seed=0xABC)
+    A = esp.ExtendableSparseMatrix(N, N)
+    A.generate_fdrand(nx, ny, nz, seed=0xABC, rand_mode=1)
+    B = esp.ExtendableSparseMatrix(N, N)
+    B.append(UPDATE, I, J, V)
+    assert A.nnznew() == len(I) == orc.fdrand_count(nx, ny, nz)
+    A.flush()
+    B.flush()
+    assert_csc_equal(hip_arrays(A), hip_arrays(B))
+
+
+def test_long_duplicate_runs_and_dense_column(esp, orc):
+    """Segments far longer than a tile: 30000 updates of one entry + a dense column."""
+    m, n = 5000, 64
+    rng = np.random.default_rng(23)
+    I = np.concatenate([np.full(30000, 17), rng.integers(1, m + 1, 40000), np.arange(1, m + 1)])
+    J = np.concatenate([np.full(30000, 5), np.full(40000, 9), np.full(m, 33)])
+    V = rng.standard_normal(len(I))
+    kinds = rng.integers(0, 3, len(I)).astype(np.uint8)
+    A = esp.ExtendableSparseMatrix(m, n)
+    O = orc.ExtendableSparseMatrix(m, n)
+    A.append(0, I, J, V, kinds=kinds)
+    O.apply(kinds, I, J, V)
+    assert_csc_equal(hip_arrays(A), O.arrays())
+
+
+def test_empty_and_tiny(esp):
+    A = esp.ExtendableSparseMatrix(1, 1)
+    A.flush()
+    assert A.nnz() == 0 and np.array_equal(A.getcolptr(), [1, 1])
+    A.updateindex("+", 3.0, 1, 1)
+    assert A.nnz() == 1 and A[1, 1] == 3.0
+    B = esp.ExtendableSparseMatrix(3, 100000)      # many empty columns
+    B[2, 77777] = 1.0
+    B[3, 5] = 2.0
+    cp, rv, nz = hip_arrays(B)
+    check_julia_invariants(3, 100000, cp, rv, nz)
+    assert list(rv) == [3, 2] and cp[5] == 2 and cp[77777] == 3 and cp[-1] == 3
+
+
+# ------------------------------------------------------------------ full-size properties
+@pytest.mark.parametrize("n", [96, 256])
+def test_fdrand_large_properties(esp, n):
+    """BASELINE config 2 size (256^3) and a mid size: size-independent properties of the result:
+    nnz formula, Julia invariants, symmetry of the pattern, zero row sums away from the boundary
+    terms (rand=()->1: diagonal = -sum(offdiag) + boundary), and the 7-point pattern."""
+    N = n ** 3
+    A = esp.ExtendableSparseMatrix(N, N)
+    A.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=0)
+    assert A.nnznew() == 12 * n * n * (n - 1) + 6 * n * n
+    A.flush()
+    assert A.nnz() == N + 6 * n * n * (n - 1)
+    cp, rv, nz = hip_arrays(A)
+    check_julia_invariants(N, N, cp, rv, nz)
+    cnt = np.diff(cp)
+    assert cnt.min() == 4 and cnt.max() == 7
+    col = np.repeat(np.arange(1, N + 1, dtype=np.int64), cnt)
+    d = rv - col
+    ad = np.abs(d)
+    assert np.all((ad == 0) | (ad == 1) | (ad == n) | (ad == n * n))
+    del ad
+    off = nz[d != 0]
+    assert np.all(off == -(1.0 / n))                     # -h*h/h
+    colsum = np.add.reduceat(nz, cp[:-1] - 1)
+    # column sums = boundary terms only: h*h times the number of boundary faces of the node
+    g = np.arange(N)
+    i, j, k = g % n, (g // n) % n, g // (n * n)
+    faces = ((i == 0) | (i == n - 1)).astype(float) + ((j == 0) | (j == n - 1)) + ((k == 0) | (k == n - 1))
+    assert np.allclose(colsum, faces / (n * n), rtol=0, atol=1e-12)
