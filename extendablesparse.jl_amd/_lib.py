@@ -77,6 +77,8 @@ SIGNATURES = {
     "esp_shard_export": (i32, [vp, i32, vp, vp, vp]),
     "esp_timing_enable": (i32, [vp, i32]),
     "esp_timing": (i32, [vp, P(esp_timing_t), i32]),
+    "esp_debug_force_path": (i32, [vp, i32]),
+    "esp_debug_last_path": (i32, [vp, P(i32)]),
 }
 
 _lib = None

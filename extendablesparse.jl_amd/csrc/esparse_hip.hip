@@ -9,6 +9,7 @@
 #include "common.hpp"
 #include "fold.hpp"
 #include "generators.hpp"
+#include "local.hpp"
 #include "merge.hpp"
 #include "radix.hpp"
 #include "scan.hpp"
@@ -37,7 +38,8 @@ struct esp_handle {
     DevBuf keys, vals;
     i64 cap = 0, count = 0;
     // ping-pong / scratch
-    DevBuf keys2, vals2, hist, segs, colend, newkey, newval, heads, misc;
+    DevBuf keys2, vals2, hist, segs, colend, newkey, newval, heads, misc, seg[2], tilef[2], segcnt, segout;
+    int force_path = 0, last_path = 0;
     // device CSC (Julia layout) + spare set for rebuilds
     DevBuf colptr, rowval, nzval, rowval2, nzval2;
     i64 nnz = 0;
@@ -237,7 +239,7 @@ extern "C" int32_t esp_destroy(esp_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->keys, &h->vals, &h->keys2, &h->vals2, &h->hist, &h->segs, &h->colend, &h->newkey,
                       &h->newval, &h->heads, &h->misc, &h->colptr, &h->rowval, &h->nzval, &h->rowval2,
-                      &h->nzval2, &h->d_st_rows, &h->d_st_cols, &h->d_st_vals, &h->d_st_kinds})
+                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->d_st_rows, &h->d_st_cols, &h->d_st_vals, &h->d_st_kinds})
         release(*b);
     if (h->st_rows) (void)hipHostFree(h->st_rows);
     if (h->st_cols) (void)hipHostFree(h->st_cols);
@@ -741,28 +743,237 @@ static int32_t sort_pending_lsd(esp_handle *h, const u64 **sk, const double **sv
 }
 
 // ------------------------------------------------------------------------ flush
-extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int32_t *pattern_changed) {
-    if (!h) return ESP_ERR_INVALID;
-    if (mode != ESP_FLUSH_ROUTED && mode != ESP_FLUSH_PLUS) FAIL(h, ESP_ERR_INVALID, "esp_flush: mode");
-    (void)hipSetDevice(h->device);
-    if (pattern_changed) *pattern_changed = 0;
+// MSD plan: partition on the top key bits until every segment fits the LDS bucket kernel.
+// Returns local_ok=false when the general (global LSD + fold_k) path must be used instead.
+struct Sorted {
+    const u64 *sk;
+    const double *sv;
+    bool in_primary;  // data in h->keys/vals (true) or h->keys2/vals2 (false)
+    int S;
+    const i64 *seg_start;
+    int rem_bits;
+    bool local_ok;
+};
+
+static int32_t sort_msd(esp_handle *h, Sorted *out) {
     const i64 E = h->count;
-    if (E == 0) {
-        if (new_nnz) *new_nnz = h->nnz;
+    const int K = h->L.sort_bits();
+    CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
+    CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
+    CK(ensure(h, h->misc, 256));
+    unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
+
+    int planned = 0;
+    if (E > esplocal::CAP) {
+        const double target = 0.8 * esplocal::CAP;
+        while (planned < K && (double)E / (double)((i64)1 << planned) > target) planned++;
+    }
+    const int npass = (planned + 7) / 8;
+
+    int cur = 0, S = 1, done = 0;
+    CK(ensure(h, h->seg[0], sizeof(i64) * 4));
+    CK(ensure(h, h->tilef[0], sizeof(u64) * (size_t)(4 + espscan::workspace_elems(4))));
+    const i64 T = ceil_div<i64>(E, espradix::TILE);
+    hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, (i64 *)h->seg[0].p, (i64)0, E, (i64)0, (i64)0);
+    hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, (i64 *)h->tilef[0].p, (i64)0, T, (i64)0, (i64)0);
+    u64 *kin = (u64 *)h->keys.p, *kout = (u64 *)h->keys2.p;
+    double *vin = (double *)h->vals.p, *vout = (double *)h->vals2.p;
+    i64 maxlen = E;
+    bool ok = true;
+    int pass_idx = 0;
+    for (;;) {
+        int bits;
+        if (pass_idx < npass) {
+            // spread the planned bits evenly over the planned passes
+            bits = (planned - done + (npass - pass_idx) - 1) / (npass - pass_idx);
+        } else {
+            if (maxlen <= esplocal::CAP) break;
+            if (done >= K || done >= 24) {
+                ok = false;
+                break;
+            }
+            bits = std::min(8, K - done);
+        }
+        espradix::Pass p;
+        p.keys_in = kin;
+        p.vals_in = vin;
+        p.keys_out = kout;
+        p.vals_out = vout;
+        p.seg_start = (const i64 *)h->seg[cur].p;
+        p.tile_first = (const i64 *)h->tilef[cur].p;
+        p.S = S;
+        p.bits = bits;
+        p.shift = ESP_TAG_BITS + K - done - bits;
+        const i64 max_tiles = S == 1 ? T : T + S;
+        CK(partition_pass(h, p, max_tiles));
+        const int S2 = S << bits;
+        CK(ensure(h, h->seg[1 - cur], sizeof(i64) * (size_t)(S2 + 1)));
+        CK(ensure(h, h->tilef[1 - cur], sizeof(u64) * (size_t)(S2 + 1 + espscan::workspace_elems(S2 + 1))));
+        {
+            Span sp(h, ESP_ST_SCAN);
+            hipLaunchKernelGGL(espradix::new_segments_k, dim3(grid_for(S2 + 1, 256)), dim3(256), 0, h->stream, (const u64 *)h->hist.p,
+                               (const i64 *)h->seg[cur].p, (const i64 *)h->tilef[cur].p, S, bits, (i64 *)h->seg[1 - cur].p, E);
+            HIPCK(h, hipMemsetAsync(d_maxlen, 0, 8, h->stream));
+            u64 *tf = (u64 *)h->tilef[1 - cur].p;
+            hipLaunchKernelGGL(espradix::seg_tiles_k, dim3(grid_for(S2 + 1, 256)), dim3(256), 0, h->stream, (const i64 *)h->seg[1 - cur].p,
+                               (i64)S2, (i64)espradix::TILE, tf, d_maxlen);
+            sp.add(2 + espscan::exclusive<u64, false>(h->stream, tf, tf, S2 + 1, tf + S2 + 1));
+        }
+        std::swap(kin, kout);
+        std::swap(vin, vout);
+        cur = 1 - cur;
+        S = S2;
+        done += bits;
+        pass_idx++;
+        if (pass_idx >= npass) {
+            HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_maxlen, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCK(h, hipStreamSynchronize(h->stream));
+            maxlen = (i64)h->pin_scalar[0];
+        }
+    }
+    HIPCK(h, hipGetLastError());
+    out->sk = kin;
+    out->sv = vin;
+    out->in_primary = (kin == (u64 *)h->keys.p);
+    out->S = S;
+    out->seg_start = (const i64 *)h->seg[cur].p;
+    out->rem_bits = K - done;
+    out->local_ok = ok && (K - done) <= esplocal::MAX_REM_BITS && maxlen <= esplocal::CAP;
+    return ESP_OK;
+}
+
+// colend (u64, n+1, zero-initialised, filled with column ends) -> colptr; merges with the old
+// CSC when there is one.  New entries are in h->newkey/h->newval (Z0>0) or already in
+// h->rowval/h->nzval (Z0==0).
+static int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn) {
+    const i64 N1 = h->n + 1;
+    u64 *colend = (u64 *)h->colend.p;
+    if (Z0 == 0) {
+        Span sp(h, ESP_ST_COLPTR);
+        sp.add(espscan::exclusive<u64, true>(h->stream, colend, colend, N1, colend + N1));
+        hipLaunchKernelGGL(espfold::colptr_finish_k, dim3(grid_for(N1, 256)), dim3(256), 0, h->stream, (const u64 *)colend,
+                           (const i64 *)nullptr, N1, (i64 *)h->colptr.p);
+        sp.add(1);
+        h->nnz = Zn;
         return ESP_OK;
     }
-    if (E >= 0xFFFFFFF0ll) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_flush: %lld pending entries exceed the 2^32 limit of one flush", (long long)E);
-    hipEvent_t fa = nullptr;
-    if (h->timing) {
-        fa = ev_get(h);
-        (void)hipEventRecord(fa, h->stream);
+    const i64 Zt = Z0 + Zn;
+    if (Z0 >= 0xFFFFFFF0ll) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_flush: CSC too large for the 32-bit column index");
+    {
+        Span sp(h, ESP_ST_COLPTR);
+        sp.add(espscan::exclusive<u64, true>(h->stream, colend, colend, N1, colend + N1));
+        const i64 hn = Z0 + 1;  // column index of every stored entry
+        CK(ensure(h, h->heads, sizeof(u32) * (size_t)(hn + espscan::workspace_elems(hn))));
+        u32 *heads = (u32 *)h->heads.p;
+        HIPCK(h, hipMemsetAsync(heads, 0, sizeof(u32) * (size_t)hn, h->stream));
+        hipLaunchKernelGGL(espfold::col_heads_k, dim3(grid_for(h->n, 256)), dim3(256), 0, h->stream, (const i64 *)h->colptr.p, h->n, heads);
+        sp.add(1 + espscan::exclusive<u32, true>(h->stream, heads, heads, hn, heads + hn));
     }
+    CK(ensure(h, h->rowval2, sizeof(i64) * (size_t)Zt));
+    CK(ensure(h, h->nzval2, sizeof(double) * (size_t)Zt));
+    {
+        Span sp(h, ESP_ST_MERGE);
+        espmerge::Args a;
+        a.old_col = (const u32 *)h->heads.p + 1;
+        a.old_row = (const i64 *)h->rowval.p;
+        a.old_val = (const double *)h->nzval.p;
+        a.Z0 = Z0;
+        a.new_key = (const u64 *)h->newkey.p;
+        a.new_val = (const double *)h->newval.p;
+        a.Zn = Zn;
+        a.rb = h->L.rb;
+        a.out_row = (i64 *)h->rowval2.p;
+        a.out_val = (double *)h->nzval2.p;
+        hipLaunchKernelGGL(espmerge::merge_k, dim3(grid_for(Zt, espmerge::TILE)), dim3(espmerge::THREADS), 0, h->stream, a);
+        sp.add(1);
+    }
+    {
+        Span sp(h, ESP_ST_COLPTR);
+        hipLaunchKernelGGL(espfold::colptr_finish_k, dim3(grid_for(N1, 256)), dim3(256), 0, h->stream, (const u64 *)colend,
+                           (const i64 *)h->colptr.p, N1, (i64 *)h->colptr.p);
+        sp.add(1);
+    }
+    std::swap(h->rowval, h->rowval2);
+    std::swap(h->nzval, h->nzval2);
+    h->nnz = Zt;
+    return ESP_OK;
+}
+
+static int32_t prepare_outputs(esp_handle *h, i64 Z0, i64 Zn) {
+    const i64 N1 = h->n + 1;
+    CK(ensure(h, h->colend, sizeof(u64) * (size_t)(N1 + espscan::workspace_elems(N1))));
+    HIPCK(h, hipMemsetAsync(h->colend.p, 0, sizeof(u64) * (size_t)N1, h->stream));
+    if (Z0 == 0) {
+        CK(ensure(h, h->rowval, sizeof(i64) * (size_t)Zn));
+        CK(ensure(h, h->nzval, sizeof(double) * (size_t)Zn));
+    } else {
+        CK(ensure(h, h->newkey, sizeof(u64) * (size_t)Zn));
+        CK(ensure(h, h->newval, sizeof(double) * (size_t)Zn));
+    }
+    return ESP_OK;
+}
+
+// fast path: LDS bucket kernel over the MSD segments
+static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
+    const i64 Z0 = h->nnz;
+    const int S = st.S;
+    u64 *tk = st.in_primary ? (u64 *)h->keys2.p : (u64 *)h->keys.p;
+    double *tv = st.in_primary ? (double *)h->vals2.p : (double *)h->vals.p;
+    CK(ensure(h, h->segcnt, sizeof(u32) * (size_t)(S + 1)));
+    CK(ensure(h, h->segout, sizeof(u64) * (size_t)(S + 1 + espscan::workspace_elems(S + 1))));
+    {
+        Span sp(h, ESP_ST_LOCAL);
+        esplocal::Args a;
+        a.keys_in = st.sk;
+        a.vals_in = st.sv;
+        a.seg_start = st.seg_start;
+        a.S = S;
+        a.rem_bits = st.rem_bits;
+        a.rb = h->L.rb;
+        a.csc = espfold::Csc{(const i64 *)h->colptr.p, (const i64 *)h->rowval.p, (double *)h->nzval.p, Z0};
+        a.mode = mode;
+        a.out_keys = tk;
+        a.out_vals = tv;
+        a.seg_count = (u32 *)h->segcnt.p;
+        hipLaunchKernelGGL(esplocal::local_k, dim3((unsigned)S), dim3(esplocal::THREADS), 0, h->stream, a);
+        sp.add(1);
+    }
+    u64 *segout = (u64 *)h->segout.p;
+    {
+        Span sp(h, ESP_ST_SCAN);
+        hipLaunchKernelGGL(esplocal::widen_counts_k, dim3(grid_for(S + 1, 256)), dim3(256), 0, h->stream, (const u32 *)h->segcnt.p, (i64)S, segout);
+        sp.add(1 + espscan::exclusive<u64, false>(h->stream, segout, segout, S + 1, segout + S + 1));
+    }
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, segout + S, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    const i64 Zn = (i64)h->pin_scalar[0];
+    *Zn_out = Zn;
+    if (Zn == 0) return ESP_OK;
+    CK(prepare_outputs(h, Z0, Zn));
+    // a segment is a whole number of columns when the partition prefix does not reach into the row bits
+    const int col_aligned = st.rem_bits >= h->L.rb ? 1 : 0;
+    {
+        Span sp(h, ESP_ST_FOLD);
+        if (Z0 == 0)
+            hipLaunchKernelGGL((esplocal::gather_k<true>), dim3((unsigned)S), dim3(256), 0, h->stream, (const u64 *)tk, (const double *)tv,
+                               st.seg_start, (const u64 *)segout, h->L.rb, col_aligned, (i64 *)h->rowval.p, (u64 *)nullptr,
+                               (double *)h->nzval.p, (u64 *)h->colend.p);
+        else
+            hipLaunchKernelGGL((esplocal::gather_k<false>), dim3((unsigned)S), dim3(256), 0, h->stream, (const u64 *)tk, (const double *)tv,
+                               st.seg_start, (const u64 *)segout, h->L.rb, col_aligned, (i64 *)nullptr, (u64 *)h->newkey.p,
+                               (double *)h->newval.p, (u64 *)h->colend.p);
+        sp.add(1);
+    }
+    return finish_csc(h, Z0, Zn);
+}
+
+// general path: finish with a full stable LSD sort and the global fold (any run length)
+static int32_t flush_global(esp_handle *h, int mode, i64 *Zn_out) {
+    const i64 E = h->count;
+    const i64 Z0 = h->nnz;
     const u64 *sk;
     const double *sv;
     CK(sort_pending_lsd(h, &sk, &sv));  // sorted data now in h->keys/h->vals; keys2/vals2 are scratch
-
-    const i64 Z0 = h->nnz;
-    const i64 N1 = h->n + 1;
     u32 *flag = (u32 *)h->vals2.p;        // E+1 u32 fits in E doubles (E>=1)
     double *fval = (double *)h->keys2.p;  // E doubles
     espfold::Csc csc{(const i64 *)h->colptr.p, (const i64 *)h->rowval.p, (double *)h->nzval.p, Z0};
@@ -781,82 +992,59 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
     HIPCK(h, hipMemcpyAsync(h->pin_scalar, flag + E, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     const i64 Zn = (i64) * (u32 *)h->pin_scalar;
-
-    if (Zn > 0) {
-        CK(ensure(h, h->colend, sizeof(u64) * (size_t)(N1 + espscan::workspace_elems(N1))));
-        u64 *colend = (u64 *)h->colend.p;
-        HIPCK(h, hipMemsetAsync(colend, 0, sizeof(u64) * (size_t)N1, h->stream));
-        if (Z0 == 0) {
-            CK(ensure(h, h->rowval, sizeof(i64) * (size_t)Zn));
-            CK(ensure(h, h->nzval, sizeof(double) * (size_t)Zn));
-            {
-                Span sp(h, ESP_ST_FOLD);
-                hipLaunchKernelGGL((espfold::compact_k<true>), dim3(grid_for(E, espfold::THREADS)), dim3(espfold::THREADS), 0, h->stream,
-                                   sk, (const double *)fval, E, (const u32 *)flag, h->L.rb, (i64 *)h->rowval.p, (u64 *)nullptr,
-                                   (double *)h->nzval.p, colend);
-                sp.add(1);
-            }
-            {
-                Span sp(h, ESP_ST_COLPTR);
-                sp.add(espscan::exclusive<u64, true>(h->stream, colend, colend, N1, colend + N1));
-                hipLaunchKernelGGL(espfold::colptr_finish_k, dim3(grid_for(N1, 256)), dim3(256), 0, h->stream, (const u64 *)colend,
-                                   (const i64 *)nullptr, N1, (i64 *)h->colptr.p);
-                sp.add(1);
-            }
-            h->nnz = Zn;
-        } else {
-            const i64 Zt = Z0 + Zn;
-            if (Z0 >= 0xFFFFFFF0ll) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_flush: CSC too large for the 32-bit column index");
-            CK(ensure(h, h->newkey, sizeof(u64) * (size_t)Zn));
-            CK(ensure(h, h->newval, sizeof(double) * (size_t)Zn));
-            {
-                Span sp(h, ESP_ST_FOLD);
-                hipLaunchKernelGGL((espfold::compact_k<false>), dim3(grid_for(E, espfold::THREADS)), dim3(espfold::THREADS), 0, h->stream,
-                                   sk, (const double *)fval, E, (const u32 *)flag, h->L.rb, (i64 *)nullptr, (u64 *)h->newkey.p,
-                                   (double *)h->newval.p, colend);
-                sp.add(1);
-            }
-            {
-                Span sp(h, ESP_ST_COLPTR);
-                sp.add(espscan::exclusive<u64, true>(h->stream, colend, colend, N1, colend + N1));
-                // column index of every stored entry
-                const i64 hn = Z0 + 1;
-                CK(ensure(h, h->heads, sizeof(u32) * (size_t)(hn + espscan::workspace_elems(hn))));
-                u32 *heads = (u32 *)h->heads.p;
-                HIPCK(h, hipMemsetAsync(heads, 0, sizeof(u32) * (size_t)hn, h->stream));
-                hipLaunchKernelGGL(espfold::col_heads_k, dim3(grid_for(h->n, 256)), dim3(256), 0, h->stream, (const i64 *)h->colptr.p, h->n, heads);
-                sp.add(1 + espscan::exclusive<u32, true>(h->stream, heads, heads, hn, heads + hn));
-            }
-            CK(ensure(h, h->rowval2, sizeof(i64) * (size_t)Zt));
-            CK(ensure(h, h->nzval2, sizeof(double) * (size_t)Zt));
-            {
-                Span sp(h, ESP_ST_MERGE);
-                espmerge::Args a;
-                a.old_col = (const u32 *)h->heads.p + 1;
-                a.old_row = (const i64 *)h->rowval.p;
-                a.old_val = (const double *)h->nzval.p;
-                a.Z0 = Z0;
-                a.new_key = (const u64 *)h->newkey.p;
-                a.new_val = (const double *)h->newval.p;
-                a.Zn = Zn;
-                a.rb = h->L.rb;
-                a.out_row = (i64 *)h->rowval2.p;
-                a.out_val = (double *)h->nzval2.p;
-                hipLaunchKernelGGL(espmerge::merge_k, dim3(grid_for(Zt, espmerge::TILE)), dim3(espmerge::THREADS), 0, h->stream, a);
-                sp.add(1);
-            }
-            {
-                Span sp(h, ESP_ST_COLPTR);
-                hipLaunchKernelGGL(espfold::colptr_finish_k, dim3(grid_for(N1, 256)), dim3(256), 0, h->stream, (const u64 *)colend,
-                                   (const i64 *)h->colptr.p, N1, (i64 *)h->colptr.p);
-                sp.add(1);
-            }
-            std::swap(h->rowval, h->rowval2);
-            std::swap(h->nzval, h->nzval2);
-            h->nnz = Zt;
-        }
-        if (pattern_changed) *pattern_changed = 1;
+    *Zn_out = Zn;
+    if (Zn == 0) return ESP_OK;
+    CK(prepare_outputs(h, Z0, Zn));
+    {
+        Span sp(h, ESP_ST_FOLD);
+        if (Z0 == 0)
+            hipLaunchKernelGGL((espfold::compact_k<true>), dim3(grid_for(E, espfold::THREADS)), dim3(espfold::THREADS), 0, h->stream, sk,
+                               (const double *)fval, E, (const u32 *)flag, h->L.rb, (i64 *)h->rowval.p, (u64 *)nullptr,
+                               (double *)h->nzval.p, (u64 *)h->colend.p);
+        else
+            hipLaunchKernelGGL((espfold::compact_k<false>), dim3(grid_for(E, espfold::THREADS)), dim3(espfold::THREADS), 0, h->stream, sk,
+                               (const double *)fval, E, (const u32 *)flag, h->L.rb, (i64 *)nullptr, (u64 *)h->newkey.p,
+                               (double *)h->newval.p, (u64 *)h->colend.p);
+        sp.add(1);
     }
+    return finish_csc(h, Z0, Zn);
+}
+
+extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int32_t *pattern_changed) {
+    if (!h) return ESP_ERR_INVALID;
+    if (mode != ESP_FLUSH_ROUTED && mode != ESP_FLUSH_PLUS) FAIL(h, ESP_ERR_INVALID, "esp_flush: mode");
+    (void)hipSetDevice(h->device);
+    if (pattern_changed) *pattern_changed = 0;
+    const i64 E = h->count;
+    if (E == 0) {
+        if (new_nnz) *new_nnz = h->nnz;
+        return ESP_OK;
+    }
+    if (E >= 0xFFFFFFF0ll) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_flush: %lld pending entries exceed the 2^32 limit of one flush", (long long)E);
+    hipEvent_t fa = nullptr;
+    if (h->timing) {
+        fa = ev_get(h);
+        (void)hipEventRecord(fa, h->stream);
+    }
+    i64 Zn = 0;
+    bool use_local = h->force_path != 2;
+    if (use_local) {
+        Sorted st;
+        CK(sort_msd(h, &st));
+        if (!st.in_primary) {  // keep "pending data lives in keys/vals" true for the general path
+            std::swap(h->keys, h->keys2);
+            std::swap(h->vals, h->vals2);
+            h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
+            st.in_primary = true;
+        }
+        if (st.local_ok)
+            CK(flush_local(h, st, mode, &Zn));
+        else
+            use_local = false;
+    }
+    if (!use_local) CK(flush_global(h, mode, &Zn));
+    h->last_path = use_local ? 1 : 2;
+    if (Zn > 0 && pattern_changed) *pattern_changed = 1;
     HIPCK(h, hipGetLastError());
     h->count = 0;
     h->shard_valid = false;
@@ -866,6 +1054,18 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         h->spans.push_back({-1, fa, fb, 0});
     }
     if (new_nnz) *new_nnz = h->nnz;
+    return ESP_OK;
+}
+
+// test/bench hook: 0 = automatic, 1 = (same as 0), 2 = force the general global path
+extern "C" int32_t esp_debug_force_path(esp_handle *h, int32_t path) {
+    if (!h) return ESP_ERR_INVALID;
+    h->force_path = path;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_last_path(const esp_handle *h, int32_t *path) {
+    if (!h || !path) return ESP_ERR_INVALID;
+    *path = h->last_path;
     return ESP_OK;
 }
 

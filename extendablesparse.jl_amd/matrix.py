@@ -387,6 +387,15 @@ class ExtendableSparseMatrix:
         self._d.commit()
         self._d.ck(self._d.lib.esp_generate_fem(self._d.h, dim, npd, seed, order_mode))
 
+    def debug_force_path(self, path):
+        """Test hook: 0 automatic, 2 force the general path (global LSD sort + global fold)."""
+        self._d.ck(self._d.lib.esp_debug_force_path(self._d.h, path))
+
+    def debug_last_path(self):
+        p = C.c_int32()
+        self._d.ck(self._d.lib.esp_debug_last_path(self._d.h, C.byref(p)))
+        return p.value
+
     def timing_enable(self, on=True):
         self._d.ck(self._d.lib.esp_timing_enable(self._d.h, 1 if on else 0))
 

@@ -350,6 +350,41 @@ def test_long_duplicate_runs_and_dense_column(esp, orc):
     A.append(0, I, J, V, kinds=kinds)
     O.apply(kinds, I, J, V)
     assert_csc_equal(hip_arrays(A), O.arrays())
+    assert A.debug_last_path() == 2        # runs longer than an LDS bucket take the general path
+
+
+@pytest.mark.parametrize("force", [0, 2])
+def test_both_pipelines_agree_with_oracle(esp, orc, force):
+    """The LDS bucket path (1) and the general path (2) are both checked against the oracle."""
+    rng = np.random.default_rng(29)
+    m, n = 3000, 2500
+    A = esp.ExtendableSparseMatrix(m, n)
+    A.debug_force_path(force)
+    O = orc.ExtendableSparseMatrix(m, n)
+    for rnd in range(3):
+        cnt = 60000
+        kinds = rng.integers(0, 3, cnt).astype(np.uint8)
+        I = rng.integers(1, m + 1, cnt)
+        J = rng.integers(1, n + 1, cnt)
+        hot = rng.random(cnt) < 0.3
+        I[hot] = rng.integers(1, 40, hot.sum())
+        J[hot] = rng.integers(1, 30, hot.sum())
+        V = np.where(rng.random(cnt) < 0.2, 0.0, rng.standard_normal(cnt))
+        A.append(0, I, J, V, kinds=kinds)
+        O.apply(kinds, I, J, V)
+        A.flush()
+        O.flush()
+        assert A.debug_last_path() == (2 if force == 2 else 1)
+        assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
+
+
+def test_general_path_fdrand_and_plus_mode(esp, orc):
+    A = esp.ExtendableSparseMatrix(20 ** 3, 20 ** 3)
+    A.debug_force_path(2)
+    esp.fdrand_device_(A, 20, 20, 20, rand_mode=1, seed=77)
+    O = orc.fdrand(20, 20, 20, rand_mode=1, seed=77, style=orc.KIND_UPDATE)
+    assert A.debug_last_path() == 2
+    assert_csc_equal(hip_arrays(A), O.arrays())
 
 
 def test_empty_and_tiny(esp):
