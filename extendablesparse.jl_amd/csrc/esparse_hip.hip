@@ -2,6 +2,7 @@
 // orchestration of the flush pipeline.  gfx950 only; no CPU fallback of any kind: without
 // a GPU every entry point that needs one returns ESP_ERR_NODEVICE.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
@@ -845,7 +846,7 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
 // colend (u64, n+1, zero-initialised, filled with column ends) -> colptr; merges with the old
 // CSC when there is one.  New entries are in h->newkey/h->newval (Z0>0) or already in
 // h->rowval/h->nzval (Z0==0).
-static int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn) {
+static int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn, const u64 *new_key, const double *new_val) {
     const i64 N1 = h->n + 1;
     u64 *colend = (u64 *)h->colend.p;
     if (Z0 == 0) {
@@ -878,8 +879,8 @@ static int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn) {
         a.old_row = (const i64 *)h->rowval.p;
         a.old_val = (const double *)h->nzval.p;
         a.Z0 = Z0;
-        a.new_key = (const u64 *)h->newkey.p;
-        a.new_val = (const double *)h->newval.p;
+        a.new_key = new_key;
+        a.new_val = new_val;
         a.Zn = Zn;
         a.rb = h->L.rb;
         a.out_row = (i64 *)h->rowval2.p;
@@ -913,58 +914,67 @@ static int32_t prepare_outputs(esp_handle *h, i64 Z0, i64 Zn) {
     return ESP_OK;
 }
 
-// fast path: LDS bucket kernel over the MSD segments
+// fast path: LDS bucket kernel over the MSD segments; writes the final arrays itself
 static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
     const i64 Z0 = h->nnz;
     const int S = st.S;
-    u64 *tk = st.in_primary ? (u64 *)h->keys2.p : (u64 *)h->keys.p;
-    double *tv = st.in_primary ? (double *)h->vals2.p : (double *)h->vals.p;
-    CK(ensure(h, h->segcnt, sizeof(u32) * (size_t)(S + 1)));
-    CK(ensure(h, h->segout, sizeof(u64) * (size_t)(S + 1 + espscan::workspace_elems(S + 1))));
+    const i64 N1 = h->n + 1;
+    // esp_flush normalised the buffers: data in keys/vals, scratch pair = keys2/vals2
+    u64 *tk = (u64 *)h->keys2.p;
+    double *tv = (double *)h->vals2.p;
+    CK(ensure(h, h->segout, sizeof(u64) * (size_t)(S + 4)));
+    u64 *status = (u64 *)h->segout.p;
+    HIPCK(h, hipMemsetAsync(status, 0, sizeof(u64) * (size_t)(S + 2), h->stream));
+    CK(ensure(h, h->colend, sizeof(u64) * (size_t)(N1 + espscan::workspace_elems(N1))));
+    HIPCK(h, hipMemsetAsync(h->colend.p, 0, sizeof(u64) * (size_t)N1, h->stream));
+    esplocal::Args a;
     {
         Span sp(h, ESP_ST_LOCAL);
-        esplocal::Args a;
         a.keys_in = st.sk;
         a.vals_in = st.sv;
         a.seg_start = st.seg_start;
         a.S = S;
         a.rem_bits = st.rem_bits;
         a.rb = h->L.rb;
+        {
+            const int clb = st.rem_bits - h->L.rb;
+            a.cl_bits = (clb >= 0 && clb <= esplocal::CL_MAX_BITS && h->force_path != 3) ? clb : -1;
+        }
+        // a segment is a whole number of columns when the prefix does not reach into the row bits
+        a.col_aligned = st.rem_bits >= h->L.rb ? 1 : 0;
         a.csc = espfold::Csc{(const i64 *)h->colptr.p, (const i64 *)h->rowval.p, (double *)h->nzval.p, Z0};
         a.mode = mode;
-        a.out_keys = tk;
-        a.out_vals = tv;
-        a.seg_count = (u32 *)h->segcnt.p;
-        hipLaunchKernelGGL(esplocal::local_k, dim3((unsigned)S), dim3(esplocal::THREADS), 0, h->stream, a);
-        sp.add(1);
-    }
-    u64 *segout = (u64 *)h->segout.p;
-    {
-        Span sp(h, ESP_ST_SCAN);
-        hipLaunchKernelGGL(esplocal::widen_counts_k, dim3(grid_for(S + 1, 256)), dim3(256), 0, h->stream, (const u32 *)h->segcnt.p, (i64)S, segout);
-        sp.add(1 + espscan::exclusive<u64, false>(h->stream, segout, segout, S + 1, segout + S + 1));
-    }
-    HIPCK(h, hipMemcpyAsync(h->pin_scalar, segout + S, 8, hipMemcpyDeviceToHost, h->stream));
-    HIPCK(h, hipStreamSynchronize(h->stream));
-    const i64 Zn = (i64)h->pin_scalar[0];
-    *Zn_out = Zn;
-    if (Zn == 0) return ESP_OK;
-    CK(prepare_outputs(h, Z0, Zn));
-    // a segment is a whole number of columns when the partition prefix does not reach into the row bits
-    const int col_aligned = st.rem_bits >= h->L.rb ? 1 : 0;
-    {
-        Span sp(h, ESP_ST_FOLD);
+        a.out_row = (i64 *)tk;
+        a.out_key = tk;
+        a.out_val = tv;
+        a.colend = (u64 *)h->colend.p;
+        a.status = status;
+        a.ticket = (u32 *)(status + S);
+        a.err = (u32 *)(status + S) + 1;
+        {
+            const char *e = getenv("ESP_LOCAL_STOP");
+            a.stop_after = e ? atoi(e) : 0;
+        }
         if (Z0 == 0)
-            hipLaunchKernelGGL((esplocal::gather_k<true>), dim3((unsigned)S), dim3(256), 0, h->stream, (const u64 *)tk, (const double *)tv,
-                               st.seg_start, (const u64 *)segout, h->L.rb, col_aligned, (i64 *)h->rowval.p, (u64 *)nullptr,
-                               (double *)h->nzval.p, (u64 *)h->colend.p);
+            hipLaunchKernelGGL((esplocal::local_k<true>), dim3((unsigned)S), dim3(esplocal::THREADS), 0, h->stream, a);
         else
-            hipLaunchKernelGGL((esplocal::gather_k<false>), dim3((unsigned)S), dim3(256), 0, h->stream, (const u64 *)tk, (const double *)tv,
-                               st.seg_start, (const u64 *)segout, h->L.rb, col_aligned, (i64 *)nullptr, (u64 *)h->newkey.p,
-                               (double *)h->newval.p, (u64 *)h->colend.p);
+            hipLaunchKernelGGL((esplocal::local_k<false>), dim3((unsigned)S), dim3(esplocal::THREADS), 0, h->stream, a);
         sp.add(1);
     }
-    return finish_csc(h, Z0, Zn);
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (S - 1), 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    const u32 lookback_err = (u32)(h->pin_scalar[1] >> 32);
+    if (lookback_err) FAIL(h, ESP_ERR_HIP, "esp_flush: look-back chain timed out inside the bucket kernel");
+    const i64 Zn = (i64)(h->pin_scalar[0] & esplocal::ST_VAL);
+    *Zn_out = Zn;
+    if (a.stop_after || Zn == 0) return ESP_OK;
+    if (Z0 == 0) {
+        // the scratch pair now holds rowval/nzval: rotate the buffers instead of copying
+        std::swap(h->rowval, h->keys2);
+        std::swap(h->nzval, h->vals2);
+        return finish_csc(h, 0, Zn, nullptr, nullptr);
+    }
+    return finish_csc(h, Z0, Zn, (const u64 *)tk, (const double *)tv);
 }
 
 // general path: finish with a full stable LSD sort and the global fold (any run length)
@@ -1007,7 +1017,7 @@ static int32_t flush_global(esp_handle *h, int mode, i64 *Zn_out) {
                                (double *)h->newval.p, (u64 *)h->colend.p);
         sp.add(1);
     }
-    return finish_csc(h, Z0, Zn);
+    return finish_csc(h, Z0, Zn, (const u64 *)h->newkey.p, (const double *)h->newval.p);
 }
 
 extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int32_t *pattern_changed) {

@@ -1,13 +1,29 @@
-// local.hpp -- LDS bucket kernel (K2 tail + K3): one workgroup takes one segment of the
-// prefix-partitioned entry array (<= CAP entries, all sharing the top key bits), finishes
-// the stable sort on the remaining key bits inside LDS, folds duplicates in append order and
-// emits the distinct entries compacted at the head of the segment's slot in the scratch pair.
+// local.hpp -- LDS bucket kernel (K2 tail + K3 + K4 marks): one workgroup takes one segment of
+// the prefix-partitioned entry array (<= CAP entries sharing the top key bits), finishes the
+// stable sort on the remaining key bits inside LDS, folds duplicates in append order and writes
+// the distinct entries to their FINAL position in the output (rowval/nzval of a fresh CSC, or
+// the compact list of new entries for the merge join) with coalesced stores.
 //
-// HBM traffic: reads 16 B per appended entry once, writes 16 B per emitted entry once.
-// LDS: packed sort keys (8 B) + values (8 B) per slot + wave digit counters; the sort moves
-// only the packed key (remaining key bits | slot index | kind), values stay in place and are
-// fetched through the slot index by the fold.  Stable LSD radix, 8-bit digits, ranking by
-// 64-lane ballot matching (no LDS atomics, deterministic).
+// HBM traffic: reads 16 B per appended entry once, writes 16 B per emitted entry once
+// (+ 8 B per non-empty column for the column-end marks).
+//
+// Structure
+//   load      : 8 B key + 8 B value per slot -> packed sort key in registers, value in LDS
+//   sort      : three tiers chosen per segment from the longest column run
+//                 <= 16 : counting sort by local column (LDS atomics, unordered inside a
+//                         column) + one lane per column sorting its run in REGISTERS with a
+//                         63-comparator merge-exchange network on (row, slot index)
+//                 <= 48 : same, insertion sort of the run in LDS
+//                 else  : stable 8-bit LSD radix on all remaining key bits (ballot ranking)
+//               the slot index is the append order, so every tier yields the stable order
+//   fold      : ordered left-to-right fold per (col,row) (espfold::fold_step), CSC hits are
+//               applied in place, misses become records
+//   compact   : records -> dense LDS prefix (ballot ranks), segment total
+//   look-back : decoupled look-back over the segment totals gives the global output offset
+//               (8-byte {flag,value} granules, relaxed agent-scope atomics both sides --
+//               MI355X L2s are per XCD; segments are claimed through a ticket so that every
+//               predecessor has started: no dispatch-order assumption; spins are bounded)
+//   store     : coalesced stores of rowval/nzval (or key/val) + column-end marks
 #pragma once
 #include "common.hpp"
 #include "fold.hpp"
@@ -23,6 +39,42 @@ constexpr int SUB_SHIFT = ESP_TAG_BITS + IDX_BITS;  // packed: sub << 14 | idx <
 constexpr int MAX_REM_BITS = 64 - SUB_SHIFT;
 static_assert((1 << IDX_BITS) == CAP, "slot index must cover the segment capacity");
 
+constexpr int CL_MAX_BITS = 11;  // up to 2048 local columns counted in LDS
+constexpr int CL_MAX = 1 << CL_MAX_BITS;
+constexpr int REG_RUN = 16;   // longest column run sorted in registers
+constexpr int RANK_MAX = 48;  // longest column run sorted by LDS insertion
+constexpr u64 NOREC = ~0ull;
+
+// look-back status granule: [63:62] flag, [61:0] value
+constexpr u64 ST_AGG = 1ull << 62;
+constexpr u64 ST_PRE = 2ull << 62;
+constexpr u64 ST_VAL = (1ull << 62) - 1ull;
+constexpr u32 SPIN_LIMIT = 1u << 24;
+
+// Batcher's merge-exchange sorting network for 16 keys (63 compare-exchanges), generated at
+// compile time; used to sort one short column run per lane entirely in registers.
+struct Net {
+    int n;
+    int a[96];
+    int b[96];
+};
+constexpr Net make_net(int N) {
+    Net r{};
+    r.n = 0;
+    for (int p = 1; p < N; p <<= 1)
+        for (int kk = p; kk >= 1; kk >>= 1)
+            for (int j = kk % p; j <= N - 1 - kk; j += 2 * kk)
+                for (int i = 0; i <= (kk - 1 < N - j - kk - 1 ? kk - 1 : N - j - kk - 1); i++)
+                    if ((i + j) / (2 * p) == (i + j + kk) / (2 * p)) {
+                        r.a[r.n] = i + j;
+                        r.b[r.n] = i + j + kk;
+                        r.n++;
+                    }
+    return r;
+}
+constexpr Net NET16 = make_net(REG_RUN);
+static_assert(NET16.n == 63, "merge-exchange network for 16 inputs has 63 comparators");
+
 struct Args {
     const u64 *keys_in;
     const double *vals_in;
@@ -30,50 +82,28 @@ struct Args {
     int S;
     int rem_bits;  // key bits below the partition prefix (col/row bits, without the kind bits)
     int rb;
+    int cl_bits;  // local column bits (rem_bits - rb) when 0..CL_MAX_BITS, else -1: radix tail only
+    int col_aligned;  // a segment is a whole number of columns (column-end marks need no atomics)
     espfold::Csc csc;
     int mode;
-    u64 *out_keys;  // (col0<<rb | row0) of emitted entries, at seg_start[s] + q
-    double *out_vals;
-    u32 *seg_count;  // emitted entries per segment
+    i64 *out_row;    // FRESH: rowval (1-based) of the new CSC
+    u64 *out_key;    // !FRESH: (col0<<rb | row0) of new entries
+    double *out_val;
+    u64 *colend;     // per column: output index just past its last emitted entry (0 = none)
+    u64 *status;     // S look-back granules, zeroed before launch
+    u32 *ticket;     // zeroed before launch
+    u32 *err;        // set to 1 if a look-back spin ran into its bound
+    int stop_after;  // timing ablation only (0 = run everything)
 };
 
-__global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
-    __shared__ u64 skey[CAP];
-    __shared__ double sval[CAP];
-    __shared__ u32 cnt[WAVES][256];
-    __shared__ u32 lw[8];
-    __shared__ u32 gcount[WAVES * ITEMS];
-
-    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const int s = blockIdx.x;
-    const i64 beg = a.seg_start[s];
-    const int n = (int)(a.seg_start[s + 1] - beg);
-    if (n == 0) {
-        if (t == 0) a.seg_count[s] = 0;
-        return;
-    }
-    const u64 submask = a.rem_bits >= 64 ? ~0ull : ((1ull << a.rem_bits) - 1ull);
-    const u64 hi = ((a.keys_in[beg] >> ESP_TAG_BITS) >> a.rem_bits) << a.rem_bits;  // shared prefix
-    const int wbase = w * (ITEMS * ESP_WAVE) + lane;
-
-    u64 k[ITEMS];
-#pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
-        const int p = wbase + i * ESP_WAVE;
-        if (p < n) {
-            const u64 key = a.keys_in[beg + p];
-            sval[p] = a.vals_in[beg + p];
-            k[i] = (((key >> ESP_TAG_BITS) & submask) << SUB_SHIFT) | ((u64)p << ESP_TAG_BITS) | (key & ESP_TAG_MASK);
-        } else {
-            k[i] = ~0ull;  // sorts behind every real entry (stable: real entries come first on ties)
-        }
-    }
-
+// Stable LSD radix tail on the packed keys held in registers (wave-striped arrangement):
+// sorts on bits [SUB_SHIFT, SUB_SHIFT+rem_bits); result in k[] and skey[].
+__device__ __forceinline__ void radix_tail(u64 (&k)[ITEMS], u64 *skey, u32 (*cnt)[256], u32 *lw, int rem_bits, int t,
+                                           int lane, int w, int wbase) {
     const u64 lt = (1ull << lane) - 1ull;
-    for (int shift = SUB_SHIFT; shift < SUB_SHIFT + a.rem_bits; shift += 8) {
-        const int bits = min(8, SUB_SHIFT + a.rem_bits - shift);
+    for (int shift = SUB_SHIFT; shift < SUB_SHIFT + rem_bits; shift += 8) {
+        const int bits = min(8, SUB_SHIFT + rem_bits - shift);
         const u32 dmask = (1u << bits) - 1u;
-        // zero the wave counters
         for (int q = t; q < WAVES * 256; q += THREADS) (&cnt[0][0])[q] = 0;
         __syncthreads();
         unsigned short rank[ITEMS];
@@ -94,7 +124,6 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             __builtin_amdgcn_wave_barrier();
         }
         __syncthreads();
-        // digit totals -> block-exclusive digit starts (+ per-wave bases) written back to cnt
         u32 c[WAVES];
         u32 tot = 0, inc = 0;
         if (t < 256) {
@@ -131,50 +160,287 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) k[i] = skey[wbase + i * ESP_WAVE];
     }
-    if (a.rem_bits <= 0) {
-#pragma unroll
-        for (int i = 0; i < ITEMS; i++) skey[wbase + i * ESP_WAVE] = k[i];
-    }
-    __syncthreads();
+}
 
-    // ---- ordered fold: run heads walk their run in LDS (append order inside a run)
-    bool emit[ITEMS];
-    double acc[ITEMS];
+// closes one (col,row) group of a column run: CSC hit -> in place, miss -> record at skey[rs+e]
+__device__ __forceinline__ void close_group(const Args &a, u64 *skey, double *sval, int rs, int &e, i64 pos, bool present,
+                                            double acc, u64 psub, u32 idx0) {
+    if (pos >= 0) {
+        if (a.mode == ESP_FLUSH_ROUTED)
+            a.csc.nzval[pos] = acc;
+        else if (present)
+            a.csc.nzval[pos] = a.csc.nzval[pos] + acc;  // csc operand first, sparsematrixlnk.jl:363
+    } else if (present) {
+        skey[rs + e] = (psub << SUB_SHIFT) | ((u64)idx0 << ESP_TAG_BITS);
+        sval[idx0] = acc;
+        e++;
+    }
+}
+
+template <bool FRESH>
+__global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
+    __shared__ u64 skey[CAP];
+    __shared__ double sval[CAP];
+    // radix tail: cnt[WAVES][256]; column tiers: ccnt[CL_MAX+1] (same storage)
+    __shared__ u32 cntraw[WAVES * 256 + 64];
+    __shared__ u32 lw[16];
+    __shared__ u32 gcount[WAVES * ITEMS];
+    __shared__ u64 s_dst;
+    __shared__ int s_seg;
+    u32(*cnt)[256] = reinterpret_cast<u32(*)[256]>(cntraw);
+    u32 *ccnt = cntraw;
+
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    // claim a segment in start order: every predecessor of a look-back chain has started
+    if (t == 0) s_seg = (int)atomicAdd(a.ticket, 1u);
+    __syncthreads();
+    const int s = s_seg;
+    const i64 beg = a.seg_start[s];
+    const int n = (int)(a.seg_start[s + 1] - beg);
+    const u64 submask = a.rem_bits >= 64 ? ~0ull : ((1ull << a.rem_bits) - 1ull);
+    const u64 hi = n > 0 ? (((a.keys_in[beg] >> ESP_TAG_BITS) >> a.rem_bits) << a.rem_bits) : 0;  // shared prefix
+    const int wbase = w * (ITEMS * ESP_WAVE) + lane;
+    const u64 lt = (1ull << lane) - 1ull;
+    const u64 rowmask = (1ull << a.rb) - 1ull;
+
+    u64 k[ITEMS];
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
-        const int q = wbase + i * ESP_WAVE;
-        emit[i] = false;
-        acc[i] = 0.0;
-        if (q < n) {
-            const u64 sub = k[i] >> SUB_SHIFT;
-            const bool head = q == 0 || (skey[q - 1] >> SUB_SHIFT) != sub;
-            if (head) {
-                const u64 full = hi | sub;
-                i64 pos = -1;
-                if (a.csc.nnz > 0) pos = espfold::csc_find(a.csc, (i64)(full >> a.rb), (i64)(full & ((1ull << a.rb) - 1ull)));
-                bool present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
-                double x = present ? a.csc.nzval[pos] : 0.0;
-                for (int j = q; j < n; j++) {
-                    const u64 kj = skey[j];
-                    if ((kj >> SUB_SHIFT) != sub) break;
-                    espfold::fold_step(present, x, (u32)(kj & ESP_TAG_MASK), sval[(kj >> ESP_TAG_BITS) & (CAP - 1)]);
+        const int p = wbase + i * ESP_WAVE;
+        if (p < n) {
+            const u64 key = a.keys_in[beg + p];
+            sval[p] = a.vals_in[beg + p];
+            k[i] = (((key >> ESP_TAG_BITS) & submask) << SUB_SHIFT) | ((u64)p << ESP_TAG_BITS) | (key & ESP_TAG_MASK);
+        } else {
+            k[i] = NOREC;  // sorts behind every real entry (stable: real entries come first on ties)
+        }
+    }
+    bool done = n == 0;
+    if (a.stop_after == 1) done = true;
+
+    if (!done && a.cl_bits >= 0) {
+        // ---- column tiers: counting sort by local column with LDS atomics
+        const int ncl = 1 << a.cl_bits;
+        const int csh = SUB_SHIFT + a.rb;  // packed >> csh = local column
+        for (int q = t; q <= ncl; q += THREADS) ccnt[q] = 0;
+        __syncthreads();
+        unsigned short slot[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            slot[i] = 0;
+            if (wbase + i * ESP_WAVE < n) slot[i] = (unsigned short)atomicAdd(&ccnt[(u32)(k[i] >> csh)], 1u);
+        }
+        __syncthreads();
+        // exclusive scan of the column counts (ncl <= 2048 -> <= 4 per thread) + longest run
+        constexpr int PER = CL_MAX / THREADS;
+        u32 v[PER];
+        u32 run = 0, mx = 0;
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int q = t * PER + j;
+            const u32 x = q < ncl ? ccnt[q] : 0;
+            mx = max(mx, x);
+            v[j] = run;
+            run += x;
+        }
+        u32 inc = run;
+#pragma unroll
+        for (int dlt = 1; dlt < ESP_WAVE; dlt <<= 1) {
+            const u32 o = __shfl_up(inc, dlt, ESP_WAVE);
+            if (lane >= dlt) inc += o;
+        }
+#pragma unroll
+        for (int dlt = 32; dlt > 0; dlt >>= 1) mx = max(mx, (u32)__shfl_xor((int)mx, dlt, ESP_WAVE));
+        if (lane == 63) lw[w] = inc;
+        if (lane == 0) lw[8 + w] = mx;
+        __syncthreads();
+        u32 base = inc - run, maxrun = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) {
+            if (i < w) base += lw[i];
+            maxrun = max(maxrun, lw[8 + i]);
+        }
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int q = t * PER + j;
+            if (q < ncl) ccnt[q] = base + v[j];
+        }
+        if (t == 0) ccnt[ncl] = (u32)n;
+        __syncthreads();
+        if (a.stop_after == 2) done = true;
+        if (!done && maxrun <= RANK_MAX) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++)
+                if (wbase + i * ESP_WAVE < n) skey[ccnt[(u32)(k[i] >> csh)] + slot[i]] = k[i];
+            __syncthreads();
+            if (a.stop_after == 3) done = true;
+            if (!done && maxrun <= REG_RUN) {
+                // one lane per column: the whole run in registers, sorting network + ordered fold
+                for (int c = t; c < ncl; c += THREADS) {
+                    const int rs = (int)ccnt[c];
+                    const int len = (int)ccnt[c + 1] - rs;
+                    u64 x[REG_RUN];
+#pragma unroll
+                    for (int j = 0; j < REG_RUN; j++) x[j] = j < len ? skey[rs + j] : NOREC;
+#pragma unroll
+                    for (int q = 0; q < NET16.n; q++) {
+                        const u64 lo = x[NET16.a[q]], hi2 = x[NET16.b[q]];
+                        const bool sw = lo > hi2;
+                        x[NET16.a[q]] = sw ? hi2 : lo;
+                        x[NET16.b[q]] = sw ? lo : hi2;
+                    }
+                    double xv[REG_RUN];
+#pragma unroll
+                    for (int j = 0; j < REG_RUN; j++) xv[j] = j < len ? sval[(x[j] >> ESP_TAG_BITS) & (CAP - 1)] : 0.0;
+                    int e = 0;
+                    bool present = false;
+                    double acc = 0.0;
+                    u64 psub = 0;
+                    u32 idx0 = 0;
+                    i64 pos = -1;
+#pragma unroll
+                    for (int j = 0; j <= REG_RUN; j++) {
+                        const bool valid = j < REG_RUN && j < len;
+                        const u64 kj = j < REG_RUN ? x[j] : NOREC;
+                        const u64 sub = kj >> SUB_SHIFT;
+                        const bool fresh = j == 0 || !valid || sub != psub;
+                        if (fresh && j > 0 && j <= len) close_group(a, skey, sval, rs, e, pos, present, acc, psub, idx0);
+                        if (valid) {
+                            if (fresh) {
+                                psub = sub;
+                                idx0 = (u32)(kj >> ESP_TAG_BITS) & (CAP - 1);
+                                pos = -1;
+                                if (a.csc.nnz > 0) {
+                                    const u64 full = hi | sub;
+                                    pos = espfold::csc_find(a.csc, (i64)(full >> a.rb), (i64)(full & rowmask));
+                                }
+                                present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
+                                acc = present ? a.csc.nzval[pos] : 0.0;
+                            }
+                            espfold::fold_step(present, acc, (u32)(kj & ESP_TAG_MASK), xv[j < REG_RUN ? j : 0]);
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < REG_RUN; j++)
+                        if (j >= e && j < len) skey[rs + j] = NOREC;
                 }
-                if (pos >= 0) {
-                    if (a.mode == ESP_FLUSH_ROUTED)
-                        a.csc.nzval[pos] = x;
-                    else if (present)
-                        a.csc.nzval[pos] = a.csc.nzval[pos] + x;
-                } else if (present) {
-                    emit[i] = true;
-                    acc[i] = x;
+                done = true;
+            } else if (!done) {
+                for (int c = t; c < ncl; c += THREADS) {
+                    const int rs = (int)ccnt[c], re = (int)ccnt[c + 1];
+                    for (int p = rs + 1; p < re; p++) {  // insertion sort, keys are unique
+                        const u64 x = skey[p];
+                        int q = p - 1;
+                        while (q >= rs) {
+                            const u64 y = skey[q];
+                            if (y < x) break;
+                            skey[q + 1] = y;
+                            q--;
+                        }
+                        skey[q + 1] = x;
+                    }
+                    int e = 0, j = rs;
+                    u64 kj = j < re ? skey[j] : 0;
+                    while (j < re) {
+                        const u64 sub = kj >> SUB_SHIFT;
+                        const u32 idx0 = (u32)(kj >> ESP_TAG_BITS) & (CAP - 1);
+                        i64 pos = -1;
+                        if (a.csc.nnz > 0) {
+                            const u64 full = hi | sub;
+                            pos = espfold::csc_find(a.csc, (i64)(full >> a.rb), (i64)(full & rowmask));
+                        }
+                        bool present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
+                        double x = present ? a.csc.nzval[pos] : 0.0;
+                        do {
+                            espfold::fold_step(present, x, (u32)(kj & ESP_TAG_MASK), sval[(kj >> ESP_TAG_BITS) & (CAP - 1)]);
+                            j++;
+                            if (j < re) kj = skey[j];
+                        } while (j < re && (kj >> SUB_SHIFT) == sub);
+                        close_group(a, skey, sval, rs, e, pos, present, x, sub, idx0);
+                    }
+                    for (int q = rs + e; q < re; q++) skey[q] = NOREC;
+                }
+                done = true;
+            }
+        }
+        __syncthreads();  // records are in place (or: ccnt storage is free for the radix counters)
+    }
+
+    if (!done) {
+        // ---- radix tier (long runs / wide column ranges): stable LSD sort of all remaining bits
+        radix_tail(k, skey, cnt, lw, a.rem_bits, t, lane, w, wbase);
+        if (a.rem_bits <= 0) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) skey[wbase + i * ESP_WAVE] = k[i];
+        }
+        __syncthreads();
+        // ordered fold: run heads walk their run in LDS (append order inside a run)
+        bool emit[ITEMS];
+        double acc[ITEMS];
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const int q = wbase + i * ESP_WAVE;
+            emit[i] = false;
+            acc[i] = 0.0;
+            if (q < n) {
+                const u64 sub = k[i] >> SUB_SHIFT;
+                const bool head = q == 0 || (skey[q - 1] >> SUB_SHIFT) != sub;
+                if (head) {
+                    const u64 full = hi | sub;
+                    i64 pos = -1;
+                    if (a.csc.nnz > 0) pos = espfold::csc_find(a.csc, (i64)(full >> a.rb), (i64)(full & rowmask));
+                    bool present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
+                    double x = present ? a.csc.nzval[pos] : 0.0;
+                    for (int j = q; j < n; j++) {
+                        const u64 kj = skey[j];
+                        if ((kj >> SUB_SHIFT) != sub) break;
+                        espfold::fold_step(present, x, (u32)(kj & ESP_TAG_MASK), sval[(kj >> ESP_TAG_BITS) & (CAP - 1)]);
+                    }
+                    if (pos >= 0) {
+                        if (a.mode == ESP_FLUSH_ROUTED)
+                            a.csc.nzval[pos] = x;
+                        else if (present)
+                            a.csc.nzval[pos] = a.csc.nzval[pos] + x;
+                    } else if (present) {
+                        emit[i] = true;
+                        acc[i] = x;
+                    }
                 }
             }
         }
-        const u64 bal = __ballot(emit[i]);
+        __syncthreads();  // every walk is finished: slots can be rewritten as records
+#pragma unroll
+        for (int i = 0; i < ITEMS; i++) {
+            const int q = wbase + i * ESP_WAVE;
+            if (q < n) {
+                if (emit[i]) {
+                    const u32 idx0 = (u32)(k[i] >> ESP_TAG_BITS) & (CAP - 1);
+                    skey[q] = (k[i] >> SUB_SHIFT << SUB_SHIFT) | ((u64)idx0 << ESP_TAG_BITS);
+                    sval[idx0] = acc[i];
+                } else {
+                    skey[q] = NOREC;
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (a.stop_after == 4) {
+        if (t == 0 && s == a.S - 1) __hip_atomic_store(&a.status[s], ST_PRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+
+    // ---- compaction: records (skey[p] != NOREC, value in sval[idx]) -> dense prefix
+    u64 rec[ITEMS];
+    double rv[ITEMS];
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const int p = wbase + i * ESP_WAVE;
+        rec[i] = (p < n && a.stop_after == 0) ? skey[p] : NOREC;
+        rv[i] = rec[i] != NOREC ? sval[(rec[i] >> ESP_TAG_BITS) & (CAP - 1)] : 0.0;
+        const u64 bal = __ballot(rec[i] != NOREC);
         if (lane == 0) gcount[w * ITEMS + i] = (u32)__popcll(bal);
     }
     __syncthreads();
-    // exclusive scan over the WAVES*ITEMS (=64) group counts by wave 0
     if (w == 0) {
         const u32 c = gcount[lane];
         u32 inc = c;
@@ -184,57 +450,86 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             if (lane >= dlt) inc += o;
         }
         gcount[lane] = inc - c;
-        if (lane == 63) a.seg_count[s] = inc;
+        const u32 total = (u32)__shfl((int)inc, 63, ESP_WAVE);
+        // ---- decoupled look-back (wave 0): exclusive prefix of the segment totals
+        u64 excl = 0;
+        if (s == 0) {
+            if (lane == 0) __hip_atomic_store(&a.status[0], ST_PRE | (u64)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (lane == 0) __hip_atomic_store(&a.status[s], ST_AGG | (u64)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            int top = s - 1;  // highest predecessor not yet accounted for
+            u32 spins = 0;
+            bool fail = false;
+            while (true) {
+                const int j = top - lane;
+                u64 v = ST_PRE;  // lanes before segment 0 act as a zero prefix
+                if (j >= 0) v = __hip_atomic_load(&a.status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const u64 ready = __ballot((v >> 62) != 0);
+                const u64 pre = __ballot((v >> 62) == 2);
+                // usable lanes: a contiguous run of ready lanes starting at lane 0, cut after the first PRE
+                const u64 notready = ~ready;
+                const int nrun = notready ? __builtin_ctzll(notready) : 64;
+                const u64 runmask = nrun >= 64 ? ~0ull : ((1ull << nrun) - 1ull);
+                const u64 prein = pre & runmask;
+                int use = nrun;
+                bool finished = false;
+                if (prein) {
+                    use = __builtin_ctzll(prein) + 1;
+                    finished = true;
+                }
+                u64 part = lane < use ? (v & ST_VAL) : 0ull;
+#pragma unroll
+                for (int dlt = 32; dlt > 0; dlt >>= 1) part += __shfl_xor(part, dlt, ESP_WAVE);
+                excl += part;
+                top -= use;
+                if (finished) break;
+                if (use == 0) {
+                    if (++spins > SPIN_LIMIT) {
+                        fail = true;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(2);
+                }
+            }
+            if (fail && lane == 0) atomicExch(a.err, 1u);
+            if (lane == 0)
+                __hip_atomic_store(&a.status[s], ST_PRE | ((excl + (u64)total) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (lane == 0) {
+            s_dst = excl;
+            lw[0] = total;
+        }
     }
     __syncthreads();
+    const u64 dst = s_dst;
+    const int total = (int)lw[0];
+    // dense prefix in LDS (all records and values are in registers: in-place is safe)
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
-        const u64 bal = __ballot(emit[i]);
-        if (emit[i]) {
+        const u64 bal = __ballot(rec[i] != NOREC);
+        if (rec[i] != NOREC) {
             const u32 e = gcount[w * ITEMS + i] + (u32)__popcll(bal & lt);
-            a.out_keys[beg + e] = hi | (k[i] >> SUB_SHIFT);
-            a.out_vals[beg + e] = acc[i];
+            skey[e] = hi | (rec[i] >> SUB_SHIFT);
+            sval[e] = rv[i];
         }
     }
-}
-
-// copy every segment's emitted run to its final place and mark column ends.
-// FRESH: final CSC arrays (rowval 1-based); else compact (key,val) list of new entries.
-template <bool FRESH>
-__global__ __launch_bounds__(256) void gather_k(const u64 *__restrict__ tkeys, const double *__restrict__ tvals,
-                                                const i64 *__restrict__ seg_start,
-                                                const u64 *__restrict__ seg_out /* exclusive scan of seg_count, S+1 */,
-                                                int rb, int col_aligned, i64 *__restrict__ out_row,
-                                                u64 *__restrict__ out_key, double *__restrict__ out_val,
-                                                u64 *__restrict__ colend) {
-    const int s = blockIdx.x;
-    const i64 src = seg_start[s];
-    const i64 dst = (i64)seg_out[s];
-    const int cnt = (int)(seg_out[s + 1] - seg_out[s]);
-    const u64 rowmask = (1ull << rb) - 1ull;
-    for (int q = threadIdx.x; q < cnt; q += 256) {
-        const u64 key = tkeys[src + q];
+    __syncthreads();
+    // ---- coalesced stores + column-end marks
+    for (int p = t; p < total; p += THREADS) {
+        const u64 key = skey[p];
         if (FRESH)
-            out_row[dst + q] = (i64)(key & rowmask) + 1;
+            a.out_row[dst + p] = (i64)(key & rowmask) + 1;
         else
-            out_key[dst + q] = key;
-        out_val[dst + q] = tvals[src + q];
-        const u64 col = key >> rb;
-        // last emitted entry of its column inside this segment; a later segment of the same
-        // column (prefix finer than a column) overwrites with a larger value: use max
-        if (q == cnt - 1 || (tkeys[src + q + 1] >> rb) != col) {
-            if (col_aligned)
-                colend[col] = (u64)(dst + q + 1);
+            a.out_key[dst + p] = key;
+        a.out_val[dst + p] = sval[p];
+        const u64 col = key >> a.rb;
+        if (p == total - 1 || (skey[p + 1] >> a.rb) != col) {
+            if (a.col_aligned)
+                a.colend[col] = dst + (u64)p + 1;
             else
-                atomicMax((unsigned long long *)&colend[col], (unsigned long long)(dst + q + 1));
+                atomicMax((unsigned long long *)&a.colend[col], (unsigned long long)(dst + (u64)p + 1));
         }
     }
-}
-
-__global__ void widen_counts_k(const u32 *__restrict__ in, i64 n, u64 *__restrict__ out) {
-    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (g > n) return;
-    out[g] = g < n ? (u64)in[g] : 0ull;
 }
 
 }  // namespace esplocal

@@ -353,7 +353,7 @@ def test_long_duplicate_runs_and_dense_column(esp, orc):
     assert A.debug_last_path() == 2        # runs longer than an LDS bucket take the general path
 
 
-@pytest.mark.parametrize("force", [0, 2])
+@pytest.mark.parametrize("force", [0, 2, 3])
 def test_both_pipelines_agree_with_oracle(esp, orc, force):
     """The LDS bucket path (1) and the general path (2) are both checked against the oracle."""
     rng = np.random.default_rng(29)
@@ -375,6 +375,30 @@ def test_both_pipelines_agree_with_oracle(esp, orc, force):
         A.flush()
         O.flush()
         assert A.debug_last_path() == (2 if force == 2 else 1)
+        assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
+
+
+@pytest.mark.parametrize("per_col", [6, 30, 200])
+def test_bucket_kernel_tiers(esp, orc, per_col):
+    """Column runs of ~6 (register sorting network), ~30 (LDS insertion) and ~200 (radix tail)
+    entries, with duplicates and SET/zero entries, all through the LDS bucket kernel."""
+    rng = np.random.default_rng(per_col)
+    m, n = 700, 2048
+    cnt = per_col * n
+    A = esp.ExtendableSparseMatrix(m, n)
+    O = orc.ExtendableSparseMatrix(m, n)
+    for rnd in range(2):
+        kinds = rng.choice(np.array([0, 1, 1, 1, 2], np.uint8), cnt)
+        I = rng.integers(1, m + 1, cnt)
+        J = rng.integers(1, n + 1, cnt)
+        dup = rng.random(cnt) < 0.3
+        I[dup] = rng.integers(1, 9, dup.sum())
+        V = np.where(rng.random(cnt) < 0.1, 0.0, rng.standard_normal(cnt))
+        A.append(0, I, J, V, kinds=kinds)
+        O.apply(kinds, I, J, V)
+        A.flush()
+        O.flush()
+        assert A.debug_last_path() == 1
         assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
 
 
