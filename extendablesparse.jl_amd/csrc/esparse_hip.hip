@@ -473,6 +473,7 @@ extern "C" int32_t esp_generate_fdrand(esp_handle *h, int64_t nx, int64_t ny, in
     a.seed = seed;
     a.rand_mode = rand_mode;
     a.kind = kind;
+    a.total = E;
     a.L = h->L;
     a.keys = (u64 *)h->keys.p + h->count;
     a.vals = (double *)h->vals.p + h->count;
@@ -684,7 +685,7 @@ static int32_t partition_pass(esp_handle *h, espradix::Pass &p, i64 max_tiles) {
     const size_t hist_bytes = sizeof(u64) * (size_t)(hn + espscan::workspace_elems(hn));
     CK(ensure(h, h->hist, hist_bytes));
     p.hist = (u64 *)h->hist.p;
-    if (p.S > 1) HIPCK(h, hipMemsetAsync(p.hist, 0, sizeof(u64) * (size_t)hn, h->stream));
+    HIPCK(h, hipMemsetAsync(p.hist, 0, sizeof(u64) * (size_t)hn, h->stream));
     {
         Span sp(h, ESP_ST_HIST);
         hipLaunchKernelGGL(espradix::tile_hist_k, dim3((unsigned)max_tiles), dim3(espradix::THREADS), 0, h->stream, p);

@@ -41,6 +41,7 @@ struct FdArgs {
     u64 seed;
     int rand_mode;
     int kind;
+    i64 total;  // number of updates of the whole stream
     KeyLayout L;
     u64 *keys;
     double *vals;
@@ -70,36 +71,78 @@ __device__ __forceinline__ i64 fd_offset(const FdArgs &a, i64 i, i64 j, i64 k, i
            (j - 1) * nx * cz + PX + (i - 1) * (cy + cz);
 }
 
-__device__ __forceinline__ void fd_put(const FdArgs &a, i64 &o, double v, i64 row, i64 col) {
-    a.keys[o] = esp_pack(a.L, row, col, a.kind);
-    a.vals[o] = v;
+constexpr int FD_MAX_PER_NODE = 15;  // 3 pairs x 4 + 3 boundary terms
+
+__device__ __forceinline__ void fd_put(const FdArgs &a, u64 *lk, double *lv, int &o, double v, i64 row, i64 col) {
+    lk[o] = esp_pack(a.L, row, col, a.kind);
+    lv[o] = v;
     o++;
 }
-__device__ __forceinline__ void fd_pair(const FdArgs &a, i64 &o, double v, i64 l, i64 l2) {
-    fd_put(a, o, -v, l, l2);  // update_pair: sprand.jl:87-92
-    fd_put(a, o, -v, l2, l);
-    fd_put(a, o, v, l, l);
-    fd_put(a, o, v, l2, l2);
+__device__ __forceinline__ void fd_pair(const FdArgs &a, u64 *lk, double *lv, int &o, double v, i64 l, i64 l2) {
+    fd_put(a, lk, lv, o, -v, l, l2);  // update_pair: sprand.jl:87-92
+    fd_put(a, lk, lv, o, -v, l2, l);
+    fd_put(a, lk, lv, o, v, l, l);
+    fd_put(a, lk, lv, o, v, l2, l2);
 }
 
+// One workgroup = 256 consecutive nodes.  Every node knows the exact position of its updates in
+// the sequential stream (closed form), the workgroup's updates form one contiguous range of the
+// buffer: they are staged in LDS and written with coalesced 16-byte stores (K1: "coalesced HBM
+// stores on the append path").  Writes 16 B per update, reads nothing.
 __global__ __launch_bounds__(THREADS) void fdrand_k(FdArgs a) {
-    const i64 g = (i64)blockIdx.x * THREADS + threadIdx.x;  // node l-1
+    __shared__ u64 lk[THREADS * FD_MAX_PER_NODE];
+    __shared__ double lv[THREADS * FD_MAX_PER_NODE];
     const i64 N = a.nx * a.ny * a.nz;
-    if (g >= N) return;
-    const i64 i = g % a.nx + 1, j = (g / a.nx) % a.ny + 1, k = g / (a.nx * a.ny) + 1;
+    const i64 g0 = (i64)blockIdx.x * THREADS;
+    const i64 g = g0 + threadIdx.x;  // node l-1
     i64 cy, cz;
-    i64 o = fd_offset(a, i, j, k, &cy, &cz);
-    const i64 l = g + 1;
-    const u64 c = 6ull * (u64)g;
-    if (i < a.nx) fd_pair(a, o, fd_rand(a.rand_mode, a.seed, c + 0) * a.hy * a.hz / a.hx, l, l + 1);
-    if (i == 1 || i == a.nx) fd_put(a, o, fd_rand(a.rand_mode, a.seed, c + 1) * a.hy * a.hz, l, l);
-    if (j < a.ny) fd_pair(a, o, fd_rand(a.rand_mode, a.seed, c + 2) * a.hx * a.hz / a.hy, l, l + a.nx);
-    if (a.ny > 2 && (j == 1 || j == a.ny))
-        fd_put(a, o, fd_rand(a.rand_mode, a.seed, c + 3) * a.hx * a.hz, l, l);
-    if (k < a.nz)
-        fd_pair(a, o, fd_rand(a.rand_mode, a.seed, c + 4) * a.hx * a.hy / a.hz, l, l + a.nx * a.ny);
-    if (a.nz > 2 && (k == 1 || k == a.nz))
-        fd_put(a, o, fd_rand(a.rand_mode, a.seed, c + 5) * a.hx * a.hy, l, l);
+    // stream position of the first node of this workgroup and of the next one
+    const i64 i0 = g0 % a.nx + 1, j0 = (g0 / a.nx) % a.ny + 1, k0 = g0 / (a.nx * a.ny) + 1;
+    const i64 off0 = fd_offset(a, i0, j0, k0, &cy, &cz);
+    if (g < N) {
+        const i64 i = g % a.nx + 1, j = (g / a.nx) % a.ny + 1, k = g / (a.nx * a.ny) + 1;
+        int o = (int)(fd_offset(a, i, j, k, &cy, &cz) - off0);
+        const i64 l = g + 1;
+        const u64 c = 6ull * (u64)g;
+        if (i < a.nx) fd_pair(a, lk, lv, o, fd_rand(a.rand_mode, a.seed, c + 0) * a.hy * a.hz / a.hx, l, l + 1);
+        if (i == 1 || i == a.nx) fd_put(a, lk, lv, o, fd_rand(a.rand_mode, a.seed, c + 1) * a.hy * a.hz, l, l);
+        if (j < a.ny) fd_pair(a, lk, lv, o, fd_rand(a.rand_mode, a.seed, c + 2) * a.hx * a.hz / a.hy, l, l + a.nx);
+        if (a.ny > 2 && (j == 1 || j == a.ny)) fd_put(a, lk, lv, o, fd_rand(a.rand_mode, a.seed, c + 3) * a.hx * a.hz, l, l);
+        if (k < a.nz) fd_pair(a, lk, lv, o, fd_rand(a.rand_mode, a.seed, c + 4) * a.hx * a.hy / a.hz, l, l + a.nx * a.ny);
+        if (a.nz > 2 && (k == 1 || k == a.nz)) fd_put(a, lk, lv, o, fd_rand(a.rand_mode, a.seed, c + 5) * a.hx * a.hy, l, l);
+    }
+    // total of the workgroup = position of the first node of the next workgroup (or the stream end)
+    i64 off1;
+    const i64 g1 = g0 + THREADS;
+    if (g1 >= N) {
+        off1 = a.total;
+    } else {
+        const i64 i1 = g1 % a.nx + 1, j1 = (g1 / a.nx) % a.ny + 1, k1 = g1 / (a.nx * a.ny) + 1;
+        off1 = fd_offset(a, i1, j1, k1, &cy, &cz);
+    }
+    const int cnt = (int)(off1 - off0);
+    __syncthreads();
+    // coalesced copy-out; 16-byte stores on the aligned body
+    u64 *gk = a.keys + off0;
+    double *gv = a.vals + off0;
+    const int head = (int)(((uintptr_t)gk >> 3) & 1);  // first element not 16-byte aligned
+    if (threadIdx.x == 0 && head && cnt > 0) {
+        gk[0] = lk[0];
+        gv[0] = lv[0];
+    }
+    const int npair = (cnt - head) >> 1;
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    ull2 *gk2 = reinterpret_cast<ull2 *>(gk + head);
+    dbl2 *gv2 = reinterpret_cast<dbl2 *>(gv + head);
+    for (int q = threadIdx.x; q < npair; q += THREADS) {
+        gk2[q] = ull2{lk[head + 2 * q], lk[head + 2 * q + 1]};
+        gv2[q] = dbl2{lv[head + 2 * q], lv[head + 2 * q + 1]};
+    }
+    if (threadIdx.x == 0 && ((cnt - head) & 1)) {
+        gk[cnt - 1] = lk[cnt - 1];
+        gv[cnt - 1] = lv[cnt - 1];
+    }
 }
 
 // ---- P1 FEM stream (test/femtools.jl:45-72) on a Kuhn-triangulated tensor grid --------

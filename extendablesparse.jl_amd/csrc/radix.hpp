@@ -62,14 +62,47 @@ __global__ __launch_bounds__(THREADS) void tile_hist_k(Pass p) {
     cnt[t] = 0;
     __syncthreads();
     const u32 mask = (1u << p.bits) - 1u;
-#pragma unroll 4
-    for (int k = 0; k < ITEMS; k++) {
-        i64 idx = beg + k * THREADS + t;
-        if (idx < end) atomicAdd(&cnt[(u32)(p.keys_in[idx] >> p.shift) & mask], 1u);
+    // 16-byte loads (two keys per lane; counting does not care about order), all loads of a
+    // thread in flight before the first count; a wave whose keys share one digit (the common
+    // case on pre-sorted streams) issues ONE LDS add per load instead of 64 conflicting ones
+    const i64 a0 = (beg + 1) & ~(i64)1;           // first 16-byte aligned key of the tile
+    const i64 a1 = end & ~(i64)1;
+    const i64 npair = a1 > a0 ? (a1 - a0) >> 1 : 0;
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+    const ull2 *pk = reinterpret_cast<const ull2 *>(p.keys_in + a0);
+    ull2 kk[ITEMS / 2];
+#pragma unroll
+    for (int k = 0; k < ITEMS / 2; k++) {
+        const i64 q = (i64)k * THREADS + t;
+        kk[k] = q < npair ? pk[q] : ull2{~0ull, ~0ull};
+    }
+    const int lane = t & 63;
+#pragma unroll
+    for (int k = 0; k < ITEMS / 2; k++) {
+        const bool valid = ((i64)k * THREADS + t) < npair;
+        const u32 dA = (u32)(kk[k].x >> p.shift) & mask, dB = (u32)(kk[k].y >> p.shift) & mask;
+        const u64 vm = __ballot(valid);
+        if (vm) {
+            const int fl = __builtin_ctzll(vm);
+            const u32 d0 = (u32)__shfl((int)dA, fl, ESP_WAVE);
+            const u64 same = __ballot(valid && dA == d0 && dB == d0);
+            if (same == vm) {
+                if (lane == fl) atomicAdd(&cnt[d0], 2u * (u32)__popcll(vm));
+            } else if (valid) {
+                atomicAdd(&cnt[dA], 1u);
+                atomicAdd(&cnt[dB], 1u);
+            }
+        }
+    }
+    if (t == 0) {  // unaligned head / tail keys
+        if (a0 > beg && beg < end) atomicAdd(&cnt[(u32)(p.keys_in[beg] >> p.shift) & mask], 1u);
+        if (a1 < end && a1 >= a0) atomicAdd(&cnt[(u32)(p.keys_in[a1] >> p.shift) & mask], 1u);
     }
     __syncthreads();
     const int R = 1 << p.bits;
-    if (t < R) p.hist[tf * R + (i64)t * nts + tin] = cnt[t];
+    // the histogram array is zeroed before the launch: only non-zero counts are stored (the
+    // digit-major layout makes every store its own cache line)
+    if (t < R && cnt[t] != 0) p.hist[tf * R + (i64)t * nts + tin] = cnt[t];
 }
 
 __global__ __launch_bounds__(THREADS, 2) void scatter_k(Pass p) {
@@ -96,29 +129,43 @@ __global__ __launch_bounds__(THREADS, 2) void scatter_k(Pass p) {
 #pragma unroll
     for (int i = 0; i < WAVES; i++) cnt[i][t] = 0;
 
-    // wave-striped arrangement: memory order == (wave, k, lane) order
+    // wave-striped arrangement: memory order == (wave, k, lane) order.  Keys AND values are
+    // loaded up front: 32 independent 8-byte loads per lane in flight (the kernel runs at two
+    // waves per SIMD, so the register file has room for them)
     u64 key[ITEMS];
+    double val[ITEMS];
     const i64 wbase = beg + (i64)w * (ESP_WAVE * ITEMS) + lane;
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
-        i64 idx = wbase + k * ESP_WAVE;
+        const i64 idx = wbase + k * ESP_WAVE;
         key[k] = idx < end ? p.keys_in[idx] : ~0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const i64 idx = wbase + k * ESP_WAVE;
+        val[k] = idx < end ? p.vals_in[idx] : 0.0;
     }
     __syncthreads();
 
-    // stable rank inside the wave by ballot matching
+    // stable rank inside the wave by ballot matching; one-digit waves skip the 8 ballots
     unsigned short rank[ITEMS];
     const u64 lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         const bool valid = (wbase + k * ESP_WAVE) < end;
         const u32 d = (u32)(key[k] >> p.shift) & mask;
-        u64 m = __ballot(valid);
+        const u64 vm = __ballot(valid);
+        u64 m = vm;
+        if (vm) {
+            const u32 d0 = (u32)__shfl((int)d, __builtin_ctzll(vm), ESP_WAVE);
+            if (__ballot(valid && d == d0) != vm) {
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const bool bit = (d >> b) & 1u;
-            const u64 bb = __ballot(bit);
-            m &= bit ? bb : ~bb;
+                for (int b = 0; b < 8; b++) {
+                    const bool bit = (d >> b) & 1u;
+                    const u64 bb = __ballot(bit);
+                    m &= bit ? bb : ~bb;
+                }
+            }
         }
         u32 prev = 0;
         if (valid) prev = cnt[w][d];
@@ -144,7 +191,7 @@ __global__ __launch_bounds__(THREADS, 2) void scatter_k(Pass p) {
     u32 blocktot;
     const u32 ds = espscan::block_exclusive<u32, false>(tot, lw, &blocktot);
     dstart[t] = ds;
-    if (t < R) goff[t] = (i64)p.hist[tf * R + (i64)t * nts + tin] - (i64)ds;
+    if (t < R && tot != 0) goff[t] = (i64)p.hist[tf * R + (i64)t * nts + tin] - (i64)ds;
     __syncthreads();
 
 #pragma unroll
@@ -154,7 +201,7 @@ __global__ __launch_bounds__(THREADS, 2) void scatter_k(Pass p) {
             const u32 d = (u32)(key[k] >> p.shift) & mask;
             const u32 slot = dstart[d] + cnt[w][d] + rank[k];
             lkeys[slot] = key[k];
-            lvals[slot] = p.vals_in[idx];
+            lvals[slot] = val[k];
         }
     }
     __syncthreads();

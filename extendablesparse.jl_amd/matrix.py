@@ -272,11 +272,11 @@ class ExtendableSparseMatrix:
             self._d = _Handle(csc.m, csc.n, device, capacity_hint)
             self._d.set_csc(csc)
             self.m, self.n = csc.m, csc.n
-            self.phash = self._pattern_hash()
+            self._phash = None  # phash(csc), evaluated on first use
         else:
             self._d = _Handle(m, n, device, capacity_hint)
             self.m, self.n = int(m), int(n)
-            self.phash = 0  # extendable.jl:40
+            self._phash = 0  # extendable.jl:40
         self._host = None
 
     @property
@@ -284,6 +284,14 @@ class ExtendableSparseMatrix:
         return (self.m, self.n)
 
     size = shape
+
+    @property
+    def phash(self):
+        """ext.phash (extendable.jl:24): recomputed after every structural flush! (:252).  The hash
+        kernel runs on first use after such a flush instead of inside flush! (same value)."""
+        if self._phash is None:
+            self._phash = self._pattern_hash()
+        return self._phash
 
     def _pattern_hash(self):
         hsh = C.c_uint64()
@@ -327,7 +335,7 @@ class ExtendableSparseMatrix:
             self._touch()
             _, changed = self._d.flush(ESP_FLUSH_ROUTED)
             if changed:
-                self.phash = self._pattern_hash()  # extendable.jl:252
+                self._phash = None  # extendable.jl:252 (evaluated lazily by the phash property)
         return self
 
     def sparse(self):  # extendable.jl:258-261: host-visible SparseMatrixCSC
