@@ -60,6 +60,8 @@ SIGNATURES = {
     "esp_append_packed": (i32, [vp, vp, vp, i64]),
     "esp_generate_fdrand": (i32, [vp, i64, i64, i64, u64, i32, i32]),
     "esp_generate_fem": (i32, [vp, i32, i64, u64, i32]),
+    "esp_generate_fdrand_range": (i32, [vp, i64, i64, i64, u64, i32, i32, i64, i64]),
+    "esp_set_column_window": (i32, [vp, i64, i64]),
     "esp_pending": (i32, [vp, P(i64)]),
     "esp_set_csc": (i32, [vp, vp, vp, vp, i64]),
     "esp_flush": (i32, [vp, i32, P(i64), P(i32)]),

@@ -41,6 +41,8 @@ struct esp_handle {
     // ping-pong / scratch
     DevBuf keys2, vals2, hist, segs, colend, newkey, newval, heads, misc, seg[2], tilef[2], segcnt, segout;
     int force_path = 0, last_path = 0;
+    // column window of the pending entries (whole matrix by default)
+    u64 win_base = 0, win_span = 0;
     // device CSC (Julia layout) + spare set for rebuilds
     DevBuf colptr, rowval, nzval, rowval2, nzval2;
     i64 nnz = 0;
@@ -208,6 +210,8 @@ extern "C" int32_t esp_create(int64_t m, int64_t n, int32_t device, int64_t capa
     h->n = n;
     h->device = device;
     h->L = KeyLayout{rb, cb};
+    h->win_base = 0;
+    h->win_span = (u64)std::max<i64>(n, 1) << rb;
     memset(&h->acc, 0, sizeof h->acc);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
@@ -450,18 +454,39 @@ extern "C" int32_t esp_append_packed(esp_handle *h, const uint64_t *d_keys, cons
     return ESP_OK;
 }
 
-extern "C" int32_t esp_generate_fdrand(esp_handle *h, int64_t nx, int64_t ny, int64_t nz, uint64_t seed,
-                                       int32_t rand_mode, int32_t kind) {
+// stream position of node g (0-based) in the k,j,i loop nest: host copy of espgen::fd_offset
+static i64 fd_offset_host(i64 nx, i64 ny, i64 nz, i64 g) {
+    const i64 N = nx * ny * nz;
+    if (g >= N) {
+        i64 E = 4 * (nx - 1) * ny * nz + (nx == 1 ? 1 : 2) * ny * nz;
+        E += 4 * nx * (ny - 1) * nz + (ny > 2 ? 2 * nx * nz : 0);
+        E += 4 * nx * ny * (nz - 1) + (nz > 2 ? 2 * nx * ny : 0);
+        return E;
+    }
+    const i64 i = g % nx + 1, j = (g / nx) % ny + 1, k = g / (nx * ny) + 1;
+    const i64 CX = 4 * (nx - 1) + (nx == 1 ? 1 : 2);
+    const i64 CY = 4 * (ny - 1) + (ny > 2 ? 2 : 0);
+    const i64 PX = 4 * (i - 1) + (i > 1 ? 1 : 0);
+    const i64 PY = 4 * (j - 1) + ((ny > 2 && j > 1) ? 1 : 0);
+    const i64 PZ = 4 * (k - 1) + ((nz > 2 && k > 1) ? 1 : 0);
+    const i64 cy = (j < ny ? 4 : 0) + ((ny > 2 && (j == 1 || j == ny)) ? 1 : 0);
+    const i64 cz = (k < nz ? 4 : 0) + ((nz > 2 && (k == 1 || k == nz)) ? 1 : 0);
+    return (k - 1) * (ny * CX + nx * CY) + nx * ny * PZ + (j - 1) * CX + nx * PY + (j - 1) * nx * cz + PX + (i - 1) * (cy + cz);
+}
+
+extern "C" int32_t esp_generate_fdrand_range(esp_handle *h, int64_t nx, int64_t ny, int64_t nz, uint64_t seed, int32_t rand_mode,
+                                             int32_t kind, int64_t node_begin, int64_t node_end) {
     if (!h) return ESP_ERR_INVALID;
     if (nx < 1 || ny < 1 || nz < 1) FAIL(h, ESP_ERR_INVALID, "fdrand: bad grid");
     const i64 N = nx * ny * nz;
     if (h->m != N || h->n != N) FAIL(h, ESP_ERR_INVALID, "Matrix size mismatch");  // sprand.jl:66-68
     if (kind != ESP_UPDATE && kind != ESP_RAWUPDATE) FAIL(h, ESP_ERR_INVALID, "fdrand: kind must be UPDATE or RAWUPDATE");
     if (rand_mode < 0 || rand_mode > 2) FAIL(h, ESP_ERR_INVALID, "fdrand: rand_mode");
+    if (node_begin < 0 || node_end > N || node_begin > node_end) FAIL(h, ESP_ERR_INVALID, "fdrand: node range");
+    if (node_begin == node_end) return ESP_OK;
     (void)hipSetDevice(h->device);
-    i64 E = 4 * (nx - 1) * ny * nz + (nx == 1 ? 1 : 2) * ny * nz;
-    E += 4 * nx * (ny - 1) * nz + (ny > 2 ? 2 * nx * nz : 0);
-    E += 4 * nx * ny * (nz - 1) + (nz > 2 ? 2 * nx * ny : 0);
+    const i64 off_b = fd_offset_host(nx, ny, nz, node_begin);
+    const i64 E = fd_offset_host(nx, ny, nz, node_end) - off_b;
     CK(reserve_append(h, E));
     espgen::FdArgs a;
     a.nx = nx;
@@ -474,17 +499,37 @@ extern "C" int32_t esp_generate_fdrand(esp_handle *h, int64_t nx, int64_t ny, in
     a.rand_mode = rand_mode;
     a.kind = kind;
     a.total = E;
+    a.g_begin = node_begin;
+    a.g_end = node_end;
+    a.off_begin = off_b;
     a.L = h->L;
     a.keys = (u64 *)h->keys.p + h->count;
     a.vals = (double *)h->vals.p + h->count;
     {
         Span sp(h, ESP_ST_APPEND);
-        hipLaunchKernelGGL(espgen::fdrand_k, dim3(grid_for(N, espgen::THREADS)), dim3(espgen::THREADS), 0, h->stream, a);
+        hipLaunchKernelGGL(espgen::fdrand_k, dim3(grid_for(node_end - node_begin, espgen::THREADS)), dim3(espgen::THREADS), 0, h->stream, a);
         sp.add(1);
     }
     HIPCK(h, hipGetLastError());
     h->count += E;
     h->shard_valid = false;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_generate_fdrand(esp_handle *h, int64_t nx, int64_t ny, int64_t nz, uint64_t seed,
+                                       int32_t rand_mode, int32_t kind) {
+    if (!h) return ESP_ERR_INVALID;
+    return esp_generate_fdrand_range(h, nx, ny, nz, seed, rand_mode, kind, 0, nx * ny * nz);
+}
+
+// All pending entries of the following flushes have their column in [col_lo, col_hi] (1-based).
+// The radix partition then spends its bits on that window only (a column shard after the
+// exchange).  Entries outside the window make esp_flush return ESP_ERR_STATE.
+extern "C" int32_t esp_set_column_window(esp_handle *h, int64_t col_lo, int64_t col_hi) {
+    if (!h) return ESP_ERR_INVALID;
+    if (col_lo < 1 || col_hi > h->n || col_lo > col_hi) FAIL(h, ESP_ERR_INVALID, "column window [%lld,%lld] outside 1..%lld", (long long)col_lo, (long long)col_hi, (long long)h->n);
+    h->win_base = (u64)(col_lo - 1) << h->L.rb;
+    h->win_span = (u64)(col_hi - col_lo + 1) << h->L.rb;
     return ESP_OK;
 }
 
@@ -709,6 +754,7 @@ static int32_t sort_pending_lsd(esp_handle *h, const u64 **sk, const double **sv
     CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
     CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
     CK(ensure(h, h->segs, sizeof(i64) * 8));
+    CK(ensure(h, h->misc, 256));
     const i64 T = ceil_div<i64>(E, espradix::TILE);
     i64 *segs = (i64 *)h->segs.p;
     hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, segs, (i64)0, E, (i64)0, T);
@@ -724,7 +770,13 @@ static int32_t sort_pending_lsd(esp_handle *h, const u64 **sk, const double **sv
         p.seg_start = segs;
         p.tile_first = segs + 2;
         p.S = 1;
-        p.shift = ESP_TAG_BITS + done;
+        p.owner_P = 0;
+        p.owner_n = 1;
+        p.colshift = 0;
+        p.base = 0;
+        p.span = ~0ull;
+        p.err = (u32 *)h->misc.p + 60;
+        p.shift = done;
         p.bits = std::min(8, K - done);
         CK(partition_pass(h, p, T));
         std::swap(kin, kout);
@@ -759,11 +811,15 @@ struct Sorted {
 
 static int32_t sort_msd(esp_handle *h, Sorted *out) {
     const i64 E = h->count;
-    const int K = h->L.sort_bits();
+    // sort bits of the key window: (key>>2) - win_base lies in [0, win_span)
+    int K = 1;
+    while (K < 62 && ((u64)1 << K) < h->win_span) K++;
     CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
     CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
     CK(ensure(h, h->misc, 256));
     unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
+    u32 *d_werr = (u32 *)h->misc.p + 60;
+    HIPCK(h, hipMemsetAsync(d_werr, 0, 4, h->stream));
 
     int planned = 0;
     if (E > esplocal::CAP) {
@@ -804,8 +860,14 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
         p.seg_start = (const i64 *)h->seg[cur].p;
         p.tile_first = (const i64 *)h->tilef[cur].p;
         p.S = S;
+        p.owner_P = 0;
+        p.owner_n = 1;
+        p.colshift = 0;
+        p.base = h->win_base;
+        p.span = h->win_span;
+        p.err = d_werr;
         p.bits = bits;
-        p.shift = ESP_TAG_BITS + K - done - bits;
+        p.shift = K - done - bits;
         const i64 max_tiles = S == 1 ? T : T + S;
         CK(partition_pass(h, p, max_tiles));
         const int S2 = S << bits;
@@ -834,6 +896,11 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
         }
     }
     HIPCK(h, hipGetLastError());
+    if (pass_idx > 0) {  // the partition passes clamp and report keys outside the window
+        HIPCK(h, hipMemcpyAsync(h->pin_scalar + 2, d_werr, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        if ((u32)h->pin_scalar[2]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window");
+    }
     out->sk = kin;
     out->sv = vin;
     out->in_primary = (kin == (u64 *)h->keys.p);
@@ -936,6 +1003,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         a.seg_start = st.seg_start;
         a.S = S;
         a.rem_bits = st.rem_bits;
+        a.base = h->win_base;
         a.rb = h->L.rb;
         {
             const int clb = st.rem_bits - h->L.rb;
@@ -963,9 +1031,12 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         sp.add(1);
     }
     HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (S - 1), 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar + 2, (u32 *)h->misc.p + 60, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
+    if ((u32)h->pin_scalar[2]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window");
     const u32 lookback_err = (u32)(h->pin_scalar[1] >> 32);
-    if (lookback_err) FAIL(h, ESP_ERR_HIP, "esp_flush: look-back chain timed out inside the bucket kernel");
+    if (lookback_err & 2u) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window");
+    if (lookback_err & 1u) FAIL(h, ESP_ERR_HIP, "esp_flush: look-back chain timed out inside the bucket kernel");
     const i64 Zn = (i64)(h->pin_scalar[0] & esplocal::ST_VAL);
     *Zn_out = Zn;
     if (a.stop_after || Zn == 0) return ESP_OK;
@@ -1081,18 +1152,101 @@ extern "C" int32_t esp_debug_last_path(const esp_handle *h, int32_t *path) {
 }
 
 // ------------------------------------------------------------------------ shards
-extern "C" int32_t esp_shard_counts(esp_handle *h, int32_t nshards, int64_t *counts) {
-    (void)h;
-    (void)nshards;
-    (void)counts;
-    FAIL(h, ESP_ERR_UNSUPPORTED, "esp_shard_counts: not built yet");
+// Column-range shards: owner(col) = floor((col-1)*P/n).  Both calls share one
+// histogram + scan of the pending entries by owner; the export is one stable partition pass, so
+// every destination receives its entries in this shard's append order.
+static int32_t shard_prepare(esp_handle *h, int P, espradix::Pass *out) {
+    if (P < 1 || P > 256) FAIL(h, ESP_ERR_INVALID, "shards: nshards must be in 1..256");
+    if ((double)h->n * (double)P >= 9.0e18) FAIL(h, ESP_ERR_UNSUPPORTED, "shards: n*nshards overflows");
+    const i64 E = h->count;
+    int bits = 1;
+    while ((1 << bits) < P) bits++;
+    const i64 T = std::max<i64>(1, ceil_div<i64>(E, espradix::TILE));
+    CK(ensure(h, h->seg[0], sizeof(i64) * 4));
+    CK(ensure(h, h->tilef[0], sizeof(u64) * (size_t)(4 + espscan::workspace_elems(4))));
+    espradix::Pass p;
+    p.keys_in = (const u64 *)h->keys.p;
+    p.vals_in = (const double *)h->vals.p;
+    p.keys_out = nullptr;
+    p.vals_out = nullptr;
+    p.seg_start = (const i64 *)h->seg[0].p;
+    p.tile_first = (const i64 *)h->tilef[0].p;
+    p.S = 1;
+    p.shift = 0;
+    p.bits = bits;
+    p.base = 0;
+    p.span = ~0ull;
+    p.err = nullptr;
+    p.owner_P = P;
+    p.owner_n = h->n;
+    p.colshift = ESP_TAG_BITS + h->L.rb;
+    const int R = 1 << bits;
+    const i64 hn = T * R;
+    CK(ensure(h, h->hist, sizeof(u64) * (size_t)(hn + espscan::workspace_elems(hn))));
+    p.hist = (u64 *)h->hist.p;
+    if (!(h->shard_valid && h->shard_P == P)) {
+        hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, (i64 *)h->seg[0].p, (i64)0, E, (i64)0, (i64)0);
+        hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, (i64 *)h->tilef[0].p, (i64)0, ceil_div<i64>(E, espradix::TILE), (i64)0, (i64)0);
+        HIPCK(h, hipMemsetAsync(p.hist, 0, sizeof(u64) * (size_t)hn, h->stream));
+        if (E > 0) {
+            Span sp(h, ESP_ST_HIST);
+            hipLaunchKernelGGL(espradix::tile_hist_k, dim3((unsigned)T), dim3(espradix::THREADS), 0, h->stream, p);
+            sp.add(1);
+        }
+        {
+            Span sp(h, ESP_ST_SCAN);
+            sp.add(espscan::exclusive<u64, false>(h->stream, p.hist, p.hist, hn, p.hist + hn));
+        }
+        // owner offsets = scanned value of (digit, tile 0); R+1 entries into seg[1]
+        CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(R + 1)));
+        hipLaunchKernelGGL(espradix::new_segments_k, dim3(grid_for(R + 1, 256)), dim3(256), 0, h->stream, (const u64 *)p.hist,
+                           (const i64 *)h->seg[0].p, (const i64 *)h->tilef[0].p, 1, bits, (i64 *)h->seg[1].p, E);
+        HIPCK(h, hipGetLastError());
+        h->shard_valid = true;
+        h->shard_P = P;
+    }
+    *out = p;
+    return ESP_OK;
 }
+
+static int32_t shard_offsets(esp_handle *h, int P, int64_t *offsets /* P+1 */) {
+    std::vector<i64> tmp((size_t)P + 1);
+    HIPCK(h, hipMemcpyAsync(tmp.data(), h->seg[1].p, sizeof(i64) * (size_t)(P + 1), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    for (int d = 0; d <= P; d++) offsets[d] = tmp[(size_t)d];
+    offsets[P] = h->count;  // digits >= P never occur
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_shard_counts(esp_handle *h, int32_t nshards, int64_t *counts) {
+    if (!h || !counts) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    espradix::Pass p;
+    CK(shard_prepare(h, nshards, &p));
+    std::vector<int64_t> off((size_t)nshards + 1);
+    CK(shard_offsets(h, nshards, off.data()));
+    for (int d = 0; d < nshards; d++) counts[d] = off[(size_t)d + 1] - off[(size_t)d];
+    return ESP_OK;
+}
+
 extern "C" int32_t esp_shard_export(esp_handle *h, int32_t nshards, uint64_t *d_keys, double *d_vals, int64_t *offsets) {
-    (void)nshards;
-    (void)d_keys;
-    (void)d_vals;
-    (void)offsets;
-    FAIL(h, ESP_ERR_UNSUPPORTED, "esp_shard_export: not built yet");
+    if (!h || !offsets) return ESP_ERR_INVALID;
+    if (h->count > 0 && (!d_keys || !d_vals)) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    espradix::Pass p;
+    CK(shard_prepare(h, nshards, &p));
+    CK(shard_offsets(h, nshards, offsets));
+    if (h->count > 0) {
+        p.keys_out = (u64 *)d_keys;
+        p.vals_out = d_vals;
+        Span sp(h, ESP_ST_SCATTER);
+        hipLaunchKernelGGL(espradix::scatter_k, dim3((unsigned)ceil_div<i64>(h->count, espradix::TILE)), dim3(espradix::THREADS), 0,
+                           h->stream, p);
+        sp.add(1);
+        HIPCK(h, hipGetLastError());
+        HIPCK(h, hipStreamSynchronize(h->stream));
+    }
+    return ESP_OK;
 }
 
 // ------------------------------------------------------------------------ measurement

@@ -41,7 +41,9 @@ struct FdArgs {
     u64 seed;
     int rand_mode;
     int kind;
-    i64 total;  // number of updates of the whole stream
+    i64 total;  // number of updates of the generated node range
+    i64 g_begin, g_end;  // node range [g_begin, g_end) (0-based l-1) of the loop nest
+    i64 off_begin;       // stream position of node g_begin
     KeyLayout L;
     u64 *keys;
     double *vals;
@@ -92,16 +94,16 @@ __device__ __forceinline__ void fd_pair(const FdArgs &a, u64 *lk, double *lv, in
 __global__ __launch_bounds__(THREADS) void fdrand_k(FdArgs a) {
     __shared__ u64 lk[THREADS * FD_MAX_PER_NODE];
     __shared__ double lv[THREADS * FD_MAX_PER_NODE];
-    const i64 N = a.nx * a.ny * a.nz;
-    const i64 g0 = (i64)blockIdx.x * THREADS;
+    const i64 N = a.g_end;
+    const i64 g0 = a.g_begin + (i64)blockIdx.x * THREADS;
     const i64 g = g0 + threadIdx.x;  // node l-1
     i64 cy, cz;
     // stream position of the first node of this workgroup and of the next one
     const i64 i0 = g0 % a.nx + 1, j0 = (g0 / a.nx) % a.ny + 1, k0 = g0 / (a.nx * a.ny) + 1;
-    const i64 off0 = fd_offset(a, i0, j0, k0, &cy, &cz);
+    const i64 off0 = fd_offset(a, i0, j0, k0, &cy, &cz) - a.off_begin;
     if (g < N) {
         const i64 i = g % a.nx + 1, j = (g / a.nx) % a.ny + 1, k = g / (a.nx * a.ny) + 1;
-        int o = (int)(fd_offset(a, i, j, k, &cy, &cz) - off0);
+        int o = (int)(fd_offset(a, i, j, k, &cy, &cz) - a.off_begin - off0);
         const i64 l = g + 1;
         const u64 c = 6ull * (u64)g;
         if (i < a.nx) fd_pair(a, lk, lv, o, fd_rand(a.rand_mode, a.seed, c + 0) * a.hy * a.hz / a.hx, l, l + 1);
@@ -118,7 +120,7 @@ __global__ __launch_bounds__(THREADS) void fdrand_k(FdArgs a) {
         off1 = a.total;
     } else {
         const i64 i1 = g1 % a.nx + 1, j1 = (g1 / a.nx) % a.ny + 1, k1 = g1 / (a.nx * a.ny) + 1;
-        off1 = fd_offset(a, i1, j1, k1, &cy, &cz);
+        off1 = fd_offset(a, i1, j1, k1, &cy, &cz) - a.off_begin;
     }
     const int cnt = (int)(off1 - off0);
     __syncthreads();

@@ -81,6 +81,7 @@ struct Args {
     const i64 *seg_start;  // S+1
     int S;
     int rem_bits;  // key bits below the partition prefix (col/row bits, without the kind bits)
+    u64 base;      // key window base: keys are sorted as (key>>2) - base
     int rb;
     int cl_bits;  // local column bits (rem_bits - rb) when 0..CL_MAX_BITS, else -1: radix tail only
     int col_aligned;  // a segment is a whole number of columns (column-end marks need no atomics)
@@ -198,7 +199,8 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     const i64 beg = a.seg_start[s];
     const int n = (int)(a.seg_start[s + 1] - beg);
     const u64 submask = a.rem_bits >= 64 ? ~0ull : ((1ull << a.rem_bits) - 1ull);
-    const u64 hi = n > 0 ? (((a.keys_in[beg] >> ESP_TAG_BITS) >> a.rem_bits) << a.rem_bits) : 0;  // shared prefix
+    // shared prefix of the segment (window-relative), turned back into an absolute key prefix
+    const u64 hi = n > 0 ? (((((a.keys_in[beg] >> ESP_TAG_BITS) - a.base) >> a.rem_bits) << a.rem_bits) + a.base) : 0;
     const int wbase = w * (ITEMS * ESP_WAVE) + lane;
     const u64 lt = (1ull << lane) - 1ull;
     const u64 rowmask = (1ull << a.rb) - 1ull;
@@ -210,7 +212,11 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         if (p < n) {
             const u64 key = a.keys_in[beg + p];
             sval[p] = a.vals_in[beg + p];
-            k[i] = (((key >> ESP_TAG_BITS) & submask) << SUB_SHIFT) | ((u64)p << ESP_TAG_BITS) | (key & ESP_TAG_MASK);
+            const u64 kn = (key >> ESP_TAG_BITS) - a.base;
+            // every entry of a segment shares the segment's prefix; anything else is an entry outside
+            // the declared key window (reported to the host, which rejects the flush)
+            if (((kn >> a.rem_bits) << a.rem_bits) + a.base != hi) atomicOr(a.err, 2u);
+            k[i] = ((kn & submask) << SUB_SHIFT) | ((u64)p << ESP_TAG_BITS) | (key & ESP_TAG_MASK);
         } else {
             k[i] = NOREC;  // sorts behind every real entry (stable: real entries come first on ties)
         }
@@ -311,7 +317,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
                                 idx0 = (u32)(kj >> ESP_TAG_BITS) & (CAP - 1);
                                 pos = -1;
                                 if (a.csc.nnz > 0) {
-                                    const u64 full = hi | sub;
+                                    const u64 full = hi + sub;
                                     pos = espfold::csc_find(a.csc, (i64)(full >> a.rb), (i64)(full & rowmask));
                                 }
                                 present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
                         const u32 idx0 = (u32)(kj >> ESP_TAG_BITS) & (CAP - 1);
                         i64 pos = -1;
                         if (a.csc.nnz > 0) {
-                            const u64 full = hi | sub;
+                            const u64 full = hi + sub;
                             pos = espfold::csc_find(a.csc, (i64)(full >> a.rb), (i64)(full & rowmask));
                         }
                         bool present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
@@ -386,7 +392,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
                 const u64 sub = k[i] >> SUB_SHIFT;
                 const bool head = q == 0 || (skey[q - 1] >> SUB_SHIFT) != sub;
                 if (head) {
-                    const u64 full = hi | sub;
+                    const u64 full = hi + sub;
                     i64 pos = -1;
                     if (a.csc.nnz > 0) pos = espfold::csc_find(a.csc, (i64)(full >> a.rb), (i64)(full & rowmask));
                     bool present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
@@ -491,7 +497,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
                     __builtin_amdgcn_s_sleep(2);
                 }
             }
-            if (fail && lane == 0) atomicExch(a.err, 1u);
+            if (fail && lane == 0) atomicOr(a.err, 1u);
             if (lane == 0)
                 __hip_atomic_store(&a.status[s], ST_PRE | ((excl + (u64)total) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -509,7 +515,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         const u64 bal = __ballot(rec[i] != NOREC);
         if (rec[i] != NOREC) {
             const u32 e = gcount[w * ITEMS + i] + (u32)__popcll(bal & lt);
-            skey[e] = hi | (rec[i] >> SUB_SHIFT);
+            skey[e] = hi + (rec[i] >> SUB_SHIFT);
             sval[e] = rv[i];
         }
     }

@@ -29,10 +29,28 @@ struct Pass {
     const i64 *seg_start;   // S+1 entry offsets (device)
     const i64 *tile_first;  // S+1 first tile of each segment (device)
     int S;
-    int shift;  // digit = (key >> shift) & ((1<<bits)-1)
+    int shift;  // digit = (((key >> 2) - base) >> shift) & ((1<<bits)-1)
+    u64 base;   // key window: every (col,row) key lies in [base, base+span)
+    u64 span;
+    u32 *err;   // set when a key falls outside the window (digit clamped, no stray access)
     int bits;   // 1..8
+    // owner mode (column-range shards): digit = floor(col0 * owner_P / owner_n), col0 = key >> colshift
+    int owner_P;
+    i64 owner_n;
+    int colshift;
     u64 *hist;  // [tile_first[s]*R + d*ntiles_s + tile_in_seg]; scanned in place
 };
+
+// CHECK: report keys outside the window (the histogram kernel sees every key of a pass with the
+// same parameters, so the scatter kernel only clamps)
+template <bool CHECK>
+__device__ __forceinline__ u32 digit_of(const Pass &p, u64 key, u32 mask) {
+    if (p.owner_P) return (u32)(((key >> p.colshift) * (u64)p.owner_P) / (u64)p.owner_n);
+    u64 kn = (key >> ESP_TAG_BITS) - p.base;
+    if (CHECK && kn >= p.span) *p.err = 1u;
+    kn = kn < p.span ? kn : p.span - 1;
+    return (u32)(kn >> p.shift) & mask;
+}
 
 // largest s with tile_first[s] <= tile, or -1 when tile is past the last segment
 __device__ __forceinline__ int find_segment(const i64 *__restrict__ tile_first, int S, i64 tile) {
@@ -80,7 +98,7 @@ __global__ __launch_bounds__(THREADS) void tile_hist_k(Pass p) {
 #pragma unroll
     for (int k = 0; k < ITEMS / 2; k++) {
         const bool valid = ((i64)k * THREADS + t) < npair;
-        const u32 dA = (u32)(kk[k].x >> p.shift) & mask, dB = (u32)(kk[k].y >> p.shift) & mask;
+        const u32 dA = valid ? digit_of<true>(p, kk[k].x, mask) : 0u, dB = valid ? digit_of<true>(p, kk[k].y, mask) : 0u;
         const u64 vm = __ballot(valid);
         if (vm) {
             const int fl = __builtin_ctzll(vm);
@@ -95,8 +113,8 @@ __global__ __launch_bounds__(THREADS) void tile_hist_k(Pass p) {
         }
     }
     if (t == 0) {  // unaligned head / tail keys
-        if (a0 > beg && beg < end) atomicAdd(&cnt[(u32)(p.keys_in[beg] >> p.shift) & mask], 1u);
-        if (a1 < end && a1 >= a0) atomicAdd(&cnt[(u32)(p.keys_in[a1] >> p.shift) & mask], 1u);
+        if (a0 > beg && beg < end) atomicAdd(&cnt[digit_of<true>(p, p.keys_in[beg], mask)], 1u);
+        if (a1 < end && a1 >= a0) atomicAdd(&cnt[digit_of<true>(p, p.keys_in[a1], mask)], 1u);
     }
     __syncthreads();
     const int R = 1 << p.bits;
@@ -112,6 +130,7 @@ __global__ __launch_bounds__(THREADS, 2) void scatter_k(Pass p) {
     __shared__ u32 dstart[RADIX];
     __shared__ i64 goff[RADIX];
     __shared__ u32 lw[WAVES];
+    __shared__ unsigned char ldig[TILE];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const i64 tile = blockIdx.x;
@@ -149,11 +168,13 @@ __global__ __launch_bounds__(THREADS, 2) void scatter_k(Pass p) {
 
     // stable rank inside the wave by ballot matching; one-digit waves skip the 8 ballots
     unsigned short rank[ITEMS];
+    unsigned char dig[ITEMS];
     const u64 lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         const bool valid = (wbase + k * ESP_WAVE) < end;
-        const u32 d = (u32)(key[k] >> p.shift) & mask;
+        const u32 d = valid ? digit_of<false>(p, key[k], mask) : 0u;
+        dig[k] = (unsigned char)d;
         const u64 vm = __ballot(valid);
         u64 m = vm;
         if (vm) {
@@ -198,10 +219,11 @@ __global__ __launch_bounds__(THREADS, 2) void scatter_k(Pass p) {
     for (int k = 0; k < ITEMS; k++) {
         const i64 idx = wbase + k * ESP_WAVE;
         if (idx < end) {
-            const u32 d = (u32)(key[k] >> p.shift) & mask;
+            const u32 d = dig[k];
             const u32 slot = dstart[d] + cnt[w][d] + rank[k];
             lkeys[slot] = key[k];
             lvals[slot] = val[k];
+            ldig[slot] = dig[k];
         }
     }
     __syncthreads();
@@ -210,7 +232,7 @@ __global__ __launch_bounds__(THREADS, 2) void scatter_k(Pass p) {
         const int slot = t + j * THREADS;
         if (slot < ntile) {
             const u64 kk = lkeys[slot];
-            const u32 d = (u32)(kk >> p.shift) & mask;
+            const u32 d = ldig[slot];
             const i64 dst = goff[d] + slot;
             p.keys_out[dst] = kk;
             p.vals_out[dst] = lvals[slot];

@@ -389,6 +389,15 @@ class ExtendableSparseMatrix:
         self._d.commit()
         self._d.ck(self._d.lib.esp_generate_fdrand(self._d.h, nx, ny, nz, seed, rand_mode, kind))
 
+    def generate_fdrand_range(self, nx, ny, nz, node_begin, node_end, seed=0x5EED0002, rand_mode=1, kind=ESP_UPDATE):
+        """The updates issued by nodes [node_begin, node_end) (0-based) of the fdrand! loop nest."""
+        self._touch()
+        self._d.commit()
+        self._d.ck(self._d.lib.esp_generate_fdrand_range(self._d.h, nx, ny, nz, seed, rand_mode, kind, node_begin, node_end))
+
+    def set_column_window(self, col_lo, col_hi):
+        self._d.ck(self._d.lib.esp_set_column_window(self._d.h, col_lo, col_hi))
+
     def generate_fem(self, dim, npd, seed=0x5EED0004, order_mode=1):
         """The update stream of testassemble! (test/femtools.jl:45-72) produced on the device."""
         self._touch()

@@ -1,0 +1,190 @@
+"""Column-range sharded assembly across the GPUs of one node.
+
+One process per GPU (torch.distributed; backend "nccl" is RCCL over xGMI on ROCm).  Every rank
+appends whatever updates its part of the assembly loop produces -- like one reference buffer per
+`tid` (src/matrix/genericmtextendablesparsematrixcsc.jl:87-99) -- and flush! routes every pending
+entry to the rank that owns its column with ONE all-to-all-v before the local flush:
+
+    owner(col) = floor((col-1) * P / n)                      contiguous column ranges
+    1. stable partition of the pending entries by owner       (esp_shard_export, HIP)
+    2. all_to_all_single of the per-destination counts        (P x 8 B)
+    3. all_to_all_single of the 8-byte keys and 8-byte values (RCCL; per link: bytes_to_peer/153 GB/s)
+    4. local flush of the received entries                    (same kernels as the 1-GPU path)
+    5. all_gather of the local nnz -> colptr offsets of the global CSC
+
+Received chunks are ordered by source rank and keep the source's append order, so the ordered
+fold stays deterministic: the result equals ONE buffer fed the streams of rank 0, 1, ... in turn.
+
+The exchange logic is independent of where the entries live: `backend` supplies the local
+operations.  HipShardBackend is the product (device memory, C ABI); tests drive the same class
+with a CPU backend over gloo.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib as L
+from ._lib import ESP_FLUSH_ROUTED
+from .matrix import ExtendableSparseMatrix, SparseMatrixCSC
+
+
+def owner_ranges(n, P):
+    """0-based column range [c0,c1) of every shard: owner(col0) = floor(col0*P/n)."""
+    bounds = [-(-r * n // P) for r in range(P + 1)]  # ceil(r*n/P)
+    return [(bounds[r], bounds[r + 1]) for r in range(P)]
+
+
+class HipShardBackend:
+    """Local operations of one shard on its GPU, through the C ABI."""
+
+    def __init__(self, m, n, device=0, capacity_hint=0):
+        import torch
+        self.torch = torch
+        self.device = torch.device("cuda", device)
+        self.A = ExtendableSparseMatrix(m, n, device=device, capacity_hint=capacity_hint)
+        self.m, self.n = int(m), int(n)
+
+    @property
+    def matrix(self):
+        return self.A
+
+    def pending(self):
+        return self.A.nnznew()
+
+    def empty(self, count, dtype):
+        return self.torch.empty(int(count), dtype=dtype, device=self.device)
+
+    def shard_counts(self, P):
+        d = self.A._d
+        d.commit()
+        counts = np.zeros(P, np.int64)
+        d.ck(d.lib.esp_shard_counts(d.h, P, counts.ctypes.data_as(C.c_void_p)))
+        return counts
+
+    def shard_export(self, P):
+        torch = self.torch
+        d = self.A._d
+        d.commit()
+        E = d.pending()
+        keys = torch.empty(E, dtype=torch.int64, device=self.device)
+        vals = torch.empty(E, dtype=torch.float64, device=self.device)
+        offsets = np.zeros(P + 1, np.int64)
+        d.ck(d.lib.esp_shard_export(d.h, P, C.c_void_p(keys.data_ptr()), C.c_void_p(vals.data_ptr()),
+                                    offsets.ctypes.data_as(C.c_void_p)))
+        return keys, vals, offsets
+
+    def replace_pending(self, keys, vals):
+        d = self.A._d
+        self.torch.cuda.synchronize(self.device)  # the collective ran on torch's stream
+        d.ck(d.lib.esp_clear_pending(d.h))
+        if keys.numel():
+            d.ck(d.lib.esp_append_packed(d.h, C.c_void_p(keys.data_ptr()), C.c_void_p(vals.data_ptr()), keys.numel()))
+            d.ck(d.lib.esp_synchronize(d.h))  # the copy is done before the tensors may be freed
+        self.A._touch()
+
+    def set_column_window(self, col_lo, col_hi):
+        self.A.set_column_window(col_lo, col_hi)
+
+    def flush(self):
+        self.A.flush()
+        return self.A._d.nnz()
+
+    def local_csc(self):
+        return self.A.sparse()
+
+
+class ShardedExtendableSparseMatrix:
+    """ExtendableSparseMatrix whose columns are sharded over the ranks of a process group."""
+
+    def __init__(self, m, n, backend, group=None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.P = dist.get_world_size(group)
+        self.m, self.n = int(m), int(n)
+        self.backend = backend
+        self.ranges = owner_ranges(self.n, self.P)
+        self.local_nnz = 0
+        self.nnz_offsets = np.zeros(self.P + 1, np.int64)
+        c0, c1 = self.ranges[self.rank]
+        if hasattr(backend, "set_column_window") and c1 > c0:
+            backend.set_column_window(c0 + 1, c1)  # after the exchange every pending column is owned
+
+    # -- updates go to the local buffer, whatever their column (like xmatrices[tid])
+    @property
+    def local(self):
+        return self.backend.matrix
+
+    def updateindex(self, op, v, i, j):
+        self.local.updateindex(op, v, i, j)
+
+    def rawupdateindex(self, op, v, i, j, tid=1):
+        self.local.rawupdateindex(op, v, i, j)
+
+    def __setitem__(self, ij, v):
+        self.local[ij] = v
+
+    def append(self, kind, I, J, V, op="+", kinds=None):
+        self.local.append(kind, I, J, V, op, kinds)
+
+    # -- the exchange + local flush
+    def flush(self):
+        import torch
+        dist, P, be = self.dist, self.P, self.backend
+        keys, vals, offsets = be.shard_export(P)
+        send_counts = torch.from_numpy(np.diff(offsets).astype(np.int64))
+        recv_counts = torch.empty(P, dtype=torch.int64)
+        dev = keys.device
+        if dev.type == "cuda":  # NCCL/RCCL moves device tensors only
+            sc, rc = send_counts.to(dev), recv_counts.to(dev)
+            dist.all_to_all_single(rc, sc, group=self.group)
+            recv_counts = rc.cpu()
+        else:
+            dist.all_to_all_single(recv_counts, send_counts, group=self.group)
+        in_splits = send_counts.tolist()
+        out_splits = recv_counts.tolist()
+        nrecv = int(sum(out_splits))
+        rkeys = be.empty(nrecv, torch.int64)
+        rvals = be.empty(nrecv, torch.float64)
+        dist.all_to_all_single(rkeys, keys, out_splits, in_splits, group=self.group)
+        dist.all_to_all_single(rvals, vals, out_splits, in_splits, group=self.group)
+        self.exchanged = (int(sum(in_splits)), nrecv)
+        be.replace_pending(rkeys, rvals)
+        self.local_nnz = be.flush()
+        # global colptr offsets: exclusive scan of the per-shard nnz
+        mine = torch.tensor([self.local_nnz], dtype=torch.int64, device=dev if dev.type == "cuda" else "cpu")
+        allnnz = [torch.empty_like(mine) for _ in range(P)]
+        dist.all_gather(allnnz, mine, group=self.group)
+        counts = np.array([int(t.item()) for t in allnnz], np.int64)
+        self.nnz_offsets = np.concatenate([[0], np.cumsum(counts)])
+        return self
+
+    def nnz(self):
+        return int(self.nnz_offsets[-1])
+
+    def local_slice(self):
+        """This shard's part of the global CSC: (c0, c1, colptr[c0..c1] global 1-based, rowval, nzval)."""
+        csc = self.backend.local_csc()
+        c0, c1 = self.ranges[self.rank]
+        colptr = csc.colptr[c0:c1 + 1] + self.nnz_offsets[self.rank]
+        if c0 > 0:
+            assert csc.colptr[c0] == 1, "entries left of the owned column range"
+        assert csc.colptr[c1] == csc.colptr[-1], "entries right of the owned column range"
+        return c0, c1, colptr, csc.rowval, csc.nzval
+
+    def gather_sparse(self, dst=0):
+        """Host-visible global SparseMatrixCSC on rank `dst` (None elsewhere); for checks/small sizes."""
+        piece = self.local_slice()
+        out = [None] * self.P if self.rank == dst else None
+        self.dist.gather_object(piece, out, dst=dst, group=self.group)
+        if self.rank != dst:
+            return None
+        colptr = np.ones(self.n + 1, np.int64)
+        rows, vals = [], []
+        for (c0, c1, cp, rv, nz) in out:
+            colptr[c0:c1 + 1] = cp
+            rows.append(rv)
+            vals.append(nz)
+        colptr[-1] = self.nnz_offsets[-1] + 1
+        return SparseMatrixCSC(self.m, self.n, colptr, np.concatenate(rows), np.concatenate(vals))

@@ -125,6 +125,11 @@ int32_t esp_generate_fdrand(esp_handle *h, int64_t nx, int64_t ny, int64_t nz, u
                             int32_t rand_mode, int32_t kind);
 int32_t esp_generate_fem(esp_handle *h, int32_t dim, int64_t npd, uint64_t seed,
                          int32_t order_mode);
+/* the part of the fdrand! stream issued by the nodes [node_begin, node_end) (0-based l-1) of the
+ * k,j,i loop nest: one rank's slab of a sharded assembly */
+int32_t esp_generate_fdrand_range(esp_handle *h, int64_t nx, int64_t ny, int64_t nz, uint64_t seed,
+                                  int32_t rand_mode, int32_t kind, int64_t node_begin,
+                                  int64_t node_end);
 /* number of appended, not yet flushed entries; >0 iff anything is pending
  * (the flush! gate of genericextendablesparsematrixcsc.jl:32 / nnznew :21) */
 int32_t esp_pending(const esp_handle *h, int64_t *count);
@@ -165,6 +170,10 @@ int32_t esp_pattern_hash(esp_handle *h, uint64_t *hash);
 int32_t esp_shard_counts(esp_handle *h, int32_t nshards, int64_t *counts);
 int32_t esp_shard_export(esp_handle *h, int32_t nshards, uint64_t *d_keys, double *d_vals,
                          int64_t *offsets);
+
+/* promise: every pending entry of the following flushes has its column in [col_lo, col_hi]
+ * (1-based); the partition then works on that window only.  Violations -> ESP_ERR_STATE. */
+int32_t esp_set_column_window(esp_handle *h, int64_t col_lo, int64_t col_hi);
 
 /* ---- measurement ---------------------------------------------------------------- */
 int32_t esp_timing_enable(esp_handle *h, int32_t on);

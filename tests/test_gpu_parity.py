@@ -454,3 +454,88 @@ def test_fdrand_large_properties(esp, n):
     i, j, k = g % n, (g // n) % n, g // (n * n)
     faces = ((i == 0) | (i == n - 1)).astype(float) + ((j == 0) | (j == n - 1)) + ((k == 0) | (k == n - 1))
     assert np.allclose(colsum, faces / (n * n), rtol=0, atol=1e-12)
+
+
+# ------------------------------------------------------------------ shards (multi-GPU building blocks)
+@pytest.mark.parametrize("P", [1, 2, 3, 8])
+def test_shard_export_is_a_stable_partition_by_owner(esp, P):
+    import torch
+    rng = np.random.default_rng(P)
+    m, n = 900, 1000
+    cnt = 50000
+    be = esp.HipShardBackend(m, n)
+    I = rng.integers(1, m + 1, cnt)
+    J = rng.integers(1, n + 1, cnt)
+    V = rng.standard_normal(cnt)
+    kinds = rng.integers(0, 3, cnt).astype(np.uint8)
+    be.matrix.append(0, I, J, V, kinds=kinds)
+    counts = be.shard_counts(P)
+    keys, vals, offsets = be.shard_export(P)
+    torch.cuda.synchronize()
+    rb = 10  # bits_for(900)
+    key = ((((J - 1) << rb) | (I - 1)) << 2) | kinds
+    owner = ((J - 1) * P) // n
+    order = np.argsort(owner, kind="stable")
+    assert np.array_equal(counts, np.bincount(owner, minlength=P))
+    assert np.array_equal(offsets, np.concatenate([[0], np.cumsum(counts)]))
+    assert np.array_equal(keys.cpu().numpy(), key[order])
+    assert np.array_equal(vals.cpu().numpy().view(np.uint64), V[order].view(np.uint64))
+
+
+def test_sharded_matrix_world1_nccl(esp, orc):
+    """The product exchange path end to end on one GPU (world_size 1, RCCL)."""
+    import torch
+    import torch.distributed as dist
+    if dist.is_initialized():
+        pytest.skip("process group already initialised")
+    os_env = __import__("os").environ
+    os_env.setdefault("MASTER_ADDR", "127.0.0.1")
+    os_env.setdefault("MASTER_PORT", "29531")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        nx, ny, nz = 12, 11, 10
+        N = nx * ny * nz
+        A = esp.ShardedExtendableSparseMatrix(N, N, esp.HipShardBackend(N, N, device=0))
+        A.local.generate_fdrand(nx, ny, nz, seed=3, rand_mode=1)
+        A.flush()
+        O = orc.fdrand(nx, ny, nz, rand_mode=1, seed=3, style=orc.KIND_UPDATE)
+        G = A.gather_sparse(0)
+        assert_csc_equal(G.arrays(), O.arrays())
+        assert A.nnz() == orc.fdrand_nnz(nx, ny, nz) and A.exchanged == (orc.fdrand_count(nx, ny, nz),) * 2
+    finally:
+        dist.destroy_process_group()
+
+
+def test_column_window(esp, orc):
+    rng = np.random.default_rng(31)
+    m, n = 3000, 40000
+    lo, hi = 12345, 17000            # 1-based inclusive window, not a power of two
+    cnt = 80000
+    I = rng.integers(1, m + 1, cnt)
+    J = rng.integers(lo, hi + 1, cnt)
+    V = rng.standard_normal(cnt)
+    A = esp.ExtendableSparseMatrix(m, n)
+    A.set_column_window(lo, hi)
+    O = orc.ExtendableSparseMatrix(m, n)
+    for _ in range(2):
+        A.append(UPDATE, I, J, V)
+        O.apply(np.full(cnt, UPDATE, np.uint8), I, J, V)
+        A.flush()
+        assert A.debug_last_path() == 1
+        assert_csc_equal(hip_arrays(A), O.arrays())
+    A.append(UPDATE, [1] * 5000, [hi + 1] * 5000, [1.0] * 5000)   # outside the window
+    with pytest.raises(esp.EspError):
+        A.flush()
+
+
+def test_generate_fdrand_range_halves(esp, orc):
+    nx, ny, nz = 9, 7, 6
+    N = nx * ny * nz
+    A = esp.ExtendableSparseMatrix(N, N)
+    cut = 3 * nx * ny + 17       # inside a plane and inside a row
+    A.generate_fdrand_range(nx, ny, nz, 0, cut, seed=8, rand_mode=1)
+    A.generate_fdrand_range(nx, ny, nz, cut, N, seed=8, rand_mode=1)
+    assert A.nnznew() == orc.fdrand_count(nx, ny, nz)
+    A.flush()
+    O = orc.fdrand(nx, ny, nz, rand_mode=1, seed=8, style=orc.KIND_UPDATE)
+    assert_csc_equal(hip_arrays(A), O.arrays())
