@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--n", type=int, default=int(os.environ.get("ESP_BENCH_N", "256")))
     ap.add_argument("--cpu-sample-n", type=int, default=int(os.environ.get("ESP_BENCH_CPU_N", "160")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--sharded", action="store_true",
+                    help="use the column-shard exchange path even on one GPU (always used for --gpus > 1)")
     args = ap.parse_args()
 
     import torch
@@ -63,15 +65,40 @@ def main():
     from esparse_loader import load
     esp = load()
     n = args.n
-    N = n ** 3
     E, Z = fd_counts(n)
-    A = esp.ExtendableSparseMatrix(N, N, device=local, capacity_hint=E)
-    A.timing_enable(True)
+    sharded = args.sharded or world > 1
+    if not sharded:
+        N = n ** 3
+        A = esp.ExtendableSparseMatrix(N, N, device=local, capacity_hint=E)
+        Z_total = Z
 
-    def step():
-        A.reset()
-        A.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1, kind=esp.ESP_UPDATE)
-        A.flush()
+        def step():
+            A.reset()
+            A.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1, kind=esp.ESP_UPDATE)
+            A.flush()
+    else:
+        # weak scaling: the global grid is n x n x (n*world); rank r assembles the z-slab of nodes
+        # it owns (fixed work per GPU), columns are range-sharded, entries of the cross-slab pairs
+        # travel through the all-to-all
+        if dist is None:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29533")
+            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
+        nzg = n * world
+        N = n * n * nzg
+        be = esp.HipShardBackend(N, N, device=local, capacity_hint=E + 4 * n * n)
+        SA = esp.ShardedExtendableSparseMatrix(N, N, be)
+        A = be.matrix
+        Z_total = N + 2 * ((n - 1) * n * nzg + n * (n - 1) * nzg + n * n * (nzg - 1))
+        nodes = n ** 3
+
+        def step():
+            A.reset()
+            A.generate_fdrand_range(n, n, nzg, rank * nodes, (rank + 1) * nodes, seed=0x5EED0002, rand_mode=1,
+                                    kind=esp.ESP_UPDATE)
+            SA.flush()
+    A.timing_enable(True)
 
     def barrier():
         if dist is not None:
@@ -91,9 +118,12 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-    assert A.nnz() == Z, (A.nnz(), Z)
+    total_nnz = SA.nnz() if sharded else A.nnz()
+    assert total_nnz == Z_total, (total_nnz, Z_total)
     tm = A.timing(clear=True)
+    Z = Z_total / world   # per-rank share of the final nnz (value below multiplies by world)
 
+    out = None
     if rank == 0:
         # dominant kernel = the stage with the largest summed device time
         stage_ms = {k: v[0] for k, v in tm.items() if isinstance(v, tuple)}
@@ -127,7 +157,8 @@ def main():
             "config": {"workload": "fdrand %d^3 Float64/Int64 fresh build: device COO append -> stable radix "
                                    "partition -> ordered fold -> CSC (BASELINE.json configs[1])" % n,
                        "n": n, "appended_entries": E, "final_nnz": Z,
-                       "parallelism": "replicas x%d (no exchange)" % world if world > 1 else "1 GPU"},
+                       "parallelism": ("column-range shards x%d, all-to-all-v entry routing (RCCL), z-slab "
+                                       "producers, global grid %dx%dx%d" % (world, n, n, n * world)) if sharded else "1 GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                          "avg_launch_ms": avg_ms, "launches": dom_launches,
@@ -140,9 +171,17 @@ def main():
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n)
-        print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints a version banner through C stdio: flush it first so the JSON is the last line
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -899,7 +899,7 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     if (pass_idx > 0) {  // the partition passes clamp and report keys outside the window
         HIPCK(h, hipMemcpyAsync(h->pin_scalar + 2, d_werr, 4, hipMemcpyDeviceToHost, h->stream));
         HIPCK(h, hipStreamSynchronize(h->stream));
-        if ((u32)h->pin_scalar[2]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window");
+        if ((u32)h->pin_scalar[2]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (partition)");
     }
     out->sk = kin;
     out->sv = vin;
@@ -1035,7 +1035,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     HIPCK(h, hipStreamSynchronize(h->stream));
     if ((u32)h->pin_scalar[2]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window");
     const u32 lookback_err = (u32)(h->pin_scalar[1] >> 32);
-    if (lookback_err & 2u) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window");
+    if (lookback_err & 2u) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (bucket)");
     if (lookback_err & 1u) FAIL(h, ESP_ERR_HIP, "esp_flush: look-back chain timed out inside the bucket kernel");
     const i64 Zn = (i64)(h->pin_scalar[0] & esplocal::ST_VAL);
     *Zn_out = Zn;

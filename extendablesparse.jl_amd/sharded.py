@@ -34,6 +34,41 @@ def owner_ranges(n, P):
     return [(bounds[r], bounds[r + 1]) for r in range(P)]
 
 
+# torch 2.10+rocm7.0 / RCCL 2.26: one all_to_all_single call that moves more than 2^27 8-byte
+# elements delivers only part of the data (measured on MI355X, tools: tests/test_gpu_parity.py
+# ::test_all_to_all_large_message).  The exchange is therefore issued in rounds of bounded size.
+A2A_MAX_ELEMS = 1 << 26
+
+
+def all_to_all_v(dist, out, inp, out_splits, in_splits, group=None, max_elems=A2A_MAX_ELEMS):
+    """all-to-all-v of 8-byte elements in rounds of at most max_elems per call; `out` keeps the
+    (source rank, source order) layout of a single all_to_all_single."""
+    import torch
+    P = len(in_splits)
+    big = max(max(in_splits, default=0), max(out_splits, default=0))
+    t = torch.tensor([big], dtype=torch.int64, device=inp.device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    big = int(t.item())
+    C = max(1, max_elems // P)
+    if big <= C:
+        dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
+        return 1
+    in_off = np.concatenate([[0], np.cumsum(in_splits)]).astype(np.int64)
+    out_off = np.concatenate([[0], np.cumsum(out_splits)]).astype(np.int64)
+    rounds = -(-big // C)
+    for q in range(rounds):
+        in_q = [int(min(max(c - q * C, 0), C)) for c in in_splits]
+        out_q = [int(min(max(c - q * C, 0), C)) for c in out_splits]
+        send = torch.cat([inp[in_off[d] + q * C: in_off[d] + q * C + in_q[d]] for d in range(P)])
+        recv = torch.empty(sum(out_q), dtype=out.dtype, device=out.device)
+        dist.all_to_all_single(recv, send, out_q, in_q, group=group)
+        pos = 0
+        for r in range(P):
+            out[out_off[r] + q * C: out_off[r] + q * C + out_q[r]] = recv[pos: pos + out_q[r]]
+            pos += out_q[r]
+    return rounds
+
+
 class HipShardBackend:
     """Local operations of one shard on its GPU, through the C ABI."""
 
@@ -147,8 +182,8 @@ class ShardedExtendableSparseMatrix:
         nrecv = int(sum(out_splits))
         rkeys = be.empty(nrecv, torch.int64)
         rvals = be.empty(nrecv, torch.float64)
-        dist.all_to_all_single(rkeys, keys, out_splits, in_splits, group=self.group)
-        dist.all_to_all_single(rvals, vals, out_splits, in_splits, group=self.group)
+        all_to_all_v(dist, rkeys, keys, out_splits, in_splits, self.group)
+        all_to_all_v(dist, rvals, vals, out_splits, in_splits, self.group)
         self.exchanged = (int(sum(in_splits)), nrecv)
         be.replace_pending(rkeys, rvals)
         self.local_nnz = be.flush()

@@ -539,3 +539,26 @@ def test_generate_fdrand_range_halves(esp, orc):
     A.flush()
     O = orc.fdrand(nx, ny, nz, rand_mode=1, seed=8, style=orc.KIND_UPDATE)
     assert_csc_equal(hip_arrays(A), O.arrays())
+
+
+def test_all_to_all_large_message(esp):
+    """Exchange helper with > 2^27 elements through RCCL (a single all_to_all_single call of that
+    size delivers only part of the data on this stack: the helper splits it into rounds)."""
+    import torch
+    import torch.distributed as dist
+    from extendablesparse_jl_amd.sharded import all_to_all_v
+    if dist.is_initialized():
+        pytest.skip("process group already initialised")
+    os_env = __import__("os").environ
+    os_env.setdefault("MASTER_ADDR", "127.0.0.1")
+    os_env.setdefault("MASTER_PORT", "29532")
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        cnt = 150_000_000
+        a = torch.arange(cnt, dtype=torch.int64, device="cuda")
+        b = torch.zeros_like(a)
+        rounds = all_to_all_v(dist, b, a, [cnt], [cnt])
+        torch.cuda.synchronize()
+        assert rounds > 1 and torch.equal(a, b)
+    finally:
+        dist.destroy_process_group()
