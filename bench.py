@@ -22,6 +22,17 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
 
 
+def pmc_traffic(kernel_stage):
+    """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json, produced by tools/pmc_traffic.py from separate FETCH_SIZE and
+    WRITE_SIZE runs of this same command, gfx950 corrections applied); None if not collected."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get(kernel_stage, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
 def fd_counts(n):
     E = 12 * n * n * (n - 1) + 6 * n * n
     Z = n ** 3 + 6 * n * n * (n - 1)
@@ -33,9 +44,11 @@ def cpu_baseline(sample_n):
     from oracle import oracle as orc
     z, ti, tf = orc.bench_fdrand(sample_n, sample_n, sample_n, orc.KIND_UPDATE)
     return {"value": z / (ti + tf), "unit": "nnz/s", "cores": 1, "kind": "port",
-            "sample": "fdrand %d^3 fresh assemble+flush!, updateindex! style, C restatement of "
-                      "SparseMatrixLNK (oracle/), insert %.2fs + flush %.2fs; host has %d cores"
-                      % (sample_n, ti, tf, os.cpu_count())}
+            "sample": "one fdrand %d^3 fresh assemble+flush! (%d update calls, %d nnz), updateindex! style, "
+                      "C restatement of SparseMatrixLNK + lnk+csc (oracle/), -O2, insert %.2fs + flush %.2fs; "
+                      "host has %d cores, 1 used (the reference path is single-threaded)"
+                      % (sample_n, 12 * sample_n * sample_n * (sample_n - 1) + 6 * sample_n * sample_n, z, ti, tf,
+                         os.cpu_count())}
 
 
 def main():
@@ -44,7 +57,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=int(os.environ.get("ESP_BENCH_N", "256")))
-    ap.add_argument("--cpu-sample-n", type=int, default=int(os.environ.get("ESP_BENCH_CPU_N", "160")))
+    ap.add_argument("--cpu-sample-n", type=int, default=int(os.environ.get("ESP_BENCH_CPU_N", "256")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sharded", action="store_true",
                     help="use the column-shard exchange path even on one GPU (always used for --gpus > 1)")
@@ -98,7 +111,7 @@ def main():
             A.generate_fdrand_range(n, n, nzg, rank * nodes, (rank + 1) * nodes, seed=0x5EED0002, rand_mode=1,
                                     kind=esp.ESP_UPDATE)
             SA.flush()
-    A.timing_enable(True)
+    A.timing_enable(not os.environ.get("ESP_BENCH_NO_STAGE_TIMING"))
 
     def barrier():
         if dist is not None:
@@ -137,7 +150,7 @@ def main():
             "local": 16.0 * E + 16.0 * Z + 8.0 * (N + 1),
             "fold": 16.0 * E + 16.0 * Z,
         }.get(dom, 16.0 * E)
-        avg_ms = dom_ms / max(dom_launches, 1)
+        avg_ms = max(dom_ms / max(dom_launches, 1), 1e-9)
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
         algo_bytes = 2 * 16.0 * E + 16.0 * Z + 8.0 * (N + 1)   # 72.08 B per final nnz
         ms_step = dt / args.steps * 1e3
@@ -160,7 +173,7 @@ def main():
                        "parallelism": ("column-range shards x%d, all-to-all-v entry routing (RCCL), z-slab "
                                        "producers, global grid %dx%dx%d" % (world, n, n, n * world)) if sharded else "1 GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
                          "avg_launch_ms": avg_ms, "launches": dom_launches,
                          "algorithmic_bytes_per_launch": per_launch_bytes},
             "pipeline": {"algorithmic_bytes_per_step": algo_bytes, "bytes_per_final_nnz": algo_bytes / Z,
