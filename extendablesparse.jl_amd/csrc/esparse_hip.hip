@@ -558,7 +558,7 @@ extern "C" int32_t esp_generate_fem(esp_handle *h, int32_t dim, int64_t npd, uin
     a.vals = (double *)h->vals.p + h->count;
     {
         Span sp(h, ESP_ST_APPEND);
-        hipLaunchKernelGGL(espgen::fem_k, dim3(grid_for(nc, espgen::THREADS)), dim3(espgen::THREADS), 0, h->stream, a);
+        hipLaunchKernelGGL(espgen::fem_k, dim3(grid_for(nc, espgen::FEM_CELLS)), dim3(espgen::FEM_CELLS), 0, h->stream, a);
         sp.add(1);
     }
     HIPCK(h, hipGetLastError());
@@ -825,6 +825,10 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     if (E > esplocal::CAP) {
         const double target = 0.8 * esplocal::CAP;
         while (planned < K && (double)E / (double)((i64)1 << planned) > target) planned++;
+        // one bit short of a whole number of 8-bit passes: an average fill of up to 95 % is worth
+        // trying with one pass less (the longest segment is checked after the planned passes and a
+        // further pass is added only if a segment really overflows)
+        if (planned > 8 && planned % 8 == 1 && (double)E / (double)((i64)1 << (planned - 1)) <= 0.95 * esplocal::CAP) planned--;
     }
     const int npass = (planned + 7) / 8;
 
@@ -850,7 +854,10 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
                 ok = false;
                 break;
             }
-            bits = std::min(8, K - done);
+            // just enough further bits to bring the longest segment under the capacity
+            bits = 1;
+            while (bits < 8 && (double)maxlen / (double)(1 << bits) > 0.8 * esplocal::CAP) bits++;
+            bits = std::min(bits, K - done);
         }
         espradix::Pass p;
         p.keys_in = kin;
@@ -1024,10 +1031,14 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
             const char *e = getenv("ESP_LOCAL_STOP");
             a.stop_after = e ? atoi(e) : 0;
         }
-        if (Z0 == 0)
-            hipLaunchKernelGGL((esplocal::local_k<true>), dim3((unsigned)S), dim3(esplocal::THREADS), 0, h->stream, a);
-        else
-            hipLaunchKernelGGL((esplocal::local_k<false>), dim3((unsigned)S), dim3(esplocal::THREADS), 0, h->stream, a);
+        const i64 max_grid = h->force_path == 4 ? 64 : esplocal::MAX_GRID;  // 4: test hook, many launches
+        for (i64 first = 0; first < S; first += max_grid) {
+            const unsigned grid = (unsigned)std::min<i64>(max_grid, S - first);
+            if (Z0 == 0)
+                hipLaunchKernelGGL((esplocal::local_k<true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+            else
+                hipLaunchKernelGGL((esplocal::local_k<false>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+        }
         sp.add(1);
     }
     HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (S - 1), 16, hipMemcpyDeviceToHost, h->stream));

@@ -179,9 +179,16 @@ __device__ __forceinline__ u64 fem_cell_at(const FemArgs &a, i64 pos) {
     return x;
 }
 
-__global__ __launch_bounds__(THREADS) void fem_k(FemArgs a) {
-    const i64 p = (i64)blockIdx.x * THREADS + threadIdx.x;
-    if (p >= a.ncells) return;
+// One workgroup = FEM_CELLS consecutive stream positions; the (dim+1)(dim+2) updates of a cell are
+// staged in LDS and the workgroup's contiguous range is written with coalesced 16-byte stores.
+constexpr int FEM_CELLS = 128;
+__global__ __launch_bounds__(FEM_CELLS) void fem_k(FemArgs a) {
+    __shared__ u64 lk[FEM_CELLS * 20];
+    __shared__ double lv[FEM_CELLS * 20];
+    const i64 p0 = (i64)blockIdx.x * FEM_CELLS;
+    const i64 p = p0 + threadIdx.x;
+    const int per = (a.dim + 1) * (a.dim + 2);
+    if (p < a.ncells) {
     const i64 cell = (i64)fem_cell_at(a, p);
     const int dim = a.dim;
     const int K = dim == 2 ? 2 : 6;
@@ -266,22 +273,46 @@ __global__ __launch_bounds__(THREADS) void fem_k(FemArgs a) {
                 S[jl][il] = sacc;
             }
         }
-    i64 o = p * (i64)((dim + 1) * (dim + 2));
+    int o = threadIdx.x * per;
 #pragma unroll
     for (int il = 0; il < 4; il++) {
         if (il <= dim) {
-            a.keys[o] = esp_pack(a.L, nodes[il], nodes[il], ESP_RAWUPDATE);
-            a.vals[o] = 0.1 * vol / (double)(dim + 1);
+            lk[o] = esp_pack(a.L, nodes[il], nodes[il], ESP_RAWUPDATE);
+            lv[o] = 0.1 * vol / (double)(dim + 1);
             o++;
 #pragma unroll
             for (int jl = 0; jl < 4; jl++) {
                 if (jl <= dim) {
-                    a.keys[o] = esp_pack(a.L, nodes[il], nodes[jl], ESP_RAWUPDATE);
-                    a.vals[o] = vol * S[il][jl];
+                    lk[o] = esp_pack(a.L, nodes[il], nodes[jl], ESP_RAWUPDATE);
+                    lv[o] = vol * S[il][jl];
                     o++;
                 }
             }
         }
+    }
+    }  // p < ncells
+    __syncthreads();
+    const i64 ncell_blk = min((i64)FEM_CELLS, a.ncells - p0);
+    const int cnt = (int)ncell_blk * per;
+    u64 *gk = a.keys + p0 * per;
+    double *gv = a.vals + p0 * per;
+    const int head = (int)(((uintptr_t)gk >> 3) & 1);
+    if (threadIdx.x == 0 && head && cnt > 0) {
+        gk[0] = lk[0];
+        gv[0] = lv[0];
+    }
+    const int npair = (cnt - head) >> 1;
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    ull2 *gk2 = reinterpret_cast<ull2 *>(gk + head);
+    dbl2 *gv2 = reinterpret_cast<dbl2 *>(gv + head);
+    for (int q = threadIdx.x; q < npair; q += FEM_CELLS) {
+        gk2[q] = ull2{lk[head + 2 * q], lk[head + 2 * q + 1]};
+        gv2[q] = dbl2{lv[head + 2 * q], lv[head + 2 * q + 1]};
+    }
+    if (threadIdx.x == 0 && cnt > 0 && ((cnt - head) & 1)) {
+        gk[cnt - 1] = lk[cnt - 1];
+        gv[cnt - 1] = lv[cnt - 1];
     }
 }
 

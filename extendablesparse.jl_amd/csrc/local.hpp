@@ -50,6 +50,7 @@ constexpr u64 ST_AGG = 1ull << 62;
 constexpr u64 ST_PRE = 2ull << 62;
 constexpr u64 ST_VAL = (1ull << 62) - 1ull;
 constexpr u32 SPIN_LIMIT = 1u << 24;
+constexpr i64 MAX_GRID = 1 << 22;  // workgroups per launch (HIP caps a grid at 2^32 threads)
 
 // Batcher's merge-exchange sorting network for 16 keys (63 compare-exchanges), generated at
 // compile time; used to sort one short column run per lane entirely in registers.
@@ -193,9 +194,12 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     // claim a segment in start order: every predecessor of a look-back chain has started
+    // (a flush with more than MAX_GRID segments is issued as several launches; the ticket counter
+    // and the look-back granules carry over from one launch to the next)
     if (t == 0) s_seg = (int)atomicAdd(a.ticket, 1u);
     __syncthreads();
     const int s = s_seg;
+    if (s >= a.S) return;
     const i64 beg = a.seg_start[s];
     const int n = (int)(a.seg_start[s + 1] - beg);
     const u64 submask = a.rem_bits >= 64 ? ~0ull : ((1ull << a.rem_bits) - 1ull);
@@ -304,6 +308,14 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
                     u64 psub = 0;
                     u32 idx0 = 0;
                     i64 pos = -1;
+                    // the run's rows come in increasing order: the CSC column is walked with a cursor
+                    // (findindex restated as a merge walk; same result as the binary search)
+                    i64 ccur = 0, cend = 0;
+                    if (a.csc.nnz > 0 && len > 0) {
+                        const i64 col0 = (i64)((hi + (x[0] >> SUB_SHIFT)) >> a.rb);
+                        ccur = a.csc.colptr[col0] - 1;
+                        cend = a.csc.colptr[col0 + 1] - 1;
+                    }
 #pragma unroll
                     for (int j = 0; j <= REG_RUN; j++) {
                         const bool valid = j < REG_RUN && j < len;
@@ -316,9 +328,10 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
                                 psub = sub;
                                 idx0 = (u32)(kj >> ESP_TAG_BITS) & (CAP - 1);
                                 pos = -1;
-                                if (a.csc.nnz > 0) {
-                                    const u64 full = hi + sub;
-                                    pos = espfold::csc_find(a.csc, (i64)(full >> a.rb), (i64)(full & rowmask));
+                                if (ccur < cend) {
+                                    const i64 want = (i64)((hi + sub) & rowmask) + 1;
+                                    while (ccur < cend && a.csc.rowval[ccur] < want) ccur++;
+                                    if (ccur < cend && a.csc.rowval[ccur] == want) pos = ccur;
                                 }
                                 present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
                                 acc = present ? a.csc.nzval[pos] : 0.0;

@@ -353,7 +353,7 @@ def test_long_duplicate_runs_and_dense_column(esp, orc):
     assert A.debug_last_path() == 2        # runs longer than an LDS bucket take the general path
 
 
-@pytest.mark.parametrize("force", [0, 2, 3])
+@pytest.mark.parametrize("force", [0, 2, 3, 4])
 def test_both_pipelines_agree_with_oracle(esp, orc, force):
     """The LDS bucket path (1) and the general path (2) are both checked against the oracle."""
     rng = np.random.default_rng(29)
@@ -376,6 +376,23 @@ def test_both_pipelines_agree_with_oracle(esp, orc, force):
         O.flush()
         assert A.debug_last_path() == (2 if force == 2 else 1)
         assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
+
+
+def test_bucket_kernel_many_launches(esp, orc):
+    """More segments than one launch takes: ticket counter and look-back state carry over."""
+    rng = np.random.default_rng(41)
+    m, n = 2000, 300000
+    cnt = 1500000
+    A = esp.ExtendableSparseMatrix(m, n)
+    A.debug_force_path(4)
+    O = orc.ExtendableSparseMatrix(m, n)
+    I = rng.integers(1, m + 1, cnt)
+    J = rng.integers(1, n + 1, cnt)
+    V = rng.standard_normal(cnt)
+    A.append(UPDATE, I, J, V)
+    O.apply(np.full(cnt, UPDATE, np.uint8), I, J, V)
+    assert_csc_equal(hip_arrays(A), O.arrays())
+    assert A.debug_last_path() == 1
 
 
 @pytest.mark.parametrize("per_col", [6, 30, 200])
