@@ -13,6 +13,7 @@
 #include "local.hpp"
 #include "merge.hpp"
 #include "radix.hpp"
+#include "runpart.hpp"
 #include "scan.hpp"
 
 // ------------------------------------------------------------------------ handle
@@ -41,6 +42,9 @@ struct esp_handle {
     // ping-pong / scratch
     DevBuf keys2, vals2, hist, segs, colend, newkey, newval, heads, misc, seg[2], tilef[2], segcnt, segout;
     int force_path = 0, last_path = 0;
+    DevBuf runbuf;
+    int runs_skip = 0, runs_penalty = 0;  // back-off after a stream turned out not to be pre-sorted
+    int last_partition = 0;               // 1 = run-based single pass, 2 = 8-bit passes only
     // column window of the pending entries (whole matrix by default)
     u64 win_base = 0, win_span = 0;
     // device CSC (Julia layout) + spare set for rebuilds
@@ -244,7 +248,7 @@ extern "C" int32_t esp_destroy(esp_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->keys, &h->vals, &h->keys2, &h->vals2, &h->hist, &h->segs, &h->colend, &h->newkey,
                       &h->newval, &h->heads, &h->misc, &h->colptr, &h->rowval, &h->nzval, &h->rowval2,
-                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->d_st_rows, &h->d_st_cols, &h->d_st_vals, &h->d_st_kinds})
+                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->runbuf, &h->d_st_rows, &h->d_st_cols, &h->d_st_vals, &h->d_st_kinds})
         release(*b);
     if (h->st_rows) (void)hipHostFree(h->st_rows);
     if (h->st_cols) (void)hipHostFree(h->st_cols);
@@ -809,6 +813,133 @@ struct Sorted {
     bool local_ok;
 };
 
+// Single-pass partition on the top `pb` (9..16) bits of the key window, for pre-sorted streams
+// (runpart.hpp).  *ok=false when some tile holds too many distinct digits: nothing was moved and the
+// caller uses the 8-bit passes.  On success kout/vout hold the partitioned entries and
+// seg_out (NB+1 entries, device) the bucket starts.
+static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u64 *kout, double *vout, int K, int pb,
+                             i64 *seg_out, bool *ok) {
+    const i64 E = h->count;
+    const i64 T = ceil_div<i64>(E, esprun::TILE);
+    const i64 NB = (i64)1 << pb;
+    const i64 RM = T * esprun::RMAX;
+    // carve the bookkeeping buffer
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t o_rd = carve(sizeof(u32) * (size_t)RM), o_rc = carve(sizeof(u32) * (size_t)RM);
+    const size_t o_ro = carve(sizeof(i64) * (size_t)RM);
+    const size_t o_nr = carve(sizeof(u64) * (size_t)(T + 1 + espscan::workspace_elems(T + 1)));
+    const size_t o_bc = carve(sizeof(u64) * (size_t)(NB + 1 + espscan::workspace_elems(NB + 1)));
+    const size_t o_hd = carve(sizeof(u64) * (size_t)NB);
+    const size_t o_lk = carve(sizeof(u64) * (size_t)RM), o_lk2 = carve(sizeof(u64) * (size_t)RM);
+    const size_t o_lv = carve(sizeof(double) * (size_t)RM), o_lv2 = carve(sizeof(double) * (size_t)RM);
+    const size_t o_sc = carve(sizeof(u64) * (size_t)(RM + 1 + espscan::workspace_elems(RM + 1)));
+    CK(ensure(h, h->runbuf, off));
+    char *B = (char *)h->runbuf.p;
+    CK(ensure(h, h->misc, 256));
+    u32 *d_over = (u32 *)h->misc.p + 61;
+    esprun::Args a;
+    a.keys_in = kin;
+    a.vals_in = vin;
+    a.keys_out = kout;
+    a.vals_out = vout;
+    a.E = E;
+    a.shift = K - pb;
+    a.base = h->win_base;
+    a.span = h->win_span;
+    a.err = (u32 *)h->misc.p + 60;
+    a.overflow = d_over;
+    a.runs_d = (u32 *)(B + o_rd);
+    a.runs_c = (u32 *)(B + o_rc);
+    a.runs_off = (i64 *)(B + o_ro);
+    a.nruns = (u64 *)(B + o_nr);
+    a.bucket_count = (unsigned long long *)(B + o_bc);
+    u64 *nruns = a.nruns, *bstart = (u64 *)(B + o_bc), *head = (u64 *)(B + o_hd);
+    u64 *lk = (u64 *)(B + o_lk), *lk2 = (u64 *)(B + o_lk2), *sc = (u64 *)(B + o_sc);
+    double *lv = (double *)(B + o_lv), *lv2 = (double *)(B + o_lv2);
+    HIPCK(h, hipMemsetAsync(d_over, 0, 4, h->stream));
+    HIPCK(h, hipMemsetAsync(bstart, 0, sizeof(u64) * (size_t)(NB + 1), h->stream));
+    HIPCK(h, hipMemsetAsync(nruns + T, 0, sizeof(u64), h->stream));
+    {
+        Span sp(h, ESP_ST_HIST);
+        hipLaunchKernelGGL(esprun::run_hist_k, dim3((unsigned)T), dim3(esprun::THREADS), 0, h->stream, a);
+        sp.add(1);
+    }
+    {
+        Span sp(h, ESP_ST_SCAN);
+        sp.add(espscan::exclusive<u64, false>(h->stream, nruns, nruns, T + 1, nruns + T + 1));
+        sp.add(espscan::exclusive<u64, false>(h->stream, bstart, bstart, NB + 1, bstart + NB + 1));
+    }
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_over, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar + 1, nruns + T, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if ((u32)h->pin_scalar[0]) {
+        *ok = false;
+        return ESP_OK;
+    }
+    const i64 R = (i64)h->pin_scalar[1];
+    {
+        Span sp(h, ESP_ST_SCAN);
+        hipLaunchKernelGGL(esprun::run_pack_k, dim3(grid_for(RM, 256)), dim3(256), 0, h->stream, (const u32 *)a.runs_d, (const u32 *)a.runs_c,
+                           (const u64 *)nruns, T, lk, lv);
+        sp.add(1);
+    }
+    // stable sort of the run list by digit with the ordinary 8-bit passes (tile order is kept)
+    {
+        CK(ensure(h, h->segs, sizeof(i64) * 8));
+        i64 *segs = (i64 *)h->segs.p;
+        const i64 TR = ceil_div<i64>(R, espradix::TILE);
+        hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, segs, (i64)0, R, (i64)0, TR);
+        u64 *ki = lk, *ko = lk2;
+        double *vi = lv, *vo = lv2;
+        for (int done = 0; done < pb; done += 8) {
+            espradix::Pass p;
+            p.keys_in = ki;
+            p.vals_in = vi;
+            p.keys_out = ko;
+            p.vals_out = vo;
+            p.seg_start = segs;
+            p.tile_first = segs + 2;
+            p.S = 1;
+            p.owner_P = 0;
+            p.owner_n = 1;
+            p.colshift = 0;
+            p.base = 0;
+            p.span = ~0ull;
+            p.err = (u32 *)h->misc.p + 62;
+            p.shift = done;
+            p.bits = std::min(8, pb - done);
+            CK(partition_pass(h, p, TR));
+            std::swap(ki, ko);
+            std::swap(vi, vo);
+        }
+        lk = ki;
+        lv = vi;
+    }
+    {
+        Span sp(h, ESP_ST_SCAN);
+        hipLaunchKernelGGL(esprun::run_counts_k, dim3(grid_for(R + 1, 256)), dim3(256), 0, h->stream, (const double *)lv, R, sc);
+        sp.add(1 + espscan::exclusive<u64, false>(h->stream, sc, sc, R + 1, sc + R + 1));
+        hipLaunchKernelGGL(esprun::run_heads_k, dim3(grid_for(R, 256)), dim3(256), 0, h->stream, (const u64 *)lk, (const u64 *)sc, R, head);
+        hipLaunchKernelGGL(esprun::run_offsets_k, dim3(grid_for(R, 256)), dim3(256), 0, h->stream, (const u64 *)lk, (const double *)lv,
+                           (const u64 *)sc, (const u64 *)head, (const u64 *)bstart, R, a.runs_off);
+        sp.add(2);
+    }
+    {
+        Span sp(h, ESP_ST_SCATTER);
+        hipLaunchKernelGGL(esprun::run_scatter_k, dim3((unsigned)T), dim3(esprun::THREADS), 0, h->stream, a);
+        sp.add(1);
+    }
+    HIPCK(h, hipMemcpyAsync(seg_out, bstart, sizeof(i64) * (size_t)(NB + 1), hipMemcpyDeviceToDevice, h->stream));
+    HIPCK(h, hipGetLastError());
+    *ok = true;
+    return ESP_OK;
+}
+
 static int32_t sort_msd(esp_handle *h, Sorted *out) {
     const i64 E = h->count;
     // sort bits of the key window: (key>>2) - win_base lies in [0, win_span)
@@ -843,11 +974,52 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     i64 maxlen = E;
     bool ok = true;
     int pass_idx = 0;
+    int npass_eff = npass;
+    h->last_partition = 2;
+    // pre-sorted streams: the first (up to) 16 bits in ONE pass (runpart.hpp)
+    if (planned > 8 && h->force_path != 5) {
+        if (h->runs_skip > 0) {
+            h->runs_skip--;
+        } else {
+            const int pb = std::min(planned, 16);
+            const int S2 = 1 << pb;
+            CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(S2 + 1)));
+            CK(ensure(h, h->tilef[1], sizeof(u64) * (size_t)(S2 + 1 + espscan::workspace_elems(S2 + 1))));
+            bool took = false;
+            CK(run_partition(h, kin, vin, kout, vout, K, pb, (i64 *)h->seg[1].p, &took));
+            if (took) {
+                {
+                    Span sp(h, ESP_ST_SCAN);
+                    HIPCK(h, hipMemsetAsync(d_maxlen, 0, 8, h->stream));
+                    u64 *tf = (u64 *)h->tilef[1].p;
+                    hipLaunchKernelGGL(espradix::seg_tiles_k, dim3(grid_for(S2 + 1, 256)), dim3(256), 0, h->stream, (const i64 *)h->seg[1].p,
+                                       (i64)S2, (i64)espradix::TILE, tf, d_maxlen);
+                    sp.add(1 + espscan::exclusive<u64, false>(h->stream, tf, tf, S2 + 1, tf + S2 + 1));
+                }
+                std::swap(kin, kout);
+                std::swap(vin, vout);
+                cur = 1;
+                S = S2;
+                done = pb;
+                npass_eff = (planned - pb + 7) / 8;
+                h->last_partition = 1;
+                h->runs_penalty = 0;
+                if (npass_eff == 0) {
+                    HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_maxlen, 8, hipMemcpyDeviceToHost, h->stream));
+                    HIPCK(h, hipStreamSynchronize(h->stream));
+                    maxlen = (i64)h->pin_scalar[0];
+                }
+            } else {
+                h->runs_penalty = std::min(16, 2 * h->runs_penalty + 1);
+                h->runs_skip = h->runs_penalty;
+            }
+        }
+    }
     for (;;) {
         int bits;
-        if (pass_idx < npass) {
+        if (pass_idx < npass_eff) {
             // spread the planned bits evenly over the planned passes
-            bits = (planned - done + (npass - pass_idx) - 1) / (npass - pass_idx);
+            bits = (planned - done + (npass_eff - pass_idx) - 1) / (npass_eff - pass_idx);
         } else {
             if (maxlen <= esplocal::CAP) break;
             if (done >= K || done >= 24) {
@@ -896,14 +1068,14 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
         S = S2;
         done += bits;
         pass_idx++;
-        if (pass_idx >= npass) {
+        if (pass_idx >= npass_eff) {
             HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_maxlen, 8, hipMemcpyDeviceToHost, h->stream));
             HIPCK(h, hipStreamSynchronize(h->stream));
             maxlen = (i64)h->pin_scalar[0];
         }
     }
     HIPCK(h, hipGetLastError());
-    if (pass_idx > 0) {  // the partition passes clamp and report keys outside the window
+    if (pass_idx > 0 || h->last_partition == 1) {  // the partition passes clamp and report keys outside the window
         HIPCK(h, hipMemcpyAsync(h->pin_scalar + 2, d_werr, 4, hipMemcpyDeviceToHost, h->stream));
         HIPCK(h, hipStreamSynchronize(h->stream));
         if ((u32)h->pin_scalar[2]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (partition)");
@@ -1154,6 +1326,11 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
 extern "C" int32_t esp_debug_force_path(esp_handle *h, int32_t path) {
     if (!h) return ESP_ERR_INVALID;
     h->force_path = path;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_last_partition(const esp_handle *h, int32_t *kind) {
+    if (!h || !kind) return ESP_ERR_INVALID;
+    *kind = h->last_partition;
     return ESP_OK;
 }
 extern "C" int32_t esp_debug_last_path(const esp_handle *h, int32_t *path) {

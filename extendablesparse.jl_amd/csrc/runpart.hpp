@@ -1,0 +1,290 @@
+// runpart.hpp -- single-pass stable partition on up to 16 key bits for pre-sorted streams.
+//
+// Assembly loops emit their updates in an order with strong locality (a tile of 4096 consecutive
+// stencil / natural-order FEM updates touches only a handful of the 65536 column blocks).  The
+// classic partition needs two 8-bit passes (each reads and writes every entry) for 16 bits; here a
+// tile is described by its few RUNS (digit, count) instead of a 65536-bin histogram:
+//
+//   run_hist_k     per tile: distinct digits and their counts (<= RMAX, else the flush falls
+//                  back to the 8-bit passes), bucket totals by a few atomics   (reads 8 B/entry)
+//   (host-ordered small kernels) bucket starts = scan of the totals; the run list of all tiles is
+//                  sorted by digit (stable -> tile order kept) with the ordinary 8-bit passes, a
+//                  scan over the counts gives every run its offset inside its bucket
+//   run_scatter_k  per tile: stable rank of every entry inside its run, stores straight from
+//                  registers to bucket_start + run offset + rank  (reads 16 B, writes 16 B/entry)
+//
+// Stability: inside a bucket the runs are ordered by tile, inside a run the entries keep the
+// (wave, item, lane) = memory order.  Deterministic: the only atomics are integer counters.
+#pragma once
+#include "common.hpp"
+#include "radix.hpp"
+
+namespace esprun {
+
+constexpr int THREADS = 256;
+constexpr int WAVES = THREADS / ESP_WAVE;
+constexpr int ITEMS = 16;
+constexpr int TILE = THREADS * ITEMS;  // same tiles as espradix
+constexpr int RMAX = 16;               // distinct digits a tile may hold on this path
+constexpr u32 EMPTY = 0xFFFFFFFFu;
+
+struct Args {
+    const u64 *keys_in;
+    const double *vals_in;
+    u64 *keys_out;
+    double *vals_out;
+    i64 E;
+    int shift;  // digit = (((key >> 2) - base) >> shift), digits < nbuckets
+    u64 base, span;
+    u32 *err;        // key outside the window
+    u32 *overflow;   // a tile holds more than RMAX distinct digits
+    u32 *runs_d;     // [tile][RMAX] digits, ascending
+    u32 *runs_c;     // [tile][RMAX] counts
+    i64 *runs_off;   // [tile][RMAX] global output offset of the run
+    u64 *nruns;      // [tile] (+1 slot for the scan)
+    unsigned long long *bucket_count;  // [nbuckets + 1]
+};
+
+__device__ __forceinline__ u32 digit16(const Args &a, u64 key, bool check) {
+    u64 kn = (key >> ESP_TAG_BITS) - a.base;
+    if (check && kn >= a.span) *a.err = 1u;
+    kn = kn < a.span ? kn : a.span - 1;
+    return (u32)(kn >> a.shift);
+}
+
+__global__ __launch_bounds__(THREADS) void run_hist_k(Args a) {
+    __shared__ u32 rd[RMAX];
+    __shared__ u32 rc[RMAX];
+    __shared__ u32 over;
+    const int t = threadIdx.x, lane = t & 63;
+    const i64 beg = (i64)blockIdx.x * TILE;
+    const i64 end = min(a.E, beg + (i64)TILE);
+    if (t < RMAX) {
+        rd[t] = EMPTY;
+        rc[t] = 0;
+    }
+    if (t == 0) over = 0;
+    u64 key[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const i64 idx = beg + k * THREADS + t;
+        key[k] = idx < end ? a.keys_in[idx] : 0ull;
+    }
+    __syncthreads();
+    // Digit-major counting: the wave walks the DISTINCT digits of its 1024 entries (a handful on a
+    // pre-sorted stream); for each one, 16 ballots count its entries.  Cost ~ distinct x items.
+    u32 dig[ITEMS];
+    u32 pend = 0;  // bit k: item k of this lane not yet counted
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const bool valid = (beg + k * THREADS + t) < end;
+        dig[k] = valid ? digit16(a, key[k], true) : 0u;
+        pend |= valid ? (1u << k) : 0u;
+    }
+    int trips = 0;
+    for (;;) {
+        const u64 lanes = __ballot(pend != 0);
+        if (!lanes) break;
+        if (++trips > RMAX) {  // more distinct digits than a tile may hold on this path
+            if (lane == 0) over = 1;
+            break;
+        }
+        const int fl = __builtin_ctzll(lanes);
+        const int kk = __builtin_ctz((u32)__builtin_amdgcn_readlane((int)pend, fl));
+        u32 cand = 0;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++)
+            if (k == kk) cand = dig[k];
+        const u32 c0 = (u32)__builtin_amdgcn_readlane((int)cand, fl);
+        u32 total = 0;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const bool hit = ((pend >> k) & 1u) && dig[k] == c0;
+            total += (u32)__popcll(__ballot(hit));
+            pend &= hit ? ~(1u << k) : ~0u;
+        }
+        if (lane == 0) {
+            bool placed = false;
+            for (int j = 0; j < RMAX; j++) {
+                const u32 old = atomicCAS(&rd[j], EMPTY, c0);
+                if (old == EMPTY || old == c0) {
+                    atomicAdd(&rc[j], total);
+                    placed = true;
+                    break;
+                }
+            }
+            if (!placed) over = 1;
+        }
+    }
+    __syncthreads();
+    if (t == 0) {
+        if (over) {
+            a.nruns[blockIdx.x] = 0;
+            atomicExch(a.overflow, 1u);
+        } else {
+            // insertion sort of the <= RMAX runs by digit
+            u32 dd[RMAX], cc[RMAX];
+            int nr = 0;
+            for (int j = 0; j < RMAX; j++) {
+                const u32 x = rd[j];
+                if (x == EMPTY) continue;
+                const u32 c = rc[j];
+                int q = nr++;
+                while (q > 0 && dd[q - 1] > x) {
+                    dd[q] = dd[q - 1];
+                    cc[q] = cc[q - 1];
+                    q--;
+                }
+                dd[q] = x;
+                cc[q] = c;
+            }
+            for (int j = 0; j < nr; j++) {
+                a.runs_d[(i64)blockIdx.x * RMAX + j] = dd[j];
+                a.runs_c[(i64)blockIdx.x * RMAX + j] = cc[j];
+                atomicAdd(&a.bucket_count[dd[j]], (unsigned long long)cc[j]);
+            }
+            a.nruns[blockIdx.x] = (u64)nr;
+        }
+    }
+}
+
+// dense run list in tile order: sortable records (key = digit << 2, payload = tile|j|count)
+__global__ void run_pack_k(const u32 *__restrict__ runs_d, const u32 *__restrict__ runs_c,
+                           const u64 *__restrict__ run_base /* exclusive scan of nruns, T+1 */, i64 T,
+                           u64 *__restrict__ lk, double *__restrict__ lv) {
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const i64 tile = g / RMAX;
+    const int j = (int)(g % RMAX);
+    if (tile >= T) return;
+    const i64 b = (i64)run_base[tile];
+    const int nr = (int)((i64)run_base[tile + 1] - b);
+    if (j >= nr) return;
+    lk[b + j] = (u64)runs_d[g] << ESP_TAG_BITS;
+    const u64 payload = ((u64)tile << 20) | ((u64)j << 16) | (u64)runs_c[g];
+    lv[b + j] = __longlong_as_double((long long)payload);
+}
+
+__global__ void run_counts_k(const double *__restrict__ lv, i64 R, u64 *__restrict__ cnt) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > R) return;
+    cnt[i] = i < R ? ((u64)__double_as_longlong(lv[i]) & 0xFFFFull) : 0ull;
+}
+
+// head[d] = scanned count at the first record of digit d
+__global__ void run_heads_k(const u64 *__restrict__ lk, const u64 *__restrict__ sc, i64 R, u64 *__restrict__ head) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const u64 d = lk[i] >> ESP_TAG_BITS;
+    if (i == 0 || (lk[i - 1] >> ESP_TAG_BITS) != d) head[d] = sc[i];
+}
+
+__global__ void run_offsets_k(const u64 *__restrict__ lk, const double *__restrict__ lv, const u64 *__restrict__ sc,
+                              const u64 *__restrict__ head, const u64 *__restrict__ bucket_start, i64 R,
+                              i64 *__restrict__ runs_off) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= R) return;
+    const u64 d = lk[i] >> ESP_TAG_BITS;
+    const u64 payload = (u64)__double_as_longlong(lv[i]);
+    const i64 tile = (i64)(payload >> 20);
+    const int j = (int)((payload >> 16) & 0xF);
+    runs_off[tile * RMAX + j] = (i64)(bucket_start[d] + sc[i] - head[d]);
+}
+
+__global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
+    __shared__ u32 rd[RMAX];
+    __shared__ i64 roff[RMAX];
+    __shared__ u32 cnt[WAVES][RMAX];
+    __shared__ int s_nr;
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const i64 tile = blockIdx.x;
+    const i64 beg = tile * TILE;
+    const i64 end = min(a.E, beg + (i64)TILE);
+    // run table of the tile (nruns holds the exclusive scan by now: nr = difference)
+    if (t == 0) s_nr = (int)(a.nruns[tile + 1] - a.nruns[tile]);
+    if (t < RMAX) {
+        rd[t] = a.runs_d[tile * RMAX + t];
+        roff[t] = a.runs_off[tile * RMAX + t];
+    }
+    if (t < WAVES * RMAX) (&cnt[0][0])[t] = 0;
+    u64 key[ITEMS];
+    double val[ITEMS];
+    const i64 wbase = beg + (i64)w * (ESP_WAVE * ITEMS) + lane;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const i64 idx = wbase + k * ESP_WAVE;
+        key[k] = idx < end ? a.keys_in[idx] : 0ull;
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const i64 idx = wbase + k * ESP_WAVE;
+        val[k] = idx < end ? a.vals_in[idx] : 0.0;
+    }
+    __syncthreads();
+    const int nr = s_nr;
+    const u64 lt = (1ull << lane) - 1ull;
+    unsigned short rank[ITEMS];
+    unsigned char jrun[ITEMS];
+    u32 dig[ITEMS];
+    u32 pend = 0;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const bool valid = (wbase + k * ESP_WAVE) < end;
+        dig[k] = valid ? digit16(a, key[k], false) : 0u;
+        pend |= valid ? (1u << k) : 0u;
+        rank[k] = 0;
+        jrun[k] = 0;
+    }
+    // digit-major stable ranking: for each distinct digit of the wave, its entries are numbered in
+    // (item, lane) order with a scalar running count -- no LDS counters inside the wave
+    for (int trips = 0; trips <= RMAX; trips++) {
+        const u64 lanes = __ballot(pend != 0);
+        if (!lanes) break;
+        const int fl = __builtin_ctzll(lanes);
+        const int kk = __builtin_ctz((u32)__builtin_amdgcn_readlane((int)pend, fl));
+        u32 cand = 0;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++)
+            if (k == kk) cand = dig[k];
+        const u32 c0 = (u32)__builtin_amdgcn_readlane((int)cand, fl);
+        int jj = 0;
+        for (int j = 0; j < nr; j++)
+            if (rd[j] == c0) jj = j;
+        u32 running = 0;
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const bool hit = ((pend >> k) & 1u) && dig[k] == c0;
+            const u64 m = __ballot(hit);
+            if (hit) {
+                rank[k] = (unsigned short)(running + (u32)__popcll(m & lt));
+                jrun[k] = (unsigned char)jj;
+            }
+            running += (u32)__popcll(m);
+            pend &= hit ? ~(1u << k) : ~0u;
+        }
+        if (lane == 0) cnt[w][jj] = running;
+    }
+    __syncthreads();
+    // exclusive prefix over the waves, per run
+    if (t < RMAX) {
+        u32 run = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) {
+            const u32 x = cnt[i][t];
+            cnt[i][t] = run;
+            run += x;
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const i64 idx = wbase + k * ESP_WAVE;
+        if (idx < end) {
+            const int jj = jrun[k];
+            const i64 dst = roff[jj] + (i64)cnt[w][jj] + (i64)rank[k];
+            a.keys_out[dst] = key[k];
+            a.vals_out[dst] = val[k];
+        }
+    }
+}
+
+}  // namespace esprun

@@ -413,6 +413,11 @@ class ExtendableSparseMatrix:
         self._d.ck(self._d.lib.esp_debug_last_path(self._d.h, C.byref(p)))
         return p.value
 
+    def debug_last_partition(self):
+        p = C.c_int32()
+        self._d.ck(self._d.lib.esp_debug_last_partition(self._d.h, C.byref(p)))
+        return p.value
+
     def timing_enable(self, on=True):
         self._d.ck(self._d.lib.esp_timing_enable(self._d.h, 1 if on else 0))
 

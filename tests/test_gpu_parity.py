@@ -443,6 +443,41 @@ def test_empty_and_tiny(esp):
 
 
 # ------------------------------------------------------------------ full-size properties
+@pytest.mark.parametrize("force", [0, 5])
+def test_run_partition_vs_passes(esp, orc, force):
+    """Pre-sorted stream (48^3 stencil, E > 2^20): the run-based single-pass partition and the 8-bit
+    passes give the same bits; a shuffled stream falls back to the passes."""
+    n = 48
+    N = n ** 3
+    A = esp.ExtendableSparseMatrix(N, N)
+    A.debug_force_path(force)
+    A.generate_fdrand(n, n, n, seed=21, rand_mode=1)
+    A.flush()
+    assert A.debug_last_partition() == (1 if force == 0 else 2)
+    O = orc.fdrand(n, n, n, rand_mode=1, seed=21, style=orc.KIND_UPDATE)
+    assert_csc_equal(hip_arrays(A), O.arrays())
+    # same entries in random order: too many distinct digits per tile -> 8-bit passes
+    I, J, V = orc.fdrand_stream(n, n, n, rand_mode=1, seed=22)
+    perm = np.random.default_rng(5).permutation(len(I))
+    B = esp.ExtendableSparseMatrix(N, N)
+    B.debug_force_path(force)
+    B.append(UPDATE, I[perm], J[perm], V[perm])
+    B.flush()
+    assert B.debug_last_partition() == 2
+    Ob = orc.ExtendableSparseMatrix(N, N)
+    Ob.apply(np.full(len(I), UPDATE, np.uint8), I[perm], J[perm], V[perm])
+    assert_csc_equal(hip_arrays(B), Ob.arrays())
+    # re-assembly on the existing pattern through the same partition
+    A.generate_fdrand(n, n, n, seed=23, rand_mode=1)
+    A.flush()
+    O.fdrand(n, n, n, rand_mode=1, seed=23, style=orc.KIND_UPDATE)
+    # (fdrand! zeroes first; the device matrix accumulated on top: compare against the same sequence)
+    O2 = orc.fdrand(n, n, n, rand_mode=1, seed=21, style=orc.KIND_UPDATE)
+    I3, J3, V3 = orc.fdrand_stream(n, n, n, rand_mode=1, seed=23)
+    O2.apply(np.full(len(I3), UPDATE, np.uint8), I3, J3, V3)
+    assert_csc_equal(hip_arrays(A), O2.arrays())
+
+
 @pytest.mark.parametrize("n", [96, 256])
 def test_fdrand_large_properties(esp, n):
     """BASELINE config 2 size (256^3) and a mid size: size-independent properties of the result:
