@@ -818,7 +818,7 @@ struct Sorted {
 // caller uses the 8-bit passes.  On success kout/vout hold the partitioned entries and
 // seg_out (NB+1 entries, device) the bucket starts.
 static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u64 *kout, double *vout, int K, int pb,
-                             i64 *seg_out, bool *ok) {
+                             i64 *seg_out, u64 *tile_first_out, bool *ok, i64 *maxlen_out) {
     const i64 E = h->count;
     const i64 T = ceil_div<i64>(E, esprun::TILE);
     const i64 NB = (i64)1 << pb;
@@ -874,14 +874,28 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
         sp.add(espscan::exclusive<u64, false>(h->stream, nruns, nruns, T + 1, nruns + T + 1));
         sp.add(espscan::exclusive<u64, false>(h->stream, bstart, bstart, NB + 1, bstart + NB + 1));
     }
+    // bucket starts are final here: tiles per bucket and the longest bucket come with the same sync
+    unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
+    {
+        Span sp(h, ESP_ST_SCAN);
+        HIPCK(h, hipMemcpyAsync(seg_out, bstart, sizeof(i64) * (size_t)(NB + 1), hipMemcpyDeviceToDevice, h->stream));
+        HIPCK(h, hipMemsetAsync(d_maxlen, 0, 8, h->stream));
+        hipLaunchKernelGGL(espradix::seg_tiles_k, dim3(grid_for(NB + 1, 256)), dim3(256), 0, h->stream, (const i64 *)seg_out, NB,
+                           (i64)espradix::TILE, tile_first_out, d_maxlen);
+        sp.add(1 + espscan::exclusive<u64, false>(h->stream, tile_first_out, tile_first_out, NB + 1, tile_first_out + NB + 1));
+    }
     HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_over, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipMemcpyAsync(h->pin_scalar + 1, nruns + T, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar + 2, d_maxlen, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar + 3, a.err, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     if ((u32)h->pin_scalar[0]) {
         *ok = false;
         return ESP_OK;
     }
+    if ((u32)h->pin_scalar[3]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (partition)");
     const i64 R = (i64)h->pin_scalar[1];
+    *maxlen_out = (i64)h->pin_scalar[2];
     {
         Span sp(h, ESP_ST_SCAN);
         hipLaunchKernelGGL(esprun::run_pack_k, dim3(grid_for(RM, 256)), dim3(256), 0, h->stream, (const u32 *)a.runs_d, (const u32 *)a.runs_c,
@@ -934,7 +948,6 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
         hipLaunchKernelGGL(esprun::run_scatter_k, dim3((unsigned)T), dim3(esprun::THREADS), 0, h->stream, a);
         sp.add(1);
     }
-    HIPCK(h, hipMemcpyAsync(seg_out, bstart, sizeof(i64) * (size_t)(NB + 1), hipMemcpyDeviceToDevice, h->stream));
     HIPCK(h, hipGetLastError());
     *ok = true;
     return ESP_OK;
@@ -975,6 +988,7 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     bool ok = true;
     int pass_idx = 0;
     int npass_eff = npass;
+    bool window_checked = false;
     h->last_partition = 2;
     // pre-sorted streams: the first (up to) 16 bits in ONE pass (runpart.hpp)
     if (planned > 8 && h->force_path != 5) {
@@ -986,16 +1000,9 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
             CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(S2 + 1)));
             CK(ensure(h, h->tilef[1], sizeof(u64) * (size_t)(S2 + 1 + espscan::workspace_elems(S2 + 1))));
             bool took = false;
-            CK(run_partition(h, kin, vin, kout, vout, K, pb, (i64 *)h->seg[1].p, &took));
+            i64 ml = E;
+            CK(run_partition(h, kin, vin, kout, vout, K, pb, (i64 *)h->seg[1].p, (u64 *)h->tilef[1].p, &took, &ml));
             if (took) {
-                {
-                    Span sp(h, ESP_ST_SCAN);
-                    HIPCK(h, hipMemsetAsync(d_maxlen, 0, 8, h->stream));
-                    u64 *tf = (u64 *)h->tilef[1].p;
-                    hipLaunchKernelGGL(espradix::seg_tiles_k, dim3(grid_for(S2 + 1, 256)), dim3(256), 0, h->stream, (const i64 *)h->seg[1].p,
-                                       (i64)S2, (i64)espradix::TILE, tf, d_maxlen);
-                    sp.add(1 + espscan::exclusive<u64, false>(h->stream, tf, tf, S2 + 1, tf + S2 + 1));
-                }
                 std::swap(kin, kout);
                 std::swap(vin, vout);
                 cur = 1;
@@ -1004,11 +1011,8 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
                 npass_eff = (planned - pb + 7) / 8;
                 h->last_partition = 1;
                 h->runs_penalty = 0;
-                if (npass_eff == 0) {
-                    HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_maxlen, 8, hipMemcpyDeviceToHost, h->stream));
-                    HIPCK(h, hipStreamSynchronize(h->stream));
-                    maxlen = (i64)h->pin_scalar[0];
-                }
+                maxlen = ml;
+                window_checked = true;
             } else {
                 h->runs_penalty = std::min(16, 2 * h->runs_penalty + 1);
                 h->runs_skip = h->runs_penalty;
@@ -1075,7 +1079,7 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
         }
     }
     HIPCK(h, hipGetLastError());
-    if (pass_idx > 0 || h->last_partition == 1) {  // the partition passes clamp and report keys outside the window
+    if (pass_idx > 0 && !(window_checked && pass_idx == 0)) {  // the partition passes clamp and report keys outside the window
         HIPCK(h, hipMemcpyAsync(h->pin_scalar + 2, d_werr, 4, hipMemcpyDeviceToHost, h->stream));
         HIPCK(h, hipStreamSynchronize(h->stream));
         if ((u32)h->pin_scalar[2]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (partition)");

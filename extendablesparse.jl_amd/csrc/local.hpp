@@ -461,14 +461,14 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     }
     __syncthreads();
     if (w == 0) {
-        const u32 c = gcount[lane];
+        const u32 c = lane < WAVES * ITEMS ? gcount[lane] : 0u;
         u32 inc = c;
 #pragma unroll
         for (int dlt = 1; dlt < ESP_WAVE; dlt <<= 1) {
             const u32 o = __shfl_up(inc, dlt, ESP_WAVE);
             if (lane >= dlt) inc += o;
         }
-        gcount[lane] = inc - c;
+        if (lane < WAVES * ITEMS) gcount[lane] = inc - c;
         const u32 total = (u32)__shfl((int)inc, 63, ESP_WAVE);
         // ---- decoupled look-back (wave 0): exclusive prefix of the segment totals
         u64 excl = 0;
