@@ -972,8 +972,9 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
         // one bit short of a whole number of 8-bit passes: an average fill of up to 95 % is worth
         // trying with one pass less (the longest segment is checked after the planned passes and a
         // further pass is added only if a segment really overflows)
-        if (planned > 8 && planned % 8 == 1 && (double)E / (double)((i64)1 << (planned - 1)) <= 0.95 * esplocal::CAP) planned--;
     }
+    const int planned_run = planned;  // the run-based pass takes up to 20 bits at once: no need to be tight
+    if (planned > 8 && planned % 8 == 1 && (double)E / (double)((i64)1 << (planned - 1)) <= 0.95 * esplocal::CAP) planned--;
     const int npass = (planned + 7) / 8;
 
     int cur = 0, S = 1, done = 0;
@@ -991,11 +992,11 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     bool window_checked = false;
     h->last_partition = 2;
     // pre-sorted streams: the first (up to) 16 bits in ONE pass (runpart.hpp)
-    if (planned > 8 && h->force_path != 5) {
+    if (planned_run > 8 && h->force_path != 5) {
         if (h->runs_skip > 0) {
             h->runs_skip--;
         } else {
-            const int pb = std::min(planned, 16);
+            const int pb = std::min(planned_run, 20);
             const int S2 = 1 << pb;
             CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(S2 + 1)));
             CK(ensure(h, h->tilef[1], sizeof(u64) * (size_t)(S2 + 1 + espscan::workspace_elems(S2 + 1))));
@@ -1008,6 +1009,7 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
                 cur = 1;
                 S = S2;
                 done = pb;
+                planned = std::max(planned_run, pb);
                 npass_eff = (planned - pb + 7) / 8;
                 h->last_partition = 1;
                 h->runs_penalty = 0;
@@ -1228,7 +1230,12 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     *Zn_out = Zn;
     if (a.stop_after || Zn == 0) return ESP_OK;
     if (Z0 == 0) {
-        // the scratch pair now holds rowval/nzval: rotate the buffers instead of copying
+        // the scratch pair now holds rowval/nzval: rotate the buffers instead of copying.  The old
+        // (empty) CSC arrays become the next flush's scratch pair: bring them to the same capacity
+        // once, so that the rotation never shrinks the scratch pair (a 10 GB hipMalloc per flush
+        // costs more than the flush itself)
+        CK(ensure(h, h->rowval, h->keys2.bytes));
+        CK(ensure(h, h->nzval, h->vals2.bytes));
         std::swap(h->rowval, h->keys2);
         std::swap(h->nzval, h->vals2);
         return finish_csc(h, 0, Zn, nullptr, nullptr);

@@ -25,7 +25,7 @@ constexpr int THREADS = 256;
 constexpr int WAVES = THREADS / ESP_WAVE;
 constexpr int ITEMS = 16;
 constexpr int TILE = THREADS * ITEMS;  // same tiles as espradix
-constexpr int RMAX = 16;               // distinct digits a tile may hold on this path
+constexpr int RMAX = 64;               // distinct digits a tile may hold on this path
 constexpr u32 EMPTY = 0xFFFFFFFFu;
 
 struct Args {
@@ -57,6 +57,8 @@ __global__ __launch_bounds__(THREADS) void run_hist_k(Args a) {
     __shared__ u32 rc[RMAX];
     __shared__ u32 over;
     const int t = threadIdx.x, lane = t & 63;
+    // a stream that is not pre-sorted is recognised by the first workgroups: the rest leave at once
+    if (__hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const i64 beg = (i64)blockIdx.x * TILE;
     const i64 end = min(a.E, beg + (i64)TILE);
     if (t < RMAX) {
@@ -103,48 +105,41 @@ __global__ __launch_bounds__(THREADS) void run_hist_k(Args a) {
             total += (u32)__popcll(__ballot(hit));
             pend &= hit ? ~(1u << k) : ~0u;
         }
-        if (lane == 0) {
+        if (lane == 0) {  // open addressing in the workgroup's run table
             bool placed = false;
-            for (int j = 0; j < RMAX; j++) {
+            int j = (int)((c0 * 0x9E3779B1u) >> 26) & (RMAX - 1);
+            for (int probe = 0; probe < RMAX; probe++) {
                 const u32 old = atomicCAS(&rd[j], EMPTY, c0);
                 if (old == EMPTY || old == c0) {
                     atomicAdd(&rc[j], total);
                     placed = true;
                     break;
                 }
+                j = (j + 1) & (RMAX - 1);
             }
             if (!placed) over = 1;
         }
     }
     __syncthreads();
-    if (t == 0) {
-        if (over) {
+    if (over) {
+        if (t == 0) {
             a.nruns[blockIdx.x] = 0;
             atomicExch(a.overflow, 1u);
-        } else {
-            // insertion sort of the <= RMAX runs by digit
-            u32 dd[RMAX], cc[RMAX];
-            int nr = 0;
-            for (int j = 0; j < RMAX; j++) {
-                const u32 x = rd[j];
-                if (x == EMPTY) continue;
-                const u32 c = rc[j];
-                int q = nr++;
-                while (q > 0 && dd[q - 1] > x) {
-                    dd[q] = dd[q - 1];
-                    cc[q] = cc[q - 1];
-                    q--;
-                }
-                dd[q] = x;
-                cc[q] = c;
-            }
-            for (int j = 0; j < nr; j++) {
-                a.runs_d[(i64)blockIdx.x * RMAX + j] = dd[j];
-                a.runs_c[(i64)blockIdx.x * RMAX + j] = cc[j];
-                atomicAdd(&a.bucket_count[dd[j]], (unsigned long long)cc[j]);
-            }
-            a.nruns[blockIdx.x] = (u64)nr;
         }
+        return;
+    }
+    // runs sorted by digit: every table slot ranks itself (digits are distinct)
+    if (t < RMAX) {
+        const u32 x = rd[t];
+        if (x != EMPTY) {
+            int r = 0;
+            for (int i = 0; i < RMAX; i++) r += (rd[i] < x) ? 1 : 0;  // EMPTY is the largest value
+            a.runs_d[(i64)blockIdx.x * RMAX + r] = x;
+            a.runs_c[(i64)blockIdx.x * RMAX + r] = rc[t];
+            atomicAdd(&a.bucket_count[x], (unsigned long long)rc[t]);
+        }
+        const u64 used = __ballot(x != EMPTY);
+        if (t == 0) a.nruns[blockIdx.x] = (u64)__popcll(used);
     }
 }
 
@@ -160,7 +155,7 @@ __global__ void run_pack_k(const u32 *__restrict__ runs_d, const u32 *__restrict
     const int nr = (int)((i64)run_base[tile + 1] - b);
     if (j >= nr) return;
     lk[b + j] = (u64)runs_d[g] << ESP_TAG_BITS;
-    const u64 payload = ((u64)tile << 20) | ((u64)j << 16) | (u64)runs_c[g];
+    const u64 payload = ((u64)tile << 24) | ((u64)j << 16) | (u64)runs_c[g];
     lv[b + j] = __longlong_as_double((long long)payload);
 }
 
@@ -185,13 +180,14 @@ __global__ void run_offsets_k(const u64 *__restrict__ lk, const double *__restri
     if (i >= R) return;
     const u64 d = lk[i] >> ESP_TAG_BITS;
     const u64 payload = (u64)__double_as_longlong(lv[i]);
-    const i64 tile = (i64)(payload >> 20);
-    const int j = (int)((payload >> 16) & 0xF);
+    const i64 tile = (i64)(payload >> 24);
+    const int j = (int)((payload >> 16) & 0xFF);
     runs_off[tile * RMAX + j] = (i64)(bucket_start[d] + sc[i] - head[d]);
 }
 
 __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
-    __shared__ u32 rd[RMAX];
+    __shared__ u32 hd[RMAX];  // open-addressing map digit -> run index of this tile
+    __shared__ u32 hj[RMAX];
     __shared__ i64 roff[RMAX];
     __shared__ u32 cnt[WAVES][RMAX];
     __shared__ int s_nr;
@@ -202,8 +198,8 @@ __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
     // run table of the tile (nruns holds the exclusive scan by now: nr = difference)
     if (t == 0) s_nr = (int)(a.nruns[tile + 1] - a.nruns[tile]);
     if (t < RMAX) {
-        rd[t] = a.runs_d[tile * RMAX + t];
         roff[t] = a.runs_off[tile * RMAX + t];
+        hd[t] = EMPTY;
     }
     if (t < WAVES * RMAX) (&cnt[0][0])[t] = 0;
     u64 key[ITEMS];
@@ -221,6 +217,18 @@ __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
     }
     __syncthreads();
     const int nr = s_nr;
+    if (t < nr) {  // build the map (digits of a tile are distinct)
+        const u32 dd = a.runs_d[tile * RMAX + t];
+        int j = (int)((dd * 0x9E3779B1u) >> 26) & (RMAX - 1);
+        for (int probe = 0; probe < RMAX; probe++) {
+            if (atomicCAS(&hd[j], EMPTY, dd) == EMPTY) {
+                hj[j] = (u32)t;
+                break;
+            }
+            j = (j + 1) & (RMAX - 1);
+        }
+    }
+    __syncthreads();
     const u64 lt = (1ull << lane) - 1ull;
     unsigned short rank[ITEMS];
     unsigned char jrun[ITEMS];
@@ -247,8 +255,16 @@ __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
             if (k == kk) cand = dig[k];
         const u32 c0 = (u32)__builtin_amdgcn_readlane((int)cand, fl);
         int jj = 0;
-        for (int j = 0; j < nr; j++)
-            if (rd[j] == c0) jj = j;
+        {
+            int j = (int)((c0 * 0x9E3779B1u) >> 26) & (RMAX - 1);
+            for (int probe = 0; probe < RMAX; probe++) {
+                if (hd[j] == c0) {
+                    jj = (int)hj[j];
+                    break;
+                }
+                j = (j + 1) & (RMAX - 1);
+            }
+        }
         u32 running = 0;
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
