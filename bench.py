@@ -169,7 +169,7 @@ def main():
             "data": "synthetic",
             "config": {"workload": "fdrand %d^3 Float64/Int64 fresh build: device COO append -> stable radix "
                                    "partition -> ordered fold -> CSC (BASELINE.json configs[1])" % n,
-                       "n": n, "appended_entries": E, "final_nnz": Z,
+                       "n": n, "appended_entries": E, "final_nnz": int(Z),
                        "parallelism": ("column-range shards x%d, all-to-all-v entry routing (RCCL), z-slab "
                                        "producers, global grid %dx%dx%d" % (world, n, n, n * world)) if sharded else "1 GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

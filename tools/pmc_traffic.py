@@ -14,8 +14,12 @@ import glob
 import json
 import sys
 
-STAGE_OF = {"fdrand_k": "append", "pack_k": "append", "fem_k": "append", "tile_hist_k": "hist",
-            "scatter_k": "scatter", "local_k": "local", "fold_k": "fold", "merge_k": "merge"}
+# kernel (qualified name prefix) -> stage of bench.py's "roofline.kernel"; the small launches that sort
+# the run list with the 8-bit pass kernels are kept apart from the big ones
+STAGE_OF = {"espgen::fdrand_k": "append", "espgen::pack_k": "append_pack", "espgen::fem_k": "append_fem",
+            "esprun::run_hist_k": "hist", "esprun::run_scatter_k": "scatter",
+            "espradix::tile_hist_k": "hist_pass8", "espradix::scatter_k": "scatter_pass8",
+            "esplocal::local_k": "local", "espfold::fold_k": "fold", "espmerge::merge_k": "merge"}
 
 
 def collect(run_dir, counter):
@@ -24,9 +28,9 @@ def collect(run_dir, counter):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != counter:
                 continue
-            name = r["Kernel_Name"]
+            name = r["Kernel_Name"].replace("void ", "")
             for k, st in STAGE_OF.items():
-                if k in name:
+                if name.startswith(k):
                     acc[st].append(float(r["Counter_Value"]))
     return acc
 
