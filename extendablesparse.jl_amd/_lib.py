@@ -77,6 +77,8 @@ SIGNATURES = {
     "esp_pattern_hash": (i32, [vp, P(u64)]),
     "esp_shard_counts": (i32, [vp, i32, vp]),
     "esp_shard_export": (i32, [vp, i32, vp, vp, vp]),
+    "esp_shard_exchange_begin": (i32, [vp, i32, i32, i64, i64, P(vp), P(vp), vp]),
+    "esp_shard_exchange_place": (i32, [vp, i64, vp, vp, i64]),
     "esp_timing_enable": (i32, [vp, i32]),
     "esp_timing": (i32, [vp, P(esp_timing_t), i32]),
     "esp_debug_force_path": (i32, [vp, i32]),

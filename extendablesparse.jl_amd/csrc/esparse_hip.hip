@@ -1448,6 +1448,85 @@ extern "C" int32_t esp_shard_export(esp_handle *h, int32_t nshards, uint64_t *d_
     return ESP_OK;
 }
 
+// In-place exchange (avoids copying what a rank owns itself).  The pending entries are partitioned by
+// owner: this rank's own chunk goes straight to its final place behind the `recv_lower` entries it
+// will receive from lower ranks, the other chunks go, compacted in owner order, to a send region
+// behind the new pending area of the same buffers.  The caller exchanges the send region (RCCL) and
+// drops the received chunks in with esp_shard_exchange_place.
+__global__ void add_digit_delta_k(u64 *hist, i64 T, int R, const i64 *__restrict__ delta) {
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= T * R) return;
+    hist[g] += (u64)delta[g / T];
+}
+
+extern "C" int32_t esp_shard_exchange_begin(esp_handle *h, int32_t nshards, int32_t self, int64_t recv_lower,
+                                            int64_t recv_higher, uint64_t **d_send_keys, double **d_send_vals,
+                                            int64_t *send_offsets) {
+    if (!h || !d_send_keys || !d_send_vals || !send_offsets) return ESP_ERR_INVALID;
+    if (self < 0 || self >= nshards || recv_lower < 0 || recv_higher < 0) FAIL(h, ESP_ERR_INVALID, "esp_shard_exchange_begin: arguments");
+    (void)hipSetDevice(h->device);
+    espradix::Pass p;
+    CK(shard_prepare(h, nshards, &p));
+    std::vector<int64_t> off((size_t)nshards + 1);
+    CK(shard_offsets(h, nshards, off.data()));
+    const i64 E = h->count;
+    const i64 own = off[(size_t)self + 1] - off[(size_t)self];
+    const i64 others = E - own;
+    const i64 newcount = recv_lower + own + recv_higher;
+    const i64 SR = newcount;  // send region starts behind the new pending area
+    CK(ensure(h, h->keys2, sizeof(u64) * (size_t)(SR + others + 1)));
+    CK(ensure(h, h->vals2, sizeof(double) * (size_t)(SR + others + 1)));
+    const int R = 1 << p.bits;
+    std::vector<i64> delta((size_t)R, 0);
+    i64 sent = 0;
+    for (int d = 0; d < nshards; d++) {
+        const i64 start = off[(size_t)d], cnt = off[(size_t)d + 1] - start;
+        send_offsets[d] = sent;
+        if (d == self) {
+            delta[(size_t)d] = recv_lower - start;
+        } else {
+            delta[(size_t)d] = SR + sent - start;
+            sent += cnt;
+        }
+    }
+    send_offsets[nshards] = sent;
+    if (E > 0) {
+        const i64 T = ceil_div<i64>(E, espradix::TILE);
+        CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(R + 1)));
+        HIPCK(h, hipMemcpyAsync(h->seg[1].p, delta.data(), sizeof(i64) * (size_t)R, hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(add_digit_delta_k, dim3(grid_for(T * R, 256)), dim3(256), 0, h->stream, p.hist, T, R, (const i64 *)h->seg[1].p);
+        p.keys_out = (u64 *)h->keys2.p;
+        p.vals_out = (double *)h->vals2.p;
+        Span sp(h, ESP_ST_SCATTER);
+        hipLaunchKernelGGL(espradix::scatter_k, dim3((unsigned)T), dim3(espradix::THREADS), 0, h->stream, p);
+        sp.add(1);
+        HIPCK(h, hipGetLastError());
+    }
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    // the partitioned buffers become the pending buffers
+    std::swap(h->keys, h->keys2);
+    std::swap(h->vals, h->vals2);
+    h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
+    h->count = newcount;
+    h->shard_valid = false;
+    *d_send_keys = (uint64_t *)h->keys.p + SR;
+    *d_send_vals = (double *)h->vals.p + SR;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_shard_exchange_place(esp_handle *h, int64_t position, const uint64_t *d_keys, const double *d_vals,
+                                            int64_t count) {
+    if (!h || position < 0 || count < 0 || position + count > h->count) return ESP_ERR_INVALID;
+    if (count == 0) return ESP_OK;
+    (void)hipSetDevice(h->device);
+    Span sp(h, ESP_ST_COPY);
+    HIPCK(h, hipMemcpyAsync((u64 *)h->keys.p + position, d_keys, sizeof(u64) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync((double *)h->vals.p + position, d_vals, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
+    sp.add(2);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return ESP_OK;
+}
+
 // ------------------------------------------------------------------------ measurement
 extern "C" int32_t esp_timing_enable(esp_handle *h, int32_t on) {
     if (!h) return ESP_ERR_INVALID;

@@ -69,6 +69,19 @@ def all_to_all_v(dist, out, inp, out_splits, in_splits, group=None, max_elems=A2
     return rounds
 
 
+class _DevArray:
+    """__cuda_array_interface__ view of library-owned device memory (no copy, no ownership)."""
+
+    def __init__(self, ptr, n, typestr):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def _wrap_device(torch, ptr, n, dtype, device):
+    if n == 0:
+        return torch.empty(0, dtype=dtype, device=device)
+    return torch.as_tensor(_DevArray(ptr, n, "<i8" if dtype == torch.int64 else "<f8"), device=device)
+
+
 class HipShardBackend:
     """Local operations of one shard on its GPU, through the C ABI."""
 
@@ -108,17 +121,41 @@ class HipShardBackend:
                                     offsets.ctypes.data_as(C.c_void_p)))
         return keys, vals, offsets
 
-    def replace_pending(self, keys, vals):
+    def replace_pending(self, pieces):
+        """pending := concatenation of the (keys, vals) device pieces, in order."""
         d = self.A._d
         self.torch.cuda.synchronize(self.device)  # the collective ran on torch's stream
         d.ck(d.lib.esp_clear_pending(d.h))
-        if keys.numel():
-            d.ck(d.lib.esp_append_packed(d.h, C.c_void_p(keys.data_ptr()), C.c_void_p(vals.data_ptr()), keys.numel()))
-            d.ck(d.lib.esp_synchronize(d.h))  # the copy is done before the tensors may be freed
+        for keys, vals in pieces:
+            if keys.numel():
+                d.ck(d.lib.esp_append_packed(d.h, C.c_void_p(keys.data_ptr()), C.c_void_p(vals.data_ptr()), keys.numel()))
+        d.ck(d.lib.esp_synchronize(d.h))  # the copies are done before the tensors may be freed
         self.A._touch()
 
     def set_column_window(self, col_lo, col_hi):
         self.A.set_column_window(col_lo, col_hi)
+
+    # -- in-place exchange (the own chunk is not copied): see esp_shard_exchange_begin
+    def exchange_begin(self, P, me, recv_lower, recv_higher):
+        torch = self.torch
+        d = self.A._d
+        d.commit()
+        pk, pv = C.c_void_p(), C.c_void_p()
+        soff = np.zeros(P + 1, np.int64)
+        d.ck(d.lib.esp_shard_exchange_begin(d.h, P, me, int(recv_lower), int(recv_higher), C.byref(pk), C.byref(pv),
+                                            soff.ctypes.data_as(C.c_void_p)))
+        n = int(soff[-1])
+        keys = _wrap_device(torch, pk.value, n, torch.int64, self.device)
+        vals = _wrap_device(torch, pv.value, n, torch.float64, self.device)
+        self.A._touch()
+        return keys, vals, soff
+
+    def exchange_place(self, position, keys, vals):
+        d = self.A._d
+        if keys.numel():
+            self.torch.cuda.synchronize(self.device)
+            d.ck(d.lib.esp_shard_exchange_place(d.h, int(position), C.c_void_p(keys.data_ptr()), C.c_void_p(vals.data_ptr()),
+                                                keys.numel()))
 
     def flush(self):
         self.A.flush()
@@ -167,6 +204,47 @@ class ShardedExtendableSparseMatrix:
     def flush(self):
         import torch
         dist, P, be = self.dist, self.P, self.backend
+        me = self.rank
+        if hasattr(be, "exchange_begin"):
+            # counts first, then the in-place partition (own chunk stays on the device where it is)
+            counts = be.shard_counts(P)
+            send_counts = torch.from_numpy(counts.astype(np.int64))
+            dev = be.device
+            rc = torch.empty(P, dtype=torch.int64, device=dev)
+            dist.all_to_all_single(rc, send_counts.to(dev), group=self.group)
+            out_splits = rc.cpu().tolist()
+            in_splits = counts.tolist()
+            out_x = list(out_splits)
+            out_x[me] = 0
+            in_x = list(in_splits)
+            in_x[me] = 0
+            lower, higher = int(sum(out_x[:me])), int(sum(out_x[me + 1:]))
+            skeys, svals, soff = be.exchange_begin(P, me, lower, higher)
+            rkeys = be.empty(lower + higher, torch.int64)
+            rvals = be.empty(lower + higher, torch.float64)
+            all_to_all_v(dist, rkeys, skeys, out_x, in_x, self.group)
+            all_to_all_v(dist, rvals, svals, out_x, in_x, self.group)
+            be.exchange_place(0, rkeys[:lower], rvals[:lower])
+            be.exchange_place(lower + in_splits[me], rkeys[lower:], rvals[lower:])
+            self.exchanged = (int(sum(in_splits)), int(sum(out_splits)))
+            self.sent_off_rank = int(sum(in_x))
+        else:
+            self._flush_exchange_generic()
+        self.local_nnz = be.flush()
+        # global colptr offsets: exclusive scan of the per-shard nnz
+        dev = getattr(be, "device", None)
+        mine = torch.tensor([self.local_nnz], dtype=torch.int64, device=dev if dev is not None else "cpu")
+        allnnz = [torch.empty_like(mine) for _ in range(P)]
+        dist.all_gather(allnnz, mine, group=self.group)
+        counts = np.array([int(t.item()) for t in allnnz], np.int64)
+        self.nnz_offsets = np.concatenate([[0], np.cumsum(counts)])
+        return self
+
+
+    def _flush_exchange_generic(self):
+        """Exchange through export buffers (any backend): used by the CPU tests."""
+        import torch
+        dist, P, be = self.dist, self.P, self.backend
         keys, vals, offsets = be.shard_export(P)
         send_counts = torch.from_numpy(np.diff(offsets).astype(np.int64))
         recv_counts = torch.empty(P, dtype=torch.int64)
@@ -179,21 +257,32 @@ class ShardedExtendableSparseMatrix:
             dist.all_to_all_single(recv_counts, send_counts, group=self.group)
         in_splits = send_counts.tolist()
         out_splits = recv_counts.tolist()
-        nrecv = int(sum(out_splits))
+        # the chunk a rank owns itself never enters the collective (in a slab-wise assembly that is
+        # almost everything): it is appended straight from the export buffer, in rank position
+        me = self.rank
+        own = in_splits[me]
+        assert out_splits[me] == own
+        in_x = list(in_splits)
+        out_x = list(out_splits)
+        in_x[me] = 0
+        out_x[me] = 0
+        own_lo = int(offsets[me])
+        if own:
+            skeys = torch.cat([keys[:own_lo], keys[own_lo + own:]]) if sum(in_x) else keys[:0]
+            svals = torch.cat([vals[:own_lo], vals[own_lo + own:]]) if sum(in_x) else vals[:0]
+        else:
+            skeys, svals = keys, vals
+        nrecv = int(sum(out_x))
         rkeys = be.empty(nrecv, torch.int64)
         rvals = be.empty(nrecv, torch.float64)
-        all_to_all_v(dist, rkeys, keys, out_splits, in_splits, self.group)
-        all_to_all_v(dist, rvals, vals, out_splits, in_splits, self.group)
-        self.exchanged = (int(sum(in_splits)), nrecv)
-        be.replace_pending(rkeys, rvals)
-        self.local_nnz = be.flush()
-        # global colptr offsets: exclusive scan of the per-shard nnz
-        mine = torch.tensor([self.local_nnz], dtype=torch.int64, device=dev if dev.type == "cuda" else "cpu")
-        allnnz = [torch.empty_like(mine) for _ in range(P)]
-        dist.all_gather(allnnz, mine, group=self.group)
-        counts = np.array([int(t.item()) for t in allnnz], np.int64)
-        self.nnz_offsets = np.concatenate([[0], np.cumsum(counts)])
-        return self
+        all_to_all_v(dist, rkeys, skeys, out_x, in_x, self.group)
+        all_to_all_v(dist, rvals, svals, out_x, in_x, self.group)
+        self.exchanged = (int(sum(in_splits)), int(sum(out_splits)))
+        self.sent_off_rank = int(sum(in_x))
+        lower = int(sum(out_x[:me]))
+        be.replace_pending([(rkeys[:lower], rvals[:lower]),
+                            (keys[own_lo:own_lo + own], vals[own_lo:own_lo + own]),
+                            (rkeys[lower:], rvals[lower:])])
 
     def nnz(self):
         return int(self.nnz_offsets[-1])

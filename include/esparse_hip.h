@@ -170,6 +170,18 @@ int32_t esp_pattern_hash(esp_handle *h, uint64_t *hash);
 int32_t esp_shard_counts(esp_handle *h, int32_t nshards, int64_t *counts);
 int32_t esp_shard_export(esp_handle *h, int32_t nshards, uint64_t *d_keys, double *d_vals,
                          int64_t *offsets);
+/* In-place form of the exchange: what this rank owns itself is not copied twice.  After the counts
+ * were exchanged the caller knows how many entries arrive from lower / higher ranks.  The pending
+ * entries are partitioned by owner; the own chunk lands at its final position recv_lower, the other
+ * chunks (compacted, owner order; send_offsets has nshards+1 entries, the own chunk counts 0) in a
+ * send region returned as device pointers that stay valid until the next append or flush.  The
+ * received chunks are then dropped in with esp_shard_exchange_place (lower ranks at position 0,
+ * higher ranks behind the own chunk). */
+int32_t esp_shard_exchange_begin(esp_handle *h, int32_t nshards, int32_t self, int64_t recv_lower,
+                                 int64_t recv_higher, uint64_t **d_send_keys, double **d_send_vals,
+                                 int64_t *send_offsets);
+int32_t esp_shard_exchange_place(esp_handle *h, int64_t position, const uint64_t *d_keys,
+                                 const double *d_vals, int64_t count);
 
 /* promise: every pending entry of the following flushes has its column in [col_lo, col_hi]
  * (1-based); the partition then works on that window only.  Violations -> ESP_ERR_STATE. */

@@ -614,3 +614,55 @@ def test_all_to_all_large_message(esp):
         assert rounds > 1 and torch.equal(a, b)
     finally:
         dist.destroy_process_group()
+
+
+def test_inplace_exchange_three_shards_on_one_gpu(esp, orc):
+    """esp_shard_exchange_begin/place with P=3, emulating the all-to-all between three handles that
+    live on the same GPU (device-to-device copies in place of RCCL): every shard must end up with
+    exactly the entries of its column range, in (source rank, source order)."""
+    import torch
+    P = 3
+    m, n = 500, 900
+    rng = np.random.default_rng(77)
+    bes = [esp.HipShardBackend(m, n) for _ in range(P)]
+    streams = []
+    for r in range(P):
+        cnt = 20000 + 3000 * r
+        I = rng.integers(1, m + 1, cnt)
+        J = rng.integers(1, n + 1, cnt)
+        V = rng.standard_normal(cnt)
+        K = rng.integers(0, 3, cnt).astype(np.uint8)
+        bes[r].matrix.append(0, I, J, V, kinds=K)
+        streams.append((K, I, J, V))
+    counts = np.stack([be.shard_counts(P) for be in bes])          # counts[src][dst]
+    sends = []
+    for r in range(P):
+        lower = int(sum(counts[s][r] for s in range(r)))
+        higher = int(sum(counts[s][r] for s in range(r + 1, P)))
+        keys, vals, soff = bes[r].exchange_begin(P, r, lower, higher)
+        assert soff[-1] == counts[r].sum() - counts[r][r]
+        sends.append((keys, vals, soff, lower))
+    torch.cuda.synchronize()
+    for dst in range(P):
+        pos_lo, pos_hi = 0, sends[dst][3] + int(counts[dst][dst])
+        for src in range(P):
+            if src == dst:
+                continue
+            k, v, soff, _ = sends[src]
+            ck, cv = k[soff[dst]:soff[dst + 1]].clone(), v[soff[dst]:soff[dst + 1]].clone()
+            if src < dst:
+                bes[dst].exchange_place(pos_lo, ck, cv)
+                pos_lo += ck.numel()
+            else:
+                bes[dst].exchange_place(pos_hi, ck, cv)
+                pos_hi += ck.numel()
+    ranges = esp.owner_ranges(n, P)
+    for dst in range(P):
+        c0, c1 = ranges[dst]
+        bes[dst].set_column_window(c0 + 1, c1)
+        bes[dst].flush()
+        O = orc.ExtendableSparseMatrix(m, n)
+        for (K, I, J, V) in streams:                               # rank order, owned columns only
+            sel = (J - 1 >= c0) & (J - 1 < c1)
+            O.apply(K[sel], I[sel], J[sel], V[sel])
+        assert_csc_equal(bes[dst].local_csc().arrays(), O.arrays(), "shard %d" % dst)

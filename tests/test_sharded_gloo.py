@@ -57,9 +57,9 @@ class CpuShardBackend:
         offsets = np.concatenate([[0], np.cumsum(np.bincount(owner, minlength=P))]).astype(np.int64)
         return torch.from_numpy(self.keys[order].copy()), torch.from_numpy(self.vals[order].copy()), offsets
 
-    def replace_pending(self, keys, vals):
-        self.keys = keys.numpy().copy()
-        self.vals = vals.numpy().copy()
+    def replace_pending(self, pieces):
+        self.keys = np.concatenate([k.numpy() for k, _ in pieces]).astype(np.int64)
+        self.vals = np.concatenate([v.numpy() for _, v in pieces]).astype(np.float64)
 
     def flush(self):
         kinds = (self.keys & 3).astype(np.uint8)
