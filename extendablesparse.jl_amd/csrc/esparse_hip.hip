@@ -1208,10 +1208,17 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         {
             const char *e = getenv("ESP_LOCAL_STOP");
             a.stop_after = e ? atoi(e) : 0;
+            a.stamps = nullptr;
+            if (getenv("ESP_LOCAL_STAMPS")) {  // diagnostics: per-segment phase stamps, dumped to a file
+                CK(ensure(h, h->heads, sizeof(u64) * (size_t)S * 8));
+                HIPCK(h, hipMemsetAsync(h->heads.p, 0, sizeof(u64) * (size_t)S * 8, h->stream));
+                a.stamps = (unsigned long long *)h->heads.p;
+            }
         }
         const i64 max_grid = h->force_path == 4 ? 64 : esplocal::MAX_GRID;  // 4: test hook, many launches
         for (i64 first = 0; first < S; first += max_grid) {
             const unsigned grid = (unsigned)std::min<i64>(max_grid, S - first);
+            a.first = first;
             if (Z0 == 0)
                 hipLaunchKernelGGL((esplocal::local_k<true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
             else
@@ -1223,6 +1230,14 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     HIPCK(h, hipMemcpyAsync(h->pin_scalar + 2, (u32 *)h->misc.p + 60, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     if ((u32)h->pin_scalar[2]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window");
+    if (a.stamps) {
+        std::vector<u64> st((size_t)S * 8);
+        HIPCK(h, hipMemcpy(st.data(), a.stamps, sizeof(u64) * st.size(), hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(getenv("ESP_LOCAL_STAMPS"), "wb")) {
+            fwrite(st.data(), sizeof(u64), st.size(), f);
+            fclose(f);
+        }
+    }
     const u32 lookback_err = (u32)(h->pin_scalar[1] >> 32);
     if (lookback_err & 2u) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (bucket)");
     if (lookback_err & 1u) FAIL(h, ESP_ERR_HIP, "esp_flush: look-back chain timed out inside the bucket kernel");

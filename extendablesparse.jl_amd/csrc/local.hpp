@@ -96,6 +96,8 @@ struct Args {
     u32 *ticket;     // zeroed before launch
     u32 *err;        // set to 1 if a look-back spin ran into its bound
     int stop_after;  // timing ablation only (0 = run everything)
+    i64 first;       // ticket value the first workgroup of this launch is expected to draw
+    unsigned long long *stamps;  // diagnostics: 8 wall-clock stamps per segment (null in production)
 };
 
 // Stable LSD radix tail on the packed keys held in registers (wave-striped arrangement):
@@ -189,6 +191,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     __shared__ u32 gcount[WAVES * ITEMS];
     __shared__ u64 s_dst;
     __shared__ int s_seg;
+    __shared__ i64 s_win[66];
     u32(*cnt)[256] = reinterpret_cast<u32(*)[256]>(cntraw);
     u32 *ccnt = cntraw;
 
@@ -196,12 +199,21 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     // claim a segment in start order: every predecessor of a look-back chain has started
     // (a flush with more than MAX_GRID segments is issued as several launches; the ticket counter
     // and the look-back granules carry over from one launch to the next)
+    // The segment starts around the expected ticket (launch offset + blockIdx) are fetched while the
+    // ticket atomic is in flight: two dependent round trips become one (speed only -- a ticket
+    // outside the window simply reloads).
+    constexpr int WIN = 64;
+    const i64 w0 = max((i64)0, a.first + (i64)blockIdx.x - WIN / 2);
+    if (t <= WIN + 1 && w0 + t <= (i64)a.S) s_win[t] = a.seg_start[w0 + t];
     if (t == 0) s_seg = (int)atomicAdd(a.ticket, 1u);
     __syncthreads();
     const int s = s_seg;
     if (s >= a.S) return;
-    const i64 beg = a.seg_start[s];
-    const int n = (int)(a.seg_start[s + 1] - beg);
+    const bool inwin = s >= w0 && (i64)s + 1 <= w0 + WIN + 1;
+    const i64 beg = inwin ? s_win[s - w0] : a.seg_start[s];
+    const i64 seg_end = inwin ? s_win[s - w0 + 1] : a.seg_start[s + 1];
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 0] = wall_clock64();
+    const int n = (int)(seg_end - beg);
     const u64 submask = a.rem_bits >= 64 ? ~0ull : ((1ull << a.rem_bits) - 1ull);
     // shared prefix of the segment (window-relative), turned back into an absolute key prefix
     const u64 hi = n > 0 ? (((((a.keys_in[beg] >> ESP_TAG_BITS) - a.base) >> a.rem_bits) << a.rem_bits) + a.base) : 0;
@@ -209,13 +221,21 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     const u64 lt = (1ull << lane) - 1ull;
     const u64 rowmask = (1ull << a.rb) - 1ull;
 
+    // all 16 loads of a thread are issued before anything depends on them: the index is clamped so
+    // that the loads need no branch (slots past the end re-read the last entry and are discarded)
     u64 k[ITEMS];
+    double vraw[ITEMS];
+    const int nlast = n > 0 ? n - 1 : 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) k[i] = n > 0 ? a.keys_in[beg + min(wbase + i * ESP_WAVE, nlast)] : 0ull;
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) vraw[i] = n > 0 ? a.vals_in[beg + min(wbase + i * ESP_WAVE, nlast)] : 0.0;
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const int p = wbase + i * ESP_WAVE;
         if (p < n) {
-            const u64 key = a.keys_in[beg + p];
-            sval[p] = a.vals_in[beg + p];
+            const u64 key = k[i];
+            sval[p] = vraw[i];
             const u64 kn = (key >> ESP_TAG_BITS) - a.base;
             // every entry of a segment shares the segment's prefix; anything else is an entry outside
             // the declared key window (reported to the host, which rejects the flush)
@@ -225,6 +245,8 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             k[i] = NOREC;  // sorts behind every real entry (stable: real entries come first on ties)
         }
     }
+    if (a.stamps) { __syncthreads(); }
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 1] = wall_clock64();
     bool done = n == 0;
     if (a.stop_after == 1) done = true;
 
@@ -277,12 +299,14 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         }
         if (t == 0) ccnt[ncl] = (u32)n;
         __syncthreads();
+        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 2] = wall_clock64();
         if (a.stop_after == 2) done = true;
         if (!done && maxrun <= RANK_MAX) {
 #pragma unroll
             for (int i = 0; i < ITEMS; i++)
                 if (wbase + i * ESP_WAVE < n) skey[ccnt[(u32)(k[i] >> csh)] + slot[i]] = k[i];
             __syncthreads();
+            if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 3] = wall_clock64();
             if (a.stop_after == 3) done = true;
             if (!done && maxrun <= REG_RUN) {
                 // one lane per column: the whole run in registers, sorting network + ordered fold
@@ -443,6 +467,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         }
         __syncthreads();
     }
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 4] = wall_clock64();
     if (a.stop_after == 4) {
         if (t == 0 && s == a.S - 1) __hip_atomic_store(&a.status[s], ST_PRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -461,6 +486,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     }
     __syncthreads();
     if (w == 0) {
+        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 5] = wall_clock64();
         const u32 c = lane < WAVES * ITEMS ? gcount[lane] : 0u;
         u32 inc = c;
 #pragma unroll
@@ -520,6 +546,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         }
     }
     __syncthreads();
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 6] = wall_clock64();
     const u64 dst = s_dst;
     const int total = (int)lw[0];
     // dense prefix in LDS (all records and values are in registers: in-place is safe)
@@ -548,6 +575,10 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             else
                 atomicMax((unsigned long long *)&a.colend[col], (unsigned long long)(dst + (u64)p + 1));
         }
+    }
+    if (a.stamps) {
+        __syncthreads();
+        if (threadIdx.x == 0) a.stamps[(size_t)s * 8 + 7] = wall_clock64();
     }
 }
 
