@@ -42,7 +42,11 @@ struct esp_handle {
     // ping-pong / scratch
     DevBuf keys2, vals2, hist, segs, colend, newkey, newval, heads, misc, seg[2], tilef[2], segcnt, segout;
     int force_path = 0, last_path = 0;
-    DevBuf runbuf;
+    DevBuf runbuf, chunkbuf;
+    i64 chunk_cap = 0, fused_chunks = 0, hint = 0;
+    int chunk_pb = 0, fused_K = 0;
+    int fused_state = 0;  // 0 no pending data, 1 every pending entry came with its run list, 2 mixed/stale
+    int last_fused = 0;
     int runs_skip = 0, runs_penalty = 0;  // back-off after a stream turned out not to be pre-sorted
     int last_partition = 0;               // 1 = run-based single pass, 2 = 8-bit passes only
     // column window of the pending entries (whole matrix by default)
@@ -70,6 +74,10 @@ struct esp_handle {
 };
 
 static thread_local std::string g_err;
+
+static bool fused_begin(esp_handle *h, i64 E_call, i64 nchunks, espgen::Fused *f);
+static void fused_invalidate(esp_handle *h);
+static void fused_reset(esp_handle *h);
 
 #define FAIL(h, code, ...)                                   \
     do {                                                     \
@@ -216,6 +224,7 @@ extern "C" int32_t esp_create(int64_t m, int64_t n, int32_t device, int64_t capa
     h->L = KeyLayout{rb, cb};
     h->win_base = 0;
     h->win_span = (u64)std::max<i64>(n, 1) << rb;
+    h->hint = capacity_hint > 0 ? capacity_hint : 0;
     memset(&h->acc, 0, sizeof h->acc);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
@@ -248,7 +257,7 @@ extern "C" int32_t esp_destroy(esp_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->keys, &h->vals, &h->keys2, &h->vals2, &h->hist, &h->segs, &h->colend, &h->newkey,
                       &h->newval, &h->heads, &h->misc, &h->colptr, &h->rowval, &h->nzval, &h->rowval2,
-                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->runbuf, &h->d_st_rows, &h->d_st_cols, &h->d_st_vals, &h->d_st_kinds})
+                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->runbuf, &h->chunkbuf, &h->d_st_rows, &h->d_st_cols, &h->d_st_vals, &h->d_st_kinds})
         release(*b);
     if (h->st_rows) (void)hipHostFree(h->st_rows);
     if (h->st_cols) (void)hipHostFree(h->st_cols);
@@ -345,6 +354,7 @@ static int32_t pack_device(esp_handle *h, const i64 *d_rows, const i64 *d_cols, 
     }
     HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
+    fused_invalidate(h);
     if (h->pin_scalar[0] != ~0ull)
         FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
              (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
@@ -453,6 +463,7 @@ extern "C" int32_t esp_append_packed(esp_handle *h, const uint64_t *d_keys, cons
     HIPCK(h, hipMemcpyAsync((u64 *)h->keys.p + h->count, d_keys, sizeof(u64) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
     HIPCK(h, hipMemcpyAsync((double *)h->vals.p + h->count, d_vals, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
     sp.add(2);
+    fused_invalidate(h);
     h->count += count;
     h->shard_valid = false;
     return ESP_OK;
@@ -509,6 +520,8 @@ extern "C" int32_t esp_generate_fdrand_range(esp_handle *h, int64_t nx, int64_t 
     a.L = h->L;
     a.keys = (u64 *)h->keys.p + h->count;
     a.vals = (double *)h->vals.p + h->count;
+    CK(ensure(h, h->misc, 256));
+    if (!fused_begin(h, E, (i64)grid_for(node_end - node_begin, espgen::THREADS), &a.fused)) fused_invalidate(h);
     {
         Span sp(h, ESP_ST_APPEND);
         hipLaunchKernelGGL(espgen::fdrand_k, dim3(grid_for(node_end - node_begin, espgen::THREADS)), dim3(espgen::THREADS), 0, h->stream, a);
@@ -566,6 +579,7 @@ extern "C" int32_t esp_generate_fem(esp_handle *h, int32_t dim, int64_t npd, uin
         sp.add(1);
     }
     HIPCK(h, hipGetLastError());
+    fused_invalidate(h);
     h->count += E;
     h->shard_valid = false;
     return ESP_OK;
@@ -629,6 +643,7 @@ extern "C" int32_t esp_csc_device(esp_handle *h, const int64_t **d_colptr, const
 
 extern "C" int32_t esp_clear_pending(esp_handle *h) {
     if (!h) return ESP_ERR_INVALID;
+    fused_reset(h);
     h->count = 0;
     h->shard_valid = false;
     return ESP_OK;
@@ -637,6 +652,7 @@ extern "C" int32_t esp_clear_pending(esp_handle *h) {
 extern "C" int32_t esp_reset(esp_handle *h) {
     if (!h) return ESP_ERR_INVALID;
     (void)hipSetDevice(h->device);
+    fused_reset(h);
     h->count = 0;
     h->shard_valid = false;
     return init_empty_csc(h);
@@ -813,65 +829,178 @@ struct Sorted {
     bool local_ok;
 };
 
-// Single-pass partition on the top `pb` (9..16) bits of the key window, for pre-sorted streams
-// (runpart.hpp).  *ok=false when some tile holds too many distinct digits: nothing was moved and the
-// caller uses the 8-bit passes.  On success kout/vout hold the partitioned entries and
-// seg_out (NB+1 entries, device) the bucket starts.
-static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u64 *kout, double *vout, int K, int pb,
-                             i64 *seg_out, u64 *tile_first_out, bool *ok, i64 *maxlen_out) {
-    const i64 E = h->count;
-    const i64 T = ceil_div<i64>(E, esprun::TILE);
+// ---- run lists of the pending entries (runpart.hpp) -------------------------------------------
+// Persistent per-handle arrays: the chunk boundaries, every chunk's runs, the bucket totals.  They
+// are filled either by run_hist_k at flush time or, chunk by chunk, by the producers themselves
+// ("fused": the flush then skips the histogram kernel, i.e. one full read of the keys).
+struct ChunkArrays {
+    i64 *chunk_start;
+    u32 *runs_d, *runs_c;
+    u64 *nruns;
+    unsigned long long *bucket_count;
+    u32 *overflow;
+};
+
+static int32_t chunk_arrays(esp_handle *h, i64 Ccap, int pb, ChunkArrays *out) {
     const i64 NB = (i64)1 << pb;
-    const i64 RM = T * esprun::RMAX;
-    // carve the bookkeeping buffer
+    const i64 RM = Ccap * esprun::RMAX;
     size_t off = 0;
     auto carve = [&](size_t bytes) {
         size_t o = off;
         off += (bytes + 255) & ~(size_t)255;
         return o;
     };
+    const size_t o_cs = carve(sizeof(i64) * (size_t)(Ccap + 2));
     const size_t o_rd = carve(sizeof(u32) * (size_t)RM), o_rc = carve(sizeof(u32) * (size_t)RM);
-    const size_t o_ro = carve(sizeof(i64) * (size_t)RM);
-    const size_t o_nr = carve(sizeof(u64) * (size_t)(T + 1 + espscan::workspace_elems(T + 1)));
+    const size_t o_nr = carve(sizeof(u64) * (size_t)(Ccap + 1 + espscan::workspace_elems(Ccap + 1)));
     const size_t o_bc = carve(sizeof(u64) * (size_t)(NB + 1 + espscan::workspace_elems(NB + 1)));
+    const size_t o_ov = carve(64);
+    if (h->chunkbuf.bytes < off || h->chunk_cap != Ccap || h->chunk_pb != pb) {
+        if (h->fused_state == 1) FAIL(h, ESP_ERR_STATE, "internal: run-list arrays resized while they hold producer data");
+        CK(ensure(h, h->chunkbuf, off));
+        h->chunk_cap = Ccap;
+        h->chunk_pb = pb;
+    }
+    char *B = (char *)h->chunkbuf.p;
+    out->chunk_start = (i64 *)(B + o_cs);
+    out->runs_d = (u32 *)(B + o_rd);
+    out->runs_c = (u32 *)(B + o_rc);
+    out->nruns = (u64 *)(B + o_nr);
+    out->bucket_count = (unsigned long long *)(B + o_bc);
+    out->overflow = (u32 *)(B + o_ov);
+    return ESP_OK;
+}
+
+// bits the run-based pass would resolve for E pending entries in a K-bit key window (0: not used)
+static int plan_run_bits(i64 E, int K) {
+    int planned = 0;
+    if (E > esplocal::CAP) {
+        const double target = 0.8 * esplocal::CAP;
+        while (planned < K && (double)E / (double)((i64)1 << planned) > target) planned++;
+    }
+    return planned > 8 ? std::min(planned, 20) : 0;
+}
+static int window_bits(const esp_handle *h) {
+    int K = 1;
+    while (K < 62 && ((u64)1 << K) < h->win_span) K++;
+    return K;
+}
+
+// a producer asks to emit the run lists of the `nchunks` chunks it is about to write
+// (E_call entries at the end of the buffer).  Returns false when fusion is not possible.
+static bool fused_begin(esp_handle *h, i64 E_call, i64 nchunks, espgen::Fused *f) {
+    memset(f, 0, sizeof *f);
+    // Off by default: measured on MI355X (256^3) the generator gets slower by what the histogram
+    // kernel cost (both are issue-bound, not bandwidth-bound), the step time does not move.
+    // force_path 7 switches it on (tests keep the path alive for a cheaper counting scheme).
+    if (h->force_path != 7 || h->fused_state == 2) return false;
+    const int K = window_bits(h);
+    if (h->fused_state == 0) {  // first producer of a batch decides the digit width
+        if (h->count != 0) return false;
+        const i64 E_expect = std::max<i64>(h->hint, E_call);  // the caller's capacity hint = expected batch size
+        const int pb = plan_run_bits(E_expect, K);
+        if (pb == 0) return false;
+        const i64 Ccap = std::max<i64>(nchunks, E_expect / 1024) + 64;
+        ChunkArrays ca;
+        if (chunk_arrays(h, Ccap, pb, &ca) != ESP_OK) return false;
+        if (hipMemsetAsync(ca.bucket_count, 0, sizeof(u64) * (size_t)(((i64)1 << pb) + 1), h->stream) != hipSuccess) return false;
+        if (hipMemsetAsync(ca.overflow, 0, 4, h->stream) != hipSuccess) return false;
+        if (hipMemsetAsync((u32 *)h->misc.p + 60, 0, 4, h->stream) != hipSuccess) return false;
+        h->fused_chunks = 0;
+        h->fused_K = K;
+    } else if (h->fused_K != K || h->fused_chunks + nchunks > h->chunk_cap) {
+        h->fused_state = 2;
+        return false;
+    }
+    ChunkArrays ca;
+    if (chunk_arrays(h, h->chunk_cap, h->chunk_pb, &ca) != ESP_OK) return false;
+    f->runs = esprun::RunSink{ca.runs_d, ca.runs_c, ca.nruns, ca.bucket_count, ca.overflow};
+    f->chunk_start = ca.chunk_start;
+    f->chunk_base = h->fused_chunks;
+    f->buf_base = h->count;
+    f->shift = K - h->chunk_pb;
+    f->base = h->win_base;
+    f->span = h->win_span;
+    f->err = (u32 *)h->misc.p + 60;
+    h->fused_state = 1;
+    h->fused_chunks += nchunks;
+    return true;
+}
+// any append that does not emit run lists, and every consumption of the buffer
+static void fused_invalidate(esp_handle *h) {
+    if (h->count > 0 || h->fused_state == 1) h->fused_state = 2;
+}
+static void fused_reset(esp_handle *h) {
+    h->fused_state = 0;
+    h->fused_chunks = 0;
+}
+
+// Single-pass partition on the top `pb` (9..20) bits of the key window, for pre-sorted streams
+// (runpart.hpp).  *ok=false when some chunk holds too many distinct digits: nothing was moved and the
+// caller uses the 8-bit passes.  On success kout/vout hold the partitioned entries, seg_out (NB+1
+// entries, device) the bucket starts and tile_first_out the tile index of every bucket.
+static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u64 *kout, double *vout, int K, int pb,
+                             i64 *seg_out, u64 *tile_first_out, bool *ok, i64 *maxlen_out) {
+    const i64 E = h->count;
+    const i64 NB = (i64)1 << pb;
+    CK(ensure(h, h->misc, 256));
+    const bool fused = h->fused_state == 1 && h->chunk_pb == pb && h->fused_K == K;
+    const i64 C = fused ? h->fused_chunks : ceil_div<i64>(E, esprun::TILE);
+    ChunkArrays ca;
+    if (fused) {
+        CK(chunk_arrays(h, h->chunk_cap, h->chunk_pb, &ca));
+    } else {
+        h->fused_state = 2;  // whatever the producers wrote is stale from here on
+        CK(chunk_arrays(h, C + 64, pb, &ca));
+    }
+    h->last_fused = fused ? 1 : 0;
+    const i64 RM = C * esprun::RMAX;
+    // scratch of this call
+    size_t off = 0;
+    auto carve = [&](size_t bytes) {
+        size_t o = off;
+        off += (bytes + 255) & ~(size_t)255;
+        return o;
+    };
+    const size_t o_ro = carve(sizeof(i64) * (size_t)RM);
     const size_t o_hd = carve(sizeof(u64) * (size_t)NB);
     const size_t o_lk = carve(sizeof(u64) * (size_t)RM), o_lk2 = carve(sizeof(u64) * (size_t)RM);
     const size_t o_lv = carve(sizeof(double) * (size_t)RM), o_lv2 = carve(sizeof(double) * (size_t)RM);
     const size_t o_sc = carve(sizeof(u64) * (size_t)(RM + 1 + espscan::workspace_elems(RM + 1)));
     CK(ensure(h, h->runbuf, off));
     char *B = (char *)h->runbuf.p;
-    CK(ensure(h, h->misc, 256));
-    u32 *d_over = (u32 *)h->misc.p + 61;
     esprun::Args a;
     a.keys_in = kin;
     a.vals_in = vin;
     a.keys_out = kout;
     a.vals_out = vout;
     a.E = E;
+    a.chunk_start = ca.chunk_start;
     a.shift = K - pb;
     a.base = h->win_base;
     a.span = h->win_span;
     a.err = (u32 *)h->misc.p + 60;
-    a.overflow = d_over;
-    a.runs_d = (u32 *)(B + o_rd);
-    a.runs_c = (u32 *)(B + o_rc);
+    a.overflow = ca.overflow;
+    a.runs_d = ca.runs_d;
+    a.runs_c = ca.runs_c;
     a.runs_off = (i64 *)(B + o_ro);
-    a.nruns = (u64 *)(B + o_nr);
-    a.bucket_count = (unsigned long long *)(B + o_bc);
-    u64 *nruns = a.nruns, *bstart = (u64 *)(B + o_bc), *head = (u64 *)(B + o_hd);
+    a.nruns = ca.nruns;
+    a.bucket_count = ca.bucket_count;
+    u64 *nruns = a.nruns, *bstart = (u64 *)ca.bucket_count, *head = (u64 *)(B + o_hd);
     u64 *lk = (u64 *)(B + o_lk), *lk2 = (u64 *)(B + o_lk2), *sc = (u64 *)(B + o_sc);
     double *lv = (double *)(B + o_lv), *lv2 = (double *)(B + o_lv2);
-    HIPCK(h, hipMemsetAsync(d_over, 0, 4, h->stream));
-    HIPCK(h, hipMemsetAsync(bstart, 0, sizeof(u64) * (size_t)(NB + 1), h->stream));
-    HIPCK(h, hipMemsetAsync(nruns + T, 0, sizeof(u64), h->stream));
-    {
+    if (!fused) {
+        HIPCK(h, hipMemsetAsync(ca.overflow, 0, 4, h->stream));
+        HIPCK(h, hipMemsetAsync(bstart, 0, sizeof(u64) * (size_t)(NB + 1), h->stream));
+        hipLaunchKernelGGL(esprun::fixed_chunks_k, dim3(grid_for(C + 1, 256)), dim3(256), 0, h->stream, ca.chunk_start, (i64)0, C, (i64)0, E);
         Span sp(h, ESP_ST_HIST);
-        hipLaunchKernelGGL(esprun::run_hist_k, dim3((unsigned)T), dim3(esprun::THREADS), 0, h->stream, a);
+        hipLaunchKernelGGL(esprun::run_hist_k, dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a, (i64)0);
         sp.add(1);
     }
+    HIPCK(h, hipMemsetAsync(nruns + C, 0, sizeof(u64), h->stream));
     {
         Span sp(h, ESP_ST_SCAN);
-        sp.add(espscan::exclusive<u64, false>(h->stream, nruns, nruns, T + 1, nruns + T + 1));
+        sp.add(espscan::exclusive<u64, false>(h->stream, nruns, nruns, C + 1, nruns + C + 1));
         sp.add(espscan::exclusive<u64, false>(h->stream, bstart, bstart, NB + 1, bstart + NB + 1));
     }
     // bucket starts are final here: tiles per bucket and the longest bucket come with the same sync
@@ -884,8 +1013,8 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
                            (i64)espradix::TILE, tile_first_out, d_maxlen);
         sp.add(1 + espscan::exclusive<u64, false>(h->stream, tile_first_out, tile_first_out, NB + 1, tile_first_out + NB + 1));
     }
-    HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_over, 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCK(h, hipMemcpyAsync(h->pin_scalar + 1, nruns + T, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, ca.overflow, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar + 1, nruns + C, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipMemcpyAsync(h->pin_scalar + 2, d_maxlen, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipMemcpyAsync(h->pin_scalar + 3, a.err, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
@@ -899,10 +1028,10 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
     {
         Span sp(h, ESP_ST_SCAN);
         hipLaunchKernelGGL(esprun::run_pack_k, dim3(grid_for(RM, 256)), dim3(256), 0, h->stream, (const u32 *)a.runs_d, (const u32 *)a.runs_c,
-                           (const u64 *)nruns, T, lk, lv);
+                           (const u64 *)nruns, C, lk, lv);
         sp.add(1);
     }
-    // stable sort of the run list by digit with the ordinary 8-bit passes (tile order is kept)
+    // stable sort of the run list by digit with the ordinary 8-bit passes (chunk order is kept)
     {
         CK(ensure(h, h->segs, sizeof(i64) * 8));
         i64 *segs = (i64 *)h->segs.p;
@@ -945,7 +1074,7 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
     }
     {
         Span sp(h, ESP_ST_SCATTER);
-        hipLaunchKernelGGL(esprun::run_scatter_k, dim3((unsigned)T), dim3(esprun::THREADS), 0, h->stream, a);
+        hipLaunchKernelGGL(esprun::run_scatter_k, dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
         sp.add(1);
     }
     HIPCK(h, hipGetLastError());
@@ -1011,7 +1140,7 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
                 done = pb;
                 planned = std::max(planned_run, pb);
                 npass_eff = (planned - pb + 7) / 8;
-                h->last_partition = 1;
+                h->last_partition = h->last_fused ? 3 : 1;
                 h->runs_penalty = 0;
                 maxlen = ml;
                 window_checked = true;
@@ -1337,6 +1466,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
     h->last_path = use_local ? 1 : 2;
     if (Zn > 0 && pattern_changed) *pattern_changed = 1;
     HIPCK(h, hipGetLastError());
+    fused_reset(h);
     h->count = 0;
     h->shard_valid = false;
     if (h->timing && fa) {
@@ -1522,6 +1652,7 @@ extern "C" int32_t esp_shard_exchange_begin(esp_handle *h, int32_t nshards, int3
     std::swap(h->keys, h->keys2);
     std::swap(h->vals, h->vals2);
     h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
+    h->fused_state = 2;
     h->count = newcount;
     h->shard_valid = false;
     *d_send_keys = (uint64_t *)h->keys.p + SR;

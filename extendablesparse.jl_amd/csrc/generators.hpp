@@ -5,8 +5,21 @@
 // Compiled with -ffp-contract=off: no FMA contraction, values match the oracle's bits.
 #pragma once
 #include "common.hpp"
+#include "runpart.hpp"
 
 namespace espgen {
+
+// Optional: the producer also emits the run list of its chunk (runpart.hpp), so that the flush can
+// skip the histogram kernel (one full read of the keys).  runs.runs_d == nullptr switches it off.
+struct Fused {
+    esprun::RunSink runs;
+    i64 *chunk_start;  // absolute buffer position of every chunk (+ the end of the last one)
+    i64 chunk_base;    // index of this launch's first chunk
+    i64 buf_base;      // buffer position of the first entry this launch writes
+    int shift;         // digit = (((key >> 2) - base) >> shift)
+    u64 base, span;
+    u32 *err;
+};
 
 constexpr int THREADS = 256;
 
@@ -44,6 +57,7 @@ struct FdArgs {
     i64 total;  // number of updates of the generated node range
     i64 g_begin, g_end;  // node range [g_begin, g_end) (0-based l-1) of the loop nest
     i64 off_begin;       // stream position of node g_begin
+    Fused fused;
     KeyLayout L;
     u64 *keys;
     double *vals;
@@ -94,6 +108,15 @@ __device__ __forceinline__ void fd_pair(const FdArgs &a, u64 *lk, double *lv, in
 __global__ __launch_bounds__(THREADS) void fdrand_k(FdArgs a) {
     __shared__ u64 lk[THREADS * FD_MAX_PER_NODE];
     __shared__ double lv[THREADS * FD_MAX_PER_NODE];
+    __shared__ u32 rd[esprun::RMAX];
+    __shared__ u32 rc[esprun::RMAX];
+    __shared__ u32 rover;
+    if (threadIdx.x < esprun::RMAX) {
+        rd[threadIdx.x] = esprun::EMPTY;
+        rc[threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 0) rover = 0;
+    int my_first = 0, my_count = 0;
     const i64 N = a.g_end;
     const i64 g0 = a.g_begin + (i64)blockIdx.x * THREADS;
     const i64 g = g0 + threadIdx.x;  // node l-1
@@ -104,6 +127,7 @@ __global__ __launch_bounds__(THREADS) void fdrand_k(FdArgs a) {
     if (g < N) {
         const i64 i = g % a.nx + 1, j = (g / a.nx) % a.ny + 1, k = g / (a.nx * a.ny) + 1;
         int o = (int)(fd_offset(a, i, j, k, &cy, &cz) - a.off_begin - off0);
+        my_first = o;
         const i64 l = g + 1;
         const u64 c = 6ull * (u64)g;
         if (i < a.nx) fd_pair(a, lk, lv, o, fd_rand(a.rand_mode, a.seed, c + 0) * a.hy * a.hz / a.hx, l, l + 1);
@@ -112,6 +136,7 @@ __global__ __launch_bounds__(THREADS) void fdrand_k(FdArgs a) {
         if (a.ny > 2 && (j == 1 || j == a.ny)) fd_put(a, lk, lv, o, fd_rand(a.rand_mode, a.seed, c + 3) * a.hx * a.hz, l, l);
         if (k < a.nz) fd_pair(a, lk, lv, o, fd_rand(a.rand_mode, a.seed, c + 4) * a.hx * a.hy / a.hz, l, l + a.nx * a.ny);
         if (a.nz > 2 && (k == 1 || k == a.nz)) fd_put(a, lk, lv, o, fd_rand(a.rand_mode, a.seed, c + 5) * a.hx * a.hy, l, l);
+        my_count = o - my_first;
     }
     // total of the workgroup = position of the first node of the next workgroup (or the stream end)
     i64 off1;
@@ -124,6 +149,23 @@ __global__ __launch_bounds__(THREADS) void fdrand_k(FdArgs a) {
     }
     const int cnt = (int)(off1 - off0);
     __syncthreads();
+    if (a.fused.runs.runs_d) {  // run list of this workgroup's chunk (every thread owns <= 15 entries)
+        const Fused &f = a.fused;
+        u32 dig[FD_MAX_PER_NODE];
+        u32 pend = 0;
+#pragma unroll
+        for (int q = 0; q < FD_MAX_PER_NODE; q++) {
+            const bool valid = q < my_count;
+            dig[q] = valid ? esprun::run_digit(lk[my_first + q], f.base, f.span, f.shift, f.err) : 0u;
+            pend |= valid ? (1u << q) : 0u;
+        }
+        const i64 chunk = f.chunk_base + blockIdx.x;
+        if (threadIdx.x == 0) {
+            f.chunk_start[chunk] = f.buf_base + off0;
+            if (blockIdx.x == gridDim.x - 1) f.chunk_start[chunk + 1] = f.buf_base + off1;
+        }
+        esprun::count_runs<FD_MAX_PER_NODE>(dig, pend, chunk, f.runs, rd, rc, &rover);
+    }
     // coalesced copy-out; 16-byte stores on the aligned body
     u64 *gk = a.keys + off0;
     double *gv = a.vals + off0;

@@ -314,8 +314,11 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
                     const int rs = (int)ccnt[c];
                     const int len = (int)ccnt[c + 1] - rs;
                     u64 x[REG_RUN];
+                    const int lastj = len > 0 ? len - 1 : 0;
 #pragma unroll
-                    for (int j = 0; j < REG_RUN; j++) x[j] = j < len ? skey[rs + j] : NOREC;
+                    for (int j = 0; j < REG_RUN; j++) x[j] = skey[rs + min(j, lastj)];  // 16 reads in flight
+#pragma unroll
+                    for (int j = 0; j < REG_RUN; j++) x[j] = j < len ? x[j] : NOREC;
 #pragma unroll
                     for (int q = 0; q < NET16.n; q++) {
                         const u64 lo = x[NET16.a[q]], hi2 = x[NET16.b[q]];
@@ -325,7 +328,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
                     }
                     double xv[REG_RUN];
 #pragma unroll
-                    for (int j = 0; j < REG_RUN; j++) xv[j] = j < len ? sval[(x[j] >> ESP_TAG_BITS) & (CAP - 1)] : 0.0;
+                    for (int j = 0; j < REG_RUN; j++) xv[j] = sval[(x[j] >> ESP_TAG_BITS) & (CAP - 1)];  // (padding reads slot CAP-1)
                     int e = 0;
                     bool present = false;
                     double acc = 0.0;

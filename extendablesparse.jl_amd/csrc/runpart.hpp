@@ -34,6 +34,7 @@ struct Args {
     u64 *keys_out;
     double *vals_out;
     i64 E;
+    const i64 *chunk_start;  // C+1 buffer positions; chunk c = [chunk_start[c], chunk_start[c+1]), <= TILE entries
     int shift;  // digit = (((key >> 2) - base) >> shift), digits < nbuckets
     u64 base, span;
     u32 *err;        // key outside the window
@@ -52,55 +53,49 @@ __device__ __forceinline__ u32 digit16(const Args &a, u64 key, bool check) {
     return (u32)(kn >> a.shift);
 }
 
-__global__ __launch_bounds__(THREADS) void run_hist_k(Args a) {
-    __shared__ u32 rd[RMAX];
-    __shared__ u32 rc[RMAX];
-    __shared__ u32 over;
+// digit of a key for producers that emit their chunk's run list themselves
+__device__ __forceinline__ u32 run_digit(u64 key, u64 base, u64 span, int shift, u32 *err) {
+    u64 kn = (key >> ESP_TAG_BITS) - base;
+    if (kn >= span) *err = 1u;
+    kn = kn < span ? kn : span - 1;
+    return (u32)(kn >> shift);
+}
+
+// where a chunk's run list goes (shared by run_hist_k and the producers that emit it themselves)
+struct RunSink {
+    u32 *runs_d;
+    u32 *runs_c;
+    u64 *nruns;
+    unsigned long long *bucket_count;
+    u32 *overflow;
+};
+
+// Digit-major counting of one chunk by a whole workgroup: every wave walks the DISTINCT digits of its
+// entries (a handful on a pre-sorted stream); for each one, NITEMS ballots count its entries.  The
+// workgroup's table (rd/rc/over in LDS, initialised and barrier'd by the caller) collects the waves'
+// results; the runs are written sorted by digit.  pend: bit k set = item k of this lane is an entry.
+template <int NITEMS>
+__device__ __forceinline__ void count_runs(const u32 (&dig)[NITEMS], u32 pend, i64 chunk, const RunSink &sink, u32 *rd,
+                                           u32 *rc, u32 *over) {
     const int t = threadIdx.x, lane = t & 63;
-    // a stream that is not pre-sorted is recognised by the first workgroups: the rest leave at once
-    if (__hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-    const i64 beg = (i64)blockIdx.x * TILE;
-    const i64 end = min(a.E, beg + (i64)TILE);
-    if (t < RMAX) {
-        rd[t] = EMPTY;
-        rc[t] = 0;
-    }
-    if (t == 0) over = 0;
-    u64 key[ITEMS];
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        const i64 idx = beg + k * THREADS + t;
-        key[k] = idx < end ? a.keys_in[idx] : 0ull;
-    }
-    __syncthreads();
-    // Digit-major counting: the wave walks the DISTINCT digits of its 1024 entries (a handful on a
-    // pre-sorted stream); for each one, 16 ballots count its entries.  Cost ~ distinct x items.
-    u32 dig[ITEMS];
-    u32 pend = 0;  // bit k: item k of this lane not yet counted
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        const bool valid = (beg + k * THREADS + t) < end;
-        dig[k] = valid ? digit16(a, key[k], true) : 0u;
-        pend |= valid ? (1u << k) : 0u;
-    }
     int trips = 0;
     for (;;) {
         const u64 lanes = __ballot(pend != 0);
         if (!lanes) break;
-        if (++trips > RMAX) {  // more distinct digits than a tile may hold on this path
-            if (lane == 0) over = 1;
+        if (++trips > RMAX) {  // more distinct digits than a chunk may hold on this path
+            if (lane == 0) *over = 1;
             break;
         }
         const int fl = __builtin_ctzll(lanes);
         const int kk = __builtin_ctz((u32)__builtin_amdgcn_readlane((int)pend, fl));
         u32 cand = 0;
 #pragma unroll
-        for (int k = 0; k < ITEMS; k++)
+        for (int k = 0; k < NITEMS; k++)
             if (k == kk) cand = dig[k];
         const u32 c0 = (u32)__builtin_amdgcn_readlane((int)cand, fl);
         u32 total = 0;
 #pragma unroll
-        for (int k = 0; k < ITEMS; k++) {
+        for (int k = 0; k < NITEMS; k++) {
             const bool hit = ((pend >> k) & 1u) && dig[k] == c0;
             total += (u32)__popcll(__ballot(hit));
             pend &= hit ? ~(1u << k) : ~0u;
@@ -117,14 +112,14 @@ __global__ __launch_bounds__(THREADS) void run_hist_k(Args a) {
                 }
                 j = (j + 1) & (RMAX - 1);
             }
-            if (!placed) over = 1;
+            if (!placed) *over = 1;
         }
     }
     __syncthreads();
-    if (over) {
+    if (*over) {
         if (t == 0) {
-            a.nruns[blockIdx.x] = 0;
-            atomicExch(a.overflow, 1u);
+            sink.nruns[chunk] = 0;
+            atomicExch(sink.overflow, 1u);
         }
         return;
     }
@@ -134,13 +129,55 @@ __global__ __launch_bounds__(THREADS) void run_hist_k(Args a) {
         if (x != EMPTY) {
             int r = 0;
             for (int i = 0; i < RMAX; i++) r += (rd[i] < x) ? 1 : 0;  // EMPTY is the largest value
-            a.runs_d[(i64)blockIdx.x * RMAX + r] = x;
-            a.runs_c[(i64)blockIdx.x * RMAX + r] = rc[t];
-            atomicAdd(&a.bucket_count[x], (unsigned long long)rc[t]);
+            sink.runs_d[chunk * RMAX + r] = x;
+            sink.runs_c[chunk * RMAX + r] = rc[t];
+            atomicAdd(&sink.bucket_count[x], (unsigned long long)rc[t]);
         }
         const u64 used = __ballot(x != EMPTY);
-        if (t == 0) a.nruns[blockIdx.x] = (u64)__popcll(used);
+        if (t == 0) sink.nruns[chunk] = (u64)__popcll(used);
     }
+}
+
+__global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_chunk) {
+    __shared__ u32 rd[RMAX];
+    __shared__ u32 rc[RMAX];
+    __shared__ u32 over;
+    const int t = threadIdx.x;
+    // a stream that is not pre-sorted is recognised by the first workgroups: the rest leave at once
+    if (__hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    const i64 chunk = first_chunk + blockIdx.x;
+    const i64 beg = a.chunk_start[chunk];
+    const i64 end = a.chunk_start[chunk + 1];
+    if (t < RMAX) {
+        rd[t] = EMPTY;
+        rc[t] = 0;
+    }
+    if (t == 0) over = 0;
+    u64 key[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const i64 idx = beg + k * THREADS + t;
+        key[k] = idx < end ? a.keys_in[idx] : 0ull;
+    }
+    __syncthreads();
+    u32 dig[ITEMS];
+    u32 pend = 0;  // bit k: item k of this lane not yet counted
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const bool valid = (beg + k * THREADS + t) < end;
+        dig[k] = valid ? digit16(a, key[k], true) : 0u;
+        pend |= valid ? (1u << k) : 0u;
+    }
+    const RunSink sink{a.runs_d, a.runs_c, a.nruns, a.bucket_count, a.overflow};
+    count_runs<ITEMS>(dig, pend, chunk, sink, rd, rc, &over);
+}
+
+// chunk_start[first + i] = from + i*TILE (clamped to `to`): fixed-size chunks for a buffer range that
+// came without run lists
+__global__ void fixed_chunks_k(i64 *chunk_start, i64 first, i64 nchunks, i64 from, i64 to) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i > nchunks) return;
+    chunk_start[first + i] = min(to, from + i * (i64)TILE);
 }
 
 // dense run list in tile order: sortable records (key = digit << 2, payload = tile|j|count)
@@ -192,9 +229,9 @@ __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
     __shared__ u32 cnt[WAVES][RMAX];
     __shared__ int s_nr;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const i64 tile = blockIdx.x;
-    const i64 beg = tile * TILE;
-    const i64 end = min(a.E, beg + (i64)TILE);
+    const i64 tile = blockIdx.x;  // = chunk index
+    const i64 beg = a.chunk_start[tile];
+    const i64 end = a.chunk_start[tile + 1];
     // run table of the tile (nruns holds the exclusive scan by now: nr = difference)
     if (t == 0) s_nr = (int)(a.nruns[tile + 1] - a.nruns[tile]);
     if (t < RMAX) {

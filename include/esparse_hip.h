@@ -193,11 +193,13 @@ int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear);
 /* test hooks: path 0 = automatic, 2 = force the general path (global LSD sort + global fold),
  * 3 = LDS bucket path with its radix tail only (no column tiers), 4 = bucket kernel issued in
  * launches of 64 workgroups (exercises the carry-over of the look-back state), 5 = never use the
- * run-based single-pass partition (8-bit passes only);
+ * run-based single-pass partition (8-bit passes only), 7 = the device generators emit the run lists of their chunks themselves (skips the
+ * histogram kernel; off by default: no net gain measured);
  * last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general) */
 int32_t esp_debug_force_path(esp_handle *h, int32_t path);
 int32_t esp_debug_last_path(const esp_handle *h, int32_t *path);
-/* which partition the last flush used: 1 = run-based single pass (pre-sorted stream), 2 = 8-bit passes */
+/* which partition the last flush used: 1 = run-based single pass (pre-sorted stream), 2 = 8-bit passes,
+ * 3 = run-based single pass on run lists the producers emitted (no histogram kernel) */
 int32_t esp_debug_last_partition(const esp_handle *h, int32_t *kind);
 
 #ifdef __cplusplus

@@ -443,7 +443,7 @@ def test_empty_and_tiny(esp):
 
 
 # ------------------------------------------------------------------ full-size properties
-@pytest.mark.parametrize("force", [0, 5])
+@pytest.mark.parametrize("force", [0, 5, 7])
 def test_run_partition_vs_passes(esp, orc, force):
     """Pre-sorted stream (48^3 stencil, E > 2^20): the run-based single-pass partition and the 8-bit
     passes give the same bits; a shuffled stream falls back to the passes."""
@@ -453,7 +453,8 @@ def test_run_partition_vs_passes(esp, orc, force):
     A.debug_force_path(force)
     A.generate_fdrand(n, n, n, seed=21, rand_mode=1)
     A.flush()
-    assert A.debug_last_partition() == (1 if force == 0 else 2)
+    # 3: the generator emitted the run lists itself; 1: histogram kernel; 2: 8-bit passes
+    assert A.debug_last_partition() == {0: 1, 5: 2, 7: 3}[force]
     O = orc.fdrand(n, n, n, rand_mode=1, seed=21, style=orc.KIND_UPDATE)
     assert_csc_equal(hip_arrays(A), O.arrays())
     # same entries in random order: too many distinct digits per tile -> 8-bit passes
@@ -476,6 +477,44 @@ def test_run_partition_vs_passes(esp, orc, force):
     I3, J3, V3 = orc.fdrand_stream(n, n, n, rand_mode=1, seed=23)
     O2.apply(np.full(len(I3), UPDATE, np.uint8), I3, J3, V3)
     assert_csc_equal(hip_arrays(A), O2.arrays())
+
+
+def test_producer_run_lists_mixed_with_other_appends(esp, orc):
+    """Run lists emitted by the generator are used only if EVERY pending entry came with one; two
+    generator calls, a host append in between, a capacity hint that is off: all must stay exact."""
+    n = 48
+    N = n ** 3
+    E = orc.fdrand_count(n, n, n)
+    half = (N // 2 // 256) * 256 + 17
+    for variant in ("two_calls", "host_append_between", "bad_hint", "good_hint"):
+        hint = {"bad_hint": 5 * E, "good_hint": E}.get(variant, 0)
+        A = esp.ExtendableSparseMatrix(N, N, capacity_hint=hint)
+        A.debug_force_path(7)        # producers emit run lists
+        O = orc.ExtendableSparseMatrix(N, N)
+        I, J, V = orc.fdrand_stream(n, n, n, rand_mode=1, seed=31)
+        if variant in ("two_calls", "host_append_between"):
+            A.generate_fdrand_range(n, n, n, 0, half, seed=31, rand_mode=1)
+            if variant == "host_append_between":
+                A.append(UPDATE, [3, 4], [5, 6], [1.5, 2.5])
+            A.generate_fdrand_range(n, n, n, half, N, seed=31, rand_mode=1)
+        else:
+            A.generate_fdrand(n, n, n, seed=31, rand_mode=1)
+        A.flush()
+        if variant == "host_append_between":
+            # the host entries sit between the two halves of the stream
+            Ih, Jh, Vh = orc.fdrand_stream(n, n, n, rand_mode=1, seed=31)
+            B = esp.ExtendableSparseMatrix(N, N)
+            B.debug_force_path(0)
+            B.generate_fdrand_range(n, n, n, 0, half, seed=31, rand_mode=1)
+            B.append(UPDATE, [3, 4], [5, 6], [1.5, 2.5])
+            B.generate_fdrand_range(n, n, n, half, N, seed=31, rand_mode=1)
+            B.flush()
+            assert_csc_equal(hip_arrays(A), hip_arrays(B), variant)
+        else:
+            O.apply(np.full(len(I), UPDATE, np.uint8), I, J, V)
+            assert_csc_equal(hip_arrays(A), O.arrays(), variant)
+        if variant == "good_hint":
+            assert A.debug_last_partition() == 3
 
 
 @pytest.mark.parametrize("n", [96, 256])
