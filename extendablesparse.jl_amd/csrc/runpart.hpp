@@ -78,41 +78,46 @@ template <int NITEMS>
 __device__ __forceinline__ void count_runs(const u32 (&dig)[NITEMS], u32 pend, i64 chunk, const RunSink &sink, u32 *rd,
                                            u32 *rc, u32 *over) {
     const int t = threadIdx.x, lane = t & 63;
+    // counted entries are blanked (EMPTY never equals a digit): a hit test is one compare
+    u32 dg[NITEMS];
+#pragma unroll
+    for (int k = 0; k < NITEMS; k++) dg[k] = ((pend >> k) & 1u) ? dig[k] : EMPTY;
     int trips = 0;
-    for (;;) {
-        const u64 lanes = __ballot(pend != 0);
-        if (!lanes) break;
-        if (++trips > RMAX) {  // more distinct digits than a chunk may hold on this path
-            if (lane == 0) *over = 1;
-            break;
-        }
-        const int fl = __builtin_ctzll(lanes);
-        const int kk = __builtin_ctz((u32)__builtin_amdgcn_readlane((int)pend, fl));
-        u32 cand = 0;
+    bool stop = false;
 #pragma unroll
-        for (int k = 0; k < NITEMS; k++)
-            if (k == kk) cand = dig[k];
-        const u32 c0 = (u32)__builtin_amdgcn_readlane((int)cand, fl);
-        u32 total = 0;
-#pragma unroll
-        for (int k = 0; k < NITEMS; k++) {
-            const bool hit = ((pend >> k) & 1u) && dig[k] == c0;
-            total += (u32)__popcll(__ballot(hit));
-            pend &= hit ? ~(1u << k) : ~0u;
-        }
-        if (lane == 0) {  // open addressing in the workgroup's run table
-            bool placed = false;
-            int j = (int)((c0 * 0x9E3779B1u) >> 26) & (RMAX - 1);
-            for (int probe = 0; probe < RMAX; probe++) {
-                const u32 old = atomicCAS(&rd[j], EMPTY, c0);
-                if (old == EMPTY || old == c0) {
-                    atomicAdd(&rc[j], total);
-                    placed = true;
-                    break;
-                }
-                j = (j + 1) & (RMAX - 1);
+    for (int k = 0; k < NITEMS; k++) {
+        // digits first met at item k (items before k are fully counted)
+        u64 m = stop ? 0ull : __ballot(dg[k] != EMPTY);
+        while (m) {
+            if (++trips > RMAX) {  // more distinct digits than a chunk may hold on this path
+                if (lane == 0) *over = 1;
+                stop = true;
+                break;
             }
-            if (!placed) *over = 1;
+            const int fl = __builtin_ctzll(m);
+            const u32 c0 = (u32)__builtin_amdgcn_readlane((int)dg[k], fl);
+            u32 total = 0;
+#pragma unroll
+            for (int q = k; q < NITEMS; q++) {
+                const bool hit = dg[q] == c0;
+                total += (u32)__popcll(__ballot(hit));
+                dg[q] = hit ? EMPTY : dg[q];
+            }
+            if (lane == 0) {  // open addressing in the workgroup's run table
+                bool placed = false;
+                int j = (int)((c0 * 0x9E3779B1u) >> 26) & (RMAX - 1);
+                for (int probe = 0; probe < RMAX; probe++) {
+                    const u32 old = atomicCAS(&rd[j], EMPTY, c0);
+                    if (old == EMPTY || old == c0) {
+                        atomicAdd(&rc[j], total);
+                        placed = true;
+                        break;
+                    }
+                    j = (j + 1) & (RMAX - 1);
+                }
+                if (!placed) *over = 1;
+            }
+            m = __ballot(dg[k] != EMPTY);
         }
     }
     __syncthreads();
@@ -280,41 +285,43 @@ __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
         jrun[k] = 0;
     }
     // digit-major stable ranking: for each distinct digit of the wave, its entries are numbered in
-    // (item, lane) order with a scalar running count -- no LDS counters inside the wave
-    for (int trips = 0; trips <= RMAX; trips++) {
-        const u64 lanes = __ballot(pend != 0);
-        if (!lanes) break;
-        const int fl = __builtin_ctzll(lanes);
-        const int kk = __builtin_ctz((u32)__builtin_amdgcn_readlane((int)pend, fl));
-        u32 cand = 0;
+    // (item, lane) order with a scalar running count -- no LDS counters inside the wave.  Ranked
+    // entries are blanked, so the hit test is one compare; digits first met at item k only look at
+    // items >= k.
 #pragma unroll
-        for (int k = 0; k < ITEMS; k++)
-            if (k == kk) cand = dig[k];
-        const u32 c0 = (u32)__builtin_amdgcn_readlane((int)cand, fl);
-        int jj = 0;
-        {
-            int j = (int)((c0 * 0x9E3779B1u) >> 26) & (RMAX - 1);
-            for (int probe = 0; probe < RMAX; probe++) {
-                if (hd[j] == c0) {
-                    jj = (int)hj[j];
-                    break;
+    for (int k = 0; k < ITEMS; k++) dig[k] = ((pend >> k) & 1u) ? dig[k] : EMPTY;
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        u64 m = __ballot(dig[k] != EMPTY);
+        while (m) {
+            const int fl = __builtin_ctzll(m);
+            const u32 c0 = (u32)__builtin_amdgcn_readlane((int)dig[k], fl);
+            int jj = 0;
+            {
+                int j = (int)((c0 * 0x9E3779B1u) >> 26) & (RMAX - 1);
+                for (int probe = 0; probe < RMAX; probe++) {
+                    if (hd[j] == c0) {
+                        jj = (int)hj[j];
+                        break;
+                    }
+                    j = (j + 1) & (RMAX - 1);
                 }
-                j = (j + 1) & (RMAX - 1);
             }
-        }
-        u32 running = 0;
+            u32 running = 0;
 #pragma unroll
-        for (int k = 0; k < ITEMS; k++) {
-            const bool hit = ((pend >> k) & 1u) && dig[k] == c0;
-            const u64 m = __ballot(hit);
-            if (hit) {
-                rank[k] = (unsigned short)(running + (u32)__popcll(m & lt));
-                jrun[k] = (unsigned char)jj;
+            for (int q = k; q < ITEMS; q++) {
+                const bool hit = dig[q] == c0;
+                const u64 mm = __ballot(hit);
+                if (hit) {
+                    rank[q] = (unsigned short)(running + (u32)__popcll(mm & lt));
+                    jrun[q] = (unsigned char)jj;
+                }
+                running += (u32)__popcll(mm);
+                dig[q] = hit ? EMPTY : dig[q];
             }
-            running += (u32)__popcll(m);
-            pend &= hit ? ~(1u << k) : ~0u;
+            if (lane == 0) cnt[w][jj] = running;
+            m = __ballot(dig[k] != EMPTY);
         }
-        if (lane == 0) cnt[w][jj] = running;
     }
     __syncthreads();
     // exclusive prefix over the waves, per run
