@@ -112,6 +112,8 @@ def main():
                                     kind=esp.ESP_UPDATE)
             SA.flush()
     A.timing_enable(not os.environ.get("ESP_BENCH_NO_STAGE_TIMING"))
+    if os.environ.get("ESP_BENCH_FORCE_PATH"):      # experiments only (see esp_debug_force_path)
+        A.debug_force_path(int(os.environ["ESP_BENCH_FORCE_PATH"]))
 
     def barrier():
         if dist is not None:

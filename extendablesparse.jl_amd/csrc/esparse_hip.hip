@@ -1370,6 +1370,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     const u32 lookback_err = (u32)(h->pin_scalar[1] >> 32);
     if (lookback_err & 2u) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (bucket)");
     if (lookback_err & 1u) FAIL(h, ESP_ERR_HIP, "esp_flush: look-back chain timed out inside the bucket kernel");
+    if (lookback_err & 4u) FAIL(h, ESP_ERR_HIP, "esp_flush: internal error (early segment total differs from the folded total)");
     const i64 Zn = (i64)(h->pin_scalar[0] & esplocal::ST_VAL);
     *Zn_out = Zn;
     if (a.stop_after || Zn == 0) return ESP_OK;

@@ -97,7 +97,7 @@ struct Args {
     u32 *err;        // set to 1 if a look-back spin ran into its bound
     int stop_after;  // timing ablation only (0 = run everything)
     i64 first;       // ticket value the first workgroup of this launch is expected to draw
-    unsigned long long *stamps;  // diagnostics: 8 wall-clock stamps per segment (null in production)
+    unsigned long long *stamps;  // diagnostics (builds with -DESP_LOCAL_STAMPS only): 8 wall-clock stamps per segment
 };
 
 // Stable LSD radix tail on the packed keys held in registers (wave-striped arrangement):
@@ -181,6 +181,141 @@ __device__ __forceinline__ void close_group(const Args &a, u64 *skey, double *sv
     }
 }
 
+// loads one column run (<= REG_RUN entries at skey[rs..rs+len)) into registers and sorts it
+__device__ __forceinline__ void load_sorted_run(const u64 *skey, const double *sval, int rs, int len, u64 (&x)[REG_RUN],
+                                                double (&xv)[REG_RUN]) {
+    const int lastj = len > 0 ? len - 1 : 0;
+#pragma unroll
+    for (int j = 0; j < REG_RUN; j++) x[j] = skey[rs + min(j, lastj)];  // 16 reads in flight
+#pragma unroll
+    for (int j = 0; j < REG_RUN; j++) x[j] = j < len ? x[j] : NOREC;
+#pragma unroll
+    for (int q = 0; q < NET16.n; q++) {
+        const u64 lo = x[NET16.a[q]], hi2 = x[NET16.b[q]];
+        const bool sw = lo > hi2;
+        x[NET16.a[q]] = sw ? hi2 : lo;
+        x[NET16.b[q]] = sw ? lo : hi2;
+    }
+#pragma unroll
+    for (int j = 0; j < REG_RUN; j++) xv[j] = sval[(x[j] >> ESP_TAG_BITS) & (CAP - 1)];  // (padding reads slot CAP-1)
+}
+
+// number of entries a sorted run will emit when nothing of it is in the CSC: a (col,row) group
+// becomes present iff one of its updates is a RAWUPDATE or has a non-zero value (fold_step)
+__device__ __forceinline__ u32 count_emitted(const u64 (&x)[REG_RUN], const double (&xv)[REG_RUN], int len) {
+    u32 e = 0;
+    bool any = false;
+    u64 psub = 0;
+#pragma unroll
+    for (int j = 0; j <= REG_RUN; j++) {
+        const bool valid = j < REG_RUN && j < len;
+        const u64 sub = (j < REG_RUN ? x[j] : NOREC) >> SUB_SHIFT;
+        const bool fresh = j == 0 || !valid || sub != psub;
+        if (fresh && j > 0 && j <= len) e += any ? 1u : 0u;
+        if (valid) {
+            if (fresh) {
+                psub = sub;
+                any = false;
+            }
+            any |= ((u32)(x[j < REG_RUN ? j : 0] & ESP_TAG_MASK) == (u32)ESP_RAWUPDATE) || xv[j < REG_RUN ? j : 0] != 0.0;
+        }
+    }
+    return e;
+}
+
+// ordered fold of one sorted run held in registers; records go to skey[rs..), NOREC behind them
+__device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval, const u64 (&x)[REG_RUN],
+                                         const double (&xv)[REG_RUN], int rs, int len, u64 hi, u64 rowmask) {
+    int e = 0;
+    bool present = false;
+    double acc = 0.0;
+    u64 psub = 0;
+    u32 idx0 = 0;
+    i64 pos = -1;
+    // the run's rows come in increasing order: the CSC column is walked with a cursor
+    // (findindex restated as a merge walk; same result as the binary search)
+    i64 ccur = 0, cend = 0;
+    if (a.csc.nnz > 0 && len > 0) {
+        const i64 col0 = (i64)((hi + (x[0] >> SUB_SHIFT)) >> a.rb);
+        ccur = a.csc.colptr[col0] - 1;
+        cend = a.csc.colptr[col0 + 1] - 1;
+    }
+#pragma unroll
+    for (int j = 0; j <= REG_RUN; j++) {
+        const bool valid = j < REG_RUN && j < len;
+        const u64 kj = j < REG_RUN ? x[j] : NOREC;
+        const u64 sub = kj >> SUB_SHIFT;
+        const bool fresh = j == 0 || !valid || sub != psub;
+        if (fresh && j > 0 && j <= len) close_group(a, skey, sval, rs, e, pos, present, acc, psub, idx0);
+        if (valid) {
+            if (fresh) {
+                psub = sub;
+                idx0 = (u32)(kj >> ESP_TAG_BITS) & (CAP - 1);
+                pos = -1;
+                if (ccur < cend) {
+                    const i64 want = (i64)((hi + sub) & rowmask) + 1;
+                    while (ccur < cend && a.csc.rowval[ccur] < want) ccur++;
+                    if (ccur < cend && a.csc.rowval[ccur] == want) pos = ccur;
+                }
+                present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
+                acc = present ? a.csc.nzval[pos] : 0.0;
+            }
+            espfold::fold_step(present, acc, (u32)(kj & ESP_TAG_MASK), xv[j < REG_RUN ? j : 0]);
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < REG_RUN; j++)
+        if (j >= e && j < len) skey[rs + j] = NOREC;
+}
+
+// decoupled look-back by ONE wave: publishes this segment's total and returns the exclusive prefix
+__device__ __forceinline__ u64 lookback_wave(const Args &a, int s, u32 total, int lane) {
+    u64 excl = 0;
+    if (s == 0) {
+        if (lane == 0) __hip_atomic_store(&a.status[0], ST_PRE | (u64)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return 0;
+    }
+    if (lane == 0) __hip_atomic_store(&a.status[s], ST_AGG | (u64)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    int top = s - 1;  // highest predecessor not yet accounted for
+    u32 spins = 0;
+    bool fail = false;
+    while (true) {
+        const int j = top - lane;
+        u64 v = ST_PRE;  // lanes before segment 0 act as a zero prefix
+        if (j >= 0) v = __hip_atomic_load(&a.status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const u64 ready = __ballot((v >> 62) != 0);
+        const u64 pre = __ballot((v >> 62) == 2);
+        // usable lanes: a contiguous run of ready lanes starting at lane 0, cut after the first PRE
+        const u64 notready = ~ready;
+        const int nrun = notready ? __builtin_ctzll(notready) : 64;
+        const u64 runmask = nrun >= 64 ? ~0ull : ((1ull << nrun) - 1ull);
+        const u64 prein = pre & runmask;
+        int use = nrun;
+        bool finished = false;
+        if (prein) {
+            use = __builtin_ctzll(prein) + 1;
+            finished = true;
+        }
+        u64 part = lane < use ? (v & ST_VAL) : 0ull;
+#pragma unroll
+        for (int dlt = 32; dlt > 0; dlt >>= 1) part += __shfl_xor(part, dlt, ESP_WAVE);
+        excl += part;
+        top -= use;
+        if (finished) break;
+        if (use == 0) {
+            if (++spins > SPIN_LIMIT) {
+                fail = true;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+    if (fail && lane == 0) atomicOr(a.err, 1u);
+    if (lane == 0)
+        __hip_atomic_store(&a.status[s], ST_PRE | ((excl + (u64)total) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return excl;
+}
+
 template <bool FRESH>
 __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     __shared__ u64 skey[CAP];
@@ -191,6 +326,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     __shared__ u32 gcount[WAVES * ITEMS];
     __shared__ u64 s_dst;
     __shared__ int s_seg;
+    __shared__ u32 s_early;
     __shared__ i64 s_win[66];
     u32(*cnt)[256] = reinterpret_cast<u32(*)[256]>(cntraw);
     u32 *ccnt = cntraw;
@@ -205,14 +341,19 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     constexpr int WIN = 64;
     const i64 w0 = max((i64)0, a.first + (i64)blockIdx.x - WIN / 2);
     if (t <= WIN + 1 && w0 + t <= (i64)a.S) s_win[t] = a.seg_start[w0 + t];
-    if (t == 0) s_seg = (int)atomicAdd(a.ticket, 1u);
+    if (t == 0) {
+        s_seg = (int)atomicAdd(a.ticket, 1u);
+        s_early = 0;
+    }
     __syncthreads();
     const int s = s_seg;
     if (s >= a.S) return;
     const bool inwin = s >= w0 && (i64)s + 1 <= w0 + WIN + 1;
     const i64 beg = inwin ? s_win[s - w0] : a.seg_start[s];
     const i64 seg_end = inwin ? s_win[s - w0 + 1] : a.seg_start[s + 1];
+#ifdef ESP_LOCAL_STAMPS
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 0] = wall_clock64();
+#endif
     const int n = (int)(seg_end - beg);
     const u64 submask = a.rem_bits >= 64 ? ~0ull : ((1ull << a.rem_bits) - 1ull);
     // shared prefix of the segment (window-relative), turned back into an absolute key prefix
@@ -245,9 +386,14 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             k[i] = NOREC;  // sorts behind every real entry (stable: real entries come first on ties)
         }
     }
+#ifdef ESP_LOCAL_STAMPS
     if (a.stamps) { __syncthreads(); }
+#endif
+#ifdef ESP_LOCAL_STAMPS
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 1] = wall_clock64();
+#endif
     bool done = n == 0;
+    bool lb_done = false;  // the look-back already ran (early publication, see the register tier)
     if (a.stop_after == 1) done = true;
 
     if (!done && a.cl_bits >= 0) {
@@ -299,76 +445,59 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         }
         if (t == 0) ccnt[ncl] = (u32)n;
         __syncthreads();
+#ifdef ESP_LOCAL_STAMPS
         if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 2] = wall_clock64();
+#endif
         if (a.stop_after == 2) done = true;
         if (!done && maxrun <= RANK_MAX) {
 #pragma unroll
             for (int i = 0; i < ITEMS; i++)
                 if (wbase + i * ESP_WAVE < n) skey[ccnt[(u32)(k[i] >> csh)] + slot[i]] = k[i];
             __syncthreads();
+#ifdef ESP_LOCAL_STAMPS
             if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 3] = wall_clock64();
+#endif
             if (a.stop_after == 3) done = true;
             if (!done && maxrun <= REG_RUN) {
                 // one lane per column: the whole run in registers, sorting network + ordered fold
-                for (int c = t; c < ncl; c += THREADS) {
-                    const int rs = (int)ccnt[c];
-                    const int len = (int)ccnt[c + 1] - rs;
+                if (FRESH && a.csc.nnz == 0 && ncl <= THREADS - ESP_WAVE) {
+                    // Nothing can hit the CSC, so the number of entries a run emits is known right after
+                    // sorting.  The segment total is published BEFORE the fold and the last wave (idle in
+                    // this phase: one lane per column) runs the look-back while the others fold.
                     u64 x[REG_RUN];
-                    const int lastj = len > 0 ? len - 1 : 0;
-#pragma unroll
-                    for (int j = 0; j < REG_RUN; j++) x[j] = skey[rs + min(j, lastj)];  // 16 reads in flight
-#pragma unroll
-                    for (int j = 0; j < REG_RUN; j++) x[j] = j < len ? x[j] : NOREC;
-#pragma unroll
-                    for (int q = 0; q < NET16.n; q++) {
-                        const u64 lo = x[NET16.a[q]], hi2 = x[NET16.b[q]];
-                        const bool sw = lo > hi2;
-                        x[NET16.a[q]] = sw ? hi2 : lo;
-                        x[NET16.b[q]] = sw ? lo : hi2;
-                    }
                     double xv[REG_RUN];
-#pragma unroll
-                    for (int j = 0; j < REG_RUN; j++) xv[j] = sval[(x[j] >> ESP_TAG_BITS) & (CAP - 1)];  // (padding reads slot CAP-1)
-                    int e = 0;
-                    bool present = false;
-                    double acc = 0.0;
-                    u64 psub = 0;
-                    u32 idx0 = 0;
-                    i64 pos = -1;
-                    // the run's rows come in increasing order: the CSC column is walked with a cursor
-                    // (findindex restated as a merge walk; same result as the binary search)
-                    i64 ccur = 0, cend = 0;
-                    if (a.csc.nnz > 0 && len > 0) {
-                        const i64 col0 = (i64)((hi + (x[0] >> SUB_SHIFT)) >> a.rb);
-                        ccur = a.csc.colptr[col0] - 1;
-                        cend = a.csc.colptr[col0 + 1] - 1;
+                    int rs = 0, len = 0;
+                    u32 ec = 0;
+                    if (t < ncl) {
+                        rs = (int)ccnt[t];
+                        len = (int)ccnt[t + 1] - rs;
+                        load_sorted_run(skey, sval, rs, len, x, xv);
+                        ec = count_emitted(x, xv, len);
                     }
 #pragma unroll
-                    for (int j = 0; j <= REG_RUN; j++) {
-                        const bool valid = j < REG_RUN && j < len;
-                        const u64 kj = j < REG_RUN ? x[j] : NOREC;
-                        const u64 sub = kj >> SUB_SHIFT;
-                        const bool fresh = j == 0 || !valid || sub != psub;
-                        if (fresh && j > 0 && j <= len) close_group(a, skey, sval, rs, e, pos, present, acc, psub, idx0);
-                        if (valid) {
-                            if (fresh) {
-                                psub = sub;
-                                idx0 = (u32)(kj >> ESP_TAG_BITS) & (CAP - 1);
-                                pos = -1;
-                                if (ccur < cend) {
-                                    const i64 want = (i64)((hi + sub) & rowmask) + 1;
-                                    while (ccur < cend && a.csc.rowval[ccur] < want) ccur++;
-                                    if (ccur < cend && a.csc.rowval[ccur] == want) pos = ccur;
-                                }
-                                present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
-                                acc = present ? a.csc.nzval[pos] : 0.0;
-                            }
-                            espfold::fold_step(present, acc, (u32)(kj & ESP_TAG_MASK), xv[j < REG_RUN ? j : 0]);
-                        }
-                    }
+                    for (int dlt = 32; dlt > 0; dlt >>= 1) ec += (u32)__shfl_xor((int)ec, dlt, ESP_WAVE);
+                    if (lane == 0 && ec) atomicAdd(&s_early, ec);
+                    __syncthreads();
+                    if (w == WAVES - 1) {
+                        const u64 excl = lookback_wave(a, s, s_early, lane);
+                        if (lane == 0) s_dst = excl;
+                    } else if (t < ncl) {
+                        // (measured: keeping the sorted keys in registers across the barrier and re-reading
+                        // only the values beats writing the run back to LDS)
 #pragma unroll
-                    for (int j = 0; j < REG_RUN; j++)
-                        if (j >= e && j < len) skey[rs + j] = NOREC;
+                        for (int j = 0; j < REG_RUN; j++) xv[j] = sval[(x[j] >> ESP_TAG_BITS) & (CAP - 1)];
+                        fold_run(a, skey, sval, x, xv, rs, len, hi, rowmask);
+                    }
+                    lb_done = true;
+                } else {
+                    for (int c = t; c < ncl; c += THREADS) {
+                        const int rs = (int)ccnt[c];
+                        const int len = (int)ccnt[c + 1] - rs;
+                        u64 x[REG_RUN];
+                        double xv[REG_RUN];
+                        load_sorted_run(skey, sval, rs, len, x, xv);
+                        fold_run(a, skey, sval, x, xv, rs, len, hi, rowmask);
+                    }
                 }
                 done = true;
             } else if (!done) {
@@ -470,7 +599,9 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         }
         __syncthreads();
     }
+#ifdef ESP_LOCAL_STAMPS
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 4] = wall_clock64();
+#endif
     if (a.stop_after == 4) {
         if (t == 0 && s == a.S - 1) __hip_atomic_store(&a.status[s], ST_PRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         return;
@@ -489,7 +620,9 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     }
     __syncthreads();
     if (w == 0) {
+#ifdef ESP_LOCAL_STAMPS
         if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 5] = wall_clock64();
+#endif
         const u32 c = lane < WAVES * ITEMS ? gcount[lane] : 0u;
         u32 inc = c;
 #pragma unroll
@@ -499,57 +632,19 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         }
         if (lane < WAVES * ITEMS) gcount[lane] = inc - c;
         const u32 total = (u32)__shfl((int)inc, 63, ESP_WAVE);
-        // ---- decoupled look-back (wave 0): exclusive prefix of the segment totals
-        u64 excl = 0;
-        if (s == 0) {
-            if (lane == 0) __hip_atomic_store(&a.status[0], ST_PRE | (u64)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            if (lane == 0) __hip_atomic_store(&a.status[s], ST_AGG | (u64)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            int top = s - 1;  // highest predecessor not yet accounted for
-            u32 spins = 0;
-            bool fail = false;
-            while (true) {
-                const int j = top - lane;
-                u64 v = ST_PRE;  // lanes before segment 0 act as a zero prefix
-                if (j >= 0) v = __hip_atomic_load(&a.status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const u64 ready = __ballot((v >> 62) != 0);
-                const u64 pre = __ballot((v >> 62) == 2);
-                // usable lanes: a contiguous run of ready lanes starting at lane 0, cut after the first PRE
-                const u64 notready = ~ready;
-                const int nrun = notready ? __builtin_ctzll(notready) : 64;
-                const u64 runmask = nrun >= 64 ? ~0ull : ((1ull << nrun) - 1ull);
-                const u64 prein = pre & runmask;
-                int use = nrun;
-                bool finished = false;
-                if (prein) {
-                    use = __builtin_ctzll(prein) + 1;
-                    finished = true;
-                }
-                u64 part = lane < use ? (v & ST_VAL) : 0ull;
-#pragma unroll
-                for (int dlt = 32; dlt > 0; dlt >>= 1) part += __shfl_xor(part, dlt, ESP_WAVE);
-                excl += part;
-                top -= use;
-                if (finished) break;
-                if (use == 0) {
-                    if (++spins > SPIN_LIMIT) {
-                        fail = true;
-                        break;
-                    }
-                    __builtin_amdgcn_s_sleep(2);
-                }
-            }
-            if (fail && lane == 0) atomicOr(a.err, 1u);
-            if (lane == 0)
-                __hip_atomic_store(&a.status[s], ST_PRE | ((excl + (u64)total) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // ---- decoupled look-back (wave 0) unless the register tier already ran it
+        if (!lb_done) {
+            const u64 excl = lookback_wave(a, s, total, lane);
+            if (lane == 0) s_dst = excl;
+        } else if (lane == 0 && total != s_early) {
+            atomicOr(a.err, 4u);  // internal consistency: the early count must equal the folded count
         }
-        if (lane == 0) {
-            s_dst = excl;
-            lw[0] = total;
-        }
+        if (lane == 0) lw[0] = total;
     }
     __syncthreads();
+#ifdef ESP_LOCAL_STAMPS
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 6] = wall_clock64();
+#endif
     const u64 dst = s_dst;
     const int total = (int)lw[0];
     // dense prefix in LDS (all records and values are in registers: in-place is safe)
@@ -579,10 +674,12 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
                 atomicMax((unsigned long long *)&a.colend[col], (unsigned long long)(dst + (u64)p + 1));
         }
     }
+#ifdef ESP_LOCAL_STAMPS
     if (a.stamps) {
         __syncthreads();
         if (threadIdx.x == 0) a.stamps[(size_t)s * 8 + 7] = wall_clock64();
     }
+#endif
 }
 
 }  // namespace esplocal
