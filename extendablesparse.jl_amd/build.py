@@ -27,7 +27,8 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return SO
-    cmd = [HIPCC] + FLAGS + ["-o", SO, os.path.join(CSRC, "esparse_hip.hip")]
+    extra = os.environ.get("ESP_EXTRA_FLAGS", "").split()  # e.g. -DESP_LOCAL_STAMPS for the phase-stamp diagnostics
+    cmd = [HIPCC] + FLAGS + extra + ["-o", SO, os.path.join(CSRC, "esparse_hip.hip")]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

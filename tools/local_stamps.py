@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Phase stamps of the bucket kernel (diagnostic build: ESP_EXTRA_FLAGS=-DESP_LOCAL_STAMPS).
+Prints the median time every segment spends between the 8 stamps of esplocal::local_k."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch  # noqa: E402
+
+torch.cuda.init()
+from esparse_loader import load  # noqa: E402
+
+esp = load()
+n = 256
+N = n ** 3
+A = esp.ExtendableSparseMatrix(N, N, capacity_hint=12 * n * n * (n - 1) + 6 * n * n)
+for it in range(3):
+    A.reset()
+    A.generate_fdrand(n, n, n, rand_mode=1)
+    if it == 2:
+        os.environ["ESP_LOCAL_STAMPS"] = "gpurun_out/stamps.bin"
+    A.flush()
+st = np.fromfile("gpurun_out/stamps.bin", dtype=np.uint64).reshape(-1, 8).astype(np.int64)
+d = np.diff(st, axis=1) * 0.01  # 100 MHz ticks -> us
+names = ["segment known -> loads arrived", "column count + scan", "scatter to LDS", "sort (+early look-back) + fold",
+         "compaction", "look-back (if not early)", "LDS compact + stores"]
+print("segments", len(st), "lifetime us: median %.2f" % np.median((st[:, 7] - st[:, 0]) * 0.01))
+for i, nm in enumerate(names):
+    print("%-34s median %6.2f  p90 %6.2f" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 90)))
+span = (st[:, 7].max() - st[:, 0].min()) * 0.01
+print("kernel span %.1f us, %.0f segments resident on average" % (span, (st[:, 7] - st[:, 0]).sum() * 0.01 / span))
