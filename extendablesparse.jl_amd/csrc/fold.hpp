@@ -39,6 +39,21 @@ __device__ __forceinline__ void fold_step(bool &present, double &acc, u32 kind, 
     }
 }
 
+// The same state machine without branches (selects only): used where 64 lanes run it in lock step on
+// different column runs.  Bit-identical to fold_step (the unused sum of an absent, non-creating
+// update is simply discarded).
+__device__ __forceinline__ void fold_step_sel(bool &present, double &acc, u32 kind, double v) {
+    const bool nz = v != 0.0;
+    const bool set = kind == ESP_SET;
+    const bool creates = set ? nz : (kind == ESP_RAWUPDATE || nz);
+    const bool np = present || creates;
+    const double sumv = (present ? acc : 0.0) + v;
+    const double acc_add = np ? sumv : acc;
+    const double acc_set = (present || nz) ? v : acc;
+    acc = set ? acc_set : acc_add;
+    present = np;
+}
+
 // findindex(csc,i,j) (sparsematrixcsc.jl:7-23) with 0-based row0/col0; returns 0-based
 // position in rowval/nzval or -1
 __device__ __forceinline__ i64 csc_find(const Csc &c, i64 col0, i64 row0) {
