@@ -79,6 +79,8 @@ SIGNATURES = {
     "esp_shard_export": (i32, [vp, i32, vp, vp, vp]),
     "esp_shard_exchange_begin": (i32, [vp, i32, i32, i64, i64, P(vp), P(vp), vp]),
     "esp_shard_exchange_place": (i32, [vp, i64, vp, vp, i64]),
+    "esp_shard_partition": (i32, [vp, i32, i32, i64, P(i32), P(vp), P(vp), P(vp), vp, P(i64)]),
+    "esp_shard_assemble": (i32, [vp, vp, vp, vp, vp, P(i32)]),
     "esp_timing_enable": (i32, [vp, i32]),
     "esp_timing": (i32, [vp, P(esp_timing_t), i32]),
     "esp_debug_force_path": (i32, [vp, i32]),

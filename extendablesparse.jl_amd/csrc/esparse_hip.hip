@@ -65,6 +65,14 @@ struct esp_handle {
     // shard cache
     bool shard_valid = false;
     int shard_P = 0;
+    // partitioned exchange (esp_shard_partition / esp_shard_assemble)
+    bool part_valid = false;      // the pending buffer is partitioned by (owner, digit); tables in parttab
+    bool part_assembled = false;  // piece tables are built: the next flush runs the bucket kernel on them
+    int part_P = 0, part_me = 0, part_shift = 0;
+    u32 part_nb = 0;
+    u64 part_base = 0, part_span = 0;
+    i64 part_total = 0;
+    DevBuf parttab, piecetab;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -74,6 +82,13 @@ struct esp_handle {
 };
 
 static thread_local std::string g_err;
+
+// the pending entries changed: whatever was derived from them is stale
+static inline void pending_changed(esp_handle *h) {
+    h->shard_valid = false;
+    h->part_valid = false;
+    h->part_assembled = false;
+}
 
 static bool fused_begin(esp_handle *h, i64 E_call, i64 nchunks, espgen::Fused *f);
 static void fused_invalidate(esp_handle *h);
@@ -359,7 +374,7 @@ static int32_t pack_device(esp_handle *h, const i64 *d_rows, const i64 *d_cols, 
         FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
              (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
     h->count += count;
-    h->shard_valid = false;
+    pending_changed(h);
     return ESP_OK;
 }
 
@@ -465,7 +480,7 @@ extern "C" int32_t esp_append_packed(esp_handle *h, const uint64_t *d_keys, cons
     sp.add(2);
     fused_invalidate(h);
     h->count += count;
-    h->shard_valid = false;
+    pending_changed(h);
     return ESP_OK;
 }
 
@@ -529,7 +544,7 @@ extern "C" int32_t esp_generate_fdrand_range(esp_handle *h, int64_t nx, int64_t 
     }
     HIPCK(h, hipGetLastError());
     h->count += E;
-    h->shard_valid = false;
+    pending_changed(h);
     return ESP_OK;
 }
 
@@ -581,7 +596,7 @@ extern "C" int32_t esp_generate_fem(esp_handle *h, int32_t dim, int64_t npd, uin
     HIPCK(h, hipGetLastError());
     fused_invalidate(h);
     h->count += E;
-    h->shard_valid = false;
+    pending_changed(h);
     return ESP_OK;
 }
 
@@ -645,7 +660,7 @@ extern "C" int32_t esp_clear_pending(esp_handle *h) {
     if (!h) return ESP_ERR_INVALID;
     fused_reset(h);
     h->count = 0;
-    h->shard_valid = false;
+    pending_changed(h);
     return ESP_OK;
 }
 
@@ -654,7 +669,7 @@ extern "C" int32_t esp_reset(esp_handle *h) {
     (void)hipSetDevice(h->device);
     fused_reset(h);
     h->count = 0;
-    h->shard_valid = false;
+    pending_changed(h);
     return init_empty_csc(h);
 }
 
@@ -827,6 +842,10 @@ struct Sorted {
     const i64 *seg_start;
     int rem_bits;
     bool local_ok;
+    // PIECES (partitioned shard exchange): segments are concatenations of per-source pieces
+    int npieces = 0;
+    const i64 *pstart = nullptr;
+    const void *const *ptab = nullptr;
 };
 
 // ---- run lists of the pending entries (runpart.hpp) -------------------------------------------
@@ -939,12 +958,21 @@ static void fused_reset(esp_handle *h) {
 // (runpart.hpp).  *ok=false when some chunk holds too many distinct digits: nothing was moved and the
 // caller uses the 8-bit passes.  On success kout/vout hold the partitioned entries, seg_out (NB+1
 // entries, device) the bucket starts and tile_first_out the tile index of every bucket.
+// several key windows side by side (column shards): see esprun::Args
+struct MultiWin {
+    int P;
+    u32 nb;
+    const u64 *d_base;
+};
+
+// mw != nullptr: buckets = mw->P * mw->nb (window r = digits [r*nb, (r+1)*nb)), pb = bits covering them
 static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u64 *kout, double *vout, int K, int pb,
-                             i64 *seg_out, u64 *tile_first_out, bool *ok, i64 *maxlen_out) {
+                             i64 *seg_out, u64 *tile_first_out, bool *ok, i64 *maxlen_out, const MultiWin *mw = nullptr,
+                             int mw_shift = 0) {
     const i64 E = h->count;
-    const i64 NB = (i64)1 << pb;
+    const i64 NB = mw ? (i64)mw->P * (i64)mw->nb : (i64)1 << pb;
     CK(ensure(h, h->misc, 256));
-    const bool fused = h->fused_state == 1 && h->chunk_pb == pb && h->fused_K == K;
+    const bool fused = !mw && h->fused_state == 1 && h->chunk_pb == pb && h->fused_K == K;
     const i64 C = fused ? h->fused_chunks : ceil_div<i64>(E, esprun::TILE);
     ChunkArrays ca;
     if (fused) {
@@ -976,9 +1004,12 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
     a.vals_out = vout;
     a.E = E;
     a.chunk_start = ca.chunk_start;
-    a.shift = K - pb;
+    a.shift = mw ? mw_shift : K - pb;
     a.base = h->win_base;
     a.span = h->win_span;
+    a.mw_P = mw ? mw->P : 0;
+    a.mw_nb = mw ? mw->nb : 0;
+    a.mw_base = mw ? mw->d_base : nullptr;
     a.err = (u32 *)h->misc.p + 60;
     a.overflow = ca.overflow;
     a.runs_d = ca.runs_d;
@@ -994,7 +1025,10 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
         HIPCK(h, hipMemsetAsync(bstart, 0, sizeof(u64) * (size_t)(NB + 1), h->stream));
         hipLaunchKernelGGL(esprun::fixed_chunks_k, dim3(grid_for(C + 1, 256)), dim3(256), 0, h->stream, ca.chunk_start, (i64)0, C, (i64)0, E);
         Span sp(h, ESP_ST_HIST);
-        hipLaunchKernelGGL(esprun::run_hist_k, dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a, (i64)0);
+        if (mw)
+            hipLaunchKernelGGL((esprun::run_hist_k<true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a, (i64)0);
+        else
+            hipLaunchKernelGGL((esprun::run_hist_k<false>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a, (i64)0);
         sp.add(1);
     }
     HIPCK(h, hipMemsetAsync(nruns + C, 0, sizeof(u64), h->stream));
@@ -1074,7 +1108,10 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
     }
     {
         Span sp(h, ESP_ST_SCATTER);
-        hipLaunchKernelGGL(esprun::run_scatter_k, dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
+        if (mw)
+            hipLaunchKernelGGL((esprun::run_scatter_k<true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
+        else
+            hipLaunchKernelGGL((esprun::run_scatter_k<false>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
         sp.add(1);
     }
     HIPCK(h, hipGetLastError());
@@ -1317,7 +1354,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         a.seg_start = st.seg_start;
         a.S = S;
         a.rem_bits = st.rem_bits;
-        a.base = h->win_base;
+        a.base = st.npieces > 0 ? h->part_base : h->win_base;
         a.rb = h->L.rb;
         {
             const int clb = st.rem_bits - h->L.rb;
@@ -1332,6 +1369,9 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         a.out_val = tv;
         a.colend = (u64 *)h->colend.p;
         a.status = status;
+        a.npieces = st.npieces;
+        a.pstart = st.pstart;
+        a.ptab = st.ptab;
         a.ticket = (u32 *)(status + S);
         a.err = (u32 *)(status + S) + 1;
         {
@@ -1348,10 +1388,16 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         for (i64 first = 0; first < S; first += max_grid) {
             const unsigned grid = (unsigned)std::min<i64>(max_grid, S - first);
             a.first = first;
-            if (Z0 == 0)
-                hipLaunchKernelGGL((esplocal::local_k<true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
-            else
-                hipLaunchKernelGGL((esplocal::local_k<false>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+            if (st.npieces > 0) {
+                if (Z0 == 0)
+                    hipLaunchKernelGGL((esplocal::local_k<true, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+                else
+                    hipLaunchKernelGGL((esplocal::local_k<false, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+            } else if (Z0 == 0) {
+                hipLaunchKernelGGL((esplocal::local_k<true, false>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+            } else {
+                hipLaunchKernelGGL((esplocal::local_k<false, false>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+            }
         }
         sp.add(1);
     }
@@ -1449,7 +1495,27 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
     }
     i64 Zn = 0;
     bool use_local = h->force_path != 2;
-    if (use_local) {
+    if (h->part_assembled) {
+        // partitioned shard exchange: the segments are already formed (esp_shard_assemble)
+        CK(ensure(h, h->misc, 256));
+        HIPCK(h, hipMemsetAsync((u32 *)h->misc.p + 60, 0, 4, h->stream));
+        Sorted st;
+        char *T = (char *)h->piecetab.p;
+        st.sk = (const u64 *)h->keys.p;
+        st.sv = (const double *)h->vals.p;
+        st.in_primary = true;
+        st.S = (int)h->part_nb;
+        st.seg_start = nullptr;
+        st.rem_bits = h->part_shift;
+        st.local_ok = true;
+        st.npieces = h->part_P;
+        st.ptab = (const void *const *)T;
+        st.pstart = (const i64 *)(T + 256 * 8);
+        CK(ensure(h, h->keys2, sizeof(u64) * (size_t)std::max<i64>(h->part_total, 1)));
+        CK(ensure(h, h->vals2, sizeof(double) * (size_t)std::max<i64>(h->part_total, 1)));
+        CK(flush_local(h, st, mode, &Zn));
+        h->last_partition = 7;
+    } else if (use_local) {
         Sorted st;
         CK(sort_msd(h, &st));
         if (!st.in_primary) {  // keep "pending data lives in keys/vals" true for the general path
@@ -1463,13 +1529,13 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         else
             use_local = false;
     }
-    if (!use_local) CK(flush_global(h, mode, &Zn));
-    h->last_path = use_local ? 1 : 2;
+    if (!use_local && !h->part_assembled) CK(flush_global(h, mode, &Zn));
+    h->last_path = (use_local || h->part_assembled) ? 1 : 2;
     if (Zn > 0 && pattern_changed) *pattern_changed = 1;
     HIPCK(h, hipGetLastError());
     fused_reset(h);
     h->count = 0;
-    h->shard_valid = false;
+    pending_changed(h);
     if (h->timing && fa) {
         hipEvent_t fb = ev_get(h);
         (void)hipEventRecord(fb, h->stream);
@@ -1502,6 +1568,7 @@ extern "C" int32_t esp_debug_last_path(const esp_handle *h, int32_t *path) {
 // every destination receives its entries in this shard's append order.
 static int32_t shard_prepare(esp_handle *h, int P, espradix::Pass *out) {
     if (P < 1 || P > 256) FAIL(h, ESP_ERR_INVALID, "shards: nshards must be in 1..256");
+    h->part_valid = h->part_assembled = false;  // (its tables share scratch arrays with this path)
     if ((double)h->n * (double)P >= 9.0e18) FAIL(h, ESP_ERR_UNSUPPORTED, "shards: n*nshards overflows");
     const i64 E = h->count;
     int bits = 1;
@@ -1655,7 +1722,7 @@ extern "C" int32_t esp_shard_exchange_begin(esp_handle *h, int32_t nshards, int3
     h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
     h->fused_state = 2;
     h->count = newcount;
-    h->shard_valid = false;
+    pending_changed(h);
     *d_send_keys = (uint64_t *)h->keys.p + SR;
     *d_send_vals = (double *)h->vals.p + SR;
     return ESP_OK;
@@ -1671,6 +1738,255 @@ extern "C" int32_t esp_shard_exchange_place(esp_handle *h, int64_t position, con
     HIPCK(h, hipMemcpyAsync((double *)h->vals.p + position, d_vals, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
     sp.add(2);
     HIPCK(h, hipStreamSynchronize(h->stream));
+    return ESP_OK;
+}
+
+// ---- partitioned exchange -------------------------------------------------------------------
+// The owner partition of esp_shard_exchange_begin and the first partition pass of the local flush are
+// ONE pass here: every rank partitions its pending entries by (owner, digit inside the owner's key
+// window) with the run-based single pass, sends every other owner its range together with the
+// per-digit counts, and the bucket kernel of the receiving rank reads a segment as the concatenation
+// of one piece per source rank (rank order, source order inside: the same deterministic order as one
+// buffer fed the ranks' streams in turn).  Nothing is moved a second time and the own range is
+// never copied.
+static inline i64 shard_col0(i64 n, int P, int r) { return (i64)(((__int128)r * (__int128)n + P - 1) / P); }  // ceil(r*n/P)
+
+__global__ void gather_stride_k(const i64 *__restrict__ src, i64 stride, int count, i64 *__restrict__ dst) {
+    const int i = threadIdx.x;
+    if (i < count) dst[i] = src[(size_t)i * (size_t)stride];
+}
+
+__global__ void diff_counts_k(const i64 *__restrict__ bstart, i64 NB, i64 *__restrict__ cnt) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < NB) cnt[i] = bstart[i + 1] - bstart[i];
+}
+
+// one workgroup per source q: pstart[q][0..nb] = exclusive scan of that source's per-digit counts
+// (q == me: the bucket starts of the own range, absolute positions in the partitioned buffer)
+// summary[q] = entries of source q (q == me: of the own range), summary[P] = start of the own range
+__global__ __launch_bounds__(1024) void piece_scan_k(const i64 *const *__restrict__ counts, const i64 *__restrict__ own_bstart, int me,
+                                                     i64 nb, i64 *__restrict__ pstart, i64 *__restrict__ summary) {
+    __shared__ i64 lw[16];
+    __shared__ i64 carry;
+    const int q = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    i64 *out = pstart + (size_t)q * (size_t)(nb + 1);
+    if (q == me) {
+        for (i64 d = t; d <= nb; d += 1024) out[d] = own_bstart[d];
+        if (t == 0) {
+            summary[q] = own_bstart[nb] - own_bstart[0];
+            summary[gridDim.x] = own_bstart[0];
+        }
+        return;
+    }
+    const i64 *c = counts[q];
+    if (t == 0) carry = 0;
+    __syncthreads();
+    for (i64 b0 = 0; b0 < nb; b0 += 1024) {
+        const i64 d = b0 + t;
+        const i64 x = d < nb ? c[d] : 0;
+        i64 inc = x;
+#pragma unroll
+        for (int dlt = 1; dlt < 64; dlt <<= 1) {
+            const i64 o = __shfl_up(inc, dlt, 64);
+            if (lane >= dlt) inc += o;
+        }
+        if (lane == 63) lw[w] = inc;
+        __syncthreads();
+        i64 pre = carry;
+        for (int i = 0; i < w; i++) pre += lw[i];
+        if (d < nb) out[d] = pre + inc - x;
+        __syncthreads();
+        if (t == 1023) carry = pre + inc;
+        __syncthreads();
+    }
+    if (t == 0) {
+        out[nb] = carry;
+        summary[q] = carry;
+    }
+}
+
+// merged length of every segment; longest one
+__global__ void piece_totals_k(const i64 *__restrict__ pstart, int P, i64 nb, unsigned long long *__restrict__ maxlen,
+                               unsigned long long *__restrict__ negative) {
+    const i64 d = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d >= nb) return;
+    i64 tot = 0;
+    for (int q = 0; q < P; q++) {
+        const i64 len = pstart[(size_t)q * (size_t)(nb + 1) + d + 1] - pstart[(size_t)q * (size_t)(nb + 1) + d];
+        if (len < 0) atomicAdd(negative, 1ull);
+        tot += len;
+    }
+    atomicMax(maxlen, (unsigned long long)tot);
+}
+
+extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t self, int64_t entries_per_shard, int32_t *ok,
+                                       uint64_t **d_keys, double **d_vals, int64_t **d_counts, int64_t *entry_offsets,
+                                       int64_t *digits_per_shard) {
+    if (!h || !ok || !d_keys || !d_vals || !d_counts || !entry_offsets || !digits_per_shard) return ESP_ERR_INVALID;
+    *ok = 0;
+    const int P = nshards;
+    if (P < 1 || self < 0 || self >= P || entries_per_shard < 0) FAIL(h, ESP_ERR_INVALID, "esp_shard_partition: arguments");
+    (void)hipSetDevice(h->device);
+    h->part_valid = h->part_assembled = false;
+    if (P > esprun::MW_MAX || P > esplocal::MAX_PIECES || h->force_path == 11) return ESP_OK;  // caller uses the plain exchange
+    if ((double)h->n * (double)P >= 9.0e18) FAIL(h, ESP_ERR_UNSUPPORTED, "shards: n*nshards overflows");
+    const i64 E = h->count;
+    if (E >= 0xFFFFFFF0ll) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_shard_partition: too many pending entries");
+    // every rank derives the same plan from (n, P, entries_per_shard)
+    std::vector<u64> base((size_t)P);
+    u64 maxspan = 1;
+    for (int r = 0; r < P; r++) {
+        const i64 c0 = shard_col0(h->n, P, r), c1 = shard_col0(h->n, P, r + 1);
+        base[(size_t)r] = (u64)c0 << h->L.rb;
+        maxspan = std::max(maxspan, (u64)(c1 - c0) << h->L.rb);
+    }
+    int K = 1;
+    while (K < 62 && ((u64)1 << K) < maxspan) K++;
+    const int pbw = plan_run_bits(std::max<i64>(entries_per_shard, 1), K);
+    if (pbw == 0 || K - pbw > esplocal::MAX_REM_BITS) return ESP_OK;  // small or odd problem: plain exchange
+    const int shift = K - pbw;
+    const u64 nb64 = ((maxspan - 1) >> shift) + 1;
+    const i64 NB = (i64)nb64 * P;
+    if (NB > ((i64)1 << 24)) return ESP_OK;
+    int pb = 1;
+    while (((i64)1 << pb) < NB) pb++;
+    // tables: bases (<= 64 u64) | owner offsets (<= 65 i64) | counts (NB i64)
+    const size_t o_cnt = 256 * 8;
+    CK(ensure(h, h->parttab, o_cnt + sizeof(i64) * (size_t)(NB + 1)));
+    char *T = (char *)h->parttab.p;
+    HIPCK(h, hipMemcpyAsync(T, base.data(), sizeof(u64) * (size_t)P, hipMemcpyHostToDevice, h->stream));
+    i64 *cnt = (i64 *)(T + o_cnt);
+    CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(NB + 1)));
+    CK(ensure(h, h->tilef[1], sizeof(u64) * (size_t)(NB + 1 + espscan::workspace_elems(NB + 1))));
+    i64 *bstart = (i64 *)h->seg[1].p;
+    std::vector<i64> off((size_t)P + 1, 0);
+    if (E > 0) {
+        CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
+        CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
+        CK(ensure(h, h->misc, 256));
+        HIPCK(h, hipMemsetAsync((u32 *)h->misc.p + 60, 0, 4, h->stream));
+        MultiWin mw{P, (u32)nb64, (const u64 *)T};
+        bool took = false;
+        i64 ml = 0;
+        CK(run_partition(h, (const u64 *)h->keys.p, (const double *)h->vals.p, (u64 *)h->keys2.p, (double *)h->vals2.p, K, pb, bstart,
+                         (u64 *)h->tilef[1].p, &took, &ml, &mw, shift));
+        if (!took) return ESP_OK;  // not a pre-sorted stream: plain exchange
+        std::swap(h->keys, h->keys2);
+        std::swap(h->vals, h->vals2);
+        h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
+        h->fused_state = 2;
+        h->shard_valid = false;
+    } else {
+        HIPCK(h, hipMemsetAsync(bstart, 0, sizeof(i64) * (size_t)(NB + 1), h->stream));
+    }
+    hipLaunchKernelGGL(diff_counts_k, dim3(grid_for(NB, 256)), dim3(256), 0, h->stream, (const i64 *)bstart, NB, cnt);
+    // owner ranges = bucket starts at every multiple of nb
+    i64 *d_off = (i64 *)(T + 64 * 8);
+    hipLaunchKernelGGL(gather_stride_k, dim3(1), dim3(128), 0, h->stream, (const i64 *)bstart, (i64)nb64, P + 1, d_off);
+    HIPCK(h, hipMemcpyAsync(off.data(), d_off, sizeof(i64) * (size_t)(P + 1), hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    for (int r = 0; r <= P; r++) entry_offsets[r] = off[(size_t)r];
+    *digits_per_shard = (int64_t)nb64;
+    *d_keys = (uint64_t *)h->keys.p;
+    *d_vals = (double *)h->vals.p;
+    *d_counts = cnt;
+    h->part_valid = true;
+    h->part_P = P;
+    h->part_me = self;
+    h->part_shift = shift;
+    h->part_nb = (u32)nb64;
+    h->part_base = base[(size_t)self];
+    h->part_span = (u64)(shard_col0(h->n, P, self + 1) - shard_col0(h->n, P, self)) << h->L.rb;
+    *ok = 1;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_shard_assemble(esp_handle *h, const uint64_t *const *d_recv_keys, const double *const *d_recv_vals,
+                                      const int64_t *const *d_recv_counts, const int64_t *recv_entries, int32_t *ok) {
+    if (!h || !d_recv_keys || !d_recv_vals || !d_recv_counts || !recv_entries || !ok) return ESP_ERR_INVALID;
+    *ok = 0;
+    if (!h->part_valid) FAIL(h, ESP_ERR_STATE, "esp_shard_assemble: no partitioned pending buffer (esp_shard_partition first; no appends in between)");
+    (void)hipSetDevice(h->device);
+    const int P = h->part_P, me = h->part_me;
+    const i64 nb = (i64)h->part_nb;
+    const i64 *bstart = (const i64 *)h->seg[1].p + (size_t)me * (size_t)nb;  // own range of the bucket starts
+    // pointer table (keys | values | counts of every source) | summary | piece starts
+    const size_t o_sum = 192 * 8, o_ps = 256 * 8;
+    CK(ensure(h, h->piecetab, o_ps + sizeof(i64) * (size_t)P * (size_t)(nb + 1)));
+    char *T = (char *)h->piecetab.p;
+    std::vector<const void *> tab(192, nullptr);
+    i64 total_recv = 0;
+    for (int q = 0; q < P; q++) {
+        if (q == me) {
+            tab[(size_t)q] = h->keys.p;
+            tab[(size_t)P + q] = h->vals.p;
+        } else {
+            if (recv_entries[q] < 0 || (recv_entries[q] > 0 && (!d_recv_keys[q] || !d_recv_vals[q])) || !d_recv_counts[q])
+                FAIL(h, ESP_ERR_INVALID, "esp_shard_assemble: received block %d", q);
+            tab[(size_t)q] = d_recv_keys[q];
+            tab[(size_t)P + q] = d_recv_vals[q];
+            tab[128 + (size_t)q] = d_recv_counts[q];
+            total_recv += recv_entries[q];
+        }
+    }
+    HIPCK(h, hipMemcpyAsync(T, tab.data(), 192 * 8, hipMemcpyHostToDevice, h->stream));
+    i64 *pstart = (i64 *)(T + o_ps);
+    i64 *d_sum = (i64 *)(T + o_sum);
+    CK(ensure(h, h->misc, 256));
+    unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
+    HIPCK(h, hipMemsetAsync(d_maxlen, 0, 16, h->stream));
+    {
+        Span sp(h, ESP_ST_SCAN);
+        hipLaunchKernelGGL(piece_scan_k, dim3((unsigned)P), dim3(1024), 0, h->stream, (const i64 *const *)(T + 128 * 8), bstart, me, nb, pstart, d_sum);
+        hipLaunchKernelGGL(piece_totals_k, dim3(grid_for(nb, 256)), dim3(256), 0, h->stream, (const i64 *)pstart, P, nb, d_maxlen, d_maxlen + 1);
+        sp.add(2);
+    }
+    std::vector<i64> last((size_t)P + 1);
+    HIPCK(h, hipMemcpyAsync(last.data(), d_sum, sizeof(i64) * (size_t)(P + 1), hipMemcpyDeviceToHost, h->stream));
+    unsigned long long mx[2];
+    HIPCK(h, hipMemcpyAsync(mx, d_maxlen, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    HIPCK(h, hipGetLastError());
+    for (int q = 0; q < P; q++)
+        if (q != me && last[(size_t)q] != recv_entries[q])
+            FAIL(h, ESP_ERR_STATE, "esp_shard_assemble: block from shard %d holds %lld entries, its digit counts sum to %lld", q,
+                 (long long)recv_entries[q], (long long)last[(size_t)q]);
+    if (mx[1]) FAIL(h, ESP_ERR_STATE, "esp_shard_assemble: negative digit count in a received block");
+    const i64 own_n = last[(size_t)me];
+    const i64 own[2] = {last[(size_t)P], last[(size_t)P] + own_n};
+    const i64 total = own_n + total_recv;
+    if (total >= 0xFFFFFFF0ll) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_shard_assemble: too many entries for one flush");
+    if ((i64)mx[0] > esplocal::CAP) {
+        // a merged segment does not fit the bucket kernel: hand the entries over as a plain pending
+        // buffer (lower ranks, own range, higher ranks) -- the next flush partitions it as usual
+        CK(ensure(h, h->keys2, sizeof(u64) * (size_t)std::max<i64>(total, 1)));
+        CK(ensure(h, h->vals2, sizeof(double) * (size_t)std::max<i64>(total, 1)));
+        i64 at = 0;
+        Span sp(h, ESP_ST_COPY);
+        for (int q = 0; q < P; q++) {
+            const u64 *sk = q == me ? (const u64 *)h->keys.p + own[0] : d_recv_keys[q];
+            const double *sv = q == me ? (const double *)h->vals.p + own[0] : d_recv_vals[q];
+            const i64 c = q == me ? own_n : recv_entries[q];
+            if (c > 0) {
+                HIPCK(h, hipMemcpyAsync((u64 *)h->keys2.p + at, sk, sizeof(u64) * (size_t)c, hipMemcpyDeviceToDevice, h->stream));
+                HIPCK(h, hipMemcpyAsync((double *)h->vals2.p + at, sv, sizeof(double) * (size_t)c, hipMemcpyDeviceToDevice, h->stream));
+                sp.add(2);
+            }
+            at += c;
+        }
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        std::swap(h->keys, h->keys2);
+        std::swap(h->vals, h->vals2);
+        h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
+        h->count = total;
+        h->fused_state = 2;
+        pending_changed(h);
+        return ESP_OK;
+    }
+    h->count = total;
+    h->part_total = total;
+    h->part_assembled = true;
+    *ok = 1;
     return ESP_OK;
 }
 

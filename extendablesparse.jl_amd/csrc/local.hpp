@@ -98,7 +98,14 @@ struct Args {
     int stop_after;  // timing ablation only (0 = run everything)
     i64 first;       // ticket value the first workgroup of this launch is expected to draw
     unsigned long long *stamps;  // diagnostics (builds with -DESP_LOCAL_STAMPS only): 8 wall-clock stamps per segment
+    // PIECES variant (column shards after the partitioned exchange): segment s is the concatenation, in
+    // source-rank order, of one piece per source: entries [pstart[q*(S+1)+s], pstart[q*(S+1)+s+1]) of the
+    // arrays ptab[q] (keys) / ptab[npieces+q] (values)
+    int npieces;
+    const i64 *pstart;
+    const void *const *ptab;
 };
+constexpr int MAX_PIECES = 64;
 
 // Stable LSD radix tail on the packed keys held in registers (wave-striped arrangement):
 // sorts on bits [SUB_SHIFT, SUB_SHIFT+rem_bits); result in k[] and skey[].
@@ -335,7 +342,7 @@ __device__ __forceinline__ u64 lookback_wave(const Args &a, int s, u32 total, in
     return lb_finish(a, st, s, total, lane);
 }
 
-template <bool FRESH>
+template <bool FRESH, bool PIECES>
 __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     __shared__ u64 skey[CAP];
     __shared__ double sval[CAP];
@@ -359,7 +366,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     // outside the window simply reloads).
     constexpr int WIN = 64;
     const i64 w0 = max((i64)0, a.first + (i64)blockIdx.x - WIN / 2);
-    if (t <= WIN + 1 && w0 + t <= (i64)a.S) s_win[t] = a.seg_start[w0 + t];
+    if (!PIECES && t <= WIN + 1 && w0 + t <= (i64)a.S) s_win[t] = a.seg_start[w0 + t];
     if (t == 0) {
         s_seg = (int)atomicAdd(a.ticket, 1u);
         s_early = 0;
@@ -367,29 +374,90 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     __syncthreads();
     const int s = s_seg;
     if (s >= a.S) return;
-    const bool inwin = s >= w0 && (i64)s + 1 <= w0 + WIN + 1;
-    const i64 beg = inwin ? s_win[s - w0] : a.seg_start[s];
-    const i64 seg_end = inwin ? s_win[s - w0 + 1] : a.seg_start[s + 1];
-#ifdef ESP_LOCAL_STAMPS
-    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 0] = wall_clock64();
-#endif
-    const int n = (int)(seg_end - beg);
     const u64 submask = a.rem_bits >= 64 ? ~0ull : ((1ull << a.rem_bits) - 1ull);
-    // shared prefix of the segment (window-relative), turned back into an absolute key prefix
-    const u64 hi = n > 0 ? (((((a.keys_in[beg] >> ESP_TAG_BITS) - a.base) >> a.rem_bits) << a.rem_bits) + a.base) : 0;
     const int wbase = w * (ITEMS * ESP_WAVE) + lane;
     const u64 lt = (1ull << lane) - 1ull;
     const u64 rowmask = (1ull << a.rb) - 1ull;
-
-    // all 16 loads of a thread are issued before anything depends on them: the index is clamped so
-    // that the loads need no branch (slots past the end re-read the last entry and are discarded)
     u64 k[ITEMS];
     double vraw[ITEMS];
-    const int nlast = n > 0 ? n - 1 : 0;
+    u64 hi;
+    int n;
+    if constexpr (!PIECES) {
+        const bool inwin = s >= w0 && (i64)s + 1 <= w0 + WIN + 1;
+        const i64 beg = inwin ? s_win[s - w0] : a.seg_start[s];
+        const i64 seg_end = inwin ? s_win[s - w0 + 1] : a.seg_start[s + 1];
+#ifdef ESP_LOCAL_STAMPS
+        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 0] = wall_clock64();
+#endif
+        n = (int)(seg_end - beg);
+        // shared prefix of the segment (window-relative), turned back into an absolute key prefix
+        hi = n > 0 ? (((((a.keys_in[beg] >> ESP_TAG_BITS) - a.base) >> a.rem_bits) << a.rem_bits) + a.base) : 0;
+        // all 16 loads of a thread are issued before anything depends on them: the index is clamped so
+        // that the loads need no branch (slots past the end re-read the last entry and are discarded)
+        const int nlast = n > 0 ? n - 1 : 0;
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) k[i] = n > 0 ? a.keys_in[beg + min(wbase + i * ESP_WAVE, nlast)] : 0ull;
+        for (int i = 0; i < ITEMS; i++) k[i] = n > 0 ? a.keys_in[beg + min(wbase + i * ESP_WAVE, nlast)] : 0ull;
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) vraw[i] = n > 0 ? a.vals_in[beg + min(wbase + i * ESP_WAVE, nlast)] : 0.0;
+        for (int i = 0; i < ITEMS; i++) vraw[i] = n > 0 ? a.vals_in[beg + min(wbase + i * ESP_WAVE, nlast)] : 0.0;
+    } else {
+        // the segment's pieces, one per source rank (most segments of a slab-wise assembly have one)
+        __shared__ i64 p_beg[MAX_PIECES];
+        __shared__ int p_pre[MAX_PIECES + 1];
+        __shared__ const u64 *p_k[MAX_PIECES];
+        __shared__ const double *p_v[MAX_PIECES];
+        __shared__ int p_single;
+        if (w == 0) {
+            int len = 0;
+            if (lane < a.npieces) {
+                const i64 b = a.pstart[(size_t)lane * (size_t)(a.S + 1) + (size_t)s];
+                len = (int)(a.pstart[(size_t)lane * (size_t)(a.S + 1) + (size_t)s + 1] - b);
+                p_beg[lane] = b;
+                p_k[lane] = static_cast<const u64 *>(a.ptab[lane]);
+                p_v[lane] = static_cast<const double *>(a.ptab[a.npieces + lane]);
+            }
+            int inc = len;
+#pragma unroll
+            for (int dlt = 1; dlt < ESP_WAVE; dlt <<= 1) {
+                const int o = __shfl_up(inc, dlt, ESP_WAVE);
+                if (lane >= dlt) inc += o;
+            }
+            if (lane < a.npieces) p_pre[lane] = inc - len;
+            if (lane == 63) p_pre[a.npieces] = inc;
+            const u64 nonempty = __ballot(len > 0);
+            if (lane == 0) p_single = __popcll(nonempty) == 1 ? __builtin_ctzll(nonempty) : -1;
+        }
+        __syncthreads();
+        n = p_pre[a.npieces];
+        n = min(n, CAP);  // (the host checked the merged length; never index past the LDS arrays)
+        hi = ((u64)s << a.rem_bits) + a.base;
+        const int nlast = n > 0 ? n - 1 : 0;
+        const int single = p_single;
+        if (single >= 0) {
+            const u64 *pk = p_k[single];
+            const double *pv = p_v[single];
+            const i64 beg = p_beg[single];
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) k[i] = pk[beg + min(wbase + i * ESP_WAVE, nlast)];
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) vraw[i] = pv[beg + min(wbase + i * ESP_WAVE, nlast)];
+        } else {
+            const u64 *ak[ITEMS];
+            const double *av[ITEMS];
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const int p = min(wbase + i * ESP_WAVE, nlast);
+                int q = 0;
+                while (q + 1 < a.npieces && p >= p_pre[q + 1]) q++;
+                const i64 at = p_beg[q] + (i64)(p - p_pre[q]);
+                ak[i] = p_k[q] + at;
+                av[i] = p_v[q] + at;
+            }
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) k[i] = n > 0 ? *ak[i] : 0ull;
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) vraw[i] = n > 0 ? *av[i] : 0.0;
+        }
+    }
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const int p = wbase + i * ESP_WAVE;

@@ -44,13 +44,38 @@ struct Args {
     i64 *runs_off;   // [tile][RMAX] global output offset of the run
     u64 *nruns;      // [tile] (+1 slot for the scan)
     unsigned long long *bucket_count;  // [nbuckets + 1]
+    // several key windows side by side (column shards, MULTI kernels): window r starts at key mw_base[r]
+    // (ascending), holds mw_nb digits of width 2^shift; global digit = r * mw_nb + local digit
+    int mw_P;
+    u32 mw_nb;
+    const u64 *mw_base;
 };
+constexpr int MW_MAX = 64;  // windows the MULTI kernels take
 
 __device__ __forceinline__ u32 digit16(const Args &a, u64 key, bool check) {
     u64 kn = (key >> ESP_TAG_BITS) - a.base;
     if (check && kn >= a.span) *a.err = 1u;
     kn = kn < a.span ? kn : a.span - 1;
     return (u32)(kn >> a.shift);
+}
+
+// MULTI: binary search of the key's window in the LDS copy of mw_base, then the digit inside it
+template <bool MULTI>
+__device__ __forceinline__ u32 digit_mw(const Args &a, const u64 *s_mw, u64 key, bool check) {
+    if constexpr (!MULTI) {
+        return digit16(a, key, check);
+    } else {
+        const u64 kp = key >> ESP_TAG_BITS;
+        int r = 0;
+#pragma unroll
+        for (int step = MW_MAX / 2; step; step >>= 1) {
+            const int c = r + step;
+            if (c < a.mw_P && kp >= s_mw[c]) r = c;
+        }
+        u64 dl = (kp - s_mw[r]) >> a.shift;
+        dl = dl < (u64)a.mw_nb ? dl : (u64)a.mw_nb - 1;
+        return (u32)r * a.mw_nb + (u32)dl;
+    }
 }
 
 // digit of a key for producers that emit their chunk's run list themselves
@@ -143,11 +168,14 @@ __device__ __forceinline__ void count_runs(const u32 (&dig)[NITEMS], u32 pend, i
     }
 }
 
+template <bool MULTI>
 __global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_chunk) {
     __shared__ u32 rd[RMAX];
     __shared__ u32 rc[RMAX];
     __shared__ u32 over;
+    __shared__ u64 s_mw[MULTI ? MW_MAX : 1];
     const int t = threadIdx.x;
+    if (MULTI && t < a.mw_P) s_mw[t] = a.mw_base[t];
     // a stream that is not pre-sorted is recognised by the first workgroups: the rest leave at once
     if (__hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const i64 chunk = first_chunk + blockIdx.x;
@@ -170,7 +198,7 @@ __global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_chunk) {
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         const bool valid = (beg + k * THREADS + t) < end;
-        dig[k] = valid ? digit16(a, key[k], true) : 0u;
+        dig[k] = valid ? digit_mw<MULTI>(a, s_mw, key[k], true) : 0u;
         pend |= valid ? (1u << k) : 0u;
     }
     const RunSink sink{a.runs_d, a.runs_c, a.nruns, a.bucket_count, a.overflow};
@@ -227,7 +255,9 @@ __global__ void run_offsets_k(const u64 *__restrict__ lk, const double *__restri
     runs_off[tile * RMAX + j] = (i64)(bucket_start[d] + sc[i] - head[d]);
 }
 
+template <bool MULTI>
 __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
+    __shared__ u64 s_mw[MULTI ? MW_MAX : 1];
     __shared__ u32 hd[RMAX];  // open-addressing map digit -> run index of this tile
     __shared__ u32 hj[RMAX];
     __shared__ i64 roff[RMAX];
@@ -244,6 +274,7 @@ __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
         hd[t] = EMPTY;
     }
     if (t < WAVES * RMAX) (&cnt[0][0])[t] = 0;
+    if (MULTI && t < a.mw_P) s_mw[t] = a.mw_base[t];
     u64 key[ITEMS];
     double val[ITEMS];
     const i64 wbase = beg + (i64)w * (ESP_WAVE * ITEMS) + lane;
@@ -279,7 +310,7 @@ __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         const bool valid = (wbase + k * ESP_WAVE) < end;
-        dig[k] = valid ? digit16(a, key[k], false) : 0u;
+        dig[k] = valid ? digit_mw<MULTI>(a, s_mw, key[k], false) : 0u;
         pend |= valid ? (1u << k) : 0u;
         rank[k] = 0;
         jrun[k] = 0;

@@ -6,14 +6,22 @@ appends whatever updates its part of the assembly loop produces -- like one refe
 entry to the rank that owns its column with ONE all-to-all-v before the local flush:
 
     owner(col) = floor((col-1) * P / n)                      contiguous column ranges
-    1. stable partition of the pending entries by owner       (esp_shard_export, HIP)
-    2. all_to_all_single of the per-destination counts        (P x 8 B)
-    3. all_to_all_single of the 8-byte keys and 8-byte values (RCCL; per link: bytes_to_peer/153 GB/s)
-    4. local flush of the received entries                    (same kernels as the 1-GPU path)
-    5. all_gather of the local nnz -> colptr offsets of the global CSC
 
-Received chunks are ordered by source rank and keep the source's append order, so the ordered
-fold stays deterministic: the result equals ONE buffer fed the streams of rank 0, 1, ... in turn.
+Partitioned exchange (streams an assembly loop emits; `last_exchange == "partitioned"`):
+    1. ONE stable pass per rank partitions its pending entries by (owner, digit inside the owner's
+       column range): the owner split and the first partition pass of the local flush at once
+       (esp_shard_partition, HIP, run-based single pass)
+    2. all_gather of (applicable?, entries per owner)        -> every rank takes the same decision
+    3. all_to_all of keys, values (ranges of the other owners; the own range is not touched) and of
+       the per-digit counts                                   (RCCL; per link: bytes_to_peer/153 GB/s)
+    4. esp_shard_assemble: piece tables -- the bucket kernel reads a segment as the concatenation of
+       one piece per source rank, straight from the receive buffers (nothing is copied or re-sorted)
+    5. bucket kernel + colptr (unchanged), all_gather of the local nnz -> global colptr offsets
+Plain exchange (any stream, and whenever some rank reports "not applicable"): stable partition by owner
+(esp_shard_exchange_begin), all-to-all-v, esp_shard_exchange_place, ordinary local flush.
+
+Either way the received entries are ordered by source rank and keep the source's append order, so the
+ordered fold stays deterministic: the result equals ONE buffer fed the streams of rank 0, 1, ... in turn.
 
 The exchange logic is independent of where the entries live: `backend` supplies the local
 operations.  HipShardBackend is the product (device memory, C ABI); tests drive the same class
@@ -40,15 +48,17 @@ def owner_ranges(n, P):
 A2A_MAX_ELEMS = 1 << 26
 
 
-def all_to_all_v(dist, out, inp, out_splits, in_splits, group=None, max_elems=A2A_MAX_ELEMS):
+def all_to_all_v(dist, out, inp, out_splits, in_splits, group=None, max_elems=A2A_MAX_ELEMS, big=None):
     """all-to-all-v of 8-byte elements in rounds of at most max_elems per call; `out` keeps the
-    (source rank, source order) layout of a single all_to_all_single."""
+    (source rank, source order) layout of a single all_to_all_single.  big = largest chunk any pair of
+    ranks exchanges, when the caller already knows it (else one all_reduce finds it)."""
     import torch
     P = len(in_splits)
-    big = max(max(in_splits, default=0), max(out_splits, default=0))
-    t = torch.tensor([big], dtype=torch.int64, device=inp.device)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
-    big = int(t.item())
+    if big is None:
+        big = max(max(in_splits, default=0), max(out_splits, default=0))
+        t = torch.tensor([big], dtype=torch.int64, device=inp.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+        big = int(t.item())
     C = max(1, max_elems // P)
     if big <= C:
         dist.all_to_all_single(out, inp, out_splits, in_splits, group=group)
@@ -157,8 +167,50 @@ class HipShardBackend:
             d.ck(d.lib.esp_shard_exchange_place(d.h, int(position), C.c_void_p(keys.data_ptr()), C.c_void_p(vals.data_ptr()),
                                                 keys.numel()))
 
+    # -- partitioned exchange (one pass = owner split + first partition pass of the local flush):
+    #    see esp_shard_partition / esp_shard_assemble
+    def part_partition(self, P, me, entries_per_shard):
+        """-> None (not applicable) or (keys, vals, counts, entry_offsets, digits): device views of the
+        partitioned pending entries, the per-(owner, digit) counts, owner r = entry_offsets[r:r+2]."""
+        torch = self.torch
+        d = self.A._d
+        d.commit()
+        ok = C.c_int32(0)
+        pk, pv, pc = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        eoff = np.zeros(P + 1, np.int64)
+        nb = C.c_int64(0)
+        d.ck(d.lib.esp_shard_partition(d.h, P, me, int(entries_per_shard), C.byref(ok), C.byref(pk), C.byref(pv),
+                                       C.byref(pc), eoff.ctypes.data_as(C.c_void_p), C.byref(nb)))
+        self.A._touch()
+        if not ok.value:
+            return None
+        n = int(eoff[-1])
+        keys = _wrap_device(torch, pk.value, n, torch.int64, self.device)
+        vals = _wrap_device(torch, pv.value, n, torch.float64, self.device)
+        counts = _wrap_device(torch, pc.value, P * nb.value, torch.int64, self.device)
+        return keys, vals, counts, eoff, int(nb.value)
+
+    def part_assemble(self, P, me, rkeys, rvals, rcounts, recv_entries):
+        """rkeys/rvals/rcounts: per source rank a device tensor (entry `me` ignored).  The tensors are
+        kept alive until the flush.  -> True: the flush runs on the pieces; False: plain pending buffer."""
+        d = self.A._d
+        self.torch.cuda.synchronize(self.device)  # the collectives ran on torch's stream
+        PK, PV, PC = (C.c_void_p * P)(), (C.c_void_p * P)(), (C.c_void_p * P)()
+        for q in range(P):
+            if q != me:
+                PK[q] = rkeys[q].data_ptr() if rkeys[q].numel() else None
+                PV[q] = rvals[q].data_ptr() if rvals[q].numel() else None
+                PC[q] = rcounts[q].data_ptr()
+        ne = np.asarray(recv_entries, np.int64)
+        ok = C.c_int32(0)
+        d.ck(d.lib.esp_shard_assemble(d.h, PK, PV, PC, ne.ctypes.data_as(C.c_void_p), C.byref(ok)))
+        self._alive = (rkeys, rvals, rcounts) if ok.value else None
+        self.A._touch()
+        return bool(ok.value)
+
     def flush(self):
         self.A.flush()
+        self._alive = None
         return self.A._d.nnz()
 
     def local_csc(self):
@@ -168,8 +220,9 @@ class HipShardBackend:
 class ShardedExtendableSparseMatrix:
     """ExtendableSparseMatrix whose columns are sharded over the ranks of a process group."""
 
-    def __init__(self, m, n, backend, group=None):
-        import torch.distributed as dist
+    def __init__(self, m, n, backend, group=None, dist=None):
+        if dist is None:   # (tests inject a stand-in that runs several ranks inside one process)
+            import torch.distributed as dist
         self.dist = dist
         self.group = group
         self.rank = dist.get_rank(group)
@@ -179,6 +232,11 @@ class ShardedExtendableSparseMatrix:
         self.ranges = owner_ranges(self.n, self.P)
         self.local_nnz = 0
         self.nnz_offsets = np.zeros(self.P + 1, np.int64)
+        self.partitioned = True      # try the partitioned exchange (falls back by consensus)
+        self.last_exchange = None    # "partitioned" | "inplace" | "generic"
+        self._eps = None             # entries per shard of the previous flush: fixes the digit width
+        self._part_skip = 0          # back-off after a flush where some rank could not partition
+        self._part_penalty = 0
         c0, c1 = self.ranges[self.rank]
         if hasattr(backend, "set_column_window") and c1 > c0:
             backend.set_column_window(c0 + 1, c1)  # after the exchange every pending column is owned
@@ -205,7 +263,10 @@ class ShardedExtendableSparseMatrix:
         import torch
         dist, P, be = self.dist, self.P, self.backend
         me = self.rank
-        if hasattr(be, "exchange_begin"):
+        if self.partitioned and hasattr(be, "part_partition") and self._flush_exchange_partitioned():
+            self.last_exchange = "partitioned"
+        elif hasattr(be, "exchange_begin"):
+            self.last_exchange = "inplace"
             # counts first, then the in-place partition (own chunk stays on the device where it is)
             counts = be.shard_counts(P)
             send_counts = torch.from_numpy(counts.astype(np.int64))
@@ -229,6 +290,7 @@ class ShardedExtendableSparseMatrix:
             self.exchanged = (int(sum(in_splits)), int(sum(out_splits)))
             self.sent_off_rank = int(sum(in_x))
         else:
+            self.last_exchange = "generic"
             self._flush_exchange_generic()
         self.local_nnz = be.flush()
         # global colptr offsets: exclusive scan of the per-shard nnz
@@ -240,6 +302,70 @@ class ShardedExtendableSparseMatrix:
         self.nnz_offsets = np.concatenate([[0], np.cumsum(counts)])
         return self
 
+
+    def _gather_ints(self, values):
+        """all_gather of a small int64 vector -> (P, len) numpy array (same on every rank)."""
+        import torch
+        dev = getattr(self.backend, "device", None)
+        mine = torch.tensor(list(values), dtype=torch.int64, device=dev if dev is not None else "cpu")
+        out = [torch.empty_like(mine) for _ in range(self.P)]
+        self.dist.all_gather(out, mine, group=self.group)
+        return np.stack([t.cpu().numpy() for t in out])
+
+    def _flush_exchange_partitioned(self):
+        """One partition pass per rank (owner split + first pass of the local flush), ranges and
+        per-digit counts to the owners, pieces assembled without a copy.  Every decision that changes
+        the communication pattern is taken from all-gathered data, i.e. identically on all ranks.
+        Returns False when the ranks agreed to use the plain exchange for this flush."""
+        import torch
+        dist, P, be, me = self.dist, self.P, self.backend, self.rank
+        if self._part_skip > 0:
+            self._part_skip -= 1
+            return False
+        if self._eps is None:   # first flush: the digit width comes from the global number of entries
+            self._eps = -(-int(self._gather_ints([be.pending()]).sum()) // P)
+        part = be.part_partition(P, me, self._eps)
+        counts = np.diff(part[3]) if part is not None else np.zeros(P, np.int64)
+        M = self._gather_ints([1 if part is not None else 0] + [int(c) for c in counts])
+        total = int(M[:, 1:].sum())
+        if not M[:, 0].all():
+            # some rank's stream is not pre-sorted (or the plan does not apply): plain exchange now, and
+            # for the next few flushes (the pending entries are intact)
+            self._part_penalty = min(16, 2 * self._part_penalty + 1)
+            self._part_skip = self._part_penalty
+            self._eps = None
+            return False
+        self._part_penalty = 0
+        self._eps = -(-total // P) if total else None
+        keys, vals, cnts, eoff, nb = part
+        in_x = [int(c) for c in counts]
+        in_x[me] = 0
+        out_x = [int(M[q, 1 + me]) for q in range(P)]
+        out_x[me] = 0
+        own_lo, own_hi = int(eoff[me]), int(eoff[me + 1])
+        if sum(in_x):
+            skeys = torch.cat([keys[:own_lo], keys[own_hi:]])
+            svals = torch.cat([vals[:own_lo], vals[own_hi:]])
+        else:
+            skeys, svals = keys[:0], vals[:0]
+        rkeys = be.empty(sum(out_x), torch.int64)
+        rvals = be.empty(sum(out_x), torch.float64)
+        rcnts = be.empty(P * nb, torch.int64)
+        if P > 1:
+            pairs = M[:, 1:].copy()
+            np.fill_diagonal(pairs, 0)
+            big = int(pairs.max())
+            all_to_all_v(dist, rkeys, skeys, out_x, in_x, self.group, big=big)
+            all_to_all_v(dist, rvals, svals, out_x, in_x, self.group, big=big)
+            dist.all_to_all_single(rcnts, cnts, group=self.group)   # nb counts to / from every rank
+        ro = np.concatenate([[0], np.cumsum(out_x)]).astype(np.int64)
+        be.part_assemble(P, me,
+                         [rkeys[ro[q]:ro[q + 1]] for q in range(P)],
+                         [rvals[ro[q]:ro[q + 1]] for q in range(P)],
+                         [rcnts[q * nb:(q + 1) * nb] for q in range(P)], out_x)
+        self.exchanged = (int(sum(counts)), int(sum(out_x)) + int(counts[me]))
+        self.sent_off_rank = int(sum(in_x))
+        return True
 
     def _flush_exchange_generic(self):
         """Exchange through export buffers (any backend): used by the CPU tests."""

@@ -183,6 +183,30 @@ int32_t esp_shard_exchange_begin(esp_handle *h, int32_t nshards, int32_t self, i
 int32_t esp_shard_exchange_place(esp_handle *h, int64_t position, const uint64_t *d_keys,
                                  const double *d_vals, int64_t count);
 
+/* Partitioned exchange (the fast path for streams an assembly loop emits; the calls above remain the
+ * general one).  ONE stable pass partitions the pending entries by (owner, digit inside the owner's
+ * column range) -- the owner split and the first partition pass of the local flush at once.
+ *   esp_shard_partition: entries_per_shard = (global number of pending entries) / nshards, the SAME
+ *     value on every rank (it fixes the digit width, which all ranks must agree on).  *ok = 0: not
+ *     applicable (stream not pre-sorted, tiny problem, > 64 shards) -- use esp_shard_exchange_begin;
+ *     the pending entries are intact (possibly permuted in a way that keeps the order per entry).
+ *     *ok = 1: owner r's entries are d_keys/d_vals[entry_offsets[r] .. entry_offsets[r+1]) and its
+ *     per-digit counts d_counts[r*digits .. (r+1)*digits) (device pointers, valid until the next
+ *     append or flush).  Send every OTHER owner its range and its counts.
+ *   esp_shard_assemble: device pointers of the blocks received from every source rank (index = source;
+ *     the own index is ignored; recv_entries[q] = entries in block q, counts blocks hold `digits`
+ *     values).  The buffers must stay alive until esp_flush returns: the bucket kernel reads a segment
+ *     as the concatenation of one piece per source (rank order), nothing is copied.  *ok = 0: a merged
+ *     segment is too long for the bucket kernel; the entries were copied into a plain pending buffer
+ *     (rank order) instead and esp_flush works as usual.
+ * esp_set_column_window(own column range) must be in force, as for the other exchange. */
+int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t self, int64_t entries_per_shard,
+                            int32_t *ok, uint64_t **d_keys, double **d_vals, int64_t **d_counts,
+                            int64_t *entry_offsets /* nshards+1 */, int64_t *digits_per_shard);
+int32_t esp_shard_assemble(esp_handle *h, const uint64_t *const *d_recv_keys,
+                           const double *const *d_recv_vals, const int64_t *const *d_recv_counts,
+                           const int64_t *recv_entries /* nshards */, int32_t *ok);
+
 /* promise: every pending entry of the following flushes has its column in [col_lo, col_hi]
  * (1-based); the partition then works on that window only.  Violations -> ESP_ERR_STATE. */
 int32_t esp_set_column_window(esp_handle *h, int64_t col_lo, int64_t col_hi);
@@ -194,12 +218,13 @@ int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear);
  * 3 = LDS bucket path with its radix tail only (no column tiers), 4 = bucket kernel issued in
  * launches of 64 workgroups (exercises the carry-over of the look-back state), 5 = never use the
  * run-based single-pass partition (8-bit passes only), 7 = the device generators emit the run lists of their chunks themselves (skips the
- * histogram kernel; off by default: no net gain measured);
+ * histogram kernel; off by default: no net gain measured), 11 = esp_shard_partition reports "not applicable";
  * last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general) */
 int32_t esp_debug_force_path(esp_handle *h, int32_t path);
 int32_t esp_debug_last_path(const esp_handle *h, int32_t *path);
 /* which partition the last flush used: 1 = run-based single pass (pre-sorted stream), 2 = 8-bit passes,
- * 3 = run-based single pass on run lists the producers emitted (no histogram kernel) */
+ * 3 = run-based single pass on run lists the producers emitted (no histogram kernel),
+ * 7 = none: the segments came assembled from esp_shard_assemble */
 int32_t esp_debug_last_partition(const esp_handle *h, int32_t *kind);
 
 #ifdef __cplusplus

@@ -479,6 +479,34 @@ def test_run_partition_vs_passes(esp, orc, force):
     assert_csc_equal(hip_arrays(A), O2.arrays())
 
 
+@pytest.mark.parametrize("force", [0, 5])
+def test_presorted_stream_mixed_kinds(esp, orc, force):
+    """Pre-sorted stream with SET/UPDATE/RAWUPDATE mixes, zeros and duplicates spread over several chunks:
+    the run-based single-pass partition (0) and the 8-bit passes (5) give the oracle's bits, on a fresh
+    matrix, on re-assembly over the existing pattern and with new positions among hits."""
+    rng = np.random.default_rng(77)
+    m, n = 150000, 120000
+    A = esp.ExtendableSparseMatrix(m, n)
+    A.debug_force_path(force)
+    O = orc.ExtendableSparseMatrix(m, n)
+    for rnd in range(3):
+        cnt = 1500000
+        # columns drift upwards with jitter (assembly-loop locality); three interleaved sub-streams
+        base = np.sort(rng.integers(1, n + 1, cnt))
+        off = np.where(np.arange(cnt) % 3 == 1, 3000, 0) + np.where(np.arange(cnt) % 3 == 2, -2500, 0)
+        J = (base + off + rng.integers(-40, 41, cnt) - 1) % n + 1
+        I = np.clip(J + rng.integers(-3, 4, cnt) * (1 + rnd), 1, m)
+        kinds = rng.integers(0, 3, cnt).astype(np.uint8)
+        V = np.where(rng.random(cnt) < 0.15, 0.0, rng.standard_normal(cnt))
+        A.append(0, I, J, V, kinds=kinds)
+        O.apply(kinds, I, J, V)
+        A.flush()
+        O.flush()
+        assert A.debug_last_path() == 1
+        assert A.debug_last_partition() == (1 if force == 0 else 2)
+        assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
+
+
 def test_producer_run_lists_mixed_with_other_appends(esp, orc):
     """Run lists emitted by the generator are used only if EVERY pending entry came with one; two
     generator calls, a host append in between, a capacity hint that is off: all must stay exact."""
@@ -595,6 +623,105 @@ def test_sharded_matrix_world1_nccl(esp, orc):
         assert A.nnz() == orc.fdrand_nnz(nx, ny, nz) and A.exchanged == (orc.fdrand_count(nx, ny, nz),) * 2
     finally:
         dist.destroy_process_group()
+
+
+def _sharded_ranks_run(esp, orc, world, deal, n=44, rounds=2, overflow=False):
+    """W ranks as threads on one GPU (tests/threaddist.py): returns per-rank exchange kinds and checks
+    the gathered CSC against ONE oracle buffer fed the ranks' streams in rank order."""
+    from threaddist import run_ranks
+    nx = ny = n
+    nzg = n * world
+    N = nx * ny * nzg
+    nodes = nx * ny * n
+    seeds = [77, 78, 79]
+    streams = [orc.fdrand_stream(nx, ny, nzg, rand_mode=1, seed=seeds[r]) for r in range(rounds)]
+    E = len(streams[0][0])
+    kinds = np.where(np.arange(E) % 5 == 0, RAW, UPDATE).astype(np.uint8)
+    if deal == "slab":
+        # rank r runs the device generator on its z-slab of nodes; in the stream that is a slice:
+        # updates per node (sprand.jl:87-126) -> slice boundaries
+        l = np.arange(N)
+        i, j, k = l % nx + 1, (l // nx) % ny + 1, l // (nx * ny) + 1
+        per = (4 * (i < nx) + ((i == 1) | (i == nx)) + 4 * (j < ny) + ((j == 1) | (j == ny))
+               + 4 * (k < nzg) + ((k == 1) | (k == nzg)))
+        assert per.sum() == E
+        off = np.concatenate([[0], np.cumsum(per)])
+        sel = [slice(int(off[r * nodes]), int(off[(r + 1) * nodes])) for r in range(world)]
+        kinds[:] = UPDATE
+    else:
+        chunk = np.arange(E) // 4096
+        sel = [(chunk % world) == r for r in range(world)]
+    perm1 = np.random.default_rng(9).permutation(int(np.count_nonzero(sel[1])) if deal != "slab" else 1)
+    extra = None
+    if overflow:
+        # both ranks pile entries on the same few columns: every rank's own bucket fits the bucket
+        # kernel, the merged segment does not
+        rng = np.random.default_rng(3)
+        extra = (rng.integers(1, N + 1, 2600), rng.integers(N // 2 + 10, N // 2 + 40, 2600), rng.standard_normal(2600))
+
+    def rank_stream(rank, rnd):
+        I, J, V = streams[rnd]
+        Ii, Jj, Vv, kk = I[sel[rank]], J[sel[rank]], V[sel[rank]], kinds[sel[rank]]
+        if deal == "shuffled_rank1" and rank == 1:
+            Ii, Jj, Vv, kk = Ii[perm1], Jj[perm1], Vv[perm1], kk[perm1]
+        return Ii, Jj, Vv, kk
+
+    def body(rank, dist):
+        be = esp.HipShardBackend(N, N, device=0)
+        A = esp.ShardedExtendableSparseMatrix(N, N, be, dist=dist)
+        hist = []
+        for rnd in range(rounds):
+            if deal == "slab":
+                A.local.generate_fdrand_range(nx, ny, nzg, rank * nodes, (rank + 1) * nodes, seed=seeds[rnd], rand_mode=1)
+            else:
+                Ii, Jj, Vv, kk = rank_stream(rank, rnd)
+                A.append(0, Ii, Jj, Vv, kinds=kk)
+            if extra is not None and rnd == 0:
+                A.append(UPDATE, extra[0], extra[1], extra[2] * (rank + 1))
+            A.flush()
+            hist.append((A.last_exchange, be.matrix.debug_last_partition()))
+        G = A.gather_sparse(0)
+        return hist, (G.arrays() if rank == 0 else None), A.nnz()
+
+    outs = run_ranks(world, body)
+    # oracle: one buffer, the ranks' streams in rank order, flush after every round
+    O = orc.ExtendableSparseMatrix(N, N)
+    for rnd in range(rounds):
+        for rank in range(world):
+            Ii, Jj, Vv, kk = rank_stream(rank, rnd)
+            O.apply(kk, Ii, Jj, Vv)
+            if extra is not None and rnd == 0:
+                O.apply(np.full(len(extra[0]), UPDATE, np.uint8), extra[0], extra[1], extra[2] * (rank + 1))
+        O.flush()
+    assert_csc_equal(outs[0][1], O.arrays())
+    assert outs[0][2] == O.nnz()
+    return [o[0] for o in outs]
+
+
+@pytest.mark.parametrize("world,deal", [(2, "slab"), (3, "slab"), (2, "scrambled"), (3, "scrambled")])
+def test_partitioned_exchange_ranks_as_threads(esp, orc, world, deal):
+    """The partitioned exchange with 2 and 3 source ranks per segment: one partition pass per rank,
+    pieces assembled without a copy, bits equal to one buffer fed the ranks' streams in turn; second
+    round = re-assembly over the existing CSC (hits applied in place through the pieces)."""
+    hist = _sharded_ranks_run(esp, orc, world, deal)
+    for h in hist:
+        assert h == [("partitioned", 7), ("partitioned", 7)], h
+
+
+def test_partitioned_exchange_falls_back_by_consensus(esp, orc):
+    """One rank's stream is shuffled: its partition reports "not applicable", ALL ranks take the plain
+    exchange for this flush (and back off for the next)."""
+    hist = _sharded_ranks_run(esp, orc, 2, "shuffled_rank1")
+    for h in hist:
+        assert [x[0] for x in h] == ["inplace", "inplace"], h
+
+
+def test_partitioned_exchange_merged_segment_overflow(esp, orc):
+    """Every rank's own bucket fits the bucket kernel but a merged segment does not: esp_shard_assemble
+    hands the entries over as a plain pending buffer (rank order) and the flush partitions again."""
+    hist = _sharded_ranks_run(esp, orc, 2, "scrambled", rounds=1, overflow=True)
+    # the piled-up columns belong to rank 1: its flush partitions again, rank 0 runs on its pieces
+    assert hist[0] == [("partitioned", 7)] and hist[1][0][0] == "partitioned" and hist[1][0][1] != 7, hist
 
 
 def test_column_window(esp, orc):

@@ -61,6 +61,48 @@ class CpuShardBackend:
         self.keys = np.concatenate([k.numpy() for k, _ in pieces]).astype(np.int64)
         self.vals = np.concatenate([v.numpy() for _, v in pieces]).astype(np.float64)
 
+    # -- partitioned exchange, numpy restatement of esp_shard_partition / esp_shard_assemble
+    NB = 8            # digits per shard
+    fail_partition = False
+
+    def part_partition(self, P, me, entries_per_shard):
+        import torch
+        if self.fail_partition:
+            return None
+        nb = self.NB
+        bounds = np.array([-(-r * self.n // P) for r in range(P + 1)], np.int64)
+        width = -(-int(np.max(np.diff(bounds))) // nb)          # columns per digit
+        col0 = self.keys >> (2 + self.rb)
+        owner = (col0 * P) // self.n
+        g = owner * nb + (col0 - bounds[owner]) // width
+        order = np.argsort(g, kind="stable")
+        self.keys, self.vals = self.keys[order], self.vals[order]
+        self._cnt = np.bincount(g, minlength=P * nb).astype(np.int64)
+        self._eoff = np.concatenate([[0], np.cumsum(np.bincount(owner, minlength=P))]).astype(np.int64)
+        return (torch.from_numpy(self.keys.copy()), torch.from_numpy(self.vals.copy()), torch.from_numpy(self._cnt.copy()),
+                self._eoff, nb)
+
+    def part_assemble(self, P, me, rkeys, rvals, rcounts, recv_entries):
+        nb = self.NB
+        blocks = []
+        for q in range(P):
+            if q == me:
+                k = self.keys[self._eoff[me]:self._eoff[me + 1]]
+                v = self.vals[self._eoff[me]:self._eoff[me + 1]]
+                c = self._cnt[me * nb:(me + 1) * nb]
+            else:
+                k, v, c = rkeys[q].numpy(), rvals[q].numpy(), rcounts[q].numpy()
+                assert len(k) == recv_entries[q] == int(c.sum())
+            blocks.append((k, v, np.concatenate([[0], np.cumsum(c)])))
+        ks, vs = [], []
+        for d in range(nb):                  # a segment = its pieces in source-rank order
+            for (k, v, o) in blocks:
+                ks.append(k[o[d]:o[d + 1]])
+                vs.append(v[o[d]:o[d + 1]])
+        self.keys = np.concatenate(ks).astype(np.int64)
+        self.vals = np.concatenate(vs).astype(np.float64)
+        return True
+
     def flush(self):
         kinds = (self.keys & 3).astype(np.uint8)
         I = ((self.keys >> 2) & ((1 << self.rb) - 1)) + 1
@@ -77,6 +119,7 @@ class CpuShardBackend:
 
 
 def _worker(rank, world, port, variant, q):
+    variant, mode = variant.split("/")
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     import torch.distributed as dist
@@ -94,9 +137,14 @@ def _worker(rank, world, port, variant, q):
         else:                      # "scrambled": updates dealt round-robin in chunks of 5
             mine = (np.arange(E) // 5) % world == rank
         kinds = np.where(np.arange(E) % 7 == 0, 2, 1).astype(np.uint8)   # mix UPDATE / RAWUPDATE
-        A = esp.ShardedExtendableSparseMatrix(N, N, CpuShardBackend(N, N, orc, esp))
+        be = CpuShardBackend(N, N, orc, esp)
+        A = esp.ShardedExtendableSparseMatrix(N, N, be)
+        A.partitioned = mode != "generic"
+        be.fail_partition = mode == "rank1_fails" and rank == 1
         A.append(0, I[mine], J[mine], V[mine], kinds=kinds[mine])
         A.flush()
+        # every rank takes the same exchange: the choice comes from all-gathered data
+        assert A.last_exchange == ("partitioned" if mode == "partitioned" else "generic"), A.last_exchange
         sent, recv = A.exchanged
         assert sent == int(mine.sum())
         # second round on the existing pattern plus new positions, to exercise hit + merge
@@ -125,7 +173,8 @@ def _worker(rank, world, port, variant, q):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("variant", ["slab", "scrambled"])
+@pytest.mark.parametrize("variant", ["slab/generic", "scrambled/generic", "slab/partitioned", "scrambled/partitioned",
+                                     "scrambled/rank1_fails"])
 def test_shard_exchange_world2(variant):
     import torch.multiprocessing as mp
     s = socket.socket()
