@@ -5,12 +5,12 @@ host-side mirror of the reference's operator interface.  Importing the package n
 oracle and never falls back to a CPU implementation.
 """
 from . import _lib
-from ._lib import (ESP_FLUSH_PLUS, ESP_FLUSH_ROUTED, ESP_OP_ADD, ESP_OP_SUB, ESP_RAWUPDATE, ESP_SET,
+from ._lib import (ESP_COO, ESP_FLUSH_PLUS, ESP_FLUSH_ROUTED, ESP_OP_ADD, ESP_OP_SUB, ESP_RAWUPDATE, ESP_SET,
                    ESP_UPDATE, BoundsError, EspError, NoDeviceError)
 from .matrix import (ExtendableSparseMatrix, GenericExtendableSparseMatrixCSC,
                      GenericMTExtendableSparseMatrixCSC, SparseMatrixCSC, SparseMatrixHIPCOO)
 from . import fdrand as fdrand_module
-from .fdrand import fdrand, fdrand_, fdrand_device_
+from .fdrand import fdrand, fdrand_, fdrand_coo, fdrand_device_
 from .sharded import HipShardBackend, ShardedExtendableSparseMatrix, owner_ranges
 
 # aliases mirroring src/ExtendableSparse.jl:34-39

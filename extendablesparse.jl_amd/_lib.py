@@ -13,7 +13,7 @@ SO = os.path.join(HERE, "libesparse_hip.so")
 ESP_OK = 0
 ESP_ERR_INVALID, ESP_ERR_BOUNDS, ESP_ERR_HIP, ESP_ERR_NOMEM = -1, -2, -3, -4
 ESP_ERR_UNSUPPORTED, ESP_ERR_STATE, ESP_ERR_NODEVICE = -5, -6, -7
-ESP_SET, ESP_UPDATE, ESP_RAWUPDATE = 0, 1, 2
+ESP_SET, ESP_UPDATE, ESP_RAWUPDATE, ESP_COO = 0, 1, 2, 3
 ESP_OP_ADD, ESP_OP_SUB = 0, 1
 ESP_FLUSH_ROUTED, ESP_FLUSH_PLUS = 0, 1
 STAGES = ("append", "hist", "scan", "scatter", "local", "fold", "colptr", "merge", "copy")

@@ -353,7 +353,7 @@ static int32_t reserve_append(esp_handle *h, i64 add) {
 static int32_t pack_device(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const double *d_vals,
                            const uint8_t *d_kinds, int kind_all, int op, i64 count) {
     if (count == 0) return ESP_OK;
-    if (!d_kinds && (kind_all < 0 || kind_all > 2)) FAIL(h, ESP_ERR_INVALID, "append: kind %d invalid", kind_all);
+    if (!d_kinds && (kind_all < 0 || kind_all > 3)) FAIL(h, ESP_ERR_INVALID, "append: kind %d invalid", kind_all);
     if (op != ESP_OP_ADD && op != ESP_OP_SUB) FAIL(h, ESP_ERR_UNSUPPORTED, "append: op %d not supported on the device path", op);
     CK(reserve_append(h, count));
     h->pin_scalar[0] = ~0ull;
@@ -510,7 +510,7 @@ extern "C" int32_t esp_generate_fdrand_range(esp_handle *h, int64_t nx, int64_t 
     if (nx < 1 || ny < 1 || nz < 1) FAIL(h, ESP_ERR_INVALID, "fdrand: bad grid");
     const i64 N = nx * ny * nz;
     if (h->m != N || h->n != N) FAIL(h, ESP_ERR_INVALID, "Matrix size mismatch");  // sprand.jl:66-68
-    if (kind != ESP_UPDATE && kind != ESP_RAWUPDATE) FAIL(h, ESP_ERR_INVALID, "fdrand: kind must be UPDATE or RAWUPDATE");
+    if (kind != ESP_UPDATE && kind != ESP_RAWUPDATE && kind != ESP_COO) FAIL(h, ESP_ERR_INVALID, "fdrand: kind must be UPDATE, RAWUPDATE or COO");
     if (rand_mode < 0 || rand_mode > 2) FAIL(h, ESP_ERR_INVALID, "fdrand: rand_mode");
     if (node_begin < 0 || node_end > N || node_begin > node_end) FAIL(h, ESP_ERR_INVALID, "fdrand: node range");
     if (node_begin == node_end) return ESP_OK;

@@ -9,6 +9,8 @@
 //   absent  --SET/UPDATE 0--> absent          sparsematrixlnk.jl:196,223
 //   present --SET v--> present(v)             sparsematrixlnk.jl:192-195
 //   present --UPDATE/RAWUPDATE v--> present(old+v)   sparsematrixlnk.jl:219-221,246-247
+//   absent  --COO v--> present(v), present --COO v--> present(old+v): sparse(I,J,V,m,n,+) of the COO
+//                                             constructors (extendable.jl:92-104; SparseArrays stdlib)
 // An (i,j) found in the CSC starts `present` with csc.nzval (ROUTED mode,
 // extendable.jl:164-166,188-189,210-211) and is written back in place.
 #pragma once
@@ -33,6 +35,9 @@ __device__ __forceinline__ void fold_step(bool &present, double &acc, u32 kind, 
         }
     } else if (present) {
         acc = acc + v;
+    } else if (kind == ESP_COO) {
+        present = true;
+        acc = v;
     } else if (kind == ESP_RAWUPDATE || v != 0.0) {
         present = true;
         acc = 0.0 + v;
@@ -45,10 +50,11 @@ __device__ __forceinline__ void fold_step(bool &present, double &acc, u32 kind, 
 __device__ __forceinline__ void fold_step_sel(bool &present, double &acc, u32 kind, double v) {
     const bool nz = v != 0.0;
     const bool set = kind == ESP_SET;
-    const bool creates = set ? nz : (kind == ESP_RAWUPDATE || nz);
+    const bool creates = set ? nz : (kind >= ESP_RAWUPDATE || nz);  // RAWUPDATE and COO always create
     const bool np = present || creates;
     const double sumv = (present ? acc : 0.0) + v;
-    const double acc_add = np ? sumv : acc;
+    // (0.0 + v == v bit for bit unless v is -0.0: a COO entry starts from v itself)
+    const double acc_add = np ? ((kind == ESP_COO && !present) ? v : sumv) : acc;
     const double acc_set = (present || nz) ? v : acc;
     acc = set ? acc_set : acc_add;
     present = np;

@@ -37,7 +37,7 @@ __global__ __launch_bounds__(THREADS) void pack_k(const i64 *__restrict__ rows,
     if (g >= count) return;
     const i64 r = rows[g], c = cols[g];
     int kind = kinds ? (int)kinds[g] : kind_all;
-    if (!(1 <= r && r <= m && 1 <= c && c <= n) || kind < 0 || kind > 2) {
+    if (!(1 <= r && r <= m && 1 <= c && c <= n) || kind < 0 || kind > 3) {
         atomicMin(err, (unsigned long long)(g + 1));
         return;
     }

@@ -208,7 +208,7 @@ __device__ __forceinline__ void load_sorted_run(const u64 *skey, const double *s
 }
 
 // number of entries a sorted run will emit when nothing of it is in the CSC: a (col,row) group
-// becomes present iff one of its updates is a RAWUPDATE or has a non-zero value (fold_step)
+// becomes present iff one of its updates is a RAWUPDATE / COO entry or has a non-zero value (fold_step)
 __device__ __forceinline__ u32 count_emitted(const u64 (&x)[REG_RUN], const double (&xv)[REG_RUN], int len) {
     u32 e = 0;
     bool any = false;
@@ -224,7 +224,7 @@ __device__ __forceinline__ u32 count_emitted(const u64 (&x)[REG_RUN], const doub
                 psub = sub;
                 any = false;
             }
-            any |= ((u32)(x[j < REG_RUN ? j : 0] & ESP_TAG_MASK) == (u32)ESP_RAWUPDATE) || xv[j < REG_RUN ? j : 0] != 0.0;
+            any |= ((u32)(x[j < REG_RUN ? j : 0] & ESP_TAG_MASK) >= (u32)ESP_RAWUPDATE) || xv[j < REG_RUN ? j : 0] != 0.0;
         }
     }
     return e;

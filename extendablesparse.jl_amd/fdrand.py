@@ -7,7 +7,7 @@ matrix class, any update style) -- the form the reference's tests use at small s
 """
 import numpy as np
 
-from ._lib import ESP_RAWUPDATE, ESP_UPDATE
+from ._lib import ESP_COO, ESP_RAWUPDATE, ESP_UPDATE
 from .matrix import ExtendableSparseMatrix
 
 MASK = (1 << 64) - 1
@@ -101,3 +101,50 @@ def fdrand(nx, ny=1, nz=1, rand_mode=1, seed=0x5EED0002, update=None, device=Tru
     if update is None and device:
         return fdrand_device_(A, nx, ny, nz, rand_mode, seed)
     return fdrand_(A, nx, ny, nz, update or update_updateindex, rand_mode, seed)
+
+
+def fdrand_coo(nx, ny=1, nz=1, rand_mode=2, seed=0x5EED0002, device=True, **kw):
+    """fdrand_coo(T,nx,ny,nz;rand) (sprand.jl:134-185): the stencil as COO triplets, then
+    sparse(I,J,V).  device=True: the triplets are produced by the on-device generator as COO entries
+    (same stream, same order); device=False: host triplets through ExtendableSparseMatrix.from_coo."""
+    N = nx * ny * nz
+    if device:
+        A = ExtendableSparseMatrix(N, N, **kw)
+        A.generate_fdrand(nx, ny, nz, seed=seed, rand_mode=rand_mode, kind=ESP_COO)
+        A.flush()
+        return A
+    rand = make_rand(rand_mode, seed)
+    I, J, V = [], [], []
+
+    def update(v, i, j):
+        I.append(i)
+        J.append(j)
+        V.append(v)
+
+    def update_pair(v, i, j):
+        update(-v, i, j)
+        update(-v, j, i)
+        update(v, i, i)
+        update(v, j, j)
+
+    hx, hy, hz = 1.0 / nx, 1.0 / ny, 1.0 / nz
+    nxy = nx * ny
+    l = 1
+    for k in range(1, nz + 1):
+        for j in range(1, ny + 1):
+            for i in range(1, nx + 1):
+                c = 6 * (l - 1)
+                if i < nx:
+                    update_pair(rand(c + 0) * hy * hz / hx, l, l + 1)
+                if i == 1 or i == nx:
+                    update(rand(c + 1) * hy * hz, l, l)
+                if j < ny:
+                    update_pair(rand(c + 2) * hx * hz / hy, l, l + nx)
+                if ny > 2 and (j == 1 or j == ny):
+                    update(rand(c + 3) * hx * hz, l, l)
+                if k < nz:
+                    update_pair(rand(c + 4) * hx * hy / hz, l, l + nxy)
+                if nz > 2 and (k == 1 or k == nz):
+                    update(rand(c + 5) * hx * hy, l, l)
+                l += 1
+    return ExtendableSparseMatrix.from_coo(I, J, V, N, N, **kw)

@@ -18,7 +18,7 @@ import ctypes as C
 import numpy as np
 
 from . import _lib as L
-from ._lib import (ESP_FLUSH_PLUS, ESP_FLUSH_ROUTED, ESP_OP_ADD, ESP_OP_SUB, ESP_RAWUPDATE, ESP_SET,
+from ._lib import (ESP_COO, ESP_FLUSH_PLUS, ESP_FLUSH_ROUTED, ESP_OP_ADD, ESP_OP_SUB, ESP_RAWUPDATE, ESP_SET,
                    ESP_UPDATE, BoundsError, check)
 
 _OPS = {"+": ESP_OP_ADD, "-": ESP_OP_SUB, ESP_OP_ADD: ESP_OP_ADD, ESP_OP_SUB: ESP_OP_SUB}
@@ -278,6 +278,23 @@ class ExtendableSparseMatrix:
             self.m, self.n = int(m), int(n)
             self._phash = 0  # extendable.jl:40
         self._host = None
+
+    @classmethod
+    def from_coo(cls, I, J, V, m=None, n=None, combine="+", device=0):
+        """ExtendableSparseMatrixCSC(I,J,V[,m,n][,combine]) (extendable.jl:85-104) = sparse(I,J,V,m,n,+):
+        the triplets go through the same device pipeline as incremental updates, as COO entries
+        (first value as it is, duplicates added in input order, numerical zeros kept).  Only
+        combine = + runs on the device (every other function stays with SparseArrays on the CPU)."""
+        if _op(combine) != ESP_OP_ADD:
+            raise ValueError("combine: only + runs on the device")
+        I = np.ascontiguousarray(I, np.int64)
+        J = np.ascontiguousarray(J, np.int64)
+        m = int(I.max()) if m is None else int(m)     # sparse(I,J,V) = sparse(I,J,V,maximum(I),maximum(J))
+        n = int(J.max()) if n is None else int(n)
+        A = cls(m, n, device=device, capacity_hint=len(I))
+        A.append(ESP_COO, I, J, V)
+        A.flush()
+        return A
 
     @property
     def shape(self):

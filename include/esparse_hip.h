@@ -48,8 +48,11 @@ typedef enum {
 /* How an appended entry combines with what is already stored at (i,j).
  * SET       = Base.setindex!      (sparsematrixlnk.jl:178-201, extendable.jl:205-218)
  * UPDATE    = updateindex!(A,+..) (sparsematrixlnk.jl:210-228, extendable.jl:159-174)
- * RAWUPDATE = rawupdateindex!     (sparsematrixlnk.jl:237-253, extendable.jl:181-197) */
-typedef enum { ESP_SET = 0, ESP_UPDATE = 1, ESP_RAWUPDATE = 2 } esp_kind;
+ * RAWUPDATE = rawupdateindex!     (sparsematrixlnk.jl:237-253, extendable.jl:181-197)
+ * COO       = a triplet of sparse(I,J,V,m,n,+), i.e. of the COO constructors (extendable.jl:85-104) and
+ *             fdrand_coo (sprand.jl:134-185): always creates, the first value as it is, duplicates
+ *             added in input order */
+typedef enum { ESP_SET = 0, ESP_UPDATE = 1, ESP_RAWUPDATE = 2, ESP_COO = 3 } esp_kind;
 
 /* `op` of updateindex!/rawupdateindex!.  Every call site of the reference passes `+`;
  * `-` is exact as `+` of the negated value.  Other functions stay on the CPU path. */

@@ -671,6 +671,62 @@ void orc_mt_reset(orc_mt *t) { /* :31-42 */
     }
 }
 
+/* ------------------------------------------------ sparse(I,J,V,m,n,+) */
+/* The COO constructors ExtendableSparseMatrixCSC(I,J,V[,m,n]) (extendable.jl:92-104) and fdrand_coo
+ * (sprand.jl:134-185) call SparseArrays.sparse(I,J,V,m,n[,+]) -- Julia stdlib, not under /root/reference,
+ * no pinned version (PARITY UNPINNED).  Restated from its published behaviour: the
+ * entries of a column in increasing row order, duplicates combined left to right in input order,
+ * the first value taken as it is (no 0+v), numerical zeros kept, indices outside m x n rejected. */
+typedef struct {
+    i64 row, idx;
+} coo_item;
+static int coo_cmp(const void *a, const void *b) {
+    const coo_item *x = a, *y = b;
+    if (x->row != y->row) return x->row < y->row ? -1 : 1;
+    return x->idx < y->idx ? -1 : (x->idx > y->idx ? 1 : 0);
+}
+orc_csc *orc_sparse_coo(i64 m, i64 n, i64 count, const i64 *I, const i64 *J, const double *V) {
+    for (i64 t = 0; t < count; t++)
+        if (I[t] < 1 || I[t] > m || J[t] < 1 || J[t] > n) return NULL;
+    i64 *start = xmalloc(sizeof(i64) * (size_t)(n + 2));
+    for (i64 j = 0; j <= n + 1; j++) start[j] = 0;
+    for (i64 t = 0; t < count; t++) start[J[t] + 1]++;
+    for (i64 j = 1; j <= n + 1; j++) start[j] += start[j - 1];
+    coo_item *it = xmalloc(sizeof(coo_item) * (size_t)(count > 0 ? count : 1));
+    i64 *fill = xmalloc(sizeof(i64) * (size_t)(n + 2));
+    for (i64 j = 0; j <= n + 1; j++) fill[j] = start[j];
+    for (i64 t = 0; t < count; t++) { /* stable counting sort by column */
+        i64 at = fill[J[t]]++;
+        it[at].row = I[t];
+        it[at].idx = t;
+    }
+    orc_csc *c = orc_csc_new(m, n);
+    free(c->rowval);
+    free(c->nzval);
+    c->rowval = xmalloc(sizeof(i64) * (size_t)(count > 0 ? count : 1));
+    c->nzval = xmalloc(sizeof(double) * (size_t)(count > 0 ? count : 1));
+    i64 z = 0;
+    for (i64 j = 1; j <= n; j++) {
+        i64 a = start[j], b = start[j + 1];
+        qsort(it + a, (size_t)(b - a), sizeof(coo_item), coo_cmp);
+        c->colptr[j - 1] = z + 1;
+        for (i64 q = a; q < b; q++) {
+            if (q > a && it[q].row == it[q - 1].row) {
+                c->nzval[z - 1] = c->nzval[z - 1] + V[it[q].idx];
+            } else {
+                c->rowval[z] = it[q].row;
+                c->nzval[z] = V[it[q].idx];
+                z++;
+            }
+        }
+    }
+    c->colptr[n] = z + 1;
+    free(start);
+    free(fill);
+    free(it);
+    return c;
+}
+
 /* --------------------------------------------------------------- streams */
 /* Counter-based uniform in [0,1): splitmix64 of (seed, counter), top 53 bits.
  * Same formula in csrc/ (device generators) -- values are bit-identical.   */

@@ -88,6 +88,7 @@ def lib():
     sig("orc_ext_zero_values", None, vp)
     sig("orc_ext_dropzeros", i64, vp)
     sig("orc_ext_apply", C.c_int, vp, i64, p_u8, p_i64, p_i64, p_f64, p_i64)
+    sig("orc_sparse_coo", vp, i64, i64, i64, p_i64, p_i64, p_f64)
     sig("orc_mt_new", vp, i64, i64, i64)
     sig("orc_mt_free", None, vp)
     sig("orc_mt_setindex", C.c_int, vp, C.c_double, i64, i64)
@@ -352,6 +353,19 @@ class MTExtendableSparseMatrix:
 
     def reset(self):
         lib().orc_mt_reset(self._h)
+
+
+def sparse_coo(I, J, V, m=None, n=None):
+    """sparse(I,J,V[,m,n]) with combine = + : what the COO constructors of extendable.jl:92-104 build."""
+    I = np.ascontiguousarray(I, np.int64)
+    J = np.ascontiguousarray(J, np.int64)
+    V = np.ascontiguousarray(V, np.float64)
+    m = int(I.max()) if m is None else m
+    n = int(J.max()) if n is None else n
+    h = lib().orc_sparse_coo(m, n, len(I), _pi(I), _pi(J), _pf(V))
+    if not h:
+        raise BoundsError()
+    return CSC(0, 0, _h=h)
 
 
 def uniform(seed, counter):

@@ -7,6 +7,7 @@ linked list, so that it shares no code path with oracle/esparse_oracle.c.
 import numpy as np
 
 SET, UPDATE, RAWUPDATE, PLUSEQ = 0, 1, 2, 3
+COO = 13  # a triplet of sparse(I,J,V,m,n,+): always creates, first value as it is (device kind 3)
 
 
 class DictModel:
@@ -37,6 +38,8 @@ class DictModel:
         elif kind == UPDATE:
             if v != 0.0:
                 self.pending[key] = 0.0 + v
+        elif kind == COO:
+            self.pending[key] = v
         else:
             self.pending[key] = 0.0 + v
 

@@ -625,6 +625,66 @@ def test_sharded_matrix_world1_nccl(esp, orc):
         dist.destroy_process_group()
 
 
+def test_coo_constructor_and_fdrand_coo(esp, orc):
+    """ExtendableSparseMatrixCSC(I,J,V[,m,n]) (extendable.jl:85-104) and fdrand_coo (sprand.jl:134-185)
+    through the device pipeline as COO entries == the oracle's sparse(I,J,V,m,n,+)."""
+    rng = np.random.default_rng(51)
+    m, n, cnt = 4000, 3500, 300000
+    I = rng.integers(1, m + 1, cnt)
+    J = rng.integers(1, n + 1, cnt)
+    hot = rng.random(cnt) < 0.25
+    I[hot] = rng.integers(1, 60, hot.sum())
+    J[hot] = rng.integers(1, 50, hot.sum())
+    V = np.where(rng.random(cnt) < 0.2, 0.0, rng.standard_normal(cnt))
+    V[rng.random(cnt) < 0.02] = -0.0
+    A = esp.ExtendableSparseMatrix.from_coo(I, J, V, m, n)
+    assert_csc_equal(hip_arrays(A), orc.sparse_coo(I, J, V, m, n).arrays())
+    B = esp.ExtendableSparseMatrix.from_coo(I, J, V)          # sizes from the largest indices
+    assert B.shape == (int(I.max()), int(J.max()))
+    assert_csc_equal(hip_arrays(B), orc.sparse_coo(I, J, V).arrays())
+    with pytest.raises((esp.BoundsError, IndexError)):
+        esp.ExtendableSparseMatrix.from_coo([1, 9], [1, 1], [1.0, 2.0], 4, 4)
+    # a lone -0.0 keeps its sign; zeros are structural entries
+    C0 = esp.ExtendableSparseMatrix.from_coo([2, 3, 3], [4, 1, 1], [-0.0, 1.5, 2.0])
+    cp, rv, nz = hip_arrays(C0)
+    assert list(cp) == [1, 2, 2, 2, 3] and list(rv) == [3, 2] and nz[0] == 3.5 and np.signbit(nz[1])
+    # fdrand_coo: device generator (COO entries) == host triplets == oracle
+    nx, ny, nz_ = 9, 8, 7
+    N = nx * ny * nz_
+    Ist, Jst, Vst = orc.fdrand_stream(nx, ny, nz_, rand_mode=2, seed=6)
+    want = orc.sparse_coo(Ist, Jst, Vst, N, N).arrays()
+    assert_csc_equal(hip_arrays(esp.fdrand_coo(nx, ny, nz_, rand_mode=2, seed=6)), want)
+    assert_csc_equal(hip_arrays(esp.fdrand_coo(nx, ny, nz_, rand_mode=2, seed=6, device=False)), want)
+    # large: 96^3 through the run-based partition
+    n3 = 96
+    D = esp.fdrand_coo(n3, n3, n3, rand_mode=1, seed=12)
+    I3, J3, V3 = orc.fdrand_stream(n3, n3, n3, rand_mode=1, seed=12)
+    assert_csc_equal(hip_arrays(D), orc.sparse_coo(I3, J3, V3, n3 ** 3, n3 ** 3).arrays())
+
+
+def test_coo_entries_mixed_with_updates(esp):
+    """COO entries among SET/UPDATE/RAWUPDATE, on a fresh matrix and over an existing CSC (ROUTED):
+    the dict model (tests/refmodel.py) gives the same bits."""
+    from refmodel import COO, DictModel
+    rng = np.random.default_rng(52)
+    m, n = 300, 200
+    A = esp.ExtendableSparseMatrix(m, n)
+    M = DictModel(m, n)
+    for rnd in range(3):
+        cnt = 20000
+        I = rng.integers(1, m + 1, cnt)
+        J = rng.integers(1, n + 1, cnt)
+        V = np.where(rng.random(cnt) < 0.25, 0.0, rng.standard_normal(cnt))
+        V[rng.random(cnt) < 0.03] = -0.0
+        kinds = rng.integers(0, 4, cnt).astype(np.uint8)
+        A.append(0, I, J, V, kinds=kinds)
+        for i, j, v, k in zip(I, J, V, kinds):
+            M.apply(COO if k == 3 else int(k), v, int(i), int(j))
+        A.flush()
+        M.flush()
+        assert_csc_equal(hip_arrays(A), M.arrays(), "round %d" % rnd)
+
+
 def _sharded_ranks_run(esp, orc, world, deal, n=44, rounds=2, overflow=False):
     """W ranks as threads on one GPU (tests/threaddist.py): returns per-rank exchange kinds and checks
     the gathered CSC against ONE oracle buffer fed the ranks' streams in rank order."""

@@ -275,6 +275,39 @@ def test_coo_constructor_equals_scipy(orc):
     assert np.allclose(nz, S.data, rtol=1e-14)
 
 
+def test_sparse_coo_restatement(orc):
+    """sparse(I,J,V,m,n,+) of the COO constructors (extendable.jl:92-104, test_constructors.jl:48-51):
+    structure = SciPy's, values = left-to-right sums in input order with the first value as it is
+    (dict model), numerical zeros kept, -0.0 survives, bounds rejected."""
+    from refmodel import COO
+    rng = np.random.default_rng(18)
+    m, n, cnt = 37, 29, 900
+    I = rng.integers(1, m + 1, cnt)
+    J = rng.integers(1, n + 1, cnt)
+    V = np.where(rng.random(cnt) < 0.2, 0.0, rng.standard_normal(cnt))
+    A = orc.sparse_coo(I, J, V, m, n)
+    M = DictModel(m, n)
+    for i, j, v in zip(I, J, V):
+        M.apply(COO, v, int(i), int(j))
+    assert_csc_equal(A.arrays(), M.arrays())
+    check_julia_invariants(m, n, *A.arrays())
+    S = sp.coo_matrix((V, (I - 1, J - 1)), shape=(m, n)).tocsc()
+    S.sort_indices()
+    cp, rv, nz = A.arrays()
+    assert np.array_equal(cp - 1, S.indptr) and np.array_equal(rv - 1, S.indices)   # zeros are kept by both
+    assert np.allclose(nz, S.data, rtol=1e-13, atol=1e-15)
+    # sizes default to the largest indices; a lone -0.0 keeps its sign (no 0.0 + v)
+    B = orc.sparse_coo([2, 3, 3], [4, 1, 1], [-0.0, 1.5, 2.0])
+    assert B.shape == (3, 4)
+    cp, rv, nz = B.arrays()
+    assert list(cp) == [1, 2, 2, 2, 3] and list(rv) == [3, 2] and nz[0] == 3.5 and np.signbit(nz[1])
+    with pytest.raises(orc.BoundsError):
+        orc.sparse_coo([1, 5], [1, 1], [1.0, 2.0], 4, 4)
+    # the stencil through the COO route equals the updateindex! route (test_fdrand.jl:47-53)
+    I, J, V = orc.fdrand_stream(5, 4, 3, rand_mode=1, seed=4)
+    assert_csc_equal(orc.sparse_coo(I, J, V, 60, 60).arrays(), orc.fdrand(5, 4, 3, rand_mode=1, seed=4, style=orc.KIND_UPDATE).arrays())
+
+
 # ------------------------------------------------------------- MT wrapper (a16,a17)
 def test_mt_wrapper_sum_semantics(orc):
     """genericmtextendablesparsematrixcsc.jl:45-114 + sparsematrixdilnkc.jl:397-435."""
