@@ -42,6 +42,7 @@ static_assert((1 << IDX_BITS) == CAP, "slot index must cover the segment capacit
 constexpr int CL_MAX_BITS = 11;  // up to 2048 local columns counted in LDS
 constexpr int CL_MAX = 1 << CL_MAX_BITS;
 constexpr int REG_RUN = 16;   // longest column run sorted in registers
+constexpr int REG_MAX_REM = 62 - SUB_SHIFT;  // ... when the packed sort keys stay below 2^62 (see load_sorted_run)
 constexpr int RANK_MAX = 48;  // longest column run sorted by LDS insertion
 constexpr u64 NOREC = ~0ull;
 
@@ -73,8 +74,12 @@ constexpr Net make_net(int N) {
                     }
     return r;
 }
-constexpr Net NET16 = make_net(REG_RUN);
-static_assert(NET16.n == 63, "merge-exchange network for 16 inputs has 63 comparators");
+template <int R>
+struct NetOf {
+    static constexpr Net net = make_net(R);
+};
+static_assert(NetOf<16>::net.n == 63, "merge-exchange network for 16 inputs has 63 comparators");
+static_assert(NetOf<12>::net.n == 42, "merge-exchange network for 12 inputs has 42 comparators");
 
 struct Args {
     const u64 *keys_in;
@@ -188,35 +193,47 @@ __device__ __forceinline__ void close_group(const Args &a, u64 *skey, double *sv
     }
 }
 
-// loads one column run (<= REG_RUN entries at skey[rs..rs+len)) into registers and sorts it
-__device__ __forceinline__ void load_sorted_run(const u64 *skey, const double *sval, int rs, int len, u64 (&x)[REG_RUN],
-                                                double (&xv)[REG_RUN]) {
+// loads one column run (<= R entries at skey[rs..rs+len)) into registers and sorts it
+template <int R>
+__device__ __forceinline__ void load_sorted_run(const u64 *skey, const double *sval, int rs, int len, u64 (&x)[R],
+                                                double (&xv)[R]) {
     const int lastj = len > 0 ? len - 1 : 0;
 #pragma unroll
-    for (int j = 0; j < REG_RUN; j++) x[j] = skey[rs + min(j, lastj)];  // 16 reads in flight
+    for (int j = 0; j < R; j++) x[j] = skey[rs + min(j, lastj)];  // all reads in flight
+    // Sort keys of this tier are < 2^62 (rem_bits <= REG_MAX_REM): read as IEEE doubles they are positive,
+    // finite and ordered like the integers (denormals are not flushed for f64), so a compare-exchange
+    // is v_min_f64 + v_max_f64 -- two full-rate instructions instead of a 64-bit compare and four
+    // selects.  Padding = the largest finite double.
+    constexpr u64 PAD = 0x7FEFFFFFFFFFFFFFull;
+    double d[R];
 #pragma unroll
-    for (int j = 0; j < REG_RUN; j++) x[j] = j < len ? x[j] : NOREC;
+    for (int j = 0; j < R; j++) d[j] = __longlong_as_double((long long)(j < len ? x[j] : PAD));
 #pragma unroll
-    for (int q = 0; q < NET16.n; q++) {
-        const u64 lo = x[NET16.a[q]], hi2 = x[NET16.b[q]];
-        const bool sw = lo > hi2;
-        x[NET16.a[q]] = sw ? hi2 : lo;
-        x[NET16.b[q]] = sw ? lo : hi2;
+    for (int q = 0; q < NetOf<R>::net.n; q++) {
+        const double lo = d[NetOf<R>::net.a[q]], hi2 = d[NetOf<R>::net.b[q]];
+        double mn, mx;
+        asm("v_min_f64 %0, %1, %2" : "=v"(mn) : "v"(lo), "v"(hi2));
+        asm("v_max_f64 %0, %1, %2" : "=v"(mx) : "v"(lo), "v"(hi2));
+        d[NetOf<R>::net.a[q]] = mn;
+        d[NetOf<R>::net.b[q]] = mx;
     }
 #pragma unroll
-    for (int j = 0; j < REG_RUN; j++) xv[j] = sval[(x[j] >> ESP_TAG_BITS) & (CAP - 1)];  // (padding reads slot CAP-1)
+    for (int j = 0; j < R; j++) x[j] = (u64)__double_as_longlong(d[j]);
+#pragma unroll
+    for (int j = 0; j < R; j++) xv[j] = sval[(x[j] >> ESP_TAG_BITS) & (CAP - 1)];  // (padding reads slot CAP-1)
 }
 
 // number of entries a sorted run will emit when nothing of it is in the CSC: a (col,row) group
 // becomes present iff one of its updates is a RAWUPDATE / COO entry or has a non-zero value (fold_step)
-__device__ __forceinline__ u32 count_emitted(const u64 (&x)[REG_RUN], const double (&xv)[REG_RUN], int len) {
+template <int R>
+__device__ __forceinline__ u32 count_emitted(const u64 (&x)[R], const double (&xv)[R], int len) {
     u32 e = 0;
     bool any = false;
     u64 psub = 0;
 #pragma unroll
-    for (int j = 0; j <= REG_RUN; j++) {
-        const bool valid = j < REG_RUN && j < len;
-        const u64 sub = (j < REG_RUN ? x[j] : NOREC) >> SUB_SHIFT;
+    for (int j = 0; j <= R; j++) {
+        const bool valid = j < R && j < len;
+        const u64 sub = (j < R ? x[j] : NOREC) >> SUB_SHIFT;
         const bool fresh = j == 0 || !valid || sub != psub;
         if (fresh && j > 0 && j <= len) e += any ? 1u : 0u;
         if (valid) {
@@ -224,15 +241,16 @@ __device__ __forceinline__ u32 count_emitted(const u64 (&x)[REG_RUN], const doub
                 psub = sub;
                 any = false;
             }
-            any |= ((u32)(x[j < REG_RUN ? j : 0] & ESP_TAG_MASK) >= (u32)ESP_RAWUPDATE) || xv[j < REG_RUN ? j : 0] != 0.0;
+            any |= ((u32)(x[j < R ? j : 0] & ESP_TAG_MASK) >= (u32)ESP_RAWUPDATE) || xv[j < R ? j : 0] != 0.0;
         }
     }
     return e;
 }
 
 // ordered fold of one sorted run held in registers; records go to skey[rs..), NOREC behind them
-__device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval, const u64 (&x)[REG_RUN],
-                                         const double (&xv)[REG_RUN], int rs, int len, u64 hi, u64 rowmask) {
+template <int R>
+__device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval, const u64 (&x)[R],
+                                         const double (&xv)[R], int rs, int len, u64 hi, u64 rowmask) {
     int e = 0;
     bool present = false;
     double acc = 0.0;
@@ -248,9 +266,9 @@ __device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval,
         cend = a.csc.colptr[col0 + 1] - 1;
     }
 #pragma unroll
-    for (int j = 0; j <= REG_RUN; j++) {
-        const bool valid = j < REG_RUN && j < len;
-        const u64 kj = j < REG_RUN ? x[j] : NOREC;
+    for (int j = 0; j <= R; j++) {
+        const bool valid = j < R && j < len;
+        const u64 kj = j < R ? x[j] : NOREC;
         const u64 sub = kj >> SUB_SHIFT;
         const bool fresh = j == 0 || !valid || sub != psub;
         if (fresh && j > 0 && j <= len) close_group(a, skey, sval, rs, e, pos, present, acc, psub, idx0);
@@ -267,11 +285,11 @@ __device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval,
                 present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
                 acc = present ? a.csc.nzval[pos] : 0.0;
             }
-            espfold::fold_step_sel(present, acc, (u32)(kj & ESP_TAG_MASK), xv[j < REG_RUN ? j : 0]);
+            espfold::fold_step_sel(present, acc, (u32)(kj & ESP_TAG_MASK), xv[j < R ? j : 0]);
         }
     }
 #pragma unroll
-    for (int j = 0; j < REG_RUN; j++)
+    for (int j = 0; j < R; j++)
         if (j >= e && j < len) skey[rs + j] = NOREC;
 }
 
@@ -340,6 +358,55 @@ __device__ __forceinline__ u64 lookback_wave(const Args &a, int s, u32 total, in
     LbState st;
     lb_init(st, s);
     return lb_finish(a, st, s, total, lane);
+}
+
+// Register tier of the bucket kernel: one lane per column, the whole run (<= R entries) in registers.
+// Returns true when the look-back already ran (early publication of the segment total).
+template <int R, bool FRESH>
+__device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval, const u32 *ccnt, int ncl, int s, u64 hi,
+                                         u64 rowmask, u32 *s_early, u64 *s_dst) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if (FRESH && a.csc.nnz == 0 && ncl <= THREADS - ESP_WAVE) {
+        // Nothing can hit the CSC, so the number of entries a run emits is known right after
+        // sorting.  The segment total is published BEFORE the fold and the last wave (idle in
+        // this phase: one lane per column) runs the look-back while the others fold.
+        u64 x[R];
+        double xv[R];
+        int rs = 0, len = 0;
+        u32 ec = 0;
+        if (t < ncl) {
+            rs = (int)ccnt[t];
+            len = (int)ccnt[t + 1] - rs;
+            load_sorted_run<R>(skey, sval, rs, len, x, xv);
+            ec = count_emitted<R>(x, xv, len);
+        }
+#pragma unroll
+        for (int dlt = 32; dlt > 0; dlt >>= 1) ec += (u32)__shfl_xor((int)ec, dlt, ESP_WAVE);
+        if (lane == 0 && ec) atomicAdd(s_early, ec);
+        __syncthreads();
+        if (w == WAVES - 1) {
+            // (measured: polling the predecessors already while the other waves sort costs
+            // more in contention than the shorter chain saves -- local 2.52 vs 2.33 ms)
+            const u64 excl = lookback_wave(a, s, *s_early, lane);
+            if (lane == 0) *s_dst = excl;
+        } else if (t < ncl) {
+            // (measured: keeping the sorted keys in registers across the barrier and re-reading
+            // only the values beats writing the run back to LDS)
+#pragma unroll
+            for (int j = 0; j < R; j++) xv[j] = sval[(x[j] >> ESP_TAG_BITS) & (CAP - 1)];
+            fold_run<R>(a, skey, sval, x, xv, rs, len, hi, rowmask);
+        }
+        return true;
+    }
+    for (int c = t; c < ncl; c += THREADS) {
+        const int rs = (int)ccnt[c];
+        const int len = (int)ccnt[c + 1] - rs;
+        u64 x[R];
+        double xv[R];
+        load_sorted_run<R>(skey, sval, rs, len, x, xv);
+        fold_run<R>(a, skey, sval, x, xv, rs, len, hi, rowmask);
+    }
+    return false;
 }
 
 template <bool FRESH, bool PIECES>
@@ -545,49 +612,13 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 3] = wall_clock64();
 #endif
             if (a.stop_after == 3) done = true;
-            if (!done && maxrun <= REG_RUN) {
-                // one lane per column: the whole run in registers, sorting network + ordered fold
-                if (FRESH && a.csc.nnz == 0 && ncl <= THREADS - ESP_WAVE) {
-                    // Nothing can hit the CSC, so the number of entries a run emits is known right after
-                    // sorting.  The segment total is published BEFORE the fold and the last wave (idle in
-                    // this phase: one lane per column) runs the look-back while the others fold.
-                    u64 x[REG_RUN];
-                    double xv[REG_RUN];
-                    int rs = 0, len = 0;
-                    u32 ec = 0;
-                    if (t < ncl) {
-                        rs = (int)ccnt[t];
-                        len = (int)ccnt[t + 1] - rs;
-                        load_sorted_run(skey, sval, rs, len, x, xv);
-                        ec = count_emitted(x, xv, len);
-                    }
-#pragma unroll
-                    for (int dlt = 32; dlt > 0; dlt >>= 1) ec += (u32)__shfl_xor((int)ec, dlt, ESP_WAVE);
-                    if (lane == 0 && ec) atomicAdd(&s_early, ec);
-                    __syncthreads();
-                    if (w == WAVES - 1) {
-                        // (measured: polling the predecessors already while the other waves sort costs
-                        // more in contention than the shorter chain saves -- local 2.52 vs 2.33 ms)
-                        const u64 excl = lookback_wave(a, s, s_early, lane);
-                        if (lane == 0) s_dst = excl;
-                    } else if (t < ncl) {
-                        // (measured: keeping the sorted keys in registers across the barrier and re-reading
-                        // only the values beats writing the run back to LDS)
-#pragma unroll
-                        for (int j = 0; j < REG_RUN; j++) xv[j] = sval[(x[j] >> ESP_TAG_BITS) & (CAP - 1)];
-                        fold_run(a, skey, sval, x, xv, rs, len, hi, rowmask);
-                    }
-                    lb_done = true;
-                } else {
-                    for (int c = t; c < ncl; c += THREADS) {
-                        const int rs = (int)ccnt[c];
-                        const int len = (int)ccnt[c + 1] - rs;
-                        u64 x[REG_RUN];
-                        double xv[REG_RUN];
-                        load_sorted_run(skey, sval, rs, len, x, xv);
-                        fold_run(a, skey, sval, x, xv, rs, len, hi, rowmask);
-                    }
-                }
+            if (!done && maxrun <= REG_RUN && a.rem_bits <= REG_MAX_REM) {
+                // one lane per column: the whole run in registers, sorting network + ordered fold; the
+                // network is sized to the longest run of the segment (12 covers a 7-point stencil)
+                if (maxrun <= 12)
+                    lb_done = reg_tier<12, FRESH>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, &s_dst);
+                else
+                    lb_done = reg_tier<REG_RUN, FRESH>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, &s_dst);
                 done = true;
             } else if (!done) {
                 for (int c = t; c < ncl; c += THREADS) {
