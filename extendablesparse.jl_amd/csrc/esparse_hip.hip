@@ -1269,11 +1269,9 @@ static int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn, const u64 *new_key, con
     const i64 N1 = h->n + 1;
     u64 *colend = (u64 *)h->colend.p;
     if (Z0 == 0) {
+        // colptr = 1 + exclusive max-scan of the column ends, written by the scan's last pass
         Span sp(h, ESP_ST_COLPTR);
-        sp.add(espscan::exclusive<u64, true>(h->stream, colend, colend, N1, colend + N1));
-        hipLaunchKernelGGL(espfold::colptr_finish_k, dim3(grid_for(N1, 256)), dim3(256), 0, h->stream, (const u64 *)colend,
-                           (const i64 *)nullptr, N1, (i64 *)h->colptr.p);
-        sp.add(1);
+        sp.add(espscan::exclusive<u64, true>(h->stream, colend, (u64 *)h->colptr.p, N1, colend + N1, (u64)1));
         h->nnz = Zn;
         return ESP_OK;
     }

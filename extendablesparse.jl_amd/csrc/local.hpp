@@ -525,6 +525,9 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             for (int i = 0; i < ITEMS; i++) vraw[i] = n > 0 ? *av[i] : 0.0;
         }
     }
+    // (LDS work that does not depend on the loads goes first: it runs while they are in flight)
+    if (a.cl_bits >= 0)
+        for (int q = t; q <= (1 << a.cl_bits); q += THREADS) ccnt[q] = 0;
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const int p = wbase + i * ESP_WAVE;
@@ -554,8 +557,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         // ---- column tiers: counting sort by local column with LDS atomics
         const int ncl = 1 << a.cl_bits;
         const int csh = SUB_SHIFT + a.rb;  // packed >> csh = local column
-        for (int q = t; q <= ncl; q += THREADS) ccnt[q] = 0;
-        __syncthreads();
+        __syncthreads();  // ccnt is zero (cleared while the loads were in flight)
         unsigned short slot[ITEMS];
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {

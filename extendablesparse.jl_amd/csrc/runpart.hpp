@@ -39,7 +39,7 @@ struct Args {
     u64 base, span;
     u32 *err;        // key outside the window
     u32 *overflow;   // a tile holds more than RMAX distinct digits
-    u32 *runs_d;     // [tile][RMAX] digits, ascending
+    u32 *runs_d;     // [tile][RMAX] digits (distinct, any order)
     u32 *runs_c;     // [tile][RMAX] counts
     i64 *runs_off;   // [tile][RMAX] global output offset of the run
     u64 *nruns;      // [tile] (+1 slot for the scan)
@@ -98,7 +98,7 @@ struct RunSink {
 // Digit-major counting of one chunk by a whole workgroup: every wave walks the DISTINCT digits of its
 // entries (a handful on a pre-sorted stream); for each one, NITEMS ballots count its entries.  The
 // workgroup's table (rd/rc/over in LDS, initialised and barrier'd by the caller) collects the waves'
-// results; the runs are written sorted by digit.  pend: bit k set = item k of this lane is an entry.
+// results.  pend: bit k set = item k of this lane is an entry.
 template <int NITEMS>
 __device__ __forceinline__ void count_runs(const u32 (&dig)[NITEMS], u32 pend, i64 chunk, const RunSink &sink, u32 *rd,
                                            u32 *rc, u32 *over) {
@@ -153,17 +153,18 @@ __device__ __forceinline__ void count_runs(const u32 (&dig)[NITEMS], u32 pend, i
         }
         return;
     }
-    // runs sorted by digit: every table slot ranks itself (digits are distinct)
+    // the used table slots, densely (RMAX == one wave; no order among the runs of a chunk is needed: the
+    // run list of all chunks is sorted by digit afterwards and a chunk's digits are distinct)
+    static_assert(RMAX == ESP_WAVE, "the run table is compacted by one wave");
     if (t < RMAX) {
         const u32 x = rd[t];
+        const u64 used = __ballot(x != EMPTY);
         if (x != EMPTY) {
-            int r = 0;
-            for (int i = 0; i < RMAX; i++) r += (rd[i] < x) ? 1 : 0;  // EMPTY is the largest value
+            const int r = __popcll(used & ((1ull << t) - 1ull));
             sink.runs_d[chunk * RMAX + r] = x;
             sink.runs_c[chunk * RMAX + r] = rc[t];
             atomicAdd(&sink.bucket_count[x], (unsigned long long)rc[t]);
         }
-        const u64 used = __ballot(x != EMPTY);
         if (t == 0) sink.nruns[chunk] = (u64)__popcll(used);
     }
 }

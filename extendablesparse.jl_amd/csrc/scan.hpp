@@ -64,9 +64,10 @@ __global__ __launch_bounds__(THREADS) void reduce_k(const T *__restrict__ in, i6
     if (threadIdx.x == 0) partial[blockIdx.x] = tot;
 }
 
+// addend: added to every output (e.g. the 1 of a 1-based colptr), outside the scan operation
 template <typename T, bool MAX>
 __global__ __launch_bounds__(THREADS) void apply_k(const T *in, T *out, i64 n,
-                                                   const T *__restrict__ carry_in) {
+                                                   const T *__restrict__ carry_in, T addend) {
     __shared__ T tile[CHUNK + ITEMS];
     __shared__ T lw[THREADS / 64];
     const i64 base = (i64)blockIdx.x * CHUNK;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(THREADS) void apply_k(const T *in, T *out, i64 n,
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         i64 idx = base + k * THREADS + threadIdx.x;
-        if (idx < n) out[idx] = tile[k * THREADS + threadIdx.x];
+        if (idx < n) out[idx] = tile[k * THREADS + threadIdx.x] + addend;
     }
 }
 
@@ -109,16 +110,16 @@ static inline i64 workspace_elems(i64 n) {
 // exclusive scan, in may equal out; ws holds workspace_elems(n) elements of T.
 // returns the number of kernel launches
 template <typename T, bool MAX>
-static int exclusive(hipStream_t s, const T *in, T *out, i64 n, T *ws) {
+static int exclusive(hipStream_t s, const T *in, T *out, i64 n, T *ws, T addend = 0) {
     if (n <= 0) return 0;
     i64 nb = ceil_div<i64>(n, CHUNK);
     if (nb == 1) {
-        hipLaunchKernelGGL((apply_k<T, MAX>), dim3(1), dim3(THREADS), 0, s, in, out, n, (const T *)nullptr);
+        hipLaunchKernelGGL((apply_k<T, MAX>), dim3(1), dim3(THREADS), 0, s, in, out, n, (const T *)nullptr, addend);
         return 1;
     }
     hipLaunchKernelGGL((reduce_k<T, MAX>), dim3((unsigned)nb), dim3(THREADS), 0, s, in, n, ws);
     int l = 1 + exclusive<T, MAX>(s, ws, ws, nb, ws + nb);
-    hipLaunchKernelGGL((apply_k<T, MAX>), dim3((unsigned)nb), dim3(THREADS), 0, s, in, out, n, (const T *)ws);
+    hipLaunchKernelGGL((apply_k<T, MAX>), dim3((unsigned)nb), dim3(THREADS), 0, s, in, out, n, (const T *)ws, addend);
     return l + 1;
 }
 
