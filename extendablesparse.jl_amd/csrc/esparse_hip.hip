@@ -73,6 +73,9 @@ struct esp_handle {
     u64 part_base = 0, part_span = 0;
     i64 part_total = 0;
     DevBuf parttab, piecetab;
+    // row-wise view of the device CSC for mul! (built on first use after a pattern change)
+    unsigned long long pattern_version = 1, csr_version = 0;
+    DevBuf csr_rowptr, csr_perm, csr_col, csr_tmp, mul_x, mul_r;
     // timing
     bool timing = false;
     std::vector<hipEvent_t> ev_pool;
@@ -215,6 +218,7 @@ static int32_t init_empty_csc(esp_handle *h) {
     hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(h->n + 1, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p,
                        h->n + 1, (i64)1);
     h->nnz = 0;
+    h->pattern_version++;
     h->csc_valid = true;
     return ESP_OK;
 }
@@ -272,7 +276,7 @@ extern "C" int32_t esp_destroy(esp_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->keys, &h->vals, &h->keys2, &h->vals2, &h->hist, &h->segs, &h->colend, &h->newkey,
                       &h->newval, &h->heads, &h->misc, &h->colptr, &h->rowval, &h->nzval, &h->rowval2,
-                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->runbuf, &h->chunkbuf, &h->d_st_rows, &h->d_st_cols, &h->d_st_vals, &h->d_st_kinds})
+                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->runbuf, &h->chunkbuf, &h->parttab, &h->piecetab, &h->csr_rowptr, &h->csr_perm, &h->csr_col, &h->csr_tmp, &h->mul_x, &h->mul_r, &h->d_st_rows, &h->d_st_cols, &h->d_st_vals, &h->d_st_kinds})
         release(*b);
     if (h->st_rows) (void)hipHostFree(h->st_rows);
     if (h->st_cols) (void)hipHostFree(h->st_cols);
@@ -617,6 +621,7 @@ extern "C" int32_t esp_set_csc(esp_handle *h, const int64_t *colptr, const int64
     sp.add(3);
     HIPCK(h, hipStreamSynchronize(h->stream));
     h->nnz = nnz;
+    h->pattern_version++;
     h->csc_valid = true;
     return ESP_OK;
 }
@@ -718,6 +723,7 @@ extern "C" int32_t esp_dropzeros(esp_handle *h, int64_t *new_nnz) {
         std::swap(h->rowval, h->rowval2);
         std::swap(h->nzval, h->nzval2);
         h->nnz = Zk;
+        h->pattern_version++;
     }
     if (new_nnz) *new_nnz = h->nnz;
     return ESP_OK;
@@ -1273,6 +1279,7 @@ static int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn, const u64 *new_key, con
         Span sp(h, ESP_ST_COLPTR);
         sp.add(espscan::exclusive<u64, true>(h->stream, colend, (u64 *)h->colptr.p, N1, colend + N1, (u64)1));
         h->nnz = Zn;
+        h->pattern_version++;
         return ESP_OK;
     }
     const i64 Zt = Z0 + Zn;
@@ -1314,6 +1321,7 @@ static int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn, const u64 *new_key, con
     std::swap(h->rowval, h->rowval2);
     std::swap(h->nzval, h->nzval2);
     h->nnz = Zt;
+    h->pattern_version++;
     return ESP_OK;
 }
 
@@ -1735,6 +1743,130 @@ extern "C" int32_t esp_shard_exchange_place(esp_handle *h, int64_t position, con
     HIPCK(h, hipMemcpyAsync((u64 *)h->keys.p + position, d_keys, sizeof(u64) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
     HIPCK(h, hipMemcpyAsync((double *)h->vals.p + position, d_vals, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
     sp.add(2);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return ESP_OK;
+}
+
+// ---- mul!(r, A, x) on the device CSC -------------------------------------------------------------
+// LinearAlgebra.mul!(r, ext, x) (abstractextendablesparsematrixcsc.jl:179-181 -> SparseArrays; the
+// coloured loop of genericmtextendablesparsematrixcsc.jl:124-143 visits the columns in the same
+// order): r .= 0, then column by column r[rows[i]] += vals[i]*x[col].  Every r[i] is therefore the
+// left-to-right sum over its row's entries in increasing column order, products and sums rounded
+// separately.  The device reproduces exactly that with a row-wise view of the CSC: a stable sort of
+// the entry indices by row (built once per pattern, values are gathered through it, so numeric
+// re-assembly does not invalidate it) and one thread per row adding in column order.  No atomics:
+// bit-identical to the reference loop.
+__global__ void csr_keys_k(const i64 *__restrict__ colptr, const i64 *__restrict__ rowval, i64 n, u64 *__restrict__ key,
+                           double *__restrict__ payload, u64 *__restrict__ colidx) {
+    const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n) return;
+    for (i64 p = colptr[c] - 1; p < colptr[c + 1] - 1; p++) {
+        key[p] = (u64)(rowval[p] - 1) << ESP_TAG_BITS;
+        payload[p] = __longlong_as_double((long long)p);
+        colidx[p] = (u64)c;
+    }
+}
+__global__ void csr_finish_k(const u64 *__restrict__ skey, const double *__restrict__ spayload, const u64 *__restrict__ colidx, i64 Z,
+                             u64 *__restrict__ perm, u64 *__restrict__ tcol, u64 *__restrict__ rowend) {
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= Z) return;
+    const u64 p = (u64)__double_as_longlong(spayload[k]);
+    perm[k] = p;
+    tcol[k] = colidx[p];
+    const u64 row = skey[k] >> ESP_TAG_BITS;
+    if (k == Z - 1 || (skey[k + 1] >> ESP_TAG_BITS) != row) rowend[row + 1] = (u64)(k + 1);
+}
+// rowptr0 = exclusive-max-scanned row ends shifted by one: entries of row i = [rowptr0[i], rowptr0[i+1])
+__global__ __launch_bounds__(256) void spmv_rows_k(const u64 *__restrict__ rowptr0, const u64 *__restrict__ perm,
+                                                   const u64 *__restrict__ tcol, const double *__restrict__ nzval,
+                                                   const double *__restrict__ x, i64 m, double *__restrict__ r) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= m) return;
+    double acc = 0.0;  // r .= zero(eltype)
+    const u64 b = rowptr0[i + 1], e = rowptr0[i + 2];
+    for (u64 k = b; k < e; k++) acc = acc + nzval[perm[k]] * x[tcol[k]];
+    r[i] = acc;
+}
+
+static int32_t build_csr(esp_handle *h) {
+    const i64 Z = h->nnz, m = h->m;
+    const i64 M2 = m + 2;
+    CK(ensure(h, h->csr_rowptr, sizeof(u64) * (size_t)(M2 + espscan::workspace_elems(M2))));
+    u64 *rowptr = (u64 *)h->csr_rowptr.p;
+    HIPCK(h, hipMemsetAsync(rowptr, 0, sizeof(u64) * (size_t)M2, h->stream));
+    if (Z > 0) {
+        CK(ensure(h, h->csr_perm, sizeof(u64) * (size_t)Z));
+        CK(ensure(h, h->csr_col, sizeof(u64) * (size_t)Z));
+        // scratch: keys A/B, payload A/B, colidx
+        CK(ensure(h, h->csr_tmp, sizeof(u64) * (size_t)Z * 5));
+        u64 *kA = (u64 *)h->csr_tmp.p, *kB = kA + Z;
+        double *vA = (double *)(kB + Z), *vB = vA + Z;
+        u64 *colidx = (u64 *)(vB + Z);
+        hipLaunchKernelGGL(csr_keys_k, dim3(grid_for(h->n, 256)), dim3(256), 0, h->stream, (const i64 *)h->colptr.p, (const i64 *)h->rowval.p,
+                           h->n, kA, vA, colidx);
+        CK(ensure(h, h->segs, sizeof(i64) * 8));
+        CK(ensure(h, h->misc, 256));
+        i64 *segs = (i64 *)h->segs.p;
+        const i64 T = ceil_div<i64>(Z, espradix::TILE);
+        hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, segs, (i64)0, Z, (i64)0, T);
+        u64 *ki = kA, *ko = kB;
+        double *vi = vA, *vo = vB;
+        for (int done = 0; done < h->L.rb; done += 8) {  // stable LSD sort by row: columns stay ascending
+            espradix::Pass p;
+            p.keys_in = ki;
+            p.vals_in = vi;
+            p.keys_out = ko;
+            p.vals_out = vo;
+            p.seg_start = segs;
+            p.tile_first = segs + 2;
+            p.S = 1;
+            p.owner_P = 0;
+            p.owner_n = 1;
+            p.colshift = 0;
+            p.base = 0;
+            p.span = ~0ull;
+            p.err = (u32 *)h->misc.p + 62;
+            p.shift = done;
+            p.bits = std::min(8, h->L.rb - done);
+            CK(partition_pass(h, p, T));
+            std::swap(ki, ko);
+            std::swap(vi, vo);
+        }
+        hipLaunchKernelGGL(csr_finish_k, dim3(grid_for(Z, 256)), dim3(256), 0, h->stream, (const u64 *)ki, (const double *)vi,
+                           (const u64 *)colidx, Z, (u64 *)h->csr_perm.p, (u64 *)h->csr_col.p, rowptr);
+    }
+    // rowptr[i+1] holds the end of row i (0 for empty rows): running maximum = start of the next row
+    espscan::exclusive<u64, true>(h->stream, rowptr, rowptr, M2, rowptr + M2);
+    HIPCK(h, hipGetLastError());
+    if (h->csr_tmp.p) {  // the scratch is 5 arrays of nnz: not worth keeping
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        (void)hipFree(h->csr_tmp.p);
+        h->csr_tmp = DevBuf{};
+    }
+    h->csr_version = h->pattern_version;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_mul(esp_handle *h, const double *x, double *r, int32_t on_device) {
+    if (!h || !x || !r) return ESP_ERR_INVALID;
+    if (h->count != 0) FAIL(h, ESP_ERR_STATE, "esp_mul: pending entries (flush first, like mul!(r, ext, x) does)");
+    (void)hipSetDevice(h->device);
+    if (!h->csc_valid) CK(init_empty_csc(h));
+    if (h->csr_version != h->pattern_version) CK(build_csr(h));
+    const double *dx = x;
+    double *dr = r;
+    if (!on_device) {
+        CK(ensure(h, h->mul_x, sizeof(double) * (size_t)std::max<i64>(h->n, 1)));
+        CK(ensure(h, h->mul_r, sizeof(double) * (size_t)std::max<i64>(h->m, 1)));
+        HIPCK(h, hipMemcpyAsync(h->mul_x.p, x, sizeof(double) * (size_t)h->n, hipMemcpyHostToDevice, h->stream));
+        dx = (const double *)h->mul_x.p;
+        dr = (double *)h->mul_r.p;
+    }
+    if (h->m > 0)
+        hipLaunchKernelGGL(spmv_rows_k, dim3(grid_for(h->m, 256)), dim3(256), 0, h->stream, (const u64 *)h->csr_rowptr.p,
+                           (const u64 *)h->csr_perm.p, (const u64 *)h->csr_col.p, (const double *)h->nzval.p, dx, h->m, dr);
+    HIPCK(h, hipGetLastError());
+    if (!on_device) HIPCK(h, hipMemcpyAsync(r, dr, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     return ESP_OK;
 }

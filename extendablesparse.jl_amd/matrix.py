@@ -383,6 +383,30 @@ class ExtendableSparseMatrix:
     def arrays(self):
         return self.sparse().arrays()
 
+    def mul(self, x, out=None):
+        """LinearAlgebra.mul!(r, ext, x) (abstractextendablesparsematrixcsc.jl:179-181): flush!, then r = A*x on
+        the device CSC, every r[i] summed in increasing column order like the reference's column loop.
+        x, out: NumPy arrays (copied through the device) or CUDA torch tensors (used in place)."""
+        self.flush()
+        d = self._d
+        if hasattr(x, "is_cuda") and x.is_cuda:
+            import torch
+            assert x.dtype == torch.float64 and x.numel() == self.n and x.is_contiguous()
+            r = out if out is not None else torch.empty(self.m, dtype=torch.float64, device=x.device)
+            assert r.is_cuda and r.dtype == torch.float64 and r.numel() == self.m and r.is_contiguous()
+            torch.cuda.current_stream(x.device).synchronize()   # the library runs on its own stream
+            d.ck(d.lib.esp_mul(d.h, C.c_void_p(x.data_ptr()), C.c_void_p(r.data_ptr()), 1))
+            return r
+        x = np.ascontiguousarray(x, np.float64)
+        if x.shape != (self.n,):
+            raise ValueError("DimensionMismatch")
+        r = out if out is not None else np.empty(self.m, np.float64)
+        d.ck(d.lib.esp_mul(d.h, _vp(x), _vp(r), 0))
+        return r
+
+    def __matmul__(self, x):  # A*x (genericmtextendablesparsematrixcsc.jl:119-121)
+        return self.mul(x)
+
     def reset(self):  # reset!: extendable.jl:269-272 (phash kept)
         self._touch()
         self._d._nst = 0

@@ -166,6 +166,14 @@ int32_t esp_getindex(esp_handle *h, int64_t i, int64_t j, double *value, int32_t
 /* stand-in for phash(csc) (sparsematrixcsc.jl:74): a 64-bit function of colptr/rowval only */
 int32_t esp_pattern_hash(esp_handle *h, uint64_t *hash);
 
+/* mul!(r, A, x) on the device CSC (abstractextendablesparsematrixcsc.jl:179-181; the coloured loop of
+ * genericmtextendablesparsematrixcsc.jl:124-143 visits the columns in the same order): r[i] = the sum of
+ * A[i,j]*x[j] over the entries of row i in increasing column order, products and sums rounded
+ * separately -- bit-identical to the reference's column loop (no atomics; a row-wise index of the CSC is
+ * built on first use after a pattern change).  x has n, r has m elements; on_device != 0: both are
+ * device pointers (a consumer that never leaves the GPU).  Pending entries -> ESP_ERR_STATE: flush first. */
+int32_t esp_mul(esp_handle *h, const double *x, double *r, int32_t on_device);
+
 /* ---- column-range shards (multi-GPU, one process per GPU) ------------------------
  * owner(col) = floor((col-1)*nshards/n).  esp_shard_counts: pending entries per owner.
  * esp_shard_export: stable partition of the pending entries by owner into the caller's

@@ -671,6 +671,16 @@ void orc_mt_reset(orc_mt *t) { /* :31-42 */
     }
 }
 
+/* ------------------------------------------------------------- mul! */
+/* LinearAlgebra.mul!(r, ext, x): abstractextendablesparsematrixcsc.jl:179-181 forwards to the CSC; the
+ * loop is the one spelled out in genericmtextendablesparsematrixcsc.jl:124-143 (with the default
+ * single partition the columns are visited in increasing order): r .= 0; r[rows[i]] += vals[i]*x[col]. */
+void orc_csc_mul(const orc_csc *c, const double *x, double *r) {
+    for (i64 i = 0; i < c->m; i++) r[i] = 0.0;
+    for (i64 col = 1; col <= c->n; col++)
+        for (i64 k = c->colptr[col - 1]; k < c->colptr[col]; k++) r[c->rowval[k - 1] - 1] += c->nzval[k - 1] * x[col - 1];
+}
+
 /* ------------------------------------------------ sparse(I,J,V,m,n,+) */
 /* The COO constructors ExtendableSparseMatrixCSC(I,J,V[,m,n]) (extendable.jl:92-104) and fdrand_coo
  * (sprand.jl:134-185) call SparseArrays.sparse(I,J,V,m,n[,+]) -- Julia stdlib, not under /root/reference,

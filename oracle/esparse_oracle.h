@@ -86,6 +86,8 @@ void orc_ext_reset(orc_ext *);
 void orc_ext_zero_values(orc_ext *);    /* fdrand!'s zero! (sprand.jl:82) */
 i64 orc_ext_dropzeros(orc_ext *);
 /* apply a whole stream; returns 0 or the first error and its position */
+/* mul!(r, A, x): r .= 0, column loop r[rows[i]] += vals[i]*x[col] (genericmtextendablesparsematrixcsc.jl:124-143) */
+void orc_csc_mul(const orc_csc *, const double *x, double *r);
 /* sparse(I,J,V,m,n,+) of the COO constructors (extendable.jl:92-104); NULL on an index outside m x n */
 orc_csc *orc_sparse_coo(i64 m, i64 n, i64 count, const i64 *I, const i64 *J, const double *V);
 int orc_ext_apply(orc_ext *, i64 count, const uint8_t *kinds, const i64 *I, const i64 *J,

@@ -89,6 +89,7 @@ def lib():
     sig("orc_ext_dropzeros", i64, vp)
     sig("orc_ext_apply", C.c_int, vp, i64, p_u8, p_i64, p_i64, p_f64, p_i64)
     sig("orc_sparse_coo", vp, i64, i64, i64, p_i64, p_i64, p_f64)
+    sig("orc_csc_mul", None, vp, p_f64, p_f64)
     sig("orc_mt_new", vp, i64, i64, i64)
     sig("orc_mt_free", None, vp)
     sig("orc_mt_setindex", C.c_int, vp, C.c_double, i64, i64)
@@ -184,6 +185,14 @@ class CSC:
 
     def dropzeros(self):
         return lib().orc_csc_dropzeros(self._h)
+
+    def mul(self, x):  # mul!(r, A, x)
+        x = np.ascontiguousarray(x, np.float64)
+        m, n = self.shape
+        assert len(x) == n
+        r = np.empty(m, np.float64)
+        lib().orc_csc_mul(self._h, _pf(x), _pf(r))
+        return r
 
     def __add__(self, lnk):  # csc + lnk  (sparsematrixlnk.jl:385)
         return lnk + self

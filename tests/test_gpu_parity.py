@@ -625,6 +625,51 @@ def test_sharded_matrix_world1_nccl(esp, orc):
         dist.destroy_process_group()
 
 
+def test_mul_bitwise_equals_column_loop(esp, orc):
+    """mul!(r, ext, x) on the device CSC: bit-identical to the reference's column loop (oracle), on random
+    rectangular matrices with empty rows/columns, after numeric re-assembly (same pattern, new values: the
+    row-wise index is reused), after a pattern change and after dropzeros!; NumPy and device-tensor forms."""
+    import torch
+    rng = np.random.default_rng(61)
+    for (m, n, cnt) in [(700, 500, 6000), (3, 4000, 5000), (5000, 7, 9000), (40, 40, 0)]:
+        A = esp.ExtendableSparseMatrix(m, n)
+        O = orc.ExtendableSparseMatrix(m, n)
+        for rnd in range(3):
+            I = rng.integers(1, m + 1, cnt)
+            J = rng.integers(1, n + 1, cnt)
+            if rnd == 1:
+                I, J = Iprev, Jprev                      # same pattern, other values
+            V = rng.standard_normal(cnt) * 10.0 ** rng.integers(-8, 9, cnt)
+            Iprev, Jprev = I, J
+            A.append(UPDATE, I, J, V)
+            O.apply(np.full(cnt, UPDATE, np.uint8), I, J, V)
+            x = rng.standard_normal(n) * 10.0 ** rng.integers(-5, 6, n)
+            want = O.sparse().mul(x)
+            got = A.mul(x)
+            assert np.array_equal(got.view(np.uint64), want.view(np.uint64)), (m, n, rnd)
+            xt = torch.from_numpy(x).cuda()
+            rt = A @ xt
+            assert np.array_equal(rt.cpu().numpy().view(np.uint64), want.view(np.uint64))
+        A.rawupdateindex("+", 0.0, m, n)                 # a structural zero, then dropped again
+        O.rawupdateindex(orc.OP_ADD, 0.0, m, n)
+        x = rng.standard_normal(n)
+        assert np.array_equal(A.mul(x).view(np.uint64), O.sparse().mul(x).view(np.uint64))
+        A.dropzeros()
+        O.dropzeros()
+        assert np.array_equal(A.mul(x).view(np.uint64), O.sparse().mul(x).view(np.uint64))
+    # the stencil: rand=()->1 gives zero row sums away from the boundary terms
+    nn = 40
+    S = esp.fdrand(nn, nn, nn, rand_mode=0)
+    y = S.mul(np.ones(nn ** 3))
+    Os = orc.fdrand(nn, nn, nn, rand_mode=0, style=orc.KIND_UPDATE)
+    assert np.array_equal(y.view(np.uint64), Os.sparse().mul(np.ones(nn ** 3)).view(np.uint64))
+    interior = np.zeros((nn, nn, nn), bool)
+    interior[1:-1, 1:-1, 1:-1] = True
+    assert np.all(np.abs(y[interior.ravel()]) < 1e-12)
+    with pytest.raises(ValueError):
+        S.mul(np.ones(5))
+
+
 def test_coo_constructor_and_fdrand_coo(esp, orc):
     """ExtendableSparseMatrixCSC(I,J,V[,m,n]) (extendable.jl:85-104) and fdrand_coo (sprand.jl:134-185)
     through the device pipeline as COO entries == the oracle's sparse(I,J,V,m,n,+)."""

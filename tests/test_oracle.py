@@ -275,6 +275,27 @@ def test_coo_constructor_equals_scipy(orc):
     assert np.allclose(nz, S.data, rtol=1e-14)
 
 
+def test_mul_restatement(orc):
+    """mul!(r, A, x) column loop == SciPy's product (to rounding), r .= 0 first, empty matrix gives zeros."""
+    rng = np.random.default_rng(19)
+    m, n, cnt = 60, 45, 500
+    I = rng.integers(1, m + 1, cnt)
+    J = rng.integers(1, n + 1, cnt)
+    V = rng.standard_normal(cnt)
+    A = orc.sparse_coo(I, J, V, m, n)
+    x = rng.standard_normal(n)
+    S = sp.coo_matrix((V, (I - 1, J - 1)), shape=(m, n)).tocsr()
+    assert np.allclose(A.mul(x), S @ x, rtol=1e-12, atol=1e-13)
+    # the exact summation order: row i adds its entries in increasing column order, starting from 0.0
+    cp, rv, nz = A.arrays()
+    r = np.zeros(m)
+    for col in range(n):
+        for k in range(cp[col] - 1, cp[col + 1] - 1):
+            r[rv[k] - 1] = r[rv[k] - 1] + nz[k] * x[col]
+    assert np.array_equal(bits(r), bits(A.mul(x)))
+    assert np.array_equal(orc.CSC(4, 3).mul(np.ones(3)), np.zeros(4))
+
+
 def test_sparse_coo_restatement(orc):
     """sparse(I,J,V,m,n,+) of the COO constructors (extendable.jl:92-104, test_constructors.jl:48-51):
     structure = SciPy's, values = left-to-right sums in input order with the first value as it is
