@@ -1385,8 +1385,8 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
             a.stop_after = e ? atoi(e) : 0;
             a.stamps = nullptr;
             if (getenv("ESP_LOCAL_STAMPS")) {  // diagnostics: per-segment phase stamps, dumped to a file
-                CK(ensure(h, h->heads, sizeof(u64) * (size_t)S * 8));
-                HIPCK(h, hipMemsetAsync(h->heads.p, 0, sizeof(u64) * (size_t)S * 8, h->stream));
+                CK(ensure(h, h->heads, sizeof(u64) * (size_t)S * 16));
+                HIPCK(h, hipMemsetAsync(h->heads.p, 0, sizeof(u64) * (size_t)S * 16, h->stream));
                 a.stamps = (unsigned long long *)h->heads.p;
             }
         }
@@ -1412,7 +1412,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     HIPCK(h, hipStreamSynchronize(h->stream));
     if ((u32)h->pin_scalar[2]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window");
     if (a.stamps) {
-        std::vector<u64> st((size_t)S * 8);
+        std::vector<u64> st((size_t)S * 16);
         HIPCK(h, hipMemcpy(st.data(), a.stamps, sizeof(u64) * st.size(), hipMemcpyDeviceToHost));
         if (FILE *f = fopen(getenv("ESP_LOCAL_STAMPS"), "wb")) {
             fwrite(st.data(), sizeof(u64), st.size(), f);

@@ -354,6 +354,18 @@ __device__ __forceinline__ u64 lb_finish(const Args &a, LbState &st, int s, u32 
         __hip_atomic_store(&a.status[s], ST_PRE | ((st.excl + (u64)total) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     return st.excl;
 }
+// the same in two steps, so that the wave can do other work (and pass barriers) in between
+__device__ __forceinline__ void lb_publish(const Args &a, LbState &st, int s, u32 total, int lane) {
+    lb_init(st, s);
+    if (lane == 0)  // (segment 0 has no predecessors: its total is the inclusive prefix already)
+        __hip_atomic_store(&a.status[s], (s > 0 ? ST_AGG : ST_PRE) | (u64)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ u64 lb_complete(const Args &a, LbState &st, int s, u32 total, int lane) {
+    lb_poll(a, st, lane, 0, true);
+    if (lane == 0)
+        __hip_atomic_store(&a.status[s], ST_PRE | ((st.excl + (u64)total) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return st.excl;
+}
 __device__ __forceinline__ u64 lookback_wave(const Args &a, int s, u32 total, int lane) {
     LbState st;
     lb_init(st, s);
@@ -364,7 +376,7 @@ __device__ __forceinline__ u64 lookback_wave(const Args &a, int s, u32 total, in
 // Returns true when the look-back already ran (early publication of the segment total).
 template <int R, bool FRESH>
 __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval, const u32 *ccnt, int ncl, int s, u64 hi,
-                                         u64 rowmask, u32 *s_early, u64 *s_dst) {
+                                         u64 rowmask, u32 *s_early, LbState &lb) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (FRESH && a.csc.nnz == 0 && ncl <= THREADS - ESP_WAVE) {
         // Nothing can hit the CSC, so the number of entries a run emits is known right after
@@ -383,18 +395,30 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
 #pragma unroll
         for (int dlt = 32; dlt > 0; dlt >>= 1) ec += (u32)__shfl_xor((int)ec, dlt, ESP_WAVE);
         if (lane == 0 && ec) atomicAdd(s_early, ec);
+#ifdef ESP_LOCAL_STAMPS
+        if (a.stamps && t == 0) a.stamps[(size_t)s * 16 + 8] = wall_clock64();
+#endif
         __syncthreads();
+#ifdef ESP_LOCAL_STAMPS
+        if (a.stamps && t == 0) a.stamps[(size_t)s * 16 + 9] = wall_clock64();
+#endif
         if (w == WAVES - 1) {
-            // (measured: polling the predecessors already while the other waves sort costs
-            // more in contention than the shorter chain saves -- local 2.52 vs 2.33 ms)
-            const u64 excl = lookback_wave(a, s, *s_early, lane);
-            if (lane == 0) *s_dst = excl;
+            // publish, then poll the predecessors a bounded number of times: the chain is usually still
+            // open when the others are done folding; the wave carries on with it between the following
+            // barriers (nothing before the final stores needs the offset)
+            // (measured: polling already while the other waves sort costs more in contention than the
+            // shorter chain saves -- local 2.52 vs 2.33 ms)
+            lb_publish(a, lb, s, *s_early, lane);
+            lb_poll(a, lb, lane, 1, false);
         } else if (t < ncl) {
             // (measured: keeping the sorted keys in registers across the barrier and re-reading
             // only the values beats writing the run back to LDS)
 #pragma unroll
             for (int j = 0; j < R; j++) xv[j] = sval[(x[j] >> ESP_TAG_BITS) & (CAP - 1)];
             fold_run<R>(a, skey, sval, x, xv, rs, len, hi, rowmask);
+#ifdef ESP_LOCAL_STAMPS
+            if (a.stamps && t == 0) a.stamps[(size_t)s * 16 + 10] = wall_clock64();
+#endif
         }
         return true;
     }
@@ -454,7 +478,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         const i64 beg = inwin ? s_win[s - w0] : a.seg_start[s];
         const i64 seg_end = inwin ? s_win[s - w0 + 1] : a.seg_start[s + 1];
 #ifdef ESP_LOCAL_STAMPS
-        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 0] = wall_clock64();
+        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 0] = wall_clock64();
 #endif
         n = (int)(seg_end - beg);
         // shared prefix of the segment (window-relative), turned back into an absolute key prefix
@@ -547,10 +571,12 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     if (a.stamps) { __syncthreads(); }
 #endif
 #ifdef ESP_LOCAL_STAMPS
-    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 1] = wall_clock64();
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 1] = wall_clock64();
 #endif
     bool done = n == 0;
-    bool lb_done = false;  // the look-back already ran (early publication, see the register tier)
+    bool lb_done = false;  // the look-back was started by the last wave (early publication, see the register tier)
+    LbState lbs;
+    lb_init(lbs, 0);
     if (a.stop_after == 1) done = true;
 
     if (!done && a.cl_bits >= 0) {
@@ -602,7 +628,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         if (t == 0) ccnt[ncl] = (u32)n;
         __syncthreads();
 #ifdef ESP_LOCAL_STAMPS
-        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 2] = wall_clock64();
+        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 2] = wall_clock64();
 #endif
         if (a.stop_after == 2) done = true;
         if (!done && maxrun <= RANK_MAX) {
@@ -611,16 +637,16 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
                 if (wbase + i * ESP_WAVE < n) skey[ccnt[(u32)(k[i] >> csh)] + slot[i]] = k[i];
             __syncthreads();
 #ifdef ESP_LOCAL_STAMPS
-            if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 3] = wall_clock64();
+            if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 3] = wall_clock64();
 #endif
             if (a.stop_after == 3) done = true;
             if (!done && maxrun <= REG_RUN && a.rem_bits <= REG_MAX_REM) {
                 // one lane per column: the whole run in registers, sorting network + ordered fold; the
                 // network is sized to the longest run of the segment (12 covers a 7-point stencil)
                 if (maxrun <= 12)
-                    lb_done = reg_tier<12, FRESH>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, &s_dst);
+                    lb_done = reg_tier<12, FRESH>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
                 else
-                    lb_done = reg_tier<REG_RUN, FRESH>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, &s_dst);
+                    lb_done = reg_tier<REG_RUN, FRESH>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
                 done = true;
             } else if (!done) {
                 for (int c = t; c < ncl; c += THREADS) {
@@ -722,7 +748,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         __syncthreads();
     }
 #ifdef ESP_LOCAL_STAMPS
-    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 4] = wall_clock64();
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 4] = wall_clock64();
 #endif
     if (a.stop_after == 4) {
         if (t == 0 && s == a.S - 1) __hip_atomic_store(&a.status[s], ST_PRE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -743,7 +769,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     __syncthreads();
     if (w == 0) {
 #ifdef ESP_LOCAL_STAMPS
-        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 5] = wall_clock64();
+        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 5] = wall_clock64();
 #endif
         const u32 c = lane < WAVES * ITEMS ? gcount[lane] : 0u;
         u32 inc = c;
@@ -762,12 +788,13 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             atomicOr(a.err, 4u);  // internal consistency: the early count must equal the folded count
         }
         if (lane == 0) lw[0] = total;
+    } else if (lb_done && w == WAVES - 1) {
+        lb_poll(a, lbs, lane, 1, false);
     }
     __syncthreads();
 #ifdef ESP_LOCAL_STAMPS
-    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 8 + 6] = wall_clock64();
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 6] = wall_clock64();
 #endif
-    const u64 dst = s_dst;
     const int total = (int)lw[0];
     // dense prefix in LDS (all records and values are in registers: in-place is safe)
 #pragma unroll
@@ -779,7 +806,15 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             sval[e] = rv[i];
         }
     }
+    if (lb_done && w == WAVES - 1) {  // the rest of the look-back chain, then the inclusive prefix for the successors
+        const u64 excl = lb_complete(a, lbs, s, s_early, lane);
+        if (lane == 0) s_dst = excl;
+#ifdef ESP_LOCAL_STAMPS
+        if (a.stamps && lane == 0) a.stamps[(size_t)s * 16 + 11] = wall_clock64();
+#endif
+    }
     __syncthreads();
+    const u64 dst = s_dst;
     // ---- coalesced stores + column-end marks
     for (int p = t; p < total; p += THREADS) {
         const u64 key = skey[p];
@@ -799,7 +834,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
 #ifdef ESP_LOCAL_STAMPS
     if (a.stamps) {
         __syncthreads();
-        if (threadIdx.x == 0) a.stamps[(size_t)s * 8 + 7] = wall_clock64();
+        if (threadIdx.x == 0) a.stamps[(size_t)s * 16 + 7] = wall_clock64();
     }
 #endif
 }

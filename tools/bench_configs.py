@@ -85,8 +85,33 @@ def config4(dim, npd):
             "path": A.debug_last_path(), "stage_ms": st}
 
 
+def mul_bench(n=256):
+    """mul!(r, A, x) on the device-resident CSC (first call builds the row-wise index)."""
+    N = n ** 3
+    A = esp.ExtendableSparseMatrix(N, N, capacity_hint=12 * n * n * (n - 1) + 6 * n * n)
+    A.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1)
+    A.flush()
+    x = torch.rand(N, device="cuda", dtype=torch.float64)
+    r = torch.empty(N, device="cuda", dtype=torch.float64)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    A.mul(x, out=r)
+    first = time.perf_counter() - t0
+    reps = 10
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        A.mul(x, out=r)
+    dt = (time.perf_counter() - t0) / reps
+    Z = A.nnz()
+    algo = 16.0 * Z + 8.0 * (N + 1) + 16.0 * N      # CSC entries once + colptr + x + r
+    return {"config": "mul!(r,A,x) %d^3 stencil on the device CSC" % n, "nnz": Z, "first_call_ms_incl_index_build": first * 1e3,
+            "ms_per_mul": dt * 1e3, "algorithmic_GBs": algo / dt / 1e9, "index_bytes_per_nnz": 16}
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["3", "4a", "4b"]
+    which = sys.argv[1:] or ["3", "4a", "4b", "mul"]
+    if "mul" in which:
+        print(json.dumps(mul_bench(int(os.environ.get("ESP_MUL_N", "256")))), flush=True)
     if "3" in which:
         print(json.dumps(config3(int(os.environ.get("ESP_CFG3_N", "256")))), flush=True)
     if "4a" in which:

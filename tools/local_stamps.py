@@ -22,7 +22,8 @@ for it in range(3):
     if it == 2:
         os.environ["ESP_LOCAL_STAMPS"] = "gpurun_out/stamps.bin"
     A.flush()
-st = np.fromfile("gpurun_out/stamps.bin", dtype=np.uint64).reshape(-1, 8).astype(np.int64)
+st16 = np.fromfile("gpurun_out/stamps.bin", dtype=np.uint64).reshape(-1, 16).astype(np.int64)
+st = st16[:, :8]
 d = np.diff(st, axis=1) * 0.01  # 100 MHz ticks -> us
 names = ["segment known -> loads arrived", "column count + scan", "scatter to LDS", "sort (+early look-back) + fold",
          "compaction", "look-back (if not early)", "LDS compact + stores"]
@@ -31,3 +32,10 @@ for i, nm in enumerate(names):
     print("%-34s median %6.2f  p90 %6.2f" % (nm, np.median(d[:, i]), np.percentile(d[:, i], 90)))
 span = (st[:, 7].max() - st[:, 0].min()) * 0.01
 print("kernel span %.1f us, %.0f segments resident on average" % (span, (st[:, 7] - st[:, 0]).sum() * 0.01 / span))
+# inside "sort + fold" (register tier with early publication): 3 = run start, 8 = sorted + counted,
+# 9 = barrier passed, 10 = fold done (wave 0), 11 = look-back done (last wave), 4 = phase end
+if st16[:, 8].any():
+    for nm, a, b in (("sort + count (wave 0)", 3, 8), ("barrier wait", 8, 9), ("fold (wave 0)", 9, 10),
+                     ("look-back (last wave)", 9, 11), ("phase end after fold", 10, 4), ("phase end after look-back", 11, 4)):
+        x = (st16[:, b] - st16[:, a]) * 0.01
+        print("  %-28s median %6.2f  p90 %6.2f" % (nm, np.median(x), np.percentile(x, 90)))
