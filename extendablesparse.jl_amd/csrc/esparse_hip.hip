@@ -1010,6 +1010,7 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
     a.vals_out = vout;
     a.E = E;
     a.chunk_start = ca.chunk_start;
+    a.fixed_chunks = fused ? 0 : 1;
     a.shift = mw ? mw_shift : K - pb;
     a.base = h->win_base;
     a.span = h->win_span;

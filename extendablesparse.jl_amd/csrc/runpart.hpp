@@ -35,6 +35,7 @@ struct Args {
     double *vals_out;
     i64 E;
     const i64 *chunk_start;  // C+1 buffer positions; chunk c = [chunk_start[c], chunk_start[c+1]), <= TILE entries
+    int fixed_chunks;        // chunk c = [c*TILE, min(E, (c+1)*TILE)): the kernels compute the bounds instead of loading them
     int shift;  // digit = (((key >> 2) - base) >> shift), digits < nbuckets
     u64 base, span;
     u32 *err;        // key outside the window
@@ -52,11 +53,15 @@ struct Args {
 };
 constexpr int MW_MAX = 64;  // windows the MULTI kernels take
 
+// (the kind bits ride along: one 64-bit subtraction and one shift per key; the histogram kernel
+// checks the window -- the host rejects the flush before the scatter kernel runs -- and only then clamps)
 __device__ __forceinline__ u32 digit16(const Args &a, u64 key, bool check) {
-    u64 kn = (key >> ESP_TAG_BITS) - a.base;
-    if (check && kn >= a.span) *a.err = 1u;
-    kn = kn < a.span ? kn : a.span - 1;
-    return (u32)(kn >> a.shift);
+    u64 rel = key - (a.base << ESP_TAG_BITS);
+    if (check && rel >= (a.span << ESP_TAG_BITS)) {
+        *a.err = 1u;
+        rel = 0;
+    }
+    return (u32)(rel >> (a.shift + ESP_TAG_BITS));
 }
 
 // MULTI: binary search of the key's window in the LDS copy of mw_base, then the digit inside it
@@ -177,11 +182,12 @@ __global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_chunk) {
     __shared__ u64 s_mw[MULTI ? MW_MAX : 1];
     const int t = threadIdx.x;
     if (MULTI && t < a.mw_P) s_mw[t] = a.mw_base[t];
-    // a stream that is not pre-sorted is recognised by the first workgroups: the rest leave at once
-    if (__hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     const i64 chunk = first_chunk + blockIdx.x;
-    const i64 beg = a.chunk_start[chunk];
-    const i64 end = a.chunk_start[chunk + 1];
+    const i64 beg = a.fixed_chunks ? chunk * TILE : a.chunk_start[chunk];
+    const i64 end = a.fixed_chunks ? min(a.E, beg + (i64)TILE) : a.chunk_start[chunk + 1];
+    // a stream that is not pre-sorted is recognised by the first workgroups: the rest leave at once
+    // (the flag is read while the keys are in flight)
+    const u32 give_up = __hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (t < RMAX) {
         rd[t] = EMPTY;
         rc[t] = 0;
@@ -193,6 +199,7 @@ __global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_chunk) {
         const i64 idx = beg + k * THREADS + t;
         key[k] = idx < end ? a.keys_in[idx] : 0ull;
     }
+    if (give_up != 0u) return;
     __syncthreads();
     u32 dig[ITEMS];
     u32 pend = 0;  // bit k: item k of this lane not yet counted
@@ -266,8 +273,8 @@ __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
     __shared__ int s_nr;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const i64 tile = blockIdx.x;  // = chunk index
-    const i64 beg = a.chunk_start[tile];
-    const i64 end = a.chunk_start[tile + 1];
+    const i64 beg = a.fixed_chunks ? tile * TILE : a.chunk_start[tile];
+    const i64 end = a.fixed_chunks ? min(a.E, beg + (i64)TILE) : a.chunk_start[tile + 1];
     // run table of the tile (nruns holds the exclusive scan by now: nr = difference)
     if (t == 0) s_nr = (int)(a.nruns[tile + 1] - a.nruns[tile]);
     if (t < RMAX) {
