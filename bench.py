@@ -175,7 +175,7 @@ def main():
                        "parallelism": ("column-range shards x%d, all-to-all-v entry routing (RCCL), z-slab "
                                        "producers, global grid %dx%dx%d" % (world, n, n, n * world)) if sharded else "1 GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom) if (n == 256 and not sharded) else None,
                          "avg_launch_ms": avg_ms, "launches": dom_launches,
                          "algorithmic_bytes_per_launch": per_launch_bytes},
             "pipeline": {"algorithmic_bytes_per_step": algo_bytes, "bytes_per_final_nnz": algo_bytes / Z,
