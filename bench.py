@@ -111,7 +111,8 @@ def main():
             A.generate_fdrand_range(n, n, nzg, rank * nodes, (rank + 1) * nodes, seed=0x5EED0002, rand_mode=1,
                                     kind=esp.ESP_UPDATE)
             SA.flush()
-    A.timing_enable(not os.environ.get("ESP_BENCH_NO_STAGE_TIMING"))
+    # level 1: HIP events around the big kernels only (ESP_BENCH_STAGE_TIMING=2 brackets the small scans too)
+    A.timing_enable(0 if os.environ.get("ESP_BENCH_NO_STAGE_TIMING") else int(os.environ.get("ESP_BENCH_STAGE_TIMING", "1")))
     if os.environ.get("ESP_BENCH_FORCE_PATH"):      # experiments only (see esp_debug_force_path)
         A.debug_force_path(int(os.environ["ESP_BENCH_FORCE_PATH"]))
 

@@ -78,6 +78,7 @@ struct esp_handle {
     DevBuf csr_rowptr, csr_perm, csr_col, csr_tmp, mul_x, mul_r;
     // timing
     bool timing = false;
+    int timing_level = 2;
     std::vector<hipEvent_t> ev_pool;
     std::vector<TimedSpan> spans;
     esp_timing_t acc;
@@ -178,7 +179,9 @@ struct Span {
     hipEvent_t a = nullptr;
     int launches = 0;
     Span(esp_handle *hh, int st) : h(hh), stage(st) {
-        if (h->timing) {
+        // timing level 1 brackets the big kernels only: the ~20 tiny launches of the "scan" stage would cost
+        // more in event records (two per span) than they run
+        if (h->timing && (h->timing_level > 1 || st != ESP_ST_SCAN)) {
             a = ev_get(h);
             (void)hipEventRecord(a, h->stream);
         }
@@ -2126,6 +2129,7 @@ extern "C" int32_t esp_timing_enable(esp_handle *h, int32_t on) {
     if (!h) return ESP_ERR_INVALID;
     timing_collect(h);
     h->timing = on != 0;
+    h->timing_level = on == 1 ? 1 : 2;   // 1: big kernels only; any other non-zero value: every stage
     return ESP_OK;
 }
 extern "C" int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear) {

@@ -460,7 +460,8 @@ class ExtendableSparseMatrix:
         return p.value
 
     def timing_enable(self, on=True):
-        self._d.ck(self._d.lib.esp_timing_enable(self._d.h, 1 if on else 0))
+        """on = True/1: events around the big kernels; 2: around every stage (incl. the small scans); False: off"""
+        self._d.ck(self._d.lib.esp_timing_enable(self._d.h, int(on)))
 
     def timing(self, clear=True):
         return self._d.timing(clear)

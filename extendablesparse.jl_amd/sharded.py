@@ -293,14 +293,17 @@ class ShardedExtendableSparseMatrix:
             self.last_exchange = "generic"
             self._flush_exchange_generic()
         self.local_nnz = be.flush()
-        # global colptr offsets: exclusive scan of the per-shard nnz
-        dev = getattr(be, "device", None)
-        mine = torch.tensor([self.local_nnz], dtype=torch.int64, device=dev if dev is not None else "cpu")
-        allnnz = [torch.empty_like(mine) for _ in range(P)]
-        dist.all_gather(allnnz, mine, group=self.group)
-        counts = np.array([int(t.item()) for t in allnnz], np.int64)
-        self.nnz_offsets = np.concatenate([[0], np.cumsum(counts)])
+        self._offsets_valid = False   # gathered on first use (nnz / local_slice / gather_sparse), see _offsets
         return self
+
+    def _offsets(self):
+        """Global colptr offsets = exclusive scan of the per-shard nnz.  COLLECTIVE on first use after a
+        flush (an all_gather): like flush itself, every rank has to get here."""
+        if not getattr(self, "_offsets_valid", True):
+            counts = self._gather_ints([self.local_nnz])[:, 0]
+            self.nnz_offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+            self._offsets_valid = True
+        return self.nnz_offsets
 
 
     def _gather_ints(self, values):
@@ -310,7 +313,7 @@ class ShardedExtendableSparseMatrix:
         mine = torch.tensor(list(values), dtype=torch.int64, device=dev if dev is not None else "cpu")
         out = [torch.empty_like(mine) for _ in range(self.P)]
         self.dist.all_gather(out, mine, group=self.group)
-        return np.stack([t.cpu().numpy() for t in out])
+        return torch.stack(out).cpu().numpy()   # one device-to-host copy, one synchronisation
 
     def _flush_exchange_partitioned(self):
         """One partition pass per rank (owner split + first pass of the local flush), ranges and
@@ -411,13 +414,13 @@ class ShardedExtendableSparseMatrix:
                             (rkeys[lower:], rvals[lower:])])
 
     def nnz(self):
-        return int(self.nnz_offsets[-1])
+        return int(self._offsets()[-1])
 
     def local_slice(self):
         """This shard's part of the global CSC: (c0, c1, colptr[c0..c1] global 1-based, rowval, nzval)."""
         csc = self.backend.local_csc()
         c0, c1 = self.ranges[self.rank]
-        colptr = csc.colptr[c0:c1 + 1] + self.nnz_offsets[self.rank]
+        colptr = csc.colptr[c0:c1 + 1] + self._offsets()[self.rank]
         if c0 > 0:
             assert csc.colptr[c0] == 1, "entries left of the owned column range"
         assert csc.colptr[c1] == csc.colptr[-1], "entries right of the owned column range"
@@ -436,5 +439,5 @@ class ShardedExtendableSparseMatrix:
             colptr[c0:c1 + 1] = cp
             rows.append(rv)
             vals.append(nz)
-        colptr[-1] = self.nnz_offsets[-1] + 1
+        colptr[-1] = self._offsets()[-1] + 1
         return SparseMatrixCSC(self.m, self.n, colptr, np.concatenate(rows), np.concatenate(vals))

@@ -36,7 +36,7 @@ def config3(n=256):
     N = n ** 3
     E = 12 * n * n * (n - 1) + 6 * n * n
     A = esp.ExtendableSparseMatrix(N, N, capacity_hint=E + 2 * n * n * (n - 2))
-    A.timing_enable(True)
+    A.timing_enable(2)
     # new positions: x second-neighbour pairs (l,l+2),(l+2,l) -- 28.4 % of Z0
     g = torch.arange(N, device="cuda", dtype=torch.int64)
     l = g[(g % n) < n - 2] + 1
@@ -70,7 +70,7 @@ def config3(n=256):
 def config4(dim, npd):
     nn = npd ** dim
     A = esp.ExtendableSparseMatrix(nn, nn)
-    A.timing_enable(True)
+    A.timing_enable(2)
 
     def step():
         A.reset()
