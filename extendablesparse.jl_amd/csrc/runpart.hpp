@@ -64,13 +64,32 @@ __device__ __forceinline__ u32 digit16(const Args &a, u64 key, bool check) {
     return (u32)(rel >> (a.shift + ESP_TAG_BITS));
 }
 
-// MULTI: binary search of the key's window in the LDS copy of mw_base, then the digit inside it
+// MULTI: the window of a key -- almost always the one of the wave's first key (r0, found once per wave
+// with scalar code), else a binary search in the LDS copy of mw_base -- then the digit inside it
+struct WaveWin {
+    u32 r0;     // window of the wave's first key
+    u64 base0;  // its first key
+    u64 width;  // keys up to the next window's first key
+};
+__device__ __forceinline__ WaveWin wave_window(const Args &a, const u64 *s_mw, u64 first_key) {
+    const u64 kp = esp_uniform_u64(first_key) >> ESP_TAG_BITS;
+    int r = 0;
+    for (int step = MW_MAX / 2; step; step >>= 1) {
+        const int c = r + step;
+        if (c < a.mw_P && kp >= esp_uniform_u64(s_mw[c])) r = c;
+    }
+    const u64 b0 = esp_uniform_u64(s_mw[r]);
+    const u64 next = r + 1 < a.mw_P ? esp_uniform_u64(s_mw[r + 1]) : ~0ull;  // (a window ends where the next one starts)
+    return WaveWin{(u32)r, b0, next - b0};
+}
 template <bool MULTI>
-__device__ __forceinline__ u32 digit_mw(const Args &a, const u64 *s_mw, u64 key, bool check) {
+__device__ __forceinline__ u32 digit_mw(const Args &a, const u64 *s_mw, const WaveWin &ww, u64 key, bool check) {
     if constexpr (!MULTI) {
         return digit16(a, key, check);
     } else {
         const u64 kp = key >> ESP_TAG_BITS;
+        const u64 rel0 = kp - ww.base0;
+        if (rel0 < ww.width) return ww.r0 * a.mw_nb + (u32)(rel0 >> a.shift);
         int r = 0;
 #pragma unroll
         for (int step = MW_MAX / 2; step; step >>= 1) {
@@ -203,10 +222,12 @@ __global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_chunk) {
     __syncthreads();
     u32 dig[ITEMS];
     u32 pend = 0;  // bit k: item k of this lane not yet counted
+    WaveWin ww{0, 0, 0};
+    if constexpr (MULTI) ww = wave_window(a, s_mw, key[0]);
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         const bool valid = (beg + k * THREADS + t) < end;
-        dig[k] = valid ? digit_mw<MULTI>(a, s_mw, key[k], true) : 0u;
+        dig[k] = valid ? digit_mw<MULTI>(a, s_mw, ww, key[k], true) : 0u;
         pend |= valid ? (1u << k) : 0u;
     }
     const RunSink sink{a.runs_d, a.runs_c, a.nruns, a.bucket_count, a.overflow};
@@ -315,10 +336,12 @@ __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
     unsigned char jrun[ITEMS];
     u32 dig[ITEMS];
     u32 pend = 0;
+    WaveWin ww{0, 0, 0};
+    if constexpr (MULTI) ww = wave_window(a, s_mw, key[0]);
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         const bool valid = (wbase + k * ESP_WAVE) < end;
-        dig[k] = valid ? digit_mw<MULTI>(a, s_mw, key[k], false) : 0u;
+        dig[k] = valid ? digit_mw<MULTI>(a, s_mw, ww, key[k], false) : 0u;
         pend |= valid ? (1u << k) : 0u;
         rank[k] = 0;
         jrun[k] = 0;
