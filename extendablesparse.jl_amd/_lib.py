@@ -76,6 +76,8 @@ SIGNATURES = {
     "esp_getindex": (i32, [vp, i64, i64, P(f64), P(i32)]),
     "esp_pattern_hash": (i32, [vp, P(u64)]),
     "esp_mul": (i32, [vp, vp, vp, i32]),
+    "esp_mark_dirichlet": (i32, [vp, f64, vp, i32]),
+    "esp_eliminate_dirichlet": (i32, [vp, vp, i32]),
     "esp_shard_counts": (i32, [vp, i32, vp]),
     "esp_shard_export": (i32, [vp, i32, vp, vp, vp]),
     "esp_shard_exchange_begin": (i32, [vp, i32, i32, i64, i64, P(vp), P(vp), vp]),

@@ -1875,6 +1875,63 @@ extern "C" int32_t esp_mul(esp_handle *h, const double *x, double *r, int32_t on
     return ESP_OK;
 }
 
+// ---- Dirichlet edits of the assembled CSC (sparsematrixcsc.jl:97-140) --------------------------------
+// one thread per column, the same statements as the reference loops (order inside a column kept)
+__global__ void mark_dirichlet_k(const i64 *__restrict__ colptr, const i64 *__restrict__ rowval, const double *__restrict__ nzval,
+                                 i64 n, double penalty, uint8_t *__restrict__ marker) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint8_t d = 0;
+    for (i64 j = colptr[i] - 1; j < colptr[i + 1] - 1; j++)
+        if (rowval[j] == i + 1 && nzval[j] >= penalty) d = 1;
+    marker[i] = d;
+}
+__global__ void eliminate_dirichlet_k(const i64 *__restrict__ colptr, const i64 *__restrict__ rowval, double *__restrict__ nzval, i64 n,
+                                      const uint8_t *__restrict__ marker) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool mine = marker[i] != 0;
+    for (i64 j = colptr[i] - 1; j < colptr[i + 1] - 1; j++) {
+        const i64 r = rowval[j] - 1;
+        double v = nzval[j];
+        if (mine) v = r == i ? 1.0 : 0.0;                 // A[:,i] = 0, A[i,i] = 1
+        if (r != i && marker[r] != 0) v = 0.0;            // A[r,:] = 0 for a marked row r
+        nzval[j] = v;
+    }
+}
+static int32_t dirichlet_call(esp_handle *h, uint8_t *marker, int32_t on_device, bool mark, double penalty) {
+    if (!h || !marker) return ESP_ERR_INVALID;
+    if (h->m != h->n) FAIL(h, ESP_ERR_INVALID, "dirichlet: the matrix must be square");
+    if (h->count != 0) FAIL(h, ESP_ERR_STATE, "dirichlet: pending entries (flush first)");
+    (void)hipSetDevice(h->device);
+    if (!h->csc_valid) CK(init_empty_csc(h));
+    const i64 n = h->n;
+    uint8_t *dm = marker;
+    if (!on_device) {
+        CK(ensure(h, h->mul_x, (size_t)std::max<i64>(n, 1)));
+        dm = (uint8_t *)h->mul_x.p;
+        if (!mark) HIPCK(h, hipMemcpyAsync(dm, marker, (size_t)n, hipMemcpyHostToDevice, h->stream));
+    }
+    if (n > 0) {
+        if (mark)
+            hipLaunchKernelGGL(mark_dirichlet_k, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, (const i64 *)h->colptr.p,
+                               (const i64 *)h->rowval.p, (const double *)h->nzval.p, n, penalty, dm);
+        else
+            hipLaunchKernelGGL(eliminate_dirichlet_k, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, (const i64 *)h->colptr.p,
+                               (const i64 *)h->rowval.p, (double *)h->nzval.p, n, (const uint8_t *)dm);
+    }
+    HIPCK(h, hipGetLastError());
+    if (!on_device && mark) HIPCK(h, hipMemcpyAsync(marker, dm, (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return ESP_OK;
+}
+extern "C" int32_t esp_mark_dirichlet(esp_handle *h, double penalty, uint8_t *marker, int32_t on_device) {
+    return dirichlet_call(h, marker, on_device, true, penalty);
+}
+extern "C" int32_t esp_eliminate_dirichlet(esp_handle *h, const uint8_t *marker, int32_t on_device) {
+    return dirichlet_call(h, const_cast<uint8_t *>(marker), on_device, false, 0.0);
+}
+
 // ---- partitioned exchange -------------------------------------------------------------------
 // The owner partition of esp_shard_exchange_begin and the first partition pass of the local flush are
 // ONE pass here: every rank partitions its pending entries by (owner, digit inside the owner's key

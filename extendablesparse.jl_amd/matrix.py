@@ -404,6 +404,24 @@ class ExtendableSparseMatrix:
         d.ck(d.lib.esp_mul(d.h, _vp(x), _vp(r), 0))
         return r
 
+    def mark_dirichlet(self, penalty=1.0e20):
+        """mark_dirichlet(A; penalty) (sparsematrixcsc.jl:94-108, via abstractextendablesparsematrixcsc.jl): flush!,
+        then the Bool vector marking the nodes with A[i,i] >= penalty."""
+        self.flush()
+        out = np.zeros(self.n, np.uint8)
+        self._d.ck(self._d.lib.esp_mark_dirichlet(self._d.h, float(penalty), _vp(out), 0))
+        return out.astype(bool)
+
+    def eliminate_dirichlet(self, marker):
+        """eliminate_dirichlet!(A, marker) (sparsematrixcsc.jl:121-144): A[:,i] = 0, A[i,:] = 0, A[i,i] = 1 for marked i."""
+        self.flush()
+        mk = np.ascontiguousarray(np.asarray(marker) != 0, np.uint8)
+        if mk.shape != (self.n,):
+            raise ValueError("DimensionMismatch")
+        self._d.ck(self._d.lib.esp_eliminate_dirichlet(self._d.h, _vp(mk), 0))
+        self._host = None
+        return self
+
     def __matmul__(self, x):  # A*x (genericmtextendablesparsematrixcsc.jl:119-121)
         return self.mul(x)
 

@@ -174,6 +174,12 @@ int32_t esp_pattern_hash(esp_handle *h, uint64_t *hash);
  * device pointers (a consumer that never leaves the GPU).  Pending entries -> ESP_ERR_STATE: flush first. */
 int32_t esp_mul(esp_handle *h, const double *x, double *r, int32_t on_device);
 
+/* mark_dirichlet(A; penalty) / eliminate_dirichlet!(A, marker) (sparsematrixcsc.jl:97-140) on the device CSC
+ * of a square matrix: marker[i] = 1 iff A[i,i] >= penalty; A[:,i] = 0, A[i,:] = 0, A[i,i] = 1 for marked i.
+ * marker has n bytes (Julia Vector{Bool}); on_device != 0: a device pointer.  Values only, the pattern stays. */
+int32_t esp_mark_dirichlet(esp_handle *h, double penalty, uint8_t *marker, int32_t on_device);
+int32_t esp_eliminate_dirichlet(esp_handle *h, const uint8_t *marker, int32_t on_device);
+
 /* ---- column-range shards (multi-GPU, one process per GPU) ------------------------
  * owner(col) = floor((col-1)*nshards/n).  esp_shard_counts: pending entries per owner.
  * esp_shard_export: stable partition of the pending entries by owner into the caller's

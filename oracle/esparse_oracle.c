@@ -671,6 +671,24 @@ void orc_mt_reset(orc_mt *t) { /* :31-42 */
     }
 }
 
+/* ------------------------------------------------- Dirichlet helpers */
+/* mark_dirichlet / eliminate_dirichlet!: sparsematrixcsc.jl:94-144, statement for statement */
+void orc_csc_mark_dirichlet(const orc_csc *c, double penalty, uint8_t *marker) {
+    for (i64 i = 1; i <= c->n; i++) {
+        marker[i - 1] = 0;
+        for (i64 j = c->colptr[i - 1]; j < c->colptr[i]; j++)
+            if (c->rowval[j - 1] == i && c->nzval[j - 1] >= penalty) marker[i - 1] = 1;
+    }
+}
+void orc_csc_eliminate_dirichlet(orc_csc *c, const uint8_t *marker) {
+    for (i64 i = 1; i <= c->n; i++) {
+        if (marker[i - 1])
+            for (i64 j = c->colptr[i - 1]; j < c->colptr[i]; j++) c->nzval[j - 1] = c->rowval[j - 1] == i ? 1.0 : 0.0;
+        for (i64 j = c->colptr[i - 1]; j < c->colptr[i]; j++)
+            if (c->rowval[j - 1] != i && marker[c->rowval[j - 1] - 1]) c->nzval[j - 1] = 0.0;
+    }
+}
+
 /* ------------------------------------------------------------- mul! */
 /* LinearAlgebra.mul!(r, ext, x): abstractextendablesparsematrixcsc.jl:179-181 forwards to the CSC; the
  * loop is the one spelled out in genericmtextendablesparsematrixcsc.jl:124-143 (with the default

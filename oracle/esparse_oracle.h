@@ -86,6 +86,9 @@ void orc_ext_reset(orc_ext *);
 void orc_ext_zero_values(orc_ext *);    /* fdrand!'s zero! (sprand.jl:82) */
 i64 orc_ext_dropzeros(orc_ext *);
 /* apply a whole stream; returns 0 or the first error and its position */
+/* mark_dirichlet(A;penalty) / eliminate_dirichlet!(A,marker) (sparsematrixcsc.jl:94-144) */
+void orc_csc_mark_dirichlet(const orc_csc *, double penalty, uint8_t *marker);
+void orc_csc_eliminate_dirichlet(orc_csc *, const uint8_t *marker);
 /* mul!(r, A, x): r .= 0, column loop r[rows[i]] += vals[i]*x[col] (genericmtextendablesparsematrixcsc.jl:124-143) */
 void orc_csc_mul(const orc_csc *, const double *x, double *r);
 /* sparse(I,J,V,m,n,+) of the COO constructors (extendable.jl:92-104); NULL on an index outside m x n */

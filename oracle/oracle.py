@@ -90,6 +90,8 @@ def lib():
     sig("orc_ext_apply", C.c_int, vp, i64, p_u8, p_i64, p_i64, p_f64, p_i64)
     sig("orc_sparse_coo", vp, i64, i64, i64, p_i64, p_i64, p_f64)
     sig("orc_csc_mul", None, vp, p_f64, p_f64)
+    sig("orc_csc_mark_dirichlet", None, vp, C.c_double, p_u8)
+    sig("orc_csc_eliminate_dirichlet", None, vp, p_u8)
     sig("orc_mt_new", vp, i64, i64, i64)
     sig("orc_mt_free", None, vp)
     sig("orc_mt_setindex", C.c_int, vp, C.c_double, i64, i64)
@@ -185,6 +187,16 @@ class CSC:
 
     def dropzeros(self):
         return lib().orc_csc_dropzeros(self._h)
+
+    def mark_dirichlet(self, penalty=1.0e20):
+        out = np.zeros(self.shape[1], np.uint8)
+        lib().orc_csc_mark_dirichlet(self._h, float(penalty), out.ctypes.data_as(p_u8))
+        return out.astype(bool)
+
+    def eliminate_dirichlet(self, marker):  # eliminate_dirichlet!(A, marker): in place
+        mk = np.ascontiguousarray(np.asarray(marker) != 0, np.uint8)
+        lib().orc_csc_eliminate_dirichlet(self._h, mk.ctypes.data_as(p_u8))
+        return self
 
     def mul(self, x):  # mul!(r, A, x)
         x = np.ascontiguousarray(x, np.float64)

@@ -670,6 +670,32 @@ def test_mul_bitwise_equals_column_loop(esp, orc):
         S.mul(np.ones(5))
 
 
+def test_dirichlet_helpers(esp, orc):
+    """mark_dirichlet / eliminate_dirichlet! (sparsematrixcsc.jl:94-144) on the device CSC == the oracle's loops."""
+    rng = np.random.default_rng(71)
+    nx, ny, nz = 14, 11, 9
+    N = nx * ny * nz
+    A = esp.fdrand(nx, ny, nz, rand_mode=1, seed=5)
+    O = orc.fdrand(nx, ny, nz, rand_mode=1, seed=5, style=orc.KIND_UPDATE)
+    nodes = rng.choice(N, 60, replace=False) + 1
+    for i in nodes:                                    # penalty method: A[i,i] += 1e30
+        A.updateindex("+", 1.0e30, int(i), int(i))
+        O.updateindex(orc.OP_ADD, 1.0e30, int(i), int(i))
+    A[5, 7] = 3.0e25                                   # a large off-diagonal entry is not a marker
+    O[5, 7] = 3.0e25
+    mk = A.mark_dirichlet()
+    want = O.sparse().mark_dirichlet()
+    assert np.array_equal(mk, want) and mk.sum() == 60 and set(np.flatnonzero(mk) + 1) == set(int(i) for i in nodes)
+    A.eliminate_dirichlet(mk)
+    C0 = O.sparse()
+    C0.eliminate_dirichlet(want)
+    assert_csc_equal(hip_arrays(A), C0.arrays())
+    x = rng.standard_normal(N)
+    assert np.array_equal(A.mul(x).view(np.uint64), C0.mul(x).view(np.uint64))
+    with pytest.raises(ValueError):
+        A.eliminate_dirichlet(np.zeros(3, bool))
+
+
 def test_coo_constructor_and_fdrand_coo(esp, orc):
     """ExtendableSparseMatrixCSC(I,J,V[,m,n]) (extendable.jl:85-104) and fdrand_coo (sprand.jl:134-185)
     through the device pipeline as COO entries == the oracle's sparse(I,J,V,m,n,+)."""
