@@ -1771,18 +1771,18 @@ __global__ void csr_keys_k(const i64 *__restrict__ colptr, const i64 *__restrict
     }
 }
 __global__ void csr_finish_k(const u64 *__restrict__ skey, const double *__restrict__ spayload, const u64 *__restrict__ colidx, i64 Z,
-                             u64 *__restrict__ perm, u64 *__restrict__ tcol, u64 *__restrict__ rowend) {
+                             u32 *__restrict__ perm, u32 *__restrict__ tcol, u64 *__restrict__ rowend) {
     const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= Z) return;
     const u64 p = (u64)__double_as_longlong(spayload[k]);
-    perm[k] = p;
-    tcol[k] = colidx[p];
+    perm[k] = (u32)p;
+    tcol[k] = (u32)colidx[p];
     const u64 row = skey[k] >> ESP_TAG_BITS;
     if (k == Z - 1 || (skey[k + 1] >> ESP_TAG_BITS) != row) rowend[row + 1] = (u64)(k + 1);
 }
 // rowptr0 = exclusive-max-scanned row ends shifted by one: entries of row i = [rowptr0[i], rowptr0[i+1])
-__global__ __launch_bounds__(256) void spmv_rows_k(const u64 *__restrict__ rowptr0, const u64 *__restrict__ perm,
-                                                   const u64 *__restrict__ tcol, const double *__restrict__ nzval,
+__global__ __launch_bounds__(256) void spmv_rows_k(const u64 *__restrict__ rowptr0, const u32 *__restrict__ perm,
+                                                   const u32 *__restrict__ tcol, const double *__restrict__ nzval,
                                                    const double *__restrict__ x, i64 m, double *__restrict__ r) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
@@ -1799,8 +1799,9 @@ static int32_t build_csr(esp_handle *h) {
     u64 *rowptr = (u64 *)h->csr_rowptr.p;
     HIPCK(h, hipMemsetAsync(rowptr, 0, sizeof(u64) * (size_t)M2, h->stream));
     if (Z > 0) {
-        CK(ensure(h, h->csr_perm, sizeof(u64) * (size_t)Z));
-        CK(ensure(h, h->csr_col, sizeof(u64) * (size_t)Z));
+        if (Z >= 0xFFFFFFF0ll || h->n >= 0xFFFFFFF0ll) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_mul: the row-wise index holds 32-bit positions and columns");
+        CK(ensure(h, h->csr_perm, sizeof(u32) * (size_t)Z));
+        CK(ensure(h, h->csr_col, sizeof(u32) * (size_t)Z));
         // scratch: keys A/B, payload A/B, colidx
         CK(ensure(h, h->csr_tmp, sizeof(u64) * (size_t)Z * 5));
         u64 *kA = (u64 *)h->csr_tmp.p, *kB = kA + Z;
@@ -1837,7 +1838,7 @@ static int32_t build_csr(esp_handle *h) {
             std::swap(vi, vo);
         }
         hipLaunchKernelGGL(csr_finish_k, dim3(grid_for(Z, 256)), dim3(256), 0, h->stream, (const u64 *)ki, (const double *)vi,
-                           (const u64 *)colidx, Z, (u64 *)h->csr_perm.p, (u64 *)h->csr_col.p, rowptr);
+                           (const u64 *)colidx, Z, (u32 *)h->csr_perm.p, (u32 *)h->csr_col.p, rowptr);
     }
     // rowptr[i+1] holds the end of row i (0 for empty rows): running maximum = start of the next row
     espscan::exclusive<u64, true>(h->stream, rowptr, rowptr, M2, rowptr + M2);
@@ -1868,7 +1869,7 @@ extern "C" int32_t esp_mul(esp_handle *h, const double *x, double *r, int32_t on
     }
     if (h->m > 0)
         hipLaunchKernelGGL(spmv_rows_k, dim3(grid_for(h->m, 256)), dim3(256), 0, h->stream, (const u64 *)h->csr_rowptr.p,
-                           (const u64 *)h->csr_perm.p, (const u64 *)h->csr_col.p, (const double *)h->nzval.p, dx, h->m, dr);
+                           (const u32 *)h->csr_perm.p, (const u32 *)h->csr_col.p, (const double *)h->nzval.p, dx, h->m, dr);
     HIPCK(h, hipGetLastError());
     if (!on_device) HIPCK(h, hipMemcpyAsync(r, dr, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));

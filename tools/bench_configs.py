@@ -105,7 +105,7 @@ def mul_bench(n=256):
     Z = A.nnz()
     algo = 16.0 * Z + 8.0 * (N + 1) + 16.0 * N      # CSC entries once + colptr + x + r
     return {"config": "mul!(r,A,x) %d^3 stencil on the device CSC" % n, "nnz": Z, "first_call_ms_incl_index_build": first * 1e3,
-            "ms_per_mul": dt * 1e3, "algorithmic_GBs": algo / dt / 1e9, "index_bytes_per_nnz": 16}
+            "ms_per_mul": dt * 1e3, "algorithmic_GBs": algo / dt / 1e9, "index_bytes_per_nnz": 8}
 
 
 if __name__ == "__main__":
