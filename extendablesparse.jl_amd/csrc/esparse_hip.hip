@@ -48,6 +48,7 @@ struct esp_handle {
     int fused_state = 0;  // 0 no pending data, 1 every pending entry came with its run list, 2 mixed/stale
     int last_fused = 0;
     int runs_skip = 0, runs_penalty = 0;  // back-off after a stream turned out not to be pre-sorted
+    int seen_maxrun = 0;                  // longest column run the bucket kernel met in the last flush
     int last_partition = 0;               // 1 = run-based single pass, 2 = 8-bit passes only
     // column window of the pending entries (whole matrix by default)
     u64 win_base = 0, win_span = 0;
@@ -1384,6 +1385,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         a.ptab = st.ptab;
         a.ticket = (u32 *)(status + S);
         a.err = (u32 *)(status + S) + 1;
+        a.maxrun_seen = (u32 *)(status + S) + 2;  // (zeroed with the granules)
         {
             const char *e = getenv("ESP_LOCAL_STOP");
             a.stop_after = e ? atoi(e) : 0;
@@ -1398,23 +1400,25 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         for (i64 first = 0; first < S; first += max_grid) {
             const unsigned grid = (unsigned)std::min<i64>(max_grid, S - first);
             a.first = first;
+            // (the variant with the 24-input register tier for a matrix whose last flush met such runs)
+            const bool big = h->seen_maxrun > 16 && h->seen_maxrun <= esplocal::REG_RUN;
+#define ESP_LAUNCH_LOCAL(F, P, B) hipLaunchKernelGGL((esplocal::local_k<F, P, B>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a)
             if (st.npieces > 0) {
-                if (Z0 == 0)
-                    hipLaunchKernelGGL((esplocal::local_k<true, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
-                else
-                    hipLaunchKernelGGL((esplocal::local_k<false, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+                if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true); else ESP_LAUNCH_LOCAL(true, true, false); }
+                else { if (big) ESP_LAUNCH_LOCAL(false, true, true); else ESP_LAUNCH_LOCAL(false, true, false); }
             } else if (Z0 == 0) {
-                hipLaunchKernelGGL((esplocal::local_k<true, false>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+                if (big) ESP_LAUNCH_LOCAL(true, false, true); else ESP_LAUNCH_LOCAL(true, false, false);
             } else {
-                hipLaunchKernelGGL((esplocal::local_k<false, false>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+                if (big) ESP_LAUNCH_LOCAL(false, false, true); else ESP_LAUNCH_LOCAL(false, false, false);
             }
+#undef ESP_LAUNCH_LOCAL
         }
         sp.add(1);
     }
-    HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (S - 1), 16, hipMemcpyDeviceToHost, h->stream));
-    HIPCK(h, hipMemcpyAsync(h->pin_scalar + 2, (u32 *)h->misc.p + 60, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (S - 1), 24, hipMemcpyDeviceToHost, h->stream));  // last granule | ticket, err | maxrun
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar + 3, (u32 *)h->misc.p + 60, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
-    if ((u32)h->pin_scalar[2]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window");
+    if ((u32)h->pin_scalar[3]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window");
     if (a.stamps) {
         std::vector<u64> st((size_t)S * 16);
         HIPCK(h, hipMemcpy(st.data(), a.stamps, sizeof(u64) * st.size(), hipMemcpyDeviceToHost));
@@ -1424,6 +1428,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         }
     }
     const u32 lookback_err = (u32)(h->pin_scalar[1] >> 32);
+    h->seen_maxrun = (int)(u32)(h->pin_scalar[2] >> 0 & 0xFFFFFFFFull);
     if (lookback_err & 2u) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (bucket)");
     if (lookback_err & 1u) FAIL(h, ESP_ERR_HIP, "esp_flush: look-back chain timed out inside the bucket kernel");
     if (lookback_err & 4u) FAIL(h, ESP_ERR_HIP, "esp_flush: internal error (early segment total differs from the folded total)");

@@ -41,7 +41,7 @@ static_assert((1 << IDX_BITS) == CAP, "slot index must cover the segment capacit
 
 constexpr int CL_MAX_BITS = 11;  // up to 2048 local columns counted in LDS
 constexpr int CL_MAX = 1 << CL_MAX_BITS;
-constexpr int REG_RUN = 16;   // longest column run sorted in registers
+constexpr int REG_RUN = 24;   // longest column run sorted in registers
 constexpr int REG_MAX_REM = 62 - SUB_SHIFT;  // ... when the packed sort keys stay below 2^62 (see load_sorted_run)
 constexpr int RANK_MAX = 48;  // longest column run sorted by LDS insertion
 constexpr u64 NOREC = ~0ull;
@@ -57,8 +57,8 @@ constexpr i64 MAX_GRID = 1 << 22;  // workgroups per launch (HIP caps a grid at 
 // compile time; used to sort one short column run per lane entirely in registers.
 struct Net {
     int n;
-    int a[96];
-    int b[96];
+    int a[160];
+    int b[160];
 };
 constexpr Net make_net(int N) {
     Net r{};
@@ -80,6 +80,7 @@ struct NetOf {
 };
 static_assert(NetOf<16>::net.n == 63, "merge-exchange network for 16 inputs has 63 comparators");
 static_assert(NetOf<12>::net.n == 42, "merge-exchange network for 12 inputs has 42 comparators");
+static_assert(NetOf<24>::net.n == 132, "merge-exchange network for 24 inputs has 132 comparators");
 
 struct Args {
     const u64 *keys_in;
@@ -109,6 +110,7 @@ struct Args {
     int npieces;
     const i64 *pstart;
     const void *const *ptab;
+    u32 *maxrun_seen;  // longest column run any segment of this flush met (atomicMax)
 };
 constexpr int MAX_PIECES = 64;
 
@@ -473,7 +475,10 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
     return false;
 }
 
-template <bool FRESH, bool PIECES>
+// BIG: the kernel also carries the 24-input register tier.  It is a separate instantiation because the
+// extra code costs the common path registers (measured: +25 % on the 12-input tier when both live in one
+// kernel); the host picks it for a handle whose last flush met runs of 17..24 (a.maxrun_seen).
+template <bool FRESH, bool PIECES, bool BIG>
 __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     __shared__ u64 skey[CAP];
     __shared__ double sval[CAP];
@@ -681,12 +686,15 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 3] = wall_clock64();
 #endif
             if (a.stop_after == 3) done = true;
-            if (!done && maxrun <= REG_RUN && a.rem_bits <= REG_MAX_REM) {
+            if (t == 0 && maxrun > 16) atomicMax(a.maxrun_seen, maxrun);  // (tells the host which kernel variant suits this matrix)
+            if (!done && maxrun <= (BIG ? REG_RUN : 16) && a.rem_bits <= REG_MAX_REM) {
                 // one lane per column: the whole run in registers, sorting network + ordered fold; the
                 // network is sized to the longest run of the segment (12 covers a 7-point stencil)
                 if (maxrun <= 12)
                     lb_done = reg_tier<12, FRESH>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
-                else
+                else if (!BIG || maxrun <= 16)
+                    lb_done = reg_tier<16, FRESH>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
+                else if constexpr (BIG)
                     lb_done = reg_tier<REG_RUN, FRESH>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
                 done = true;
             } else if (!done) {

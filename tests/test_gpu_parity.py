@@ -419,6 +419,33 @@ def test_bucket_kernel_tiers(esp, orc, per_col):
         assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
 
 
+def test_bucket_kernel_24_input_tier(esp, orc):
+    """Column runs of exactly 20 entries: the first flush of a handle takes the LDS insertion tier, the
+    following ones the kernel variant with the 24-input register tier (chosen from the longest run the
+    previous flush met) -- over an existing CSC (ROUTED) and, after reset!, on a fresh matrix."""
+    rng = np.random.default_rng(24)
+    m, n, per = 900, 4096, 20
+    cnt = per * n
+    A = esp.ExtendableSparseMatrix(m, n)
+    O = orc.ExtendableSparseMatrix(m, n)
+    for rnd in range(4):
+        if rnd == 2:
+            A.reset()
+            O.reset()
+        kinds = rng.choice(np.array([0, 1, 1, 1, 2], np.uint8), cnt)
+        J = rng.permutation(np.repeat(np.arange(1, n + 1), per))
+        I = rng.integers(1, m + 1, cnt)
+        dup = rng.random(cnt) < 0.4
+        I[dup] = rng.integers(1, 7, dup.sum())
+        V = np.where(rng.random(cnt) < 0.1, 0.0, rng.standard_normal(cnt))
+        A.append(0, I, J, V, kinds=kinds)
+        O.apply(kinds, I, J, V)
+        A.flush()
+        O.flush()
+        assert A.debug_last_path() == 1
+        assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
+
+
 def test_general_path_fdrand_and_plus_mode(esp, orc):
     A = esp.ExtendableSparseMatrix(20 ** 3, 20 ** 3)
     A.debug_force_path(2)
