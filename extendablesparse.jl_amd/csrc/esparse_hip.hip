@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <thread>
 
 #include "common.hpp"
 #include "fold.hpp"
@@ -57,11 +58,15 @@ struct esp_handle {
     i64 nnz = 0;
     bool csc_valid = false;  // colptr initialised
     // host staging (pinned) + device staging
-    i64 stage_cap = 0;
-    i64 *st_rows = nullptr, *st_cols = nullptr;
-    double *st_vals = nullptr;
-    uint8_t *st_kinds = nullptr;
-    DevBuf d_st_rows, d_st_cols, d_st_vals, d_st_kinds;
+    // pinned staging areas (+ their device mirrors): `stage` is the one esp_stage_begin hands to the caller
+    // (its pointers stay valid until the caller asks for a larger one); `bulk` is private to esp_append_host
+    struct StageArea {
+        i64 cap = 0;
+        i64 *rows = nullptr, *cols = nullptr;
+        double *vals = nullptr;
+        uint8_t *kinds = nullptr;
+        DevBuf d_rows, d_cols, d_vals, d_kinds;
+    } stage, bulk;
     unsigned long long *pin_scalar = nullptr;  // pinned, 8 slots
     // shard cache
     bool shard_valid = false;
@@ -87,6 +92,7 @@ struct esp_handle {
 };
 
 static thread_local std::string g_err;
+static void par_memcpy(void *dst, const void *src, size_t bytes);
 
 // the pending entries changed: whatever was derived from them is stale
 static inline void pending_changed(esp_handle *h) {
@@ -280,12 +286,14 @@ extern "C" int32_t esp_destroy(esp_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->keys, &h->vals, &h->keys2, &h->vals2, &h->hist, &h->segs, &h->colend, &h->newkey,
                       &h->newval, &h->heads, &h->misc, &h->colptr, &h->rowval, &h->nzval, &h->rowval2,
-                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->runbuf, &h->chunkbuf, &h->parttab, &h->piecetab, &h->csr_rowptr, &h->csr_perm, &h->csr_col, &h->csr_tmp, &h->mul_x, &h->mul_r, &h->d_st_rows, &h->d_st_cols, &h->d_st_vals, &h->d_st_kinds})
+                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->runbuf, &h->chunkbuf, &h->parttab, &h->piecetab, &h->csr_rowptr, &h->csr_perm, &h->csr_col, &h->csr_tmp, &h->mul_x, &h->mul_r, &h->stage.d_rows, &h->stage.d_cols, &h->stage.d_vals, &h->stage.d_kinds, &h->bulk.d_rows, &h->bulk.d_cols, &h->bulk.d_vals, &h->bulk.d_kinds})
         release(*b);
-    if (h->st_rows) (void)hipHostFree(h->st_rows);
-    if (h->st_cols) (void)hipHostFree(h->st_cols);
-    if (h->st_vals) (void)hipHostFree(h->st_vals);
-    if (h->st_kinds) (void)hipHostFree(h->st_kinds);
+    for (esp_handle::StageArea *sa : {&h->stage, &h->bulk}) {
+        if (sa->rows) (void)hipHostFree(sa->rows);
+        if (sa->cols) (void)hipHostFree(sa->cols);
+        if (sa->vals) (void)hipHostFree(sa->vals);
+        if (sa->kinds) (void)hipHostFree(sa->kinds);
+    }
     if (h->pin_scalar) (void)hipHostFree(h->pin_scalar);
     for (auto &s : h->spans) {
         (void)hipEventDestroy(s.a);
@@ -372,7 +380,7 @@ static int32_t pack_device(esp_handle *h, const i64 *d_rows, const i64 *d_cols, 
         Span sp(h, ESP_ST_APPEND);
         hipLaunchKernelGGL(espgen::pack_k, dim3(grid_for(count, espgen::THREADS)), dim3(espgen::THREADS), 0, h->stream,
                            d_rows, d_cols, d_vals, d_kinds, kind_all, op == ESP_OP_SUB ? 1 : 0, count, h->m, h->n, h->L,
-                           (u64 *)h->keys.p + h->count, (double *)h->vals.p + h->count, d_err);
+                           (u64 *)h->keys.p + h->count, (double *)h->vals.p + h->count, d_err, (i64)0);
         sp.add(1);
     }
     HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 8, hipMemcpyDeviceToHost, h->stream));
@@ -386,26 +394,27 @@ static int32_t pack_device(esp_handle *h, const i64 *d_rows, const i64 *d_cols, 
     return ESP_OK;
 }
 
-static int32_t ensure_stage(esp_handle *h, i64 want) {
-    if (want <= h->stage_cap) return ESP_OK;
+static int32_t ensure_stage(esp_handle *h, esp_handle::StageArea &sa, i64 want) {
+    if (want <= sa.cap) return ESP_OK;
     i64 cap = std::max<i64>(want, 1 << 16);
-    if (h->st_rows) (void)hipHostFree(h->st_rows);
-    if (h->st_cols) (void)hipHostFree(h->st_cols);
-    if (h->st_vals) (void)hipHostFree(h->st_vals);
-    if (h->st_kinds) (void)hipHostFree(h->st_kinds);
-    h->st_rows = h->st_cols = nullptr;
-    h->st_vals = nullptr;
-    h->st_kinds = nullptr;
-    h->stage_cap = 0;
-    HIPCK(h, hipHostMalloc((void **)&h->st_rows, sizeof(i64) * (size_t)cap, hipHostMallocDefault));
-    HIPCK(h, hipHostMalloc((void **)&h->st_cols, sizeof(i64) * (size_t)cap, hipHostMallocDefault));
-    HIPCK(h, hipHostMalloc((void **)&h->st_vals, sizeof(double) * (size_t)cap, hipHostMallocDefault));
-    HIPCK(h, hipHostMalloc((void **)&h->st_kinds, (size_t)cap, hipHostMallocDefault));
-    CK(ensure(h, h->d_st_rows, sizeof(i64) * (size_t)cap));
-    CK(ensure(h, h->d_st_cols, sizeof(i64) * (size_t)cap));
-    CK(ensure(h, h->d_st_vals, sizeof(double) * (size_t)cap));
-    CK(ensure(h, h->d_st_kinds, (size_t)cap));
-    h->stage_cap = cap;
+    HIPCK(h, hipStreamSynchronize(h->stream));  // (a transfer out of the old area may be in flight)
+    if (sa.rows) (void)hipHostFree(sa.rows);
+    if (sa.cols) (void)hipHostFree(sa.cols);
+    if (sa.vals) (void)hipHostFree(sa.vals);
+    if (sa.kinds) (void)hipHostFree(sa.kinds);
+    sa.rows = sa.cols = nullptr;
+    sa.vals = nullptr;
+    sa.kinds = nullptr;
+    sa.cap = 0;
+    HIPCK(h, hipHostMalloc((void **)&sa.rows, sizeof(i64) * (size_t)cap, hipHostMallocDefault));
+    HIPCK(h, hipHostMalloc((void **)&sa.cols, sizeof(i64) * (size_t)cap, hipHostMallocDefault));
+    HIPCK(h, hipHostMalloc((void **)&sa.vals, sizeof(double) * (size_t)cap, hipHostMallocDefault));
+    HIPCK(h, hipHostMalloc((void **)&sa.kinds, (size_t)cap, hipHostMallocDefault));
+    CK(ensure(h, sa.d_rows, sizeof(i64) * (size_t)cap));
+    CK(ensure(h, sa.d_cols, sizeof(i64) * (size_t)cap));
+    CK(ensure(h, sa.d_vals, sizeof(double) * (size_t)cap));
+    CK(ensure(h, sa.d_kinds, (size_t)cap));
+    sa.cap = cap;
     return ESP_OK;
 }
 
@@ -415,58 +424,110 @@ extern "C" int32_t esp_stage_begin(esp_handle *h, int64_t want, int64_t **rows, 
     (void)hipSetDevice(h->device);
     if (want <= 0) want = 1 << 20;
     want = std::min<i64>(want, (i64)1 << 26);
-    CK(ensure_stage(h, want));
-    *rows = h->st_rows;
-    *cols = h->st_cols;
-    *vals = h->st_vals;
-    if (kinds) *kinds = h->st_kinds;
-    *got = h->stage_cap;
+    CK(ensure_stage(h, h->stage, want));
+    *rows = h->stage.rows;
+    *cols = h->stage.cols;
+    *vals = h->stage.vals;
+    if (kinds) *kinds = h->stage.kinds;
+    *got = h->stage.cap;
     return ESP_OK;
 }
 
 extern "C" int32_t esp_commit(esp_handle *h, int64_t count, int32_t kind_all, int32_t op) {
     if (!h) return ESP_ERR_INVALID;
-    if (count < 0 || count > h->stage_cap) FAIL(h, ESP_ERR_INVALID, "esp_commit: count %lld exceeds the staged chunk", (long long)count);
+    if (count < 0 || count > h->stage.cap) FAIL(h, ESP_ERR_INVALID, "esp_commit: count %lld exceeds the staged chunk", (long long)count);
     if (count == 0) return ESP_OK;
     (void)hipSetDevice(h->device);
     {
         Span sp(h, ESP_ST_COPY);
-        HIPCK(h, hipMemcpyAsync(h->d_st_rows.p, h->st_rows, sizeof(i64) * (size_t)count, hipMemcpyHostToDevice, h->stream));
-        HIPCK(h, hipMemcpyAsync(h->d_st_cols.p, h->st_cols, sizeof(i64) * (size_t)count, hipMemcpyHostToDevice, h->stream));
-        HIPCK(h, hipMemcpyAsync(h->d_st_vals.p, h->st_vals, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(h->stage.d_rows.p, h->stage.rows, sizeof(i64) * (size_t)count, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(h->stage.d_cols.p, h->stage.cols, sizeof(i64) * (size_t)count, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(h->stage.d_vals.p, h->stage.vals, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, h->stream));
         sp.add(3);
         if (kind_all < 0) {
-            HIPCK(h, hipMemcpyAsync(h->d_st_kinds.p, h->st_kinds, (size_t)count, hipMemcpyHostToDevice, h->stream));
+            HIPCK(h, hipMemcpyAsync(h->stage.d_kinds.p, h->stage.kinds, (size_t)count, hipMemcpyHostToDevice, h->stream));
             sp.add(1);
         }
     }
-    return pack_device(h, (const i64 *)h->d_st_rows.p, (const i64 *)h->d_st_cols.p, (const double *)h->d_st_vals.p,
-                       kind_all < 0 ? (const uint8_t *)h->d_st_kinds.p : nullptr, kind_all, op, count);
+    return pack_device(h, (const i64 *)h->stage.d_rows.p, (const i64 *)h->stage.d_cols.p, (const double *)h->stage.d_vals.p,
+                       kind_all < 0 ? (const uint8_t *)h->stage.d_kinds.p : nullptr, kind_all, op, count);
 }
 
+// host memcpy with a few threads: one core moves ~10 GB/s, PCIe takes ~55 GB/s
+static void par_memcpy(void *dst, const void *src, size_t bytes) {
+    const size_t min_part = (size_t)4 << 20;
+    int nt = (int)std::min<size_t>(4, bytes / min_part);
+    if (nt <= 1) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    std::thread th[4];
+    const size_t part = ((bytes / (size_t)nt) + 63) & ~(size_t)63;
+    for (int i = 0; i < nt; i++) {
+        const size_t o = (size_t)i * part;
+        const size_t c = i == nt - 1 ? bytes - o : part;
+        th[i] = std::thread([=] { memcpy((char *)dst + o, (const char *)src + o, c); });
+    }
+    for (int i = 0; i < nt; i++) th[i].join();
+}
+
+// Bulk append from host arrays: the batch goes through the pinned staging area in chunks, two halves in
+// flight (the host copy of chunk i+1 overlaps the PCIe transfer and the pack kernel of chunk i); bounds
+// are checked on the device and read back ONCE: the call is one batch, nothing is committed on error.
 extern "C" int32_t esp_append_host(esp_handle *h, const int64_t *rows, const int64_t *cols, const double *vals,
                                    const uint8_t *kinds, int32_t kind_all, int32_t op, int64_t count) {
     if (!h || count < 0 || (count > 0 && (!rows || !cols || !vals))) return ESP_ERR_INVALID;
+    if (count == 0) return ESP_OK;
     (void)hipSetDevice(h->device);
-    const i64 chunk = (i64)1 << 22;
-    const i64 start_count = h->count;
-    for (i64 off = 0; off < count; off += chunk) {
+    if (!kinds && (kind_all < 0 || kind_all > 3)) FAIL(h, ESP_ERR_INVALID, "append: kind %d invalid", kind_all);
+    if (op != ESP_OP_ADD && op != ESP_OP_SUB) FAIL(h, ESP_ERR_UNSUPPORTED, "append: op %d not supported on the device path", op);
+    const i64 chunk = std::min<i64>((i64)1 << 22, std::max<i64>(count, 1));
+    esp_handle::StageArea &sa = h->bulk;
+    CK(ensure_stage(h, sa, 2 * chunk));
+    CK(reserve_append(h, count));
+    CK(ensure(h, h->misc, 256));
+    unsigned long long *d_err = (unsigned long long *)h->misc.p;
+    h->pin_scalar[0] = ~0ull;
+    HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 8, hipMemcpyHostToDevice, h->stream));
+    hipEvent_t done[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; i++) HIPCK(h, hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    int32_t rc = ESP_OK;
+    i64 it = 0;
+    for (i64 off = 0; off < count && rc == ESP_OK; off += chunk, it++) {
         const i64 c = std::min<i64>(chunk, count - off);
-        int64_t *r, *cc;
-        double *v;
-        uint8_t *k;
-        int64_t got;
-        CK(esp_stage_begin(h, c, &r, &cc, &v, &k, &got));
-        memcpy(r, rows + off, sizeof(i64) * (size_t)c);
-        memcpy(cc, cols + off, sizeof(i64) * (size_t)c);
-        memcpy(v, vals + off, sizeof(double) * (size_t)c);
-        if (kinds) memcpy(k, kinds + off, (size_t)c);
-        int32_t st = esp_commit(h, c, kinds ? -1 : kind_all, op);
-        if (st != ESP_OK) {
-            h->count = start_count;  // the whole call is one batch: nothing is committed
-            return st;
-        }
+        const int half = (int)(it & 1);
+        const i64 so = half ? chunk : 0;  // this half of the staging arrays (host and device)
+        if (it >= 2 && hipEventSynchronize(done[half]) != hipSuccess) rc = ESP_ERR_HIP;
+        par_memcpy(sa.rows + so, rows + off, sizeof(i64) * (size_t)c);
+        par_memcpy(sa.cols + so, cols + off, sizeof(i64) * (size_t)c);
+        par_memcpy(sa.vals + so, vals + off, sizeof(double) * (size_t)c);
+        if (kinds) memcpy(sa.kinds + so, kinds + off, (size_t)c);
+        i64 *dr = (i64 *)sa.d_rows.p + so, *dc = (i64 *)sa.d_cols.p + so;
+        double *dv = (double *)sa.d_vals.p + so;
+        uint8_t *dk = (uint8_t *)sa.d_kinds.p + so;
+        Span sp(h, ESP_ST_COPY);
+        if (hipMemcpyAsync(dr, sa.rows + so, sizeof(i64) * (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(dc, sa.cols + so, sizeof(i64) * (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(dv, sa.vals + so, sizeof(double) * (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            (kinds && hipMemcpyAsync(dk, sa.kinds + so, (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess))
+            rc = ESP_ERR_HIP;
+        sp.add(kinds ? 4 : 3);
+        hipLaunchKernelGGL(espgen::pack_k, dim3(grid_for(c, espgen::THREADS)), dim3(espgen::THREADS), 0, h->stream, (const i64 *)dr,
+                           (const i64 *)dc, (const double *)dv, kinds ? (const uint8_t *)dk : nullptr, kind_all, op == ESP_OP_SUB ? 1 : 0, c,
+                           h->m, h->n, h->L, (u64 *)h->keys.p + h->count + off, (double *)h->vals.p + h->count + off, d_err, off);
+        (void)hipEventRecord(done[half], h->stream);
     }
+    hipError_t e1 = hipMemcpyAsync(h->pin_scalar, d_err, 8, hipMemcpyDeviceToHost, h->stream);
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 2; i++) (void)hipEventDestroy(done[i]);
+    if (rc != ESP_OK || e1 != hipSuccess || e2 != hipSuccess || hipGetLastError() != hipSuccess)
+        FAIL(h, ESP_ERR_HIP, "esp_append_host: transfer failed");
+    fused_invalidate(h);
+    if (h->pin_scalar[0] != ~0ull)
+        FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
+             (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
+    h->count += count;
+    pending_changed(h);
     return ESP_OK;
 }
 
@@ -630,20 +691,54 @@ extern "C" int32_t esp_set_csc(esp_handle *h, const int64_t *colptr, const int64
     return ESP_OK;
 }
 
+// Device -> pageable host memory (a Julia Vector, a NumPy array) through two pinned bounce buffers: the
+// PCIe transfer of chunk i+1 overlaps the (multi-threaded) host copy of chunk i.  A plain hipMemcpy into
+// pageable memory runs at ~10 GB/s here, this at ~45 GB/s.
+static int32_t d2h_pipelined(esp_handle *h, void *dst, const void *d_src, size_t bytes) {
+    if (bytes == 0) return ESP_OK;
+    const size_t small = (size_t)8 << 20;
+    if (bytes <= small) {
+        HIPCK(h, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        return ESP_OK;
+    }
+    CK(ensure_stage(h, h->bulk, (i64)1 << 22));  // rows / cols of the bulk area: 2 x 32 MiB pinned
+    char *pin[2] = {(char *)h->bulk.rows, (char *)h->bulk.cols};
+    const size_t chunk = (size_t)h->bulk.cap * 8;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; i++) HIPCK(h, hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    const size_t nchunks = (bytes + chunk - 1) / chunk;
+    int32_t rc = ESP_OK;
+    for (size_t c = 0; c <= nchunks && rc == ESP_OK; c++) {
+        if (c < nchunks) {  // issue the transfer of chunk c
+            const size_t o = c * chunk, len = std::min(chunk, bytes - o);
+            if (hipMemcpyAsync(pin[c & 1], (const char *)d_src + o, len, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                hipEventRecord(ev[c & 1], h->stream) != hipSuccess)
+                rc = ESP_ERR_HIP;
+        }
+        if (c > 0 && rc == ESP_OK) {  // ... while chunk c-1 moves from its bounce buffer to the caller
+            const size_t o = (c - 1) * chunk, len = std::min(chunk, bytes - o);
+            if (hipEventSynchronize(ev[(c - 1) & 1]) != hipSuccess) rc = ESP_ERR_HIP;
+            else par_memcpy((char *)dst + o, pin[(c - 1) & 1], len);
+        }
+    }
+    (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 2; i++) (void)hipEventDestroy(ev[i]);
+    if (rc != ESP_OK) FAIL(h, ESP_ERR_HIP, "device-to-host transfer failed");
+    return ESP_OK;
+}
+
 extern "C" int32_t esp_get_csc(esp_handle *h, int64_t *colptr, int64_t *rowval, double *nzval) {
     if (!h || !colptr) return ESP_ERR_INVALID;
     (void)hipSetDevice(h->device);
-    {
-        Span sp(h, ESP_ST_COPY);
-        HIPCK(h, hipMemcpyAsync(colptr, h->colptr.p, sizeof(i64) * (size_t)(h->n + 1), hipMemcpyDeviceToHost, h->stream));
-        if (h->nnz > 0) {
-            if (!rowval || !nzval) FAIL(h, ESP_ERR_INVALID, "esp_get_csc: rowval/nzval NULL with nnz>0");
-            HIPCK(h, hipMemcpyAsync(rowval, h->rowval.p, sizeof(i64) * (size_t)h->nnz, hipMemcpyDeviceToHost, h->stream));
-            HIPCK(h, hipMemcpyAsync(nzval, h->nzval.p, sizeof(double) * (size_t)h->nnz, hipMemcpyDeviceToHost, h->stream));
-        }
-        sp.add(3);
+    if (h->nnz > 0 && (!rowval || !nzval)) FAIL(h, ESP_ERR_INVALID, "esp_get_csc: rowval/nzval NULL with nnz>0");
+    Span sp(h, ESP_ST_COPY);
+    CK(d2h_pipelined(h, colptr, h->colptr.p, sizeof(i64) * (size_t)(h->n + 1)));
+    if (h->nnz > 0) {
+        CK(d2h_pipelined(h, rowval, h->rowval.p, sizeof(i64) * (size_t)h->nnz));
+        CK(d2h_pipelined(h, nzval, h->nzval.p, sizeof(double) * (size_t)h->nnz));
     }
-    HIPCK(h, hipStreamSynchronize(h->stream));
+    sp.add(3);
     return ESP_OK;
 }
 
@@ -652,9 +747,7 @@ extern "C" int32_t esp_get_nzval(esp_handle *h, double *nzval) {
     if (h->nnz == 0) return ESP_OK;
     if (!nzval) return ESP_ERR_INVALID;
     (void)hipSetDevice(h->device);
-    HIPCK(h, hipMemcpyAsync(nzval, h->nzval.p, sizeof(double) * (size_t)h->nnz, hipMemcpyDeviceToHost, h->stream));
-    HIPCK(h, hipStreamSynchronize(h->stream));
-    return ESP_OK;
+    return d2h_pipelined(h, nzval, h->nzval.p, sizeof(double) * (size_t)h->nnz);
 }
 
 extern "C" int32_t esp_csc_device(esp_handle *h, const int64_t **d_colptr, const int64_t **d_rowval, const double **d_nzval) {

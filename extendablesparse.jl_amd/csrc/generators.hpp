@@ -32,13 +32,13 @@ __global__ __launch_bounds__(THREADS) void pack_k(const i64 *__restrict__ rows,
                                                   const uint8_t *__restrict__ kinds, int kind_all,
                                                   int negate, i64 count, i64 m, i64 n, KeyLayout L,
                                                   u64 *__restrict__ keys, double *__restrict__ out,
-                                                  unsigned long long *__restrict__ err) {
+                                                  unsigned long long *__restrict__ err, i64 index_base) {
     const i64 g = (i64)blockIdx.x * THREADS + threadIdx.x;
     if (g >= count) return;
     const i64 r = rows[g], c = cols[g];
     int kind = kinds ? (int)kinds[g] : kind_all;
     if (!(1 <= r && r <= m && 1 <= c && c <= n) || kind < 0 || kind > 3) {
-        atomicMin(err, (unsigned long long)(g + 1));
+        atomicMin(err, (unsigned long long)(index_base + g + 1));  // first offending entry of the whole batch
         return;
     }
     double v = vals[g];

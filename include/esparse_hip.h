@@ -105,7 +105,10 @@ int32_t esp_key_layout(const esp_handle *h, int32_t *row_bits, int32_t *col_bits
 
 /* ---- append (replaces setindex!/updateindex!/rawupdateindex! on the buffer) -----
  * Host-fed: Julia fills a pinned chunk obtained from esp_stage_begin and commits it;
- * one ccall per chunk, not per entry.  kinds may be left untouched when kind_all>=0. */
+ * one ccall per chunk, not per entry.  kinds may be left untouched when kind_all>=0.
+ * The chunk pointers stay valid until esp_stage_begin is called with a larger `want` (or esp_destroy);
+ * no other call moves them (esp_append_host stages through an area of its own).  esp_commit returns
+ * when the chunk may be refilled. */
 int32_t esp_stage_begin(esp_handle *h, int64_t want, int64_t **rows, int64_t **cols,
                         double **vals, uint8_t **kinds, int64_t *got);
 int32_t esp_commit(esp_handle *h, int64_t count, int32_t kind_all, int32_t op);

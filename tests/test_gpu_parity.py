@@ -419,6 +419,35 @@ def test_bucket_kernel_tiers(esp, orc, per_col):
         assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
 
 
+def test_staged_pushes_around_a_bulk_append(esp, orc):
+    """Per-entry updates (staged in the caller's pinned chunk) before and after a bulk append that is larger
+    than that chunk: the bulk path has its own staging area, the caller's chunk pointers stay valid."""
+    rng = np.random.default_rng(88)
+    m, n = 500, 400
+    A = esp.ExtendableSparseMatrix(m, n)
+    O = orc.ExtendableSparseMatrix(m, n)
+    for i in range(100):
+        A.updateindex("+", 1.0 + i, 1 + i % m, 1 + (7 * i) % n)
+        O.updateindex(orc.OP_ADD, 1.0 + i, 1 + i % m, 1 + (7 * i) % n)
+    cnt = 300000
+    I = rng.integers(1, m + 1, cnt)
+    J = rng.integers(1, n + 1, cnt)
+    V = rng.standard_normal(cnt)
+    A.append(UPDATE, I, J, V)
+    O.apply(np.full(cnt, UPDATE, np.uint8), I, J, V)
+    for i in range(100):
+        A[1 + (3 * i) % m, 1 + i % n] = float(i)
+        O[1 + (3 * i) % m, 1 + i % n] = float(i)
+    assert_csc_equal(hip_arrays(A), O.arrays())
+    # an out-of-range entry in the middle of a bulk batch rejects the whole batch, nothing is committed
+    I2 = I.copy()
+    I2[cnt // 2] = m + 1
+    with pytest.raises((esp.BoundsError, IndexError)):
+        A.append(UPDATE, I2, J, V)
+    assert A.nnznew() == 0
+    assert_csc_equal(hip_arrays(A), O.arrays())
+
+
 def test_bucket_kernel_24_input_tier(esp, orc):
     """Column runs of exactly 20 entries: the first flush of a handle takes the LDS insertion tier, the
     following ones the kernel variant with the 24-input register tier (chosen from the longest run the
