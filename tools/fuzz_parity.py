@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Randomised parity fuzz (GPU): random shapes (incl. very tall matrices: many row bits), kinds, duplicate
+patterns, stream orders (sorted / clustered / shuffled), multi-flush sequences, both flush modes --
+every result compared bit for bit with the CPU oracle.  usage: tools/fuzz_parity.py [seconds] [seed]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+
+torch.cuda.init()
+from esparse_loader import load  # noqa: E402
+from oracle import oracle as orc  # noqa: E402
+from refmodel import assert_csc_equal  # noqa: E402
+
+esp = load()
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
+seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+rng = np.random.default_rng(seed)
+t_end = time.time() + budget
+cases = 0
+paths = {}
+while time.time() < t_end:
+    n = int(rng.choice([1, 3, 64, 257, 5000, 70000, 400000]))
+    m = int(rng.choice([1, 2, 100, 4097, 10 ** 6, 2 ** 31 - 1, 2 ** 33, 2 ** 40]))
+    A = esp.ExtendableSparseMatrix(m, n)
+    O = orc.ExtendableSparseMatrix(m, n)
+    force = int(rng.choice([0, 0, 0, 2, 3, 4, 5]))
+    A.debug_force_path(force)
+    nflush = int(rng.integers(1, 4))
+    for f in range(nflush):
+        cnt = int(rng.choice([0, 1, 50, 5000, 200000, 1500000]))
+        per_col = float(rng.choice([0.5, 5, 14, 22, 40, 300]))
+        ncols_used = max(1, min(n, int(cnt / per_col) + 1))
+        cols = rng.integers(1, n + 1, ncols_used)
+        J = cols[rng.integers(0, ncols_used, cnt)]
+        nrows_used = max(1, int(rng.choice([1, 3, 50, 10 ** 4, 10 ** 9])))
+        rowpool = rng.integers(1, m + 1, min(nrows_used, 10 ** 6))
+        I = rowpool[rng.integers(0, len(rowpool), cnt)]
+        order = rng.choice(["asis", "sorted", "clustered"])
+        if order == "sorted":
+            o = np.argsort(J, kind="stable")
+            I, J = I[o], J[o]
+        elif order == "clustered":
+            o = np.argsort(J // max(1, n // 64), kind="stable")
+            I, J = I[o], J[o]
+        kinds = rng.choice(np.array([0, 1, 1, 2], np.uint8), cnt)
+        V = np.where(rng.random(cnt) < 0.2, 0.0, rng.standard_normal(cnt))
+        V[rng.random(cnt) < 0.02] = -0.0
+        A.append(0, I, J, V, kinds=kinds)
+        O.apply(kinds, I, J, V)
+        A.flush()
+        O.flush()
+        key = (A.debug_last_path(), A.debug_last_partition())
+        paths[key] = paths.get(key, 0) + 1
+        try:
+            assert_csc_equal(A.sparse().arrays(), O.arrays())
+        except AssertionError:
+            print("MISMATCH seed", seed, "case", cases, dict(m=m, n=n, force=force, flush=f, cnt=cnt, per_col=per_col, order=str(order)))
+            raise
+    cases += 1
+print("fuzz ok: cases", cases, "paths (pipeline, partition):", paths)
