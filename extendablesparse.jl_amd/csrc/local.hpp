@@ -640,23 +640,28 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         // exclusive scan of the column counts (ncl <= 2048 -> <= 4 per thread) + longest run
         constexpr int PER = CL_MAX / THREADS;
         u32 v[PER];
-        u32 run = 0, mx = 0;
+        u32 run = 0, mx = 0, inc = 0;
+        // (a wave whose columns all lie past ncl -- 7 of 8 waves when a segment is 256 columns -- only
+        // reports zeros: the phase is bound by the instructions issued, not by the data)
+        const bool wave_has = (t & ~(ESP_WAVE - 1)) * PER < ncl;
+        if (wave_has) {
 #pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const int q = t * PER + j;
-            const u32 x = q < ncl ? ccnt[q] : 0;
-            mx = max(mx, x);
-            v[j] = run;
-            run += x;
+            for (int j = 0; j < PER; j++) {
+                const int q = t * PER + j;
+                const u32 x = q < ncl ? ccnt[q] : 0;
+                mx = max(mx, x);
+                v[j] = run;
+                run += x;
+            }
+            inc = run;
+#pragma unroll
+            for (int dlt = 1; dlt < ESP_WAVE; dlt <<= 1) {
+                const u32 o = __shfl_up(inc, dlt, ESP_WAVE);
+                if (lane >= dlt) inc += o;
+            }
+#pragma unroll
+            for (int dlt = 32; dlt > 0; dlt >>= 1) mx = max(mx, (u32)__shfl_xor((int)mx, dlt, ESP_WAVE));
         }
-        u32 inc = run;
-#pragma unroll
-        for (int dlt = 1; dlt < ESP_WAVE; dlt <<= 1) {
-            const u32 o = __shfl_up(inc, dlt, ESP_WAVE);
-            if (lane >= dlt) inc += o;
-        }
-#pragma unroll
-        for (int dlt = 32; dlt > 0; dlt >>= 1) mx = max(mx, (u32)__shfl_xor((int)mx, dlt, ESP_WAVE));
         if (lane == 63) lw[w] = inc;
         if (lane == 0) lw[8 + w] = mx;
         __syncthreads();
@@ -666,10 +671,12 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             if (i < w) base += lw[i];
             maxrun = max(maxrun, lw[8 + i]);
         }
+        if (wave_has) {
 #pragma unroll
-        for (int j = 0; j < PER; j++) {
-            const int q = t * PER + j;
-            if (q < ncl) ccnt[q] = base + v[j];
+            for (int j = 0; j < PER; j++) {
+                const int q = t * PER + j;
+                if (q < ncl) ccnt[q] = base + v[j];
+            }
         }
         if (t == 0) ccnt[ncl] = (u32)n;
         __syncthreads();
