@@ -7,23 +7,33 @@
 // HBM traffic: reads 16 B per appended entry once, writes 16 B per emitted entry once
 // (+ 8 B per non-empty column for the column-end marks).
 //
-// Structure
-//   load      : 8 B key + 8 B value per slot -> packed sort key in registers, value in LDS
-//   sort      : three tiers chosen per segment from the longest column run
-//                 <= 16 : counting sort by local column (LDS atomics, unordered inside a
-//                         column) + one lane per column sorting its run in REGISTERS with a
-//                         63-comparator merge-exchange network on (row, slot index)
-//                 <= 48 : same, insertion sort of the run in LDS
+// Structure (one workgroup = 512 threads = 8 waves per segment, 2 workgroups per CU: 64 KiB of LDS each)
+//   claim     : segments are claimed through an atomic ticket (start order = ticket order); the segment
+//               bounds around the expected ticket are fetched while the atomic is in flight
+//   load      : 8 B key + 8 B value per slot, all 16 loads of a thread in flight; branch-free transform
+//               to the packed sort key (bits below the segment prefix | slot index | kind) in registers,
+//               value to LDS.  PIECES variant (column shards): the segment is the concatenation of one
+//               piece per source rank, read in place from the receive buffers
+//   sort      : counting sort by local column (LDS atomics, unordered inside a column), then per column
+//               run, chosen per segment from the longest run:
+//                 <= 12 / 16 / 24 : one lane per column, the run in REGISTERS, merge-exchange network
+//                         of 42 / 63 / 132 compare-exchanges = v_min_f64 + v_max_f64 (keys < 2^62 order
+//                         like doubles); 24 lives in its own kernel instantiation (BIG)
+//                 <= 48 : insertion sort of the run in LDS
 //                 else  : stable 8-bit LSD radix on all remaining key bits (ballot ranking)
 //               the slot index is the append order, so every tier yields the stable order
-//   fold      : ordered left-to-right fold per (col,row) (espfold::fold_step), CSC hits are
-//               applied in place, misses become records
-//   compact   : records -> dense LDS prefix (ballot ranks), segment total
-//   look-back : decoupled look-back over the segment totals gives the global output offset
-//               (8-byte {flag,value} granules, relaxed agent-scope atomics both sides --
-//               MI355X L2s are per XCD; segments are claimed through a ticket so that every
-//               predecessor has started: no dispatch-order assumption; spins are bounded)
+//   fold      : ordered left-to-right fold per (col,row) (espfold::fold_step); CSC hits are applied in
+//               place (merge walk over the CSC column), misses become records.  Fresh matrix: the
+//               number of records is known right after the sort, so the segment total is published
+//               BEFORE the fold
+//   look-back : decoupled look-back over the segment totals gives the global output offset (8-byte
+//               {flag,value} granules, relaxed agent-scope atomics both sides -- MI355X L2s are per XCD;
+//               spins are bounded).  The last wave -- idle while one lane per column folds -- owns it and
+//               carries it across the following barriers: nothing before the final stores needs the
+//               offset
+//   compact   : records -> dense LDS prefix (ballot ranks)
 //   store     : coalesced stores of rowval/nzval (or key/val) + column-end marks
+// Bound: instruction issue and barrier latency at 4 waves per SIMD (128 VGPRs), not HBM bytes; see DESIGN.md.
 #pragma once
 #include "common.hpp"
 #include "fold.hpp"
