@@ -3,7 +3,7 @@
 # A maintainer of ExtendableSparse.jl adds this file next to src/matrix/sparsematrixlnk.jl and
 # `include`s it from src/ExtendableSparse.jl after line 32.  It plugs the device buffer into the
 # package's own extension slot (src/matrix/abstractsparsematrixextension.jl:6-14): nothing else in
-# the package changes.  NOT executed in the build container (no Julia there); kept under 150 lines.
+# the package changes.  NOT executed in the build container (no Julia there); kept short.
 
 const libesparse = get(ENV, "ESPARSE_HIP_LIB", "libesparse_hip.so")
 const ESP_SET, ESP_UPDATE, ESP_RAWUPDATE = Int32(0), Int32(1), Int32(2)
@@ -110,3 +110,69 @@ end
 # aliases in the style of src/ExtendableSparse.jl:34-39
 const HIPExtendableSparseMatrixCSC{Tv, Ti} = GenericExtendableSparseMatrixCSC{SparseMatrixHIPCOO{Tv, Ti}, Tv, Ti}
 const MTHIPExtendableSparseMatrixCSC{Tv, Ti} = GenericMTExtendableSparseMatrixCSC{SparseMatrixHIPCOO{Tv, Ti}, Tv, Ti}
+
+# ------------------------------------------------------------------------------------------------
+# North-star form (INTEGRATION.md): same fields and methods as ExtendableSparseMatrixCSC
+# (src/matrix/extendable.jl:10-25,159-272), but buffer AND CSC stay on the GPU between flushes; the
+# host copy is fetched on demand.  Every update goes to the device (no host findindex); esp_flush in
+# ROUTED mode applies updates of stored positions in call order (extendable.jl:164-166).
+const ESP_FLUSH_ROUTED = Int32(0)
+mutable struct HIPResidentSparseMatrixCSC{Tv, Ti <: Integer} <: AbstractExtendableSparseMatrixCSC{Tv, Ti}
+    buf::SparseMatrixHIPCOO{Tv, Ti}                     # in the role of lnkmatrix (handle + staging chunk)
+    cscmatrix::Union{SparseMatrixCSC{Tv, Ti}, Nothing}  # host copy, valid until the next update
+    phash::UInt64
+end
+HIPResidentSparseMatrixCSC{Float64, Int64}(m, n) =
+    HIPResidentSparseMatrixCSC{Float64, Int64}(SparseMatrixHIPCOO{Float64, Int64}(m, n), spzeros(Float64, Int64, m, n), 0)
+Base.size(A::HIPResidentSparseMatrixCSC) = size(A.buf)
+touch!(A::HIPResidentSparseMatrixCSC) = (A.cscmatrix = nothing; A)
+Base.setindex!(A::HIPResidentSparseMatrixCSC, v, i::Integer, j::Integer) = (setindex!(A.buf, v, i, j); touch!(A))
+updateindex!(A::HIPResidentSparseMatrixCSC, op, v, i, j) = (updateindex!(A.buf, op, v, i, j); touch!(A))
+rawupdateindex!(A::HIPResidentSparseMatrixCSC, op, v, i, j, part = 1) = (rawupdateindex!(A.buf, op, v, i, j); touch!(A))
+
+function flush!(A::HIPResidentSparseMatrixCSC)                       # extendable.jl:248-255
+    commit!(A.buf)
+    z, changed = Ref{Int64}(0), Ref{Int32}(0)
+    esp_check(A.buf.handle, ccall((:esp_flush, libesparse), Int32, (Ptr{Cvoid}, Int32, Ptr{Int64}, Ptr{Int32}),
+                                  A.buf.handle, ESP_FLUSH_ROUTED, z, changed))
+    if changed[] != 0                                                # the CSC was rebuilt: new pattern hash (:252)
+        hsh = Ref{UInt64}(0)
+        esp_check(A.buf.handle, ccall((:esp_pattern_hash, libesparse), Int32, (Ptr{Cvoid}, Ptr{UInt64}), A.buf.handle, hsh))
+        A.phash = hsh[]
+    end
+    A
+end
+
+function SparseArrays.sparse(A::HIPResidentSparseMatrixCSC{Float64, Int64})   # extendable.jl:258-261
+    flush!(A)
+    A.cscmatrix === nothing || return A.cscmatrix
+    h, (m, n) = A.buf.handle, size(A)
+    z = Ref{Int64}(0)
+    esp_check(h, ccall((:esp_nnz, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}), h, z))
+    colptr, rowval, nzval = Vector{Int64}(undef, n + 1), Vector{Int64}(undef, z[]), Vector{Float64}(undef, z[])
+    esp_check(h, ccall((:esp_get_csc, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}), h, colptr, rowval, nzval))
+    A.cscmatrix = SparseMatrixCSC{Float64, Int64}(m, n, colptr, rowval, nzval)
+end
+
+# consumers that never leave the GPU (SURVEY 8f): mul! sums every row in column order, like the column loop
+function LinearAlgebra.mul!(r::Vector{Float64}, A::HIPResidentSparseMatrixCSC{Float64, Int64}, x::Vector{Float64})
+    flush!(A)
+    esp_check(A.buf.handle, ccall((:esp_mul, libesparse), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int32), A.buf.handle, x, r, 0))
+    r
+end
+function mark_dirichlet(A::HIPResidentSparseMatrixCSC; penalty = 1.0e20)      # sparsematrixcsc.jl:94-108
+    flush!(A)
+    marker = zeros(Bool, size(A, 2))
+    esp_check(A.buf.handle, ccall((:esp_mark_dirichlet, libesparse), Int32, (Ptr{Cvoid}, Float64, Ptr{Bool}, Int32), A.buf.handle, penalty, marker, 0))
+    marker
+end
+function eliminate_dirichlet!(A::HIPResidentSparseMatrixCSC, marker::Vector{Bool})   # sparsematrixcsc.jl:121-144
+    flush!(A)
+    esp_check(A.buf.handle, ccall((:esp_eliminate_dirichlet, libesparse), Int32, (Ptr{Cvoid}, Ptr{Bool}, Int32), A.buf.handle, marker, 0))
+    touch!(A)
+end
+function reset!(A::HIPResidentSparseMatrixCSC)                                 # extendable.jl:269-272 (phash kept)
+    A.buf.nstaged = 0
+    esp_check(A.buf.handle, ccall((:esp_reset, libesparse), Int32, (Ptr{Cvoid},), A.buf.handle))
+    touch!(A)
+end
