@@ -539,11 +539,14 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         hi = n > 0 ? esp_uniform_u64(((((a.keys_in[beg] >> ESP_TAG_BITS) - a.base) >> a.rem_bits) << a.rem_bits) + a.base) : 0;
         // all 16 loads of a thread are issued before anything depends on them: the index is clamped so
         // that the loads need no branch (slots past the end re-read the last entry and are discarded)
+        // (an empty segment reads its predecessor's last entry instead -- or entry 0 -- and ignores it: one
+        // guard per load would cost two scalar instructions each)
+        const i64 lbeg = n > 0 ? beg : max(beg - 1, (i64)0);
         const int nlast = n > 0 ? n - 1 : 0;
 #pragma unroll
-        for (int i = 0; i < ITEMS; i++) k[i] = n > 0 ? a.keys_in[beg + min(wbase + i * ESP_WAVE, nlast)] : 0ull;
+        for (int i = 0; i < ITEMS; i++) k[i] = a.keys_in[lbeg + min(wbase + i * ESP_WAVE, nlast)];
 #pragma unroll
-        for (int i = 0; i < ITEMS; i++) vraw[i] = n > 0 ? a.vals_in[beg + min(wbase + i * ESP_WAVE, nlast)] : 0.0;
+        for (int i = 0; i < ITEMS; i++) vraw[i] = a.vals_in[lbeg + min(wbase + i * ESP_WAVE, nlast)];
     } else {
         // the segment's pieces, one per source rank (most segments of a slab-wise assembly have one)
         __shared__ i64 p_beg[MAX_PIECES];
@@ -622,7 +625,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         const u64 kk = ((rel & ~(u64)ESP_TAG_MASK) << IDX_BITS) | (u64)(u32)((p << ESP_TAG_BITS) | ((u32)key & (u32)ESP_TAG_MASK));
         k[i] = p < n ? kk : NOREC;  // NOREC sorts behind every real entry
     }
-    if (bad != 0) atomicOr(a.err, 2u);
+    if (bad != 0 && n > 0) atomicOr(a.err, 2u);
 #ifdef ESP_LOCAL_STAMPS
     if (a.stamps) { __syncthreads(); }
 #endif
