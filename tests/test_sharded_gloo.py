@@ -176,6 +176,15 @@ def _worker(rank, world, port, variant, q):
 @pytest.mark.parametrize("variant", ["slab/generic", "scrambled/generic", "slab/partitioned", "scrambled/partitioned",
                                      "scrambled/rank1_fails"])
 def test_shard_exchange_world2(variant):
+    _run_world(2, variant)
+
+
+def test_shard_exchange_world3_partitioned():
+    """three ranks: every rank exchanges with two others (not only with a neighbour)"""
+    _run_world(3, "scrambled/partitioned")
+
+
+def _run_world(world, variant):
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -183,7 +192,7 @@ def test_shard_exchange_world2(variant):
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, variant, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, variant, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
