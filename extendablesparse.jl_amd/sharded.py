@@ -46,6 +46,8 @@ def owner_ranges(n, P):
 # elements delivers only part of the data (measured on MI355X, tools: tests/test_gpu_parity.py
 # ::test_all_to_all_large_message).  The exchange is therefore issued in rounds of bounded size.
 A2A_MAX_ELEMS = 1 << 26
+# up to this many 8-byte words per rank the partitioned exchange packs counts, keys and values into one message
+ONE_MESSAGE_MAX_ELEMS = 1 << 23
 
 
 def all_to_all_v(dist, out, inp, out_splits, in_splits, group=None, max_elems=A2A_MAX_ELEMS, big=None):
@@ -346,26 +348,57 @@ class ShardedExtendableSparseMatrix:
         out_x = [int(M[q, 1 + me]) for q in range(P)]
         out_x[me] = 0
         own_lo, own_hi = int(eoff[me]), int(eoff[me + 1])
-        if sum(in_x):
-            skeys = torch.cat([keys[:own_lo], keys[own_hi:]])
-            svals = torch.cat([vals[:own_lo], vals[own_hi:]])
+        pairs = M[:, 1:].copy()
+        np.fill_diagonal(pairs, 0)
+        big = int(pairs.max()) if P > 1 else 0
+        # what the busiest rank sends or receives, in 8-byte words (same number on every rank)
+        busiest = int(max(pairs.sum(axis=1).max(), pairs.sum(axis=0).max())) * 2 + (P - 1) * nb if P > 1 else 0
+        if 1 < P and busiest <= ONE_MESSAGE_MAX_ELEMS and 2 * big + nb <= A2A_MAX_ELEMS // P:
+            # small exchange (a slab-wise assembly): counts, keys and values of one destination travel as ONE
+            # message [nb counts | keys | values]: one collective instead of three
+            parts, in_f = [], []
+            for r in range(P):
+                if r == me:
+                    in_f.append(0)
+                    continue
+                lo, hi = int(eoff[r]), int(eoff[r + 1])
+                parts += [cnts[r * nb:(r + 1) * nb], keys[lo:hi], vals[lo:hi].view(torch.int64)]
+                in_f.append(nb + 2 * (hi - lo))
+            out_f = [0 if q == me else nb + 2 * out_x[q] for q in range(P)]
+            sbuf = torch.cat(parts)
+            rbuf = be.empty(sum(out_f), torch.int64)
+            dist.all_to_all_single(rbuf, sbuf, out_f, in_f, group=self.group)
+            fo = np.concatenate([[0], np.cumsum(out_f)]).astype(np.int64)
+            rk, rv, rc = [], [], []
+            for q in range(P):
+                o, c = int(fo[q]), out_x[q]
+                if q == me:
+                    rk.append(rbuf[:0]), rv.append(rbuf[:0].view(torch.float64)), rc.append(rbuf[:0])
+                else:
+                    rc.append(rbuf[o:o + nb])
+                    rk.append(rbuf[o + nb:o + nb + c])
+                    rv.append(rbuf[o + nb + c:o + nb + 2 * c].view(torch.float64))
+            be.part_assemble(P, me, rk, rv, rc, out_x)
+            self.last_messages = 1
         else:
-            skeys, svals = keys[:0], vals[:0]
-        rkeys = be.empty(sum(out_x), torch.int64)
-        rvals = be.empty(sum(out_x), torch.float64)
-        rcnts = be.empty(P * nb, torch.int64)
-        if P > 1:
-            pairs = M[:, 1:].copy()
-            np.fill_diagonal(pairs, 0)
-            big = int(pairs.max())
-            all_to_all_v(dist, rkeys, skeys, out_x, in_x, self.group, big=big)
-            all_to_all_v(dist, rvals, svals, out_x, in_x, self.group, big=big)
-            dist.all_to_all_single(rcnts, cnts, group=self.group)   # nb counts to / from every rank
-        ro = np.concatenate([[0], np.cumsum(out_x)]).astype(np.int64)
-        be.part_assemble(P, me,
-                         [rkeys[ro[q]:ro[q + 1]] for q in range(P)],
-                         [rvals[ro[q]:ro[q + 1]] for q in range(P)],
-                         [rcnts[q * nb:(q + 1) * nb] for q in range(P)], out_x)
+            if sum(in_x):
+                skeys = torch.cat([keys[:own_lo], keys[own_hi:]])
+                svals = torch.cat([vals[:own_lo], vals[own_hi:]])
+            else:
+                skeys, svals = keys[:0], vals[:0]
+            rkeys = be.empty(sum(out_x), torch.int64)
+            rvals = be.empty(sum(out_x), torch.float64)
+            rcnts = be.empty(P * nb, torch.int64)
+            if P > 1:
+                all_to_all_v(dist, rkeys, skeys, out_x, in_x, self.group, big=big)
+                all_to_all_v(dist, rvals, svals, out_x, in_x, self.group, big=big)
+                dist.all_to_all_single(rcnts, cnts, group=self.group)   # nb counts to / from every rank
+            ro = np.concatenate([[0], np.cumsum(out_x)]).astype(np.int64)
+            be.part_assemble(P, me,
+                             [rkeys[ro[q]:ro[q + 1]] for q in range(P)],
+                             [rvals[ro[q]:ro[q + 1]] for q in range(P)],
+                             [rcnts[q * nb:(q + 1) * nb] for q in range(P)], out_x)
+            self.last_messages = 3
         self.exchanged = (int(sum(counts)), int(sum(out_x)) + int(counts[me]))
         self.sent_off_rank = int(sum(in_x))
         return True

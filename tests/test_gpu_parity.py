@@ -4,6 +4,8 @@ Integer structure (colptr/rowval) must match bit for bit; Float64 nzval must mat
 the sort is stable and the fold runs left to right, so the device reproduces the reference's
 accumulation order (the north star allows 2 ulp; the tests hold the stricter bar).
 """
+import sys
+
 import numpy as np
 import pytest
 
@@ -812,7 +814,7 @@ def test_coo_entries_mixed_with_updates(esp):
         assert_csc_equal(hip_arrays(A), M.arrays(), "round %d" % rnd)
 
 
-def _sharded_ranks_run(esp, orc, world, deal, n=44, rounds=2, overflow=False):
+def _sharded_ranks_run(esp, orc, world, deal, n=44, rounds=2, overflow=False, one_message=True):
     """W ranks as threads on one GPU (tests/threaddist.py): returns per-rank exchange kinds and checks
     the gathered CSC against ONE oracle buffer fed the ranks' streams in rank order."""
     from threaddist import run_ranks
@@ -870,7 +872,14 @@ def _sharded_ranks_run(esp, orc, world, deal, n=44, rounds=2, overflow=False):
         G = A.gather_sparse(0)
         return hist, (G.arrays() if rank == 0 else None), A.nnz()
 
-    outs = run_ranks(world, body)
+    shmod = sys.modules[esp.ShardedExtendableSparseMatrix.__module__]
+    keep = shmod.ONE_MESSAGE_MAX_ELEMS
+    if not one_message:
+        shmod.ONE_MESSAGE_MAX_ELEMS = 0   # counts, keys, values as three collectives (large exchanges)
+    try:
+        outs = run_ranks(world, body)
+    finally:
+        shmod.ONE_MESSAGE_MAX_ELEMS = keep
     # oracle: one buffer, the ranks' streams in rank order, flush after every round
     O = orc.ExtendableSparseMatrix(N, N)
     for rnd in range(rounds):
@@ -890,7 +899,7 @@ def test_partitioned_exchange_ranks_as_threads(esp, orc, world, deal):
     """The partitioned exchange with 2 and 3 source ranks per segment: one partition pass per rank,
     pieces assembled without a copy, bits equal to one buffer fed the ranks' streams in turn; second
     round = re-assembly over the existing CSC (hits applied in place through the pieces)."""
-    hist = _sharded_ranks_run(esp, orc, world, deal)
+    hist = _sharded_ranks_run(esp, orc, world, deal, one_message=(world == 2))
     for h in hist:
         assert h == [("partitioned", 7), ("partitioned", 7)], h
 

@@ -139,12 +139,17 @@ def _worker(rank, world, port, variant, q):
         kinds = np.where(np.arange(E) % 7 == 0, 2, 1).astype(np.uint8)   # mix UPDATE / RAWUPDATE
         be = CpuShardBackend(N, N, orc, esp)
         A = esp.ShardedExtendableSparseMatrix(N, N, be)
+        if mode == "partitioned3":   # counts, keys and values as three collectives (the path of large exchanges)
+            sys.modules[type(A).__module__].ONE_MESSAGE_MAX_ELEMS = 0
+            mode = "partitioned"
         A.partitioned = mode != "generic"
         be.fail_partition = mode == "rank1_fails" and rank == 1
         A.append(0, I[mine], J[mine], V[mine], kinds=kinds[mine])
         A.flush()
         # every rank takes the same exchange: the choice comes from all-gathered data
         assert A.last_exchange == ("partitioned" if mode == "partitioned" else "generic"), A.last_exchange
+        if mode == "partitioned":
+            assert A.last_messages == (3 if sys.modules[type(A).__module__].ONE_MESSAGE_MAX_ELEMS == 0 else 1)
         sent, recv = A.exchanged
         assert sent == int(mine.sum())
         # second round on the existing pattern plus new positions, to exercise hit + merge
@@ -174,7 +179,7 @@ def _worker(rank, world, port, variant, q):
 
 
 @pytest.mark.parametrize("variant", ["slab/generic", "scrambled/generic", "slab/partitioned", "scrambled/partitioned",
-                                     "scrambled/rank1_fails"])
+                                     "scrambled/partitioned3", "scrambled/rank1_fails"])
 def test_shard_exchange_world2(variant):
     _run_world(2, variant)
 
