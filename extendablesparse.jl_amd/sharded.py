@@ -13,7 +13,9 @@ Partitioned exchange (streams an assembly loop emits; `last_exchange == "partiti
        (esp_shard_partition, HIP, run-based single pass)
     2. all_gather of (applicable?, entries per owner)        -> every rank takes the same decision
     3. all_to_all of keys, values (ranges of the other owners; the own range is not touched) and of
-       the per-digit counts                                   (RCCL; per link: bytes_to_peer/153 GB/s)
+       the per-digit counts                                   (RCCL; per link: bytes_to_peer/153 GB/s);
+       a small exchange (slab-wise assembly) travels as ONE message per destination
+       [counts | keys | values]: one collective instead of three
     4. esp_shard_assemble: piece tables -- the bucket kernel reads a segment as the concatenation of
        one piece per source rank, straight from the receive buffers (nothing is copied or re-sorted)
     5. bucket kernel + colptr (unchanged), all_gather of the local nnz -> global colptr offsets
