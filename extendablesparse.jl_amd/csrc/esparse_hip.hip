@@ -81,7 +81,8 @@ struct esp_handle {
     DevBuf parttab, piecetab;
     // row-wise view of the device CSC for mul! (built on first use after a pattern change)
     unsigned long long pattern_version = 1, csr_version = 0;
-    DevBuf csr_rowptr, csr_perm, csr_col, csr_tmp, mul_x, mul_r;
+    unsigned long long values_version = 1, csr_val_version = 0;  // nzval changed / row-wise copy of the values
+    DevBuf csr_rowptr, csr_perm, csr_col, csr_tmp, csr_val, mul_x, mul_r;
     // timing
     bool timing = false;
     int timing_level = 2;
@@ -228,7 +229,7 @@ static int32_t init_empty_csc(esp_handle *h) {
     hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(h->n + 1, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p,
                        h->n + 1, (i64)1);
     h->nnz = 0;
-    h->pattern_version++;
+    h->pattern_version++, h->values_version++;
     h->csc_valid = true;
     return ESP_OK;
 }
@@ -286,7 +287,7 @@ extern "C" int32_t esp_destroy(esp_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     for (DevBuf *b : {&h->keys, &h->vals, &h->keys2, &h->vals2, &h->hist, &h->segs, &h->colend, &h->newkey,
                       &h->newval, &h->heads, &h->misc, &h->colptr, &h->rowval, &h->nzval, &h->rowval2,
-                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->runbuf, &h->chunkbuf, &h->parttab, &h->piecetab, &h->csr_rowptr, &h->csr_perm, &h->csr_col, &h->csr_tmp, &h->mul_x, &h->mul_r, &h->stage.d_rows, &h->stage.d_cols, &h->stage.d_vals, &h->stage.d_kinds, &h->bulk.d_rows, &h->bulk.d_cols, &h->bulk.d_vals, &h->bulk.d_kinds})
+                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->runbuf, &h->chunkbuf, &h->parttab, &h->piecetab, &h->csr_rowptr, &h->csr_perm, &h->csr_col, &h->csr_tmp, &h->csr_val, &h->mul_x, &h->mul_r, &h->stage.d_rows, &h->stage.d_cols, &h->stage.d_vals, &h->stage.d_kinds, &h->bulk.d_rows, &h->bulk.d_cols, &h->bulk.d_vals, &h->bulk.d_kinds})
         release(*b);
     for (esp_handle::StageArea *sa : {&h->stage, &h->bulk}) {
         if (sa->rows) (void)hipHostFree(sa->rows);
@@ -686,7 +687,7 @@ extern "C" int32_t esp_set_csc(esp_handle *h, const int64_t *colptr, const int64
     sp.add(3);
     HIPCK(h, hipStreamSynchronize(h->stream));
     h->nnz = nnz;
-    h->pattern_version++;
+    h->pattern_version++, h->values_version++;
     h->csc_valid = true;
     return ESP_OK;
 }
@@ -780,6 +781,7 @@ extern "C" int32_t esp_zero_values(esp_handle *h) {
     if (h->nnz == 0) return ESP_OK;
     (void)hipSetDevice(h->device);
     HIPCK(h, hipMemsetAsync(h->nzval.p, 0, sizeof(double) * (size_t)h->nnz, h->stream));
+    h->values_version++;
     return ESP_OK;
 }
 
@@ -820,7 +822,7 @@ extern "C" int32_t esp_dropzeros(esp_handle *h, int64_t *new_nnz) {
         std::swap(h->rowval, h->rowval2);
         std::swap(h->nzval, h->nzval2);
         h->nnz = Zk;
-        h->pattern_version++;
+        h->pattern_version++, h->values_version++;
     }
     if (new_nnz) *new_nnz = h->nnz;
     return ESP_OK;
@@ -1377,7 +1379,7 @@ static int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn, const u64 *new_key, con
         Span sp(h, ESP_ST_COLPTR);
         sp.add(espscan::exclusive<u64, true>(h->stream, colend, (u64 *)h->colptr.p, N1, colend + N1, (u64)1));
         h->nnz = Zn;
-        h->pattern_version++;
+        h->pattern_version++, h->values_version++;
         return ESP_OK;
     }
     const i64 Zt = Z0 + Zn;
@@ -1419,7 +1421,7 @@ static int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn, const u64 *new_key, con
     std::swap(h->rowval, h->rowval2);
     std::swap(h->nzval, h->nzval2);
     h->nnz = Zt;
-    h->pattern_version++;
+    h->pattern_version++, h->values_version++;
     return ESP_OK;
 }
 
@@ -1640,6 +1642,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
     if (!use_local && !h->part_assembled) CK(flush_global(h, mode, &Zn));
     h->last_path = (use_local || h->part_assembled) ? 1 : 2;
     if (Zn > 0 && pattern_changed) *pattern_changed = 1;
+    h->values_version++;  // (hits were applied in place)
     HIPCK(h, hipGetLastError());
     fused_reset(h);
     h->count = 0;
@@ -1879,14 +1882,20 @@ __global__ void csr_finish_k(const u64 *__restrict__ skey, const double *__restr
     if (k == Z - 1 || (skey[k + 1] >> ESP_TAG_BITS) != row) rowend[row + 1] = (u64)(k + 1);
 }
 // rowptr0 = exclusive-max-scanned row ends shifted by one: entries of row i = [rowptr0[i], rowptr0[i+1])
-__global__ __launch_bounds__(256) void spmv_rows_k(const u64 *__restrict__ rowptr0, const u32 *__restrict__ perm,
-                                                   const u32 *__restrict__ tcol, const double *__restrict__ nzval,
-                                                   const double *__restrict__ x, i64 m, double *__restrict__ r) {
+// row-wise copy of the values (refreshed when nzval changed: one gather per assembly, then every product
+// of a solver loop streams it)
+__global__ void csr_values_k(const u32 *__restrict__ perm, const double *__restrict__ nzval, i64 Z, double *__restrict__ rval) {
+    const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < Z) rval[k] = nzval[perm[k]];
+}
+__global__ __launch_bounds__(256) void spmv_rows_k(const u64 *__restrict__ rowptr0, const double *__restrict__ rval,
+                                                   const u32 *__restrict__ tcol, const double *__restrict__ x, i64 m,
+                                                   double *__restrict__ r) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= m) return;
     double acc = 0.0;  // r .= zero(eltype)
     const u64 b = rowptr0[i + 1], e = rowptr0[i + 2];
-    for (u64 k = b; k < e; k++) acc = acc + nzval[perm[k]] * x[tcol[k]];
+    for (u64 k = b; k < e; k++) acc = acc + rval[k] * x[tcol[k]];
     r[i] = acc;
 }
 
@@ -1955,7 +1964,16 @@ extern "C" int32_t esp_mul(esp_handle *h, const double *x, double *r, int32_t on
     if (h->count != 0) FAIL(h, ESP_ERR_STATE, "esp_mul: pending entries (flush first, like mul!(r, ext, x) does)");
     (void)hipSetDevice(h->device);
     if (!h->csc_valid) CK(init_empty_csc(h));
-    if (h->csr_version != h->pattern_version) CK(build_csr(h));
+    if (h->csr_version != h->pattern_version) {
+        CK(build_csr(h));
+        h->csr_val_version = 0;
+    }
+    if (h->csr_val_version != h->values_version && h->nnz > 0) {
+        CK(ensure(h, h->csr_val, sizeof(double) * (size_t)h->nnz));
+        hipLaunchKernelGGL(csr_values_k, dim3(grid_for(h->nnz, 256)), dim3(256), 0, h->stream, (const u32 *)h->csr_perm.p,
+                           (const double *)h->nzval.p, h->nnz, (double *)h->csr_val.p);
+        h->csr_val_version = h->values_version;
+    }
     const double *dx = x;
     double *dr = r;
     if (!on_device) {
@@ -1967,7 +1985,7 @@ extern "C" int32_t esp_mul(esp_handle *h, const double *x, double *r, int32_t on
     }
     if (h->m > 0)
         hipLaunchKernelGGL(spmv_rows_k, dim3(grid_for(h->m, 256)), dim3(256), 0, h->stream, (const u64 *)h->csr_rowptr.p,
-                           (const u32 *)h->csr_perm.p, (const u32 *)h->csr_col.p, (const double *)h->nzval.p, dx, h->m, dr);
+                           (const double *)h->csr_val.p, (const u32 *)h->csr_col.p, dx, h->m, dr);
     HIPCK(h, hipGetLastError());
     if (!on_device) HIPCK(h, hipMemcpyAsync(r, dr, sizeof(double) * (size_t)h->m, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
@@ -2018,6 +2036,7 @@ static int32_t dirichlet_call(esp_handle *h, uint8_t *marker, int32_t on_device,
         else
             hipLaunchKernelGGL(eliminate_dirichlet_k, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, (const i64 *)h->colptr.p,
                                (const i64 *)h->rowval.p, (double *)h->nzval.p, n, (const uint8_t *)dm);
+        if (!mark) h->values_version++;
     }
     HIPCK(h, hipGetLastError());
     if (!on_device && mark) HIPCK(h, hipMemcpyAsync(marker, dm, (size_t)n, hipMemcpyDeviceToHost, h->stream));
