@@ -53,6 +53,13 @@ struct esp_handle {
     int last_partition = 0;               // 1 = run-based single pass, 2 = 8-bit passes only
     // column window of the pending entries (whole matrix by default)
     u64 win_base = 0, win_span = 0;
+    // A shard works on its column range only.  When the window [wc0, wc1) (0-based columns) was
+    // declared on an empty matrix and kept since, no entry can lie outside it: the per-column work of a
+    // flush (colend clear, colptr scan) then runs over the window only -- with P shards the global colptr
+    // has P times the columns a shard owns.  colptr[c] = 1 for c <= wc0 always; the part behind the window
+    // (= nnz+1) is rewritten only when somebody needs the whole array (tail_stale).
+    i64 wc0 = 0, wc1 = 0;
+    bool win_excl = false, tail_stale = false;
     // device CSC (Julia layout) + spare set for rebuilds
     DevBuf colptr, rowval, nzval, rowval2, nzval2;
     i64 nnz = 0;
@@ -224,10 +231,36 @@ extern "C" const char *esp_version(void) { return "esparse-hip 0.1 (gfx950)"; }
 
 extern "C" const char *esp_last_error(const esp_handle *h) { return h ? h->err.c_str() : g_err.c_str(); }
 
+static inline bool windowed(const esp_handle *h) { return h->win_excl && (h->wc0 > 0 || h->wc1 < h->n); }
+// first entry and number of entries of the per-column arrays (colptr, colend: n+1 entries) a flush touches
+static inline void col_range(const esp_handle *h, i64 *c0, i64 *cnt) {
+    *c0 = windowed(h) ? h->wc0 : 0;
+    *cnt = windowed(h) ? h->wc1 - h->wc0 + 1 : h->n + 1;
+}
+// colptr behind the window := nnz+1, if it was left stale by windowed flushes
+static int32_t fix_tail(esp_handle *h) {
+    if (!h->tail_stale) return ESP_OK;
+    h->tail_stale = false;
+    const i64 from = h->wc1 + 1, cnt = h->n + 1 - from;
+    if (cnt > 0 && h->colptr.p)
+        hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(cnt, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p + from, cnt, h->nnz + 1);
+    HIPCK(h, hipGetLastError());
+    return ESP_OK;
+}
+
 static int32_t init_empty_csc(esp_handle *h) {
     CK(ensure(h, h->colptr, sizeof(i64) * (size_t)(h->n + 1)));
-    hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(h->n + 1, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p,
-                       h->n + 1, (i64)1);
+    if (h->csc_valid && windowed(h)) {
+        // every entry was inside the window: colptr is 1 up to it already, the part behind it is refreshed lazily
+        i64 c0, cnt;
+        col_range(h, &c0, &cnt);
+        hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(cnt, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p + c0, cnt, (i64)1);
+        h->tail_stale = h->wc1 < h->n;
+    } else {
+        hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(h->n + 1, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p,
+                           h->n + 1, (i64)1);
+        h->tail_stale = false;
+    }
     h->nnz = 0;
     h->pattern_version++, h->values_version++;
     h->csc_valid = true;
@@ -630,8 +663,13 @@ extern "C" int32_t esp_generate_fdrand(esp_handle *h, int64_t nx, int64_t ny, in
 extern "C" int32_t esp_set_column_window(esp_handle *h, int64_t col_lo, int64_t col_hi) {
     if (!h) return ESP_ERR_INVALID;
     if (col_lo < 1 || col_hi > h->n || col_lo > col_hi) FAIL(h, ESP_ERR_INVALID, "column window [%lld,%lld] outside 1..%lld", (long long)col_lo, (long long)col_hi, (long long)h->n);
+    (void)hipSetDevice(h->device);
+    CK(fix_tail(h));  // (with the old window)
     h->win_base = (u64)(col_lo - 1) << h->L.rb;
     h->win_span = (u64)(col_hi - col_lo + 1) << h->L.rb;
+    h->wc0 = col_lo - 1;
+    h->wc1 = col_hi;
+    h->win_excl = h->nnz == 0 && h->count == 0;  // nothing stored or pending outside it, and flushes enforce it from now on
     return ESP_OK;
 }
 
@@ -689,6 +727,8 @@ extern "C" int32_t esp_set_csc(esp_handle *h, const int64_t *colptr, const int64
     h->nnz = nnz;
     h->pattern_version++, h->values_version++;
     h->csc_valid = true;
+    h->win_excl = false;  // (the uploaded CSC may hold entries outside a declared window)
+    h->tail_stale = false;
     return ESP_OK;
 }
 
@@ -732,6 +772,7 @@ static int32_t d2h_pipelined(esp_handle *h, void *dst, const void *d_src, size_t
 extern "C" int32_t esp_get_csc(esp_handle *h, int64_t *colptr, int64_t *rowval, double *nzval) {
     if (!h || !colptr) return ESP_ERR_INVALID;
     (void)hipSetDevice(h->device);
+    CK(fix_tail(h));
     if (h->nnz > 0 && (!rowval || !nzval)) FAIL(h, ESP_ERR_INVALID, "esp_get_csc: rowval/nzval NULL with nnz>0");
     Span sp(h, ESP_ST_COPY);
     CK(d2h_pipelined(h, colptr, h->colptr.p, sizeof(i64) * (size_t)(h->n + 1)));
@@ -753,6 +794,8 @@ extern "C" int32_t esp_get_nzval(esp_handle *h, double *nzval) {
 
 extern "C" int32_t esp_csc_device(esp_handle *h, const int64_t **d_colptr, const int64_t **d_rowval, const double **d_nzval) {
     if (!h) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    CK(fix_tail(h));
     if (d_colptr) *d_colptr = (const i64 *)h->colptr.p;
     if (d_rowval) *d_rowval = (const i64 *)h->rowval.p;
     if (d_nzval) *d_nzval = (const double *)h->nzval.p;
@@ -796,6 +839,7 @@ static int32_t scan_inplace(esp_handle *h, T *data, i64 n, DevBuf &ws, int *laun
 extern "C" int32_t esp_dropzeros(esp_handle *h, int64_t *new_nnz) {
     if (!h) return ESP_ERR_INVALID;
     (void)hipSetDevice(h->device);
+    CK(fix_tail(h));
     const i64 Z = h->nnz;
     if (Z == 0) {
         if (new_nnz) *new_nnz = 0;
@@ -832,6 +876,7 @@ extern "C" int32_t esp_getindex(esp_handle *h, int64_t i, int64_t j, double *val
     if (!h || !value) return ESP_ERR_INVALID;
     if (!(1 <= i && i <= h->m && 1 <= j && j <= h->n)) FAIL(h, ESP_ERR_BOUNDS, "BoundsError: (%lld,%lld) outside %lld x %lld", (long long)i, (long long)j, (long long)h->m, (long long)h->n);
     (void)hipSetDevice(h->device);
+    CK(fix_tail(h));
     CK(ensure(h, h->misc, 256));
     espfold::Csc c{(const i64 *)h->colptr.p, (const i64 *)h->rowval.p, (double *)h->nzval.p, h->nnz};
     double *d_out = (double *)h->misc.p + 8;
@@ -847,6 +892,7 @@ extern "C" int32_t esp_getindex(esp_handle *h, int64_t i, int64_t j, double *val
 extern "C" int32_t esp_pattern_hash(esp_handle *h, uint64_t *hash) {
     if (!h || !hash) return ESP_ERR_INVALID;
     (void)hipSetDevice(h->device);
+    CK(fix_tail(h));
     CK(ensure(h, h->misc, 256));
     unsigned long long *acc = (unsigned long long *)h->misc.p + 16;
     HIPCK(h, hipMemsetAsync(acc, 0, 16, h->stream));
@@ -1374,10 +1420,13 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
 static int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn, const u64 *new_key, const double *new_val) {
     const i64 N1 = h->n + 1;
     u64 *colend = (u64 *)h->colend.p;
+    i64 c0, ccnt;  // the columns this flush can have touched (a shard's window, else all)
+    col_range(h, &c0, &ccnt);
+    if (windowed(h)) h->tail_stale = h->wc1 < h->n;
     if (Z0 == 0) {
         // colptr = 1 + exclusive max-scan of the column ends, written by the scan's last pass
         Span sp(h, ESP_ST_COLPTR);
-        sp.add(espscan::exclusive<u64, true>(h->stream, colend, (u64 *)h->colptr.p, N1, colend + N1, (u64)1));
+        sp.add(espscan::exclusive<u64, true>(h->stream, colend + c0, (u64 *)h->colptr.p + c0, ccnt, colend + N1, (u64)1));
         h->nnz = Zn;
         h->pattern_version++, h->values_version++;
         return ESP_OK;
@@ -1386,12 +1435,13 @@ static int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn, const u64 *new_key, con
     if (Z0 >= 0xFFFFFFF0ll) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_flush: CSC too large for the 32-bit column index");
     {
         Span sp(h, ESP_ST_COLPTR);
-        sp.add(espscan::exclusive<u64, true>(h->stream, colend, colend, N1, colend + N1));
+        sp.add(espscan::exclusive<u64, true>(h->stream, colend + c0, colend + c0, ccnt, colend + N1));
         const i64 hn = Z0 + 1;  // column index of every stored entry
         CK(ensure(h, h->heads, sizeof(u32) * (size_t)(hn + espscan::workspace_elems(hn))));
         u32 *heads = (u32 *)h->heads.p;
         HIPCK(h, hipMemsetAsync(heads, 0, sizeof(u32) * (size_t)hn, h->stream));
-        hipLaunchKernelGGL(espfold::col_heads_k, dim3(grid_for(h->n, 256)), dim3(256), 0, h->stream, (const i64 *)h->colptr.p, h->n, heads);
+        hipLaunchKernelGGL(espfold::col_heads_k, dim3(grid_for(ccnt - 1, 256)), dim3(256), 0, h->stream, (const i64 *)h->colptr.p, c0, ccnt - 1,
+                           heads);
         sp.add(1 + espscan::exclusive<u32, true>(h->stream, heads, heads, hn, heads + hn));
     }
     CK(ensure(h, h->rowval2, sizeof(i64) * (size_t)Zt));
@@ -1414,8 +1464,8 @@ static int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn, const u64 *new_key, con
     }
     {
         Span sp(h, ESP_ST_COLPTR);
-        hipLaunchKernelGGL(espfold::colptr_finish_k, dim3(grid_for(N1, 256)), dim3(256), 0, h->stream, (const u64 *)colend,
-                           (const i64 *)h->colptr.p, N1, (i64 *)h->colptr.p);
+        hipLaunchKernelGGL(espfold::colptr_finish_k, dim3(grid_for(ccnt, 256)), dim3(256), 0, h->stream, (const u64 *)colend + c0,
+                           (const i64 *)h->colptr.p + c0, ccnt, (i64 *)h->colptr.p + c0);
         sp.add(1);
     }
     std::swap(h->rowval, h->rowval2);
@@ -1451,7 +1501,11 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     u64 *status = (u64 *)h->segout.p;
     HIPCK(h, hipMemsetAsync(status, 0, sizeof(u64) * (size_t)(S + 2), h->stream));
     CK(ensure(h, h->colend, sizeof(u64) * (size_t)(N1 + espscan::workspace_elems(N1))));
-    HIPCK(h, hipMemsetAsync(h->colend.p, 0, sizeof(u64) * (size_t)N1, h->stream));
+    {
+        i64 c0, cnt;
+        col_range(h, &c0, &cnt);
+        HIPCK(h, hipMemsetAsync((u64 *)h->colend.p + c0, 0, sizeof(u64) * (size_t)cnt, h->stream));
+    }
     esplocal::Args a;
     {
         Span sp(h, ESP_ST_LOCAL);
@@ -1964,6 +2018,7 @@ extern "C" int32_t esp_mul(esp_handle *h, const double *x, double *r, int32_t on
     if (h->count != 0) FAIL(h, ESP_ERR_STATE, "esp_mul: pending entries (flush first, like mul!(r, ext, x) does)");
     (void)hipSetDevice(h->device);
     if (!h->csc_valid) CK(init_empty_csc(h));
+    CK(fix_tail(h));
     if (h->csr_version != h->pattern_version) {
         CK(build_csr(h));
         h->csr_val_version = 0;
@@ -2022,6 +2077,7 @@ static int32_t dirichlet_call(esp_handle *h, uint8_t *marker, int32_t on_device,
     if (h->count != 0) FAIL(h, ESP_ERR_STATE, "dirichlet: pending entries (flush first)");
     (void)hipSetDevice(h->device);
     if (!h->csc_valid) CK(init_empty_csc(h));
+    CK(fix_tail(h));
     const i64 n = h->n;
     uint8_t *dm = marker;
     if (!on_device) {

@@ -152,9 +152,10 @@ __global__ void colptr_finish_k(const u64 *__restrict__ scanned, const i64 *__re
 
 // column index of every stored entry: heads[start(c)] = c for non-empty columns, then an
 // exclusive max-scan over Z+1 slots gives colidx[p] at scanned[p+1]
-__global__ void col_heads_k(const i64 *__restrict__ colptr, i64 n, u32 *__restrict__ heads) {
-    const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n) return;
+// (columns [c0, c0+n): a shard's window, else all)
+__global__ void col_heads_k(const i64 *__restrict__ colptr, i64 c0, i64 n, u32 *__restrict__ heads) {
+    const i64 c = c0 + (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= c0 + n) return;
     const i64 a = colptr[c] - 1, b = colptr[c + 1] - 1;
     if (b > a) heads[a] = (u32)c;
 }

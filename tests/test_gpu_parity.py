@@ -940,6 +940,27 @@ def test_column_window(esp, orc):
     A.append(UPDATE, [1] * 5000, [hi + 1] * 5000, [1.0] * 5000)   # outside the window
     with pytest.raises(esp.EspError):
         A.flush()
+    # reset! keeps the window: per-column work stays inside it, the rest of colptr is refreshed on demand
+    A.reset()
+    O.reset()
+    for rnd in range(2):
+        V2 = rng.standard_normal(cnt)
+        A.append(UPDATE, I, J, V2)
+        O.apply(np.full(cnt, UPDATE, np.uint8), I, J, V2)
+        A.flush()
+        assert A[int(I[0]), int(J[0])] == O[int(I[0]), int(J[0])]          # (getindex reads colptr)
+        assert_csc_equal(hip_arrays(A), O.arrays())
+    # a window declared on a matrix that already holds entries elsewhere only restricts the pending ones
+    B = esp.ExtendableSparseMatrix(m, n)
+    OB = orc.ExtendableSparseMatrix(m, n)
+    Jall = rng.integers(1, n + 1, cnt)
+    B.append(UPDATE, I, Jall, V)
+    OB.apply(np.full(cnt, UPDATE, np.uint8), I, Jall, V)
+    B.flush()
+    B.set_column_window(lo, hi)
+    B.append(UPDATE, I, J, V)
+    OB.apply(np.full(cnt, UPDATE, np.uint8), I, J, V)
+    assert_csc_equal(hip_arrays(B), OB.arrays())
 
 
 def test_generate_fdrand_range_halves(esp, orc):
