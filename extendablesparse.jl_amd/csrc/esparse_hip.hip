@@ -287,6 +287,8 @@ extern "C" int32_t esp_create(int64_t m, int64_t n, int32_t device, int64_t capa
     h->L = KeyLayout{rb, cb};
     h->win_base = 0;
     h->win_span = (u64)std::max<i64>(n, 1) << rb;
+    h->wc0 = 0;
+    h->wc1 = n;
     h->hint = capacity_hint > 0 ? capacity_hint : 0;
     memset(&h->acc, 0, sizeof h->acc);
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
