@@ -126,18 +126,61 @@ constexpr int MAX_PIECES = 64;
 
 // Stable LSD radix tail on the packed keys held in registers (wave-striped arrangement):
 // sorts on bits [SUB_SHIFT, SUB_SHIFT+rem_bits); result in k[] and skey[].
-__device__ __forceinline__ void radix_tail(u64 (&k)[ITEMS], u64 *skey, u32 (*cnt)[256], u32 *lw, int rem_bits, int t,
-                                           int lane, int w, int wbase) {
+// Only the key bits in which the segment's entries actually DIFFER are sorted: (col,row) keys of one
+// segment usually agree in a block of middle bits (rows near the diagonal: the high row bits), and a
+// digit may be put together from two runs of varying bits, so such a block costs no pass.  Returns the
+// number of passes (0: all entries share one (col,row); skey is not written then).
+__device__ __forceinline__ int radix_tail(u64 (&k)[ITEMS], u64 *skey, u32 (*cnt)[256], u32 *lw, int rem_bits, int t, int lane,
+                                          int w, int wbase, int n, u64 *scratch /* 2*WAVES words */) {
     const u64 lt = (1ull << lane) - 1ull;
-    for (int shift = SUB_SHIFT; shift < SUB_SHIFT + rem_bits; shift += 8) {
-        const int bits = min(8, SUB_SHIFT + rem_bits - shift);
-        const u32 dmask = (1u << bits) - 1u;
+    // varying bits = AND ^ OR over the real entries
+    u64 vand = ~0ull, vor = 0ull;
+#pragma unroll
+    for (int i = 0; i < ITEMS; i++) {
+        const bool real = wbase + i * ESP_WAVE < n;
+        vand &= real ? k[i] : ~0ull;
+        vor |= real ? k[i] : 0ull;
+    }
+#pragma unroll
+    for (int dlt = 32; dlt > 0; dlt >>= 1) {
+        vand &= __shfl_xor(vand, dlt, ESP_WAVE);
+        vor |= __shfl_xor(vor, dlt, ESP_WAVE);
+    }
+    if (lane == 0) {
+        scratch[w] = vand;
+        scratch[WAVES + w] = vor;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < WAVES; i++) {
+        vand &= scratch[i];
+        vor |= scratch[WAVES + i];
+    }
+    const u64 sortmask = rem_bits >= 64 - SUB_SHIFT ? ~0ull : (((u64)1 << rem_bits) - 1ull);
+    u64 rest = ((vand ^ vor) >> SUB_SHIFT) & sortmask;  // bit j: key bit SUB_SHIFT + j varies
+    int npass = 0;
+    while (rest) {
+        // a digit of up to 8 bits from the lowest one or two runs of varying bits (A below B)
+        const int sA = __builtin_ctzll(rest);
+        const int lenA = (int)__builtin_ctzll(~(rest >> sA) | ((u64)1 << 63));
+        const int bA = min(lenA, 8);
+        rest &= ~((((u64)1 << bA) - 1ull) << sA);
+        int sB = 0, bB = 0;
+        if (bA < 8 && rest) {
+            sB = __builtin_ctzll(rest);
+            const int lenB = (int)__builtin_ctzll(~(rest >> sB) | ((u64)1 << 63));
+            bB = min(lenB, 8 - bA);
+            rest &= ~((((u64)1 << bB) - 1ull) << sB);
+        }
+        const int shA = SUB_SHIFT + sA, shB = SUB_SHIFT + sB;
+        const u32 mA = (1u << bA) - 1u, mB = (1u << bB) - 1u;
+        npass++;
         for (int q = t; q < WAVES * 256; q += THREADS) (&cnt[0][0])[q] = 0;
         __syncthreads();
         unsigned short rank[ITEMS];
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
-            const u32 d = (u32)(k[i] >> shift) & dmask;
+            const u32 d = ((u32)(k[i] >> shA) & mA) | (((u32)(k[i] >> shB) & mB) << bA);
             u64 m = ~0ull;
 #pragma unroll
             for (int b = 0; b < 8; b++) {
@@ -181,13 +224,14 @@ __device__ __forceinline__ void radix_tail(u64 (&k)[ITEMS], u64 *skey, u32 (*cnt
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
-            const u32 d = (u32)(k[i] >> shift) & dmask;
+            const u32 d = ((u32)(k[i] >> shA) & mA) | (((u32)(k[i] >> shB) & mB) << bA);
             skey[cnt[w][d] + rank[i]] = k[i];
         }
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) k[i] = skey[wbase + i * ESP_WAVE];
     }
+    return npass;
 }
 
 // closes one (col,row) group of a column run: CSC hit -> in place, miss -> record at skey[rs+e]
@@ -760,61 +804,82 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
 
     if (!done) {
         // ---- radix tier (long runs / wide column ranges): stable LSD sort of all remaining bits
-        radix_tail(k, skey, cnt, lw, a.rem_bits, t, lane, w, wbase);
-        if (a.rem_bits <= 0) {
+        const int npass = radix_tail(k, skey, cnt, lw, a.rem_bits, t, lane, w, wbase, n, reinterpret_cast<u64 *>(s_win));
+        if (npass == 0) {
 #pragma unroll
             for (int i = 0; i < ITEMS; i++) skey[wbase + i * ESP_WAVE] = k[i];
         }
         __syncthreads();
-        // ordered fold: run heads walk their run in LDS (append order inside a run)
-        bool emit[ITEMS];
-        double acc[ITEMS];
+#ifdef ESP_LOCAL_STAMPS
+        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 12] = wall_clock64();
+#endif
+        // ---- ordered fold, one (col,row) group per thread.  The walk of a group is sequential (append
+        // order); with one thread per GROUP the phase takes as long as the longest group, not 8 x as long
+        // (a thread that owns 8 slots walked up to 8 groups one after the other, and every wave waited for
+        // its longest walk each time -- FEM diagonals hold ~50 duplicates).  Group heads are numbered by a
+        // ballot scan over the slots; the list of head positions sits in the radix counters' storage.
+        unsigned short *ghead = reinterpret_cast<unsigned short *>(cntraw);  // <= CAP heads (+1 end mark)
+        static_assert(sizeof(cntraw) >= (CAP + 1) * sizeof(unsigned short), "head list fits the counter storage");
+        bool ishead[ITEMS];
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) {
             const int q = wbase + i * ESP_WAVE;
-            emit[i] = false;
-            acc[i] = 0.0;
-            if (q < n) {
-                const u64 sub = k[i] >> SUB_SHIFT;
-                const bool head = q == 0 || (skey[q - 1] >> SUB_SHIFT) != sub;
-                if (head) {
-                    const u64 full = hi + sub;
-                    i64 pos = -1;
-                    if (a.csc.nnz > 0) pos = espfold::csc_find(a.csc, (i64)(full >> a.rb), (i64)(full & rowmask));
-                    bool present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
-                    double x = present ? a.csc.nzval[pos] : 0.0;
-                    for (int j = q; j < n; j++) {
-                        const u64 kj = skey[j];
-                        if ((kj >> SUB_SHIFT) != sub) break;
-                        espfold::fold_step(present, x, (u32)(kj & ESP_TAG_MASK), sval[(kj >> ESP_TAG_BITS) & (CAP - 1)]);
-                    }
-                    if (pos >= 0) {
-                        if (a.mode == ESP_FLUSH_ROUTED)
-                            a.csc.nzval[pos] = x;
-                        else if (present)
-                            a.csc.nzval[pos] = a.csc.nzval[pos] + x;
-                    } else if (present) {
-                        emit[i] = true;
-                        acc[i] = x;
-                    }
-                }
-            }
+            ishead[i] = q < n && (q == 0 || (skey[q - 1] >> SUB_SHIFT) != (k[i] >> SUB_SHIFT));
+            const u64 bal = __ballot(ishead[i]);
+            if (lane == 0) gcount[w * ITEMS + i] = (u32)__popcll(bal);
         }
-        __syncthreads();  // every walk is finished: slots can be rewritten as records
+        __syncthreads();
+        {
+            const u32 c = gcount[lane];  // (WAVES * ITEMS == 64 groups of slots: every wave scans them itself)
+            u32 inc = c;
 #pragma unroll
-        for (int i = 0; i < ITEMS; i++) {
-            const int q = wbase + i * ESP_WAVE;
-            if (q < n) {
-                if (emit[i]) {
-                    const u32 idx0 = (u32)(k[i] >> ESP_TAG_BITS) & (CAP - 1);
-                    skey[q] = (k[i] >> SUB_SHIFT << SUB_SHIFT) | ((u64)idx0 << ESP_TAG_BITS);
-                    sval[idx0] = acc[i];
-                } else {
-                    skey[q] = NOREC;
+            for (int dlt = 1; dlt < ESP_WAVE; dlt <<= 1) {
+                const u32 o = __shfl_up(inc, dlt, ESP_WAVE);
+                if (lane >= dlt) inc += o;
+            }
+            const u32 exc = inc - c;
+            const int G = (int)__shfl((int)inc, 63, ESP_WAVE);
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) {
+                const u64 bal = __ballot(ishead[i]);
+                const u32 gb = (u32)__shfl((int)exc, w * ITEMS + i, ESP_WAVE);
+                if (ishead[i]) ghead[gb + (u32)__popcll(bal & lt)] = (unsigned short)(wbase + i * ESP_WAVE);
+            }
+            if (t == 0) ghead[G] = (unsigned short)n;
+            __syncthreads();
+            for (int g = t; g < G; g += THREADS) {
+                const int q0 = ghead[g], q1 = ghead[g + 1];
+                const u64 k0 = skey[q0];
+                const u64 sub = k0 >> SUB_SHIFT;
+                const u64 full = hi + sub;
+                i64 pos = -1;
+                if (a.csc.nnz > 0) pos = espfold::csc_find(a.csc, (i64)(full >> a.rb), (i64)(full & rowmask));
+                bool present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
+                double x = present ? a.csc.nzval[pos] : 0.0;
+                for (int j = q0; j < q1; j++) {
+                    const u64 kj = skey[j];
+                    espfold::fold_step(present, x, (u32)(kj & ESP_TAG_MASK), sval[(kj >> ESP_TAG_BITS) & (CAP - 1)]);
                 }
+                // the group's slots belong to this thread alone: the record (or nothing) replaces them
+                bool emit = false;
+                if (pos >= 0) {
+                    if (a.mode == ESP_FLUSH_ROUTED)
+                        a.csc.nzval[pos] = x;
+                    else if (present)
+                        a.csc.nzval[pos] = a.csc.nzval[pos] + x;
+                } else if (present) {
+                    emit = true;
+                }
+                const u32 idx0 = (u32)(k0 >> ESP_TAG_BITS) & (CAP - 1);
+                skey[q0] = emit ? ((k0 >> SUB_SHIFT << SUB_SHIFT) | ((u64)idx0 << ESP_TAG_BITS)) : NOREC;
+                if (emit) sval[idx0] = x;
+                for (int j = q0 + 1; j < q1; j++) skey[j] = NOREC;
             }
         }
         __syncthreads();
+#ifdef ESP_LOCAL_STAMPS
+        if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 13] = wall_clock64();
+#endif
     }
 #ifdef ESP_LOCAL_STAMPS
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 4] = wall_clock64();

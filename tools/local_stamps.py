@@ -13,12 +13,16 @@ torch.cuda.init()
 from esparse_loader import load  # noqa: E402
 
 esp = load()
+fem = int(os.environ.get("ESP_STAMP_FEM", "0"))   # e.g. 120: P1 FEM 3-D on 120^3 nodes instead of the stencil
 n = 256
-N = n ** 3
-A = esp.ExtendableSparseMatrix(N, N, capacity_hint=12 * n * n * (n - 1) + 6 * n * n)
+N = fem ** 3 if fem else n ** 3
+A = esp.ExtendableSparseMatrix(N, N, capacity_hint=0 if fem else 12 * n * n * (n - 1) + 6 * n * n)
 for it in range(3):
     A.reset()
-    A.generate_fdrand(n, n, n, rand_mode=1)
+    if fem:
+        A.generate_fem(3, fem, seed=4, order_mode=1)
+    else:
+        A.generate_fdrand(n, n, n, rand_mode=1)
     if it == 2:
         os.environ["ESP_LOCAL_STAMPS"] = "gpurun_out/stamps.bin"
     A.flush()
@@ -37,5 +41,9 @@ print("kernel span %.1f us, %.0f segments resident on average" % (span, (st[:, 7
 if st16[:, 8].any():
     for nm, a, b in (("sort + count (wave 0)", 3, 8), ("barrier wait", 8, 9), ("fold (wave 0)", 9, 10),
                      ("look-back (last wave)", 9, 11), ("phase end after fold", 10, 4), ("phase end after look-back", 11, 4)):
+        x = (st16[:, b] - st16[:, a]) * 0.01
+        print("  %-28s median %6.2f  p90 %6.2f" % (nm, np.median(x), np.percentile(x, 90)))
+if st16[:, 12].any():   # radix tier: 2 = counts scanned, 12 = radix sort done, 13 = fold walks done, 4 = records written
+    for nm, a, b in (("radix sort", 2, 12), ("fold walks", 12, 13), ("records", 13, 4)):
         x = (st16[:, b] - st16[:, a]) * 0.01
         print("  %-28s median %6.2f  p90 %6.2f" % (nm, np.median(x), np.percentile(x, 90)))
