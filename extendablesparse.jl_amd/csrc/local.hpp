@@ -19,8 +19,8 @@
 //                 <= 12 / 16 / 24 : one lane per column, the run in REGISTERS, merge-exchange network
 //                         of 42 / 63 / 132 compare-exchanges = v_min_f64 + v_max_f64 (keys < 2^62 order
 //                         like doubles); 24 lives in its own kernel instantiation (BIG)
-//                 <= 48 : insertion sort of the run in LDS
-//                 else  : stable 8-bit LSD radix on all remaining key bits (ballot ranking)
+//                 else  : stable 8-bit LSD radix on the varying key bits (ballot ranking), then a fold with
+//                         one (col,row) group per thread
 //               the slot index is the append order, so every tier yields the stable order
 //   fold      : ordered left-to-right fold per (col,row) (espfold::fold_step); CSC hits are applied in
 //               place (merge walk over the CSC column), misses become records.  Fresh matrix: the
@@ -53,7 +53,6 @@ constexpr int CL_MAX_BITS = 11;  // up to 2048 local columns counted in LDS
 constexpr int CL_MAX = 1 << CL_MAX_BITS;
 constexpr int REG_RUN = 24;   // longest column run sorted in registers
 constexpr int REG_MAX_REM = 62 - SUB_SHIFT;  // ... when the packed sort keys stay below 2^62 (see load_sorted_run)
-constexpr int RANK_MAX = 48;  // longest column run sorted by LDS insertion
 constexpr u64 NOREC = ~0ull;
 
 // look-back status granule: [63:62] flag, [61:0] value
@@ -741,7 +740,11 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 2] = wall_clock64();
 #endif
         if (a.stop_after == 2) done = true;
-        if (!done && maxrun <= RANK_MAX) {
+        // longer runs go to the radix tier (measured: from 25 entries per column on it beats an insertion sort of
+        // the run by its lane 2.5 to 4 times; the insertion tier is gone)
+        const int reg_max = BIG ? REG_RUN : 16;
+        if (t == 0 && maxrun > 16) atomicMax(a.maxrun_seen, maxrun);  // (tells the host which kernel variant suits this matrix)
+        if (!done && maxrun <= reg_max && a.rem_bits <= REG_MAX_REM) {
 #pragma unroll
             for (int i = 0; i < ITEMS; i++)
                 if (wbase + i * ESP_WAVE < n) skey[ccnt[(u32)(k[i] >> csh)] + slot[i]] = k[i];
@@ -750,7 +753,6 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 3] = wall_clock64();
 #endif
             if (a.stop_after == 3) done = true;
-            if (t == 0 && maxrun > 16) atomicMax(a.maxrun_seen, maxrun);  // (tells the host which kernel variant suits this matrix)
             if (!done && maxrun <= (BIG ? REG_RUN : 16) && a.rem_bits <= REG_MAX_REM) {
                 // one lane per column: the whole run in registers, sorting network + ordered fold; the
                 // network is sized to the longest run of the segment (12 covers a 7-point stencil)
@@ -760,42 +762,6 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
                     lb_done = reg_tier<16, FRESH>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
                 else if constexpr (BIG)
                     lb_done = reg_tier<REG_RUN, FRESH>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
-                done = true;
-            } else if (!done) {
-                for (int c = t; c < ncl; c += THREADS) {
-                    const int rs = (int)ccnt[c], re = (int)ccnt[c + 1];
-                    for (int p = rs + 1; p < re; p++) {  // insertion sort, keys are unique
-                        const u64 x = skey[p];
-                        int q = p - 1;
-                        while (q >= rs) {
-                            const u64 y = skey[q];
-                            if (y < x) break;
-                            skey[q + 1] = y;
-                            q--;
-                        }
-                        skey[q + 1] = x;
-                    }
-                    int e = 0, j = rs;
-                    u64 kj = j < re ? skey[j] : 0;
-                    while (j < re) {
-                        const u64 sub = kj >> SUB_SHIFT;
-                        const u32 idx0 = (u32)(kj >> ESP_TAG_BITS) & (CAP - 1);
-                        i64 pos = -1;
-                        if (a.csc.nnz > 0) {
-                            const u64 full = hi + sub;
-                            pos = espfold::csc_find(a.csc, (i64)(full >> a.rb), (i64)(full & rowmask));
-                        }
-                        bool present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
-                        double x = present ? a.csc.nzval[pos] : 0.0;
-                        do {
-                            espfold::fold_step(present, x, (u32)(kj & ESP_TAG_MASK), sval[(kj >> ESP_TAG_BITS) & (CAP - 1)]);
-                            j++;
-                            if (j < re) kj = skey[j];
-                        } while (j < re && (kj >> SUB_SHIFT) == sub);
-                        close_group(a, skey, sval, rs, e, pos, present, x, sub, idx0);
-                    }
-                    for (int q = rs + e; q < re; q++) skey[q] = NOREC;
-                }
                 done = true;
             }
         }

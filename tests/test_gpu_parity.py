@@ -399,8 +399,9 @@ def test_bucket_kernel_many_launches(esp, orc):
 
 @pytest.mark.parametrize("per_col", [6, 30, 200])
 def test_bucket_kernel_tiers(esp, orc, per_col):
-    """Column runs of ~6 (register sorting network), ~30 (LDS insertion) and ~200 (radix tail)
-    entries, with duplicates and SET/zero entries, all through the LDS bucket kernel."""
+    """Column runs of ~6 (register sorting network), ~30 and ~200 (radix tier: varying key bits only, one
+    (col,row) group per thread in the fold) entries, with duplicates and SET/zero entries, all through the
+    LDS bucket kernel."""
     rng = np.random.default_rng(per_col)
     m, n = 700, 2048
     cnt = per_col * n
@@ -451,7 +452,7 @@ def test_staged_pushes_around_a_bulk_append(esp, orc):
 
 
 def test_bucket_kernel_24_input_tier(esp, orc):
-    """Column runs of exactly 20 entries: the first flush of a handle takes the LDS insertion tier, the
+    """Column runs of exactly 20 entries: the first flush of a handle takes the radix tier, the
     following ones the kernel variant with the 24-input register tier (chosen from the longest run the
     previous flush met) -- over an existing CSC (ROUTED) and, after reset!, on a fresh matrix."""
     rng = np.random.default_rng(24)
