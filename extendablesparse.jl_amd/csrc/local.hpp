@@ -882,8 +882,19 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         const u32 total = (u32)__shfl((int)inc, 63, ESP_WAVE);
         // ---- decoupled look-back (wave 0) unless the register tier already ran it
         if (!lb_done) {
-            const u64 excl = lookback_wave(a, s, total, lane);
-            if (lane == 0) s_dst = excl;
+            // A segment that emits nothing (re-assembly over the stored pattern: every update hit the CSC)
+            // has no use for its offset: it publishes its (zero) total and leaves without waiting for its
+            // predecessors.  Every 64th segment and the last one still resolve their chain and publish
+            // the inclusive prefix, so nobody ever walks back more than 64 + the segments in flight.
+            if (total == 0 && (s & 63) != 63 && s != a.S - 1 && s != 0) {
+                if (lane == 0) {
+                    __hip_atomic_store(&a.status[s], ST_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    s_dst = 0;
+                }
+            } else {
+                const u64 excl = lookback_wave(a, s, total, lane);
+                if (lane == 0) s_dst = excl;
+            }
         } else if (lane == 0 && total != s_early) {
             atomicOr(a.err, 4u);  // internal consistency: the early count must equal the folded count
         }

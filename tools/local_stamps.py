@@ -17,8 +17,12 @@ fem = int(os.environ.get("ESP_STAMP_FEM", "0"))   # e.g. 120: P1 FEM 3-D on 120^
 n = 256
 N = fem ** 3 if fem else n ** 3
 A = esp.ExtendableSparseMatrix(N, N, capacity_hint=0 if fem else 12 * n * n * (n - 1) + 6 * n * n)
+reasm = int(os.environ.get("ESP_STAMP_REASM", "0"))   # 1: stamps of the SECOND flush (re-assembly over the existing CSC)
 for it in range(3):
     A.reset()
+    if reasm:
+        A.generate_fdrand(n, n, n, rand_mode=1)
+        A.flush()
     if fem:
         A.generate_fem(3, fem, seed=4, order_mode=1)
     else:
