@@ -422,6 +422,34 @@ def test_bucket_kernel_tiers(esp, orc, per_col):
         assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
 
 
+def test_reassembly_with_a_few_new_entries(esp, orc):
+    """Re-assembly over the stored pattern: almost every segment of the bucket kernel emits nothing (and does
+    not wait for its look-back chain); a handful of new positions far apart must still land at the right
+    offsets, across long stretches of such segments."""
+    n = 48
+    N = n ** 3
+    A = esp.ExtendableSparseMatrix(N, N)
+    A.generate_fdrand(n, n, n, seed=41, rand_mode=1)
+    A.flush()
+    O = orc.fdrand(n, n, n, rand_mode=1, seed=41, style=orc.KIND_UPDATE)
+    rng = np.random.default_rng(43)
+    for rnd in range(3):
+        I, J, V = orc.fdrand_stream(n, n, n, rand_mode=1, seed=50 + rnd)
+        A.generate_fdrand(n, n, n, seed=50 + rnd, rand_mode=1)
+        O.apply(np.full(len(I), UPDATE, np.uint8), I, J, V)
+        if rnd > 0:                                   # new positions: 1, then 7, spread over the columns
+            k = 1 if rnd == 1 else 7
+            In = rng.integers(1, N + 1, k)
+            Jn = np.sort(rng.choice(N, k, replace=False)) + 1
+            Vn = rng.standard_normal(k)
+            A.append(UPDATE, In, Jn, Vn)
+            O.apply(np.full(k, UPDATE, np.uint8), In, Jn, Vn)
+        A.flush()
+        O.flush()
+        assert A.debug_last_path() == 1
+        assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
+
+
 def test_staged_pushes_around_a_bulk_append(esp, orc):
     """Per-entry updates (staged in the caller's pinned chunk) before and after a bulk append that is larger
     than that chunk: the bulk path has its own staging area, the caller's chunk pointers stay valid."""
