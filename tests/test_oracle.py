@@ -275,6 +275,33 @@ def test_coo_constructor_equals_scipy(orc):
     assert np.allclose(nz, S.data, rtol=1e-14)
 
 
+@pytest.mark.parametrize("dims", [(1000, 1, 1), (20, 20, 1), (10, 10, 10)])
+def test_dirichlet_known_answer(orc, dims):
+    """test/test_dirichlet.jl:8-20: penalty rows A[i,i]=1e30 vs mark_dirichlet + eliminate_dirichlet: both
+    systems have the same solution (right-hand side zeroed at the marked nodes)."""
+    import scipy.sparse.linalg as spla
+    nx, ny, nz = dims
+    N = nx * ny * nz
+    A = orc.fdrand(nx, ny, nz, rand_mode=1, seed=3, style=orc.KIND_UPDATE)
+    for i in range(1, N + 1, 10):
+        A[i, i] = 1.0e30
+    f = np.ones(N)
+    u = spla.spsolve(_to_scipy(A.arrays(), N, N).tocsc(), f)
+    C0 = A.sparse()
+    diri = C0.mark_dirichlet()
+    assert diri.sum() == len(range(1, N + 1, 10)) and diri[0] and not diri[1]
+    fD = f * (1 - diri)
+    C0.eliminate_dirichlet(diri)
+    AD = _to_scipy(C0.arrays(), N, N).tocsc()
+    uD = spla.spsolve(AD, fD)
+    assert np.max(np.abs(uD - u)) <= 1e-9 * max(1.0, np.max(np.abs(u)))
+    # structure of the eliminated matrix: unit rows/columns at the marked nodes, pattern unchanged
+    D = AD.toarray() if N <= 1000 else None
+    if D is not None:
+        for i in np.flatnonzero(diri):
+            assert D[i, i] == 1.0 and np.count_nonzero(D[i, :]) == 1 and np.count_nonzero(D[:, i]) == 1
+
+
 def test_mul_restatement(orc):
     """mul!(r, A, x) column loop == SciPy's product (to rounding), r .= 0 first, empty matrix gives zeros."""
     rng = np.random.default_rng(19)
