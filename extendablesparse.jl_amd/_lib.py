@@ -47,6 +47,7 @@ P = C.POINTER
 SIGNATURES = {
     "esp_create": (i32, [i64, i64, i32, i64, P(vp)]),
     "esp_destroy": (i32, [vp]),
+    "esp_clone": (i32, [vp, P(vp)]),
     "esp_last_error": (C.c_char_p, [vp]),
     "esp_version": (C.c_char_p, []),
     "esp_set_stream": (i32, [vp, vp]),

@@ -341,6 +341,53 @@ extern "C" int32_t esp_destroy(esp_handle *h) {
     return ESP_OK;
 }
 
+static int32_t reserve_append(esp_handle *h, i64 add);
+// Base.copy(ext) (extendable.jl:279-285): a second handle with the same CSC, the same pending entries
+// (the copy of lnkmatrix) and the same column window; device-to-device copies only.
+extern "C" int32_t esp_clone(esp_handle *h, esp_handle **out) {
+    if (!h || !out) return ESP_ERR_INVALID;
+    *out = nullptr;
+    (void)hipSetDevice(h->device);
+    esp_handle *c = nullptr;
+    CK(esp_create(h->m, h->n, h->device, h->hint, &c));
+    auto fail = [&](int32_t st) {
+        h->err = c->err;
+        esp_destroy(c);
+        return st;
+    };
+    int32_t st = ESP_OK;
+    HIPCK(h, hipStreamSynchronize(h->stream));  // everything the copy reads is complete
+    if (h->count > 0) {
+        if ((st = reserve_append(c, h->count)) != ESP_OK) return fail(st);
+        if (hipMemcpyAsync(c->keys.p, h->keys.p, sizeof(u64) * (size_t)h->count, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(c->vals.p, h->vals.p, sizeof(double) * (size_t)h->count, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+            return fail(ESP_ERR_HIP);
+        c->count = h->count;
+        c->fused_state = 2;  // (no run lists came with these entries)
+    }
+    if ((st = fix_tail(h)) != ESP_OK) return fail(st);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (hipMemcpyAsync(c->colptr.p, h->colptr.p, sizeof(i64) * (size_t)(h->n + 1), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return fail(ESP_ERR_HIP);
+    if (h->nnz > 0) {
+        if ((st = ensure(c, c->rowval, sizeof(i64) * (size_t)h->nnz)) != ESP_OK) return fail(st);
+        if ((st = ensure(c, c->nzval, sizeof(double) * (size_t)h->nnz)) != ESP_OK) return fail(st);
+        if (hipMemcpyAsync(c->rowval.p, h->rowval.p, sizeof(i64) * (size_t)h->nnz, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(c->nzval.p, h->nzval.p, sizeof(double) * (size_t)h->nnz, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+            return fail(ESP_ERR_HIP);
+    }
+    c->nnz = h->nnz;
+    c->pattern_version++, c->values_version++;
+    c->win_base = h->win_base;
+    c->win_span = h->win_span;
+    c->wc0 = h->wc0;
+    c->wc1 = h->wc1;
+    c->win_excl = h->win_excl;
+    c->seen_maxrun = h->seen_maxrun;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(ESP_ERR_HIP);
+    *out = c;
+    return ESP_OK;
+}
+
 extern "C" int32_t esp_set_stream(esp_handle *h, void *hip_stream) {
     if (!h) return ESP_ERR_INVALID;
     (void)hipStreamSynchronize(h->stream);

@@ -113,6 +113,16 @@ class _Handle:
         self._st = None
         self._nst = 0
 
+    def clone(self):
+        """A second handle with the same CSC and pending entries (device-to-device): Base.copy."""
+        self.commit()
+        c = object.__new__(_Handle)
+        c.lib, c.m, c.n = self.lib, self.m, self.n
+        h = C.c_void_p()
+        self.ck(self.lib.esp_clone(self.h, C.byref(h)))
+        c.h, c._st, c._nst = h, None, 0
+        return c
+
     def close(self):
         if getattr(self, "h", None):
             self.lib.esp_destroy(self.h)
@@ -403,6 +413,15 @@ class ExtendableSparseMatrix:
         r = out if out is not None else np.empty(self.m, np.float64)
         d.ck(d.lib.esp_mul(d.h, _vp(x), _vp(r), 0))
         return r
+
+    def copy(self):
+        """Base.copy(ext) (extendable.jl:279-285): CSC, pending entries and phash are copied."""
+        c = object.__new__(ExtendableSparseMatrix)
+        c._d = self._d.clone()
+        c.m, c.n = self.m, self.n
+        c._phash = self._phash
+        c._host = None
+        return c
 
     def mark_dirichlet(self, penalty=1.0e20):
         """mark_dirichlet(A; penalty) (sparsematrixcsc.jl:94-108, via abstractextendablesparsematrixcsc.jl): flush!,

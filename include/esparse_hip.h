@@ -93,6 +93,8 @@ typedef struct {
  * sparsematrixlnk.jl:75-77).  capacity_hint = expected number of appended entries. */
 int32_t esp_create(int64_t m, int64_t n, int32_t device, int64_t capacity_hint, esp_handle **out);
 int32_t esp_destroy(esp_handle *h);
+/* Base.copy(ext) (extendable.jl:279-285): same CSC, same pending entries, same window; device-to-device */
+int32_t esp_clone(esp_handle *h, esp_handle **out);
 const char *esp_last_error(const esp_handle *h);
 const char *esp_version(void);
 /* use an external HIP stream (hipStream_t) instead of the handle's own */

@@ -450,6 +450,32 @@ def test_reassembly_with_a_few_new_entries(esp, orc):
         assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
 
 
+def test_copy_is_independent(esp, orc):
+    """Base.copy(ext) (extendable.jl:279-285): CSC and pending entries are copied; the two matrices then evolve
+    independently (device-to-device copy of the handle)."""
+    rng = np.random.default_rng(90)
+    m, n, cnt = 400, 300, 20000
+    A = esp.ExtendableSparseMatrix(m, n)
+    O = orc.ExtendableSparseMatrix(m, n)
+    I, J, V = rng.integers(1, m + 1, cnt), rng.integers(1, n + 1, cnt), rng.standard_normal(cnt)
+    A.append(UPDATE, I, J, V)
+    O.apply(np.full(cnt, UPDATE, np.uint8), I, J, V)
+    A.flush()
+    I2, J2, V2 = rng.integers(1, m + 1, 500), rng.integers(1, n + 1, 500), rng.standard_normal(500)
+    A.append(UPDATE, I2, J2, V2)                       # pending at the time of the copy
+    A.updateindex("+", 2.5, 7, 9)                      # (still in the staging chunk)
+    B = A.copy()
+    assert B.phash == A.phash and B.nnznew() == A.nnznew() == 501
+    O.apply(np.full(500, UPDATE, np.uint8), I2, J2, V2)
+    O.updateindex(orc.OP_ADD, 2.5, 7, 9)
+    want = O.arrays()
+    A[1, 1] = 99.0                                     # only A changes from here on
+    assert_csc_equal(hip_arrays(B), want)
+    O[1, 1] = 99.0
+    assert_csc_equal(hip_arrays(A), O.arrays())
+    assert_csc_equal(hip_arrays(B), want)
+
+
 def test_staged_pushes_around_a_bulk_append(esp, orc):
     """Per-entry updates (staged in the caller's pinned chunk) before and after a bulk append that is larger
     than that chunk: the bulk path has its own staging area, the caller's chunk pointers stay valid."""
