@@ -75,6 +75,9 @@ struct esp_handle {
         DevBuf d_rows, d_cols, d_vals, d_kinds;
     } stage, bulk;
     unsigned long long *pin_scalar = nullptr;  // pinned, 8 slots
+    int last_run_order = 0;      // esp_debug_last_run_order
+    hipStream_t aux = nullptr;   // second stream + event: small device-to-host reads beside a running kernel
+    hipEvent_t aux_ev = nullptr;  // (created on first use, aux_ready)
     // shard cache
     bool shard_valid = false;
     int shard_P = 0;
@@ -291,6 +294,7 @@ extern "C" int32_t esp_create(int64_t m, int64_t n, int32_t device, int64_t capa
     h->wc1 = n;
     h->hint = capacity_hint > 0 ? capacity_hint : 0;
     memset(&h->acc, 0, sizeof h->acc);
+    if (const char *e = getenv("ESP_DEBUG_FORCE_PATH")) h->force_path = atoi(e);  // (same-box A/B of the test hooks)
     if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
         delete h;
         FAIL((esp_handle *)nullptr, ESP_ERR_HIP, "esp_create: cannot create a stream on device %d", device);
@@ -336,6 +340,8 @@ extern "C" int32_t esp_destroy(esp_handle *h) {
         (void)hipEventDestroy(s.b);
     }
     for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->aux_ev) (void)hipEventDestroy(h->aux_ev);
+    if (h->aux) (void)hipStreamDestroy(h->aux);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return ESP_OK;
@@ -1058,6 +1064,10 @@ struct ChunkArrays {
     u64 *nruns;
     unsigned long long *bucket_count;
     u32 *overflow;
+    u32 *dcount;  // (directly in front of bucket_count: one memset clears both)
+    u64 *dlist;
+    u64 *coarse;  // totals of 256 digits each
+    size_t clear_bytes;  // dcount .. bucket_count[NB]
 };
 
 static int32_t chunk_arrays(esp_handle *h, i64 Ccap, int pb, ChunkArrays *out) {
@@ -1072,8 +1082,11 @@ static int32_t chunk_arrays(esp_handle *h, i64 Ccap, int pb, ChunkArrays *out) {
     const size_t o_cs = carve(sizeof(i64) * (size_t)(Ccap + 2));
     const size_t o_rd = carve(sizeof(u32) * (size_t)RM), o_rc = carve(sizeof(u32) * (size_t)RM);
     const size_t o_nr = carve(sizeof(u64) * (size_t)(Ccap + 1 + espscan::workspace_elems(Ccap + 1)));
+    const size_t o_dc = carve(sizeof(u32) * (size_t)NB);
     const size_t o_bc = carve(sizeof(u64) * (size_t)(NB + 1 + espscan::workspace_elems(NB + 1)));
     const size_t o_ov = carve(64);
+    const size_t o_dl = carve(sizeof(u64) * (size_t)NB * esprun::DCAP);
+    const size_t o_co = carve(sizeof(u64) * (size_t)(NB / 256 + 2));
     if (h->chunkbuf.bytes < off || h->chunk_cap != Ccap || h->chunk_pb != pb) {
         if (h->fused_state == 1) FAIL(h, ESP_ERR_STATE, "internal: run-list arrays resized while they hold producer data");
         CK(ensure(h, h->chunkbuf, off));
@@ -1087,6 +1100,10 @@ static int32_t chunk_arrays(esp_handle *h, i64 Ccap, int pb, ChunkArrays *out) {
     out->nruns = (u64 *)(B + o_nr);
     out->bucket_count = (unsigned long long *)(B + o_bc);
     out->overflow = (u32 *)(B + o_ov);
+    out->dcount = (u32 *)(B + o_dc);
+    out->dlist = (u64 *)(B + o_dl);
+    out->coarse = (u64 *)(B + o_co);
+    out->clear_bytes = o_bc + sizeof(u64) * (size_t)(NB + 1) - o_dc;
     return ESP_OK;
 }
 
@@ -1165,10 +1182,16 @@ struct MultiWin {
     const u64 *d_base;
 };
 
+static int32_t aux_ready(esp_handle *h) {
+    if (!h->aux) HIPCK(h, hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+    if (!h->aux_ev) HIPCK(h, hipEventCreateWithFlags(&h->aux_ev, hipEventDisableTiming));
+    return ESP_OK;
+}
+
 // mw != nullptr: buckets = mw->P * mw->nb (window r = digits [r*nb, (r+1)*nb)), pb = bits covering them
 static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u64 *kout, double *vout, int K, int pb,
-                             i64 *seg_out, u64 *tile_first_out, bool *ok, i64 *maxlen_out, const MultiWin *mw = nullptr,
-                             int mw_shift = 0) {
+                             i64 *seg_out, u64 *tile_first_out, bool *tiles_ready, bool *ok, i64 *maxlen_out,
+                             const MultiWin *mw = nullptr, int mw_shift = 0) {
     const i64 E = h->count;
     const i64 NB = mw ? (i64)mw->P * (i64)mw->nb : (i64)1 << pb;
     CK(ensure(h, h->misc, 256));
@@ -1221,16 +1244,80 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
     u64 *nruns = a.nruns, *bstart = (u64 *)ca.bucket_count, *head = (u64 *)(B + o_hd);
     u64 *lk = (u64 *)(B + o_lk), *lk2 = (u64 *)(B + o_lk2), *sc = (u64 *)(B + o_sc);
     double *lv = (double *)(B + o_lv), *lv2 = (double *)(B + o_lv2);
+    // flags[0] window error, [1] a chunk with too many digits, [2] (run-list sort passes), [3] a digit with too
+    // many runs; maxlen in front of them: one 64-byte block the CALLER zeroed
+    unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
+    u32 *flags = (u32 *)h->misc.p + 60;
+    a.dcount = nullptr;
+    a.dlist = nullptr;
+    a.nruns_raw = 0;
+    a.flags = nullptr;
+    *tiles_ready = false;
+    // ranked: every digit collects its own runs, ONE kernel turns them into run offsets (run_rank_k), the
+    // scatter kernel follows without a host round trip (force_path 12: the radix-ordered run list instead)
+    const bool ranked = !fused && h->force_path != 12;
+    h->last_run_order = 2;
+    if (ranked) CK(aux_ready(h));
     if (!fused) {
-        HIPCK(h, hipMemsetAsync(ca.overflow, 0, 4, h->stream));
-        HIPCK(h, hipMemsetAsync(bstart, 0, sizeof(u64) * (size_t)(NB + 1), h->stream));
-        hipLaunchKernelGGL(esprun::fixed_chunks_k, dim3(grid_for(C + 1, 256)), dim3(256), 0, h->stream, ca.chunk_start, (i64)0, C, (i64)0, E);
+        a.overflow = flags + 1;
+        if (ranked) {
+            a.dcount = ca.dcount;
+            a.dlist = ca.dlist;
+            HIPCK(h, hipMemsetAsync(ca.dcount, 0, ca.clear_bytes, h->stream));
+        } else {
+            HIPCK(h, hipMemsetAsync(bstart, 0, sizeof(u64) * (size_t)(NB + 1), h->stream));
+        }
         Span sp(h, ESP_ST_HIST);
         if (mw)
             hipLaunchKernelGGL((esprun::run_hist_k<true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a, (i64)0);
         else
             hipLaunchKernelGGL((esprun::run_hist_k<false>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a, (i64)0);
         sp.add(1);
+    }
+    if (ranked) {
+        {
+            Span sp(h, ESP_ST_SCAN);
+            const unsigned g = (unsigned)grid_for(NB + 1, esprun::THREADS);
+            u64 *coarse = ca.coarse;
+            hipLaunchKernelGGL(esprun::run_coarse_k, dim3(g), dim3(esprun::THREADS), 0, h->stream, (const unsigned long long *)ca.bucket_count,
+                               NB, coarse);
+            hipLaunchKernelGGL(esprun::run_rank_k, dim3(g), dim3(esprun::THREADS), 0, h->stream, (const unsigned long long *)ca.bucket_count,
+                               (const u64 *)coarse, (const u32 *)ca.dcount, (const u64 *)ca.dlist, NB, seg_out, a.runs_off, d_maxlen,
+                               flags + 3);
+            sp.add(2);
+        }
+        // the host reads the flags on the second stream while the scatter kernel (which leaves at once when one
+        // of them is set) already runs
+        HIPCK(h, hipEventRecord(h->aux_ev, h->stream));
+        a.nruns_raw = 1;
+        a.flags = flags;
+        {
+            Span sp(h, ESP_ST_SCATTER);
+            if (mw)
+                hipLaunchKernelGGL((esprun::run_scatter_k<true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
+            else
+                hipLaunchKernelGGL((esprun::run_scatter_k<false>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
+            sp.add(1);
+        }
+        HIPCK(h, hipStreamWaitEvent(h->aux, h->aux_ev, 0));
+        HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_maxlen, 64, hipMemcpyDeviceToHost, h->aux));
+        HIPCK(h, hipStreamSynchronize(h->aux));
+        const u32 f_err = (u32)h->pin_scalar[6], f_over = (u32)(h->pin_scalar[6] >> 32), f_many = (u32)(h->pin_scalar[7] >> 32);
+        if (f_over) {
+            *ok = false;
+            return ESP_OK;
+        }
+        if (f_err) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (partition)");
+        h->last_run_order = f_many ? 3 : 1;
+        if (!f_many) {
+            *maxlen_out = (i64)h->pin_scalar[0];
+            HIPCK(h, hipGetLastError());
+            *ok = true;
+            return ESP_OK;
+        }
+        // some digit has more runs than its list holds (nothing was moved): order the run list with the radix passes
+        a.nruns_raw = 0;
+        a.flags = nullptr;
     }
     HIPCK(h, hipMemsetAsync(nruns + C, 0, sizeof(u64), h->stream));
     {
@@ -1239,7 +1326,6 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
         sp.add(espscan::exclusive<u64, false>(h->stream, bstart, bstart, NB + 1, bstart + NB + 1));
     }
     // bucket starts are final here: tiles per bucket and the longest bucket come with the same sync
-    unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
     {
         Span sp(h, ESP_ST_SCAN);
         HIPCK(h, hipMemcpyAsync(seg_out, bstart, sizeof(i64) * (size_t)(NB + 1), hipMemcpyDeviceToDevice, h->stream));
@@ -1248,7 +1334,8 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
                            (i64)espradix::TILE, tile_first_out, d_maxlen);
         sp.add(1 + espscan::exclusive<u64, false>(h->stream, tile_first_out, tile_first_out, NB + 1, tile_first_out + NB + 1));
     }
-    HIPCK(h, hipMemcpyAsync(h->pin_scalar, ca.overflow, 4, hipMemcpyDeviceToHost, h->stream));
+    *tiles_ready = true;
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, a.overflow, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipMemcpyAsync(h->pin_scalar + 1, nruns + C, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipMemcpyAsync(h->pin_scalar + 2, d_maxlen, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipMemcpyAsync(h->pin_scalar + 3, a.err, 4, hipMemcpyDeviceToHost, h->stream));
@@ -1330,7 +1417,7 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     CK(ensure(h, h->misc, 256));
     unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
     u32 *d_werr = (u32 *)h->misc.p + 60;
-    HIPCK(h, hipMemsetAsync(d_werr, 0, 4, h->stream));
+    HIPCK(h, hipMemsetAsync(d_maxlen, 0, 64, h->stream));  // maxlen .. the four flag words (run_partition)
 
     int planned = 0;
     if (E > esplocal::CAP) {
@@ -1348,8 +1435,7 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     CK(ensure(h, h->seg[0], sizeof(i64) * 4));
     CK(ensure(h, h->tilef[0], sizeof(u64) * (size_t)(4 + espscan::workspace_elems(4))));
     const i64 T = ceil_div<i64>(E, espradix::TILE);
-    hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, (i64 *)h->seg[0].p, (i64)0, E, (i64)0, (i64)0);
-    hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, (i64 *)h->tilef[0].p, (i64)0, T, (i64)0, (i64)0);
+    bool tiles_ready = false;  // seg[cur] has its tile table in tilef[cur] (only the 8-bit passes need one)
     u64 *kin = (u64 *)h->keys.p, *kout = (u64 *)h->keys2.p;
     double *vin = (double *)h->vals.p, *vout = (double *)h->vals2.p;
     i64 maxlen = E;
@@ -1369,7 +1455,9 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
             CK(ensure(h, h->tilef[1], sizeof(u64) * (size_t)(S2 + 1 + espscan::workspace_elems(S2 + 1))));
             bool took = false;
             i64 ml = E;
-            CK(run_partition(h, kin, vin, kout, vout, K, pb, (i64 *)h->seg[1].p, (u64 *)h->tilef[1].p, &took, &ml));
+            bool tr = false;
+            CK(run_partition(h, kin, vin, kout, vout, K, pb, (i64 *)h->seg[1].p, (u64 *)h->tilef[1].p, &tr, &took, &ml));
+            if (took) tiles_ready = tr;
             if (took) {
                 std::swap(kin, kout);
                 std::swap(vin, vout);
@@ -1403,6 +1491,21 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
             bits = 1;
             while (bits < 8 && (double)maxlen / (double)(1 << bits) > 0.8 * esplocal::CAP) bits++;
             bits = std::min(bits, K - done);
+        }
+        if (!tiles_ready) {
+            Span sp(h, ESP_ST_SCAN);
+            if (S == 1) {  // the whole buffer as one segment
+                hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, (i64 *)h->seg[0].p, (i64)0, E, (i64)0, (i64)0);
+                hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, (i64 *)h->tilef[0].p, (i64)0, T, (i64)0, (i64)0);
+                sp.add(2);
+            } else {  // (segments of the run-based pass, whose ranked flavour leaves the tile table to its user)
+                u64 *tf = (u64 *)h->tilef[cur].p;
+                HIPCK(h, hipMemsetAsync(d_maxlen, 0, 8, h->stream));
+                hipLaunchKernelGGL(espradix::seg_tiles_k, dim3(grid_for((i64)S + 1, 256)), dim3(256), 0, h->stream, (const i64 *)h->seg[cur].p,
+                                   (i64)S, (i64)espradix::TILE, tf, d_maxlen);
+                sp.add(1 + espscan::exclusive<u64, false>(h->stream, tf, tf, (i64)S + 1, tf + S + 1));
+            }
+            tiles_ready = true;
         }
         espradix::Pass p;
         p.keys_in = kin;
@@ -1447,6 +1550,8 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
             maxlen = (i64)h->pin_scalar[0];
         }
     }
+    if (S == 1 && !tiles_ready)  // no pass at all: the buffer is the one segment
+        hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, (i64 *)h->seg[0].p, (i64)0, E, (i64)0, (i64)0);
     HIPCK(h, hipGetLastError());
     if (pass_idx > 0 && !(window_checked && pass_idx == 0)) {  // the partition passes clamp and report keys outside the window
         HIPCK(h, hipMemcpyAsync(h->pin_scalar + 2, d_werr, 4, hipMemcpyDeviceToHost, h->stream));
@@ -1763,6 +1868,11 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
 extern "C" int32_t esp_debug_force_path(esp_handle *h, int32_t path) {
     if (!h) return ESP_ERR_INVALID;
     h->force_path = path;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_last_run_order(const esp_handle *h, int32_t *kind) {
+    if (!h || !kind) return ESP_ERR_INVALID;
+    *kind = h->last_run_order;
     return ESP_OK;
 }
 extern "C" int32_t esp_debug_last_partition(const esp_handle *h, int32_t *kind) {
@@ -2278,12 +2388,12 @@ extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t s
         CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
         CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
         CK(ensure(h, h->misc, 256));
-        HIPCK(h, hipMemsetAsync((u32 *)h->misc.p + 60, 0, 4, h->stream));
+        HIPCK(h, hipMemsetAsync((unsigned long long *)h->misc.p + 24, 0, 64, h->stream));  // maxlen .. flag words
         MultiWin mw{P, (u32)nb64, (const u64 *)T};
-        bool took = false;
+        bool took = false, tiles = false;
         i64 ml = 0;
         CK(run_partition(h, (const u64 *)h->keys.p, (const double *)h->vals.p, (u64 *)h->keys2.p, (double *)h->vals2.p, K, pb, bstart,
-                         (u64 *)h->tilef[1].p, &took, &ml, &mw, shift));
+                         (u64 *)h->tilef[1].p, &tiles, &took, &ml, &mw, shift));
         if (!took) return ESP_OK;  // not a pre-sorted stream: plain exchange
         std::swap(h->keys, h->keys2);
         std::swap(h->vals, h->vals2);

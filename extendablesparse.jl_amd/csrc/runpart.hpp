@@ -18,6 +18,7 @@
 #pragma once
 #include "common.hpp"
 #include "radix.hpp"
+#include "scan.hpp"
 
 namespace esprun {
 
@@ -27,6 +28,7 @@ constexpr int ITEMS = 16;
 constexpr int TILE = THREADS * ITEMS;  // same tiles as espradix
 constexpr int RMAX = 64;               // distinct digits a tile may hold on this path
 constexpr u32 EMPTY = 0xFFFFFFFFu;
+constexpr int DCAP = 32;               // runs one digit may collect in its own list (ranked path)
 
 struct Args {
     const u64 *keys_in;
@@ -45,6 +47,12 @@ struct Args {
     i64 *runs_off;   // [tile][RMAX] global output offset of the run
     u64 *nruns;      // [tile] (+1 slot for the scan)
     unsigned long long *bucket_count;  // [nbuckets + 1]
+    // ranked path (run_rank_k): every digit collects its runs (chunk | index in the chunk | count) itself
+    u32 *dcount;     // [nbuckets] runs of the digit
+    u64 *dlist;      // [nbuckets][DCAP]
+    int nruns_raw;   // nruns holds the counts themselves, not their scan
+    const u32 *flags;  // run_scatter_k leaves at once when flags[0], [1] or [3] is set (window error, too many
+                       // digits in a chunk, too many runs of a digit): the host reads them while it runs
     // several key windows side by side (column shards, MULTI kernels): window r starts at key mw_base[r]
     // (ascending), holds mw_nb digits of width 2^shift; global digit = r * mw_nb + local digit
     int mw_P;
@@ -117,6 +125,8 @@ struct RunSink {
     u64 *nruns;
     unsigned long long *bucket_count;
     u32 *overflow;
+    u32 *dcount = nullptr;  // ranked path: the digit's own run list (nullptr: not collected)
+    u64 *dlist = nullptr;
 };
 
 // Digit-major counting of one chunk by a whole workgroup: every wave walks the DISTINCT digits of its
@@ -188,6 +198,10 @@ __device__ __forceinline__ void count_runs(const u32 (&dig)[NITEMS], u32 pend, i
             sink.runs_d[chunk * RMAX + r] = x;
             sink.runs_c[chunk * RMAX + r] = rc[t];
             atomicAdd(&sink.bucket_count[x], (unsigned long long)rc[t]);
+            if (sink.dlist) {  // (any order: run_rank_k orders a digit's few runs by chunk)
+                const u32 slot = atomicAdd(&sink.dcount[x], 1u);
+                if (slot < (u32)DCAP) sink.dlist[(size_t)x * DCAP + slot] = ((u64)chunk << 24) | ((u64)r << 16) | (u64)rc[t];
+            }
         }
         if (t == 0) sink.nruns[chunk] = (u64)__popcll(used);
     }
@@ -230,7 +244,7 @@ __global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_chunk) {
         dig[k] = valid ? digit_mw<MULTI>(a, s_mw, ww, key[k], true) : 0u;
         pend |= valid ? (1u << k) : 0u;
     }
-    const RunSink sink{a.runs_d, a.runs_c, a.nruns, a.bucket_count, a.overflow};
+    const RunSink sink{a.runs_d, a.runs_c, a.nruns, a.bucket_count, a.overflow, a.dcount, a.dlist};
     count_runs<ITEMS>(dig, pend, chunk, sink, rd, rc, &over);
 }
 
@@ -284,6 +298,67 @@ __global__ void run_offsets_k(const u64 *__restrict__ lk, const double *__restri
     runs_off[tile * RMAX + j] = (i64)(bucket_start[d] + sc[i] - head[d]);
 }
 
+// Ranked path: two launches between the histogram and the scatter kernel.
+//   run_coarse_k   coarse[b] = entries of the digits [256 b, 256 b + 256)
+//   run_rank_k     one thread per digit d:
+//     seg_out[d]  = entries of all digits before d (the workgroup sums the coarse totals before its own 256
+//                   digits and scans its own), seg_out[nb] = all entries
+//     runs_off    = seg_out[d] + the entries of the digit's runs from earlier chunks, for each of its runs
+//                   (<= DCAP of them, a handful on a pre-sorted stream: quadratic walk over an LDS copy)
+//     maxlen      = the longest bucket; *too_many = 1 when some digit has more than DCAP runs (the host
+//                   then orders the run list with the radix passes instead)
+__global__ __launch_bounds__(THREADS) void run_coarse_k(const unsigned long long *__restrict__ bucket_count, i64 nb,
+                                                         u64 *__restrict__ coarse) {
+    __shared__ u64 lw[WAVES];
+    const i64 d = (i64)blockIdx.x * THREADS + threadIdx.x;
+    u64 tot;
+    espscan::block_exclusive<u64, false>(d < nb ? (u64)bucket_count[d] : 0ull, lw, &tot);
+    if (threadIdx.x == 0) coarse[blockIdx.x] = tot;
+}
+
+__global__ __launch_bounds__(THREADS) void run_rank_k(const unsigned long long *__restrict__ bucket_count,
+                                                       const u64 *__restrict__ coarse, const u32 *__restrict__ dcount,
+                                                       const u64 *__restrict__ dlist, i64 nb, i64 *__restrict__ seg_out,
+                                                       i64 *__restrict__ runs_off, unsigned long long *maxlen, u32 *too_many) {
+    __shared__ u64 rows[DCAP * THREADS];  // [i][t]: run i of thread t's digit (64 KiB)
+    u64 *lw = rows;                       // (the block scans are over before the rows are filled)
+    const int t = threadIdx.x;
+    const i64 d = (i64)blockIdx.x * THREADS + t;
+    const u64 own = d < nb ? (u64)bucket_count[d] : 0ull;
+    const u32 n = d < nb ? dcount[d] : 0u;
+    u64 before = 0;
+    for (i64 i = t; i < (i64)blockIdx.x; i += THREADS) before += coarse[i];
+    u64 base, tot;
+    espscan::block_exclusive<u64, false>(before, lw, &base);
+    const u64 start = base + espscan::block_exclusive<u64, false>(own, lw, &tot);
+    if (d <= nb) seg_out[d] = (i64)start;
+    {
+        u64 mx = own;
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            const u64 x = __shfl_xor(mx, o, ESP_WAVE);
+            mx = x > mx ? x : mx;
+        }
+        if ((t & 63) == 0 && mx) atomicMax(maxlen, (unsigned long long)mx);
+    }
+    if (n > (u32)DCAP) {
+        *too_many = 1u;
+        return;
+    }
+    const u64 *mine = dlist + (size_t)d * DCAP;
+    for (u32 i = 0; i < n; i++) rows[i * THREADS + t] = mine[i];
+    for (u32 i = 0; i < n; i++) {
+        const u64 e = rows[i * THREADS + t];
+        const u64 chunk = e >> 24;
+        u64 off = 0;
+        for (u32 k = 0; k < n; k++) {
+            const u64 o = rows[k * THREADS + t];
+            off += (o >> 24) < chunk ? (o & 0xFFFFull) : 0ull;
+        }
+        runs_off[chunk * RMAX + ((e >> 16) & 0xFFull)] = (i64)(start + off);
+    }
+}
+
 template <bool MULTI>
 __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
     __shared__ u64 s_mw[MULTI ? MW_MAX : 1];
@@ -297,7 +372,8 @@ __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
     const i64 beg = a.fixed_chunks ? tile * TILE : a.chunk_start[tile];
     const i64 end = a.fixed_chunks ? min(a.E, beg + (i64)TILE) : a.chunk_start[tile + 1];
     // run table of the tile (nruns holds the exclusive scan by now: nr = difference)
-    if (t == 0) s_nr = (int)(a.nruns[tile + 1] - a.nruns[tile]);
+    if (a.flags && (a.flags[0] | a.flags[1] | a.flags[3]) != 0u) return;  // (uniform: the flush takes another path)
+    if (t == 0) s_nr = a.nruns_raw ? (int)a.nruns[tile] : (int)(a.nruns[tile + 1] - a.nruns[tile]);
     if (t < RMAX) {
         roff[t] = a.runs_off[tile * RMAX + t];
         hd[t] = EMPTY;

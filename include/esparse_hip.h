@@ -242,10 +242,16 @@ int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear);
  * 3 = LDS bucket path with its radix tail only (no column tiers), 4 = bucket kernel issued in
  * launches of 64 workgroups (exercises the carry-over of the look-back state), 5 = never use the
  * run-based single-pass partition (8-bit passes only), 7 = the device generators emit the run lists of their chunks themselves (skips the
- * histogram kernel; off by default: no net gain measured), 11 = esp_shard_partition reports "not applicable";
+ * histogram kernel; off by default: no net gain measured), 11 = esp_shard_partition reports "not applicable",
+ * 12 = the run-based partition orders its run list with radix passes (several small launches and a host round
+ * trip) instead of the one ranking kernel;
  * last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general) */
 int32_t esp_debug_force_path(esp_handle *h, int32_t path);
 int32_t esp_debug_last_path(const esp_handle *h, int32_t *path);
+/* how the last run-based partition turned its run lists into offsets: 1 = one ranking kernel over per-digit run
+ * lists, 2 = radix-ordered run list, 3 = ranking kernel given up (a digit with more runs than its list holds),
+ * radix-ordered run list used */
+int32_t esp_debug_last_run_order(const esp_handle *h, int32_t *kind);
 /* which partition the last flush used: 1 = run-based single pass (pre-sorted stream), 2 = 8-bit passes,
  * 3 = run-based single pass on run lists the producers emitted (no histogram kernel),
  * 7 = none: the segments came assembled from esp_shard_assemble */

@@ -556,7 +556,7 @@ def test_empty_and_tiny(esp):
 
 
 # ------------------------------------------------------------------ full-size properties
-@pytest.mark.parametrize("force", [0, 5, 7])
+@pytest.mark.parametrize("force", [0, 5, 7, 12])
 def test_run_partition_vs_passes(esp, orc, force):
     """Pre-sorted stream (48^3 stencil, E > 2^20): the run-based single-pass partition and the 8-bit
     passes give the same bits; a shuffled stream falls back to the passes."""
@@ -567,7 +567,9 @@ def test_run_partition_vs_passes(esp, orc, force):
     A.generate_fdrand(n, n, n, seed=21, rand_mode=1)
     A.flush()
     # 3: the generator emitted the run lists itself; 1: histogram kernel; 2: 8-bit passes
-    assert A.debug_last_partition() == {0: 1, 5: 2, 7: 3}[force]
+    assert A.debug_last_partition() == {0: 1, 5: 2, 7: 3, 12: 1}[force]
+    if force in (0, 12):  # run offsets from the ranking kernel / from the radix-ordered run list
+        assert A.debug_last_run_order() == (1 if force == 0 else 2)
     O = orc.fdrand(n, n, n, rand_mode=1, seed=21, style=orc.KIND_UPDATE)
     assert_csc_equal(hip_arrays(A), O.arrays())
     # same entries in random order: too many distinct digits per tile -> 8-bit passes
@@ -592,7 +594,7 @@ def test_run_partition_vs_passes(esp, orc, force):
     assert_csc_equal(hip_arrays(A), O2.arrays())
 
 
-@pytest.mark.parametrize("force", [0, 5])
+@pytest.mark.parametrize("force", [0, 5, 12])
 def test_presorted_stream_mixed_kinds(esp, orc, force):
     """Pre-sorted stream with SET/UPDATE/RAWUPDATE mixes, zeros and duplicates spread over several chunks:
     the run-based single-pass partition (0) and the 8-bit passes (5) give the oracle's bits, on a fresh
@@ -616,8 +618,36 @@ def test_presorted_stream_mixed_kinds(esp, orc, force):
         A.flush()
         O.flush()
         assert A.debug_last_path() == 1
-        assert A.debug_last_partition() == (1 if force == 0 else 2)
+        assert A.debug_last_partition() == (2 if force == 5 else 1)
         assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
+
+
+def test_digit_with_many_runs_falls_back_to_ordered_run_list(esp, orc):
+    """A pre-sorted stream in which every chunk also touches the first columns: that digit collects one run per
+    chunk, more than its list holds -> the ranking kernel gives up, nothing is moved, the radix-ordered run list
+    takes over; same bits as the oracle.  Without those entries the ranking kernel serves the stream."""
+    rng = np.random.default_rng(91)
+    m = n = 200000
+    cnt = 1500000
+    J = np.sort(rng.integers(1, n + 1, cnt))
+    I = np.clip(J + rng.integers(-3, 4, cnt), 1, m)
+    V = rng.standard_normal(cnt)
+    for hot in (True, False):
+        Jh = J.copy()
+        Ih = I.copy()
+        if hot:
+            Jh[::1000] = 1 + (np.arange(len(Jh[::1000])) % 3)   # one entry per chunk (4096 entries) and more
+            Ih[::1000] = 1 + (np.arange(len(Ih[::1000])) % 5)
+        kinds = rng.integers(0, 3, cnt).astype(np.uint8)
+        A = esp.ExtendableSparseMatrix(m, n)
+        O = orc.ExtendableSparseMatrix(m, n)
+        A.append(0, Ih, Jh, V, kinds=kinds)
+        O.apply(kinds, Ih, Jh, V)
+        A.flush()
+        O.flush()
+        assert A.debug_last_partition() == 1
+        assert A.debug_last_run_order() == (3 if hot else 1)
+        assert_csc_equal(hip_arrays(A), O.arrays(), "hot %s" % hot)
 
 
 def test_producer_run_lists_mixed_with_other_appends(esp, orc):
