@@ -76,6 +76,7 @@ struct esp_handle {
     } stage, bulk;
     unsigned long long *pin_scalar = nullptr;  // pinned, 8 slots
     int last_run_order = 0;      // esp_debug_last_run_order
+    int last_colptr_direct = 0;  // the bucket kernel of the last flush wrote colptr itself
     hipStream_t aux = nullptr;   // second stream + event: small device-to-host reads beside a running kernel
     hipEvent_t aux_ev = nullptr;  // (created on first use, aux_ready)
     // shard cache
@@ -1655,14 +1656,31 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     u64 *status = (u64 *)h->segout.p;
     HIPCK(h, hipMemsetAsync(status, 0, sizeof(u64) * (size_t)(S + 2), h->stream));
     CK(ensure(h, h->colend, sizeof(u64) * (size_t)(N1 + espscan::workspace_elems(N1))));
+    esplocal::Args a;
+    const char *stop_env = getenv("ESP_LOCAL_STOP");
+    // A fresh matrix over the full key window whose segments are whole blocks of <= CL_MAX columns: every segment
+    // writes the colptr of its own columns (no column-end marks, no memset and no scan over all columns).
+    // force_path 13: marks + scan.
+    bool direct = false;
     {
+        const int clb = st.rem_bits - h->L.rb;
+        direct = Z0 == 0 && st.npieces == 0 && clb >= 0 && clb <= esplocal::CL_MAX_BITS && h->force_path != 3 && h->force_path != 13 &&
+                 !windowed(h) && h->win_base == 0 && ((i64)S << clb) >= h->n && !stop_env;  // (the segments cover every column)
+    }
+    h->last_colptr_direct = direct ? 1 : 0;
+    if (!direct) {
         i64 c0, cnt;
         col_range(h, &c0, &cnt);
         HIPCK(h, hipMemsetAsync((u64 *)h->colend.p + c0, 0, sizeof(u64) * (size_t)cnt, h->stream));
     }
-    esplocal::Args a;
+    // (a failed flush must not leave a half-written colptr behind)
+    auto restore_colptr = [&]() {
+        if (direct) hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(N1, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p, N1, (i64)1);
+    };
     {
         Span sp(h, ESP_ST_LOCAL);
+        a.colptr_out = direct ? (i64 *)h->colptr.p : nullptr;
+        a.ncols = h->n;
         a.keys_in = st.sk;
         a.vals_in = st.sv;
         a.seg_start = st.seg_start;
@@ -1690,8 +1708,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         a.err = (u32 *)(status + S) + 1;
         a.maxrun_seen = (u32 *)(status + S) + 2;  // (zeroed with the granules)
         {
-            const char *e = getenv("ESP_LOCAL_STOP");
-            a.stop_after = e ? atoi(e) : 0;
+            a.stop_after = stop_env ? atoi(stop_env) : 0;
             a.stamps = nullptr;
             if (getenv("ESP_LOCAL_STAMPS")) {  // diagnostics: per-segment phase stamps, dumped to a file
                 CK(ensure(h, h->heads, sizeof(u64) * (size_t)S * 16));
@@ -1721,7 +1738,10 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (S - 1), 24, hipMemcpyDeviceToHost, h->stream));  // last granule | ticket, err | maxrun
     HIPCK(h, hipMemcpyAsync(h->pin_scalar + 3, (u32 *)h->misc.p + 60, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
-    if ((u32)h->pin_scalar[3]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window");
+    if ((u32)h->pin_scalar[3]) {
+        restore_colptr();
+        FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window");
+    }
     if (a.stamps) {
         std::vector<u64> st((size_t)S * 16);
         HIPCK(h, hipMemcpy(st.data(), a.stamps, sizeof(u64) * st.size(), hipMemcpyDeviceToHost));
@@ -1732,6 +1752,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     }
     const u32 lookback_err = (u32)(h->pin_scalar[1] >> 32);
     h->seen_maxrun = (int)(u32)(h->pin_scalar[2] >> 0 & 0xFFFFFFFFull);
+    if (lookback_err & 7u) restore_colptr();
     if (lookback_err & 2u) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (bucket)");
     if (lookback_err & 1u) FAIL(h, ESP_ERR_HIP, "esp_flush: look-back chain timed out inside the bucket kernel");
     if (lookback_err & 4u) FAIL(h, ESP_ERR_HIP, "esp_flush: internal error (early segment total differs from the folded total)");
@@ -1747,6 +1768,11 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         CK(ensure(h, h->nzval, h->vals2.bytes));
         std::swap(h->rowval, h->keys2);
         std::swap(h->nzval, h->vals2);
+        if (direct) {  // colptr is complete
+            h->nnz = Zn;
+            h->pattern_version++, h->values_version++;
+            return ESP_OK;
+        }
         return finish_csc(h, 0, Zn, nullptr, nullptr);
     }
     return finish_csc(h, Z0, Zn, (const u64 *)tk, (const double *)tv);
@@ -1873,6 +1899,11 @@ extern "C" int32_t esp_debug_force_path(esp_handle *h, int32_t path) {
 extern "C" int32_t esp_debug_last_run_order(const esp_handle *h, int32_t *kind) {
     if (!h || !kind) return ESP_ERR_INVALID;
     *kind = h->last_run_order;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_last_colptr_direct(const esp_handle *h, int32_t *direct) {
+    if (!h || !direct) return ESP_ERR_INVALID;
+    *direct = h->last_colptr_direct;
     return ESP_OK;
 }
 extern "C" int32_t esp_debug_last_partition(const esp_handle *h, int32_t *kind) {

@@ -120,6 +120,10 @@ struct Args {
     const i64 *pstart;
     const void *const *ptab;
     u32 *maxrun_seen;  // longest column run any segment of this flush met (atomicMax)
+    // FRESH kernels on whole-column segments of a full key window: the segment writes colptr (1-based) for its own
+    // columns itself -- no column-end marks, no scan over all columns afterwards (nullptr: marks in colend)
+    i64 *colptr_out;
+    i64 ncols;  // columns of the matrix (colptr_out[ncols] = 1 + nnz comes from the last segment)
 };
 constexpr int MAX_PIECES = 64;
 
@@ -579,7 +583,9 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
 #endif
         n = (int)(seg_end - beg);
         // shared prefix of the segment (window-relative), turned back into an absolute key prefix
-        hi = n > 0 ? esp_uniform_u64(((((a.keys_in[beg] >> ESP_TAG_BITS) - a.base) >> a.rem_bits) << a.rem_bits) + a.base) : 0;
+        // (an empty segment has no key to take it from: its index is the prefix)
+        hi = n > 0 ? esp_uniform_u64(((((a.keys_in[beg] >> ESP_TAG_BITS) - a.base) >> a.rem_bits) << a.rem_bits) + a.base)
+                   : ((u64)s << a.rem_bits) + a.base;
         // all 16 loads of a thread are issued before anything depends on them: the index is clamped so
         // that the loads need no branch (slots past the end re-read the last entry and are discarded)
         // (an empty segment reads its predecessor's last entry instead -- or entry 0 -- and ignores it: one
@@ -886,7 +892,8 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             // has no use for its offset: it publishes its (zero) total and leaves without waiting for its
             // predecessors.  Every 64th segment and the last one still resolve their chain and publish
             // the inclusive prefix, so nobody ever walks back more than 64 + the segments in flight.
-            if (total == 0 && (s & 63) != 63 && s != a.S - 1 && s != 0) {
+            // (a segment that writes its columns' colptr itself needs its offset even then)
+            if (total == 0 && (s & 63) != 63 && s != a.S - 1 && s != 0 && !(FRESH && a.colptr_out)) {
                 if (lane == 0) {
                     __hip_atomic_store(&a.status[s], ST_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_dst = 0;
@@ -926,7 +933,9 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     }
     __syncthreads();
     const u64 dst = esp_uniform_u64(s_dst);
-    // ---- coalesced stores + column-end marks
+    // ---- coalesced stores + column-end marks (or colptr itself)
+    const bool direct = FRESH && a.colptr_out != nullptr;
+    const i64 c_lo = (i64)(hi >> a.rb);  // (direct: the segment's columns are [c_lo, c_hi))
     for (int p = t; p < total; p += THREADS) {
         const u64 key = skey[p];
         if (FRESH)
@@ -935,12 +944,22 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             a.out_key[dst + p] = key;
         a.out_val[dst + p] = sval[p];
         const u64 col = key >> a.rb;
-        if (p == total - 1 || (skey[p + 1] >> a.rb) != col) {
+        if (direct) {
+            // first entry of its column: that column and the empty ones in front of it start here
+            const i64 prev = p == 0 ? c_lo - 1 : (i64)(skey[p - 1] >> a.rb);
+            for (i64 c = prev + 1; c <= (i64)col; c++) a.colptr_out[c] = (i64)(dst + (u64)p) + 1;
+        } else if (p == total - 1 || (skey[p + 1] >> a.rb) != col) {
             if (a.col_aligned)
                 a.colend[col] = dst + (u64)p + 1;
             else
                 atomicMax((unsigned long long *)&a.colend[col], (unsigned long long)(dst + (u64)p + 1));
         }
+    }
+    if (direct) {  // the columns behind the last entry (all of them for an empty segment)
+        const i64 c_hi = min(c_lo + ((i64)1 << a.cl_bits), a.ncols);
+        const i64 after = total > 0 ? (i64)(skey[total - 1] >> a.rb) + 1 : c_lo;
+        for (i64 c = after + t; c < c_hi; c += THREADS) a.colptr_out[c] = (i64)(dst + (u64)total) + 1;
+        if (s == a.S - 1 && t == 0) a.colptr_out[a.ncols] = (i64)(dst + (u64)total) + 1;
     }
 #ifdef ESP_LOCAL_STAMPS
     if (a.stamps) {

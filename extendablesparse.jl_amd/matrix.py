@@ -502,6 +502,12 @@ class ExtendableSparseMatrix:
         self._d.ck(self._d.lib.esp_debug_last_run_order(self._d.h, C.byref(p)))
         return p.value
 
+    def debug_last_colptr_direct(self):
+        """True when the bucket kernel of the last flush wrote colptr itself (no scan over the columns)"""
+        p = C.c_int32()
+        self._d.ck(self._d.lib.esp_debug_last_colptr_direct(self._d.h, C.byref(p)))
+        return bool(p.value)
+
     def timing_enable(self, on=True):
         """on = True/1: events around the big kernels; 2: around every stage (incl. the small scans); False: off"""
         self._d.ck(self._d.lib.esp_timing_enable(self._d.h, int(on)))

@@ -622,6 +622,43 @@ def test_presorted_stream_mixed_kinds(esp, orc, force):
         assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
 
 
+@pytest.mark.parametrize("force", [0, 13])
+@pytest.mark.parametrize("n", [300007, 2048 * 64, 1000])
+def test_colptr_written_by_the_bucket_kernel(esp, orc, n, force):
+    """Fresh matrix: every segment writes the colptr of its own columns (0) / column-end marks + scan (13).
+    Empty columns in front, between and behind the entries, a column count that is no multiple of the segment
+    width, whole empty segments, and a second flush (merge path) on top: the oracle's arrays each time."""
+    rng = np.random.default_rng(5 + n)
+    m = 50000
+    cnt = 1400000 if n > 1000 else 30000
+    used = np.sort(rng.choice(np.arange(n // 10, n - n // 7), size=max(1, n // 3), replace=False)) + 1   # 2/3 of the columns stay empty
+    J = np.sort(used[rng.integers(0, len(used), cnt)])
+    J = J[~((J > n // 2) & (J < n // 2 + n // 8))]                      # a hole of n/8 columns (whole empty segments)
+    cnt = len(J)
+    I = rng.integers(1, m + 1, cnt)
+    V = rng.standard_normal(cnt)
+    kinds = rng.integers(0, 3, cnt).astype(np.uint8)
+    A = esp.ExtendableSparseMatrix(m, n)
+    A.debug_force_path(force)
+    O = orc.ExtendableSparseMatrix(m, n)
+    A.append(0, I, J, V, kinds=kinds)
+    O.apply(kinds, I, J, V)
+    A.flush()
+    O.flush()
+    assert A.debug_last_path() == 1
+    assert A.debug_last_colptr_direct() == (force == 0)
+    assert_csc_equal(hip_arrays(A), O.arrays(), "fresh")
+    J2 = np.sort(rng.integers(1, n + 1, 20000))
+    I2 = rng.integers(1, m + 1, 20000)
+    V2 = rng.standard_normal(20000)
+    A.append(UPDATE, I2, J2, V2)
+    O.apply(np.full(20000, UPDATE, np.uint8), I2, J2, V2)
+    A.flush()
+    O.flush()
+    assert not A.debug_last_colptr_direct()
+    assert_csc_equal(hip_arrays(A), O.arrays(), "second flush")
+
+
 def test_digit_with_many_runs_falls_back_to_ordered_run_list(esp, orc):
     """A pre-sorted stream in which every chunk also touches the first columns: that digit collects one run per
     chunk, more than its list holds -> the ranking kernel gives up, nothing is moved, the radix-ordered run list
