@@ -200,7 +200,8 @@ struct Span {
     Span(esp_handle *hh, int st) : h(hh), stage(st) {
         // timing level 1 brackets the big kernels only: the ~20 tiny launches of the "scan" stage would cost
         // more in event records (two per span) than they run
-        if (h->timing && (h->timing_level > 1 || st != ESP_ST_SCAN)) {
+        if (h->timing && (h->timing_level == 2 || (h->timing_level == 1 && st != ESP_ST_SCAN) ||
+                          (h->timing_level == 3 && (st == ESP_ST_LOCAL || st == ESP_ST_FOLD)))) {
             a = ev_get(h);
             (void)hipEventRecord(a, h->stream);
         }
@@ -1104,7 +1105,9 @@ static int32_t chunk_arrays(esp_handle *h, i64 Ccap, int pb, ChunkArrays *out) {
     out->dcount = (u32 *)(B + o_dc);
     out->dlist = (u64 *)(B + o_dl);
     out->coarse = (u64 *)(B + o_co);
-    out->clear_bytes = o_bc + sizeof(u64) * (size_t)(NB + 1) - o_dc;
+    // (a multiple of 256 bytes -- the runtime splits an odd-sized memset into two launches; what follows the totals
+    // inside their carve is scan workspace)
+    out->clear_bytes = ((o_bc + sizeof(u64) * (size_t)(NB + 1) + 255) & ~(size_t)255) - o_dc;
     return ESP_OK;
 }
 
@@ -2550,7 +2553,7 @@ extern "C" int32_t esp_timing_enable(esp_handle *h, int32_t on) {
     if (!h) return ESP_ERR_INVALID;
     timing_collect(h);
     h->timing = on != 0;
-    h->timing_level = on == 1 ? 1 : 2;   // 1: big kernels only; any other non-zero value: every stage
+    h->timing_level = (on == 1 || on == 3) ? on : 2;  // 1: big kernels; 3: bucket / fold kernel only; else every stage
     return ESP_OK;
 }
 extern "C" int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear) {

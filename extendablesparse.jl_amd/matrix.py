@@ -509,7 +509,8 @@ class ExtendableSparseMatrix:
         return bool(p.value)
 
     def timing_enable(self, on=True):
-        """on = True/1: events around the big kernels; 2: around every stage (incl. the small scans); False: off"""
+        """on = True/1: events around the big kernels; 2: around every stage (incl. the small scans); 3: around the
+        bucket kernel (general path: fold kernel) only; False: off"""
         self._d.ck(self._d.lib.esp_timing_enable(self._d.h, int(on)))
 
     def timing(self, clear=True):

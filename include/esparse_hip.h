@@ -235,7 +235,9 @@ int32_t esp_set_column_window(esp_handle *h, int64_t col_lo, int64_t col_hi);
 
 /* ---- measurement ---------------------------------------------------------------- */
 /* on = 1: HIP events around the big kernels (append, hist, scatter, local, fold, colptr, merge, copy);
- * on = 2: also around the small launches of the "scan" stage (costs about 3 % of a 256^3 step); 0: off */
+ * on = 2: also around the small launches of the "scan" stage (costs about 3 % of a 256^3 step);
+ * on = 3: around the bucket kernel (general path: the fold kernel) only -- every bracketed kernel costs two event
+ * records of about 6 us on the stream; 0: off */
 int32_t esp_timing_enable(esp_handle *h, int32_t on);
 int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear);
 /* test hooks: path 0 = automatic, 2 = force the general path (global LSD sort + global fold),
