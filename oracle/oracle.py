@@ -260,7 +260,7 @@ class ExtendableSparseMatrix:
             self._h = L.orc_ext_new(m, n)
 
     def __del__(self):
-        if self._h:
+        if getattr(self, "_h", None) and lib is not None:   # (module globals may be gone at interpreter shutdown)
             lib().orc_ext_free(self._h)
             self._h = None
 
