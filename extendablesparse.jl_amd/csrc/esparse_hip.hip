@@ -1661,14 +1661,17 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     CK(ensure(h, h->colend, sizeof(u64) * (size_t)(N1 + espscan::workspace_elems(N1))));
     esplocal::Args a;
     const char *stop_env = getenv("ESP_LOCAL_STOP");
-    // A fresh matrix over the full key window whose segments are whole blocks of <= CL_MAX columns: every segment
-    // writes the colptr of its own columns (no column-end marks, no memset and no scan over all columns).
+    // A fresh matrix whose segments are whole blocks of <= CL_MAX columns that start at the first column of the
+    // range this flush can touch (all columns, or the column window of a shard) and cover it: every segment writes
+    // the colptr of its own columns (no column-end marks, no memset and no scan over the columns).
     // force_path 13: marks + scan.
     bool direct = false;
+    const i64 col_begin = windowed(h) ? h->wc0 : 0, col_end = windowed(h) ? h->wc1 : h->n;
     {
         const int clb = st.rem_bits - h->L.rb;
-        direct = Z0 == 0 && st.npieces == 0 && clb >= 0 && clb <= esplocal::CL_MAX_BITS && h->force_path != 3 && h->force_path != 13 &&
-                 !windowed(h) && h->win_base == 0 && ((i64)S << clb) >= h->n && !stop_env;  // (the segments cover every column)
+        const u64 seg_base = st.npieces > 0 ? h->part_base : h->win_base;
+        direct = Z0 == 0 && clb >= 0 && clb <= esplocal::CL_MAX_BITS && h->force_path != 3 && h->force_path != 13 && !stop_env &&
+                 seg_base == ((u64)col_begin << h->L.rb) && col_begin + ((i64)S << clb) >= col_end;
     }
     h->last_colptr_direct = direct ? 1 : 0;
     if (!direct) {
@@ -1678,12 +1681,15 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     }
     // (a failed flush must not leave a half-written colptr behind)
     auto restore_colptr = [&]() {
-        if (direct) hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(N1, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p, N1, (i64)1);
+        if (direct) {
+            hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(N1, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p, N1, (i64)1);
+            h->tail_stale = false;
+        }
     };
     {
         Span sp(h, ESP_ST_LOCAL);
         a.colptr_out = direct ? (i64 *)h->colptr.p : nullptr;
-        a.ncols = h->n;
+        a.col_end = col_end;
         a.keys_in = st.sk;
         a.vals_in = st.sv;
         a.seg_start = st.seg_start;
@@ -1771,7 +1777,8 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         CK(ensure(h, h->nzval, h->vals2.bytes));
         std::swap(h->rowval, h->keys2);
         std::swap(h->nzval, h->vals2);
-        if (direct) {  // colptr is complete
+        if (direct) {  // colptr is complete (behind a column window it is refreshed lazily, as after the scan)
+            if (windowed(h)) h->tail_stale = h->wc1 < h->n;
             h->nnz = Zn;
             h->pattern_version++, h->values_version++;
             return ESP_OK;
@@ -2437,12 +2444,17 @@ extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t s
     } else {
         HIPCK(h, hipMemsetAsync(bstart, 0, sizeof(i64) * (size_t)(NB + 1), h->stream));
     }
-    hipLaunchKernelGGL(diff_counts_k, dim3(grid_for(NB, 256)), dim3(256), 0, h->stream, (const i64 *)bstart, NB, cnt);
+    // The counts and owner ranges follow from the bucket starts, which the ranking kernel wrote BEFORE the scatter
+    // kernel started: they are produced on the second stream (it already waits for the ranking kernel) and this call
+    // returns while the entries are still being moved -- the caller's consensus round runs beside the scatter
+    // kernel; esp_synchronize() before the key/value arrays are read.
+    hipStream_t qs = (E > 0 && h->last_run_order == 1) ? h->aux : h->stream;
+    hipLaunchKernelGGL(diff_counts_k, dim3(grid_for(NB, 256)), dim3(256), 0, qs, (const i64 *)bstart, NB, cnt);
     // owner ranges = bucket starts at every multiple of nb
     i64 *d_off = (i64 *)(T + 64 * 8);
-    hipLaunchKernelGGL(gather_stride_k, dim3(1), dim3(128), 0, h->stream, (const i64 *)bstart, (i64)nb64, P + 1, d_off);
-    HIPCK(h, hipMemcpyAsync(off.data(), d_off, sizeof(i64) * (size_t)(P + 1), hipMemcpyDeviceToHost, h->stream));
-    HIPCK(h, hipStreamSynchronize(h->stream));
+    hipLaunchKernelGGL(gather_stride_k, dim3(1), dim3(128), 0, qs, (const i64 *)bstart, (i64)nb64, P + 1, d_off);
+    HIPCK(h, hipMemcpyAsync(off.data(), d_off, sizeof(i64) * (size_t)(P + 1), hipMemcpyDeviceToHost, qs));
+    HIPCK(h, hipStreamSynchronize(qs));
     for (int r = 0; r <= P; r++) entry_offsets[r] = off[(size_t)r];
     *digits_per_shard = (int64_t)nb64;
     *d_keys = (uint64_t *)h->keys.p;

@@ -120,10 +120,10 @@ struct Args {
     const i64 *pstart;
     const void *const *ptab;
     u32 *maxrun_seen;  // longest column run any segment of this flush met (atomicMax)
-    // FRESH kernels on whole-column segments of a full key window: the segment writes colptr (1-based) for its own
-    // columns itself -- no column-end marks, no scan over all columns afterwards (nullptr: marks in colend)
+    // FRESH kernels on whole-column segments that cover the flush's column range: the segment writes colptr (1-based)
+    // for its own columns itself -- no column-end marks, no scan over the columns afterwards (nullptr: marks in colend)
     i64 *colptr_out;
-    i64 ncols;  // columns of the matrix (colptr_out[ncols] = 1 + nnz comes from the last segment)
+    i64 col_end;  // end of the column range (colptr_out[col_end] = 1 + nnz comes from the last segment)
 };
 constexpr int MAX_PIECES = 64;
 
@@ -956,10 +956,10 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         }
     }
     if (direct) {  // the columns behind the last entry (all of them for an empty segment)
-        const i64 c_hi = min(c_lo + ((i64)1 << a.cl_bits), a.ncols);
+        const i64 c_hi = min(c_lo + ((i64)1 << a.cl_bits), a.col_end);
         const i64 after = total > 0 ? (i64)(skey[total - 1] >> a.rb) + 1 : c_lo;
         for (i64 c = after + t; c < c_hi; c += THREADS) a.colptr_out[c] = (i64)(dst + (u64)total) + 1;
-        if (s == a.S - 1 && t == 0) a.colptr_out[a.ncols] = (i64)(dst + (u64)total) + 1;
+        if (s == a.S - 1 && t == 0) a.colptr_out[a.col_end] = (i64)(dst + (u64)total) + 1;
     }
 #ifdef ESP_LOCAL_STAMPS
     if (a.stamps) {

@@ -75,9 +75,9 @@ __device__ __forceinline__ u32 digit16(const Args &a, u64 key, bool check) {
 // MULTI: the window of a key -- almost always the one of the wave's first key (r0, found once per wave
 // with scalar code), else a binary search in the LDS copy of mw_base -- then the digit inside it
 struct WaveWin {
-    u32 r0;     // window of the wave's first key
-    u64 base0;  // its first key
-    u64 width;  // keys up to the next window's first key
+    u32 d0;      // first global digit of the window of the wave's first key
+    u64 base4;   // its first key, as a packed key (kind bits = 0)
+    u64 width4;  // packed keys up to the next window's first key
 };
 __device__ __forceinline__ WaveWin wave_window(const Args &a, const u64 *s_mw, u64 first_key) {
     const u64 kp = esp_uniform_u64(first_key) >> ESP_TAG_BITS;
@@ -87,17 +87,21 @@ __device__ __forceinline__ WaveWin wave_window(const Args &a, const u64 *s_mw, u
         if (c < a.mw_P && kp >= esp_uniform_u64(s_mw[c])) r = c;
     }
     const u64 b0 = esp_uniform_u64(s_mw[r]);
-    const u64 next = r + 1 < a.mw_P ? esp_uniform_u64(s_mw[r + 1]) : ~0ull;  // (a window ends where the next one starts)
-    return WaveWin{(u32)r, b0, next - b0};
+    // (a window ends where the next one starts; the last one is open -- up to the largest key, so that a key
+    // BELOW the window, whose difference wraps around, still fails the width test)
+    const u64 b4 = b0 << ESP_TAG_BITS;
+    const u64 w4 = r + 1 < a.mw_P ? (esp_uniform_u64(s_mw[r + 1]) - b0) << ESP_TAG_BITS : ~0ull - b4;
+    return WaveWin{(u32)r * a.mw_nb, b4, w4};
 }
 template <bool MULTI>
 __device__ __forceinline__ u32 digit_mw(const Args &a, const u64 *s_mw, const WaveWin &ww, u64 key, bool check) {
     if constexpr (!MULTI) {
         return digit16(a, key, check);
     } else {
+        // (the kind bits ride along, as in digit16: one subtraction, one compare, one shift)
+        const u64 rel0 = key - ww.base4;
+        if (rel0 < ww.width4) return ww.d0 + (u32)(rel0 >> (a.shift + ESP_TAG_BITS));
         const u64 kp = key >> ESP_TAG_BITS;
-        const u64 rel0 = kp - ww.base0;
-        if (rel0 < ww.width) return ww.r0 * a.mw_nb + (u32)(rel0 >> a.shift);
         int r = 0;
 #pragma unroll
         for (int step = MW_MAX / 2; step; step >>= 1) {

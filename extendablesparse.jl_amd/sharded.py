@@ -194,6 +194,10 @@ class HipShardBackend:
         counts = _wrap_device(torch, pc.value, P * nb.value, torch.int64, self.device)
         return keys, vals, counts, eoff, int(nb.value)
 
+    def part_wait(self):
+        """The key/value views of part_partition are complete (the scatter kernel may still run when it returns)."""
+        self.A.synchronize()
+
     def part_assemble(self, P, me, rkeys, rvals, rcounts, recv_entries):
         """rkeys/rvals/rcounts: per source rank a device tensor (entry `me` ignored).  The tensors are
         kept alive until the flush.  -> True: the flush runs on the pieces; False: plain pending buffer."""
@@ -344,6 +348,7 @@ class ShardedExtendableSparseMatrix:
             return False
         self._part_penalty = 0
         self._eps = -(-total // P) if total else None
+        be.part_wait()   # (the consensus round above ran beside the partition's scatter kernel)
         keys, vals, cnts, eoff, nb = part
         in_x = [int(c) for c in counts]
         in_x[me] = 0

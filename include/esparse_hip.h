@@ -214,7 +214,9 @@ int32_t esp_shard_exchange_place(esp_handle *h, int64_t position, const uint64_t
  *     the pending entries are intact (possibly permuted in a way that keeps the order per entry).
  *     *ok = 1: owner r's entries are d_keys/d_vals[entry_offsets[r] .. entry_offsets[r+1]) and its
  *     per-digit counts d_counts[r*digits .. (r+1)*digits) (device pointers, valid until the next
- *     append or flush).  Send every OTHER owner its range and its counts.
+ *     append or flush).  Send every OTHER owner its range and its counts.  entry_offsets and d_counts are
+ *     final on return; the kernel that moves the entries into d_keys/d_vals may still be running on the
+ *     handle's stream (the callers' consensus round fits beside it): esp_synchronize(h) before reading them.
  *   esp_shard_assemble: device pointers of the blocks received from every source rank (index = source;
  *     the own index is ignored; recv_entries[q] = entries in block q, counts blocks hold `digits`
  *     values).  The buffers must stay alive until esp_flush returns: the bucket kernel reads a segment

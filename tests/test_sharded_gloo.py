@@ -82,6 +82,9 @@ class CpuShardBackend:
         return (torch.from_numpy(self.keys.copy()), torch.from_numpy(self.vals.copy()), torch.from_numpy(self._cnt.copy()),
                 self._eoff, nb)
 
+    def part_wait(self):
+        pass
+
     def part_assemble(self, P, me, rkeys, rvals, rcounts, recv_entries):
         nb = self.NB
         blocks = []

@@ -1,8 +1,9 @@
 #!/bin/bash
+# usage: tools/step_trace.sh [bench args, e.g. --sharded]
 # Ordered kernel trace of the LAST bench step (name, start offset us, duration us, gap to previous us) -> gpurun_out/step_trace.txt
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/trc
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/trc -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > gpurun_out/trc.log 2>&1
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/trc -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > gpurun_out/trc.log 2>&1
 python3 - <<'P'
 import csv, glob
 rows = []
