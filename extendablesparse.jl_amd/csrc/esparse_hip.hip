@@ -75,6 +75,11 @@ struct esp_handle {
         DevBuf d_rows, d_cols, d_vals, d_kinds;
     } stage, bulk;
     unsigned long long *pin_scalar = nullptr;  // pinned, 8 slots
+    // kind bookkeeping of the pending batch: when every pending entry was appended with ONE known kind the run-based
+    // partition hands the bucket kernel 4-byte keys (the key bits below the partition prefix) instead of packed keys
+    i64 kind_noted = 0;     // pending entries appended with a single known kind
+    int kind_uniform = -1;  // that kind; -1 none yet, -2 mixed / an append of unknown kinds (until the buffer is empty again)
+    int last_key_bytes = 8;      // esp_debug_last_key_bytes
     int last_run_order = 0;      // esp_debug_last_run_order
     int last_colptr_direct = 0;  // the bucket kernel of the last flush wrote colptr itself
     hipStream_t aux = nullptr;   // second stream + event: small device-to-host reads beside a running kernel
@@ -108,11 +113,23 @@ static void par_memcpy(void *dst, const void *src, size_t bytes);
 
 // the pending entries changed: whatever was derived from them is stale
 static inline void pending_changed(esp_handle *h) {
+    if (h->count == 0) {
+        h->kind_noted = 0;
+        h->kind_uniform = -1;
+    } else if (h->kind_noted != h->count) {
+        h->kind_uniform = -2;  // (some entries came or went without note_kind: sticky until the buffer is empty)
+    }
     h->shard_valid = false;
     h->part_valid = false;
     h->part_assembled = false;
 }
 
+// call right before h->count grows by cnt entries that all carry `kind`
+static inline void note_kind(esp_handle *h, int kind, i64 cnt) {
+    if (h->count == 0 && h->kind_noted == 0 && h->kind_uniform == -1) h->kind_uniform = kind;
+    else if (h->kind_uniform != kind) h->kind_uniform = -2;
+    h->kind_noted += cnt;
+}
 static bool fused_begin(esp_handle *h, i64 E_call, i64 nchunks, espgen::Fused *f);
 static void fused_invalidate(esp_handle *h);
 static void fused_reset(esp_handle *h);
@@ -480,6 +497,7 @@ static int32_t pack_device(esp_handle *h, const i64 *d_rows, const i64 *d_cols, 
     if (h->pin_scalar[0] != ~0ull)
         FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
              (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
+    if (!d_kinds) note_kind(h, kind_all, count);
     h->count += count;
     pending_changed(h);
     return ESP_OK;
@@ -617,6 +635,7 @@ extern "C" int32_t esp_append_host(esp_handle *h, const int64_t *rows, const int
     if (h->pin_scalar[0] != ~0ull)
         FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
              (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
+    if (!kinds) note_kind(h, kind_all, count);
     h->count += count;
     pending_changed(h);
     return ESP_OK;
@@ -703,6 +722,7 @@ extern "C" int32_t esp_generate_fdrand_range(esp_handle *h, int64_t nx, int64_t 
         sp.add(1);
     }
     HIPCK(h, hipGetLastError());
+    note_kind(h, kind, E);
     h->count += E;
     pending_changed(h);
     return ESP_OK;
@@ -1050,6 +1070,8 @@ struct Sorted {
     const i64 *seg_start;
     int rem_bits;
     bool local_ok;
+    int key_bytes = 8;  // 4: sk holds 32-bit keys (the bits below the prefix); every entry has the kind `kind`
+    int kind = 0;
     // PIECES (partitioned shard exchange): segments are concatenations of per-source pieces
     int npieces = 0;
     const i64 *pstart = nullptr;
@@ -1195,7 +1217,7 @@ static int32_t aux_ready(esp_handle *h) {
 // mw != nullptr: buckets = mw->P * mw->nb (window r = digits [r*nb, (r+1)*nb)), pb = bits covering them
 static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u64 *kout, double *vout, int K, int pb,
                              i64 *seg_out, u64 *tile_first_out, bool *tiles_ready, bool *ok, i64 *maxlen_out,
-                             const MultiWin *mw = nullptr, int mw_shift = 0) {
+                             const MultiWin *mw = nullptr, int mw_shift = 0, bool allow_k32 = false, int *key_bytes_out = nullptr) {
     const i64 E = h->count;
     const i64 NB = mw ? (i64)mw->P * (i64)mw->nb : (i64)1 << pb;
     CK(ensure(h, h->misc, 256));
@@ -1256,6 +1278,9 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
     a.dlist = nullptr;
     a.nruns_raw = 0;
     a.flags = nullptr;
+    a.maxlen = nullptr;
+    a.cap = 0;
+    if (key_bytes_out) *key_bytes_out = 8;
     *tiles_ready = false;
     // ranked: every digit collects its own runs, ONE kernel turns them into run offsets (run_rank_k), the
     // scatter kernel follows without a host round trip (force_path 12: the radix-ordered run list instead)
@@ -1295,12 +1320,20 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
         HIPCK(h, hipEventRecord(h->aux_ev, h->stream));
         a.nruns_raw = 1;
         a.flags = flags;
+        // 4-byte keys for the bucket kernel: one kind for all pending entries, <= 32 key bits below the prefix, no
+        // further pass (force_path 14: packed keys always)
+        const bool k32 = allow_k32 && key_bytes_out && !mw && h->force_path != 14 && h->kind_uniform >= 0 && h->kind_noted == E &&
+                         a.shift <= 32;
+        a.maxlen = d_maxlen;
+        a.cap = esplocal::CAP;
         {
             Span sp(h, ESP_ST_SCATTER);
             if (mw)
-                hipLaunchKernelGGL((esprun::run_scatter_k<true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
+                hipLaunchKernelGGL((esprun::run_scatter_k<true, false>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
+            else if (k32)
+                hipLaunchKernelGGL((esprun::run_scatter_k<false, true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
             else
-                hipLaunchKernelGGL((esprun::run_scatter_k<false>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
+                hipLaunchKernelGGL((esprun::run_scatter_k<false, false>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
             sp.add(1);
         }
         HIPCK(h, hipStreamWaitEvent(h->aux, h->aux_ev, 0));
@@ -1314,6 +1347,7 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
         if (f_err) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (partition)");
         h->last_run_order = f_many ? 3 : 1;
         if (!f_many) {
+            if (key_bytes_out) *key_bytes_out = (k32 && (i64)h->pin_scalar[0] <= (i64)esplocal::CAP) ? 4 : 8;
             *maxlen_out = (i64)h->pin_scalar[0];
             HIPCK(h, hipGetLastError());
             *ok = true;
@@ -1401,9 +1435,9 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
     {
         Span sp(h, ESP_ST_SCATTER);
         if (mw)
-            hipLaunchKernelGGL((esprun::run_scatter_k<true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
+            hipLaunchKernelGGL((esprun::run_scatter_k<true, false>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
         else
-            hipLaunchKernelGGL((esprun::run_scatter_k<false>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
+            hipLaunchKernelGGL((esprun::run_scatter_k<false, false>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
         sp.add(1);
     }
     HIPCK(h, hipGetLastError());
@@ -1460,8 +1494,14 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
             bool took = false;
             i64 ml = E;
             bool tr = false;
-            CK(run_partition(h, kin, vin, kout, vout, K, pb, (i64 *)h->seg[1].p, (u64 *)h->tilef[1].p, &tr, &took, &ml));
-            if (took) tiles_ready = tr;
+            int kb = 8;
+            CK(run_partition(h, kin, vin, kout, vout, K, pb, (i64 *)h->seg[1].p, (u64 *)h->tilef[1].p, &tr, &took, &ml, nullptr, 0,
+                             /*allow_k32=*/pb >= planned_run, &kb));
+            if (took) {
+                tiles_ready = tr;
+                out->key_bytes = kb;
+                out->kind = h->kind_uniform;
+            }
             if (took) {
                 std::swap(kin, kout);
                 std::swap(vin, vout);
@@ -1562,6 +1602,8 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
         HIPCK(h, hipStreamSynchronize(h->stream));
         if ((u32)h->pin_scalar[2]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (partition)");
     }
+    if (out->key_bytes == 4 && (pass_idx > 0 || cur != 1))
+        FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (4-byte keys met a further partition pass)");
     out->sk = kin;
     out->sv = vin;
     out->in_primary = (kin == (u64 *)h->keys.p);
@@ -1688,6 +1730,8 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     };
     {
         Span sp(h, ESP_ST_LOCAL);
+        a.kind32 = (u32)(st.key_bytes == 4 ? st.kind : 0);
+        h->last_key_bytes = st.key_bytes;
         a.colptr_out = direct ? (i64 *)h->colptr.p : nullptr;
         a.col_end = col_end;
         a.keys_in = st.sk;
@@ -1731,14 +1775,17 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
             a.first = first;
             // (the variant with the 24-input register tier for a matrix whose last flush met such runs)
             const bool big = h->seen_maxrun > 16 && h->seen_maxrun <= esplocal::REG_RUN;
-#define ESP_LAUNCH_LOCAL(F, P, B) hipLaunchKernelGGL((esplocal::local_k<F, P, B>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a)
+#define ESP_LAUNCH_LOCAL(F, P, B, K) hipLaunchKernelGGL((esplocal::local_k<F, P, B, K>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a)
             if (st.npieces > 0) {
-                if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true); else ESP_LAUNCH_LOCAL(true, true, false); }
-                else { if (big) ESP_LAUNCH_LOCAL(false, true, true); else ESP_LAUNCH_LOCAL(false, true, false); }
+                if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, false); else ESP_LAUNCH_LOCAL(true, true, false, false); }
+                else { if (big) ESP_LAUNCH_LOCAL(false, true, true, false); else ESP_LAUNCH_LOCAL(false, true, false, false); }
+            } else if (st.key_bytes == 4) {
+                if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, false, true, true); else ESP_LAUNCH_LOCAL(true, false, false, true); }
+                else { if (big) ESP_LAUNCH_LOCAL(false, false, true, true); else ESP_LAUNCH_LOCAL(false, false, false, true); }
             } else if (Z0 == 0) {
-                if (big) ESP_LAUNCH_LOCAL(true, false, true); else ESP_LAUNCH_LOCAL(true, false, false);
+                if (big) ESP_LAUNCH_LOCAL(true, false, true, false); else ESP_LAUNCH_LOCAL(true, false, false, false);
             } else {
-                if (big) ESP_LAUNCH_LOCAL(false, false, true); else ESP_LAUNCH_LOCAL(false, false, false);
+                if (big) ESP_LAUNCH_LOCAL(false, false, true, false); else ESP_LAUNCH_LOCAL(false, false, false, false);
             }
 #undef ESP_LAUNCH_LOCAL
         }
@@ -1909,6 +1956,11 @@ extern "C" int32_t esp_debug_force_path(esp_handle *h, int32_t path) {
 extern "C" int32_t esp_debug_last_run_order(const esp_handle *h, int32_t *kind) {
     if (!h || !kind) return ESP_ERR_INVALID;
     *kind = h->last_run_order;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_last_key_bytes(const esp_handle *h, int32_t *bytes) {
+    if (!h || !bytes) return ESP_ERR_INVALID;
+    *bytes = h->last_key_bytes;
     return ESP_OK;
 }
 extern "C" int32_t esp_debug_last_colptr_direct(const esp_handle *h, int32_t *direct) {

@@ -122,6 +122,7 @@ struct Args {
     u32 *maxrun_seen;  // longest column run any segment of this flush met (atomicMax)
     // FRESH kernels on whole-column segments that cover the flush's column range: the segment writes colptr (1-based)
     // for its own columns itself -- no column-end marks, no scan over the columns afterwards (nullptr: marks in colend)
+    u32 kind32;  // K32 kernels: the kind of every entry
     i64 *colptr_out;
     i64 col_end;  // end of the column range (colptr_out[col_end] = 1 + nnz comes from the last segment)
 };
@@ -535,8 +536,11 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
 // BIG: the kernel also carries the 24-input register tier.  It is a separate instantiation because the
 // extra code costs the common path registers (measured: +25 % on the 12-input tier when both live in one
 // kernel); the host picks it for a handle whose last flush met runs of 17..24 (a.maxrun_seen).
-template <bool FRESH, bool PIECES, bool BIG>
+// K32 (never with PIECES): keys_in holds 4-byte keys -- the key bits below the segment's prefix -- and every entry
+// has the kind a.kind32 (the run-based partition writes them when all pending entries share one kind)
+template <bool FRESH, bool PIECES, bool BIG, bool K32>
 __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
+    static_assert(!(PIECES && K32), "pieces arrive as packed keys");
     __shared__ u64 skey[CAP];
     __shared__ double sval[CAP];
     // radix tail: cnt[WAVES][256]; column tiers: ccnt[CL_MAX+1] (same storage)
@@ -584,16 +588,25 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         n = (int)(seg_end - beg);
         // shared prefix of the segment (window-relative), turned back into an absolute key prefix
         // (an empty segment has no key to take it from: its index is the prefix)
-        hi = n > 0 ? esp_uniform_u64(((((a.keys_in[beg] >> ESP_TAG_BITS) - a.base) >> a.rem_bits) << a.rem_bits) + a.base)
-                   : ((u64)s << a.rem_bits) + a.base;
+        if constexpr (K32)
+            hi = ((u64)s << a.rem_bits) + a.base;
+        else
+            hi = n > 0 ? esp_uniform_u64(((((a.keys_in[beg] >> ESP_TAG_BITS) - a.base) >> a.rem_bits) << a.rem_bits) + a.base)
+                       : ((u64)s << a.rem_bits) + a.base;
         // all 16 loads of a thread are issued before anything depends on them: the index is clamped so
         // that the loads need no branch (slots past the end re-read the last entry and are discarded)
         // (an empty segment reads its predecessor's last entry instead -- or entry 0 -- and ignores it: one
         // guard per load would cost two scalar instructions each)
         const i64 lbeg = n > 0 ? beg : max(beg - 1, (i64)0);
         const int nlast = n > 0 ? n - 1 : 0;
+        if constexpr (K32) {
+            const u32 *k32 = reinterpret_cast<const u32 *>(a.keys_in);
 #pragma unroll
-        for (int i = 0; i < ITEMS; i++) k[i] = a.keys_in[lbeg + min(wbase + i * ESP_WAVE, nlast)];
+            for (int i = 0; i < ITEMS; i++) k[i] = (u64)k32[lbeg + min(wbase + i * ESP_WAVE, nlast)];
+        } else {
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) k[i] = a.keys_in[lbeg + min(wbase + i * ESP_WAVE, nlast)];
+        }
 #pragma unroll
         for (int i = 0; i < ITEMS; i++) vraw[i] = a.vals_in[lbeg + min(wbase + i * ESP_WAVE, nlast)];
     } else {
@@ -669,9 +682,15 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         // key - hi4 = (bits below the segment's prefix) << 2 | kind for every entry of the segment;
         // anything above is an entry outside the declared key window / the segment (reported to
         // the host, which rejects the flush)
-        const u64 rel = key - hi4;
-        bad |= rel >> (a.rem_bits + ESP_TAG_BITS);
-        const u64 kk = ((rel & ~(u64)ESP_TAG_MASK) << IDX_BITS) | (u64)(u32)((p << ESP_TAG_BITS) | ((u32)key & (u32)ESP_TAG_MASK));
+        u64 kk;
+        if constexpr (K32) {
+            // (the partition masked the key to the bits below the prefix: nothing to check)
+            kk = (key << SUB_SHIFT) | (u64)(u32)((p << ESP_TAG_BITS) | a.kind32);
+        } else {
+            const u64 rel = key - hi4;
+            bad |= rel >> (a.rem_bits + ESP_TAG_BITS);
+            kk = ((rel & ~(u64)ESP_TAG_MASK) << IDX_BITS) | (u64)(u32)((p << ESP_TAG_BITS) | ((u32)key & (u32)ESP_TAG_MASK));
+        }
         k[i] = p < n ? kk : NOREC;  // NOREC sorts behind every real entry
     }
     if (bad != 0 && n > 0) atomicOr(a.err, 2u);

@@ -51,6 +51,11 @@ struct Args {
     u32 *dcount;     // [nbuckets] runs of the digit
     u64 *dlist;      // [nbuckets][DCAP]
     int nruns_raw;   // nruns holds the counts themselves, not their scan
+    // K32 scatter kernels: when the longest bucket fits the bucket kernel (*maxlen <= cap) the key goes out as 4
+    // bytes -- its bits below the partition prefix, (key >> 2) - base masked to `shift` (<= 32) bits; the kind is the
+    // same for all pending entries and travels outside the data
+    const unsigned long long *maxlen;
+    i64 cap;
     const u32 *flags;  // run_scatter_k leaves at once when flags[0], [1] or [3] is set (window error, too many
                        // digits in a chunk, too many runs of a digit): the host reads them while it runs
     // several key windows side by side (column shards, MULTI kernels): window r starts at key mw_base[r]
@@ -363,7 +368,7 @@ __global__ __launch_bounds__(THREADS) void run_rank_k(const unsigned long long *
     }
 }
 
-template <bool MULTI>
+template <bool MULTI, bool K32>
 __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
     __shared__ u64 s_mw[MULTI ? MW_MAX : 1];
     __shared__ u32 hd[RMAX];  // open-addressing map digit -> run index of this tile
@@ -477,13 +482,20 @@ __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
         }
     }
     __syncthreads();
+    bool short_keys = false;
+    if constexpr (K32) short_keys = *a.maxlen <= (unsigned long long)a.cap;  // (uniform; the host applies the same rule)
+    const u32 kmask = a.shift >= 32 ? 0xFFFFFFFFu : ((1u << a.shift) - 1u);
+    const u64 base4 = a.base << ESP_TAG_BITS;
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         const i64 idx = wbase + k * ESP_WAVE;
         if (idx < end) {
             const int jj = jrun[k];
             const i64 dst = roff[jj] + (i64)cnt[w][jj] + (i64)rank[k];
-            a.keys_out[dst] = key[k];
+            if (K32 && short_keys)
+                reinterpret_cast<u32 *>(a.keys_out)[dst] = (u32)((key[k] - base4) >> ESP_TAG_BITS) & kmask;
+            else
+                a.keys_out[dst] = key[k];
             a.vals_out[dst] = val[k];
         }
     }

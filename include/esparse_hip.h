@@ -248,7 +248,8 @@ int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear);
  * run-based single-pass partition (8-bit passes only), 7 = the device generators emit the run lists of their chunks themselves (skips the
  * histogram kernel; off by default: no net gain measured), 11 = esp_shard_partition reports "not applicable",
  * 12 = the run-based partition orders its run list with radix passes (several small launches and a host round
- * trip) instead of the one ranking kernel, 13 = the bucket kernel of a fresh matrix marks column ends and a scan
+ * trip) instead of the one ranking kernel, 14 = packed 8-byte keys for the bucket kernel always,
+ * 13 = the bucket kernel of a fresh matrix marks column ends and a scan
  * over all columns builds colptr (instead of every segment writing the colptr of its own columns);
  * last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general) */
 int32_t esp_debug_force_path(esp_handle *h, int32_t path);
@@ -260,6 +261,10 @@ int32_t esp_debug_last_run_order(const esp_handle *h, int32_t *kind);
 /* 1 when the bucket kernel of the last flush wrote colptr itself (fresh matrix, full key window, segments = whole
  * blocks of at most 2048 columns), 0 when column-end marks + a scan over the columns did */
 int32_t esp_debug_last_colptr_direct(const esp_handle *h, int32_t *direct);
+/* bytes per key the bucket kernel of the last flush read: 4 when every pending entry had been appended with one
+ * known kind, at most 32 key bits were left below the partition prefix and the run-based partition served the
+ * flush (it then writes only those bits), else 8 (packed keys) */
+int32_t esp_debug_last_key_bytes(const esp_handle *h, int32_t *bytes);
 /* which partition the last flush used: 1 = run-based single pass (pre-sorted stream), 2 = 8-bit passes,
  * 3 = run-based single pass on run lists the producers emitted (no histogram kernel),
  * 7 = none: the segments came assembled from esp_shard_assemble */

@@ -556,7 +556,7 @@ def test_empty_and_tiny(esp):
 
 
 # ------------------------------------------------------------------ full-size properties
-@pytest.mark.parametrize("force", [0, 5, 7, 12])
+@pytest.mark.parametrize("force", [0, 5, 7, 12, 14])
 def test_run_partition_vs_passes(esp, orc, force):
     """Pre-sorted stream (48^3 stencil, E > 2^20): the run-based single-pass partition and the 8-bit
     passes give the same bits; a shuffled stream falls back to the passes."""
@@ -567,9 +567,11 @@ def test_run_partition_vs_passes(esp, orc, force):
     A.generate_fdrand(n, n, n, seed=21, rand_mode=1)
     A.flush()
     # 3: the generator emitted the run lists itself; 1: histogram kernel; 2: 8-bit passes
-    assert A.debug_last_partition() == {0: 1, 5: 2, 7: 3, 12: 1}[force]
+    assert A.debug_last_partition() == {0: 1, 5: 2, 7: 3, 12: 1, 14: 1}[force]
     if force in (0, 12):  # run offsets from the ranking kernel / from the radix-ordered run list
         assert A.debug_last_run_order() == (1 if force == 0 else 2)
+    # one kind for the whole batch + ranking kernel: the bucket kernel reads 4-byte keys (14: packed keys)
+    assert A.debug_last_key_bytes() == (4 if force == 0 else 8)
     O = orc.fdrand(n, n, n, rand_mode=1, seed=21, style=orc.KIND_UPDATE)
     assert_csc_equal(hip_arrays(A), O.arrays())
     # same entries in random order: too many distinct digits per tile -> 8-bit passes
@@ -619,6 +621,55 @@ def test_presorted_stream_mixed_kinds(esp, orc, force):
         O.flush()
         assert A.debug_last_path() == 1
         assert A.debug_last_partition() == (2 if force == 5 else 1)
+        assert A.debug_last_key_bytes() == 8          # per-entry kinds: packed keys
+        assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
+
+
+def test_four_byte_keys_only_for_a_batch_of_one_kind(esp, orc):
+    """The bucket kernel gets 4-byte keys only when EVERY pending entry was appended with one known kind; batches of
+    several appends, a different kind, a per-entry kinds array, packed keys from outside, a flush in between (the
+    bookkeeping starts over), re-assembly over the stored pattern: the oracle's bits each time."""
+    rng = np.random.default_rng(123)
+    m, n = 90000, 110000
+
+    def stream(cnt):
+        J = np.sort(rng.integers(1, n + 1, cnt))
+        I = np.clip(J + rng.integers(-4, 5, cnt), 1, m)
+        return I, J, rng.standard_normal(cnt)
+
+    A = esp.ExtendableSparseMatrix(m, n)
+    O = orc.ExtendableSparseMatrix(m, n)
+    plans = [
+        ([UPDATE, UPDATE], None, 4),          # two appends, one kind
+        ([RAW, RAW, RAW], None, 4),           # re-assembly + new entries, another kind than the last batch
+        ([UPDATE, SET], None, 8),             # two kinds
+        ([SET], None, 4),
+        ([UPDATE], "kinds", 8),               # per-entry kinds array (all equal, but unknown to the host)
+        ([UPDATE], "packed", 8),              # packed keys handed over on the device
+        ([UPDATE], None, 4),
+    ]
+    for rnd, (kinds_of, special, expect) in enumerate(plans):
+        for kd in kinds_of:
+            I, J, V = stream(1000000)
+            if special == "kinds":
+                A.append(0, I, J, V, kinds=np.full(len(I), kd, np.uint8))
+            elif special == "packed":
+                import ctypes
+                src = esp.HipShardBackend(m, n)
+                src.A.append(kd, I, J, V)
+                kk, vv, _ = src.shard_export(1)             # packed keys + values on the device, append order
+                d = A._d
+                d.commit()
+                d.ck(d.lib.esp_append_packed(d.h, ctypes.c_void_p(kk.data_ptr()), ctypes.c_void_p(vv.data_ptr()), kk.numel()))
+                d.ck(d.lib.esp_synchronize(d.h))
+                A._touch()
+            else:
+                A.append(kd, I, J, V)
+            O.apply(np.full(len(I), kd, np.uint8), I, J, V)
+        A.flush()
+        O.flush()
+        assert A.debug_last_partition() == 1, rnd
+        assert A.debug_last_key_bytes() == expect, (rnd, A.debug_last_key_bytes())
         assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
 
 
