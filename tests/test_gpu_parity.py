@@ -1093,6 +1093,36 @@ def test_partitioned_exchange_merged_segment_overflow(esp, orc):
     assert hist[0] == [("partitioned", 7)] and hist[1][0][0] == "partitioned" and hist[1][0][1] != 7, hist
 
 
+def test_failed_fresh_flush_leaves_the_empty_matrix_intact(esp, orc):
+    """A fresh flush whose bucket kernel writes colptr itself and then meets an entry outside the declared
+    window: the flush fails, colptr is all ones again (nnz 0), and the matrix works afterwards."""
+    rng = np.random.default_rng(32)
+    m, n = 3000, 40000
+    lo, hi = 20001, 21000
+    cnt = 3000                                        # one segment: the bucket kernel is the first to look at the keys
+    I = rng.integers(1, m + 1, cnt)
+    J = rng.integers(lo, hi + 1, cnt)
+    V = rng.standard_normal(cnt)
+    A = esp.ExtendableSparseMatrix(m, n)
+    A.set_column_window(lo, hi)
+    A.append(UPDATE, I, J, V)
+    A.append(UPDATE, [1, 2, 3], [hi + 5, hi + 6, 7], [1.0, 2.0, 3.0])
+    with pytest.raises(esp.EspError):
+        A.flush()
+    d = A._d                                          # (the accessors would flush again: drop the batch first)
+    d.ck(d.lib.esp_clear_pending(d.h))
+    A._touch()
+    assert A.nnz() == 0
+    assert np.all(A.getcolptr() == 1)
+    A.reset()
+    O = orc.ExtendableSparseMatrix(m, n)
+    A.append(UPDATE, I, J, V)
+    O.apply(np.full(cnt, UPDATE, np.uint8), I, J, V)
+    A.flush()
+    assert A.debug_last_colptr_direct()
+    assert_csc_equal(hip_arrays(A), O.arrays())
+
+
 def test_column_window(esp, orc):
     rng = np.random.default_rng(31)
     m, n = 3000, 40000
