@@ -1776,16 +1776,21 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
             // (the variant with the 24-input register tier for a matrix whose last flush met such runs)
             const bool big = h->seen_maxrun > 16 && h->seen_maxrun <= esplocal::REG_RUN;
 #define ESP_LAUNCH_LOCAL(F, P, B, K) hipLaunchKernelGGL((esplocal::local_k<F, P, B, K>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a)
+            // (key format: 0 packed, 1 four-byte keys of one kind, 2 four-byte keys that are all UPDATEs)
+            const int keys = st.npieces > 0 || st.key_bytes != 4 ? 0 : (st.kind == ESP_UPDATE && h->force_path != 15 ? 2 : 1);
             if (st.npieces > 0) {
-                if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, false); else ESP_LAUNCH_LOCAL(true, true, false, false); }
-                else { if (big) ESP_LAUNCH_LOCAL(false, true, true, false); else ESP_LAUNCH_LOCAL(false, true, false, false); }
-            } else if (st.key_bytes == 4) {
-                if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, false, true, true); else ESP_LAUNCH_LOCAL(true, false, false, true); }
-                else { if (big) ESP_LAUNCH_LOCAL(false, false, true, true); else ESP_LAUNCH_LOCAL(false, false, false, true); }
+                if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 0); else ESP_LAUNCH_LOCAL(true, true, false, 0); }
+                else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 0); else ESP_LAUNCH_LOCAL(false, true, false, 0); }
+            } else if (keys == 2) {
+                if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, false, true, 2); else ESP_LAUNCH_LOCAL(true, false, false, 2); }
+                else { if (big) ESP_LAUNCH_LOCAL(false, false, true, 2); else ESP_LAUNCH_LOCAL(false, false, false, 2); }
+            } else if (keys == 1) {
+                if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, false, true, 1); else ESP_LAUNCH_LOCAL(true, false, false, 1); }
+                else { if (big) ESP_LAUNCH_LOCAL(false, false, true, 1); else ESP_LAUNCH_LOCAL(false, false, false, 1); }
             } else if (Z0 == 0) {
-                if (big) ESP_LAUNCH_LOCAL(true, false, true, false); else ESP_LAUNCH_LOCAL(true, false, false, false);
+                if (big) ESP_LAUNCH_LOCAL(true, false, true, 0); else ESP_LAUNCH_LOCAL(true, false, false, 0);
             } else {
-                if (big) ESP_LAUNCH_LOCAL(false, false, true, false); else ESP_LAUNCH_LOCAL(false, false, false, false);
+                if (big) ESP_LAUNCH_LOCAL(false, false, true, 0); else ESP_LAUNCH_LOCAL(false, false, false, 0);
             }
 #undef ESP_LAUNCH_LOCAL
         }

@@ -60,6 +60,14 @@ __device__ __forceinline__ void fold_step_sel(bool &present, double &acc, u32 ki
     present = np;
 }
 
+// The state machine when the entry is known to be an UPDATE: an absent position holds acc == +0.0, and
+// +0.0 + v is v for a creating update and +0.0 for v == +-0.0 -- the sum can be taken unconditionally,
+// bit for bit the result of fold_step.
+__device__ __forceinline__ void fold_step_update(bool &present, double &acc, double v) {
+    acc = acc + v;
+    present = present || (v != 0.0);
+}
+
 // findindex(csc,i,j) (sparsematrixcsc.jl:7-23) with 0-based row0/col0; returns 0-based
 // position in rowval/nzval or -1
 __device__ __forceinline__ i64 csc_find(const Csc &c, i64 col0, i64 row0) {

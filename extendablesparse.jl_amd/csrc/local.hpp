@@ -293,7 +293,8 @@ __device__ __forceinline__ void load_sorted_run(const u64 *skey, const double *s
 
 // number of entries a sorted run will emit when nothing of it is in the CSC: a (col,row) group
 // becomes present iff one of its updates is a RAWUPDATE / COO entry or has a non-zero value (fold_step)
-template <int R>
+// UPD: every entry is an UPDATE (the kernel was told so): no kind to decode
+template <int R, bool UPD>
 __device__ __forceinline__ u32 count_emitted(const u64 (&x)[R], const double (&xv)[R], int len) {
     u32 e = 0;
     bool any = false;
@@ -309,7 +310,10 @@ __device__ __forceinline__ u32 count_emitted(const u64 (&x)[R], const double (&x
                 psub = sub;
                 any = false;
             }
-            any |= ((u32)(x[j < R ? j : 0] & ESP_TAG_MASK) >= (u32)ESP_RAWUPDATE) || xv[j < R ? j : 0] != 0.0;
+            if constexpr (UPD)
+                any |= xv[j < R ? j : 0] != 0.0;
+            else
+                any |= ((u32)(x[j < R ? j : 0] & ESP_TAG_MASK) >= (u32)ESP_RAWUPDATE) || xv[j < R ? j : 0] != 0.0;
         }
     }
     return e;
@@ -317,7 +321,7 @@ __device__ __forceinline__ u32 count_emitted(const u64 (&x)[R], const double (&x
 
 // ordered fold of one sorted run held in registers; records go to skey[rs..), NOREC behind them
 // NOCSC: the matrix holds no entries yet (fresh build): no position can hit the CSC
-template <int R, bool NOCSC>
+template <int R, bool NOCSC, bool UPD>
 __device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval, const u64 (&x)[R], int rs, int len, u64 hi,
                                          u64 rowmask) {
     if constexpr (NOCSC) {
@@ -343,7 +347,12 @@ __device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval,
                 present = false;
                 acc = 0.0;
             }
-            if (valid) espfold::fold_step_sel(present, acc, (u32)(kj & ESP_TAG_MASK), xv[j < R ? j : 0]);
+            if (valid) {
+                if constexpr (UPD)
+                    espfold::fold_step_update(present, acc, xv[j < R ? j : 0]);
+                else
+                    espfold::fold_step_sel(present, acc, (u32)(kj & ESP_TAG_MASK), xv[j < R ? j : 0]);
+            }
         }
 #pragma unroll
         for (int j = 0; j < R; j++)
@@ -388,7 +397,10 @@ __device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval,
                 present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
                 acc = present ? a.csc.nzval[pos] : 0.0;
             }
-            espfold::fold_step_sel(present, acc, (u32)(kj & ESP_TAG_MASK), xv[j < R ? j : 0]);
+            if constexpr (UPD)
+                espfold::fold_step_update(present, acc, xv[j < R ? j : 0]);
+            else
+                espfold::fold_step_sel(present, acc, (u32)(kj & ESP_TAG_MASK), xv[j < R ? j : 0]);
         }
     }
 #pragma unroll
@@ -477,7 +489,7 @@ __device__ __forceinline__ u64 lookback_wave(const Args &a, int s, u32 total, in
 
 // Register tier of the bucket kernel: one lane per column, the whole run (<= R entries) in registers.
 // Returns true when the look-back already ran (early publication of the segment total).
-template <int R, bool FRESH>
+template <int R, bool FRESH, bool UPD>
 __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval, const u32 *ccnt, int ncl, int s, u64 hi,
                                          u64 rowmask, u32 *s_early, LbState &lb) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -493,7 +505,7 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
             rs = (int)ccnt[t];
             len = (int)ccnt[t + 1] - rs;
             load_sorted_run<R>(skey, sval, rs, len, x, xv);
-            ec = count_emitted<R>(x, xv, len);
+            ec = count_emitted<R, UPD>(x, xv, len);
         }
 #pragma unroll
         for (int dlt = 32; dlt > 0; dlt >>= 1) ec += (u32)__shfl_xor((int)ec, dlt, ESP_WAVE);
@@ -516,7 +528,7 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
         } else if (t < ncl) {
             // (measured: keeping the sorted keys in registers across the barrier and re-reading
             // only the values beats writing the run back to LDS)
-            fold_run<R, true>(a, skey, sval, x, rs, len, hi, rowmask);
+            fold_run<R, true, UPD>(a, skey, sval, x, rs, len, hi, rowmask);
 #ifdef ESP_LOCAL_STAMPS
             if (a.stamps && t == 0) a.stamps[(size_t)s * 16 + 10] = wall_clock64();
 #endif
@@ -528,7 +540,7 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
         const int len = (int)ccnt[c + 1] - rs;
         u64 x[R];
         sort_run_keys<R>(skey, rs, len, x);
-        fold_run<R, FRESH>(a, skey, sval, x, rs, len, hi, rowmask);  // (a FRESH launch has an empty CSC)
+        fold_run<R, FRESH, UPD>(a, skey, sval, x, rs, len, hi, rowmask);  // (a FRESH launch has an empty CSC)
     }
     return false;
 }
@@ -536,10 +548,13 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
 // BIG: the kernel also carries the 24-input register tier.  It is a separate instantiation because the
 // extra code costs the common path registers (measured: +25 % on the 12-input tier when both live in one
 // kernel); the host picks it for a handle whose last flush met runs of 17..24 (a.maxrun_seen).
-// K32 (never with PIECES): keys_in holds 4-byte keys -- the key bits below the segment's prefix -- and every entry
-// has the kind a.kind32 (the run-based partition writes them when all pending entries share one kind)
-template <bool FRESH, bool PIECES, bool BIG, bool K32>
+// KEYS (0 with PIECES): 0 = packed 8-byte keys; 1 = keys_in holds 4-byte keys -- the key bits below the segment's
+// prefix -- and every entry has the kind a.kind32 (the run-based partition writes them when all pending entries
+// share one kind); 2 = the same and that kind is UPDATE (an assembly loop of updateindex! calls): the register
+// tiers fold without decoding a kind
+template <bool FRESH, bool PIECES, bool BIG, int KEYS>
 __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
+    constexpr bool K32 = KEYS != 0, UPD = KEYS == 2;
     static_assert(!(PIECES && K32), "pieces arrive as packed keys");
     __shared__ u64 skey[CAP];
     __shared__ double sval[CAP];
@@ -782,11 +797,11 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
                 // one lane per column: the whole run in registers, sorting network + ordered fold; the
                 // network is sized to the longest run of the segment (12 covers a 7-point stencil)
                 if (maxrun <= 12)
-                    lb_done = reg_tier<12, FRESH>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
+                    lb_done = reg_tier<12, FRESH, UPD>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
                 else if (!BIG || maxrun <= 16)
-                    lb_done = reg_tier<16, FRESH>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
+                    lb_done = reg_tier<16, FRESH, UPD>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
                 else if constexpr (BIG)
-                    lb_done = reg_tier<REG_RUN, FRESH>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
+                    lb_done = reg_tier<REG_RUN, FRESH, UPD>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
                 done = true;
             }
         }

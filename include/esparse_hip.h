@@ -248,7 +248,8 @@ int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear);
  * run-based single-pass partition (8-bit passes only), 7 = the device generators emit the run lists of their chunks themselves (skips the
  * histogram kernel; off by default: no net gain measured), 11 = esp_shard_partition reports "not applicable",
  * 12 = the run-based partition orders its run list with radix passes (several small launches and a host round
- * trip) instead of the one ranking kernel, 14 = packed 8-byte keys for the bucket kernel always,
+ * trip) instead of the one ranking kernel, 14 = packed 8-byte keys for the bucket kernel always, 15 = 4-byte keys but the generic fold (no UPDATE-only
+ * variant of the register tiers),
  * 13 = the bucket kernel of a fresh matrix marks column ends and a scan
  * over all columns builds colptr (instead of every segment writing the colptr of its own columns);
  * last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general) */

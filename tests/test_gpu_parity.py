@@ -556,7 +556,7 @@ def test_empty_and_tiny(esp):
 
 
 # ------------------------------------------------------------------ full-size properties
-@pytest.mark.parametrize("force", [0, 5, 7, 12, 14])
+@pytest.mark.parametrize("force", [0, 5, 7, 12, 14, 15])
 def test_run_partition_vs_passes(esp, orc, force):
     """Pre-sorted stream (48^3 stencil, E > 2^20): the run-based single-pass partition and the 8-bit
     passes give the same bits; a shuffled stream falls back to the passes."""
@@ -567,11 +567,12 @@ def test_run_partition_vs_passes(esp, orc, force):
     A.generate_fdrand(n, n, n, seed=21, rand_mode=1)
     A.flush()
     # 3: the generator emitted the run lists itself; 1: histogram kernel; 2: 8-bit passes
-    assert A.debug_last_partition() == {0: 1, 5: 2, 7: 3, 12: 1, 14: 1}[force]
+    assert A.debug_last_partition() == {0: 1, 5: 2, 7: 3, 12: 1, 14: 1, 15: 1}[force]
     if force in (0, 12):  # run offsets from the ranking kernel / from the radix-ordered run list
         assert A.debug_last_run_order() == (1 if force == 0 else 2)
-    # one kind for the whole batch + ranking kernel: the bucket kernel reads 4-byte keys (14: packed keys)
-    assert A.debug_last_key_bytes() == (4 if force == 0 else 8)
+    # one kind for the whole batch + ranking kernel: the bucket kernel reads 4-byte keys (14: packed keys;
+    # 0: the UPDATE-only variant of the register tiers, 15: the generic fold on 4-byte keys)
+    assert A.debug_last_key_bytes() == (4 if force in (0, 15) else 8)
     O = orc.fdrand(n, n, n, rand_mode=1, seed=21, style=orc.KIND_UPDATE)
     assert_csc_equal(hip_arrays(A), O.arrays())
     # same entries in random order: too many distinct digits per tile -> 8-bit passes

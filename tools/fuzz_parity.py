@@ -30,7 +30,7 @@ while time.time() < t_end:
     m = int(rng.choice([1, 2, 100, 4097, 10 ** 6, 2 ** 31 - 1, 2 ** 33, 2 ** 40]))
     A = esp.ExtendableSparseMatrix(m, n)
     O = orc.ExtendableSparseMatrix(m, n)
-    force = int(rng.choice([0, 0, 0, 2, 3, 4, 5, 12, 13, 14]))
+    force = int(rng.choice([0, 0, 0, 2, 3, 4, 5, 12, 13, 14, 15]))
     A.debug_force_path(force)
     nflush = int(rng.integers(1, 4))
     for f in range(nflush):
