@@ -111,7 +111,17 @@ def main():
         nzg = n * world
         N = n * n * nzg
         be = esp.HipShardBackend(N, N, device=local, capacity_hint=E + 4 * n * n)
-        SA = esp.ShardedExtendableSparseMatrix(N, N, be)
+        # the small agreements of a flush travel over a gloo group (host memory, loopback: one node): a device
+        # collective would sit behind the partition's scatter kernel
+        ctrl = None
+        if not os.environ.get("ESP_BENCH_NO_CTRL_GROUP"):
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            try:
+                ctrl = dist.new_group(backend="gloo")
+            except Exception as ex:   # (same outcome on every rank of the node: fall back to the data group)
+                print("bench: no gloo control group (%s), using the RCCL group" % ex, file=sys.stderr)
+                ctrl = None
+        SA = esp.ShardedExtendableSparseMatrix(N, N, be, ctrl_group=ctrl)
         A = be.matrix
         Z_total = N + 2 * ((n - 1) * n * nzg + n * (n - 1) * nzg + n * n * (nzg - 1))
         nodes = n ** 3

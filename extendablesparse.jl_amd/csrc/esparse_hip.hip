@@ -1209,7 +1209,13 @@ struct MultiWin {
 };
 
 static int32_t aux_ready(esp_handle *h) {
-    if (!h->aux) HIPCK(h, hipStreamCreateWithFlags(&h->aux, hipStreamNonBlocking));
+    if (!h->aux) {
+        // highest priority: its few tiny launches must get workgroup slots WHILE a kernel that fills the chip runs
+        // on the main stream (at equal priority they were seen to start only after that kernel had drained)
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        HIPCK(h, hipStreamCreateWithPriority(&h->aux, hipStreamNonBlocking, greatest));
+    }
     if (!h->aux_ev) HIPCK(h, hipEventCreateWithFlags(&h->aux_ev, hipEventDisableTiming));
     return ESP_OK;
 }

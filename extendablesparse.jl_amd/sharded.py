@@ -228,11 +228,16 @@ class HipShardBackend:
 class ShardedExtendableSparseMatrix:
     """ExtendableSparseMatrix whose columns are sharded over the ranks of a process group."""
 
-    def __init__(self, m, n, backend, group=None, dist=None):
+    def __init__(self, m, n, backend, group=None, dist=None, ctrl_group=None):
+        """ctrl_group: a process group over the same ranks for the small host-side agreements of a flush (entry
+        counts, "my stream is pre-sorted") -- a gloo group keeps them off the GPU, where a tiny collective queued
+        behind the partition's scatter kernel only runs once that kernel has drained (measured: the device copy
+        of three integers took the scatter kernel's 1.2 ms); None: the data group with device tensors."""
         if dist is None:   # (tests inject a stand-in that runs several ranks inside one process)
             import torch.distributed as dist
         self.dist = dist
         self.group = group
+        self.ctrl_group = ctrl_group
         self.rank = dist.get_rank(group)
         self.P = dist.get_world_size(group)
         self.m, self.n = int(m), int(n)
@@ -317,6 +322,11 @@ class ShardedExtendableSparseMatrix:
     def _gather_ints(self, values):
         """all_gather of a small int64 vector -> (P, len) numpy array (same on every rank)."""
         import torch
+        if self.ctrl_group is not None:   # host tensors over the control group: nothing is queued on the GPU
+            mine = torch.tensor(list(values), dtype=torch.int64)
+            out = [torch.empty_like(mine) for _ in range(self.P)]
+            self.dist.all_gather(out, mine, group=self.ctrl_group)
+            return torch.stack(out).numpy()
         dev = getattr(self.backend, "device", None)
         mine = torch.tensor(list(values), dtype=torch.int64, device=dev if dev is not None else "cpu")
         out = [torch.empty_like(mine) for _ in range(self.P)]

@@ -141,7 +141,12 @@ def _worker(rank, world, port, variant, q):
             mine = (np.arange(E) // 5) % world == rank
         kinds = np.where(np.arange(E) % 7 == 0, 2, 1).astype(np.uint8)   # mix UPDATE / RAWUPDATE
         be = CpuShardBackend(N, N, orc, esp)
-        A = esp.ShardedExtendableSparseMatrix(N, N, be)
+        ctrl = None
+        if mode == "partitioned_ctrl":   # the small agreements over a separate control group (bench.py's set-up)
+            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
+            ctrl = dist.new_group(backend="gloo")
+            mode = "partitioned"
+        A = esp.ShardedExtendableSparseMatrix(N, N, be, ctrl_group=ctrl)
         if mode == "partitioned3":   # counts, keys and values as three collectives (the path of large exchanges)
             sys.modules[type(A).__module__].ONE_MESSAGE_MAX_ELEMS = 0
             mode = "partitioned"
@@ -182,7 +187,7 @@ def _worker(rank, world, port, variant, q):
 
 
 @pytest.mark.parametrize("variant", ["slab/generic", "scrambled/generic", "slab/partitioned", "scrambled/partitioned",
-                                     "scrambled/partitioned3", "scrambled/rank1_fails"])
+                                     "scrambled/partitioned3", "scrambled/rank1_fails", "scrambled/partitioned_ctrl"])
 def test_shard_exchange_world2(variant):
     _run_world(2, variant)
 
