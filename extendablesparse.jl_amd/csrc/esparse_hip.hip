@@ -2390,16 +2390,15 @@ __global__ void diff_counts_k(const i64 *__restrict__ bstart, i64 NB, i64 *__res
 }
 
 // one workgroup per source q: pstart[q][0..nb] = exclusive scan of that source's per-digit counts
-// (q == me: the bucket starts of the own range, absolute positions in the partitioned buffer)
+// (q == me: the bucket starts of the own range -- absolute positions in the partitioned buffer -- which the host
+// copies into the row with a device-to-device copy; the workgroup only writes the summary)
 // summary[q] = entries of source q (q == me: of the own range), summary[P] = start of the own range
 __global__ __launch_bounds__(1024) void piece_scan_k(const i64 *const *__restrict__ counts, const i64 *__restrict__ own_bstart, int me,
                                                      i64 nb, i64 *__restrict__ pstart, i64 *__restrict__ summary) {
-    __shared__ i64 lw[16];
-    __shared__ i64 carry;
+    __shared__ i64 lw[2][16];
     const int q = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
     i64 *out = pstart + (size_t)q * (size_t)(nb + 1);
     if (q == me) {
-        for (i64 d = t; d <= nb; d += 1024) out[d] = own_bstart[d];
         if (t == 0) {
             summary[q] = own_bstart[nb] - own_bstart[0];
             summary[gridDim.x] = own_bstart[0];
@@ -2407,9 +2406,9 @@ __global__ __launch_bounds__(1024) void piece_scan_k(const i64 *const *__restric
         return;
     }
     const i64 *c = counts[q];
-    if (t == 0) carry = 0;
-    __syncthreads();
-    for (i64 b0 = 0; b0 < nb; b0 += 1024) {
+    i64 carry = 0;  // (the same in every thread: all of them add up the 16 wave totals of a round)
+    int buf = 0;
+    for (i64 b0 = 0; b0 < nb; b0 += 1024, buf ^= 1) {
         const i64 d = b0 + t;
         const i64 x = d < nb ? c[d] : 0;
         i64 inc = x;
@@ -2418,14 +2417,17 @@ __global__ __launch_bounds__(1024) void piece_scan_k(const i64 *const *__restric
             const i64 o = __shfl_up(inc, dlt, 64);
             if (lane >= dlt) inc += o;
         }
-        if (lane == 63) lw[w] = inc;
-        __syncthreads();
-        i64 pre = carry;
-        for (int i = 0; i < w; i++) pre += lw[i];
+        if (lane == 63) lw[buf][w] = inc;
+        __syncthreads();  // (one barrier per round: the wave totals alternate between two buffers)
+        i64 pre = carry, tot = 0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const i64 v = lw[buf][i];
+            pre += i < w ? v : 0;
+            tot += v;
+        }
         if (d < nb) out[d] = pre + inc - x;
-        __syncthreads();
-        if (t == 1023) carry = pre + inc;
-        __syncthreads();
+        carry += tot;
     }
     if (t == 0) {
         out[nb] = carry;
@@ -2437,14 +2439,21 @@ __global__ __launch_bounds__(1024) void piece_scan_k(const i64 *const *__restric
 __global__ void piece_totals_k(const i64 *__restrict__ pstart, int P, i64 nb, unsigned long long *__restrict__ maxlen,
                                unsigned long long *__restrict__ negative) {
     const i64 d = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (d >= nb) return;
     i64 tot = 0;
-    for (int q = 0; q < P; q++) {
-        const i64 len = pstart[(size_t)q * (size_t)(nb + 1) + d + 1] - pstart[(size_t)q * (size_t)(nb + 1) + d];
-        if (len < 0) atomicAdd(negative, 1ull);
-        tot += len;
+    bool neg = false;
+    if (d < nb)
+        for (int q = 0; q < P; q++) {
+            const i64 len = pstart[(size_t)q * (size_t)(nb + 1) + d + 1] - pstart[(size_t)q * (size_t)(nb + 1) + d];
+            neg |= len < 0;
+            tot += len;
+        }
+    if (neg) atomicAdd(negative, 1ull);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {  // one atomic per wave
+        const i64 x = __shfl_xor(tot, o, 64);
+        tot = x > tot ? x : tot;
     }
-    atomicMax(maxlen, (unsigned long long)tot);
+    if ((threadIdx.x & 63) == 0 && tot > 0) atomicMax(maxlen, (unsigned long long)tot);
 }
 
 extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t self, int64_t entries_per_shard, int32_t *ok,
@@ -2570,6 +2579,7 @@ extern "C" int32_t esp_shard_assemble(esp_handle *h, const uint64_t *const *d_re
     HIPCK(h, hipMemsetAsync(d_maxlen, 0, 16, h->stream));
     {
         Span sp(h, ESP_ST_SCAN);
+        HIPCK(h, hipMemcpyAsync(pstart + (size_t)me * (size_t)(nb + 1), bstart, sizeof(i64) * (size_t)(nb + 1), hipMemcpyDeviceToDevice, h->stream));
         hipLaunchKernelGGL(piece_scan_k, dim3((unsigned)P), dim3(1024), 0, h->stream, (const i64 *const *)(T + 128 * 8), bstart, me, nb, pstart, d_sum);
         hipLaunchKernelGGL(piece_totals_k, dim3(grid_for(nb, 256)), dim3(256), 0, h->stream, (const i64 *)pstart, P, nb, d_maxlen, d_maxlen + 1);
         sp.add(2);

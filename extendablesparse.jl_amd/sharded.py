@@ -202,7 +202,8 @@ class HipShardBackend:
         """rkeys/rvals/rcounts: per source rank a device tensor (entry `me` ignored).  The tensors are
         kept alive until the flush.  -> True: the flush runs on the pieces; False: plain pending buffer."""
         d = self.A._d
-        self.torch.cuda.synchronize(self.device)  # the collectives ran on torch's stream
+        if P > 1:
+            self.torch.cuda.synchronize(self.device)  # the collectives ran on torch's stream
         PK, PV, PC = (C.c_void_p * P)(), (C.c_void_p * P)(), (C.c_void_p * P)()
         for q in range(P):
             if q != me:
@@ -358,7 +359,8 @@ class ShardedExtendableSparseMatrix:
             return False
         self._part_penalty = 0
         self._eps = -(-total // P) if total else None
-        be.part_wait()   # (the consensus round above ran beside the partition's scatter kernel)
+        # (the consensus round above and the host work below run beside the partition's scatter kernel:
+        # be.part_wait() comes right before the first operation that reads the moved entries)
         keys, vals, cnts, eoff, nb = part
         in_x = [int(c) for c in counts]
         in_x[me] = 0
@@ -382,8 +384,9 @@ class ShardedExtendableSparseMatrix:
                 parts += [cnts[r * nb:(r + 1) * nb], keys[lo:hi], vals[lo:hi].view(torch.int64)]
                 in_f.append(nb + 2 * (hi - lo))
             out_f = [0 if q == me else nb + 2 * out_x[q] for q in range(P)]
-            sbuf = torch.cat(parts)
             rbuf = be.empty(sum(out_f), torch.int64)
+            be.part_wait()
+            sbuf = torch.cat(parts)
             dist.all_to_all_single(rbuf, sbuf, out_f, in_f, group=self.group)
             fo = np.concatenate([[0], np.cumsum(out_f)]).astype(np.int64)
             rk, rv, rc = [], [], []
@@ -398,19 +401,21 @@ class ShardedExtendableSparseMatrix:
             be.part_assemble(P, me, rk, rv, rc, out_x)
             self.last_messages = 1
         else:
+            rkeys = be.empty(sum(out_x), torch.int64)
+            rvals = be.empty(sum(out_x), torch.float64)
+            rcnts = be.empty(P * nb, torch.int64)
+            ro = np.concatenate([[0], np.cumsum(out_x)]).astype(np.int64)
+            if P > 1:   # (a single shard hands its pieces to the library on the same stream: no wait needed)
+                be.part_wait()
             if sum(in_x):
                 skeys = torch.cat([keys[:own_lo], keys[own_hi:]])
                 svals = torch.cat([vals[:own_lo], vals[own_hi:]])
             else:
                 skeys, svals = keys[:0], vals[:0]
-            rkeys = be.empty(sum(out_x), torch.int64)
-            rvals = be.empty(sum(out_x), torch.float64)
-            rcnts = be.empty(P * nb, torch.int64)
             if P > 1:
                 all_to_all_v(dist, rkeys, skeys, out_x, in_x, self.group, big=big)
                 all_to_all_v(dist, rvals, svals, out_x, in_x, self.group, big=big)
                 dist.all_to_all_single(rcnts, cnts, group=self.group)   # nb counts to / from every rank
-            ro = np.concatenate([[0], np.cumsum(out_x)]).astype(np.int64)
             be.part_assemble(P, me,
                              [rkeys[ro[q]:ro[q + 1]] for q in range(P)],
                              [rvals[ro[q]:ro[q + 1]] for q in range(P)],
