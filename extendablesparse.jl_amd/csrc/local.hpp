@@ -4,15 +4,16 @@
 // the distinct entries to their FINAL position in the output (rowval/nzval of a fresh CSC, or
 // the compact list of new entries for the merge join) with coalesced stores.
 //
-// HBM traffic: reads 16 B per appended entry once, writes 16 B per emitted entry once
-// (+ 8 B per non-empty column for the column-end marks).
+// HBM traffic: reads 16 B per appended entry once (12 B when the partition handed over 4-byte keys), writes
+// 16 B per emitted entry once + 8 B per column (colptr itself for a fresh matrix, else column-end marks).
 //
 // Structure (one workgroup = 512 threads = 8 waves per segment, 2 workgroups per CU: 64 KiB of LDS each)
 //   claim     : segments are claimed through an atomic ticket (start order = ticket order); the segment
 //               bounds around the expected ticket are fetched while the atomic is in flight
 //   load      : 8 B key + 8 B value per slot, all 16 loads of a thread in flight; branch-free transform
 //               to the packed sort key (bits below the segment prefix | slot index | kind) in registers,
-//               value to LDS.  PIECES variant (column shards): the segment is the concatenation of one
+//               value to LDS.  KEYS 1/2: 4-byte keys (the bits below the prefix; one kind for all entries,
+//               KEYS 2: that kind is UPDATE and the register tiers fold without decoding it).  PIECES variant (column shards): the segment is the concatenation of one
 //               piece per source rank, read in place from the receive buffers
 //   sort      : counting sort by local column (LDS atomics, unordered inside a column), then per column
 //               run, chosen per segment from the longest run:
@@ -32,7 +33,9 @@
 //               carries it across the following barriers: nothing before the final stores needs the
 //               offset
 //   compact   : records -> dense LDS prefix (ballot ranks)
-//   store     : coalesced stores of rowval/nzval (or key/val) + column-end marks
+//   store     : coalesced stores of rowval/nzval (or key/val); fresh matrix over whole-column segments: the
+//               first entry of a column writes colptr for it and the empty columns before it (no marks, no
+//               scan over the columns afterwards); else column-end marks
 // Bound: instruction issue and barrier latency at 4 waves per SIMD (128 VGPRs), not HBM bytes; see DESIGN.md.
 #pragma once
 #include "common.hpp"

@@ -6,12 +6,15 @@
 // tile is described by its few RUNS (digit, count) instead of a 65536-bin histogram:
 //
 //   run_hist_k     per tile: distinct digits and their counts (<= RMAX, else the flush falls
-//                  back to the 8-bit passes), bucket totals by a few atomics   (reads 8 B/entry)
-//   (host-ordered small kernels) bucket starts = scan of the totals; the run list of all tiles is
-//                  sorted by digit (stable -> tile order kept) with the ordinary 8-bit passes, a
-//                  scan over the counts gives every run its offset inside its bucket
+//                  back to the 8-bit passes), bucket totals by a few atomics; every digit also
+//                  collects its own runs (tile, index in the tile, count)      (reads 8 B/entry)
+//   run_coarse_k + run_rank_k   bucket starts (block scan + sums of 256 totals) and, one thread per
+//                  digit, the output offset of each of its runs = bucket start + the entries of its
+//                  runs from earlier tiles (a digit with more than DCAP runs: the run list of all
+//                  tiles is ordered by the 8-bit pass kernels and scanned instead, host-driven)
 //   run_scatter_k  per tile: stable rank of every entry inside its run, stores straight from
-//                  registers to bucket_start + run offset + rank  (reads 16 B, writes 16 B/entry)
+//                  registers to run offset + rank  (reads 16 B, writes 16 B/entry -- 12 B when all
+//                  pending entries share one kind and <= 32 key bits remain: 4-byte keys)
 //
 // Stability: inside a bucket the runs are ordered by tile, inside a run the entries keep the
 // (wave, item, lane) = memory order.  Deterministic: the only atomics are integer counters.
