@@ -1740,6 +1740,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         h->last_key_bytes = st.key_bytes;
         a.colptr_out = direct ? (i64 *)h->colptr.p : nullptr;
         a.col_end = col_end;
+        a.n_cols = h->n;
         a.keys_in = st.sk;
         a.vals_in = st.sv;
         a.seg_start = st.seg_start;

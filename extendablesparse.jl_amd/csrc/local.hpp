@@ -127,6 +127,7 @@ struct Args {
     // for its own columns itself -- no column-end marks, no scan over the columns afterwards (nullptr: marks in colend)
     u32 kind32;  // K32 kernels: the kind of every entry
     i64 *colptr_out;
+    i64 n_cols;   // columns of the matrix (column-end marks of a failing flush -- keys outside the window -- stay inside colend)
     i64 col_end;  // end of the column range (colptr_out[col_end] = 1 + nnz comes from the last segment)
 };
 constexpr int MAX_PIECES = 64;
@@ -692,6 +693,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         for (int q = t; q <= (1 << a.cl_bits); q += THREADS) ccnt[q] = 0;
     // branch-free: slots past the end hold a copy of the last entry (clamped loads) and become NOREC
     u64 bad = 0;
+    const u64 relmask = (((u64)1 << (a.rem_bits + ESP_TAG_BITS - 1)) << 1) - 1ull;  // (rem_bits + 2 may be 64)
 #pragma unroll
     for (int i = 0; i < ITEMS; i++) {
         const int p = wbase + i * ESP_WAVE;
@@ -705,9 +707,11 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             // (the partition masked the key to the bits below the prefix: nothing to check)
             kk = (key << SUB_SHIFT) | (u64)(u32)((p << ESP_TAG_BITS) | a.kind32);
         } else {
+            // (... and is folded back into the segment: whatever follows -- LDS counters, CSC look-ups, column
+            // marks -- stays inside its arrays; the flush fails anyway)
             const u64 rel = key - hi4;
             bad |= rel >> (a.rem_bits + ESP_TAG_BITS);
-            kk = ((rel & ~(u64)ESP_TAG_MASK) << IDX_BITS) | (u64)(u32)((p << ESP_TAG_BITS) | ((u32)key & (u32)ESP_TAG_MASK));
+            kk = (((rel & relmask) & ~(u64)ESP_TAG_MASK) << IDX_BITS) | (u64)(u32)((p << ESP_TAG_BITS) | ((u32)key & (u32)ESP_TAG_MASK));
         }
         k[i] = p < n ? kk : NOREC;  // NOREC sorts behind every real entry
     }
@@ -972,7 +976,10 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     const u64 dst = esp_uniform_u64(s_dst);
     // ---- coalesced stores + column-end marks (or colptr itself)
     const bool direct = FRESH && a.colptr_out != nullptr;
-    const i64 c_lo = (i64)(hi >> a.rb);  // (direct: the segment's columns are [c_lo, c_hi))
+    // (direct: the segment's columns are [c_lo, c_hi); every colptr store is clamped to them -- a key outside the
+    // declared window, which fails the flush, must not turn into a store outside the array)
+    const i64 c_lo = (i64)(hi >> a.rb);
+    const i64 c_hi = direct ? min(c_lo + ((i64)1 << a.cl_bits), a.col_end) : c_lo;
     for (int p = t; p < total; p += THREADS) {
         const u64 key = skey[p];
         if (FRESH)
@@ -984,8 +991,8 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         if (direct) {
             // first entry of its column: that column and the empty ones in front of it start here
             const i64 prev = p == 0 ? c_lo - 1 : (i64)(skey[p - 1] >> a.rb);
-            for (i64 c = prev + 1; c <= (i64)col; c++) a.colptr_out[c] = (i64)(dst + (u64)p) + 1;
-        } else if (p == total - 1 || (skey[p + 1] >> a.rb) != col) {
+            for (i64 c = max(prev + 1, c_lo); c <= min((i64)col, c_hi - 1); c++) a.colptr_out[c] = (i64)(dst + (u64)p) + 1;
+        } else if ((p == total - 1 || (skey[p + 1] >> a.rb) != col) && col < (u64)a.n_cols) {
             if (a.col_aligned)
                 a.colend[col] = dst + (u64)p + 1;
             else
@@ -993,8 +1000,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         }
     }
     if (direct) {  // the columns behind the last entry (all of them for an empty segment)
-        const i64 c_hi = min(c_lo + ((i64)1 << a.cl_bits), a.col_end);
-        const i64 after = total > 0 ? (i64)(skey[total - 1] >> a.rb) + 1 : c_lo;
+        const i64 after = total > 0 ? max((i64)(skey[total - 1] >> a.rb) + 1, c_lo) : c_lo;
         for (i64 c = after + t; c < c_hi; c += THREADS) a.colptr_out[c] = (i64)(dst + (u64)total) + 1;
         if (s == a.S - 1 && t == 0) a.colptr_out[a.col_end] = (i64)(dst + (u64)total) + 1;
     }

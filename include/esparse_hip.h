@@ -232,7 +232,9 @@ int32_t esp_shard_assemble(esp_handle *h, const uint64_t *const *d_recv_keys,
                            const int64_t *recv_entries /* nshards */, int32_t *ok);
 
 /* promise: every pending entry of the following flushes has its column in [col_lo, col_hi]
- * (1-based); the partition then works on that window only.  Violations -> ESP_ERR_STATE. */
+ * (1-based); the partition then works on that window only.  Violations -> ESP_ERR_STATE from esp_flush: the
+ * stored pattern is untouched and the batch stays pending (esp_clear_pending / esp_reset), but updates of the
+ * batch that hit stored positions may already have been applied to their values. */
 int32_t esp_set_column_window(esp_handle *h, int64_t col_lo, int64_t col_hi);
 
 /* ---- measurement ---------------------------------------------------------------- */

@@ -1107,7 +1107,7 @@ def test_failed_fresh_flush_leaves_the_empty_matrix_intact(esp, orc):
     A = esp.ExtendableSparseMatrix(m, n)
     A.set_column_window(lo, hi)
     A.append(UPDATE, I, J, V)
-    A.append(UPDATE, [1, 2, 3], [hi + 5, hi + 6, 7], [1.0, 2.0, 3.0])
+    A.append(UPDATE, [1, 2, 3], [hi + 5, hi + 6, 7], [1.0, 2.0, 3.0])   # above and BELOW the window (key difference wraps)
     with pytest.raises(esp.EspError):
         A.flush()
     d = A._d                                          # (the accessors would flush again: drop the batch first)
@@ -1121,6 +1121,42 @@ def test_failed_fresh_flush_leaves_the_empty_matrix_intact(esp, orc):
     O.apply(np.full(cnt, UPDATE, np.uint8), I, J, V)
     A.flush()
     assert A.debug_last_colptr_direct()
+    assert_csc_equal(hip_arrays(A), O.arrays())
+
+
+def test_window_violation_below_the_window_with_stored_entries(esp, orc):
+    """Entries below a declared window (their key difference wraps around) on a matrix that already holds
+    entries: the bucket kernel marks column ends -- inside the array -- and the flush fails cleanly."""
+    rng = np.random.default_rng(33)
+    m, n = 3000, 40000
+    lo, hi = 20001, 21000
+    cnt = 3000
+    I = rng.integers(1, m + 1, cnt)
+    J = rng.integers(lo, hi + 1, cnt)
+    V = rng.standard_normal(cnt)
+    A = esp.ExtendableSparseMatrix(m, n)
+    O = orc.ExtendableSparseMatrix(m, n)
+    A.append(UPDATE, I, J, V)
+    O.apply(np.full(cnt, UPDATE, np.uint8), I, J, V)
+    A.flush()
+    A.set_column_window(lo, hi)
+    A.append(UPDATE, I[:100], J[:100], V[:100])
+    A.append(UPDATE, [5, 6], [3, lo - 1], [1.0, 2.0])
+    with pytest.raises(esp.EspError):
+        A.flush()
+    d = A._d
+    d.ck(d.lib.esp_clear_pending(d.h))
+    A._touch()
+    # the pattern is intact (the values are not specified after a failed flush: updates that hit stored
+    # positions are applied in place before the violation is known)
+    cp, rv, _ = hip_arrays(A)
+    ocp, orv, _ = O.arrays()
+    assert np.array_equal(cp, ocp) and np.array_equal(rv, orv)
+    A.reset()
+    O.reset()
+    A.append(UPDATE, I, J, V)
+    O.apply(np.full(cnt, UPDATE, np.uint8), I, J, V)
+    A.flush()
     assert_csc_equal(hip_arrays(A), O.arrays())
 
 
