@@ -91,6 +91,7 @@ SIGNATURES = {
     "esp_debug_last_run_order": (i32, [vp, P(i32)]),
     "esp_debug_last_colptr_direct": (i32, [vp, P(i32)]),
     "esp_debug_last_key_bytes": (i32, [vp, P(i32)]),
+    "esp_debug_last_fold_update": (i32, [vp, P(i32)]),
     "esp_debug_last_path": (i32, [vp, P(i32)]),
     "esp_debug_last_partition": (i32, [vp, P(i32)]),
 }

@@ -80,6 +80,9 @@ struct esp_handle {
     i64 kind_noted = 0;     // pending entries appended with a single known kind
     int kind_uniform = -1;  // that kind; -1 none yet, -2 mixed / an append of unknown kinds (until the buffer is empty again)
     int last_key_bytes = 8;      // esp_debug_last_key_bytes
+    int last_fold_update = 0;    // the register tiers of the last flush ran their UPDATE-only fold
+    bool part_own_update = false;  // esp_shard_partition: every pending entry was appended as an UPDATE
+    bool part_all_update = false;  // esp_shard_assemble: ... and so is every received entry (checked on the device)
     int last_run_order = 0;      // esp_debug_last_run_order
     int last_colptr_direct = 0;  // the bucket kernel of the last flush wrote colptr itself
     hipStream_t aux = nullptr;   // second stream + event: small device-to-host reads beside a running kernel
@@ -1070,6 +1073,7 @@ struct Sorted {
     const i64 *seg_start;
     int rem_bits;
     bool local_ok;
+    bool all_update = false;  // PIECES: every entry of every piece is an UPDATE (esp_shard_assemble checked)
     int key_bytes = 8;  // 4: sk holds 32-bit keys (the bits below the prefix); every entry has the kind `kind`
     int kind = 0;
     // PIECES (partitioned shard exchange): segments are concatenations of per-source pieces
@@ -1784,8 +1788,14 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
             const bool big = h->seen_maxrun > 16 && h->seen_maxrun <= esplocal::REG_RUN;
 #define ESP_LAUNCH_LOCAL(F, P, B, K) hipLaunchKernelGGL((esplocal::local_k<F, P, B, K>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a)
             // (key format: 0 packed, 1 four-byte keys of one kind, 2 four-byte keys that are all UPDATEs)
-            const int keys = st.npieces > 0 || st.key_bytes != 4 ? 0 : (st.kind == ESP_UPDATE && h->force_path != 15 ? 2 : 1);
-            if (st.npieces > 0) {
+            // (3: packed keys whose kinds are all UPDATE -- the pieces of a shard)
+            const int keys = st.npieces > 0 ? (st.all_update && h->force_path != 15 ? 3 : 0)
+                                            : st.key_bytes != 4 ? 0 : (st.kind == ESP_UPDATE && h->force_path != 15 ? 2 : 1);
+            h->last_fold_update = keys >= 2 ? 1 : 0;
+            if (st.npieces > 0 && keys == 3) {
+                if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 3); else ESP_LAUNCH_LOCAL(true, true, false, 3); }
+                else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 3); else ESP_LAUNCH_LOCAL(false, true, false, 3); }
+            } else if (st.npieces > 0) {
                 if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 0); else ESP_LAUNCH_LOCAL(true, true, false, 0); }
                 else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 0); else ESP_LAUNCH_LOCAL(false, true, false, 0); }
             } else if (keys == 2) {
@@ -1922,6 +1932,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         st.rem_bits = h->part_shift;
         st.local_ok = true;
         st.npieces = h->part_P;
+        st.all_update = h->part_all_update;
         st.ptab = (const void *const *)T;
         st.pstart = (const i64 *)(T + 256 * 8);
         CK(ensure(h, h->keys2, sizeof(u64) * (size_t)std::max<i64>(h->part_total, 1)));
@@ -1968,6 +1979,11 @@ extern "C" int32_t esp_debug_force_path(esp_handle *h, int32_t path) {
 extern "C" int32_t esp_debug_last_run_order(const esp_handle *h, int32_t *kind) {
     if (!h || !kind) return ESP_ERR_INVALID;
     *kind = h->last_run_order;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_last_fold_update(const esp_handle *h, int32_t *on) {
+    if (!h || !on) return ESP_ERR_INVALID;
+    *on = h->last_fold_update;
     return ESP_OK;
 }
 extern "C" int32_t esp_debug_last_key_bytes(const esp_handle *h, int32_t *bytes) {
@@ -2436,6 +2452,13 @@ __global__ __launch_bounds__(1024) void piece_scan_k(const i64 *const *__restric
     }
 }
 
+// *other = 1 when a received entry is not an UPDATE (the UPDATE-only fold of the bucket kernel is then not used)
+__global__ void kinds_check_k(const u64 *__restrict__ keys, i64 count, unsigned long long *__restrict__ other) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool bad = i < count && (u32)(keys[i] & ESP_TAG_MASK) != (u32)ESP_UPDATE;
+    if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(other, 1ull);
+}
+
 // merged length of every segment; longest one
 __global__ void piece_totals_k(const i64 *__restrict__ pstart, int P, i64 nb, unsigned long long *__restrict__ maxlen,
                                unsigned long long *__restrict__ negative) {
@@ -2466,6 +2489,7 @@ extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t s
     if (P < 1 || self < 0 || self >= P || entries_per_shard < 0) FAIL(h, ESP_ERR_INVALID, "esp_shard_partition: arguments");
     (void)hipSetDevice(h->device);
     h->part_valid = h->part_assembled = false;
+    h->part_own_update = h->kind_uniform == ESP_UPDATE && h->kind_noted == h->count;
     if (P > esprun::MW_MAX || P > esplocal::MAX_PIECES || h->force_path == 11) return ESP_OK;  // caller uses the plain exchange
     if ((double)h->n * (double)P >= 9.0e18) FAIL(h, ESP_ERR_UNSUPPORTED, "shards: n*nshards overflows");
     const i64 E = h->count;
@@ -2577,9 +2601,16 @@ extern "C" int32_t esp_shard_assemble(esp_handle *h, const uint64_t *const *d_re
     i64 *d_sum = (i64 *)(T + o_sum);
     CK(ensure(h, h->misc, 256));
     unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
-    HIPCK(h, hipMemsetAsync(d_maxlen, 0, 16, h->stream));
+    HIPCK(h, hipMemsetAsync(d_maxlen, 0, 24, h->stream));
     {
         Span sp(h, ESP_ST_SCAN);
+        if (h->part_own_update)  // (the received blocks are the cross-shard pairs only: a few launches over little data)
+            for (int q = 0; q < P; q++)
+                if (q != me && recv_entries[q] > 0) {
+                    hipLaunchKernelGGL(kinds_check_k, dim3(grid_for(recv_entries[q], 256)), dim3(256), 0, h->stream, (const u64 *)d_recv_keys[q],
+                                       (i64)recv_entries[q], d_maxlen + 2);
+                    sp.add(1);
+                }
         HIPCK(h, hipMemcpyAsync(pstart + (size_t)me * (size_t)(nb + 1), bstart, sizeof(i64) * (size_t)(nb + 1), hipMemcpyDeviceToDevice, h->stream));
         hipLaunchKernelGGL(piece_scan_k, dim3((unsigned)P), dim3(1024), 0, h->stream, (const i64 *const *)(T + 128 * 8), bstart, me, nb, pstart, d_sum);
         hipLaunchKernelGGL(piece_totals_k, dim3(grid_for(nb, 256)), dim3(256), 0, h->stream, (const i64 *)pstart, P, nb, d_maxlen, d_maxlen + 1);
@@ -2587,8 +2618,8 @@ extern "C" int32_t esp_shard_assemble(esp_handle *h, const uint64_t *const *d_re
     }
     std::vector<i64> last((size_t)P + 1);
     HIPCK(h, hipMemcpyAsync(last.data(), d_sum, sizeof(i64) * (size_t)(P + 1), hipMemcpyDeviceToHost, h->stream));
-    unsigned long long mx[2];
-    HIPCK(h, hipMemcpyAsync(mx, d_maxlen, 16, hipMemcpyDeviceToHost, h->stream));
+    unsigned long long mx[3];
+    HIPCK(h, hipMemcpyAsync(mx, d_maxlen, 24, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     HIPCK(h, hipGetLastError());
     for (int q = 0; q < P; q++)
@@ -2596,6 +2627,7 @@ extern "C" int32_t esp_shard_assemble(esp_handle *h, const uint64_t *const *d_re
             FAIL(h, ESP_ERR_STATE, "esp_shard_assemble: block from shard %d holds %lld entries, its digit counts sum to %lld", q,
                  (long long)recv_entries[q], (long long)last[(size_t)q]);
     if (mx[1]) FAIL(h, ESP_ERR_STATE, "esp_shard_assemble: negative digit count in a received block");
+    h->part_all_update = h->part_own_update && mx[2] == 0;
     const i64 own_n = last[(size_t)me];
     const i64 own[2] = {last[(size_t)P], last[(size_t)P] + own_n};
     const i64 total = own_n + total_recv;

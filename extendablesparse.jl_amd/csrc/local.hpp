@@ -555,10 +555,11 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
 // KEYS (0 with PIECES): 0 = packed 8-byte keys; 1 = keys_in holds 4-byte keys -- the key bits below the segment's
 // prefix -- and every entry has the kind a.kind32 (the run-based partition writes them when all pending entries
 // share one kind); 2 = the same and that kind is UPDATE (an assembly loop of updateindex! calls): the register
-// tiers fold without decoding a kind
+// tiers fold without decoding a kind; 3 = packed keys whose kinds are all UPDATE (the pieces of a shard whose
+// received blocks were checked): the same fold
 template <bool FRESH, bool PIECES, bool BIG, int KEYS>
 __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
-    constexpr bool K32 = KEYS != 0, UPD = KEYS == 2;
+    constexpr bool K32 = KEYS == 1 || KEYS == 2, UPD = KEYS >= 2;
     static_assert(!(PIECES && K32), "pieces arrive as packed keys");
     __shared__ u64 skey[CAP];
     __shared__ double sval[CAP];

@@ -502,6 +502,12 @@ class ExtendableSparseMatrix:
         self._d.ck(self._d.lib.esp_debug_last_run_order(self._d.h, C.byref(p)))
         return p.value
 
+    def debug_last_fold_update(self):
+        """True when the bucket kernel of the last flush used its UPDATE-only fold"""
+        p = C.c_int32()
+        self._d.ck(self._d.lib.esp_debug_last_fold_update(self._d.h, C.byref(p)))
+        return bool(p.value)
+
     def debug_last_key_bytes(self):
         """4: the bucket kernel of the last flush read 4-byte keys (one kind for all pending entries), else 8"""
         p = C.c_int32()

@@ -268,6 +268,9 @@ int32_t esp_debug_last_colptr_direct(const esp_handle *h, int32_t *direct);
  * known kind, at most 32 key bits were left below the partition prefix and the run-based partition served the
  * flush (it then writes only those bits), else 8 (packed keys) */
 int32_t esp_debug_last_key_bytes(const esp_handle *h, int32_t *bytes);
+/* 1 when the register tiers of the last flush's bucket kernel ran the UPDATE-only fold (every entry known to be an
+ * updateindex! call: the batch's bookkeeping, for a shard also a device check of the received blocks) */
+int32_t esp_debug_last_fold_update(const esp_handle *h, int32_t *on);
 /* which partition the last flush used: 1 = run-based single pass (pre-sorted stream), 2 = 8-bit passes,
  * 3 = run-based single pass on run lists the producers emitted (no histogram kernel),
  * 7 = none: the segments came assembled from esp_shard_assemble */

@@ -1032,7 +1032,7 @@ def _sharded_ranks_run(esp, orc, world, deal, n=44, rounds=2, overflow=False, on
     def body(rank, dist):
         be = esp.HipShardBackend(N, N, device=0)
         A = esp.ShardedExtendableSparseMatrix(N, N, be, dist=dist)
-        hist = []
+        hist, folds = [], []
         for rnd in range(rounds):
             if deal == "slab":
                 A.local.generate_fdrand_range(nx, ny, nzg, rank * nodes, (rank + 1) * nodes, seed=seeds[rnd], rand_mode=1)
@@ -1043,8 +1043,9 @@ def _sharded_ranks_run(esp, orc, world, deal, n=44, rounds=2, overflow=False, on
                 A.append(UPDATE, extra[0], extra[1], extra[2] * (rank + 1))
             A.flush()
             hist.append((A.last_exchange, be.matrix.debug_last_partition()))
+            folds.append(be.matrix.debug_last_fold_update())
         G = A.gather_sparse(0)
-        return hist, (G.arrays() if rank == 0 else None), A.nnz()
+        return hist, (G.arrays() if rank == 0 else None), A.nnz(), folds
 
     shmod = sys.modules[esp.ShardedExtendableSparseMatrix.__module__]
     keep = shmod.ONE_MESSAGE_MAX_ELEMS
@@ -1065,6 +1066,12 @@ def _sharded_ranks_run(esp, orc, world, deal, n=44, rounds=2, overflow=False, on
         O.flush()
     assert_csc_equal(outs[0][1], O.arrays())
     assert outs[0][2] == O.nnz()
+    # the UPDATE-only fold of the bucket kernel: a shard uses it when its own batch was appended as UPDATEs AND the
+    # device check of the received blocks found nothing else (slab: the generator's updateindex! stream; the
+    # other deals come with per-entry kinds, RAWUPDATEs among them)
+    for o in outs:
+        if o[0] and all(h == ("partitioned", 7) for h in o[0]):
+            assert o[3] == [deal == "slab"] * len(o[3]), (deal, o[3])
     return [o[0] for o in outs]
 
 
