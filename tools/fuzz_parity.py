@@ -34,7 +34,8 @@ while time.time() < t_end:
     A.debug_force_path(force)
     nflush = int(rng.integers(1, 4))
     for f in range(nflush):
-        cnt = int(rng.choice([0, 1, 50, 5000, 200000, 1500000]))
+        big = rng.random() < 0.3     # a batch large enough for the run-based partition, often pre-sorted
+        cnt = 1500000 if big else int(rng.choice([0, 1, 50, 5000, 200000, 1500000]))
         per_col = float(rng.choice([0.5, 5, 14, 22, 40, 300]))
         ncols_used = max(1, min(n, int(cnt / per_col) + 1))
         cols = rng.integers(1, n + 1, ncols_used)
@@ -42,7 +43,7 @@ while time.time() < t_end:
         nrows_used = max(1, int(rng.choice([1, 3, 50, 10 ** 4, 10 ** 9])))
         rowpool = rng.integers(1, m + 1, min(nrows_used, 10 ** 6))
         I = rowpool[rng.integers(0, len(rowpool), cnt)]
-        order = rng.choice(["asis", "sorted", "clustered"])
+        order = rng.choice(["sorted", "sorted", "clustered"]) if big else rng.choice(["asis", "sorted", "clustered"])
         if order == "sorted":
             o = np.argsort(J, kind="stable")
             I, J = I[o], J[o]
@@ -52,11 +53,23 @@ while time.time() < t_end:
         kinds = rng.choice(np.array([0, 1, 1, 2], np.uint8), cnt)
         V = np.where(rng.random(cnt) < 0.2, 0.0, rng.standard_normal(cnt))
         V[rng.random(cnt) < 0.02] = -0.0
-        A.append(0, I, J, V, kinds=kinds)
-        O.apply(kinds, I, J, V)
+        # per-entry kinds, or one / two appends with a single kind each (the batch bookkeeping behind the 4-byte keys
+        # and the UPDATE-only fold of the bucket kernel)
+        style = rng.choice(["kinds", "one_kind", "two_appends"])
+        if style == "kinds" or cnt < 2:
+            A.append(0, I, J, V, kinds=kinds)
+            O.apply(kinds, I, J, V)
+        else:
+            cut = cnt if style == "one_kind" else cnt // 2
+            k1 = int(rng.choice([0, 1, 1, 1, 2]))
+            k2 = k1 if rng.random() < 0.5 else int(rng.choice([0, 1, 2]))
+            for lo_, hi_, kd in ((0, cut, k1), (cut, cnt, k2)):
+                if hi_ > lo_:
+                    A.append(kd, I[lo_:hi_], J[lo_:hi_], V[lo_:hi_])
+                    O.apply(np.full(hi_ - lo_, kd, np.uint8), I[lo_:hi_], J[lo_:hi_], V[lo_:hi_])
         A.flush()
         O.flush()
-        key = (A.debug_last_path(), A.debug_last_partition())
+        key = (A.debug_last_path(), A.debug_last_partition(), A.debug_last_key_bytes(), int(A.debug_last_fold_update()))
         paths[key] = paths.get(key, 0) + 1
         try:
             assert_csc_equal(A.sparse().arrays(), O.arrays())
@@ -64,4 +77,4 @@ while time.time() < t_end:
             print("MISMATCH seed", seed, "case", cases, dict(m=m, n=n, force=force, flush=f, cnt=cnt, per_col=per_col, order=str(order)))
             raise
     cases += 1
-print("fuzz ok: cases", cases, "paths (pipeline, partition):", paths)
+print("fuzz ok: cases", cases, "paths (pipeline, partition, key bytes, update-only fold):", paths)
