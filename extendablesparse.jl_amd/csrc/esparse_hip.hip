@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <cmath>
 #include <thread>
 
 #include "common.hpp"
@@ -1137,12 +1138,19 @@ static int32_t chunk_arrays(esp_handle *h, i64 Ccap, int pb, ChunkArrays *out) {
     return ESP_OK;
 }
 
-// bits the run-based pass would resolve for E pending entries in a K-bit key window (0: not used)
-static int plan_run_bits(i64 E, int K) {
+// The digits of a partition cut the 2^K keys of the window's bit range, of which only `span` exist (a matrix
+// with 2^k + 1 columns fills half of it): the plan counts the entries as if the empty part were filled as well,
+// so that the occupied buckets come out at the planned fill.
+static double plan_entries(i64 E, int K, u64 span) {
+    const double full = std::ldexp(1.0, K);
+    return span > 0 && (double)span < full ? (double)E * full / (double)span : (double)E;
+}
+// bits the run-based pass would resolve for E pending entries in a K-bit key window holding `span` keys (0: not used)
+static int plan_run_bits(i64 E, int K, u64 span) {
     int planned = 0;
     if (E > esplocal::CAP) {
-        const double target = 0.8 * esplocal::CAP;
-        while (planned < K && (double)E / (double)((i64)1 << planned) > target) planned++;
+        const double target = 0.8 * esplocal::CAP, Ee = plan_entries(E, K, span);
+        while (planned < K && Ee / (double)((i64)1 << planned) > target) planned++;
     }
     return planned > 8 ? std::min(planned, 20) : 0;
 }
@@ -1164,7 +1172,7 @@ static bool fused_begin(esp_handle *h, i64 E_call, i64 nchunks, espgen::Fused *f
     if (h->fused_state == 0) {  // first producer of a batch decides the digit width
         if (h->count != 0) return false;
         const i64 E_expect = std::max<i64>(h->hint, E_call);  // the caller's capacity hint = expected batch size
-        const int pb = plan_run_bits(E_expect, K);
+        const int pb = plan_run_bits(E_expect, K, h->win_span);
         if (pb == 0) return false;
         const i64 Ccap = std::max<i64>(nchunks, E_expect / 1024) + 64;
         ChunkArrays ca;
@@ -1468,15 +1476,16 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     HIPCK(h, hipMemsetAsync(d_maxlen, 0, 64, h->stream));  // maxlen .. the four flag words (run_partition)
 
     int planned = 0;
+    const double Ee = plan_entries(E, K, h->win_span);  // (see plan_entries: the window fills only part of its 2^K keys)
     if (E > esplocal::CAP) {
         const double target = 0.8 * esplocal::CAP;
-        while (planned < K && (double)E / (double)((i64)1 << planned) > target) planned++;
+        while (planned < K && Ee / (double)((i64)1 << planned) > target) planned++;
         // one bit short of a whole number of 8-bit passes: an average fill of up to 95 % is worth
         // trying with one pass less (the longest segment is checked after the planned passes and a
         // further pass is added only if a segment really overflows)
     }
     const int planned_run = planned;  // the run-based pass takes up to 20 bits at once: no need to be tight
-    if (planned > 8 && planned % 8 == 1 && (double)E / (double)((i64)1 << (planned - 1)) <= 0.95 * esplocal::CAP) planned--;
+    if (planned > 8 && planned % 8 == 1 && Ee / (double)((i64)1 << (planned - 1)) <= 0.95 * esplocal::CAP) planned--;
     const int npass = (planned + 7) / 8;
 
     int cur = 0, S = 1, done = 0;
@@ -2504,7 +2513,7 @@ extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t s
     }
     int K = 1;
     while (K < 62 && ((u64)1 << K) < maxspan) K++;
-    const int pbw = plan_run_bits(std::max<i64>(entries_per_shard, 1), K);
+    const int pbw = plan_run_bits(std::max<i64>(entries_per_shard, 1), K, maxspan);
     if (pbw == 0 || K - pbw > esplocal::MAX_REM_BITS) return ESP_OK;  // small or odd problem: plain exchange
     const int shift = K - pbw;
     const u64 nb64 = ((maxspan - 1) >> shift) + 1;

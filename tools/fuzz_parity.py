@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Randomised parity fuzz (GPU): random shapes (incl. very tall matrices: many row bits), kinds, duplicate
 patterns, stream orders (sorted / clustered / shuffled), multi-flush sequences, both flush modes --
-every result compared bit for bit with the CPU oracle.  usage: tools/fuzz_parity.py [seconds] [seed]"""
+every result compared bit for bit with the CPU oracle.  usage: tools/fuzz_parity.py [seconds] [seed]
+ESP_FUZZ_FOCUS=k32: shapes and batches that reach the 4-byte keys / UPDATE-only fold of the bucket kernel."""
 import os
 import sys
 import time
@@ -28,13 +29,19 @@ paths = {}
 while time.time() < t_end:
     n = int(rng.choice([1, 3, 64, 257, 5000, 70000, 400000]))
     m = int(rng.choice([1, 2, 100, 4097, 10 ** 6, 2 ** 31 - 1, 2 ** 33, 2 ** 40]))
+    focus = os.environ.get("ESP_FUZZ_FOCUS") == "k32"   # few row bits, many columns: <= 32 key bits below the prefix
+    if focus:
+        n = int(rng.choice([70000, 400000, 3000000]))
+        m = int(rng.choice([3, 100, 4097, 60000]))
     A = esp.ExtendableSparseMatrix(m, n)
     O = orc.ExtendableSparseMatrix(m, n)
     force = int(rng.choice([0, 0, 0, 2, 3, 4, 5, 12, 13, 14, 15]))
+    if focus:
+        force = int(rng.choice([0, 0, 13, 15, 4]))
     A.debug_force_path(force)
     nflush = int(rng.integers(1, 4))
     for f in range(nflush):
-        big = rng.random() < 0.3     # a batch large enough for the run-based partition, often pre-sorted
+        big = rng.random() < (0.8 if focus else 0.3)     # a batch large enough for the run-based partition, often pre-sorted
         cnt = 1500000 if big else int(rng.choice([0, 1, 50, 5000, 200000, 1500000]))
         per_col = float(rng.choice([0.5, 5, 14, 22, 40, 300]))
         ncols_used = max(1, min(n, int(cnt / per_col) + 1))
@@ -55,7 +62,7 @@ while time.time() < t_end:
         V[rng.random(cnt) < 0.02] = -0.0
         # per-entry kinds, or one / two appends with a single kind each (the batch bookkeeping behind the 4-byte keys
         # and the UPDATE-only fold of the bucket kernel)
-        style = rng.choice(["kinds", "one_kind", "two_appends"])
+        style = rng.choice(["one_kind", "one_kind", "two_appends"]) if focus else rng.choice(["kinds", "one_kind", "two_appends"])
         if style == "kinds" or cnt < 2:
             A.append(0, I, J, V, kinds=kinds)
             O.apply(kinds, I, J, V)
