@@ -81,6 +81,10 @@ struct esp_handle {
     i64 kind_noted = 0;     // pending entries appended with a single known kind
     int kind_uniform = -1;  // that kind; -1 none yet, -2 mixed / an append of unknown kinds (until the buffer is empty again)
     int last_key_bytes = 8;      // esp_debug_last_key_bytes
+    // longest segment / average segment of the last bucket-path flush (0: not known): an assembly that repeats on
+    // a handle with regular data (spread ~1.0x) is planned one partition bit tighter when the predicted longest
+    // segment still fits the bucket kernel -- half-full segments cost that kernel up to 1.8x
+    double seen_spread = 0.0;
     int last_fold_update = 0;    // the register tiers of the last flush ran their UPDATE-only fold
     bool part_own_update = false;  // esp_shard_partition: every pending entry was appended as an UPDATE
     bool part_all_update = false;  // esp_shard_assemble: ... and so is every received entry (checked on the device)
@@ -1141,6 +1145,15 @@ static int32_t chunk_arrays(esp_handle *h, i64 Ccap, int pb, ChunkArrays *out) {
 // The digits of a partition cut the 2^K keys of the window's bit range, of which only `span` exist (a matrix
 // with 2^k + 1 columns fills half of it): the plan counts the entries as if the empty part were filled as well,
 // so that the occupied buckets come out at the planned fill.
+// planned average fill of a segment (fraction of the bucket kernel's capacity); ESP_PLAN_FILL overrides (experiments)
+static double plan_fill() {
+    static const double f = [] {
+        const char *e = getenv("ESP_PLAN_FILL");
+        const double v = e ? atof(e) : 0.9;
+        return v > 0.1 && v <= 1.0 ? v : 0.9;
+    }();
+    return f;
+}
 static double plan_entries(i64 E, int K, u64 span) {
     const double full = std::ldexp(1.0, K);
     return span > 0 && (double)span < full ? (double)E * full / (double)span : (double)E;
@@ -1149,7 +1162,7 @@ static double plan_entries(i64 E, int K, u64 span) {
 static int plan_run_bits(i64 E, int K, u64 span) {
     int planned = 0;
     if (E > esplocal::CAP) {
-        const double target = 0.8 * esplocal::CAP, Ee = plan_entries(E, K, span);
+        const double target = plan_fill() * esplocal::CAP, Ee = plan_entries(E, K, span);
         while (planned < K && Ee / (double)((i64)1 << planned) > target) planned++;
     }
     return planned > 8 ? std::min(planned, 20) : 0;
@@ -1478,12 +1491,21 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     int planned = 0;
     const double Ee = plan_entries(E, K, h->win_span);  // (see plan_entries: the window fills only part of its 2^K keys)
     if (E > esplocal::CAP) {
-        const double target = 0.8 * esplocal::CAP;
+        const double target = plan_fill() * esplocal::CAP;
         while (planned < K && Ee / (double)((i64)1 << planned) > target) planned++;
         // one bit short of a whole number of 8-bit passes: an average fill of up to 95 % is worth
         // trying with one pass less (the longest segment is checked after the planned passes and a
         // further pass is added only if a segment really overflows)
     }
+    if (planned > 0 && h->seen_spread > 0.0 && h->seen_spread < 2.0 &&
+        Ee / (double)((i64)1 << (planned - 1)) * h->seen_spread <= 0.98 * esplocal::CAP)
+        planned--;  // (see seen_spread; a wrong guess costs one further pass and corrects itself)
+    // ... and irregular data (the longest segment well above the average) gets the bits up front that the last flush
+    // had to add in a further pass
+    for (int extra = 0; extra < 3 && planned > 0 && planned < K && h->seen_spread >= 1.0 && h->seen_spread < 8.0 &&
+                        Ee / (double)((i64)1 << planned) * h->seen_spread > (double)esplocal::CAP;
+         extra++)
+        planned++;
     const int planned_run = planned;  // the run-based pass takes up to 20 bits at once: no need to be tight
     if (planned > 8 && planned % 8 == 1 && Ee / (double)((i64)1 << (planned - 1)) <= 0.95 * esplocal::CAP) planned--;
     const int npass = (planned + 7) / 8;
@@ -1630,6 +1652,7 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     out->seg_start = (const i64 *)h->seg[cur].p;
     out->rem_bits = K - done;
     out->local_ok = ok && (K - done) <= esplocal::MAX_REM_BITS && maxlen <= esplocal::CAP;
+    h->seen_spread = (done > 0 && Ee > 0.0) ? (double)maxlen * std::ldexp(1.0, done) / Ee : 0.0;
     return ESP_OK;
 }
 
