@@ -45,13 +45,24 @@ struct esp_handle {
     DevBuf keys2, vals2, hist, segs, colend, newkey, newval, heads, misc, seg[2], tilef[2], segcnt, segout;
     int force_path = 0, last_path = 0;
     DevBuf runbuf, chunkbuf;
-    i64 chunk_cap = 0, fused_chunks = 0, hint = 0;
-    int chunk_pb = 0, fused_K = 0;
-    int fused_state = 0;  // 0 no pending data, 1 every pending entry came with its run list, 2 mixed/stale
-    int last_fused = 0;
+    i64 chunk_cap = 0, hint = 0;
+    int chunk_pb = 0;
     int runs_skip = 0, runs_penalty = 0;  // back-off after a stream turned out not to be pre-sorted
     int seen_maxrun = 0;                  // longest column run the bucket kernel met in the last flush
-    int last_partition = 0;               // 1 = run-based single pass, 2 = 8-bit passes only
+    int last_partition = 0;               // 1 = run-based single pass, 2 = 8-bit passes only, 4 = the producer's, 7 = shard pieces
+    // Producer-side partition: a device-side producer appended to the empty buffer with its PART kernel (runpart.hpp,
+    // "the append IS the partition"): the pending entries lie bucket by bucket -- a stable permutation of the stream --
+    // and the flush starts at the bucket kernel.  Bucket starts: seg[1] (S + 1 entries).
+    struct PrePart {
+        bool valid = false;
+        int K = 0, pb = 0;       // bits of the key window / of the prefix: S = 1 << pb buckets
+        int key_bytes = 8;       // 4: `keys` holds u32 keys (the bits below the prefix); every entry has the kind `kind`
+        int kind = 0;
+        i64 E = 0, maxlen = 0;   // entries, longest bucket
+        u64 base = 0, span = 0;  // the key window it was made for
+        double Ee = 0.0;         // (plan_entries of the batch: spread bookkeeping)
+    } pre;
+    bool shard_user = false;     // the handle is driven through esp_shard_*: producers append in stream order
     // column window of the pending entries (whole matrix by default)
     u64 win_base = 0, win_span = 0;
     // A shard works on its column range only.  When the window [wc0, wc1) (0-based columns) was
@@ -130,7 +141,28 @@ static inline void pending_changed(esp_handle *h) {
     h->shard_valid = false;
     h->part_valid = false;
     h->part_assembled = false;
+    h->pre.valid = false;  // (whoever changes a bucket-ordered buffer called pending_materialize first)
 }
+static int32_t pending_materialize(esp_handle *h);
+
+// set-up of a producer-side partition (prepart_* below, next to run_partition)
+struct PartSetup {
+    bool on = false;
+    esprun::PartOut out;   // for the producer's PART kernel
+    esprun::RunSink sink;  // for its COUNT kernel
+    u32 *err = nullptr;    // window flag of the COUNT kernel
+    int K = 0, pb = 0, kind = -1;
+    i64 E = 0, chunks = 0;
+    double Ee = 0.0;
+    i64 *seg_out = nullptr, *runs_off = nullptr;
+    const unsigned long long *bucket_count = nullptr;
+    u64 *coarse = nullptr;
+    const u32 *dcount = nullptr;
+    const u64 *dlist = nullptr;
+};
+static int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSetup *ps);
+static int32_t prepart_rank(esp_handle *h, PartSetup *ps);
+static int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took);
 
 // call right before h->count grows by cnt entries that all carry `kind`
 static inline void note_kind(esp_handle *h, int kind, i64 cnt) {
@@ -138,9 +170,6 @@ static inline void note_kind(esp_handle *h, int kind, i64 cnt) {
     else if (h->kind_uniform != kind) h->kind_uniform = -2;
     h->kind_noted += cnt;
 }
-static bool fused_begin(esp_handle *h, i64 E_call, i64 nchunks, espgen::Fused *f);
-static void fused_invalidate(esp_handle *h);
-static void fused_reset(esp_handle *h);
 
 #define FAIL(h, code, ...)                                   \
     do {                                                     \
@@ -389,6 +418,7 @@ extern "C" int32_t esp_clone(esp_handle *h, esp_handle **out) {
         return st;
     };
     int32_t st = ESP_OK;
+    if ((st = pending_materialize(h)) != ESP_OK) return fail(st);
     HIPCK(h, hipStreamSynchronize(h->stream));  // everything the copy reads is complete
     if (h->count > 0) {
         if ((st = reserve_append(c, h->count)) != ESP_OK) return fail(st);
@@ -396,7 +426,6 @@ extern "C" int32_t esp_clone(esp_handle *h, esp_handle **out) {
             hipMemcpyAsync(c->vals.p, h->vals.p, sizeof(double) * (size_t)h->count, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
             return fail(ESP_ERR_HIP);
         c->count = h->count;
-        c->fused_state = 2;  // (no run lists came with these entries)
     }
     if ((st = fix_tail(h)) != ESP_OK) return fail(st);
     HIPCK(h, hipStreamSynchronize(h->stream));
@@ -460,6 +489,7 @@ extern "C" int32_t esp_nnz(const esp_handle *h, int64_t *nnz) {
 
 // ------------------------------------------------------------------------ append
 static int32_t reserve_append(esp_handle *h, i64 add) {
+    CK(pending_materialize(h));  // (an append behind a bucket-ordered batch: back to packed keys first)
     const i64 need = h->count + add;
     if (need <= h->cap) return ESP_OK;
     i64 ncap = std::max<i64>(need, h->cap + h->cap / 2);
@@ -501,7 +531,6 @@ static int32_t pack_device(esp_handle *h, const i64 *d_rows, const i64 *d_cols, 
     }
     HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
-    fused_invalidate(h);
     if (h->pin_scalar[0] != ~0ull)
         FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
              (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
@@ -639,7 +668,6 @@ extern "C" int32_t esp_append_host(esp_handle *h, const int64_t *rows, const int
     for (int i = 0; i < 2; i++) (void)hipEventDestroy(done[i]);
     if (rc != ESP_OK || e1 != hipSuccess || e2 != hipSuccess || hipGetLastError() != hipSuccess)
         FAIL(h, ESP_ERR_HIP, "esp_append_host: transfer failed");
-    fused_invalidate(h);
     if (h->pin_scalar[0] != ~0ull)
         FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
              (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
@@ -665,7 +693,6 @@ extern "C" int32_t esp_append_packed(esp_handle *h, const uint64_t *d_keys, cons
     HIPCK(h, hipMemcpyAsync((u64 *)h->keys.p + h->count, d_keys, sizeof(u64) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
     HIPCK(h, hipMemcpyAsync((double *)h->vals.p + h->count, d_vals, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
     sp.add(2);
-    fused_invalidate(h);
     h->count += count;
     pending_changed(h);
     return ESP_OK;
@@ -719,20 +746,48 @@ extern "C" int32_t esp_generate_fdrand_range(esp_handle *h, int64_t nx, int64_t 
     a.g_begin = node_begin;
     a.g_end = node_end;
     a.off_begin = off_b;
+    // (magic = 2^64 / d + 1: n / d = high half of magic * n for n, d < 2^32, d >= 2)
+    a.fast = (N < ((i64)1 << 32) && nx >= 2) ? 1 : 0;
+    a.magic_nx = a.fast ? ~0ull / (u64)nx + 1ull : 0;
+    a.magic_nxny = a.fast ? ~0ull / (u64)(nx * ny) + 1ull : 0;
     a.L = h->L;
     a.keys = (u64 *)h->keys.p + h->count;
     a.vals = (double *)h->vals.p + h->count;
     CK(ensure(h, h->misc, 256));
-    if (!fused_begin(h, E, (i64)grid_for(node_end - node_begin, espgen::THREADS), &a.fused)) fused_invalidate(h);
-    {
+    const dim3 grid(grid_for(node_end - node_begin, espgen::THREADS)), block(espgen::THREADS);
+    // the append is the partition when the buffer is empty and the stream is one an assembly loop emits: COUNT launch
+    // (ALU only), two tiny ranking launches, then every update goes straight to its bucket
+    PartSetup ps;
+    CK(prepart_begin(h, E, (i64)grid.x, kind, &ps));
+    a.part = ps.out;
+    bool took = false;
+    if (ps.on) {
+        {
+            Span sp(h, ESP_ST_HIST);
+            hipLaunchKernelGGL(espgen::fd_count_k, grid, block, 0, h->stream, a, ps.sink, ps.err);
+            sp.add(1);
+        }
+        CK(prepart_rank(h, &ps));
+        {
+            Span sp(h, ESP_ST_APPEND);
+            if (ps.out.k32)
+                hipLaunchKernelGGL(espgen::fdrand_part_k<true>, grid, block, 0, h->stream, a);
+            else
+                hipLaunchKernelGGL(espgen::fdrand_part_k<false>, grid, block, 0, h->stream, a);
+            sp.add(1);
+        }
+        CK(prepart_finish(h, &ps, &took));
+    }
+    if (!took) {  // stream order (the PART launch left without a store when the stream turned out not to be pre-sorted)
         Span sp(h, ESP_ST_APPEND);
-        hipLaunchKernelGGL(espgen::fdrand_k, dim3(grid_for(node_end - node_begin, espgen::THREADS)), dim3(espgen::THREADS), 0, h->stream, a);
+        hipLaunchKernelGGL(espgen::fdrand_k, grid, block, 0, h->stream, a);
         sp.add(1);
     }
     HIPCK(h, hipGetLastError());
     note_kind(h, kind, E);
     h->count += E;
     pending_changed(h);
+    h->pre.valid = took;
     return ESP_OK;
 }
 
@@ -781,15 +836,39 @@ extern "C" int32_t esp_generate_fem(esp_handle *h, int32_t dim, int64_t npd, uin
     a.L = h->L;
     a.keys = (u64 *)h->keys.p + h->count;
     a.vals = (double *)h->vals.p + h->count;
-    {
+    CK(ensure(h, h->misc, 256));
+    const dim3 grid(grid_for(nc, espgen::FEM_CELLS)), block(espgen::FEM_CELLS);
+    PartSetup ps;
+    CK(prepart_begin(h, E, (i64)grid.x, ESP_RAWUPDATE, &ps));  // (a shuffled cell order fails the COUNT launch's digit limit)
+    a.part = ps.out;
+    bool took = false;
+    if (ps.on) {
+        {
+            Span sp(h, ESP_ST_HIST);
+            hipLaunchKernelGGL(espgen::fem_count_k, grid, block, 0, h->stream, a, ps.sink, ps.err);
+            sp.add(1);
+        }
+        CK(prepart_rank(h, &ps));
+        {
+            Span sp(h, ESP_ST_APPEND);
+            if (ps.out.k32)
+                hipLaunchKernelGGL(espgen::fem_part_k<true>, grid, block, 0, h->stream, a);
+            else
+                hipLaunchKernelGGL(espgen::fem_part_k<false>, grid, block, 0, h->stream, a);
+            sp.add(1);
+        }
+        CK(prepart_finish(h, &ps, &took));
+    }
+    if (!took) {
         Span sp(h, ESP_ST_APPEND);
-        hipLaunchKernelGGL(espgen::fem_k, dim3(grid_for(nc, espgen::FEM_CELLS)), dim3(espgen::FEM_CELLS), 0, h->stream, a);
+        hipLaunchKernelGGL(espgen::fem_k, grid, block, 0, h->stream, a);
         sp.add(1);
     }
     HIPCK(h, hipGetLastError());
-    fused_invalidate(h);
+    note_kind(h, ESP_RAWUPDATE, E);
     h->count += E;
     pending_changed(h);
+    h->pre.valid = took;
     return ESP_OK;
 }
 
@@ -889,7 +968,6 @@ extern "C" int32_t esp_csc_device(esp_handle *h, const int64_t **d_colptr, const
 
 extern "C" int32_t esp_clear_pending(esp_handle *h) {
     if (!h) return ESP_ERR_INVALID;
-    fused_reset(h);
     h->count = 0;
     pending_changed(h);
     return ESP_OK;
@@ -898,7 +976,6 @@ extern "C" int32_t esp_clear_pending(esp_handle *h) {
 extern "C" int32_t esp_reset(esp_handle *h) {
     if (!h) return ESP_ERR_INVALID;
     (void)hipSetDevice(h->device);
-    fused_reset(h);
     h->count = 0;
     pending_changed(h);
     return init_empty_csc(h);
@@ -1088,11 +1165,9 @@ struct Sorted {
 };
 
 // ---- run lists of the pending entries (runpart.hpp) -------------------------------------------
-// Persistent per-handle arrays: the chunk boundaries, every chunk's runs, the bucket totals.  They
-// are filled either by run_hist_k at flush time or, chunk by chunk, by the producers themselves
-// ("fused": the flush then skips the histogram kernel, i.e. one full read of the keys).
+// Persistent per-handle arrays: every chunk's runs, the digits' own run lists, the bucket totals.  They are
+// filled by run_hist_k at flush time or by the COUNT launch of a producer whose append is the partition.
 struct ChunkArrays {
-    i64 *chunk_start;
     u32 *runs_d, *runs_c;
     u64 *nruns;
     unsigned long long *bucket_count;
@@ -1112,7 +1187,6 @@ static int32_t chunk_arrays(esp_handle *h, i64 Ccap, int pb, ChunkArrays *out) {
         off += (bytes + 255) & ~(size_t)255;
         return o;
     };
-    const size_t o_cs = carve(sizeof(i64) * (size_t)(Ccap + 2));
     const size_t o_rd = carve(sizeof(u32) * (size_t)RM), o_rc = carve(sizeof(u32) * (size_t)RM);
     const size_t o_nr = carve(sizeof(u64) * (size_t)(Ccap + 1 + espscan::workspace_elems(Ccap + 1)));
     const size_t o_dc = carve(sizeof(u32) * (size_t)NB);
@@ -1121,13 +1195,11 @@ static int32_t chunk_arrays(esp_handle *h, i64 Ccap, int pb, ChunkArrays *out) {
     const size_t o_dl = carve(sizeof(u64) * (size_t)NB * esprun::DCAP);
     const size_t o_co = carve(sizeof(u64) * (size_t)(NB / 256 + 2));
     if (h->chunkbuf.bytes < off || h->chunk_cap != Ccap || h->chunk_pb != pb) {
-        if (h->fused_state == 1) FAIL(h, ESP_ERR_STATE, "internal: run-list arrays resized while they hold producer data");
         CK(ensure(h, h->chunkbuf, off));
         h->chunk_cap = Ccap;
         h->chunk_pb = pb;
     }
     char *B = (char *)h->chunkbuf.p;
-    out->chunk_start = (i64 *)(B + o_cs);
     out->runs_d = (u32 *)(B + o_rd);
     out->runs_c = (u32 *)(B + o_rc);
     out->nruns = (u64 *)(B + o_nr);
@@ -1167,59 +1239,31 @@ static int plan_run_bits(i64 E, int K, u64 span) {
     }
     return planned > 8 ? std::min(planned, 20) : 0;
 }
+// prefix bits that bring the segments of E pending entries under the bucket kernel's capacity at the planned fill,
+// corrected by what the handle's last flush saw (seen_spread)
+static int plan_prefix_bits(const esp_handle *h, i64 E, int K, double *Ee_out) {
+    int planned = 0;
+    const double Ee = plan_entries(E, K, h->win_span);  // (see plan_entries: the window fills only part of its 2^K keys)
+    if (E > esplocal::CAP) {
+        const double target = plan_fill() * esplocal::CAP;
+        while (planned < K && Ee / (double)((i64)1 << planned) > target) planned++;
+    }
+    if (planned > 0 && h->seen_spread > 0.0 && h->seen_spread < 2.0 &&
+        Ee / (double)((i64)1 << (planned - 1)) * h->seen_spread <= 0.98 * esplocal::CAP)
+        planned--;  // (see seen_spread; a wrong guess costs one further pass and corrects itself)
+    // ... and irregular data (the longest segment well above the average) gets the bits up front that the last flush
+    // had to add in a further pass
+    for (int extra = 0; extra < 3 && planned > 0 && planned < K && h->seen_spread >= 1.0 && h->seen_spread < 8.0 &&
+                        Ee / (double)((i64)1 << planned) * h->seen_spread > (double)esplocal::CAP;
+         extra++)
+        planned++;
+    *Ee_out = Ee;
+    return planned;
+}
 static int window_bits(const esp_handle *h) {
     int K = 1;
     while (K < 62 && ((u64)1 << K) < h->win_span) K++;
     return K;
-}
-
-// a producer asks to emit the run lists of the `nchunks` chunks it is about to write
-// (E_call entries at the end of the buffer).  Returns false when fusion is not possible.
-static bool fused_begin(esp_handle *h, i64 E_call, i64 nchunks, espgen::Fused *f) {
-    memset(f, 0, sizeof *f);
-    // Off by default: measured on MI355X (256^3) the generator gets slower by what the histogram
-    // kernel cost (both are issue-bound, not bandwidth-bound), the step time does not move.
-    // force_path 7 switches it on (tests keep the path alive for a cheaper counting scheme).
-    if (h->force_path != 7 || h->fused_state == 2) return false;
-    const int K = window_bits(h);
-    if (h->fused_state == 0) {  // first producer of a batch decides the digit width
-        if (h->count != 0) return false;
-        const i64 E_expect = std::max<i64>(h->hint, E_call);  // the caller's capacity hint = expected batch size
-        const int pb = plan_run_bits(E_expect, K, h->win_span);
-        if (pb == 0) return false;
-        const i64 Ccap = std::max<i64>(nchunks, E_expect / 1024) + 64;
-        ChunkArrays ca;
-        if (chunk_arrays(h, Ccap, pb, &ca) != ESP_OK) return false;
-        if (hipMemsetAsync(ca.bucket_count, 0, sizeof(u64) * (size_t)(((i64)1 << pb) + 1), h->stream) != hipSuccess) return false;
-        if (hipMemsetAsync(ca.overflow, 0, 4, h->stream) != hipSuccess) return false;
-        if (hipMemsetAsync((u32 *)h->misc.p + 60, 0, 4, h->stream) != hipSuccess) return false;
-        h->fused_chunks = 0;
-        h->fused_K = K;
-    } else if (h->fused_K != K || h->fused_chunks + nchunks > h->chunk_cap) {
-        h->fused_state = 2;
-        return false;
-    }
-    ChunkArrays ca;
-    if (chunk_arrays(h, h->chunk_cap, h->chunk_pb, &ca) != ESP_OK) return false;
-    f->runs = esprun::RunSink{ca.runs_d, ca.runs_c, ca.nruns, ca.bucket_count, ca.overflow};
-    f->chunk_start = ca.chunk_start;
-    f->chunk_base = h->fused_chunks;
-    f->buf_base = h->count;
-    f->shift = K - h->chunk_pb;
-    f->base = h->win_base;
-    f->span = h->win_span;
-    f->err = (u32 *)h->misc.p + 60;
-    h->fused_state = 1;
-    h->fused_chunks += nchunks;
-    return true;
-}
-// any append that does not emit run lists, and every consumption of the buffer
-static void fused_invalidate(esp_handle *h) {
-    if (h->count > 0 || h->fused_state == 1) h->fused_state = 2;
-}
-static void fused_reset(esp_handle *h) {
-    h->fused_state = 0;
-    h->fused_chunks = 0;
 }
 
 // Single-pass partition on the top `pb` (9..20) bits of the key window, for pre-sorted streams
@@ -1245,6 +1289,126 @@ static int32_t aux_ready(esp_handle *h) {
     return ESP_OK;
 }
 
+// ---- producer-side partition: host side (the kernels: runpart.hpp "the append IS the partition") ----------
+// prepart_begin: a device-side producer is about to append E entries in `chunks` chunks (= its workgroups, at most
+// esprun::TILE entries each) -- kind >= 0: all of that kind.  ps->on = true when the append can be the partition:
+// empty buffer, a prefix of 9..20 bits that brings the buckets under the bucket kernel's capacity without reaching
+// into the row bits, handle not driven through esp_shard_* (its flush partitions by owner first).  Clears the tables.
+// force_path 16: never.
+static int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSetup *ps) {
+    ps->on = false;
+    memset(&ps->out, 0, sizeof ps->out);
+    if (h->count != 0 || h->shard_user || E <= esplocal::CAP || chunks >= ((i64)1 << 38)) return ESP_OK;
+    if (h->force_path == 2 || h->force_path == 5 || h->force_path == 12 || h->force_path == 16) return ESP_OK;
+    const int K = window_bits(h);
+    double Ee = 0.0;
+    const int planned = plan_prefix_bits(h, E, K, &Ee);
+    const int pb = planned;
+    const int shift = K - pb;
+    if (pb <= 8 || pb > 20 || shift < h->L.rb || shift > esplocal::MAX_REM_BITS) return ESP_OK;
+    const i64 NB = (i64)1 << pb;
+    ChunkArrays ca;
+    CK(chunk_arrays(h, chunks + 64, pb, &ca));
+    CK(ensure(h, h->runbuf, sizeof(i64) * (size_t)chunks * esprun::RMAX));
+    CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(NB + 1)));
+    CK(ensure(h, h->misc, 256));
+    CK(aux_ready(h));
+    unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
+    u32 *flags = (u32 *)h->misc.p + 60;
+    HIPCK(h, hipMemsetAsync(d_maxlen, 0, 64, h->stream));  // maxlen .. the four flag words
+    HIPCK(h, hipMemsetAsync(ca.dcount, 0, ca.clear_bytes, h->stream));
+    ps->sink = esprun::RunSink{ca.runs_d, ca.runs_c, ca.nruns, ca.bucket_count, flags + 1, ca.dcount, ca.dlist};
+    ps->err = flags;
+    ps->K = K;
+    ps->pb = pb;
+    ps->kind = kind;
+    ps->E = E;
+    ps->chunks = chunks;
+    ps->Ee = Ee;
+    ps->seg_out = (i64 *)h->seg[1].p;
+    ps->runs_off = (i64 *)h->runbuf.p;
+    ps->bucket_count = ca.bucket_count;
+    ps->coarse = ca.coarse;
+    ps->dcount = ca.dcount;
+    ps->dlist = ca.dlist;
+    esprun::PartOut &o = ps->out;
+    o.runs_d = ca.runs_d;
+    o.runs_off = ps->runs_off;
+    o.nruns = ca.nruns;
+    o.flags = flags;
+    o.maxlen = d_maxlen;
+    o.cap = esplocal::CAP;
+    o.k32 = (kind >= 0 && h->force_path != 14 && shift <= 32) ? 1 : 0;
+    o.shift = shift;
+    o.base = h->win_base;
+    o.span = h->win_span;
+    o.keys_out = (u64 *)h->keys.p;
+    o.vals_out = (double *)h->vals.p;
+    o.chunk_base = 0;
+    ps->on = true;
+    return ESP_OK;
+}
+// between the COUNT and the PART launch: bucket starts and run offsets (the two ranking launches of run_partition)
+static int32_t prepart_rank(esp_handle *h, PartSetup *ps) {
+    const i64 NB = (i64)1 << ps->pb;
+    unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
+    u32 *flags = (u32 *)h->misc.p + 60;
+    {
+        Span sp(h, ESP_ST_SCAN);
+        const unsigned g = (unsigned)grid_for(NB + 1, esprun::THREADS);
+        hipLaunchKernelGGL(esprun::run_coarse_k, dim3(g), dim3(esprun::THREADS), 0, h->stream, ps->bucket_count, NB, ps->coarse);
+        hipLaunchKernelGGL(esprun::run_rank_k, dim3(g), dim3(esprun::THREADS), 0, h->stream, ps->bucket_count, (const u64 *)ps->coarse,
+                           ps->dcount, ps->dlist, NB, ps->seg_out, ps->runs_off, d_maxlen, flags + 3);
+        sp.add(2);
+    }
+    HIPCK(h, hipEventRecord(h->aux_ev, h->stream));  // (the host reads the flags while the PART launch runs)
+    return ESP_OK;
+}
+// after the PART launch was issued: *took = false when it left without a store (window error, a chunk with too many
+// digits, a digit with too many runs: the caller issues the plain producer); else the handle's buffer is bucket-ordered
+static int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took) {
+    *took = false;
+    HIPCK(h, hipStreamWaitEvent(h->aux, h->aux_ev, 0));
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, (unsigned long long *)h->misc.p + 24, 64, hipMemcpyDeviceToHost, h->aux));
+    HIPCK(h, hipStreamSynchronize(h->aux));
+    const u32 f_err = (u32)h->pin_scalar[6], f_over = (u32)(h->pin_scalar[6] >> 32), f_many = (u32)(h->pin_scalar[7] >> 32);
+    if (f_err | f_over | f_many) {
+        // (flags[0] stays set for nobody: the plain producer follows and the flush's own partition checks the window)
+        HIPCK(h, hipMemsetAsync((u32 *)h->misc.p + 60, 0, 16, h->stream));
+        return ESP_OK;
+    }
+    if (ps->out.k32 && (i64)h->pin_scalar[0] > (i64)esplocal::CAP) return ESP_OK;  // (the K32 launch left without a store)
+    esp_handle::PrePart &pp = h->pre;
+    pp.K = ps->K;
+    pp.pb = ps->pb;
+    pp.maxlen = (i64)h->pin_scalar[0];
+    pp.key_bytes = ps->out.k32 ? 4 : 8;
+    pp.kind = ps->kind;
+    pp.E = ps->E;
+    pp.base = h->win_base;
+    pp.span = h->win_span;
+    pp.Ee = ps->Ee;
+    *took = true;  // (the caller sets pre.valid once the entries are counted in)
+    return ESP_OK;
+}
+// A bucket-ordered pending buffer is a valid pending buffer -- a stable permutation of the stream -- once its keys are
+// packed keys again: every call that reads or extends the pending entries other than the flush they were written for
+static int32_t pending_materialize(esp_handle *h) {
+    if (!h->pre.valid) return ESP_OK;
+    h->pre.valid = false;
+    if (h->pre.key_bytes != 4 || h->count == 0) return ESP_OK;
+    const esp_handle::PrePart &pp = h->pre;
+    CK(ensure(h, h->keys2, std::max(h->keys.bytes, sizeof(u64) * (size_t)h->count)));
+    Span sp(h, ESP_ST_COPY);
+    hipLaunchKernelGGL(esprun::expand_keys_k, dim3((unsigned)((i64)1 << pp.pb)), dim3(esprun::THREADS), 0, h->stream, (const u32 *)h->keys.p,
+                       (const i64 *)h->seg[1].p, pp.K - pp.pb, pp.base, (u32)pp.kind, (u64 *)h->keys2.p);
+    sp.add(1);
+    HIPCK(h, hipGetLastError());
+    std::swap(h->keys, h->keys2);
+    h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
+    return ESP_OK;
+}
+
 // mw != nullptr: buckets = mw->P * mw->nb (window r = digits [r*nb, (r+1)*nb)), pb = bits covering them
 static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u64 *kout, double *vout, int K, int pb,
                              i64 *seg_out, u64 *tile_first_out, bool *tiles_ready, bool *ok, i64 *maxlen_out,
@@ -1252,16 +1416,9 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
     const i64 E = h->count;
     const i64 NB = mw ? (i64)mw->P * (i64)mw->nb : (i64)1 << pb;
     CK(ensure(h, h->misc, 256));
-    const bool fused = !mw && h->fused_state == 1 && h->chunk_pb == pb && h->fused_K == K;
-    const i64 C = fused ? h->fused_chunks : ceil_div<i64>(E, esprun::TILE);
+    const i64 C = ceil_div<i64>(E, esprun::TILE);
     ChunkArrays ca;
-    if (fused) {
-        CK(chunk_arrays(h, h->chunk_cap, h->chunk_pb, &ca));
-    } else {
-        h->fused_state = 2;  // whatever the producers wrote is stale from here on
-        CK(chunk_arrays(h, C + 64, pb, &ca));
-    }
-    h->last_fused = fused ? 1 : 0;
+    CK(chunk_arrays(h, C + 64, pb, &ca));
     const i64 RM = C * esprun::RMAX;
     // scratch of this call
     size_t off = 0;
@@ -1283,8 +1440,6 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
     a.keys_out = kout;
     a.vals_out = vout;
     a.E = E;
-    a.chunk_start = ca.chunk_start;
-    a.fixed_chunks = fused ? 0 : 1;
     a.shift = mw ? mw_shift : K - pb;
     a.base = h->win_base;
     a.span = h->win_span;
@@ -1315,10 +1470,10 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
     *tiles_ready = false;
     // ranked: every digit collects its own runs, ONE kernel turns them into run offsets (run_rank_k), the
     // scatter kernel follows without a host round trip (force_path 12: the radix-ordered run list instead)
-    const bool ranked = !fused && h->force_path != 12;
+    const bool ranked = h->force_path != 12;
     h->last_run_order = 2;
     if (ranked) CK(aux_ready(h));
-    if (!fused) {
+    {
         a.overflow = flags + 1;
         if (ranked) {
             a.dcount = ca.dcount;
@@ -1488,25 +1643,12 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     u32 *d_werr = (u32 *)h->misc.p + 60;
     HIPCK(h, hipMemsetAsync(d_maxlen, 0, 64, h->stream));  // maxlen .. the four flag words (run_partition)
 
-    int planned = 0;
-    const double Ee = plan_entries(E, K, h->win_span);  // (see plan_entries: the window fills only part of its 2^K keys)
-    if (E > esplocal::CAP) {
-        const double target = plan_fill() * esplocal::CAP;
-        while (planned < K && Ee / (double)((i64)1 << planned) > target) planned++;
-        // one bit short of a whole number of 8-bit passes: an average fill of up to 95 % is worth
-        // trying with one pass less (the longest segment is checked after the planned passes and a
-        // further pass is added only if a segment really overflows)
-    }
-    if (planned > 0 && h->seen_spread > 0.0 && h->seen_spread < 2.0 &&
-        Ee / (double)((i64)1 << (planned - 1)) * h->seen_spread <= 0.98 * esplocal::CAP)
-        planned--;  // (see seen_spread; a wrong guess costs one further pass and corrects itself)
-    // ... and irregular data (the longest segment well above the average) gets the bits up front that the last flush
-    // had to add in a further pass
-    for (int extra = 0; extra < 3 && planned > 0 && planned < K && h->seen_spread >= 1.0 && h->seen_spread < 8.0 &&
-                        Ee / (double)((i64)1 << planned) * h->seen_spread > (double)esplocal::CAP;
-         extra++)
-        planned++;
+    double Ee = 0.0;
+    int planned = plan_prefix_bits(h, E, K, &Ee);
     const int planned_run = planned;  // the run-based pass takes up to 20 bits at once: no need to be tight
+    // one bit short of a whole number of 8-bit passes: an average fill of up to 95 % is worth
+    // trying with one pass less (the longest segment is checked after the planned passes and a
+    // further pass is added only if a segment really overflows)
     if (planned > 8 && planned % 8 == 1 && Ee / (double)((i64)1 << (planned - 1)) <= 0.95 * esplocal::CAP) planned--;
     const int npass = (planned + 7) / 8;
 
@@ -1551,7 +1693,7 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
                 done = pb;
                 planned = std::max(planned_run, pb);
                 npass_eff = (planned - pb + 7) / 8;
-                h->last_partition = h->last_fused ? 3 : 1;
+                h->last_partition = 1;
                 h->runs_penalty = 0;
                 maxlen = ml;
                 window_checked = true;
@@ -1950,7 +2092,30 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
     }
     i64 Zn = 0;
     bool use_local = h->force_path != 2;
-    if (h->part_assembled) {
+    if (h->pre.valid) {  // the producer's partition serves this flush if nothing changed since
+        const esp_handle::PrePart &pp = h->pre;
+        const bool usable = use_local && !h->part_assembled && pp.E == E && pp.base == h->win_base && pp.span == h->win_span &&
+                            pp.maxlen <= (i64)esplocal::CAP && pp.K - pp.pb <= esplocal::MAX_REM_BITS;
+        if (!usable) CK(pending_materialize(h));
+    }
+    if (h->pre.valid) {
+        const esp_handle::PrePart &pp = h->pre;
+        Sorted st;
+        st.sk = (const u64 *)h->keys.p;
+        st.sv = (const double *)h->vals.p;
+        st.in_primary = true;
+        st.S = 1 << pp.pb;
+        st.seg_start = (const i64 *)h->seg[1].p;
+        st.rem_bits = pp.K - pp.pb;
+        st.local_ok = true;
+        st.key_bytes = pp.key_bytes;
+        st.kind = pp.kind;
+        CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
+        CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
+        CK(flush_local(h, st, mode, &Zn));
+        h->last_partition = 4;
+        h->seen_spread = pp.Ee > 0.0 ? (double)pp.maxlen * std::ldexp(1.0, pp.pb) / pp.Ee : 0.0;
+    } else if (h->part_assembled) {
         // partitioned shard exchange: the segments are already formed (esp_shard_assemble)
         CK(ensure(h, h->misc, 256));
         HIPCK(h, hipMemsetAsync((u32 *)h->misc.p + 60, 0, 4, h->stream));
@@ -1980,17 +2145,25 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
             h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
             st.in_primary = true;
         }
-        if (st.local_ok)
-            CK(flush_local(h, st, mode, &Zn));
-        else
+        if (st.local_ok) {
+            const int32_t rc = flush_local(h, st, mode, &Zn);
+            if (rc != ESP_OK && st.key_bytes == 4) {
+                // the batch stays pending: its packed keys are intact in the scratch pair (the partition wrote the 4-byte
+                // keys into the other one)
+                std::swap(h->keys, h->keys2);
+                std::swap(h->vals, h->vals2);
+                h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
+            }
+            CK(rc);
+        } else {
             use_local = false;
+        }
     }
     if (!use_local && !h->part_assembled) CK(flush_global(h, mode, &Zn));
     h->last_path = (use_local || h->part_assembled) ? 1 : 2;
     if (Zn > 0 && pattern_changed) *pattern_changed = 1;
     h->values_version++;  // (hits were applied in place)
     HIPCK(h, hipGetLastError());
-    fused_reset(h);
     h->count = 0;
     pending_changed(h);
     if (h->timing && fa) {
@@ -2045,6 +2218,8 @@ extern "C" int32_t esp_debug_last_path(const esp_handle *h, int32_t *path) {
 // every destination receives its entries in this shard's append order.
 static int32_t shard_prepare(esp_handle *h, int P, espradix::Pass *out) {
     if (P < 1 || P > 256) FAIL(h, ESP_ERR_INVALID, "shards: nshards must be in 1..256");
+    h->shard_user = true;
+    CK(pending_materialize(h));
     h->part_valid = h->part_assembled = false;  // (its tables share scratch arrays with this path)
     if ((double)h->n * (double)P >= 9.0e18) FAIL(h, ESP_ERR_UNSUPPORTED, "shards: n*nshards overflows");
     const i64 E = h->count;
@@ -2197,9 +2372,10 @@ extern "C" int32_t esp_shard_exchange_begin(esp_handle *h, int32_t nshards, int3
     std::swap(h->keys, h->keys2);
     std::swap(h->vals, h->vals2);
     h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
-    h->fused_state = 2;
     h->count = newcount;
+    h->kind_noted = 0;  // entries of other ranks, with kinds of their own, are about to be placed among these
     pending_changed(h);
+    if (h->count > 0) h->kind_uniform = -2;
     *d_send_keys = (uint64_t *)h->keys.p + SR;
     *d_send_vals = (double *)h->vals.p + SR;
     return ESP_OK;
@@ -2210,6 +2386,8 @@ extern "C" int32_t esp_shard_exchange_place(esp_handle *h, int64_t position, con
     if (!h || position < 0 || count < 0 || position + count > h->count) return ESP_ERR_INVALID;
     if (count == 0) return ESP_OK;
     (void)hipSetDevice(h->device);
+    h->kind_uniform = -2;  // (foreign entries: kinds unknown to this handle's bookkeeping)
+    h->kind_noted = 0;
     Span sp(h, ESP_ST_COPY);
     HIPCK(h, hipMemcpyAsync((u64 *)h->keys.p + position, d_keys, sizeof(u64) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
     HIPCK(h, hipMemcpyAsync((double *)h->vals.p + position, d_vals, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
@@ -2520,6 +2698,8 @@ extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t s
     const int P = nshards;
     if (P < 1 || self < 0 || self >= P || entries_per_shard < 0) FAIL(h, ESP_ERR_INVALID, "esp_shard_partition: arguments");
     (void)hipSetDevice(h->device);
+    h->shard_user = true;
+    CK(pending_materialize(h));
     h->part_valid = h->part_assembled = false;
     h->part_own_update = h->kind_uniform == ESP_UPDATE && h->kind_noted == h->count;
     if (P > esprun::MW_MAX || P > esplocal::MAX_PIECES || h->force_path == 11) return ESP_OK;  // caller uses the plain exchange
@@ -2568,7 +2748,6 @@ extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t s
         std::swap(h->keys, h->keys2);
         std::swap(h->vals, h->vals2);
         h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
-        h->fused_state = 2;
         h->shard_valid = false;
     } else {
         HIPCK(h, hipMemsetAsync(bstart, 0, sizeof(i64) * (size_t)(NB + 1), h->stream));
@@ -2687,8 +2866,9 @@ extern "C" int32_t esp_shard_assemble(esp_handle *h, const uint64_t *const *d_re
         std::swap(h->vals, h->vals2);
         h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
         h->count = total;
-        h->fused_state = 2;
+        h->kind_noted = 0;  // (the received entries carry kinds of their own)
         pending_changed(h);
+        if (h->count > 0) h->kind_uniform = -2;
         return ESP_OK;
     }
     h->count = total;

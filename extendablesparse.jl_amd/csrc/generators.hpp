@@ -4,22 +4,12 @@
 // the ordered fold reproduces the CPU accumulation order bit for bit.
 // Compiled with -ffp-contract=off: no FMA contraction, values match the oracle's bits.
 #pragma once
+#include <type_traits>
+
 #include "common.hpp"
 #include "runpart.hpp"
 
 namespace espgen {
-
-// Optional: the producer also emits the run list of its chunk (runpart.hpp), so that the flush can
-// skip the histogram kernel (one full read of the keys).  runs.runs_d == nullptr switches it off.
-struct Fused {
-    esprun::RunSink runs;
-    i64 *chunk_start;  // absolute buffer position of every chunk (+ the end of the last one)
-    i64 chunk_base;    // index of this launch's first chunk
-    i64 buf_base;      // buffer position of the first entry this launch writes
-    int shift;         // digit = (((key >> 2) - base) >> shift)
-    u64 base, span;
-    u32 *err;
-};
 
 constexpr int THREADS = 256;
 
@@ -57,7 +47,10 @@ struct FdArgs {
     i64 total;  // number of updates of the generated node range
     i64 g_begin, g_end;  // node range [g_begin, g_end) (0-based l-1) of the loop nest
     i64 off_begin;       // stream position of node g_begin
-    Fused fused;
+    // nx*ny*nz < 2^32: node -> (i,j,k) with two multiply-high instead of 64-bit divisions (fd_node)
+    int fast;
+    u64 magic_nx, magic_nxny;
+    esprun::PartOut part;  // the PART kernels: the append is the partition (runpart.hpp)
     KeyLayout L;
     u64 *keys;
     double *vals;
@@ -89,6 +82,25 @@ __device__ __forceinline__ i64 fd_offset(const FdArgs &a, i64 i, i64 j, i64 k, i
 
 constexpr int FD_MAX_PER_NODE = 15;  // 3 pairs x 4 + 3 boundary terms
 
+// n / d for n, d < 2^32 with magic = 2^64 / d + 1 (host: fd_magic)
+__device__ __forceinline__ u32 fast_div(u32 n, u64 magic) { return (u32)__umul64hi(magic, (u64)n); }
+// node g (0-based l-1) -> (i,j,k), 1-based
+__device__ __forceinline__ void fd_node(const FdArgs &a, i64 g, i64 *i, i64 *j, i64 *k) {
+    if (a.fast) {
+        const u32 g32 = (u32)g, nx = (u32)a.nx, nxny = (u32)(a.nx * a.ny);
+        const u32 k0 = fast_div(g32, a.magic_nxny);
+        const u32 rem = g32 - k0 * nxny;
+        const u32 j0 = fast_div(rem, a.magic_nx);
+        *i = (i64)(rem - j0 * nx) + 1;
+        *j = (i64)j0 + 1;
+        *k = (i64)k0 + 1;
+    } else {
+        *i = g % a.nx + 1;
+        *j = (g / a.nx) % a.ny + 1;
+        *k = g / (a.nx * a.ny) + 1;
+    }
+}
+
 __device__ __forceinline__ void fd_put(const FdArgs &a, u64 *lk, double *lv, int &o, double v, i64 row, i64 col) {
     lk[o] = esp_pack(a.L, row, col, a.kind);
     lv[o] = v;
@@ -103,31 +115,20 @@ __device__ __forceinline__ void fd_pair(const FdArgs &a, u64 *lk, double *lv, in
 
 // One workgroup = 256 consecutive nodes.  Every node knows the exact position of its updates in
 // the sequential stream (closed form), the workgroup's updates form one contiguous range of the
-// buffer: they are staged in LDS and written with coalesced 16-byte stores (K1: "coalesced HBM
-// stores on the append path").  Writes 16 B per update, reads nothing.
-__global__ __launch_bounds__(THREADS) void fdrand_k(FdArgs a) {
-    __shared__ u64 lk[THREADS * FD_MAX_PER_NODE];
-    __shared__ double lv[THREADS * FD_MAX_PER_NODE];
-    __shared__ u32 rd[esprun::RMAX];
-    __shared__ u32 rc[esprun::RMAX];
-    __shared__ u32 rover;
-    if (threadIdx.x < esprun::RMAX) {
-        rd[threadIdx.x] = esprun::EMPTY;
-        rc[threadIdx.x] = 0;
-    }
-    if (threadIdx.x == 0) rover = 0;
-    int my_first = 0, my_count = 0;
+// stream: they are staged in LDS in stream order.  Returns the range [off0, off0 + cnt) of the stream.
+__device__ __forceinline__ void fd_stage(const FdArgs &a, u64 *lk, double *lv, i64 *off0_out, int *cnt_out) {
     const i64 N = a.g_end;
     const i64 g0 = a.g_begin + (i64)blockIdx.x * THREADS;
     const i64 g = g0 + threadIdx.x;  // node l-1
     i64 cy, cz;
     // stream position of the first node of this workgroup and of the next one
-    const i64 i0 = g0 % a.nx + 1, j0 = (g0 / a.nx) % a.ny + 1, k0 = g0 / (a.nx * a.ny) + 1;
+    i64 i0, j0, k0;
+    fd_node(a, g0, &i0, &j0, &k0);
     const i64 off0 = fd_offset(a, i0, j0, k0, &cy, &cz) - a.off_begin;
     if (g < N) {
-        const i64 i = g % a.nx + 1, j = (g / a.nx) % a.ny + 1, k = g / (a.nx * a.ny) + 1;
+        i64 i, j, k;
+        fd_node(a, g, &i, &j, &k);
         int o = (int)(fd_offset(a, i, j, k, &cy, &cz) - a.off_begin - off0);
-        my_first = o;
         const i64 l = g + 1;
         const u64 c = 6ull * (u64)g;
         if (i < a.nx) fd_pair(a, lk, lv, o, fd_rand(a.rand_mode, a.seed, c + 0) * a.hy * a.hz / a.hx, l, l + 1);
@@ -136,7 +137,6 @@ __global__ __launch_bounds__(THREADS) void fdrand_k(FdArgs a) {
         if (a.ny > 2 && (j == 1 || j == a.ny)) fd_put(a, lk, lv, o, fd_rand(a.rand_mode, a.seed, c + 3) * a.hx * a.hz, l, l);
         if (k < a.nz) fd_pair(a, lk, lv, o, fd_rand(a.rand_mode, a.seed, c + 4) * a.hx * a.hy / a.hz, l, l + a.nx * a.ny);
         if (a.nz > 2 && (k == 1 || k == a.nz)) fd_put(a, lk, lv, o, fd_rand(a.rand_mode, a.seed, c + 5) * a.hx * a.hy, l, l);
-        my_count = o - my_first;
     }
     // total of the workgroup = position of the first node of the next workgroup (or the stream end)
     i64 off1;
@@ -144,31 +144,17 @@ __global__ __launch_bounds__(THREADS) void fdrand_k(FdArgs a) {
     if (g1 >= N) {
         off1 = a.total;
     } else {
-        const i64 i1 = g1 % a.nx + 1, j1 = (g1 / a.nx) % a.ny + 1, k1 = g1 / (a.nx * a.ny) + 1;
+        i64 i1, j1, k1;
+        fd_node(a, g1, &i1, &j1, &k1);
         off1 = fd_offset(a, i1, j1, k1, &cy, &cz) - a.off_begin;
     }
-    const int cnt = (int)(off1 - off0);
-    __syncthreads();
-    if (a.fused.runs.runs_d) {  // run list of this workgroup's chunk (every thread owns <= 15 entries)
-        const Fused &f = a.fused;
-        u32 dig[FD_MAX_PER_NODE];
-        u32 pend = 0;
-#pragma unroll
-        for (int q = 0; q < FD_MAX_PER_NODE; q++) {
-            const bool valid = q < my_count;
-            dig[q] = valid ? esprun::run_digit(lk[my_first + q], f.base, f.span, f.shift, f.err) : 0u;
-            pend |= valid ? (1u << q) : 0u;
-        }
-        const i64 chunk = f.chunk_base + blockIdx.x;
-        if (threadIdx.x == 0) {
-            f.chunk_start[chunk] = f.buf_base + off0;
-            if (blockIdx.x == gridDim.x - 1) f.chunk_start[chunk + 1] = f.buf_base + off1;
-        }
-        esprun::count_runs<FD_MAX_PER_NODE>(dig, pend, chunk, f.runs, rd, rc, &rover);
-    }
-    // coalesced copy-out; 16-byte stores on the aligned body
-    u64 *gk = a.keys + off0;
-    double *gv = a.vals + off0;
+    *off0_out = off0;
+    *cnt_out = (int)(off1 - off0);
+}
+
+// coalesced copy-out of a staged range to its place in the stream; 16-byte stores on the aligned body
+template <int NT>
+__device__ __forceinline__ void copy_out_staged(const u64 *lk, const double *lv, int cnt, u64 *gk, double *gv) {
     const int head = (int)(((uintptr_t)gk >> 3) & 1);  // first element not 16-byte aligned
     if (threadIdx.x == 0 && head && cnt > 0) {
         gk[0] = lk[0];
@@ -179,14 +165,121 @@ __global__ __launch_bounds__(THREADS) void fdrand_k(FdArgs a) {
     typedef double dbl2 __attribute__((ext_vector_type(2)));
     ull2 *gk2 = reinterpret_cast<ull2 *>(gk + head);
     dbl2 *gv2 = reinterpret_cast<dbl2 *>(gv + head);
-    for (int q = threadIdx.x; q < npair; q += THREADS) {
+    for (int q = threadIdx.x; q < npair; q += NT) {
         gk2[q] = ull2{lk[head + 2 * q], lk[head + 2 * q + 1]};
         gv2[q] = dbl2{lv[head + 2 * q], lv[head + 2 * q + 1]};
     }
-    if (threadIdx.x == 0 && ((cnt - head) & 1)) {
+    if (threadIdx.x == 0 && cnt > 0 && ((cnt - head) & 1)) {
         gk[cnt - 1] = lk[cnt - 1];
         gv[cnt - 1] = lv[cnt - 1];
     }
+}
+
+// The stream goes to the buffer as it is (coalesced 16-byte stores: K1, "coalesced HBM stores on the append path";
+// writes 16 B per update, reads nothing).
+__global__ __launch_bounds__(THREADS) void fdrand_k(FdArgs a) {
+    __shared__ u64 lk[THREADS * FD_MAX_PER_NODE];
+    __shared__ double lv[THREADS * FD_MAX_PER_NODE];
+    i64 off0;
+    int cnt;
+    fd_stage(a, lk, lv, &off0, &cnt);
+    __syncthreads();
+    copy_out_staged<THREADS>(lk, lv, cnt, a.keys + off0, a.vals + off0);
+}
+
+// What a node sends where: 2 updates per pair it starts to its own column and 2 to the partner's, its boundary terms
+// to its own (fd_pair / fd_put above) -- four (column, count) items; px/py/pz: the node starts a pair in x/y/z
+struct FdItems {
+    u32 dig[4], wt[4];
+    bool px, py, pz, bx, by, bz;
+    i64 i, j, k;
+};
+__device__ __forceinline__ void fd_items(const FdArgs &a, i64 g, FdItems &it, u32 *err) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) it.dig[q] = it.wt[q] = 0;
+    it.px = it.py = it.pz = it.bx = it.by = it.bz = false;
+    if (g >= a.g_end) return;
+    fd_node(a, g, &it.i, &it.j, &it.k);
+    it.px = it.i < a.nx;
+    it.py = it.j < a.ny;
+    it.pz = it.k < a.nz;
+    it.bx = it.i == 1 || it.i == a.nx;
+    it.by = a.ny > 2 && (it.j == 1 || it.j == a.ny);
+    it.bz = a.nz > 2 && (it.k == 1 || it.k == a.nz);
+    const esprun::PartOut &p = a.part;
+    it.wt[0] = 2u * ((u32)it.px + (u32)it.py + (u32)it.pz) + (u32)it.bx + (u32)it.by + (u32)it.bz;
+    it.wt[1] = 2u * (u32)it.px;
+    it.wt[2] = 2u * (u32)it.py;
+    it.wt[3] = 2u * (u32)it.pz;
+    it.dig[0] = esprun::column_digit(g, a.L.rb, p.base, p.span, p.shift, err);
+    if (it.px) it.dig[1] = esprun::column_digit(g + 1, a.L.rb, p.base, p.span, p.shift, err);
+    if (it.py) it.dig[2] = esprun::column_digit(g + a.nx, a.L.rb, p.base, p.span, p.shift, err);
+    if (it.pz) it.dig[3] = esprun::column_digit(g + a.nx * a.ny, a.L.rb, p.base, p.span, p.shift, err);
+}
+
+// COUNT launch of the stencil producer: no update is formed.  Same chunks (workgroups of 256 nodes) as the PART launch.
+__global__ __launch_bounds__(THREADS) void fd_count_k(FdArgs a, esprun::RunSink sink, u32 *err) {
+    __shared__ u32 rd[esprun::RMAX];
+    __shared__ u32 rc[esprun::RMAX];
+    __shared__ u32 over;
+    if (threadIdx.x < esprun::RMAX) {
+        rd[threadIdx.x] = esprun::EMPTY;
+        rc[threadIdx.x] = 0;
+    }
+    if (threadIdx.x == 0) over = 0;
+    __syncthreads();
+    FdItems it;
+    fd_items(a, a.g_begin + (i64)blockIdx.x * THREADS + threadIdx.x, it, err);
+    esprun::count_runs_weighted<4>(it.dig, it.wt, a.part.chunk_base + blockIdx.x, sink, rd, rc, &over);
+}
+
+// PART launch: every update goes straight to its bucket -- the flush needs no partition pass.  The workgroup's updates
+// are staged in LDS run by run (esprun::tile_slots: a node's updates for one column lie together, in call order) and
+// every run is copied to `run offset` with consecutive stores.  K32: 4-byte keys (the bits below the bucket prefix;
+// 12 B per update, 46 KiB of LDS: 3 workgroups per CU); else packed keys.
+template <bool K32>
+__global__ __launch_bounds__(THREADS) void fdrand_part_k(FdArgs a) {
+    typedef typename std::conditional<K32, u32, u64>::type KT;
+    __shared__ KT lk[THREADS * FD_MAX_PER_NODE];
+    __shared__ double lv[THREADS * FD_MAX_PER_NODE];
+    __shared__ esprun::TileLds<THREADS / ESP_WAVE> S;
+    const esprun::PartOut &p = a.part;
+    if (K32 && *p.maxlen > (unsigned long long)p.cap) return;  // (uniform; the host issues the plain producer instead)
+    const i64 g = a.g_begin + (i64)blockIdx.x * THREADS + threadIdx.x;
+    FdItems it;
+    fd_items(a, g, it, nullptr);  // (the COUNT launch checked the window)
+    u32 slot[4];
+    int total;
+    if (!esprun::tile_slots<4, THREADS / ESP_WAVE>(p, p.chunk_base + blockIdx.x, it.dig, it.wt, slot, S, &total)) return;
+    const u32 kmask = p.shift >= 32 ? 0xFFFFFFFFu : ((1u << p.shift) - 1u);
+    auto put = [&](u32 at, double v, i64 row, i64 col) {
+        const u64 kp = ((u64)(col - 1) << a.L.rb) | (u64)(row - 1);
+        if constexpr (K32)
+            lk[at] = (u32)(kp - p.base) & kmask;
+        else
+            lk[at] = (kp << ESP_TAG_BITS) | (u64)a.kind;
+        lv[at] = v;
+    };
+    // update_pair (sprand.jl:87-92): (l,l2) (l2,l) (l,l) (l2,l2) -- column l2 gets the first and the last one
+    auto pair = [&](u32 &own, u32 other, double v, i64 l, i64 l2) {
+        put(other, -v, l, l2);
+        put(own++, -v, l2, l);
+        put(own++, v, l, l);
+        put(other + 1, v, l2, l2);
+    };
+    if (g < a.g_end) {
+        const i64 l = g + 1;
+        const u64 c = 6ull * (u64)g;
+        u32 own = slot[0];
+        if (it.px) pair(own, slot[1], fd_rand(a.rand_mode, a.seed, c + 0) * a.hy * a.hz / a.hx, l, l + 1);
+        if (it.bx) put(own++, fd_rand(a.rand_mode, a.seed, c + 1) * a.hy * a.hz, l, l);
+        if (it.py) pair(own, slot[2], fd_rand(a.rand_mode, a.seed, c + 2) * a.hx * a.hz / a.hy, l, l + a.nx);
+        if (it.by) put(own++, fd_rand(a.rand_mode, a.seed, c + 3) * a.hx * a.hz, l, l);
+        if (it.pz) pair(own, slot[3], fd_rand(a.rand_mode, a.seed, c + 4) * a.hx * a.hy / a.hz, l, l + a.nx * a.ny);
+        if (it.bz) put(own++, fd_rand(a.rand_mode, a.seed, c + 5) * a.hx * a.hy, l, l);
+    }
+    __syncthreads();
+    esprun::copy_out_runs<KT, THREADS>(p, lk, lv, total, S.lstart, S.roff);
 }
 
 // ---- P1 FEM stream (test/femtools.jl:45-72) on a Kuhn-triangulated tensor grid --------
@@ -198,6 +291,7 @@ struct FemArgs {
     int bits;  // even bit count of the Feistel domain
     double h;
     KeyLayout L;
+    esprun::PartOut part;  // part.on: the append is the partition (runpart.hpp)
     u64 *keys;
     double *vals;
 };
@@ -221,23 +315,13 @@ __device__ __forceinline__ u64 fem_cell_at(const FemArgs &a, i64 pos) {
     return x;
 }
 
-// One workgroup = FEM_CELLS consecutive stream positions; the (dim+1)(dim+2) updates of a cell are
-// staged in LDS and the workgroup's contiguous range is written with coalesced 16-byte stores.
-constexpr int FEM_CELLS = 128;
-__global__ __launch_bounds__(FEM_CELLS) void fem_k(FemArgs a) {
-    __shared__ u64 lk[FEM_CELLS * 20];
-    __shared__ double lv[FEM_CELLS * 20];
-    const i64 p0 = (i64)blockIdx.x * FEM_CELLS;
-    const i64 p = p0 + threadIdx.x;
-    const int per = (a.dim + 1) * (a.dim + 2);
-    if (p < a.ncells) {
-    const i64 cell = (i64)fem_cell_at(a, p);
+// vertices of a cell of the Kuhn triangulation: grid coordinates vx[k][d] and node numbers (1-based)
+__device__ __forceinline__ void fem_vertices(const FemArgs &a, i64 cell, i64 (&vx)[4][3], i64 (&nodes)[4]) {
     const int dim = a.dim;
     const int K = dim == 2 ? 2 : 6;
     const i64 q = a.npd - 1;
     const i64 cube = cell / K;
     const int s = (int)(cell % K);
-    i64 vx[4][3];
     vx[0][0] = cube % q;
     vx[0][1] = (cube / q) % q;
     vx[0][2] = dim == 3 ? cube / (q * q) : 0;
@@ -252,12 +336,29 @@ __global__ __launch_bounds__(FEM_CELLS) void fem_k(FemArgs a) {
             for (int d = 0; d < 3; d++) vx[k + 1][d] = vx[k][d] + (d == ax ? 1 : 0);
         }
     }
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (k <= dim) nodes[k] = 1 + vx[k][0] + a.npd * (vx[k][1] + a.npd * vx[k][2]);
+}
+
+// One workgroup = FEM_CELLS consecutive stream positions; the (dim+1)(dim+2) updates of a cell are
+// staged in LDS in stream order.
+constexpr int FEM_CELLS = 128;
+constexpr int FEM_MAX_PER_CELL = 20;
+// slot == nullptr: stream order from LDS position o0 on (packed keys); else entry (il,jl) goes to the column's item
+// (esprun::tile_slots) and KT = u32 stages the key bits below the bucket prefix
+template <typename KT>
+__device__ __forceinline__ void fem_stage(const FemArgs &a, KT *lk, double *lv, int o0, const u32 *slot, i64 p) {
+    if (p >= a.ncells) return;
+    const i64 cell = (i64)fem_cell_at(a, p);
+    const int dim = a.dim;
+    i64 vx[4][3];
     i64 nodes[4];
+    fem_vertices(a, cell, vx, nodes);
     double X[4][3];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
         if (k <= dim) {
-            nodes[k] = 1 + vx[k][0] + a.npd * (vx[k][1] + a.npd * vx[k][2]);
 #pragma unroll
             for (int d = 0; d < 3; d++) X[k][d] = (double)vx[k][d] * a.h;
         }
@@ -315,47 +416,93 @@ __global__ __launch_bounds__(FEM_CELLS) void fem_k(FemArgs a) {
                 S[jl][il] = sacc;
             }
         }
-    int o = threadIdx.x * per;
+    int o = o0;
+    const u32 kmask = a.part.shift >= 32 ? 0xFFFFFFFFu : ((1u << a.part.shift) - 1u);
+    auto put = [&](int at, i64 row, i64 col, double v) {
+        if constexpr (sizeof(KT) == 4)
+            lk[at] = (u32)((((u64)(col - 1) << a.L.rb) | (u64)(row - 1)) - a.part.base) & kmask;
+        else
+            lk[at] = esp_pack(a.L, row, col, ESP_RAWUPDATE);
+        lv[at] = v;
+    };
 #pragma unroll
     for (int il = 0; il < 4; il++) {
         if (il <= dim) {
-            lk[o] = esp_pack(a.L, nodes[il], nodes[il], ESP_RAWUPDATE);
-            lv[o] = 0.1 * vol / (double)(dim + 1);
+            put(slot ? (int)slot[il] + il : o, nodes[il], nodes[il], 0.1 * vol / (double)(dim + 1));
             o++;
 #pragma unroll
             for (int jl = 0; jl < 4; jl++) {
                 if (jl <= dim) {
-                    lk[o] = esp_pack(a.L, nodes[il], nodes[jl], ESP_RAWUPDATE);
-                    lv[o] = vol * S[il][jl];
+                    put(slot ? (int)slot[jl] + il + (il >= jl ? 1 : 0) : o, nodes[il], nodes[jl], vol * S[il][jl]);
                     o++;
                 }
             }
         }
     }
-    }  // p < ncells
+}
+
+__global__ __launch_bounds__(FEM_CELLS) void fem_k(FemArgs a) {
+    __shared__ u64 lk[FEM_CELLS * FEM_MAX_PER_CELL];
+    __shared__ double lv[FEM_CELLS * FEM_MAX_PER_CELL];
+    const i64 p0 = (i64)blockIdx.x * FEM_CELLS;
+    const int per = (a.dim + 1) * (a.dim + 2);
+    fem_stage(a, lk, lv, threadIdx.x * per, nullptr, p0 + threadIdx.x);
     __syncthreads();
-    const i64 ncell_blk = min((i64)FEM_CELLS, a.ncells - p0);
-    const int cnt = (int)ncell_blk * per;
-    u64 *gk = a.keys + p0 * per;
-    double *gv = a.vals + p0 * per;
-    const int head = (int)(((uintptr_t)gk >> 3) & 1);
-    if (threadIdx.x == 0 && head && cnt > 0) {
-        gk[0] = lk[0];
-        gv[0] = lv[0];
+    const int cnt = (int)min((i64)FEM_CELLS, a.ncells - p0) * per;
+    copy_out_staged<FEM_CELLS>(lk, lv, cnt, a.keys + p0 * per, a.vals + p0 * per);
+}
+
+// the vertex columns of a cell as (digit, count) items: every vertex column receives dim+2 updates (one per row of
+// the element matrix, one more for the diagonal's mass term)
+__device__ __forceinline__ void fem_items(const FemArgs &a, i64 pos, u32 (&dig)[4], u32 (&wt)[4], u32 *err) {
+#pragma unroll
+    for (int k = 0; k < 4; k++) dig[k] = wt[k] = 0;
+    if (pos >= a.ncells) return;
+    i64 vx[4][3];
+    i64 nodes[4];
+    fem_vertices(a, (i64)fem_cell_at(a, pos), vx, nodes);
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (k <= a.dim) {
+            wt[k] = (u32)(a.dim + 2);
+            dig[k] = esprun::column_digit(nodes[k] - 1, a.L.rb, a.part.base, a.part.span, a.part.shift, err);
+        }
+}
+
+// COUNT launch of the FEM producer (same chunks -- workgroups of 128 cells -- as the PART launch)
+__global__ __launch_bounds__(FEM_CELLS) void fem_count_k(FemArgs a, esprun::RunSink sink, u32 *err) {
+    __shared__ u32 rd[esprun::RMAX];
+    __shared__ u32 rc[esprun::RMAX];
+    __shared__ u32 over;
+    if (threadIdx.x < esprun::RMAX) {
+        rd[threadIdx.x] = esprun::EMPTY;
+        rc[threadIdx.x] = 0;
     }
-    const int npair = (cnt - head) >> 1;
-    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
-    typedef double dbl2 __attribute__((ext_vector_type(2)));
-    ull2 *gk2 = reinterpret_cast<ull2 *>(gk + head);
-    dbl2 *gv2 = reinterpret_cast<dbl2 *>(gv + head);
-    for (int q = threadIdx.x; q < npair; q += FEM_CELLS) {
-        gk2[q] = ull2{lk[head + 2 * q], lk[head + 2 * q + 1]};
-        gv2[q] = dbl2{lv[head + 2 * q], lv[head + 2 * q + 1]};
-    }
-    if (threadIdx.x == 0 && cnt > 0 && ((cnt - head) & 1)) {
-        gk[cnt - 1] = lk[cnt - 1];
-        gv[cnt - 1] = lv[cnt - 1];
-    }
+    if (threadIdx.x == 0) over = 0;
+    __syncthreads();
+    u32 dig[4], wt[4];
+    fem_items(a, (i64)blockIdx.x * FEM_CELLS + threadIdx.x, dig, wt, err);
+    esprun::count_runs_weighted<4>(dig, wt, a.part.chunk_base + blockIdx.x, sink, rd, rc, &over);
+}
+
+// PART launch of the FEM producer (see fdrand_part_k): the updates of a cell for vertex column jl lie together, in
+// call order: row il's term at il (+1 from the diagonal's row on: the mass term comes right before the diagonal)
+template <bool K32>
+__global__ __launch_bounds__(FEM_CELLS) void fem_part_k(FemArgs a) {
+    typedef typename std::conditional<K32, u32, u64>::type KT;
+    __shared__ KT lk[FEM_CELLS * FEM_MAX_PER_CELL];
+    __shared__ double lv[FEM_CELLS * FEM_MAX_PER_CELL];
+    __shared__ esprun::TileLds<FEM_CELLS / ESP_WAVE> S;
+    const esprun::PartOut &p = a.part;
+    if (K32 && *p.maxlen > (unsigned long long)p.cap) return;
+    const i64 pos = (i64)blockIdx.x * FEM_CELLS + threadIdx.x;
+    u32 dig[4], wt[4], slot[4];
+    fem_items(a, pos, dig, wt, nullptr);
+    int total;
+    if (!esprun::tile_slots<4, FEM_CELLS / ESP_WAVE>(p, p.chunk_base + blockIdx.x, dig, wt, slot, S, &total)) return;
+    fem_stage(a, lk, lv, 0, slot, pos);
+    __syncthreads();
+    esprun::copy_out_runs<KT, FEM_CELLS>(p, lk, lv, total, S.lstart, S.roff);
 }
 
 }  // namespace espgen

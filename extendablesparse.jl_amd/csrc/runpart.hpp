@@ -39,8 +39,7 @@ struct Args {
     u64 *keys_out;
     double *vals_out;
     i64 E;
-    const i64 *chunk_start;  // C+1 buffer positions; chunk c = [chunk_start[c], chunk_start[c+1]), <= TILE entries
-    int fixed_chunks;        // chunk c = [c*TILE, min(E, (c+1)*TILE)): the kernels compute the bounds instead of loading them
+    // chunk c = [c*TILE, min(E, (c+1)*TILE)) of the pending buffer
     int shift;  // digit = (((key >> 2) - base) >> shift), digits < nbuckets
     u64 base, span;
     u32 *err;        // key outside the window
@@ -141,6 +140,53 @@ struct RunSink {
     u64 *dlist = nullptr;
 };
 
+// one wave's total for digit c0 goes into the workgroup's run table (open addressing; lane 0 calls it)
+__device__ __forceinline__ void run_table_add(u32 *rd, u32 *rc, u32 *over, u32 c0, u32 total) {
+    bool placed = false;
+    int j = (int)((c0 * 0x9E3779B1u) >> 26) & (RMAX - 1);
+    for (int probe = 0; probe < RMAX; probe++) {
+        const u32 old = atomicCAS(&rd[j], EMPTY, c0);
+        if (old == EMPTY || old == c0) {
+            atomicAdd(&rc[j], total);
+            placed = true;
+            break;
+        }
+        j = (j + 1) & (RMAX - 1);
+    }
+    if (!placed) *over = 1;
+}
+
+// the workgroup's run table -> the chunk's run list, bucket totals and the digits' own run lists
+// (call after a barrier that follows the last run_table_add)
+__device__ __forceinline__ void emit_run_table(i64 chunk, const RunSink &sink, const u32 *rd, const u32 *rc, const u32 *over) {
+    const int t = threadIdx.x;
+    if (*over) {
+        if (t == 0) {
+            sink.nruns[chunk] = 0;
+            atomicExch(sink.overflow, 1u);
+        }
+        return;
+    }
+    // the used table slots, densely (RMAX == one wave; no order among the runs of a chunk is needed: a chunk's
+    // digits are distinct and the runs of a digit are ordered by chunk afterwards)
+    static_assert(RMAX == ESP_WAVE, "the run table is compacted by one wave");
+    if (t < RMAX) {
+        const u32 x = rd[t];
+        const u64 used = __ballot(x != EMPTY);
+        if (x != EMPTY) {
+            const int r = __popcll(used & ((1ull << t) - 1ull));
+            sink.runs_d[chunk * RMAX + r] = x;
+            sink.runs_c[chunk * RMAX + r] = rc[t];
+            atomicAdd(&sink.bucket_count[x], (unsigned long long)rc[t]);
+            if (sink.dlist) {  // (any order: run_rank_k orders a digit's few runs by chunk)
+                const u32 slot = atomicAdd(&sink.dcount[x], 1u);
+                if (slot < (u32)DCAP) sink.dlist[(size_t)x * DCAP + slot] = ((u64)chunk << 24) | ((u64)r << 16) | (u64)rc[t];
+            }
+        }
+        if (t == 0) sink.nruns[chunk] = (u64)__popcll(used);
+    }
+}
+
 // Digit-major counting of one chunk by a whole workgroup: every wave walks the DISTINCT digits of its
 // entries (a handful on a pre-sorted stream); for each one, NITEMS ballots count its entries.  The
 // workgroup's table (rd/rc/over in LDS, initialised and barrier'd by the caller) collects the waves'
@@ -148,7 +194,7 @@ struct RunSink {
 template <int NITEMS>
 __device__ __forceinline__ void count_runs(const u32 (&dig)[NITEMS], u32 pend, i64 chunk, const RunSink &sink, u32 *rd,
                                            u32 *rc, u32 *over) {
-    const int t = threadIdx.x, lane = t & 63;
+    const int lane = threadIdx.x & 63;
     // counted entries are blanked (EMPTY never equals a digit): a hit test is one compare
     u32 dg[NITEMS];
 #pragma unroll
@@ -174,49 +220,52 @@ __device__ __forceinline__ void count_runs(const u32 (&dig)[NITEMS], u32 pend, i
                 total += (u32)__popcll(__ballot(hit));
                 dg[q] = hit ? EMPTY : dg[q];
             }
-            if (lane == 0) {  // open addressing in the workgroup's run table
-                bool placed = false;
-                int j = (int)((c0 * 0x9E3779B1u) >> 26) & (RMAX - 1);
-                for (int probe = 0; probe < RMAX; probe++) {
-                    const u32 old = atomicCAS(&rd[j], EMPTY, c0);
-                    if (old == EMPTY || old == c0) {
-                        atomicAdd(&rc[j], total);
-                        placed = true;
-                        break;
-                    }
-                    j = (j + 1) & (RMAX - 1);
-                }
-                if (!placed) *over = 1;
-            }
+            if (lane == 0) run_table_add(rd, rc, over, c0, total);
             m = __ballot(dg[k] != EMPTY);
         }
     }
     __syncthreads();
-    if (*over) {
-        if (t == 0) {
-            sink.nruns[chunk] = 0;
-            atomicExch(sink.overflow, 1u);
-        }
-        return;
-    }
-    // the used table slots, densely (RMAX == one wave; no order among the runs of a chunk is needed: the
-    // run list of all chunks is sorted by digit afterwards and a chunk's digits are distinct)
-    static_assert(RMAX == ESP_WAVE, "the run table is compacted by one wave");
-    if (t < RMAX) {
-        const u32 x = rd[t];
-        const u64 used = __ballot(x != EMPTY);
-        if (x != EMPTY) {
-            const int r = __popcll(used & ((1ull << t) - 1ull));
-            sink.runs_d[chunk * RMAX + r] = x;
-            sink.runs_c[chunk * RMAX + r] = rc[t];
-            atomicAdd(&sink.bucket_count[x], (unsigned long long)rc[t]);
-            if (sink.dlist) {  // (any order: run_rank_k orders a digit's few runs by chunk)
-                const u32 slot = atomicAdd(&sink.dcount[x], 1u);
-                if (slot < (u32)DCAP) sink.dlist[(size_t)x * DCAP + slot] = ((u64)chunk << 24) | ((u64)r << 16) | (u64)rc[t];
+    emit_run_table(chunk, sink, rd, rc, over);
+}
+
+// The same for a producer's COUNT pass (the append is the partition, see PartOut below): a lane holds a few
+// (digit, weight) items instead of its entries -- a stencil node knows that it sends 8 entries to its own column
+// block and 2 to each of three others without forming them.  wt == 0: no item.
+template <int NITEMS>
+__device__ __forceinline__ void count_runs_weighted(const u32 (&dig)[NITEMS], const u32 (&wt)[NITEMS], i64 chunk,
+                                                    const RunSink &sink, u32 *rd, u32 *rc, u32 *over) {
+    const int lane = threadIdx.x & 63;
+    u32 dg[NITEMS];
+#pragma unroll
+    for (int k = 0; k < NITEMS; k++) dg[k] = wt[k] ? dig[k] : EMPTY;
+    int trips = 0;
+    bool stop = false;
+#pragma unroll
+    for (int k = 0; k < NITEMS; k++) {
+        u64 m = stop ? 0ull : __ballot(dg[k] != EMPTY);
+        while (m) {
+            if (++trips > RMAX) {
+                if (lane == 0) *over = 1;
+                stop = true;
+                break;
             }
+            const int fl = __builtin_ctzll(m);
+            const u32 c0 = (u32)__builtin_amdgcn_readlane((int)dg[k], fl);
+            u32 part = 0;
+#pragma unroll
+            for (int q = k; q < NITEMS; q++) {
+                const bool hit = dg[q] == c0;
+                part += hit ? wt[q] : 0u;
+                dg[q] = hit ? EMPTY : dg[q];
+            }
+#pragma unroll
+            for (int o = 32; o; o >>= 1) part += (u32)__shfl_xor((int)part, o, ESP_WAVE);
+            if (lane == 0) run_table_add(rd, rc, over, c0, part);
+            m = __ballot(dg[k] != EMPTY);
         }
-        if (t == 0) sink.nruns[chunk] = (u64)__popcll(used);
     }
+    __syncthreads();
+    emit_run_table(chunk, sink, rd, rc, over);
 }
 
 template <bool MULTI>
@@ -228,8 +277,8 @@ __global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_chunk) {
     const int t = threadIdx.x;
     if (MULTI && t < a.mw_P) s_mw[t] = a.mw_base[t];
     const i64 chunk = first_chunk + blockIdx.x;
-    const i64 beg = a.fixed_chunks ? chunk * TILE : a.chunk_start[chunk];
-    const i64 end = a.fixed_chunks ? min(a.E, beg + (i64)TILE) : a.chunk_start[chunk + 1];
+    const i64 beg = chunk * TILE;
+    const i64 end = min(a.E, beg + (i64)TILE);
     // a stream that is not pre-sorted is recognised by the first workgroups: the rest leave at once
     // (the flag is read while the keys are in flight)
     const u32 give_up = __hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -258,14 +307,6 @@ __global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_chunk) {
     }
     const RunSink sink{a.runs_d, a.runs_c, a.nruns, a.bucket_count, a.overflow, a.dcount, a.dlist};
     count_runs<ITEMS>(dig, pend, chunk, sink, rd, rc, &over);
-}
-
-// chunk_start[first + i] = from + i*TILE (clamped to `to`): fixed-size chunks for a buffer range that
-// came without run lists
-__global__ void fixed_chunks_k(i64 *chunk_start, i64 first, i64 nchunks, i64 from, i64 to) {
-    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i > nchunks) return;
-    chunk_start[first + i] = min(to, from + i * (i64)TILE);
 }
 
 // dense run list in tile order: sortable records (key = digit << 2, payload = tile|j|count)
@@ -371,6 +412,49 @@ __global__ __launch_bounds__(THREADS) void run_rank_k(const unsigned long long *
     }
 }
 
+// Digit-major stable ranking of one wave's entries: for each distinct digit of the wave, its entries are
+// numbered in (item, lane) order with a scalar running count -- no LDS counters inside the wave.  Ranked
+// entries are blanked (dig: EMPTY = no entry; destroyed), so the hit test is one compare; digits first met at
+// item k only look at items >= k.  hd/hj: the tile's map digit -> run index; cnt_w[j] = the wave's entries in run j.
+template <int NI>
+__device__ __forceinline__ void rank_in_runs(u32 (&dig)[NI], const u32 *hd, const u32 *hj, u32 *cnt_w, int lane,
+                                             unsigned short (&rank)[NI], unsigned char (&jrun)[NI]) {
+    const u64 lt = (1ull << lane) - 1ull;
+#pragma unroll
+    for (int k = 0; k < NI; k++) {
+        u64 m = __ballot(dig[k] != EMPTY);
+        while (m) {
+            const int fl = __builtin_ctzll(m);
+            const u32 c0 = (u32)__builtin_amdgcn_readlane((int)dig[k], fl);
+            int jj = 0;
+            {
+                int j = (int)((c0 * 0x9E3779B1u) >> 26) & (RMAX - 1);
+                for (int probe = 0; probe < RMAX; probe++) {
+                    if (hd[j] == c0) {
+                        jj = (int)hj[j];
+                        break;
+                    }
+                    j = (j + 1) & (RMAX - 1);
+                }
+            }
+            u32 running = 0;
+#pragma unroll
+            for (int q = k; q < NI; q++) {
+                const bool hit = dig[q] == c0;
+                const u64 mm = __ballot(hit);
+                if (hit) {
+                    rank[q] = (unsigned short)(running + (u32)__popcll(mm & lt));
+                    jrun[q] = (unsigned char)jj;
+                }
+                running += (u32)__popcll(mm);
+                dig[q] = hit ? EMPTY : dig[q];
+            }
+            if (lane == 0) cnt_w[jj] = running;
+            m = __ballot(dig[k] != EMPTY);
+        }
+    }
+}
+
 template <bool MULTI, bool K32>
 __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
     __shared__ u64 s_mw[MULTI ? MW_MAX : 1];
@@ -381,8 +465,8 @@ __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
     __shared__ int s_nr;
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const i64 tile = blockIdx.x;  // = chunk index
-    const i64 beg = a.fixed_chunks ? tile * TILE : a.chunk_start[tile];
-    const i64 end = a.fixed_chunks ? min(a.E, beg + (i64)TILE) : a.chunk_start[tile + 1];
+    const i64 beg = tile * TILE;
+    const i64 end = min(a.E, beg + (i64)TILE);
     // run table of the tile (nruns holds the exclusive scan by now: nr = difference)
     if (a.flags && (a.flags[0] | a.flags[1] | a.flags[3]) != 0u) return;  // (uniform: the flush takes another path)
     if (t == 0) s_nr = a.nruns_raw ? (int)a.nruns[tile] : (int)(a.nruns[tile + 1] - a.nruns[tile]);
@@ -419,7 +503,6 @@ __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
         }
     }
     __syncthreads();
-    const u64 lt = (1ull << lane) - 1ull;
     unsigned short rank[ITEMS];
     unsigned char jrun[ITEMS];
     u32 dig[ITEMS];
@@ -434,45 +517,9 @@ __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
         rank[k] = 0;
         jrun[k] = 0;
     }
-    // digit-major stable ranking: for each distinct digit of the wave, its entries are numbered in
-    // (item, lane) order with a scalar running count -- no LDS counters inside the wave.  Ranked
-    // entries are blanked, so the hit test is one compare; digits first met at item k only look at
-    // items >= k.
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) dig[k] = ((pend >> k) & 1u) ? dig[k] : EMPTY;
-#pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        u64 m = __ballot(dig[k] != EMPTY);
-        while (m) {
-            const int fl = __builtin_ctzll(m);
-            const u32 c0 = (u32)__builtin_amdgcn_readlane((int)dig[k], fl);
-            int jj = 0;
-            {
-                int j = (int)((c0 * 0x9E3779B1u) >> 26) & (RMAX - 1);
-                for (int probe = 0; probe < RMAX; probe++) {
-                    if (hd[j] == c0) {
-                        jj = (int)hj[j];
-                        break;
-                    }
-                    j = (j + 1) & (RMAX - 1);
-                }
-            }
-            u32 running = 0;
-#pragma unroll
-            for (int q = k; q < ITEMS; q++) {
-                const bool hit = dig[q] == c0;
-                const u64 mm = __ballot(hit);
-                if (hit) {
-                    rank[q] = (unsigned short)(running + (u32)__popcll(mm & lt));
-                    jrun[q] = (unsigned char)jj;
-                }
-                running += (u32)__popcll(mm);
-                dig[q] = hit ? EMPTY : dig[q];
-            }
-            if (lane == 0) cnt[w][jj] = running;
-            m = __ballot(dig[k] != EMPTY);
-        }
-    }
+    rank_in_runs<ITEMS>(dig, hd, hj, cnt[w], lane, rank, jrun);
     __syncthreads();
     // exclusive prefix over the waves, per run
     if (t < RMAX) {
@@ -502,6 +549,157 @@ __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
             a.vals_out[dst] = val[k];
         }
     }
+}
+
+// ---- the append IS the partition (device-side producers) ------------------------------------------------
+// A producer that can count before it writes -- the stencil and FEM generators, a device-side triplet array --
+// needs no partition pass at all: a COUNT launch of the producer (ALU only: no entry is formed or stored) fills
+// the run lists of its chunks (count_runs_weighted -> RunSink), run_coarse_k + run_rank_k turn them into bucket
+// starts and run offsets exactly as for run_scatter_k, and the WRITE launch stages a chunk's entries in LDS in
+// stream order (as the plain producer does for its coalesced copy-out) and stores every entry straight to
+// `run offset + stable rank inside the run` -- run_scatter_k's stores without its loads.  Chunk = workgroup
+// of the producer, the same in both launches.  The pending buffer then holds the entries bucket by bucket
+// (a stable permutation: entries of one (col,row) keep their append order), the flush starts at the bucket kernel.
+struct PartOut {
+    const u32 *runs_d;     // [chunk][RMAX]
+    const i64 *runs_off;   // [chunk][RMAX]
+    const u64 *nruns;      // [chunk] (raw counts)
+    const u32 *flags;      // the write launch leaves at once when flags[0] (window), [1] (too many digits in a chunk)
+                           // or [3] (too many runs of a digit) is set: the host then runs the plain producer
+    const unsigned long long *maxlen;  // longest bucket (run_rank_k)
+    i64 cap;               // a K32 launch leaves without a store when *maxlen > cap (the host applies the same rule)
+    int k32;               // the batch has one known kind and <= 32 key bits lie below the prefix: the K32 kernels
+                           // stage and store 4-byte keys = the bits below the prefix
+    int shift;             // digit = ((key >> 2) - base) >> shift
+    u64 base, span;
+    u64 *keys_out;
+    double *vals_out;
+    i64 chunk_base;        // chunk index of the launch's first workgroup
+};
+
+// LDS tables of one producer workgroup (tile = chunk)
+template <int NWAVES>
+struct TileLds {
+    u32 cnt[NWAVES][RMAX];  // entries of wave w in run j of the tile
+    i64 roff[RMAX];         // global offset of run j (run_rank_k)
+    u32 lstart[RMAX + 1];   // first LDS slot of run j: the tile is staged run by run
+};
+
+// Where a thread's entries go inside the tile's LDS staging area.  A thread (a stencil node, a FEM cell) holds NQ
+// items (digit, count): its entries for one column each, in stream order inside the item.  The staging area is laid
+// out run by run (a run = the tile's entries of one digit), inside a run thread by thread, inside a thread item by
+// item.  That is a stable order for the fold: entries of one (row,col) lie in ONE item of a thread and keep their
+// order there, and of two threads the earlier one's come first -- entries of different columns may trade places
+// freely (the bucket kernel sorts by column anyway).  slot[q] = first LDS slot of item q.  Two barriers.
+// Returns false (uniform) when the launch has to leave without a store (see PartOut::flags).
+template <int NQ, int NWAVES>
+__device__ __forceinline__ bool tile_slots(const PartOut &p, i64 chunk, const u32 (&dig)[NQ], const u32 (&wt)[NQ], u32 (&slot)[NQ],
+                                           TileLds<NWAVES> &S, int *total_out) {
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    if ((p.flags[0] | p.flags[1] | p.flags[3]) != 0u) return false;
+    const int nr = (int)p.nruns[chunk];
+    const u32 my_run_digit = lane < nr ? p.runs_d[chunk * RMAX + lane] : EMPTY;  // lane j holds the digit of run j
+    S.cnt[w][lane] = 0;
+    u32 dg[NQ], pq[NQ], jq[NQ];
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        dg[q] = wt[q] ? dig[q] : EMPTY;
+        pq[q] = 0;
+        jq[q] = 0;
+    }
+    int trips = 0;
+#pragma unroll
+    for (int q = 0; q < NQ; q++) {
+        u64 m = __ballot(dg[q] != EMPTY);
+        while (m && ++trips <= RMAX) {
+            const u32 c0 = (u32)__builtin_amdgcn_readlane((int)dg[q], __builtin_ctzll(m));
+            const u64 hitrun = __ballot(my_run_digit == c0);
+            const u32 j = hitrun ? (u32)__builtin_ctzll(hitrun) : 0u;  // (the COUNT launch listed every digit of the tile)
+            u32 mine = 0;
+#pragma unroll
+            for (int r = q; r < NQ; r++) mine += dg[r] == c0 ? wt[r] : 0u;
+            u32 inc = mine;
+#pragma unroll
+            for (int dlt = 1; dlt < ESP_WAVE; dlt <<= 1) {
+                const u32 o = (u32)__shfl_up((int)inc, dlt, ESP_WAVE);
+                if (lane >= dlt) inc += o;
+            }
+            u32 acc = inc - mine;
+#pragma unroll
+            for (int r = q; r < NQ; r++) {
+                const bool hit = dg[r] == c0;
+                pq[r] = hit ? acc : pq[r];
+                jq[r] = hit ? j : jq[r];
+                acc += hit ? wt[r] : 0u;
+                dg[r] = hit ? EMPTY : dg[r];
+            }
+            if (lane == 63) S.cnt[w][j] = inc;  // the wave's total of this digit
+            m = __ballot(dg[q] != EMPTY);
+        }
+    }
+    __syncthreads();
+    // every wave: lane j adds up run j over the waves; run starts = exclusive scan over the runs
+    u32 tot = 0, before = 0;
+#pragma unroll
+    for (int i = 0; i < NWAVES; i++) {
+        const u32 x = S.cnt[i][lane];
+        before += i < w ? x : 0u;
+        tot += x;
+    }
+    u32 inc = tot;
+#pragma unroll
+    for (int dlt = 1; dlt < ESP_WAVE; dlt <<= 1) {
+        const u32 o = (u32)__shfl_up((int)inc, dlt, ESP_WAVE);
+        if (lane >= dlt) inc += o;
+    }
+    const u32 lst = inc - tot;
+    const u32 sb = lst + before;  // first slot of this wave's part of run `lane`
+    const int total = __shfl((int)inc, 63, ESP_WAVE);
+    if (w == 0) {
+        S.lstart[lane] = lst;
+        if (lane == 63) S.lstart[RMAX] = inc;
+        S.roff[lane] = lane < nr ? p.runs_off[chunk * RMAX + lane] : 0;
+    }
+#pragma unroll
+    for (int q = 0; q < NQ; q++) slot[q] = (u32)__shfl((int)sb, (int)jq[q], ESP_WAVE) + pq[q];
+    *total_out = total;
+    return true;
+}
+
+// staged tile (run by run, see tile_slots) -> its runs' places in the buffer; consecutive threads store consecutive
+// entries of a run.  A barrier lies between the last staging store and this call.
+template <typename KT, int NT>
+__device__ __forceinline__ void copy_out_runs(const PartOut &p, const KT *lk, const double *lv, int total, const u32 *lstart,
+                                              const i64 *roff) {
+    KT *gk = reinterpret_cast<KT *>(p.keys_out);
+    int j = 0;
+    for (int q = threadIdx.x; q < total; q += NT) {
+        while (q >= (int)lstart[j + 1]) j++;
+        const i64 dst = roff[j] + (i64)(q - (int)lstart[j]);
+        gk[dst] = lk[q];
+        p.vals_out[dst] = lv[q];
+    }
+}
+
+// digit of a column for a count launch (the digit must not reach into the row bits: shift >= rb); columns outside
+// the key window raise *err
+__device__ __forceinline__ u32 column_digit(i64 col0, int rb, u64 base, u64 span, int shift, u32 *err) {
+    u64 kn = ((u64)col0 << rb) - base;
+    if (kn >= span) {
+        if (err) *err = 1u;
+        kn = 0;
+    }
+    return (u32)(kn >> shift);
+}
+
+// 4-byte keys of a bucket-ordered pending buffer back to packed keys (any call that reads or extends the pending
+// entries other than the flush they were written for): one workgroup per bucket
+__global__ __launch_bounds__(THREADS) void expand_keys_k(const u32 *__restrict__ k32, const i64 *__restrict__ seg_start, int shift,
+                                                         u64 base, u32 kind, u64 *__restrict__ out) {
+    const i64 s = blockIdx.x;
+    const i64 b = seg_start[s], e = seg_start[s + 1];
+    const u64 hi = ((u64)s << shift) + base;
+    for (i64 i = b + threadIdx.x; i < e; i += THREADS) out[i] = ((hi + (u64)k32[i]) << ESP_TAG_BITS) | (u64)kind;
 }
 
 }  // namespace esprun

@@ -125,7 +125,11 @@ int32_t esp_append_device(esp_handle *h, const int64_t *d_rows, const int64_t *d
 /* entries already packed in this handle's key layout (used by the shard exchange) */
 int32_t esp_append_packed(esp_handle *h, const uint64_t *d_keys, const double *d_vals,
                           int64_t count);
-/* on-device update streams of the reference's workloads:
+/* on-device update streams of the reference's workloads.  Called on an EMPTY buffer with a stream an assembly loop
+ * emits (few column blocks per 256 nodes / 128 cells) the append is the partition: the entries are stored bucket by
+ * bucket -- a stable permutation of the stream, so every (i,j) keeps its call order -- and esp_flush needs no partition
+ * pass.  Any later append, clone or shard call first turns the batch back into an ordinary pending buffer.
+ *
  * fdrand!(A,nx,ny,nz;update,rand) hot loop (src/matrix/sprand.jl:87-124); rand_mode
  * 0: ()->1, 1: 0.1+u (fdrand default, :232), 2: u; kind = ESP_UPDATE / ESP_RAWUPDATE;
  * testassemble! (test/femtools.jl:45-72) on a Kuhn grid with npd points per axis.    */
@@ -247,13 +251,13 @@ int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear);
 /* test hooks: path 0 = automatic, 2 = force the general path (global LSD sort + global fold),
  * 3 = LDS bucket path with its radix tail only (no column tiers), 4 = bucket kernel issued in
  * launches of 64 workgroups (exercises the carry-over of the look-back state), 5 = never use the
- * run-based single-pass partition (8-bit passes only), 7 = the device generators emit the run lists of their chunks themselves (skips the
- * histogram kernel; off by default: no net gain measured), 11 = esp_shard_partition reports "not applicable",
+ * run-based single-pass partition (8-bit passes only; the producers append in stream order), 11 = esp_shard_partition reports "not applicable",
  * 12 = the run-based partition orders its run list with radix passes (several small launches and a host round
  * trip) instead of the one ranking kernel, 14 = packed 8-byte keys for the bucket kernel always, 15 = 4-byte keys but the generic fold (no UPDATE-only
  * variant of the register tiers),
  * 13 = the bucket kernel of a fresh matrix marks column ends and a scan
- * over all columns builds colptr (instead of every segment writing the colptr of its own columns);
+ * over all columns builds colptr (instead of every segment writing the colptr of its own columns),
+ * 16 = the device-side producers (esp_generate_*) always append in stream order (never the producer-side partition);
  * last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general) */
 int32_t esp_debug_force_path(esp_handle *h, int32_t path);
 int32_t esp_debug_last_path(const esp_handle *h, int32_t *path);
@@ -272,7 +276,8 @@ int32_t esp_debug_last_key_bytes(const esp_handle *h, int32_t *bytes);
  * updateindex! call: the batch's bookkeeping, for a shard also a device check of the received blocks) */
 int32_t esp_debug_last_fold_update(const esp_handle *h, int32_t *on);
 /* which partition the last flush used: 1 = run-based single pass (pre-sorted stream), 2 = 8-bit passes,
- * 3 = run-based single pass on run lists the producers emitted (no histogram kernel),
+ * 4 = none: the producer wrote every entry straight to its bucket (esp_generate_* on an empty buffer: a COUNT launch
+ *     of the producer, then its stores go to `bucket start + stable rank`; the flush starts at the bucket kernel),
  * 7 = none: the segments came assembled from esp_shard_assemble */
 int32_t esp_debug_last_partition(const esp_handle *h, int32_t *kind);
 

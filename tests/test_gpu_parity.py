@@ -556,23 +556,25 @@ def test_empty_and_tiny(esp):
 
 
 # ------------------------------------------------------------------ full-size properties
-@pytest.mark.parametrize("force", [0, 5, 7, 12, 14, 15])
+@pytest.mark.parametrize("force", [0, 5, 12, 14, 15, 16])
 def test_run_partition_vs_passes(esp, orc, force):
-    """Pre-sorted stream (48^3 stencil, E > 2^20): the run-based single-pass partition and the 8-bit
-    passes give the same bits; a shuffled stream falls back to the passes."""
+    """Pre-sorted stream (48^3 stencil, E > 2^20): the producer-side partition (the generator writes every update
+    straight to its bucket), the run-based single-pass partition of the flush and the 8-bit passes give the same
+    bits; a shuffled stream falls back to the passes."""
     n = 48
     N = n ** 3
     A = esp.ExtendableSparseMatrix(N, N)
     A.debug_force_path(force)
     A.generate_fdrand(n, n, n, seed=21, rand_mode=1)
     A.flush()
-    # 3: the generator emitted the run lists itself; 1: histogram kernel; 2: 8-bit passes
-    assert A.debug_last_partition() == {0: 1, 5: 2, 7: 3, 12: 1, 14: 1, 15: 1}[force]
-    if force in (0, 12):  # run offsets from the ranking kernel / from the radix-ordered run list
-        assert A.debug_last_run_order() == (1 if force == 0 else 2)
-    # one kind for the whole batch + ranking kernel: the bucket kernel reads 4-byte keys (14: packed keys;
+    # 4: the producer's own partition (0; 14: with packed keys, 15: generic fold); 16: never the producer's ->
+    # 1: histogram + scatter kernel of the flush; 12: its radix-ordered run list; 5: 8-bit passes
+    assert A.debug_last_partition() == {0: 4, 5: 2, 12: 1, 14: 4, 15: 4, 16: 1}[force]
+    if force in (16, 12):  # run offsets from the ranking kernel / from the radix-ordered run list
+        assert A.debug_last_run_order() == (1 if force == 16 else 2)
+    # one kind for the whole batch: the bucket kernel reads 4-byte keys (14: packed keys;
     # 0: the UPDATE-only variant of the register tiers, 15: the generic fold on 4-byte keys)
-    assert A.debug_last_key_bytes() == (4 if force in (0, 15) else 8)
+    assert A.debug_last_key_bytes() == (4 if force in (0, 15, 16) else 8)
     O = orc.fdrand(n, n, n, rand_mode=1, seed=21, style=orc.KIND_UPDATE)
     assert_csc_equal(hip_arrays(A), O.arrays())
     # same entries in random order: too many distinct digits per tile -> 8-bit passes
@@ -739,42 +741,103 @@ def test_digit_with_many_runs_falls_back_to_ordered_run_list(esp, orc):
         assert_csc_equal(hip_arrays(A), O.arrays(), "hot %s" % hot)
 
 
-def test_producer_run_lists_mixed_with_other_appends(esp, orc):
-    """Run lists emitted by the generator are used only if EVERY pending entry came with one; two
-    generator calls, a host append in between, a capacity hint that is off: all must stay exact."""
+def test_producer_side_partition_mixed_with_other_appends(esp, orc):
+    """The append is the partition only for a producer that finds the buffer empty; whatever follows (a second
+    generator call, a host append, a clone, a changed column window) first turns the bucket-ordered batch back into
+    an ordinary pending buffer (4-byte keys expanded): all must stay exact."""
     n = 48
     N = n ** 3
-    E = orc.fdrand_count(n, n, n)
     half = (N // 2 // 256) * 256 + 17
-    for variant in ("two_calls", "host_append_between", "bad_hint", "good_hint"):
-        hint = {"bad_hint": 5 * E, "good_hint": E}.get(variant, 0)
-        A = esp.ExtendableSparseMatrix(N, N, capacity_hint=hint)
-        A.debug_force_path(7)        # producers emit run lists
+    I, J, V = orc.fdrand_stream(n, n, n, rand_mode=1, seed=31)
+    for variant in ("alone", "two_calls", "host_append_after", "host_append_between", "clone", "window", "reassembly",
+                    "clear_then_again"):
+        A = esp.ExtendableSparseMatrix(N, N)
         O = orc.ExtendableSparseMatrix(N, N)
-        I, J, V = orc.fdrand_stream(n, n, n, rand_mode=1, seed=31)
-        if variant in ("two_calls", "host_append_between"):
+        upd = lambda I, J, V: O.apply(np.full(len(I), UPDATE, np.uint8), I, J, V)
+        expect = 4
+        if variant == "alone":
+            A.generate_fdrand(n, n, n, seed=31, rand_mode=1)
+            upd(I, J, V)
+        elif variant in ("two_calls", "host_append_between"):
             A.generate_fdrand_range(n, n, n, 0, half, seed=31, rand_mode=1)
             if variant == "host_append_between":
                 A.append(UPDATE, [3, 4], [5, 6], [1.5, 2.5])
             A.generate_fdrand_range(n, n, n, half, N, seed=31, rand_mode=1)
-        else:
-            A.generate_fdrand(n, n, n, seed=31, rand_mode=1)
-        A.flush()
-        if variant == "host_append_between":
-            # the host entries sit between the two halves of the stream
-            Ih, Jh, Vh = orc.fdrand_stream(n, n, n, rand_mode=1, seed=31)
+            # stream position of node `half`
+            Ia, Ja, Va = orc.fdrand_stream(n, n, n, rand_mode=1, seed=31)
             B = esp.ExtendableSparseMatrix(N, N)
-            B.debug_force_path(0)
+            B.debug_force_path(16)
             B.generate_fdrand_range(n, n, n, 0, half, seed=31, rand_mode=1)
-            B.append(UPDATE, [3, 4], [5, 6], [1.5, 2.5])
-            B.generate_fdrand_range(n, n, n, half, N, seed=31, rand_mode=1)
+            cut = B.nnznew()
+            upd(Ia[:cut], Ja[:cut], Va[:cut])
+            if variant == "host_append_between":
+                upd(np.array([3, 4]), np.array([5, 6]), np.array([1.5, 2.5]))
+            upd(Ia[cut:], Ja[cut:], Va[cut:])
+            expect = 1
+        elif variant == "host_append_after":
+            A.generate_fdrand(n, n, n, seed=31, rand_mode=1)
+            A.append(UPDATE, [3, 4, 3], [5, 6, 5], [1.5, 2.5, -0.25])
+            upd(I, J, V)
+            upd(np.array([3, 4, 3]), np.array([5, 6, 5]), np.array([1.5, 2.5, -0.25]))
+            expect = 1
+        elif variant == "clone":
+            A.generate_fdrand(n, n, n, seed=31, rand_mode=1)
+            A2 = A.copy()
+            A2.flush()
+            upd(I, J, V)
+            O.flush()
+            assert_csc_equal(hip_arrays(A2), O.arrays(), "clone")
+            expect = 1   # (the clone read the pending keys: packed again)
+        elif variant == "window":
+            A.generate_fdrand(n, n, n, seed=31, rand_mode=1)
+            A.set_column_window(1, N)    # same window: the partition still serves
+            upd(I, J, V)
+        elif variant == "reassembly":
+            A.generate_fdrand(n, n, n, seed=30, rand_mode=1)
+            A.flush()
+            assert A.debug_last_partition() == 4
+            I0, J0, V0 = orc.fdrand_stream(n, n, n, rand_mode=1, seed=30)
+            upd(I0, J0, V0)
+            O.flush()
+            A.generate_fdrand(n, n, n, seed=31, rand_mode=1)       # hits only, over the stored pattern
+            upd(I, J, V)
+        elif variant == "clear_then_again":
+            A.generate_fdrand(n, n, n, seed=30, rand_mode=1)
+            A._d.ck(A._d.lib.esp_clear_pending(A._d.h))
+            A._touch()
+            A.generate_fdrand(n, n, n, seed=31, rand_mode=1)
+            upd(I, J, V)
+        A.flush()
+        O.flush()
+        assert A.debug_last_partition() == expect, variant
+        assert_csc_equal(hip_arrays(A), O.arrays(), variant)
+
+
+def test_producer_side_partition_fem_and_fallbacks(esp, orc):
+    """FEM producer in natural cell order: partition by the producer (4-byte keys, RAWUPDATE kind); shuffled cell
+    order: the COUNT launch finds too many digits per chunk, the plain producer runs and the flush partitions with
+    its 8-bit passes.  A 1-D stencil whose buckets would cut into the row bits does not qualify either."""
+    for dim, npd in ((2, 400), (3, 40)):
+        nn = npd ** dim
+        for order in (0, 1):
+            A = esp.ExtendableSparseMatrix(nn, nn)
+            A.generate_fem(dim, npd, seed=0x5EED0004, order_mode=order)
+            A.flush()
+            B = esp.ExtendableSparseMatrix(nn, nn)
+            B.debug_force_path(16)
+            B.generate_fem(dim, npd, seed=0x5EED0004, order_mode=order)
             B.flush()
-            assert_csc_equal(hip_arrays(A), hip_arrays(B), variant)
-        else:
-            O.apply(np.full(len(I), UPDATE, np.uint8), I, J, V)
-            assert_csc_equal(hip_arrays(A), O.arrays(), variant)
-        if variant == "good_hint":
-            assert A.debug_last_partition() == 3
+            assert A.debug_last_partition() == (4 if order == 0 else 2), (dim, order, A.debug_last_partition())
+            assert B.debug_last_partition() in (1, 2)
+            if order == 0:
+                assert A.debug_last_key_bytes() == 4
+            assert_csc_equal(hip_arrays(A), hip_arrays(B), "fem %d %d" % (dim, order))
+            if order == 0:
+                O = orc.ExtendableSparseMatrix(nn, nn)
+                I, J, V = orc.fem_stream(dim, npd, seed=0x5EED0004, order_mode=order)
+                O.apply(np.full(len(I), RAW, np.uint8), I, J, V)
+                O.flush()
+                assert_csc_equal(hip_arrays(A), O.arrays(), "fem vs oracle")
 
 
 @pytest.mark.parametrize("n", [96, 256])
