@@ -62,5 +62,39 @@ __device__ __forceinline__ unsigned long long esp_uniform_u64(unsigned long long
     return ((unsigned long long)hi << 32) | lo;
 }
 __device__ __forceinline__ long long esp_uniform_i64(long long x) { return (long long)esp_uniform_u64((unsigned long long)x); }
+
+// Inclusive add-scan / max-scan of one u32 per lane over the whole wave in six DPP instructions (row_shr 1,2,4,8 inside
+// the rows of 16 lanes, then row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3; lanes without a source
+// read 0) -- no LDS traffic, unlike __shfl_up (ds_bpermute + address arithmetic + select per step).  All 64 lanes
+// must be active.
+__device__ __forceinline__ u32 esp_wave_scan_add(u32 x) {
+    int v = (int)x;
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);
+    return (u32)v;
+}
+__device__ __forceinline__ u32 esp_wave_scan_max(u32 x) {
+    u32 v = x;
+#define ESP_DPP_MAX(ctrl, rows)                                                                  \
+    {                                                                                            \
+        const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)v, ctrl, rows, 0xf, true);        \
+        v = o > v ? o : v;                                                                       \
+    }
+    ESP_DPP_MAX(0x111, 0xf)
+    ESP_DPP_MAX(0x112, 0xf)
+    ESP_DPP_MAX(0x114, 0xf)
+    ESP_DPP_MAX(0x118, 0xf)
+    ESP_DPP_MAX(0x142, 0xa)
+    ESP_DPP_MAX(0x143, 0xc)
+#undef ESP_DPP_MAX
+    return v;
+}
+// the wave's total / maximum, in every lane (as a uniform value)
+__device__ __forceinline__ u32 esp_wave_sum(u32 x) { return (u32)__builtin_amdgcn_readlane((int)esp_wave_scan_add(x), 63); }
+__device__ __forceinline__ u32 esp_wave_max(u32 x) { return (u32)__builtin_amdgcn_readlane((int)esp_wave_scan_max(x), 63); }
 #endif
 

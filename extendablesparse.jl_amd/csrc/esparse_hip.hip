@@ -72,6 +72,9 @@ struct esp_handle {
     // (= nnz+1) is rewritten only when somebody needs the whole array (tail_stale).
     i64 wc0 = 0, wc1 = 0;
     bool win_excl = false, tail_stale = false;
+    // reset! of an unwindowed matrix leaves colptr := 1 to whoever reads it next (fix_tail): the fresh flush that
+    // normally follows rewrites every entry
+    bool ones_pending = false;
     // device CSC (Julia layout) + spare set for rebuilds
     DevBuf colptr, rowval, nzval, rowval2, nzval2;
     i64 nnz = 0;
@@ -298,6 +301,14 @@ static inline void col_range(const esp_handle *h, i64 *c0, i64 *cnt) {
 }
 // colptr behind the window := nnz+1, if it was left stale by windowed flushes
 static int32_t fix_tail(esp_handle *h) {
+    if (h->ones_pending) {
+        h->ones_pending = false;
+        h->tail_stale = false;
+        if (h->colptr.p)
+            hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(h->n + 1, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p, h->n + 1, (i64)1);
+        HIPCK(h, hipGetLastError());
+        return ESP_OK;
+    }
     if (!h->tail_stale) return ESP_OK;
     h->tail_stale = false;
     const i64 from = h->wc1 + 1, cnt = h->n + 1 - from;
@@ -315,10 +326,14 @@ static int32_t init_empty_csc(esp_handle *h) {
         col_range(h, &c0, &cnt);
         hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(cnt, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p + c0, cnt, (i64)1);
         h->tail_stale = h->wc1 < h->n;
+    } else if (h->csc_valid && !windowed(h) && h->n > 4096) {
+        h->ones_pending = true;  // (filled on first use unless a fresh flush writes all of colptr before)
+        h->tail_stale = false;
     } else {
         hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(h->n + 1, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p,
                            h->n + 1, (i64)1);
         h->tail_stale = false;
+        h->ones_pending = false;
     }
     h->nnz = 0;
     h->pattern_version++, h->values_version++;
@@ -893,6 +908,7 @@ extern "C" int32_t esp_set_csc(esp_handle *h, const int64_t *colptr, const int64
     h->csc_valid = true;
     h->win_excl = false;  // (the uploaded CSC may hold entries outside a declared window)
     h->tail_stale = false;
+    h->ones_pending = false;
     return ESP_OK;
 }
 
@@ -1811,6 +1827,7 @@ static int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn, const u64 *new_key, con
         // colptr = 1 + exclusive max-scan of the column ends, written by the scan's last pass
         Span sp(h, ESP_ST_COLPTR);
         sp.add(espscan::exclusive<u64, true>(h->stream, colend + c0, (u64 *)h->colptr.p + c0, ccnt, colend + N1, (u64)1));
+        if (!windowed(h)) h->ones_pending = false;  // (every entry of colptr was written)
         h->nnz = Zn;
         h->pattern_version++, h->values_version++;
         return ESP_OK;
@@ -1910,6 +1927,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         if (direct) {
             hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(N1, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p, N1, (i64)1);
             h->tail_stale = false;
+            h->ones_pending = false;
         }
     };
     {
@@ -2002,6 +2020,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
             fclose(f);
         }
     }
+    if (direct && !windowed(h)) h->ones_pending = false;  // (the bucket kernel wrote every entry of colptr)
     const u32 lookback_err = (u32)(h->pin_scalar[1] >> 32);
     h->seen_maxrun = (int)(u32)(h->pin_scalar[2] >> 0 & 0xFFFFFFFFull);
     if (lookback_err & 7u) restore_colptr();
@@ -2092,6 +2111,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
     }
     i64 Zn = 0;
     bool use_local = h->force_path != 2;
+    if (h->ones_pending && windowed(h)) CK(fix_tail(h));  // (cannot happen: a window is declared through fix_tail)
     if (h->pre.valid) {  // the producer's partition serves this flush if nothing changed since
         const esp_handle::PrePart &pp = h->pre;
         const bool usable = use_local && !h->part_assembled && pp.E == E && pp.base == h->win_base && pp.span == h->win_span &&

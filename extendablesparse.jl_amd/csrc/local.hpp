@@ -511,8 +511,7 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
             load_sorted_run<R>(skey, sval, rs, len, x, xv);
             ec = count_emitted<R, UPD>(x, xv, len);
         }
-#pragma unroll
-        for (int dlt = 32; dlt > 0; dlt >>= 1) ec += (u32)__shfl_xor((int)ec, dlt, ESP_WAVE);
+        ec = esp_wave_sum(ec);
         if (lane == 0 && ec) atomicAdd(s_early, ec);
 #ifdef ESP_LOCAL_STAMPS
         if (a.stamps && t == 0) a.stamps[(size_t)s * 16 + 8] = wall_clock64();
@@ -757,14 +756,8 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
                 v[j] = run;
                 run += x;
             }
-            inc = run;
-#pragma unroll
-            for (int dlt = 1; dlt < ESP_WAVE; dlt <<= 1) {
-                const u32 o = __shfl_up(inc, dlt, ESP_WAVE);
-                if (lane >= dlt) inc += o;
-            }
-#pragma unroll
-            for (int dlt = 32; dlt > 0; dlt >>= 1) mx = max(mx, (u32)__shfl_xor((int)mx, dlt, ESP_WAVE));
+            inc = esp_wave_scan_add(run);
+            mx = esp_wave_max(mx);
         }
         if (lane == 63) lw[w] = inc;
         if (lane == 0) lw[8 + w] = mx;
@@ -920,14 +913,9 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 5] = wall_clock64();
 #endif
         const u32 c = lane < WAVES * ITEMS ? gcount[lane] : 0u;
-        u32 inc = c;
-#pragma unroll
-        for (int dlt = 1; dlt < ESP_WAVE; dlt <<= 1) {
-            const u32 o = __shfl_up(inc, dlt, ESP_WAVE);
-            if (lane >= dlt) inc += o;
-        }
+        const u32 inc = esp_wave_scan_add(c);
         if (lane < WAVES * ITEMS) gcount[lane] = inc - c;
-        const u32 total = (u32)__shfl((int)inc, 63, ESP_WAVE);
+        const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
         // ---- decoupled look-back (wave 0) unless the register tier already ran it
         if (!lb_done) {
             // A segment that emits nothing (re-assembly over the stored pattern: every update hit the CSC)

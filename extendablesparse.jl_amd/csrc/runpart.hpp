@@ -258,8 +258,7 @@ __device__ __forceinline__ void count_runs_weighted(const u32 (&dig)[NITEMS], co
                 part += hit ? wt[q] : 0u;
                 dg[q] = hit ? EMPTY : dg[q];
             }
-#pragma unroll
-            for (int o = 32; o; o >>= 1) part += (u32)__shfl_xor((int)part, o, ESP_WAVE);
+            part = esp_wave_sum(part);
             if (lane == 0) run_table_add(rd, rc, over, c0, part);
             m = __ballot(dg[k] != EMPTY);
         }
@@ -618,12 +617,7 @@ __device__ __forceinline__ bool tile_slots(const PartOut &p, i64 chunk, const u3
             u32 mine = 0;
 #pragma unroll
             for (int r = q; r < NQ; r++) mine += dg[r] == c0 ? wt[r] : 0u;
-            u32 inc = mine;
-#pragma unroll
-            for (int dlt = 1; dlt < ESP_WAVE; dlt <<= 1) {
-                const u32 o = (u32)__shfl_up((int)inc, dlt, ESP_WAVE);
-                if (lane >= dlt) inc += o;
-            }
+            const u32 inc = esp_wave_scan_add(mine);
             u32 acc = inc - mine;
 #pragma unroll
             for (int r = q; r < NQ; r++) {
@@ -646,15 +640,10 @@ __device__ __forceinline__ bool tile_slots(const PartOut &p, i64 chunk, const u3
         before += i < w ? x : 0u;
         tot += x;
     }
-    u32 inc = tot;
-#pragma unroll
-    for (int dlt = 1; dlt < ESP_WAVE; dlt <<= 1) {
-        const u32 o = (u32)__shfl_up((int)inc, dlt, ESP_WAVE);
-        if (lane >= dlt) inc += o;
-    }
+    const u32 inc = esp_wave_scan_add(tot);
     const u32 lst = inc - tot;
     const u32 sb = lst + before;  // first slot of this wave's part of run `lane`
-    const int total = __shfl((int)inc, 63, ESP_WAVE);
+    const int total = __builtin_amdgcn_readlane((int)inc, 63);
     if (w == 0) {
         S.lstart[lane] = lst;
         if (lane == 63) S.lstart[RMAX] = inc;
