@@ -6,13 +6,21 @@ A "step" is one fresh assembly of fdrand(Float64,n,n,n; matrixtype=ExtendableSpa
 append buffer (inputs resident in HBM, no PCIe in the timed region), then flush! builds the CSC.
 value = nnz of the resulting CSC x steps x ranks / wall time (max over ranks).
 
+`--gpus N` (N > 1): one process per GPU.  Under `python -m torch.distributed.run` the ranks exist already
+(RANK / LOCAL_RANK / WORLD_SIZE in the environment); started plainly, this process only LAUNCHES N rank
+processes (it never touches the GPU itself), relays rank 0's JSON line and fails loudly when the node has
+fewer than N GPUs.  Weak scaling: the global grid is n x n x (n*N), rank r assembles its z-slab, columns are
+range-sharded, the entries of the cross-slab pairs travel through an RCCL all-to-all-v.
+
 Prints ONE JSON line (rank 0).  Extra objects: "roofline" (dominant kernel, hipEvent-timed on the
 library's stream), "pipeline" (whole step against the compulsory bytes of SURVEY.md section 8d),
-"cpu_baseline" (the C oracle timed on this box's host, bounded sample).
+"cpu_baseline" (the C oracle timed on this box's host, bounded sample), "extra.configs" (BASELINE.json
+configs 3 and 4, three steps each, measured after the headline loop).
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -25,12 +33,14 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.
 def pmc_traffic(kernel_stage):
     """HBM bytes per launch of the stage's kernel from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json, produced by tools/pmc_traffic.py from separate FETCH_SIZE and
-    WRITE_SIZE runs of this same command, gfx950 corrections applied); None if not collected."""
+    WRITE_SIZE runs of this same command, gfx950 corrections applied) and the name of the profile round
+    they come from; (None, None) if not collected."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get(kernel_stage, {}).get("hbm_bytes_per_launch")
+            d = json.load(f)
+        return d.get(kernel_stage, {}).get("hbm_bytes_per_launch"), d.get("_meta", {}).get("round")
     except Exception:
-        return None
+        return None, None
 
 
 def fd_counts(n):
@@ -39,28 +49,204 @@ def fd_counts(n):
     return E, Z
 
 
-def cpu_baseline(sample_n):
-    """Reference algorithm (LNK insert via updateindex! + lnk+csc flush) on the host, 1 thread."""
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except Exception:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(sample_n, mt_n):
+    """Reference algorithm (LNK insert via updateindex! + lnk+csc flush) on the host, 1 thread, and the
+    P-thread shape of MTExtendableSparseMatrixCSC (one buffer per thread + COO merge) as `mt`."""
     from oracle import oracle as orc
     z, ti, tf = orc.bench_fdrand(sample_n, sample_n, sample_n, orc.KIND_UPDATE)
-    return {"value": z / (ti + tf), "unit": "nnz/s", "cores": 1, "kind": "port",
-            "sample": "one fdrand %d^3 fresh assemble+flush! (%d update calls, %d nnz), updateindex! style, "
-                      "C restatement of SparseMatrixLNK + lnk+csc (oracle/), -O2, insert %.2fs + flush %.2fs; "
-                      "host has %d cores, 1 used (the reference path is single-threaded)"
-                      % (sample_n, 12 * sample_n * sample_n * (sample_n - 1) + 6 * sample_n * sample_n, z, ti, tf,
-                         os.cpu_count())}
+    out = {"value": z / (ti + tf), "unit": "nnz/s", "cores": 1, "kind": "port",
+           "sample": "one fdrand %d^3 fresh assemble+flush! (%d update calls, %d nnz), updateindex! style, "
+                     "C restatement of SparseMatrixLNK + lnk+csc (oracle/, %s), insert %.2fs + flush %.2fs; "
+                     "host: %s, %d cores, 1 used (the reference path is single-threaded)"
+                     % (sample_n, 12 * sample_n * sample_n * (sample_n - 1) + 6 * sample_n * sample_n, z,
+                        orc.build_flags(), ti, tf, cpu_model(), os.cpu_count())}
+    if mt_n > 0 and hasattr(orc, "bench_fdrand_mt"):
+        try:
+            p = max(1, min(os.cpu_count() or 1, 16))
+            zm, tmi, tmf = orc.bench_fdrand_mt(mt_n, mt_n, mt_n, p)
+            out["mt"] = {"value": zm / (tmi + tmf), "unit": "nnz/s", "cores": p, "kind": "port",
+                         "sample": "fdrand %d^3, %d threads, one column-slab buffer per thread (SparseMatrixDILNKC "
+                                   "shape) + COO merge (sparsematrixdilnkc.jl:397-435): insert %.2fs + merge %.2fs"
+                                   % (mt_n, p, tmi, tmf)}
+        except Exception as ex:   # the secondary baseline must never cost the headline line
+            out["mt"] = {"error": str(ex)}
+    return out
 
 
 def baseline_metric():
     """BASELINE.json's metric string (the line reports its nnz/s part as `value`; the HBM GB/s and %-of-peak
     part is in `roofline` and `pipeline`)."""
     try:
-        with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "BASELINE.json")) as f:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
             return json.load(f)["metric"]
     except Exception:
         return "assembled+flushed nnz/sec and HBM GB/s %peak, 256^3 7-pt stencil, 1/2/4/8 GPU"
 
 
+# ---------------------------------------------------------------------------------------- launcher
+def launch(args, argv):
+    """Parent of a plain `python bench.py --gpus N`: spawns the N ranks, never initialises the GPU."""
+    import torch
+    have = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    if have < args.gpus:
+        print("bench.py: --gpus %d but this node shows %d GPU(s); refusing to run a smaller job under that name"
+              % (args.gpus, have), file=sys.stderr)
+        return 2
+    port = int(os.environ.get("MASTER_PORT", "29541"))
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
+                    "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    out0, _ = procs[0].communicate()
+    rc = procs[0].returncode
+    for p in procs[1:]:
+        p.wait()
+        rc = rc or p.returncode
+    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+    if lines:
+        print(lines[-1], flush=True)
+    return rc
+
+
+def launch_probe(args):
+    """Test hook of the launcher (tests/test_bench_launcher.py, no GPU): the ranks it made meet over gloo and rank 0
+    reports what it saw instead of running the bench."""
+    import torch
+    import torch.distributed as dist
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        return 3
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank)], dtype=torch.float64)
+        dist.all_reduce(t)
+        ranks = float(t.item())
+        dist.destroy_process_group()
+    else:
+        ranks = 0.0
+    if rank == 0:
+        print(json.dumps({"probe": True, "n_gpus": world, "rank_sum": ranks, "local_rank": int(os.environ.get("LOCAL_RANK", "-1")),
+                          "master": os.environ.get("MASTER_ADDR")}), flush=True)
+    return 0
+
+
+# ---------------------------------------------------------------------------------------- extra configs
+def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
+    """BASELINE.json configs 3 and 4 in front of the driver (bounded: `steps` steps each, after the headline
+    loop).  Algorithmic bytes as in SURVEY.md 8d; frac = bytes / time / 8 TB/s."""
+    import ctypes as C
+    out = {}
+
+    def stages(tm, reps):
+        return {k: round(v[0] / reps, 3) for k, v in tm.items() if isinstance(v, tuple) and v[0] > 0}
+
+    # ---- config 3: existing CSC = the config-2 result; the full stencil stream again (all hits) plus the x
+    # second-neighbour pairs (l,l+2),(l+2,l) as new positions (28.4 % of Z0), one flush (merge-path join hot)
+    try:
+        n = n_cfg3
+        N = n ** 3
+        E, Z0 = fd_counts(n)
+        g = torch.arange(N, device="cuda", dtype=torch.int64)
+        l = g[(g % n) < n - 2] + 1
+        rows = torch.cat([l, l + 2])
+        cols = torch.cat([l + 2, l])
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(0x5EED0003)
+        v = torch.rand(l.numel(), device="cuda", dtype=torch.float64, generator=gen)
+        vals = torch.cat([v, v])
+        Zn = rows.numel()
+        del g, l, v
+        A = esp.ExtendableSparseMatrix(N, N, device=local, capacity_hint=E + Zn)
+        d = A._d
+        torch.cuda.synchronize()
+        dts = []
+        tm = None
+        for it in range(steps + 2):          # one warm-up, `steps` timed, one with stage events
+            A.timing_enable(0)
+            A.reset()
+            A.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1)
+            A.flush()                          # the stored CSC (untimed)
+            A.synchronize()
+            A.timing_enable(1 if it == steps + 1 else 0)
+            A.timing(clear=True)
+            t0 = time.perf_counter()
+            d.ck(d.lib.esp_append_device(d.h, C.c_void_p(rows.data_ptr()), C.c_void_p(cols.data_ptr()),
+                                         C.c_void_p(vals.data_ptr()), None, esp.ESP_UPDATE, 0, Zn))
+            A._touch()
+            A.generate_fdrand(n, n, n, seed=0x5EED0012, rand_mode=1)
+            A.flush()
+            A.synchronize()
+            if it == steps + 1:
+                tm = A.timing(clear=True)
+            elif it > 0:
+                dts.append(time.perf_counter() - t0)
+        Z1 = A.nnz()
+        assert Z1 == Z0 + Zn, (Z1, Z0, Zn)
+        dt = sum(dts) / len(dts)
+        Ea = E + Zn
+        algo = 2 * 16.0 * Ea + (16.0 * Z0 + 8.0 * (N + 1)) + (16.0 * Z1 + 8.0 * (N + 1))
+        out["cfg3_reassembly"] = {
+            "workload": "existing %d^3 stencil CSC (%d nnz) + the full update stream again + %d new positions "
+                        "(%.1f %% of the stored nnz): append + flush! with merge-path join" % (n, Z0, Zn, 100.0 * Zn / Z0),
+            "ms": dt * 1e3, "nnz_per_s": Z1 / dt, "appended_per_s": Ea / dt, "algorithmic_bytes": algo,
+            "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS, "stage_ms": stages(tm, 1), "steps": len(dts)}
+        del A, rows, cols, vals
+    except Exception as ex:
+        out["cfg3_reassembly"] = {"error": repr(ex)}
+
+    # ---- config 4: P1 FEM in random cell order (test/femtools.jl:45-72), ~10 M DoF, 2-D and 3-D
+    for tag, dim, npd in (("cfg4_fem2d", 2, fem2d), ("cfg4_fem3d", 3, fem3d)):
+        if npd <= 0:
+            continue
+        try:
+            nn = npd ** dim
+            q = npd - 1
+            E = (2 * q * q if dim == 2 else 6 * q ** 3) * (dim + 1) * (dim + 2)
+            A = esp.ExtendableSparseMatrix(nn, nn, device=local, capacity_hint=E)
+            dts = []
+            tm = None
+            for it in range(steps + 2):
+                A.timing_enable(1 if it == steps + 1 else 0)
+                A.timing(clear=True)
+                A.synchronize()
+                t0 = time.perf_counter()
+                A.reset()
+                A.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
+                A.flush()
+                A.synchronize()
+                if it == steps + 1:
+                    tm = A.timing(clear=True)
+                elif it > 0:
+                    dts.append(time.perf_counter() - t0)
+            Z = A.nnz()
+            dt = sum(dts) / len(dts)
+            algo = 2 * 16.0 * E + 16.0 * Z + 8.0 * (nn + 1)
+            out[tag] = {"workload": "P1 FEM %d-D, %d^%d nodes (%d DoF), Kuhn grid, random cell order: %d rawupdateindex! "
+                                    "calls -> fresh CSC" % (dim, npd, dim, nn, E),
+                        "ms": dt * 1e3, "nnz_per_s": Z / dt, "appended_per_s": E / dt, "final_nnz": Z,
+                        "algorithmic_bytes": algo, "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS,
+                        "partition": A.debug_last_partition(), "stage_ms": stages(tm, 1), "steps": len(dts)}
+            del A
+        except Exception as ex:
+            out[tag] = {"error": repr(ex)}
+    return out
+
+
+# ---------------------------------------------------------------------------------------- one rank
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,15 +254,27 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--n", type=int, default=int(os.environ.get("ESP_BENCH_N", "256")))
     ap.add_argument("--cpu-sample-n", type=int, default=int(os.environ.get("ESP_BENCH_CPU_N", "256")))
+    ap.add_argument("--cpu-mt-n", type=int, default=int(os.environ.get("ESP_BENCH_CPU_MT_N", "192")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra.configs measurements (configs 3 and 4)")
     ap.add_argument("--sharded", action="store_true",
                     help="use the column-shard exchange path even on one GPU (always used for --gpus > 1)")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch(args, sys.argv[1:]))
+    if os.environ.get("ESP_BENCH_LAUNCH_PROBE"):
+        raise SystemExit(launch_probe(args))
 
     import torch
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if torch.cuda.device_count() < max(1, min(world, local + 1)):
+        raise SystemExit("bench.py: rank %d needs GPU %d, the node shows %d" % (rank, local, torch.cuda.device_count()))
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -90,6 +288,7 @@ def main():
     n = args.n
     E, Z = fd_counts(n)
     sharded = args.sharded or world > 1
+    SA = None
     if not sharded:
         N = n ** 3
         A = esp.ExtendableSparseMatrix(N, N, device=local, capacity_hint=E)
@@ -153,13 +352,18 @@ def main():
         step()
     barrier()
     dt = time.perf_counter() - t0
+    sent = SA.sent_off_rank if SA is not None and getattr(SA, "sent_off_rank", None) is not None else 0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        s = torch.tensor([float(sent)], dtype=torch.float64, device="cuda")
+        dist.all_reduce(s, op=dist.ReduceOp.MAX)
+        sent = int(s.item())
     total_nnz = SA.nnz() if sharded else A.nnz()
     assert total_nnz == Z_total or os.environ.get("ESP_LOCAL_STOP"), (total_nnz, Z_total)   # (ablation runs produce nothing)
     tm = A.timing(clear=True)
+    partition_kind = A.debug_last_partition()
     breakdown_steps = 0
     tm_all = tm
     if timing_level == 3:   # stage breakdown: separate untimed steps with events around every big kernel
@@ -169,6 +373,7 @@ def main():
             step()
         barrier()
         tm_all = A.timing(clear=True)
+    A.timing_enable(0)
     Z = Z_total / world   # per-rank share of the final nnz (value below multiplies by world)
 
     out = None
@@ -192,6 +397,7 @@ def main():
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
         algo_bytes = 2 * 16.0 * E + 16.0 * Z + 8.0 * (N + 1)   # 72.08 B per final nnz
         ms_step = dt / args.steps * 1e3
+        traffic, traffic_round = pmc_traffic(dom) if (n == 256 and not sharded) else (None, None)
         out = {
             "metric": baseline_metric(),
             "value": Z * args.steps * world / dt,
@@ -205,13 +411,18 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
-            "config": {"workload": "fdrand %d^3 Float64/Int64 fresh build: device COO append -> stable radix "
-                                   "partition -> ordered fold -> CSC (BASELINE.json configs[1])" % n,
+            "config": {"workload": "fdrand %d^3 Float64/Int64 fresh build: device COO append (the producer writes every "
+                                   "update to its radix bucket) -> LDS bucket sort + ordered fold -> CSC "
+                                   "(BASELINE.json configs[1])" % n,
                        "n": n, "appended_entries": E, "final_nnz": int(Z),
-                       "parallelism": ("column-range shards x%d, all-to-all-v entry routing (RCCL), z-slab "
-                                       "producers, global grid %dx%dx%d" % (world, n, n, n * world)) if sharded else "1 GPU"},
+                       "partition": {1: "run-based single pass in flush!", 2: "8-bit passes in flush!",
+                                     4: "producer-side (append = partition)", 7: "shard pieces"}.get(partition_kind, str(partition_kind)),
+                       "parallelism": ("column-range shards x%d, all-to-all-v entry routing (RCCL world size %d), z-slab "
+                                       "producers, global grid %dx%dx%d, at most %d entries sent off-rank per flush"
+                                       % (world, world, n, n, n * world, sent)) if sharded else "1 GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": pmc_traffic(dom) if (n == 256 and not sharded) else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "traffic_from": ("profiles/pmc_traffic.json (%s)" % traffic_round) if traffic else None,
                          "avg_launch_ms": avg_ms, "launches": dom_launches,
                          "events": "timed region" if in_timed else "breakdown steps after the timed region",
                          "algorithmic_bytes_per_launch": per_launch_bytes},
@@ -223,8 +434,12 @@ def main():
                                            % breakdown_steps) if breakdown_steps else "timed region",
                          "flush_ms_per_step": tm["flush_ms"] / max(tm["flushes"], 1)},
         }
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n)
+    if rank == 0 and world == 1 and not sharded and not args.no_extra:
+        del A
+        out["extra"] = {"configs": extra_configs(esp, torch, local, n, int(os.environ.get("ESP_CFG4_2D", "3163")),
+                                                 int(os.environ.get("ESP_CFG4_3D", "216")))}
+    if rank == 0 and not args.no_cpu_baseline and world == 1:
+        out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, args.cpu_mt_n)
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

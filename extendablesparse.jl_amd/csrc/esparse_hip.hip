@@ -1316,6 +1316,7 @@ static int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSet
     memset(&ps->out, 0, sizeof ps->out);
     if (h->count != 0 || h->shard_user || E <= esplocal::CAP || chunks >= ((i64)1 << 38)) return ESP_OK;
     if (h->force_path == 2 || h->force_path == 5 || h->force_path == 12 || h->force_path == 16) return ESP_OK;
+    if (h->runs_skip > 0) return ESP_OK;  // (the handle's last streams were not pre-sorted: back-off, see sort_msd)
     const int K = window_bits(h);
     double Ee = 0.0;
     const int planned = plan_prefix_bits(h, E, K, &Ee);
@@ -1391,6 +1392,10 @@ static int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took) {
     if (f_err | f_over | f_many) {
         // (flags[0] stays set for nobody: the plain producer follows and the flush's own partition checks the window)
         HIPCK(h, hipMemsetAsync((u32 *)h->misc.p + 60, 0, 16, h->stream));
+        if (f_over | f_many) {  // not a pre-sorted stream: neither this handle's producers nor its next flushes try again soon
+            h->runs_penalty = std::min(16, 2 * h->runs_penalty + 1);
+            h->runs_skip = h->runs_penalty + 1;  // (+1: the flush of this very batch)
+        }
         return ESP_OK;
     }
     if (ps->out.k32 && (i64)h->pin_scalar[0] > (i64)esplocal::CAP) return ESP_OK;  // (the K32 launch left without a store)
@@ -2134,6 +2139,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
         CK(flush_local(h, st, mode, &Zn));
         h->last_partition = 4;
+        h->runs_penalty = 0;
         h->seen_spread = pp.Ee > 0.0 ? (double)pp.maxlen * std::ldexp(1.0, pp.pb) / pp.Ee : 0.0;
     } else if (h->part_assembled) {
         // partitioned shard exchange: the segments are already formed (esp_shard_assemble)

@@ -227,6 +227,8 @@ __global__ __launch_bounds__(THREADS) void fd_count_k(FdArgs a, esprun::RunSink 
         rc[threadIdx.x] = 0;
     }
     if (threadIdx.x == 0) over = 0;
+    // a stream that is not pre-sorted is recognised by the first workgroups: the rest leave at once
+    if (__hip_atomic_load(sink.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
     __syncthreads();
     FdItems it;
     fd_items(a, a.g_begin + (i64)blockIdx.x * THREADS + threadIdx.x, it, err);
@@ -479,6 +481,7 @@ __global__ __launch_bounds__(FEM_CELLS) void fem_count_k(FemArgs a, esprun::RunS
         rc[threadIdx.x] = 0;
     }
     if (threadIdx.x == 0) over = 0;
+    if (__hip_atomic_load(sink.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;  // (see fd_count_k)
     __syncthreads();
     u32 dig[4], wt[4];
     fem_items(a, (i64)blockIdx.x * FEM_CELLS + threadIdx.x, dig, wt, err);

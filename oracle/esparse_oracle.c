@@ -13,6 +13,7 @@
 #include "esparse_oracle.h"
 
 #include <math.h>
+#include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
@@ -787,12 +788,18 @@ typedef void (*fd_sink)(void *ctx, double v, i64 i, i64 j);
  * slot s (0..5) at node l uses counter 6*(l-1)+s, so the stream can also be
  * produced out of order (device generator).  `rand()*hy*hz/hx` is evaluated
  * left to right as Julia does.                                             */
-static void fdrand_walk(i64 nx, i64 ny, i64 nz, int mode, uint64_t seed, fd_sink sink, void *ctx) {
+/* nodes l_begin <= l < l_end of the loop nest (the whole nest: 1 .. nx*ny*nz+1) */
+static void fdrand_walk_range(i64 nx, i64 ny, i64 nz, int mode, uint64_t seed, fd_sink sink, void *ctx, i64 l_begin,
+                              i64 l_end) {
     double hx = 1.0 / (double)nx, hy = 1.0 / (double)ny, hz = 1.0 / (double)nz;
-    i64 nxy = nx * ny, l = 1;
-    for (i64 k = 1; k <= nz; k++)
-        for (i64 j = 1; j <= ny; j++)
-            for (i64 i = 1; i <= nx; i++) {
+    i64 nxy = nx * ny, l = l_begin;
+    if (l_begin >= l_end) return;
+    /* the loop nest `for k, for j, for i` entered at node l_begin */
+    const i64 k0 = (l_begin - 1) / nxy + 1, j0 = ((l_begin - 1) / nx) % ny + 1, i0 = (l_begin - 1) % nx + 1;
+    for (i64 k = k0; k <= nz; k++)
+        for (i64 j = (k == k0 ? j0 : 1); j <= ny; j++)
+            for (i64 i = (k == k0 && j == j0 ? i0 : 1); i <= nx; i++) {
+                if (l >= l_end) return;
                 uint64_t c = 6 * (uint64_t)(l - 1);
                 if (i < nx) {
                     double v = fd_rand(mode, seed, c + 0) * hy * hz / hx;
@@ -822,6 +829,9 @@ static void fdrand_walk(i64 nx, i64 ny, i64 nz, int mode, uint64_t seed, fd_sink
                     sink(ctx, fd_rand(mode, seed, c + 5) * hx * hy, l, l);
                 l++;
             }
+}
+static void fdrand_walk(i64 nx, i64 ny, i64 nz, int mode, uint64_t seed, fd_sink sink, void *ctx) {
+    fdrand_walk_range(nx, ny, nz, mode, seed, sink, ctx, 1, nx * ny * nz + 1);
 }
 
 typedef struct {
@@ -898,6 +908,72 @@ i64 orc_bench_fdrand(i64 nx, i64 ny, i64 nz, int style, double *t_insert_s, doub
     return z;
 }
 
+/* Secondary CPU baseline of bench.py (cpu_baseline.mt): the shape of GenericMTExtendableSparseMatrixCSC with
+ * Tm = SparseMatrixDILNKC.  np threads; thread p issues rawupdateindex!(A,+,v,i,j,tid=p) for the nodes of its slab
+ * (genericmtextendablesparsematrixcsc.jl:87-99: the CSC is empty, so everything goes to xmatrices[tid]; orc_lnk
+ * serves as the per-partition buffer, see orc_mt above), then flush! = Base.sum(xmatrices, csc)
+ * (sparsematrixdilnkc.jl:397-435): every buffer's entries, partition by partition and column by column, into
+ * I,J,V, then sparse!(I,J,V,m,n,+) -- serial, as in the reference.  Values: rand mode 1, seed 0x5EED0002. */
+typedef struct {
+    orc_lnk *x;
+    i64 nx, ny, nz, l_begin, l_end;
+} mt_job;
+static void mt_sink(void *c, double v, i64 i, i64 j) { orc_lnk_rawupdateindex((orc_lnk *)c, ORC_OP_ADD, v, i, j); }
+static void *mt_worker(void *arg) {
+    mt_job *jb = arg;
+    jb->x = orc_lnk_new(jb->nx * jb->ny * jb->nz, jb->nx * jb->ny * jb->nz); /* T_ext(m,n) of this partition */
+    fdrand_walk_range(jb->nx, jb->ny, jb->nz, 1, 0x5EED0002ull, mt_sink, jb->x, jb->l_begin, jb->l_end);
+    return NULL;
+}
+i64 orc_bench_fdrand_mt(i64 nx, i64 ny, i64 nz, i64 np, double *t_insert_s, double *t_merge_s) {
+    i64 N = nx * ny * nz;
+    if (np < 1) np = 1;
+    double t0 = now_s();
+    mt_job *jobs = xmalloc(sizeof(mt_job) * (size_t)np);
+    pthread_t *th = xmalloc(sizeof(pthread_t) * (size_t)np);
+    for (i64 p = 0; p < np; p++) {
+        jobs[p].x = NULL;
+        jobs[p].nx = nx;
+        jobs[p].ny = ny;
+        jobs[p].nz = nz;
+        jobs[p].l_begin = 1 + N * p / np;
+        jobs[p].l_end = 1 + N * (p + 1) / np;
+        pthread_create(&th[p], NULL, mt_worker, &jobs[p]);
+    }
+    for (i64 p = 0; p < np; p++) pthread_join(th[p], NULL);
+    double t1 = now_s();
+    i64 lnew = 0;
+    for (i64 p = 0; p < np; p++) lnew += jobs[p].x->nnz;
+    i64 *I = xmalloc(sizeof(i64) * (size_t)(lnew > 0 ? lnew : 1)), *J = xmalloc(sizeof(i64) * (size_t)(lnew > 0 ? lnew : 1));
+    double *V = xmalloc(sizeof(double) * (size_t)(lnew > 0 ? lnew : 1));
+    i64 at = 0;
+    for (i64 p = 0; p < np; p++) {
+        const orc_lnk *l = jobs[p].x;
+        for (i64 j = 1; j <= l->n; j++) {
+            if (l->rowval[j] == 0) continue; /* empty head slot: the column is not in this buffer */
+            for (i64 k = j; k > 0; k = l->colptr[k]) {
+                I[at] = l->rowval[k];
+                J[at] = j;
+                V[at] = l->nzval[k];
+                at++;
+            }
+        }
+    }
+    orc_csc *c = orc_sparse_coo(N, N, at, I, J, V);
+    double t2 = now_s();
+    i64 z = c ? orc_csc_nnz(c) : -1;
+    orc_csc_free(c);
+    free(I);
+    free(J);
+    free(V);
+    for (i64 p = 0; p < np; p++) orc_lnk_free(jobs[p].x);
+    free(jobs);
+    free(th);
+    if (t_insert_s) *t_insert_s = t1 - t0;
+    if (t_merge_s) *t_merge_s = t2 - t1;
+    return z;
+}
+
 /* ------------------------------------------------------------------- FEM */
 /* Update pattern of testassemble! (test/femtools.jl:45-72): per simplex,
  * for il: rawupdateindex!(A,+,0.1*vol/(dim+1),i,i); for jl:
@@ -966,7 +1042,7 @@ static void fem_local(int dim, i64 npd, i64 cell, i64 *nodes, double *vol_out, d
     i64 vx[4][3];
     fem_cell_lattice(dim, npd, cell, vx);
     double h = 1.0 / (double)(npd - 1);
-    double X[4][3];
+    double X[4][3] = {{0.0}};
     for (int k = 0; k <= dim; k++) {
         nodes[k] = 1 + vx[k][0] + npd * (vx[k][1] + npd * vx[k][2]);
         for (int d = 0; d < 3; d++) X[k][d] = (double)vx[k][d] * h;

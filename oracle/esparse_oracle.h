@@ -119,6 +119,8 @@ void orc_fdrand_stream(i64 nx, i64 ny, i64 nz, int rand_mode, uint64_t seed, i64
 int orc_fdrand_ext(orc_ext *, i64 nx, i64 ny, i64 nz, int rand_mode, uint64_t seed, int style);
 /* CPU baseline: same thing with wall-clock split; returns nnz */
 i64 orc_bench_fdrand(i64 nx, i64 ny, i64 nz, int style, double *t_insert_s, double *t_flush_s);
+/* np threads, one buffer per thread (node slabs), COO merge: the shape of GenericMTExtendableSparseMatrixCSC */
+i64 orc_bench_fdrand_mt(i64 nx, i64 ny, i64 nz, i64 np, double *t_insert_s, double *t_merge_s);
 
 /* P1 FEM on a Kuhn-triangulated tensor grid (update pattern of test/femtools.jl:45-72) */
 i64 orc_fem_ncells(int dim, i64 npd);

@@ -30,6 +30,47 @@ def build(force=False):
     return _SO
 
 
+_native = None       # (CDLL, flags) of the box-native build used by the baseline timings
+_native_tried = False
+
+
+def _make_var(name):
+    out = subprocess.check_output(["make", "-C", _HERE, "-pn"], stderr=subprocess.DEVNULL, text=True)
+    for line in out.splitlines():
+        if line.startswith(name + " ") and "=" in line:
+            return line.split("=", 1)[1].strip()
+    return ""
+
+
+def build_native():
+    """-O3 -march=native build of the same source ON THIS BOX (oracle/_native/, never shipped): what bench.py's
+    cpu_baseline leg times.  Returns (CDLL, flags); falls back to the portable library if the compile fails."""
+    global _native, _native_tried
+    if _native_tried:
+        return _native
+    _native_tried = True
+    so = os.path.join(_HERE, "_native", "libesparse_oracle_native.so")
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "_native/libesparse_oracle_native.so"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        L = C.CDLL(so)
+        flags = "gcc -O3 -march=native -ffp-contract=off, built on this box"
+    except Exception:
+        L = lib()
+        flags = "gcc -O3 -ffp-contract=off (portable build; the -march=native build failed on this box)"
+    for name in ("orc_bench_fdrand", "orc_bench_fdrand_mt"):
+        f = getattr(L, name)
+        f.restype = C.c_int64
+    L.orc_bench_fdrand.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    L.orc_bench_fdrand_mt.argtypes = [C.c_int64, C.c_int64, C.c_int64, C.c_int64, C.POINTER(C.c_double), C.POINTER(C.c_double)]
+    _native = (L, flags)
+    return _native
+
+
+def build_flags():
+    return build_native()[1]
+
+
 _lib = None
 i64 = C.c_int64
 p_i64 = C.POINTER(C.c_int64)
@@ -108,6 +149,7 @@ def lib():
     sig("orc_fdrand_stream", None, i64, i64, i64, C.c_int, C.c_uint64, p_i64, p_i64, p_f64)
     sig("orc_fdrand_ext", C.c_int, vp, i64, i64, i64, C.c_int, C.c_uint64, C.c_int)
     sig("orc_bench_fdrand", i64, i64, i64, i64, C.c_int, p_f64, p_f64)
+    sig("orc_bench_fdrand_mt", i64, i64, i64, i64, i64, p_f64, p_f64)
     sig("orc_fem_ncells", i64, C.c_int, i64)
     sig("orc_fem_nnodes", i64, C.c_int, i64)
     sig("orc_fem_count", i64, C.c_int, i64)
@@ -418,7 +460,14 @@ def fdrand(nx, ny=1, nz=1, rand_mode=1, seed=0x5EED0002, style=KIND_PLUSEQ):
 
 def bench_fdrand(nx, ny, nz, style=KIND_UPDATE):
     ti, tf = C.c_double(), C.c_double()
-    z = lib().orc_bench_fdrand(nx, ny, nz, style, C.byref(ti), C.byref(tf))
+    z = build_native()[0].orc_bench_fdrand(nx, ny, nz, style, C.byref(ti), C.byref(tf))
+    return z, ti.value, tf.value
+
+
+def bench_fdrand_mt(nx, ny, nz, nthreads):
+    """cpu_baseline.mt of bench.py: nthreads buffers filled in parallel + serial COO merge (see orc_bench_fdrand_mt)."""
+    ti, tf = C.c_double(), C.c_double()
+    z = build_native()[0].orc_bench_fdrand_mt(nx, ny, nz, nthreads, C.byref(ti), C.byref(tf))
     return z, ti.value, tf.value
 
 

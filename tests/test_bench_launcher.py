@@ -1,0 +1,55 @@
+"""bench.py --gpus N: the parent only launches N rank processes (it never touches the GPU), relays rank 0's line
+and refuses to run when the node has fewer GPUs than asked for.  CPU-only: the ranks meet over gloo (probe hook)."""
+import importlib.util
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench():
+    spec = importlib.util.spec_from_file_location("esp_bench_mod", os.path.join(ROOT, "bench.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+class _Args:
+    def __init__(self, gpus):
+        self.gpus = gpus
+
+
+def test_launcher_refuses_when_the_node_has_fewer_gpus(monkeypatch, capfd):
+    import torch
+    bench = _bench()
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 1)
+    rc = bench.launch(_Args(2), ["--gpus", "2"])
+    assert rc != 0
+    assert "refusing" in capfd.readouterr().err
+
+
+@pytest.mark.parametrize("n", [2, 3])
+def test_launcher_starts_n_ranks(monkeypatch, capfd, n):
+    import torch
+    bench = _bench()
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setenv("ESP_BENCH_LAUNCH_PROBE", "1")
+    monkeypatch.setenv("MASTER_PORT", str(29600 + n))
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    rc = bench.launch(_Args(n), ["--gpus", str(n), "--steps", "1"])
+    out = capfd.readouterr().out.strip().splitlines()
+    assert rc == 0 and out, out
+    d = json.loads(out[-1])
+    assert d["probe"] and d["n_gpus"] == n and d["rank_sum"] == n * (n - 1) / 2
+    assert d["local_rank"] == 0 and d["master"] == "127.0.0.1"
+
+
+def test_world_size_mismatch_is_an_error():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1"], env=env,
+                       capture_output=True, text=True)
+    assert r.returncode != 0 and "WORLD_SIZE" in (r.stderr + r.stdout)
