@@ -18,9 +18,18 @@ def digest(*arrs):
     return h.hexdigest()
 
 
-def digests():
+def cfg3_new_positions(n, seed=0x5EED0003):
+    """BASELINE config 3's new entries on an n^3 stencil: the x second-neighbour pairs (l,l+2),(l+2,l),
+    values U[0,1) from numpy's default_rng(seed) (host-made, so that the oracle and the device see the same bits)."""
+    g = np.arange(n ** 3, dtype=np.int64)
+    l = g[(g % n) < n - 2] + 1
+    v = np.random.default_rng(seed).random(len(l))
+    return np.concatenate([l, l + 2]), np.concatenate([l + 2, l]), np.concatenate([v, v])
+
+
+def digests(name="digests.txt"):
     out = {}
-    with open(os.path.join(GOLDEN, "digests.txt")) as f:
+    with open(os.path.join(GOLDEN, name)) as f:
         for line in f:
             parts = line.split()
             out[parts[0]] = dict(p.split("=") for p in parts[1:])

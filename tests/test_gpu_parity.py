@@ -1359,3 +1359,98 @@ def test_inplace_exchange_three_shards_on_one_gpu(esp, orc):
             sel = (J - 1 >= c0) & (J - 1 < c1)
             O.apply(K[sel], I[sel], J[sel], V[sel])
         assert_csc_equal(bes[dst].local_csc().arrays(), O.arrays(), "shard %d" % dst)
+
+
+# ------------------------------------------------------------------ full-size pins (tests/golden/digests_large.txt)
+@pytest.mark.parametrize("n", [128, 192, 256])
+def test_fdrand_full_size_digest(esp, n):
+    """BASELINE config 2 with random values at the bench's size (256^3: rand_mode 1, seed 0x5EED0002, updateindex!
+    style -- exactly 32 key bits below the 16-bit prefix) and two smaller cubes: the device CSC's sha256 equals the
+    oracle's (tests/golden/make_digests_large.py).  Producer-side partition and, with the hook, the flush's own."""
+    d = gu.digests("digests_large.txt")["fd_%d_m1" % n]
+    N = n ** 3
+    for force in ((0, 16) if n < 256 else (0,)):
+        A = esp.ExtendableSparseMatrix(N, N)
+        A.debug_force_path(force)
+        A.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1)
+        A.flush()
+        assert A.debug_last_partition() == (4 if force == 0 else 1)
+        assert A.debug_last_key_bytes() == 4
+        arrs = hip_arrays(A)
+        assert len(arrs[1]) == int(d["nnz"])
+        assert gu.digest(*arrs) == d["csc"], (n, force)
+        del A, arrs
+
+
+def test_config3_digest_128(esp):
+    """BASELINE config 3 at 128^3: stored stencil CSC + new second-neighbour positions + the full stream again, one
+    flush through the routed fold and the merge-path join; digest of the oracle's result."""
+    n = 128
+    N = n ** 3
+    d = gu.digests("digests_large.txt")["cfg3_%d" % n]
+    I2, J2, V2 = gu.cfg3_new_positions(n)
+    for order in ("append_first", "generate_first"):
+        A = esp.ExtendableSparseMatrix(N, N)
+        A.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1)
+        A.flush()
+        if order == "append_first":
+            A.append(UPDATE, I2, J2, V2)
+            A.generate_fdrand(n, n, n, seed=0x5EED0012, rand_mode=1)
+        else:
+            # (different call order, same result: the new positions and the stencil's never coincide)
+            A.generate_fdrand(n, n, n, seed=0x5EED0012, rand_mode=1)
+            A.append(UPDATE, I2, J2, V2)
+        A.flush()
+        arrs = hip_arrays(A)
+        assert len(arrs[1]) == int(d["nnz"])
+        assert gu.digest(*arrs) == d["csc"], order
+
+
+@pytest.mark.parametrize("dim,npd", [(2, 1000), (3, 64)])
+@pytest.mark.parametrize("order", [0, 1])
+def test_fem_digest(esp, dim, npd, order):
+    """BASELINE config 4 at 10^6 / 2.6 10^5 DoF, natural (producer-side partition) and random cell order (8-bit passes)."""
+    d = gu.digests("digests_large.txt")["fem%dd_%d_o%d" % (dim, npd, order)]
+    nn = npd ** dim
+    A = esp.ExtendableSparseMatrix(nn, nn)
+    A.generate_fem(dim, npd, seed=0x5EED0004, order_mode=order)
+    A.flush()
+    assert A.debug_last_partition() == (4 if order == 0 else 2)
+    arrs = hip_arrays(A)
+    assert len(arrs[1]) == int(d["nnz"])
+    assert gu.digest(*arrs) == d["csc"]
+
+
+@pytest.mark.parametrize("dims", [(4096, 300, 1), (300, 4096, 1), (2000001, 1, 1), (37, 41, 1013), (1021, 3, 509), (2, 2, 400000),
+                                  (129, 127, 131)])
+def test_producer_partition_odd_grids(esp, orc, dims):
+    """Producer-side partition on grids whose lines, planes and buckets do not line up with the 256-node chunks
+    (1-D and 2-D stencils, prime extents, two-node lines): the oracle's bits, and the same bits without it."""
+    nx, ny, nz = dims
+    N = nx * ny * nz
+    O = orc.fdrand(nx, ny, nz, rand_mode=1, seed=99, style=orc.KIND_UPDATE)
+    want = O.arrays()
+    seen = set()
+    for force in (0, 16):
+        A = esp.ExtendableSparseMatrix(N, N)
+        A.debug_force_path(force)
+        A.generate_fdrand(nx, ny, nz, seed=99, rand_mode=1)
+        A.flush()
+        seen.add(A.debug_last_partition())
+        assert_csc_equal(hip_arrays(A), want, "%s force %d" % (dims, force))
+    assert 4 in seen, seen
+
+
+@pytest.mark.parametrize("focus,seed,seconds", [("", 11, 20), ("k32", 12, 12)])
+def test_bounded_fuzz(focus, seed, seconds):
+    """tools/fuzz_parity.py (random shapes, kinds, orders, flush sequences, forced paths; every result against the
+    oracle bit for bit) with fixed seeds and a bounded budget."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    if focus:
+        env["ESP_FUZZ_FOCUS"] = focus
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), str(seconds), str(seed)], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
