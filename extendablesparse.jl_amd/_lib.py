@@ -85,6 +85,17 @@ SIGNATURES = {
     "esp_shard_exchange_place": (i32, [vp, i64, vp, vp, i64]),
     "esp_shard_partition": (i32, [vp, i32, i32, i64, P(i32), P(vp), P(vp), P(vp), vp, P(i64)]),
     "esp_shard_assemble": (i32, [vp, vp, vp, vp, vp, P(i32)]),
+    "esp_group_unique_id": (i32, [vp]),
+    "esp_group_create": (i32, [vp, i32, i32, vp, P(vp)]),
+    "esp_group_create_comm": (i32, [vp, i32, i32, vp, P(vp)]),
+    "esp_group_destroy": (i32, [vp]),
+    "esp_group_handle": (i32, [vp, P(vp)]),
+    "esp_group_last_error": (C.c_char_p, [vp]),
+    "esp_group_column_range": (i32, [vp, P(i64), P(i64)]),
+    "esp_group_flush": (i32, [vp, i32, P(i64), P(i32)]),
+    "esp_group_nnz": (i32, [vp, P(i64), P(i64)]),
+    "esp_group_get_csc": (i32, [vp, vp, vp, vp]),
+    "esp_group_last_exchange": (i32, [vp, P(i32), P(i64)]),
     "esp_timing_enable": (i32, [vp, i32]),
     "esp_timing": (i32, [vp, P(esp_timing_t), i32]),
     "esp_debug_force_path": (i32, [vp, i32]),
@@ -95,6 +106,15 @@ SIGNATURES = {
     "esp_debug_last_path": (i32, [vp, P(i32)]),
     "esp_debug_last_partition": (i32, [vp, P(i32)]),
 }
+
+# esp_comm_t: the host-supplied transport of esp_group_create_comm
+ALLGATHER_FN = C.CFUNCTYPE(i32, vp, P(i64), i32, P(i64))
+ALLTOALLV_FN = C.CFUNCTYPE(i32, vp, P(vp), P(i64), P(vp), P(i64), vp)
+
+
+class esp_comm_t(C.Structure):
+    _fields_ = [("ctx", vp), ("allgather_i64", ALLGATHER_FN), ("alltoallv_dev", ALLTOALLV_FN)]
+
 
 _lib = None
 

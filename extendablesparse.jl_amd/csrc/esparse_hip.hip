@@ -2919,3 +2919,6 @@ extern "C" int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear) {
     if (clear) memset(&h->acc, 0, sizeof h->acc);
     return ESP_OK;
 }
+
+// ------------------------------------------------------------------------ groups (one process per GPU)
+#include "group.hpp"

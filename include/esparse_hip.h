@@ -235,6 +235,46 @@ int32_t esp_shard_assemble(esp_handle *h, const uint64_t *const *d_recv_keys,
                            const double *const *d_recv_vals, const int64_t *const *d_recv_counts,
                            const int64_t *recv_entries /* nshards */, int32_t *ok);
 
+/* ---- esp_group: the sharded flush as ONE call per rank (one process per GPU) --------------------------
+ * What GenericMTExtendableSparseMatrixCSC does with threads (one buffer per tid, flush! = Base.sum(xmatrices, csc):
+ * src/matrix/genericmtextendablesparsematrixcsc.jl:45-51,87-99) across the GPUs of a node: every rank appends whatever
+ * its part of the assembly loop produces to ITS handle (any column), esp_group_flush routes every pending entry to the
+ * rank that owns its column and runs the local flush.  It drives the esp_shard_* calls above; the transport is RCCL
+ * (grouped ncclSend/ncclRecv on the handle's stream, loaded with dlopen: no link-time dependency) or a callback table
+ * of the host (MPI, a test harness).  Every esp_group_flush / _nnz / _get_csc is COLLECTIVE: all ranks call it.
+ *
+ *   rank 0:  esp_group_unique_id(id)  ->  the host broadcasts the 128 bytes (MPI_Bcast, a socket, Distributed.jl)
+ *   all:     esp_create(m, n, device, hint, &h); esp_group_create(h, nranks, rank, id, &g)
+ *   loop:    appends on h (esp_commit / esp_append_* / esp_generate_*);  esp_group_flush(g, mode, &local_nnz, &changed)
+ *   result:  esp_group_nnz (global nnz, this rank's offset), esp_group_get_csc (own column range, global colptr values),
+ *            or the device CSC of the handle (esp_csc_device) for consumers that stay on the GPU.                    */
+typedef struct esp_group esp_group;
+typedef struct {
+    void *ctx;
+    /* all-gather of `count` int64 per rank through HOST memory; recv holds nranks * count values, rank-major */
+    int32_t (*allgather_i64)(void *ctx, const int64_t *send, int32_t count, int64_t *recv);
+    /* all-to-all-v on DEVICE memory of the handle's device: for every peer q (the own index is ignored) send
+     * send_bytes[q] bytes from send[q] and receive recv_bytes[q] bytes into recv[q]; must be complete, or ordered on
+     * hip_stream (the handle's hipStream_t) in front of whatever is enqueued there next, when it returns */
+    int32_t (*alltoallv_dev)(void *ctx, const void *const *send, const int64_t *send_bytes, void *const *recv,
+                             const int64_t *recv_bytes, void *hip_stream);
+} esp_comm_t;
+int32_t esp_group_unique_id(uint8_t *id128 /* 128 bytes: an ncclUniqueId */);
+/* the handle must be empty; its column window becomes the rank's own column range */
+int32_t esp_group_create(esp_handle *h, int32_t nranks, int32_t rank, const uint8_t *id128, esp_group **out);
+int32_t esp_group_create_comm(esp_handle *h, int32_t nranks, int32_t rank, const esp_comm_t *comm, esp_group **out);
+int32_t esp_group_destroy(esp_group *g);   /* (the handle stays the caller's) */
+int32_t esp_group_handle(esp_group *g, esp_handle **out);
+const char *esp_group_last_error(const esp_group *g);
+/* the rank's own columns, 1-based inclusive: owner(col) = floor((col-1)*nranks/n) */
+int32_t esp_group_column_range(const esp_group *g, int64_t *col_lo, int64_t *col_hi);
+int32_t esp_group_flush(esp_group *g, int32_t mode, int64_t *local_nnz, int32_t *pattern_changed);
+int32_t esp_group_nnz(esp_group *g, int64_t *global_nnz, int64_t *nnz_before_me);
+/* colptr_own: col_hi - col_lo + 2 entries = the GLOBAL colptr[col_lo .. col_hi + 1]; rowval, nzval: local_nnz entries */
+int32_t esp_group_get_csc(esp_group *g, int64_t *colptr_own, int64_t *rowval, double *nzval);
+/* kind: 1 = partitioned exchange (pre-sorted streams), 2 = in-place exchange; entries sent to other ranks */
+int32_t esp_group_last_exchange(const esp_group *g, int32_t *kind, int64_t *sent_off_rank);
+
 /* promise: every pending entry of the following flushes has its column in [col_lo, col_hi]
  * (1-based); the partition then works on that window only.  Violations -> ESP_ERR_STATE from esp_flush: the
  * stored pattern is untouched and the batch stays pending (esp_clear_pending / esp_reset), but updates of the

@@ -1454,3 +1454,111 @@ def test_bounded_fuzz(focus, seed, seconds):
     r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), str(seconds), str(seed)], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+
+
+# ------------------------------------------------------------------ the C group API (esp_group_*)
+def _group_ranks_run(esp, orc, world, deal, n=44, rounds=2):
+    """W ranks as threads on one GPU, each with its own handle and esp_group (transport: the callback table of
+    tests/threaddist.py::ThreadComm): the exchange and its policy run inside the library.  The stitched CSC must equal
+    ONE oracle buffer fed the ranks' streams in rank order."""
+    from threaddist import ThreadComm, run_ranks
+    nx = ny = n
+    nzg = n * world
+    N = nx * ny * nzg
+    nodes = nx * ny * n
+    seeds = [77, 78, 79]
+    streams = [orc.fdrand_stream(nx, ny, nzg, rand_mode=1, seed=seeds[r]) for r in range(rounds)]
+    E = len(streams[0][0])
+    kinds = np.where(np.arange(E) % 5 == 0, RAW, UPDATE).astype(np.uint8)
+    if deal == "slab":
+        l = np.arange(N)
+        i, j, k = l % nx + 1, (l // nx) % ny + 1, l // (nx * ny) + 1
+        per = (4 * (i < nx) + ((i == 1) | (i == nx)) + 4 * (j < ny) + ((j == 1) | (j == ny))
+               + 4 * (k < nzg) + ((k == 1) | (k == nzg)))
+        off = np.concatenate([[0], np.cumsum(per)])
+        sel = [slice(int(off[r * nodes]), int(off[(r + 1) * nodes])) for r in range(world)]
+        kinds[:] = UPDATE
+    else:
+        chunk = np.arange(E) // 4096
+        sel = [(chunk % world) == r for r in range(world)]
+    perm1 = np.random.default_rng(9).permutation(int(np.count_nonzero(sel[1])) if deal != "slab" else 1)
+
+    def rank_stream(rank, rnd):
+        I, J, V = streams[rnd]
+        Ii, Jj, Vv, kk = I[sel[rank]], J[sel[rank]], V[sel[rank]], kinds[sel[rank]]
+        if deal == "shuffled_rank1" and rank == 1:
+            Ii, Jj, Vv, kk = Ii[perm1], Jj[perm1], Vv[perm1], kk[perm1]
+        return Ii, Jj, Vv, kk
+
+    comm = ThreadComm(world, esp._lib)
+
+    def body(rank, dist):
+        holder = {}
+        table = comm.table(rank, lambda: holder["A"].local._d.h)
+        A = esp.GroupShardedMatrix(N, N, nranks=world, rank=rank, comm=table)
+        holder["A"] = A
+        hist = []
+        for rnd in range(rounds):
+            if deal == "slab":
+                A.local.generate_fdrand_range(nx, ny, nzg, rank * nodes, (rank + 1) * nodes, seed=seeds[rnd], rand_mode=1)
+            else:
+                Ii, Jj, Vv, kk = rank_stream(rank, rnd)
+                A.local.append(0, Ii, Jj, Vv, kinds=kk)
+            A.flush()
+            hist.append((A.last_exchange, A.local.debug_last_partition()))
+        total = A.nnz()
+        piece = A.local_slice()
+        lo, hi = A.column_range()
+        assert (lo - 1, hi) == esp.owner_ranges(N, world)[rank]
+        return hist, piece, total
+
+    outs = run_ranks(world, body)
+    if comm.errors:
+        raise comm.errors[0]
+    O = orc.ExtendableSparseMatrix(N, N)
+    for rnd in range(rounds):
+        for rank in range(world):
+            Ii, Jj, Vv, kk = rank_stream(rank, rnd)
+            O.apply(kk, Ii, Jj, Vv)
+        O.flush()
+    G = esp.GroupShardedMatrix.stitch(N, N, [o[1] for o in outs], outs[0][2])
+    assert_csc_equal(G.arrays(), O.arrays())
+    assert all(o[2] == O.nnz() for o in outs)
+    return [o[0] for o in outs]
+
+
+@pytest.mark.parametrize("world,deal", [(2, "slab"), (3, "slab"), (2, "scrambled"), (3, "scrambled")])
+def test_group_api_partitioned_exchange(esp, orc, world, deal):
+    hist = _group_ranks_run(esp, orc, world, deal)
+    for h in hist:
+        assert h == [("partitioned", 7), ("partitioned", 7)], h
+
+
+def test_group_api_falls_back_by_consensus(esp, orc):
+    hist = _group_ranks_run(esp, orc, 2, "shuffled_rank1")
+    for h in hist:
+        assert [x[0] for x in h] == ["inplace", "inplace"], h
+
+
+def test_group_api_world1_rccl(esp, orc):
+    """The RCCL transport of the library itself (ncclCommInitRank from a unique id, world size 1): fresh build, then
+    re-assembly with new entries; global nnz / column range / stitched CSC."""
+    n = 40
+    N = n ** 3
+    uid = esp.GroupShardedMatrix.unique_id()
+    assert len(uid) == 128
+    A = esp.GroupShardedMatrix(N, N, nranks=1, rank=0, unique_id=uid)
+    O = orc.ExtendableSparseMatrix(N, N)
+    rng = np.random.default_rng(2)
+    for rnd in range(2):
+        A.local.generate_fdrand(n, n, n, seed=5 + rnd, rand_mode=1)
+        I, J, V = orc.fdrand_stream(n, n, n, rand_mode=1, seed=5 + rnd)
+        O.apply(np.full(len(I), UPDATE, np.uint8), I, J, V)
+        Ix, Jx, Vx = rng.integers(1, N + 1, 3000), rng.integers(1, N + 1, 3000), rng.standard_normal(3000)
+        A.local.append(RAW, Ix, Jx, Vx)
+        O.apply(np.full(3000, RAW, np.uint8), Ix, Jx, Vx)
+        A.flush()
+        O.flush()
+        assert A.nnz() == O.nnz() and A.column_range() == (1, N)
+        c0, c1, cp, rv, nz = A.local_slice()
+        assert_csc_equal((cp, rv, nz), O.arrays())

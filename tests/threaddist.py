@@ -108,3 +108,64 @@ def run_ranks(world, fn):
         if e is not None:
             raise e
     return outs
+
+
+class ThreadComm:
+    """esp_comm_t callback tables (esp_group_create_comm) for W ranks that live in W threads of one process:
+    the C group API's exchange driven with a transport of the host.  deposit / barrier / copy / barrier."""
+
+    def __init__(self, world, lib_module):
+        self.W = world
+        self.L = lib_module            # extendablesparse.jl_amd._lib
+        self._bar = threading.Barrier(world)
+        self._box = [None] * world
+        self._keep = []
+        self.errors = []
+
+    def table(self, rank, handle_getter):
+        """handle_getter(): the rank's esp_handle pointer (c_void_p), known once the matrix exists."""
+        import ctypes as C
+        L = self.L
+        lib = L.load()
+
+        def wrap(ptr, nbytes):
+            from extendablesparse_devview import view_u8
+            return view_u8(torch, ptr, nbytes)
+
+        def allgather(ctx, send, count, recv):
+            try:
+                self._box[rank] = [send[i] for i in range(count)]
+                self._bar.wait()
+                for q in range(self.W):
+                    for i in range(count):
+                        recv[q * count + i] = self._box[q][i]
+                self._bar.wait()
+                return 0
+            except BaseException as e:  # noqa: BLE001
+                self.errors.append(e)
+                self._bar.abort()
+                return -3
+
+        def alltoallv(ctx, send, send_bytes, recv, recv_bytes, stream):
+            try:
+                lib.esp_synchronize(handle_getter())     # the send ranges are complete
+                self._box[rank] = ([send[q] for q in range(self.W)], [send_bytes[q] for q in range(self.W)])
+                self._bar.wait()
+                for q in range(self.W):
+                    if q == rank:
+                        continue
+                    src, nb = self._box[q][0][rank], self._box[q][1][rank]
+                    assert nb == recv_bytes[q], (rank, q, nb, recv_bytes[q])
+                    if nb:
+                        wrap(recv[q], nb).copy_(wrap(src, nb))
+                torch.cuda.synchronize()
+                self._bar.wait()
+                return 0
+            except BaseException as e:  # noqa: BLE001
+                self.errors.append(e)
+                self._bar.abort()
+                return -3
+
+        t = L.esp_comm_t(None, L.ALLGATHER_FN(allgather), L.ALLTOALLV_FN(alltoallv))
+        self._keep.append(t)
+        return t
