@@ -302,26 +302,15 @@ def main():
         # weak scaling: the global grid is n x n x (n*world); rank r assembles the z-slab of nodes
         # it owns (fixed work per GPU), columns are range-sharded, entries of the cross-slab pairs
         # travel through the all-to-all
-        if dist is None:
-            import torch.distributed as dist
-            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-            os.environ.setdefault("MASTER_PORT", "29533")
-            dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", local))
         nzg = n * world
         N = n * n * nzg
-        be = esp.HipShardBackend(N, N, device=local, capacity_hint=E + 4 * n * n)
-        # the small agreements of a flush travel over a gloo group (host memory, loopback: one node): a device
-        # collective would sit behind the partition's scatter kernel
-        ctrl = None
-        if not os.environ.get("ESP_BENCH_NO_CTRL_GROUP"):
-            os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
-            try:
-                ctrl = dist.new_group(backend="gloo")
-            except Exception as ex:   # (same outcome on every rank of the node: fall back to the data group)
-                print("bench: no gloo control group (%s), using the RCCL group" % ex, file=sys.stderr)
-                ctrl = None
-        SA = esp.ShardedExtendableSparseMatrix(N, N, be, ctrl_group=ctrl)
-        A = be.matrix
+        # the C group API: exchange policy and RCCL all-to-all-v (grouped ncclSend/ncclRecv on the library's stream)
+        # live inside libesparse_hip.so; torch.distributed only carries the 128-byte id, the barrier and the timing
+        uid = [esp.GroupShardedMatrix.unique_id() if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(uid, src=0)
+        SA = esp.GroupShardedMatrix(N, N, nranks=world, rank=rank, device=local, capacity_hint=E + 4 * n * n, unique_id=uid[0])
+        A = SA.local
         Z_total = N + 2 * ((n - 1) * n * nzg + n * (n - 1) * nzg + n * n * (nzg - 1))
         nodes = n ** 3
 

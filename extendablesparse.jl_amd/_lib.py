@@ -76,6 +76,8 @@ SIGNATURES = {
     "esp_dropzeros": (i32, [vp, P(i64)]),
     "esp_getindex": (i32, [vp, i64, i64, P(f64), P(i32)]),
     "esp_pattern_hash": (i32, [vp, P(u64)]),
+    "esp_pending_getindex": (i32, [vp, i64, i64, P(f64), P(i32)]),
+    "esp_release_buffers": (i32, [vp]),
     "esp_mul": (i32, [vp, vp, vp, i32]),
     "esp_mark_dirichlet": (i32, [vp, f64, vp, i32]),
     "esp_eliminate_dirichlet": (i32, [vp, vp, i32]),

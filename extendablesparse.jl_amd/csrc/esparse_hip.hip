@@ -219,6 +219,23 @@ static void release(DevBuf &b) {
     b.bytes = 0;
 }
 
+static void release_all(esp_handle *h) {
+    for (DevBuf *b : {&h->keys, &h->vals, &h->keys2, &h->vals2, &h->hist, &h->segs, &h->colend, &h->newkey,
+                      &h->newval, &h->heads, &h->misc, &h->colptr, &h->rowval, &h->nzval, &h->rowval2,
+                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->runbuf, &h->chunkbuf, &h->parttab, &h->piecetab, &h->csr_rowptr, &h->csr_perm, &h->csr_col, &h->csr_tmp, &h->csr_val, &h->mul_x, &h->mul_r, &h->stage.d_rows, &h->stage.d_cols, &h->stage.d_vals, &h->stage.d_kinds, &h->bulk.d_rows, &h->bulk.d_cols, &h->bulk.d_vals, &h->bulk.d_kinds})
+        release(*b);
+    for (esp_handle::StageArea *sa : {&h->stage, &h->bulk}) {
+        if (sa->rows) (void)hipHostFree(sa->rows);
+        if (sa->cols) (void)hipHostFree(sa->cols);
+        if (sa->vals) (void)hipHostFree(sa->vals);
+        if (sa->kinds) (void)hipHostFree(sa->kinds);
+        sa->rows = sa->cols = nullptr;
+        sa->vals = nullptr;
+        sa->kinds = nullptr;
+        sa->cap = 0;
+    }
+}
+
 // ------------------------------------------------------------------------ timing
 static hipEvent_t ev_get(esp_handle *h) {
     if (!h->ev_pool.empty()) {
@@ -284,6 +301,13 @@ __global__ void set_i64_k(i64 *p, i64 a, i64 b, i64 c, i64 d) {
 __global__ void fill_i64_k(i64 *p, i64 n, i64 v) {
     const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (g < n) p[g] = v;
+}
+
+// The 64-byte block of partition results (longest bucket + four flag words) goes to pinned HOST memory with plain
+// stores: the host then needs neither a copy engine nor a blit kernel -- which may queue behind the kernel that fills
+// the chip -- to read it, only the event recorded behind this launch.
+__global__ void publish_block_k(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ host_dst) {
+    if (threadIdx.x < 8) __hip_atomic_store(&host_dst[threadIdx.x], src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 static inline unsigned grid_for(i64 n, int threads) { return (unsigned)std::max<i64>(1, ceil_div<i64>(n, threads)); }
@@ -395,16 +419,7 @@ extern "C" int32_t esp_destroy(esp_handle *h) {
     if (!h) return ESP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
-    for (DevBuf *b : {&h->keys, &h->vals, &h->keys2, &h->vals2, &h->hist, &h->segs, &h->colend, &h->newkey,
-                      &h->newval, &h->heads, &h->misc, &h->colptr, &h->rowval, &h->nzval, &h->rowval2,
-                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->runbuf, &h->chunkbuf, &h->parttab, &h->piecetab, &h->csr_rowptr, &h->csr_perm, &h->csr_col, &h->csr_tmp, &h->csr_val, &h->mul_x, &h->mul_r, &h->stage.d_rows, &h->stage.d_cols, &h->stage.d_vals, &h->stage.d_kinds, &h->bulk.d_rows, &h->bulk.d_cols, &h->bulk.d_vals, &h->bulk.d_kinds})
-        release(*b);
-    for (esp_handle::StageArea *sa : {&h->stage, &h->bulk}) {
-        if (sa->rows) (void)hipHostFree(sa->rows);
-        if (sa->cols) (void)hipHostFree(sa->cols);
-        if (sa->vals) (void)hipHostFree(sa->vals);
-        if (sa->kinds) (void)hipHostFree(sa->kinds);
-    }
+    release_all(h);
     if (h->pin_scalar) (void)hipHostFree(h->pin_scalar);
     for (auto &s : h->spans) {
         (void)hipEventDestroy(s.a);
@@ -416,6 +431,31 @@ extern "C" int32_t esp_destroy(esp_handle *h) {
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return ESP_OK;
+}
+
+static int32_t init_empty_csc(esp_handle *h);
+// The Generic wrappers of the reference replace their buffer by a fresh T_ext(m,n) after every flush!
+// (genericextendablesparsematrixcsc.jl:34, genericmt...:47-49) and leave the old one to the garbage collector, which
+// does not see device or pinned memory: the shim calls this on the old buffer right after `buffer + csc` returned.
+// The handle stays valid (an empty matrix with an empty buffer; the staging chunk pointers of esp_stage_begin are
+// gone); everything is allocated again on next use.
+extern "C" int32_t esp_release_buffers(esp_handle *h) {
+    if (!h) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    timing_collect(h);
+    release_all(h);
+    h->cap = 0;
+    h->count = 0;
+    h->chunk_cap = 0;
+    h->chunk_pb = 0;
+    pending_changed(h);
+    h->csc_valid = false;
+    h->ones_pending = false;
+    h->tail_stale = false;
+    h->csr_version = 0;
+    h->csr_val_version = 0;
+    return init_empty_csc(h);
 }
 
 static int32_t reserve_append(esp_handle *h, i64 add);
@@ -1067,6 +1107,81 @@ extern "C" int32_t esp_getindex(esp_handle *h, int64_t i, int64_t j, double *val
     return ESP_OK;
 }
 
+// ---- getindex(buffer, i, j): the value the pending entries alone give position (i,j) ---------------------------
+// SparseMatrixLNK's getindex (sparsematrixlnk.jl:151-171) returns what the inserts so far left at (i,j), zero if
+// there is no entry.  The device buffer holds the calls themselves: the matching ones are collected (buffer position,
+// kind, value), ordered by position -- the call order, also in a bucket-ordered batch -- and folded by the state
+// machine of fold.hpp.  A slow path by design (one pass over the pending keys per call): GenericExtendableSparseMatrixCSC
+// reaches it for reads of positions that are not in the CSC yet (genericextendablesparsematrixcsc.jl:60-69).
+constexpr int PENDING_MATCH_CAP = 2048;
+__global__ void pending_matches_k(const u64 *__restrict__ keys, const double *__restrict__ vals, i64 E, u64 target,
+                                  unsigned long long *__restrict__ count, u64 *__restrict__ mpos, double *__restrict__ mval) {
+    const i64 stride = (i64)gridDim.x * blockDim.x;
+    for (i64 p = (i64)blockIdx.x * blockDim.x + threadIdx.x; p < E; p += stride) {
+        const u64 k = keys[p];
+        if ((k >> ESP_TAG_BITS) == target) {
+            const unsigned long long at = atomicAdd(count, 1ull);
+            if (at < (unsigned long long)PENDING_MATCH_CAP) {
+                mpos[at] = ((u64)p << ESP_TAG_BITS) | (k & ESP_TAG_MASK);
+                mval[at] = vals[p];
+            }
+        }
+    }
+}
+__global__ __launch_bounds__(256) void pending_fold_k(const unsigned long long *__restrict__ count, const u64 *__restrict__ mpos,
+                                                      const double *__restrict__ mval, double *__restrict__ out) {
+    __shared__ u64 spos[PENDING_MATCH_CAP];
+    __shared__ double sval[PENDING_MATCH_CAP];
+    const int n = (int)min(*count, (unsigned long long)PENDING_MATCH_CAP);
+    for (int q = threadIdx.x; q < n; q += 256) {  // rank sort by buffer position (positions are distinct)
+        const u64 me = mpos[q];
+        int r = 0;
+        for (int o = 0; o < n; o++) r += mpos[o] < me ? 1 : 0;
+        spos[r] = me;
+        sval[r] = mval[q];
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        bool present = false;
+        double acc = 0.0;
+        for (int q = 0; q < n; q++) espfold::fold_step(present, acc, (u32)(spos[q] & ESP_TAG_MASK), sval[q]);
+        out[0] = present ? acc : 0.0;
+        out[1] = present ? 1.0 : 0.0;
+    }
+}
+extern "C" int32_t esp_pending_getindex(esp_handle *h, int64_t i, int64_t j, double *value, int32_t *found) {
+    if (!h || !value) return ESP_ERR_INVALID;
+    if (!(1 <= i && i <= h->m && 1 <= j && j <= h->n)) FAIL(h, ESP_ERR_BOUNDS, "BoundsError: (%lld,%lld) outside %lld x %lld", (long long)i, (long long)j, (long long)h->m, (long long)h->n);
+    *value = 0.0;
+    if (found) *found = 0;
+    if (h->count == 0) return ESP_OK;
+    (void)hipSetDevice(h->device);
+    if (h->part_assembled) FAIL(h, ESP_ERR_STATE, "esp_pending_getindex: the pending entries are spread over shard pieces (flush first)");
+    CK(pending_materialize(h));  // (packed keys)
+    const size_t bytes = 64 + (sizeof(u64) + sizeof(double)) * (size_t)PENDING_MATCH_CAP;
+    CK(ensure(h, h->heads, bytes));
+    unsigned long long *cnt = (unsigned long long *)h->heads.p;
+    double *d_out = (double *)h->heads.p + 2;
+    u64 *mpos = (u64 *)((char *)h->heads.p + 64);
+    double *mval = (double *)(mpos + PENDING_MATCH_CAP);
+    HIPCK(h, hipMemsetAsync(cnt, 0, 64, h->stream));
+    const u64 target = ((u64)(j - 1) << h->L.rb) | (u64)(i - 1);
+    const unsigned grid = (unsigned)std::min<i64>(4096, std::max<i64>(1, ceil_div<i64>(h->count, 256)));
+    hipLaunchKernelGGL(pending_matches_k, dim3(grid), dim3(256), 0, h->stream, (const u64 *)h->keys.p, (const double *)h->vals.p, h->count,
+                       target, cnt, mpos, mval);
+    hipLaunchKernelGGL(pending_fold_k, dim3(1), dim3(256), 0, h->stream, (const unsigned long long *)cnt, (const u64 *)mpos,
+                       (const double *)mval, d_out);
+    HIPCK(h, hipGetLastError());
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, cnt, 32, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (h->pin_scalar[0] > (unsigned long long)PENDING_MATCH_CAP)
+        FAIL(h, ESP_ERR_UNSUPPORTED, "esp_pending_getindex: more than %d pending updates of (%lld,%lld); flush first", PENDING_MATCH_CAP, (long long)i, (long long)j);
+    const double *r = (const double *)(h->pin_scalar + 2);
+    *value = r[0];
+    if (found) *found = r[1] != 0.0;
+    return ESP_OK;
+}
+
 extern "C" int32_t esp_pattern_hash(esp_handle *h, uint64_t *hash) {
     if (!h || !hash) return ESP_ERR_INVALID;
     (void)hipSetDevice(h->device);
@@ -1378,16 +1493,16 @@ static int32_t prepart_rank(esp_handle *h, PartSetup *ps) {
                            ps->dcount, ps->dlist, NB, ps->seg_out, ps->runs_off, d_maxlen, flags + 3);
         sp.add(2);
     }
-    HIPCK(h, hipEventRecord(h->aux_ev, h->stream));  // (the host reads the flags while the PART launch runs)
+    // (the host reads the flags while the PART launch runs)
+    hipLaunchKernelGGL(publish_block_k, dim3(1), dim3(64), 0, h->stream, (const unsigned long long *)d_maxlen, h->pin_scalar);
+    HIPCK(h, hipEventRecord(h->aux_ev, h->stream));
     return ESP_OK;
 }
 // after the PART launch was issued: *took = false when it left without a store (window error, a chunk with too many
 // digits, a digit with too many runs: the caller issues the plain producer); else the handle's buffer is bucket-ordered
 static int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took) {
     *took = false;
-    HIPCK(h, hipStreamWaitEvent(h->aux, h->aux_ev, 0));
-    HIPCK(h, hipMemcpyAsync(h->pin_scalar, (unsigned long long *)h->misc.p + 24, 64, hipMemcpyDeviceToHost, h->aux));
-    HIPCK(h, hipStreamSynchronize(h->aux));
+    HIPCK(h, hipEventSynchronize(h->aux_ev));  // (publish_block_k has written the block to pin_scalar)
     const u32 f_err = (u32)h->pin_scalar[6], f_over = (u32)(h->pin_scalar[6] >> 32), f_many = (u32)(h->pin_scalar[7] >> 32);
     if (f_err | f_over | f_many) {
         // (flags[0] stays set for nobody: the plain producer follows and the flush's own partition checks the window)
@@ -1524,6 +1639,7 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
         }
         // the host reads the flags on the second stream while the scatter kernel (which leaves at once when one
         // of them is set) already runs
+        hipLaunchKernelGGL(publish_block_k, dim3(1), dim3(64), 0, h->stream, (const unsigned long long *)d_maxlen, h->pin_scalar);
         HIPCK(h, hipEventRecord(h->aux_ev, h->stream));
         a.nruns_raw = 1;
         a.flags = flags;
@@ -1543,9 +1659,7 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
                 hipLaunchKernelGGL((esprun::run_scatter_k<false, false>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
             sp.add(1);
         }
-        HIPCK(h, hipStreamWaitEvent(h->aux, h->aux_ev, 0));
-        HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_maxlen, 64, hipMemcpyDeviceToHost, h->aux));
-        HIPCK(h, hipStreamSynchronize(h->aux));
+        HIPCK(h, hipEventSynchronize(h->aux_ev));  // (publish_block_k has written the block to pin_scalar)
         const u32 f_err = (u32)h->pin_scalar[6], f_over = (u32)(h->pin_scalar[6] >> 32), f_many = (u32)(h->pin_scalar[7] >> 32);
         if (f_over) {
             *ok = false;
@@ -2783,6 +2897,7 @@ extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t s
     // returns while the entries are still being moved -- the caller's consensus round runs beside the scatter
     // kernel; esp_synchronize() before the key/value arrays are read.
     hipStream_t qs = (E > 0 && h->last_run_order == 1) ? h->aux : h->stream;
+    if (qs == h->aux) HIPCK(h, hipStreamWaitEvent(h->aux, h->aux_ev, 0));  // (recorded right behind the ranking kernel)
     hipLaunchKernelGGL(diff_counts_k, dim3(grid_for(NB, 256)), dim3(256), 0, qs, (const i64 *)bstart, NB, cnt);
     // owner ranges = bucket starts at every multiple of nb
     i64 *d_off = (i64 *)(T + 64 * 8);

@@ -233,8 +233,21 @@ class SparseMatrixHIPCOO:
         self._d.push(ESP_SET, float(v), int(ij[0]), int(ij[1]))
 
     def __getitem__(self, ij):
-        raise RuntimeError("getindex on pending device entries: flush! the matrix first "
-                           "(cf. genericmtextendablesparsematrixcsc.jl:80)")
+        """getindex(buffer,i,j) (sparsematrixlnk.jl:151-171): what the pending entries alone leave at (i,j) -- their
+        ordered fold on the device, 0.0 if no entry exists.  One pass over the pending keys per call (slow path)."""
+        i, j = int(ij[0]), int(ij[1])
+        if not (1 <= i <= self.m and 1 <= j <= self.n):
+            raise BoundsError("(%d,%d) outside %d x %d" % (i, j, self.m, self.n))
+        self._d.commit()
+        val, found = C.c_double(), C.c_int32()
+        self._d.ck(self._d.lib.esp_pending_getindex(self._d.h, i, j, C.byref(val), C.byref(found)))
+        return val.value
+
+    def release(self):
+        """Free the device and pinned memory of this buffer now (what the shim does with the buffer a Generic
+        wrapper drops after flush!: the garbage collector does not see device memory)."""
+        self._d._st, self._d._nst = None, 0
+        self._d.ck(self._d.lib.esp_release_buffers(self._d.h))
 
     def updateindex(self, op, v, i, j):  # updateindex!: sparsematrixlnk.jl:210-228
         v = float(v)
@@ -557,8 +570,9 @@ class GenericExtendableSparseMatrixCSC:
     def flush(self):  # :31-37
         if self.xmatrix.nnz() > 0:
             self.cscmatrix = self.xmatrix + self.cscmatrix
-            m, n = self.cscmatrix.shape
-            self.xmatrix = self.Tm(m, n, **self._kw)
+            # :34 `ext.xmatrix = Tm(m,n)`: the flushed buffer IS an empty T_ext(m,n) again -- it is kept (its device
+            # memory serves the next assembly; the Julia shim, which cannot change the wrapper, releases the dropped
+            # buffer's memory eagerly instead: esp_release_buffers)
         return self
 
     def sparse(self):  # :39-42
@@ -578,14 +592,11 @@ class GenericExtendableSparseMatrixCSC:
         else:
             self.xmatrix[ij] = v
 
-    def __getitem__(self, ij):  # :57-66 (pending entries: flush-then-lookup)
+    def __getitem__(self, ij):  # :57-66
         k = self.cscmatrix.findindex(*ij)
         if k > 0:
             return float(self.cscmatrix.nzval[k - 1])
-        if self.xmatrix.nnz() == 0:
-            return 0.0
-        self.flush()
-        return self.cscmatrix[ij]
+        return self.xmatrix[ij]   # getindex(ext.xmatrix,i,j): the buffer's own (device-side) lookup
 
     def rawupdateindex(self, op, v, i, j):  # :68-79
         k = self.cscmatrix.findindex(i, j)

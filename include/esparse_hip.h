@@ -95,6 +95,10 @@ int32_t esp_create(int64_t m, int64_t n, int32_t device, int64_t capacity_hint, 
 int32_t esp_destroy(esp_handle *h);
 /* Base.copy(ext) (extendable.jl:279-285): same CSC, same pending entries, same window; device-to-device */
 int32_t esp_clone(esp_handle *h, esp_handle **out);
+/* frees every device and pinned buffer of the handle NOW (the Generic wrappers drop their buffer after every flush!
+ * -- genericextendablesparsematrixcsc.jl:34 -- and Julia's GC does not see device memory); the handle stays valid:
+ * an empty matrix with an empty buffer.  Staging pointers from esp_stage_begin are invalid afterwards. */
+int32_t esp_release_buffers(esp_handle *h);
 const char *esp_last_error(const esp_handle *h);
 const char *esp_version(void);
 /* use an external HIP stream (hipStream_t) instead of the handle's own */
@@ -172,6 +176,11 @@ int32_t esp_zero_values(esp_handle *h);
 int32_t esp_dropzeros(esp_handle *h, int64_t *new_nnz);
 /* findindex(csc,i,j)+nzval[k] (sparsematrixcsc.jl:7-23) on the device CSC; found=0 if absent */
 int32_t esp_getindex(esp_handle *h, int64_t i, int64_t j, double *value, int32_t *found);
+/* getindex(buffer,i,j) (sparsematrixlnk.jl:151-171): the value the PENDING entries alone give (i,j) -- their ordered
+ * fold -- 0 and found=0 if none creates an entry.  Slow by design (one pass over the pending keys per call); what
+ * GenericExtendableSparseMatrixCSC's getindex falls back to for positions not yet in the CSC (genericext...:60-69).
+ * More than 2048 pending updates of one position -> ESP_ERR_UNSUPPORTED (flush first). */
+int32_t esp_pending_getindex(esp_handle *h, int64_t i, int64_t j, double *value, int32_t *found);
 /* stand-in for phash(csc) (sparsematrixcsc.jl:74): a 64-bit function of colptr/rowval only */
 int32_t esp_pattern_hash(esp_handle *h, uint64_t *hash);
 

@@ -268,9 +268,52 @@ def test_generic_wrapper_vs_oracle(esp, orc):
             else:
                 G.rawupdateindex("+", v, i, j)
                 O.rawupdateindex(orc.OP_ADD, v, i, j)
+        # getindex of pending positions = the buffer's own lookup (the ordered fold of the pending calls on the
+        # device, esp_pending_getindex), of stored ones = the CSC's (genericextendablesparsematrixcsc.jl:57-66)
+        for _ in range(40):
+            i, j = int(rng.integers(1, m + 1)), int(rng.integers(1, n + 1))
+            assert bits(np.array([G[i, j]])) == bits(np.array([O[i, j]])), (rnd, i, j)
         G.flush()
         O.flush()
         assert_csc_equal(G.arrays(), O.arrays(), "round %d" % rnd)
+
+
+def test_pending_getindex_and_release(esp, orc):
+    """getindex(buffer,i,j) on a large pending batch (also a bucket-ordered one: 4-byte keys are expanded first), the
+    `A[i,j] += v` idiom through it, bounds; esp_release_buffers leaves a valid empty buffer."""
+    n = 48
+    N = n ** 3
+    X = esp.SparseMatrixHIPCOO(N, N)
+    A = esp.ExtendableSparseMatrix(N, N)           # device generator into the buffer: X's API on the same handle
+    X._d = A._d
+    A.generate_fdrand(n, n, n, seed=3, rand_mode=1)
+    O = orc.fdrand(n, n, n, rand_mode=1, seed=3, style=orc.KIND_UPDATE)    # (flushed: the fold of the same calls)
+    rng = np.random.default_rng(8)
+    for _ in range(25):
+        l = int(rng.integers(1, N + 1))
+        for (i, j) in ((l, l), (l, min(N, l + 1)), (min(N, l + n), l), (l, max(1, l - 7 * n))):
+            assert bits(np.array([X[i, j]])) == bits(np.array([O[i, j]])), (i, j)
+    with pytest.raises((esp.BoundsError, IndexError)):
+        X[0, 1]
+    A.flush()
+    assert_csc_equal(hip_arrays(A), O.arrays())
+    # += through the buffer lookup on a small matrix (SET after a read of the pending value)
+    Y = esp.GenericExtendableSparseMatrixCSC(6, 7)
+    Oy = orc.ExtendableSparseMatrix(6, 7)
+    for t in range(200):
+        i, j, v = int(rng.integers(1, 7)), int(rng.integers(1, 8)), float(rng.standard_normal())
+        Y[i, j] = Y[i, j] + v
+        Oy.apply(np.array([orc.KIND_PLUSEQ], np.uint8), [i], [j], [v])
+    assert_csc_equal(Y.arrays(), Oy.arrays())
+    # release: memory gone, handle still a valid empty buffer
+    Z = esp.SparseMatrixHIPCOO(50, 60)
+    Z.append(UPDATE, [1, 2, 50], [3, 60, 1], [1.0, 2.0, 3.0])
+    assert Z.nnz() == 3
+    Z.release()
+    assert Z.nnz() == 0
+    Z.updateindex("+", 4.0, 7, 8)
+    C1 = Z + esp.SparseMatrixCSC(50, 60)
+    assert C1.nnz() == 1 and C1[7, 8] == 4.0
 
 
 def test_mt_wrapper_vs_oracle(esp, orc):
