@@ -81,6 +81,8 @@ SIGNATURES = {
     "esp_mul": (i32, [vp, vp, vp, i32]),
     "esp_mark_dirichlet": (i32, [vp, f64, vp, i32]),
     "esp_eliminate_dirichlet": (i32, [vp, vp, i32]),
+    "esp_jacobi_setup": (i32, [vp, vp, i32]),
+    "esp_ilu0_setup": (i32, [vp, vp, vp, i32]),
     "esp_shard_counts": (i32, [vp, i32, vp]),
     "esp_shard_export": (i32, [vp, i32, vp, vp, vp]),
     "esp_shard_exchange_begin": (i32, [vp, i32, i32, i64, i64, P(vp), P(vp), vp]),

@@ -2736,6 +2736,67 @@ extern "C" int32_t esp_eliminate_dirichlet(esp_handle *h, const uint8_t *marker,
     return dirichlet_call(h, const_cast<uint8_t *>(marker), on_device, false, 0.0);
 }
 
+// ---- set-up of the point preconditioners on the device CSC -------------------------------------
+// jacobi(A) (factorizations/jacobi.jl:5-12): invdiag[i] = one(Tv) / A[i,i]; getindex of a position that is not stored
+// gives zero, i.e. Inf.  ilu0(A) (factorizations/ilu0.jl:8-41): idiag[j] = index of the diagonal entry of column j in
+// rowval/nzval; xdiag: iteration j of the reference's loop first sets xdiag[j] = 1/nzval[idiag[j]] and then updates
+// xdiag[i] for rows i > j -- every such update is overwritten when iteration i sets xdiag[i] itself, so the loop leaves
+// xdiag[j] = 1/nzval[idiag[j]] (restated literally in oracle/esparse_oracle.c: orc_ilu0).  One thread per column.
+__global__ void diag_setup_k(espfold::Csc c, i64 n, double *__restrict__ inv, i64 *__restrict__ idiag, unsigned long long *__restrict__ missing) {
+    const i64 j = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const i64 pos = c.nnz > 0 ? espfold::csc_find(c, j, j) : -1;
+    if (idiag) {
+        idiag[j] = pos + 1;
+        if (pos < 0) atomicMin(missing, (unsigned long long)(j + 1));
+    }
+    inv[j] = 1.0 / (pos >= 0 ? c.nzval[pos] : 0.0);
+}
+static int32_t diag_setup(esp_handle *h, double *inv, int64_t *idiag, int32_t on_device, const char *what) {
+    if (!h || !inv) return ESP_ERR_INVALID;
+    if (h->m != h->n) FAIL(h, ESP_ERR_INVALID, "%s: the matrix must be square", what);
+    if (h->count != 0) FAIL(h, ESP_ERR_STATE, "%s: pending entries (flush first)", what);
+    (void)hipSetDevice(h->device);
+    if (!h->csc_valid) CK(init_empty_csc(h));
+    CK(fix_tail(h));
+    const i64 n = h->n;
+    if (n == 0) return ESP_OK;
+    double *d_inv = inv;
+    i64 *d_idiag = idiag;
+    if (!on_device) {
+        CK(ensure(h, h->mul_x, sizeof(double) * (size_t)n));
+        d_inv = (double *)h->mul_x.p;
+        if (idiag) {
+            CK(ensure(h, h->mul_r, sizeof(i64) * (size_t)n));
+            d_idiag = (i64 *)h->mul_r.p;
+        }
+    }
+    CK(ensure(h, h->misc, 256));
+    unsigned long long *d_missing = (unsigned long long *)h->misc.p + 20;
+    h->pin_scalar[0] = ~0ull;
+    HIPCK(h, hipMemcpyAsync(d_missing, h->pin_scalar, 8, hipMemcpyHostToDevice, h->stream));
+    espfold::Csc c{(const i64 *)h->colptr.p, (const i64 *)h->rowval.p, (double *)h->nzval.p, h->nnz};
+    hipLaunchKernelGGL(diag_setup_k, dim3(grid_for(n, 256)), dim3(256), 0, h->stream, c, n, d_inv, d_idiag, d_missing);
+    HIPCK(h, hipGetLastError());
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_missing, 8, hipMemcpyDeviceToHost, h->stream));
+    if (!on_device) {
+        HIPCK(h, hipMemcpyAsync(inv, d_inv, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+        if (idiag) HIPCK(h, hipMemcpyAsync(idiag, d_idiag, sizeof(i64) * (size_t)n, hipMemcpyDeviceToHost, h->stream));
+    }
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (idiag && h->pin_scalar[0] != ~0ull)
+        FAIL(h, ESP_ERR_INVALID, "%s: column %llu has no stored diagonal entry (the reference reads an undefined idiag there)", what,
+             (unsigned long long)h->pin_scalar[0]);
+    return ESP_OK;
+}
+extern "C" int32_t esp_jacobi_setup(esp_handle *h, double *invdiag, int32_t on_device) {
+    return diag_setup(h, invdiag, nullptr, on_device, "esp_jacobi_setup");
+}
+extern "C" int32_t esp_ilu0_setup(esp_handle *h, double *xdiag, int64_t *idiag, int32_t on_device) {
+    if (!idiag) return ESP_ERR_INVALID;
+    return diag_setup(h, xdiag, idiag, on_device, "esp_ilu0_setup");
+}
+
 // ---- partitioned exchange -------------------------------------------------------------------
 // The owner partition of esp_shard_exchange_begin and the first partition pass of the local flush are
 // ONE pass here: every rank partitions its pending entries by (owner, digit inside the owner's key

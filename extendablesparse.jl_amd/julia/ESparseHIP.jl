@@ -3,12 +3,14 @@
 # A maintainer of ExtendableSparse.jl adds this file next to src/matrix/sparsematrixlnk.jl and
 # `include`s it from src/ExtendableSparse.jl after line 32.  It plugs the device buffer into the
 # package's own extension slot (src/matrix/abstractsparsematrixextension.jl:6-14): nothing else in
-# the package changes.  NOT executed in the build container (no Julia there); kept short.
+# the package changes.
+# UNTESTED IN THE BUILD CONTAINER: there is no Julia there.  tests/test_julia_shim.py checks every `ccall` of this file
+# against include/esparse_hip.h (symbol, arity, pointer / scalar kind of every argument, return type).
 
 const libesparse = get(ENV, "ESPARSE_HIP_LIB", "libesparse_hip.so")
-const ESP_SET, ESP_UPDATE, ESP_RAWUPDATE = Int32(0), Int32(1), Int32(2)
-const ESP_FLUSH_PLUS = Int32(1)
-const ESP_CHUNK = 1 << 20
+const ESP_SET, ESP_UPDATE, ESP_RAWUPDATE, ESP_COO = Int32(0), Int32(1), Int32(2), Int32(3)
+const ESP_FLUSH_ROUTED, ESP_FLUSH_PLUS = Int32(0), Int32(1)
+const ESP_CHUNK = 1 << 16        # staged updates per ccall (pinned; allocated on the first push)
 
 function esp_check(h, rc::Int32)
     rc == 0 && return nothing
@@ -26,27 +28,38 @@ mutable struct SparseMatrixHIPCOO{Tv, Ti <: Integer} <: AbstractSparseMatrixExte
     m::Ti
     n::Ti
     handle::Ptr{Cvoid}
-    rows::Vector{Int64}      # views of the pinned staging chunk
+    rows::Vector{Int64}      # views of the pinned staging chunk (empty until the first push)
     cols::Vector{Int64}
     vals::Vector{Float64}
     kinds::Vector{UInt8}
     nstaged::Int
 end
 
-function SparseMatrixHIPCOO{Float64, Int64}(m, n; device = 0)
+function wrap_handle(m, n, h::Ptr{Cvoid})
+    x = SparseMatrixHIPCOO{Float64, Int64}(m, n, h, Int64[], Int64[], Float64[], UInt8[], 0)
+    finalizer(y -> (y.handle == C_NULL || ccall((:esp_destroy, libesparse), Int32, (Ptr{Cvoid},), y.handle); y.handle = C_NULL), x)
+end
+
+function SparseMatrixHIPCOO{Float64, Int64}(m, n; device = 0, capacity_hint = 0)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     esp_check(C_NULL, ccall((:esp_create, libesparse), Int32, (Int64, Int64, Int32, Int64, Ptr{Ptr{Cvoid}}),
-                            m, n, device, 0, h))
-    r, c, v, k, got = Ref{Ptr{Int64}}(), Ref{Ptr{Int64}}(), Ref{Ptr{Float64}}(), Ref{Ptr{UInt8}}(), Ref{Int64}()
-    esp_check(h[], ccall((:esp_stage_begin, libesparse), Int32,
-                         (Ptr{Cvoid}, Int64, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{UInt8}}, Ptr{Int64}),
-                         h[], ESP_CHUNK, r, c, v, k, got))
-    x = SparseMatrixHIPCOO{Float64, Int64}(m, n, h[], unsafe_wrap(Array, r[], got[]), unsafe_wrap(Array, c[], got[]),
-                                           unsafe_wrap(Array, v[], got[]), unsafe_wrap(Array, k[], got[]), 0)
-    finalizer(y -> ccall((:esp_destroy, libesparse), Int32, (Ptr{Cvoid},), y.handle), x)
+                            m, n, device, capacity_hint, h))
+    wrap_handle(m, n, h[])
 end
 
 Base.size(x::SparseMatrixHIPCOO) = (x.m, x.n)
+
+# the pinned staging chunk: asked for on the first update (a buffer that a Generic wrapper creates after every flush!
+# and never fills costs no pinned memory)
+function stage!(x::SparseMatrixHIPCOO)
+    r, c, v, k, got = Ref{Ptr{Int64}}(), Ref{Ptr{Int64}}(), Ref{Ptr{Float64}}(), Ref{Ptr{UInt8}}(), Ref{Int64}()
+    esp_check(x.handle, ccall((:esp_stage_begin, libesparse), Int32,
+                              (Ptr{Cvoid}, Int64, Ptr{Ptr{Int64}}, Ptr{Ptr{Int64}}, Ptr{Ptr{Float64}}, Ptr{Ptr{UInt8}}, Ptr{Int64}),
+                              x.handle, ESP_CHUNK, r, c, v, k, got))
+    x.rows, x.cols = unsafe_wrap(Array, r[], got[]), unsafe_wrap(Array, c[], got[])
+    x.vals, x.kinds = unsafe_wrap(Array, v[], got[]), unsafe_wrap(Array, k[], got[])
+    x
+end
 
 function commit!(x::SparseMatrixHIPCOO)
     x.nstaged == 0 && return x
@@ -57,9 +70,18 @@ end
 
 @inline function push_entry!(x::SparseMatrixHIPCOO, kind, v, i, j)
     (1 <= i <= x.m) & (1 <= j <= x.n) || throw(BoundsError(x, (i, j)))
+    isempty(x.rows) && stage!(x)
     k = (x.nstaged += 1)
     @inbounds x.rows[k] = i; @inbounds x.cols[k] = j; @inbounds x.vals[k] = v; @inbounds x.kinds[k] = kind
     k == length(x.rows) && commit!(x)
+    x
+end
+
+# free the device and pinned memory NOW: the GC does not see it, and the Generic wrappers drop a buffer per flush!
+function release!(x::SparseMatrixHIPCOO)
+    x.nstaged = 0
+    x.rows, x.cols, x.vals, x.kinds = Int64[], Int64[], Float64[], UInt8[]      # the chunk pointers die with the buffers
+    esp_check(x.handle, ccall((:esp_release_buffers, libesparse), Int32, (Ptr{Cvoid},), x.handle))
     x
 end
 
@@ -75,8 +97,16 @@ updateindex!(x::SparseMatrixHIPCOO, ::typeof(+), v, i, j) = push_entry!(x, ESP_U
 updateindex!(x::SparseMatrixHIPCOO, ::typeof(-), v, i, j) = push_entry!(x, ESP_UPDATE, -Float64(v), i, j)
 rawupdateindex!(x::SparseMatrixHIPCOO, ::typeof(+), v, i, j, tid = 1) = push_entry!(x, ESP_RAWUPDATE, Float64(v), i, j)
 rawupdateindex!(x::SparseMatrixHIPCOO, ::typeof(-), v, i, j, tid = 1) = push_entry!(x, ESP_RAWUPDATE, -Float64(v), i, j)
-# pending entries live on the device: the wrapper flushes before reading (cf. genericmt...jl:80)
-Base.getindex(x::SparseMatrixHIPCOO, i, j) = error("flush! the matrix before getindex on device-pending entries")
+
+# getindex(buffer,i,j) (sparsematrixlnk.jl:151-171; reached from genericextendablesparsematrixcsc.jl:57-66 for
+# positions not yet in the CSC): the ordered fold of the pending calls at (i,j), on the device.  Slow path by design.
+function Base.getindex(x::SparseMatrixHIPCOO, i::Integer, j::Integer)
+    commit!(x)
+    v, found = Ref{Float64}(0.0), Ref{Int32}(0)
+    esp_check(x.handle, ccall((:esp_pending_getindex, libesparse), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Int32}),
+                              x.handle, i, j, v, found))
+    v[]
+end
 
 """
 `ext + csc -> SparseMatrixCSC`: THE flush (replaces sparsematrixlnk.jl:294-383).
@@ -94,6 +124,9 @@ function Base.:+(x::SparseMatrixHIPCOO{Float64, Int64}, csc::SparseMatrixCSC{Flo
     rowval = Vector{Int64}(undef, z[])
     nzval = Vector{Float64}(undef, z[])
     esp_check(h, ccall((:esp_get_csc, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}), h, colptr, rowval, nzval))
+    # the wrapper replaces this buffer by a fresh T_ext(m,n) right after `+` (genericextendablesparsematrixcsc.jl:34):
+    # its device memory (pending buffers, scratch, the device copy of the CSC) goes now, not at some later GC
+    release!(x)
     SparseMatrixCSC{Float64, Int64}(x.m, x.n, colptr, rowval, nzval)
 end
 Base.:+(csc::SparseMatrixCSC, x::SparseMatrixHIPCOO) = x + csc
@@ -116,19 +149,28 @@ const MTHIPExtendableSparseMatrixCSC{Tv, Ti} = GenericMTExtendableSparseMatrixCS
 # (src/matrix/extendable.jl:10-25,159-272), but buffer AND CSC stay on the GPU between flushes; the
 # host copy is fetched on demand.  Every update goes to the device (no host findindex); esp_flush in
 # ROUTED mode applies updates of stored positions in call order (extendable.jl:164-166).
-const ESP_FLUSH_ROUTED = Int32(0)
 mutable struct HIPResidentSparseMatrixCSC{Tv, Ti <: Integer} <: AbstractExtendableSparseMatrixCSC{Tv, Ti}
     buf::SparseMatrixHIPCOO{Tv, Ti}                     # in the role of lnkmatrix (handle + staging chunk)
     cscmatrix::Union{SparseMatrixCSC{Tv, Ti}, Nothing}  # host copy, valid until the next update
     phash::UInt64
 end
-HIPResidentSparseMatrixCSC{Float64, Int64}(m, n) =
-    HIPResidentSparseMatrixCSC{Float64, Int64}(SparseMatrixHIPCOO{Float64, Int64}(m, n), spzeros(Float64, Int64, m, n), 0)
+HIPResidentSparseMatrixCSC{Float64, Int64}(m, n; kwargs...) =
+    HIPResidentSparseMatrixCSC{Float64, Int64}(SparseMatrixHIPCOO{Float64, Int64}(m, n; kwargs...), spzeros(Float64, Int64, m, n), 0)
 Base.size(A::HIPResidentSparseMatrixCSC) = size(A.buf)
 touch!(A::HIPResidentSparseMatrixCSC) = (A.cscmatrix = nothing; A)
 Base.setindex!(A::HIPResidentSparseMatrixCSC, v, i::Integer, j::Integer) = (setindex!(A.buf, v, i, j); touch!(A))
 updateindex!(A::HIPResidentSparseMatrixCSC, op, v, i, j) = (updateindex!(A.buf, op, v, i, j); touch!(A))
 rawupdateindex!(A::HIPResidentSparseMatrixCSC, op, v, i, j, part = 1) = (rawupdateindex!(A.buf, op, v, i, j); touch!(A))
+
+# ExtendableSparseMatrix(I, J, V[, m, n]) (extendable.jl:85-104) = sparse(I,J,V,m,n,+): the triplets go through the
+# device pipeline as COO entries (first value as it is, duplicates added in input order, numerical zeros kept)
+function HIPResidentSparseMatrixCSC(I::Vector{Int64}, J::Vector{Int64}, V::Vector{Float64}, m = maximum(I), n = maximum(J))
+    A = HIPResidentSparseMatrixCSC{Float64, Int64}(m, n; capacity_hint = length(I))
+    esp_check(A.buf.handle, ccall((:esp_append_host, libesparse), Int32,
+                                  (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Ptr{UInt8}, Int32, Int32, Int64),
+                                  A.buf.handle, I, J, V, C_NULL, ESP_COO, 0, length(I)))
+    flush!(touch!(A))
+end
 
 function flush!(A::HIPResidentSparseMatrixCSC)                       # extendable.jl:248-255
     commit!(A.buf)
@@ -143,6 +185,23 @@ function flush!(A::HIPResidentSparseMatrixCSC)                       # extendabl
     A
 end
 
+# getindex (extendable.jl:226-238): pending entries live on the device, so the lookup is flush! + findindex on the
+# device CSC (`A[i,j] += v` works; assembly loops should call updateindex!, which is bitwise the same update)
+function Base.getindex(A::HIPResidentSparseMatrixCSC, i::Integer, j::Integer)
+    flush!(A)
+    v, found = Ref{Float64}(0.0), Ref{Int32}(0)
+    esp_check(A.buf.handle, ccall((:esp_getindex, libesparse), Int32, (Ptr{Cvoid}, Int64, Int64, Ptr{Float64}, Ptr{Int32}),
+                                  A.buf.handle, i, j, v, found))
+    v[]
+end
+
+function SparseArrays.nnz(A::HIPResidentSparseMatrixCSC)                       # abstractextendablesparsematrixcsc.jl:80
+    flush!(A)
+    z = Ref{Int64}(0)
+    esp_check(A.buf.handle, ccall((:esp_nnz, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}), A.buf.handle, z))
+    z[]
+end
+
 function SparseArrays.sparse(A::HIPResidentSparseMatrixCSC{Float64, Int64})   # extendable.jl:258-261
     flush!(A)
     A.cscmatrix === nothing || return A.cscmatrix
@@ -152,6 +211,27 @@ function SparseArrays.sparse(A::HIPResidentSparseMatrixCSC{Float64, Int64})   # 
     colptr, rowval, nzval = Vector{Int64}(undef, n + 1), Vector{Int64}(undef, z[]), Vector{Float64}(undef, z[])
     esp_check(h, ccall((:esp_get_csc, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}), h, colptr, rowval, nzval))
     A.cscmatrix = SparseMatrixCSC{Float64, Int64}(m, n, colptr, rowval, nzval)
+end
+
+# dropzeros!(ext) (abstractextendablesparsematrixcsc.jl:282) and fdrand!'s zero!(A) = nonzeros(A) .= 0 (sprand.jl:82)
+function SparseArrays.dropzeros!(A::HIPResidentSparseMatrixCSC)
+    flush!(A)
+    z = Ref{Int64}(0)
+    esp_check(A.buf.handle, ccall((:esp_dropzeros, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}), A.buf.handle, z))
+    touch!(A)
+end
+function zero!(A::HIPResidentSparseMatrixCSC)
+    flush!(A)
+    esp_check(A.buf.handle, ccall((:esp_zero_values, libesparse), Int32, (Ptr{Cvoid},), A.buf.handle))
+    touch!(A)
+end
+
+# Base.copy(ext) (extendable.jl:279-285): CSC, pending entries and phash; device-to-device
+function Base.copy(A::HIPResidentSparseMatrixCSC{Float64, Int64})
+    commit!(A.buf)
+    h2 = Ref{Ptr{Cvoid}}(C_NULL)
+    esp_check(A.buf.handle, ccall((:esp_clone, libesparse), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), A.buf.handle, h2))
+    HIPResidentSparseMatrixCSC{Float64, Int64}(wrap_handle(A.buf.m, A.buf.n, h2[]), A.cscmatrix === nothing ? nothing : copy(A.cscmatrix), A.phash)
 end
 
 # consumers that never leave the GPU (SURVEY 8f): mul! sums every row in column order, like the column loop
@@ -171,8 +251,69 @@ function eliminate_dirichlet!(A::HIPResidentSparseMatrixCSC, marker::Vector{Bool
     esp_check(A.buf.handle, ccall((:esp_eliminate_dirichlet, libesparse), Int32, (Ptr{Cvoid}, Ptr{Bool}, Int32), A.buf.handle, marker, 0))
     touch!(A)
 end
+# set-up of the point preconditioners on the device CSC (factorizations/jacobi.jl:5-20, ilu0.jl:8-41)
+function jacobi_setup(A::HIPResidentSparseMatrixCSC{Float64, Int64})
+    flush!(A)
+    invdiag = Vector{Float64}(undef, size(A, 2))
+    esp_check(A.buf.handle, ccall((:esp_jacobi_setup, libesparse), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int32), A.buf.handle, invdiag, 0))
+    invdiag
+end
+function ilu0_setup(A::HIPResidentSparseMatrixCSC{Float64, Int64})
+    flush!(A)
+    n = size(A, 2)
+    xdiag, idiag = Vector{Float64}(undef, n), Vector{Int64}(undef, n)
+    esp_check(A.buf.handle, ccall((:esp_ilu0_setup, libesparse), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Int64}, Int32), A.buf.handle, xdiag, idiag, 0))
+    xdiag, idiag
+end
 function reset!(A::HIPResidentSparseMatrixCSC)                                 # extendable.jl:269-272 (phash kept)
     A.buf.nstaged = 0
     esp_check(A.buf.handle, ccall((:esp_reset, libesparse), Int32, (Ptr{Cvoid},), A.buf.handle))
     touch!(A)
+end
+
+# ------------------------------------------------------------------------------------------------
+# Column shards across the GPUs of a node, one Julia process per GPU (INTEGRATION.md section 3): what
+# GenericMTExtendableSparseMatrixCSC does with one buffer per thread (genericmt...jl:45-51,87-99), across processes.
+# `id` = esp_group_unique_id() made on rank 0 and broadcast by the host (MPI.Bcast!, Distributed).
+function esp_group_unique_id()
+    id = Vector{UInt8}(undef, 128)
+    esp_check(C_NULL, ccall((:esp_group_unique_id, libesparse), Int32, (Ptr{UInt8},), id))
+    id
+end
+mutable struct HIPShardedSparseMatrixCSC
+    A::HIPResidentSparseMatrixCSC{Float64, Int64}       # this rank's shard: append ANY (i,j) to it
+    group::Ptr{Cvoid}
+end
+function HIPShardedSparseMatrixCSC(m, n, nranks, rank, id::Vector{UInt8}; device = rank)
+    A = HIPResidentSparseMatrixCSC{Float64, Int64}(m, n; device = device)
+    g = Ref{Ptr{Cvoid}}(C_NULL)
+    esp_check(A.buf.handle, ccall((:esp_group_create, libesparse), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}, Ptr{Ptr{Cvoid}}),
+                                  A.buf.handle, nranks, rank, id, g))
+    S = HIPShardedSparseMatrixCSC(A, g[])
+    finalizer(s -> (s.group == C_NULL || ccall((:esp_group_destroy, libesparse), Int32, (Ptr{Cvoid},), s.group); s.group = C_NULL), S)
+end
+updateindex!(S::HIPShardedSparseMatrixCSC, op, v, i, j) = updateindex!(S.A, op, v, i, j)
+rawupdateindex!(S::HIPShardedSparseMatrixCSC, op, v, i, j, tid = 1) = rawupdateindex!(S.A, op, v, i, j)
+function flush!(S::HIPShardedSparseMatrixCSC)            # COLLECTIVE: all-to-all-v entry routing (RCCL) + local flush
+    commit!(S.A.buf)
+    z, changed = Ref{Int64}(0), Ref{Int32}(0)
+    esp_check(S.A.buf.handle, ccall((:esp_group_flush, libesparse), Int32, (Ptr{Cvoid}, Int32, Ptr{Int64}, Ptr{Int32}),
+                                    S.group, ESP_FLUSH_ROUTED, z, changed))
+    touch!(S.A)
+    S
+end
+function SparseArrays.nnz(S::HIPShardedSparseMatrixCSC)  # global nnz (collective on first use after a flush)
+    tot, before = Ref{Int64}(0), Ref{Int64}(0)
+    esp_check(S.A.buf.handle, ccall((:esp_group_nnz, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}), S.group, tot, before))
+    tot[]
+end
+# this rank's columns col_lo:col_hi of the global CSC: (col_lo, col_hi, colptr[col_lo:col_hi+1], rowval, nzval)
+function local_csc(S::HIPShardedSparseMatrixCSC)
+    lo, hi, z = Ref{Int64}(0), Ref{Int64}(0), Ref{Int64}(0)
+    esp_check(S.A.buf.handle, ccall((:esp_group_column_range, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}), S.group, lo, hi))
+    esp_check(S.A.buf.handle, ccall((:esp_nnz, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}), S.A.buf.handle, z))
+    colptr, rowval, nzval = Vector{Int64}(undef, hi[] - lo[] + 2), Vector{Int64}(undef, z[]), Vector{Float64}(undef, z[])
+    esp_check(S.A.buf.handle, ccall((:esp_group_get_csc, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}),
+                                    S.group, colptr, rowval, nzval))
+    lo[], hi[], colptr, rowval, nzval
 end

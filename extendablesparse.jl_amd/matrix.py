@@ -454,6 +454,21 @@ class ExtendableSparseMatrix:
         self._host = None
         return self
 
+    def jacobi(self):
+        """jacobi(A) (src/factorizations/jacobi.jl:5-12) on the device CSC: invdiag = 1 ./ diag(A)."""
+        self.flush()
+        out = np.empty(self.n, np.float64)
+        self._d.ck(self._d.lib.esp_jacobi_setup(self._d.h, _vp(out), 0))
+        return out
+
+    def ilu0(self):
+        """ilu0(A) (src/factorizations/ilu0.jl:8-41) on the device CSC: (xdiag, idiag)."""
+        self.flush()
+        xd = np.empty(self.n, np.float64)
+        idg = np.empty(self.n, np.int64)
+        self._d.ck(self._d.lib.esp_ilu0_setup(self._d.h, _vp(xd), _vp(idg), 0))
+        return xd, idg
+
     def __matmul__(self, x):  # A*x (genericmtextendablesparsematrixcsc.jl:119-121)
         return self.mul(x)
 

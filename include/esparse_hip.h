@@ -198,6 +198,15 @@ int32_t esp_mul(esp_handle *h, const double *x, double *r, int32_t on_device);
 int32_t esp_mark_dirichlet(esp_handle *h, double penalty, uint8_t *marker, int32_t on_device);
 int32_t esp_eliminate_dirichlet(esp_handle *h, const uint8_t *marker, int32_t on_device);
 
+/* set-up of the point preconditioners on the device CSC of a square matrix (pending entries -> ESP_ERR_STATE).
+ * esp_jacobi_setup = jacobi(A) (src/factorizations/jacobi.jl:5-12): invdiag[i] = 1 / A[i,i] (Inf where the diagonal
+ * is not stored: getindex gives zero).  esp_ilu0_setup = ilu0(A) (src/factorizations/ilu0.jl:8-41): idiag[j] = 1-based
+ * index of column j's diagonal entry in rowval/nzval, xdiag[j] = what the reference's loop leaves: 1 / nzval[idiag[j]]
+ * (its `xdiag[i] -= ...` updates of rows i > j are overwritten by iteration i); a column without a stored diagonal
+ * -> ESP_ERR_INVALID.  n entries each; on_device != 0: device pointers. */
+int32_t esp_jacobi_setup(esp_handle *h, double *invdiag, int32_t on_device);
+int32_t esp_ilu0_setup(esp_handle *h, double *xdiag, int64_t *idiag, int32_t on_device);
+
 /* ---- column-range shards (multi-GPU, one process per GPU) ------------------------
  * owner(col) = floor((col-1)*nshards/n).  esp_shard_counts: pending entries per owner.
  * esp_shard_export: stable partition of the pending entries by owner into the caller's

@@ -694,6 +694,48 @@ void orc_csc_eliminate_dirichlet(orc_csc *c, const uint8_t *marker) {
 /* LinearAlgebra.mul!(r, ext, x): abstractextendablesparsematrixcsc.jl:179-181 forwards to the CSC; the
  * loop is the one spelled out in genericmtextendablesparsematrixcsc.jl:124-143 (with the default
  * single partition the columns are visited in increasing order): r .= 0; r[rows[i]] += vals[i]*x[col]. */
+/* jacobi(A): src/factorizations/jacobi.jl:5-12 -- invdiag[i] = one(Tv) / A[i,i]; getindex of an absent position is zero */
+void orc_csc_jacobi(const orc_csc *c, double *invdiag) {
+    for (i64 i = 1; i <= c->n; i++) {
+        i64 k = (i <= c->m) ? orc_csc_findindex(c, i, i) : 0;
+        invdiag[i - 1] = 1.0 / (k > 0 ? c->nzval[k - 1] : 0.0);
+    }
+}
+/* ilu0(A): src/factorizations/ilu0.jl:8-41, statement for statement.  xdiag is `undef` in the reference: the
+ * `xdiag[i] -= ...` of iteration j works on memory that iteration i overwrites with `xdiag[i] = 1/nzval[idiag[i]]`
+ * before anything reads it (here the array starts as zeros; the result is the same).  Returns 0, or j (1-based) of the
+ * first column without a diagonal entry (the reference reads an undefined idiag[j] there). */
+i64 orc_csc_ilu0(const orc_csc *c, double *xdiag, i64 *idiag) {
+    const i64 n = c->n;
+    const i64 *colptr = c->colptr, *rowval = c->rowval;
+    const double *nzval = c->nzval;
+    for (i64 j = 1; j <= n; j++) {
+        idiag[j - 1] = 0;
+        for (i64 k = colptr[j - 1]; k <= colptr[j] - 1; k++) {
+            i64 i = rowval[k - 1];
+            if (i == j) {
+                idiag[j - 1] = k;
+                break;
+            }
+        }
+        if (idiag[j - 1] == 0) return j;
+    }
+    for (i64 j = 0; j < n; j++) xdiag[j] = 0.0;
+    for (i64 j = 1; j <= n; j++) {
+        xdiag[j - 1] = 1.0 / nzval[idiag[j - 1] - 1];
+        for (i64 k = idiag[j - 1] + 1; k <= colptr[j] - 1; k++) {
+            i64 i = rowval[k - 1];
+            for (i64 l = colptr[i - 1]; l <= colptr[i] - 1; l++) {
+                if (rowval[l - 1] == j) {
+                    xdiag[i - 1] -= nzval[l - 1] * xdiag[j - 1] * nzval[k - 1];
+                    break;
+                }
+            }
+        }
+    }
+    return 0;
+}
+
 void orc_csc_mul(const orc_csc *c, const double *x, double *r) {
     for (i64 i = 0; i < c->m; i++) r[i] = 0.0;
     for (i64 col = 1; col <= c->n; col++)

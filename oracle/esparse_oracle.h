@@ -55,6 +55,9 @@ i64 orc_csc_findindex(const orc_csc *, i64 i, i64 j);
 int orc_csc_pattern_equal(const orc_csc *, const orc_csc *);
 uint64_t orc_csc_pattern_hash(const orc_csc *);
 i64 orc_csc_dropzeros(orc_csc *);
+/* set-up of the point preconditioners: src/factorizations/jacobi.jl:5-12, ilu0.jl:8-41 */
+void orc_csc_jacobi(const orc_csc *, double *invdiag);
+i64 orc_csc_ilu0(const orc_csc *, double *xdiag, i64 *idiag);
 
 /* ---- SparseMatrixLNK (sparsematrixlnk.jl) */
 orc_lnk *orc_lnk_new(i64 m, i64 n);

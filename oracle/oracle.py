@@ -102,6 +102,8 @@ def lib():
     sig("orc_csc_pattern_equal", C.c_int, vp, vp)
     sig("orc_csc_pattern_hash", C.c_uint64, vp)
     sig("orc_csc_dropzeros", i64, vp)
+    sig("orc_csc_jacobi", None, vp, p_f64)
+    sig("orc_csc_ilu0", i64, vp, p_f64, p_i64)
     sig("orc_lnk_new", vp, i64, i64)
     sig("orc_lnk_from_csc", vp, vp)
     sig("orc_lnk_free", None, vp)
@@ -247,6 +249,19 @@ class CSC:
         r = np.empty(m, np.float64)
         lib().orc_csc_mul(self._h, _pf(x), _pf(r))
         return r
+
+    def jacobi(self):
+        out = np.empty(self.shape[1], np.float64)
+        lib().orc_csc_jacobi(self._h, _pf(out))
+        return out
+
+    def ilu0(self):
+        n = self.shape[1]
+        xd, idg = np.empty(n, np.float64), np.empty(n, np.int64)
+        bad = lib().orc_csc_ilu0(self._h, _pf(xd), _pi(idg))
+        if bad:
+            raise ValueError("column %d has no diagonal entry" % bad)
+        return xd, idg
 
     def __add__(self, lnk):  # csc + lnk  (sparsematrixlnk.jl:385)
         return lnk + self

@@ -1605,3 +1605,34 @@ def test_group_api_world1_rccl(esp, orc):
         assert A.nnz() == O.nnz() and A.column_range() == (1, N)
         c0, c1, cp, rv, nz = A.local_slice()
         assert_csc_equal((cp, rv, nz), O.arrays())
+
+
+def test_jacobi_and_ilu0_setup(esp, orc):
+    """set-up of the point preconditioners on the device CSC (jacobi.jl:5-12, ilu0.jl:8-41) == the
+    oracle's literal restatement, bit for bit; missing diagonal: Inf (Jacobi) / an error (ILU0: undefined idiag)."""
+    n = 40
+    N = n ** 3
+    A = esp.fdrand(n, n, n, rand_mode=1, seed=11)
+    O = orc.fdrand(n, n, n, rand_mode=1, seed=11, style=orc.KIND_UPDATE)
+    C0 = O.sparse()
+    assert np.array_equal(bits(A.jacobi()), bits(C0.jacobi()))
+    xd, idg = A.ilu0()
+    xo, io = C0.ilu0()
+    assert np.array_equal(bits(xd), bits(xo)) and np.array_equal(idg, io)
+    # device-resident outputs
+    import ctypes
+    import torch
+    tx = torch.empty(N, dtype=torch.float64, device="cuda")
+    ti = torch.empty(N, dtype=torch.int64, device="cuda")
+    d = A._d
+    d.ck(d.lib.esp_ilu0_setup(d.h, ctypes.c_void_p(tx.data_ptr()), ctypes.c_void_p(ti.data_ptr()), 1))
+    assert np.array_equal(bits(tx.cpu().numpy()), bits(xo)) and np.array_equal(ti.cpu().numpy(), io)
+    # rectangular -> error; a column without a diagonal entry
+    B = esp.ExtendableSparseMatrix(5, 5)
+    B.append(UPDATE, [1, 2, 4, 5, 1], [1, 2, 4, 5, 3], [2.0, 4.0, 8.0, 16.0, 1.0])
+    inv = B.jacobi()
+    assert list(inv[[0, 1, 3, 4]]) == [0.5, 0.25, 0.125, 0.0625] and np.isinf(inv[2])
+    with pytest.raises(esp.EspError):
+        B.ilu0()
+    with pytest.raises(esp.EspError):
+        esp.ExtendableSparseMatrix(4, 5).jacobi()

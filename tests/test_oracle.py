@@ -416,3 +416,31 @@ def test_uniform_is_splitmix64(orc):
     for seed, ctr in [(0, 0), (0x5EED0002, 12345), (2**63 + 5, 2**40)]:
         z = mix((seed + (ctr + 1) * 0x9E3779B97F4A7C15) & ((1 << 64) - 1))
         assert orc.uniform(seed, ctr) == (z >> 11) * 2.0 ** -53
+
+
+def test_jacobi_and_ilu0_setup_restatement(orc):
+    """jacobi.jl:5-12 and ilu0.jl:8-41: the literal loops give invdiag = 1 ./ diag(A) and, for ILU0, idiag = position of
+    the diagonal and xdiag = 1 ./ diag(A) as well (every `xdiag[i] -= ...` of an earlier column is overwritten)."""
+    import scipy.sparse as sp
+    rng = np.random.default_rng(5)
+    n = 40
+    M = sp.random(n, n, density=0.15, random_state=3, format="csc") + sp.diags(2.0 + rng.random(n))
+    M = sp.csc_matrix(M)
+    M.sort_indices()
+    C0 = orc.CSC(n, n, M.indptr + 1, M.indices + 1, M.data)
+    d = M.diagonal()
+    assert np.array_equal(C0.jacobi(), 1.0 / d)
+    xd, idg = C0.ilu0()
+    assert np.array_equal(xd, 1.0 / d)
+    cp, rv, nz = C0.arrays()
+    assert np.all(rv[idg - 1] == np.arange(1, n + 1)) and np.all((idg >= cp[:-1]) & (idg < cp[1:]))
+    # a matrix without a stored diagonal entry in column 3: Jacobi gives Inf there, ILU0 has no idiag
+    M2 = M.tolil()
+    M2[2, 2] = 0.0
+    M2 = sp.csc_matrix(M2)
+    M2.eliminate_zeros()
+    M2.sort_indices()
+    C2 = orc.CSC(n, n, M2.indptr + 1, M2.indices + 1, M2.data)
+    assert np.isinf(C2.jacobi()[2])
+    with pytest.raises(ValueError):
+        C2.ilu0()
