@@ -1952,21 +1952,25 @@ static int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn, const u64 *new_key, con
         return ESP_OK;
     }
     const i64 Zt = Z0 + Zn;
-    if (Z0 >= 0xFFFFFFF0ll) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_flush: CSC too large for the 32-bit column index");
     {
         Span sp(h, ESP_ST_COLPTR);
         sp.add(espscan::exclusive<u64, true>(h->stream, colend + c0, colend + c0, ccnt, colend + N1));
-        const i64 hn = Z0 + 1;  // column index of every stored entry
-        CK(ensure(h, h->heads, sizeof(u32) * (size_t)(hn + espscan::workspace_elems(hn))));
-        u32 *heads = (u32 *)h->heads.p;
-        HIPCK(h, hipMemsetAsync(heads, 0, sizeof(u32) * (size_t)hn, h->stream));
-        hipLaunchKernelGGL(espfold::col_heads_k, dim3(grid_for(ccnt - 1, 256)), dim3(256), 0, h->stream, (const i64 *)h->colptr.p, c0, ccnt - 1,
-                           heads);
-        sp.add(1 + espscan::exclusive<u32, true>(h->stream, heads, heads, hn, heads + hn));
     }
     CK(ensure(h, h->rowval2, sizeof(i64) * (size_t)Zt));
     CK(ensure(h, h->nzval2, sizeof(double) * (size_t)Zt));
-    {
+    if (h->force_path == 17) {
+        // (test hook: the merge-path join over a per-entry column array, kept as a second implementation of the same join)
+        if (Z0 >= 0xFFFFFFF0ll) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_flush: CSC too large for the 32-bit column index");
+        {
+            Span sp(h, ESP_ST_COLPTR);
+            const i64 hn = Z0 + 1;  // column index of every stored entry
+            CK(ensure(h, h->heads, sizeof(u32) * (size_t)(hn + espscan::workspace_elems(hn))));
+            u32 *heads = (u32 *)h->heads.p;
+            HIPCK(h, hipMemsetAsync(heads, 0, sizeof(u32) * (size_t)hn, h->stream));
+            hipLaunchKernelGGL(espfold::col_heads_k, dim3(grid_for(ccnt - 1, 256)), dim3(256), 0, h->stream, (const i64 *)h->colptr.p, c0, ccnt - 1,
+                               heads);
+            sp.add(1 + espscan::exclusive<u32, true>(h->stream, heads, heads, hn, heads + hn));
+        }
         Span sp(h, ESP_ST_MERGE);
         espmerge::Args a;
         a.old_col = (const u32 *)h->heads.p + 1;
@@ -1980,6 +1984,31 @@ static int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn, const u64 *new_key, con
         a.out_row = (i64 *)h->rowval2.p;
         a.out_val = (double *)h->nzval2.p;
         hipLaunchKernelGGL(espmerge::merge_k, dim3(grid_for(Zt, espmerge::TILE)), dim3(espmerge::THREADS), 0, h->stream, a);
+        sp.add(1);
+    } else {
+        // column-tiled join: every stored and every new entry finds its own place in its merged column.  The stored
+        // entries outside the flush's column range (a shard's window) keep their order: in front of the range they
+        // stay where they are, behind it they move up by Zn.
+        Span sp(h, ESP_ST_MERGE);
+        const i64 ncols = ccnt - 1;
+        if (windowed(h)) {
+            // (win_excl: nothing is stored outside the window)
+        } else if (c0 != 0 || ncols != h->n) {
+            FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (column range of the join)");
+        }
+        espmerge::ColArgs a;
+        a.old_colptr = (const i64 *)h->colptr.p;
+        a.old_row = (const i64 *)h->rowval.p;
+        a.old_val = (const double *)h->nzval.p;
+        a.newstart = (const u64 *)colend;
+        a.new_key = new_key;
+        a.new_val = new_val;
+        a.rb = h->L.rb;
+        a.c_begin = c0;
+        a.ncols = ncols;
+        a.out_row = (i64 *)h->rowval2.p;
+        a.out_val = (double *)h->nzval2.p;
+        hipLaunchKernelGGL(espmerge::colmerge_k, dim3(grid_for(ncols, espmerge::CT)), dim3(espmerge::THREADS), 0, h->stream, a);
         sp.add(1);
     }
     {

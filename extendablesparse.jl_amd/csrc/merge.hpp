@@ -103,4 +103,83 @@ __global__ __launch_bounds__(THREADS) void merge_k(Args a) {
     }
 }
 
+
+// ---- column-tiled join ------------------------------------------------------------------------------------
+// The same join without the per-entry column array (a scan over all stored entries) and without diagonal searches:
+// a workgroup takes CT consecutive columns; every stored entry and every new entry of those columns finds its own
+// place in the merged column: output index = own index + number of entries of the OTHER list in front of it
+//   stored entry p of column c :  p + newstart[c] + #{new entries of c with a smaller row}
+//   new entry q of column c    :  q + (colptr[c]-1) + #{stored entries of c with a smaller row}
+// (newstart[c] = new entries in the columns before c: the exclusive max-scan of the bucket kernel's column-end marks.)
+// The two lists of a column are disjoint (hits were folded into the stored values) and short, so the counts are
+// binary searches of a few steps in cached memory; consecutive lanes take consecutive entries and write nearly
+// consecutive places.  Reads 16 B per stored and per new entry + 16 B per column, writes 16 B per output entry.
+constexpr int CT = 256;
+struct ColArgs {
+    const i64 *old_colptr;  // 1-based values, n + 1
+    const i64 *old_row;     // 1-based
+    const double *old_val;
+    const u64 *newstart;    // n + 1
+    const u64 *new_key;     // (col0 << rb) | row0, increasing
+    const double *new_val;
+    int rb;
+    i64 c_begin, ncols;     // columns [c_begin, c_begin + ncols) hold every new entry
+    i64 *out_row;
+    double *out_val;
+};
+
+__global__ __launch_bounds__(THREADS) void colmerge_k(ColArgs a) {
+    __shared__ i64 s_cp[CT + 1];
+    __shared__ u64 s_ns[CT + 1];
+    const int t = threadIdx.x;
+    const i64 c0 = a.c_begin + (i64)blockIdx.x * CT;
+    const int nc = (int)min((i64)CT, a.c_begin + a.ncols - c0);
+    for (int q = t; q <= nc; q += THREADS) {
+        s_cp[q] = a.old_colptr[c0 + q] - 1;
+        s_ns[q] = a.newstart[c0 + q];
+    }
+    __syncthreads();
+    const i64 op0 = s_cp[0], op1 = s_cp[nc];
+    const i64 np0 = (i64)s_ns[0], np1 = (i64)s_ns[nc];
+    const u64 rowmask = (1ull << a.rb) - 1ull;
+    for (i64 p = op0 + t; p < op1; p += THREADS) {
+        int lo = 0, hi = nc;  // the column: largest c with s_cp[c] <= p
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_cp[mid] <= p)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const i64 row = a.old_row[p];
+        i64 b = (i64)s_ns[lo], e = (i64)s_ns[lo + 1];
+        while (b < e) {  // new entries of the column with a smaller row
+            const i64 mid = b + ((e - b) >> 1);
+            if ((i64)(a.new_key[mid] & rowmask) + 1 < row)
+                b = mid + 1;
+            else
+                e = mid;
+        }
+        const i64 out = p + b;  // = p + newstart[c] + count
+        a.out_row[out] = row;
+        a.out_val[out] = a.old_val[p];
+    }
+    for (i64 q = np0 + t; q < np1; q += THREADS) {
+        const u64 key = a.new_key[q];
+        const int lc = (int)((i64)(key >> a.rb) - c0);
+        const i64 row = (i64)(key & rowmask) + 1;
+        i64 b = s_cp[lc], e = s_cp[lc + 1];
+        while (b < e) {  // stored entries of the column with a smaller row
+            const i64 mid = b + ((e - b) >> 1);
+            if (a.old_row[mid] < row)
+                b = mid + 1;
+            else
+                e = mid;
+        }
+        const i64 out = q + b;  // = q + (colptr[c]-1) + count
+        a.out_row[out] = row;
+        a.out_val[out] = a.new_val[q];
+    }
+}
+
 }  // namespace espmerge

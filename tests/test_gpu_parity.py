@@ -465,13 +465,15 @@ def test_bucket_kernel_tiers(esp, orc, per_col):
         assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
 
 
-def test_reassembly_with_a_few_new_entries(esp, orc):
+@pytest.mark.parametrize("force", [0, 17])
+def test_reassembly_with_a_few_new_entries(esp, orc, force):
     """Re-assembly over the stored pattern: almost every segment of the bucket kernel emits nothing (and does
     not wait for its look-back chain); a handful of new positions far apart must still land at the right
-    offsets, across long stretches of such segments."""
+    offsets, across long stretches of such segments.  Join: column-tiled (0) / merge-path (17)."""
     n = 48
     N = n ** 3
     A = esp.ExtendableSparseMatrix(N, N)
+    A.debug_force_path(force)
     A.generate_fdrand(n, n, n, seed=41, rand_mode=1)
     A.flush()
     O = orc.fdrand(n, n, n, rand_mode=1, seed=41, style=orc.KIND_UPDATE)
@@ -1636,3 +1638,44 @@ def test_jacobi_and_ilu0_setup(esp, orc):
         B.ilu0()
     with pytest.raises(esp.EspError):
         esp.ExtendableSparseMatrix(4, 5).jacobi()
+
+
+@pytest.mark.parametrize("force", [0, 17])
+def test_join_dense_columns_empty_columns_and_rectangular(esp, orc, force):
+    """The join with an existing CSC on shapes that stress its column tiles: columns with thousands of stored and new
+    entries next to long runs of empty columns, new entries before / between / behind the stored rows of a column, a
+    wide rectangular matrix, PLUS mode (csc + buffer)."""
+    rng = np.random.default_rng(17)
+    for (m, n) in ((5000, 1000), (300, 70000), (2 ** 20, 513)):
+        A = esp.ExtendableSparseMatrix(m, n)
+        A.debug_force_path(force)
+        O = orc.ExtendableSparseMatrix(m, n)
+        for rnd in range(3):
+            cnt = 60000
+            heavy = rng.choice(n, 3, replace=False) + 1
+            J = np.where(rng.random(cnt) < 0.5, rng.choice(heavy, cnt), rng.integers(1, n + 1, cnt))
+            J[rng.random(cnt) < 0.3] = rng.integers(max(1, n // 2), min(n, n // 2 + 40) + 1, int((rng.random(cnt) < 0.3).sum()) or 1)[0]
+            I = rng.integers(1, m + 1, cnt)
+            V = rng.standard_normal(cnt)
+            kinds = rng.integers(0, 3, cnt).astype(np.uint8)
+            A.append(0, I, J, V, kinds=kinds)
+            O.apply(kinds, I, J, V)
+            A.flush()
+            O.flush()
+            assert_csc_equal(hip_arrays(A), O.arrays(), "%dx%d round %d" % (m, n, rnd))
+    # PLUS mode through the buffer type: csc + x
+    m, n = 700, 900
+    C0 = orc.ExtendableSparseMatrix(m, n)
+    I, J, V = rng.integers(1, m + 1, 9000), rng.integers(1, n + 1, 9000), rng.standard_normal(9000)
+    C0.apply(np.full(9000, RAW, np.uint8), I, J, V)
+    cp, rv, nz = C0.arrays()
+    X = esp.SparseMatrixHIPCOO(m, n)
+    X._d.lib.esp_debug_force_path(X._d.h, force)
+    L = orc.SparseMatrixLNK(m, n)
+    I2, J2, V2 = rng.integers(1, m + 1, 9000), rng.integers(1, n + 1, 9000), rng.standard_normal(9000)
+    X.append(UPDATE, I2, J2, V2)
+    for i, j, v in zip(I2, J2, V2):
+        L.updateindex(orc.OP_ADD, float(v), int(i), int(j))
+    got = X + esp.SparseMatrixCSC(m, n, cp, rv, nz)
+    want = L + orc.CSC(m, n, cp, rv, nz)
+    assert_csc_equal(got.arrays(), want.arrays())
