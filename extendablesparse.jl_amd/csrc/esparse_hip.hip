@@ -61,8 +61,20 @@ struct esp_handle {
         i64 E = 0, maxlen = 0;   // entries, longest bucket
         u64 base = 0, span = 0;  // the key window it was made for
         double Ee = 0.0;         // (plan_entries of the batch: spread bookkeeping)
+        // column shards: the batch was partitioned by (owner, digit inside the owner's column range) -- what
+        // esp_shard_partition produces; mw_P windows of mw_nb digits, digit width 2^mw_shift, plan made for mw_eps
+        int mw_P = 0, mw_me = 0, mw_shift = 0;
+        u32 mw_nb = 0;
+        i64 mw_eps = 0;
     } pre;
-    bool shard_user = false;     // the handle is driven through esp_shard_*: producers append in stream order
+    bool shard_user = false;     // the handle is driven through esp_shard_*: its flushes partition by owner first
+    int last_shard_source = 0;   // esp_shard_partition: 1 = its own pass moved the entries, 2 = the producer had
+    // esp_shard_plan: the producers that find the buffer empty partition for the next esp_shard_partition(P, me, eps)
+    struct ShardPlan {
+        bool valid = false;
+        int P = 0, me = 0;
+        i64 eps = 0;
+    } shard_plan;
     // column window of the pending entries (whole matrix by default)
     u64 win_base = 0, win_span = 0;
     // A shard works on its column range only.  When the window [wc0, wc1) (0-based columns) was
@@ -157,6 +169,10 @@ struct PartSetup {
     int K = 0, pb = 0, kind = -1;
     i64 E = 0, chunks = 0;
     double Ee = 0.0;
+    i64 NB = 0;            // buckets (1 << pb, or shards * digits per shard)
+    int mw_P = 0, mw_me = 0, mw_shift = 0;
+    u32 mw_nb = 0;
+    i64 mw_eps = 0;
     i64 *seg_out = nullptr, *runs_off = nullptr;
     const unsigned long long *bucket_count = nullptr;
     u64 *coarse = nullptr;
@@ -826,9 +842,11 @@ extern "C" int32_t esp_generate_fdrand_range(esp_handle *h, int64_t nx, int64_t 
         {
             Span sp(h, ESP_ST_APPEND);
             if (ps.out.k32)
-                hipLaunchKernelGGL(espgen::fdrand_part_k<true>, grid, block, 0, h->stream, a);
+                hipLaunchKernelGGL((espgen::fdrand_part_k<true, true>), grid, block, 0, h->stream, a);
+            else if (ps.out.s32)
+                hipLaunchKernelGGL((espgen::fdrand_part_k<true, false>), grid, block, 0, h->stream, a);
             else
-                hipLaunchKernelGGL(espgen::fdrand_part_k<false>, grid, block, 0, h->stream, a);
+                hipLaunchKernelGGL((espgen::fdrand_part_k<false, false>), grid, block, 0, h->stream, a);
             sp.add(1);
         }
         CK(prepart_finish(h, &ps, &took));
@@ -907,9 +925,11 @@ extern "C" int32_t esp_generate_fem(esp_handle *h, int32_t dim, int64_t npd, uin
         {
             Span sp(h, ESP_ST_APPEND);
             if (ps.out.k32)
-                hipLaunchKernelGGL(espgen::fem_part_k<true>, grid, block, 0, h->stream, a);
+                hipLaunchKernelGGL((espgen::fem_part_k<true, true>), grid, block, 0, h->stream, a);
+            else if (ps.out.s32)
+                hipLaunchKernelGGL((espgen::fem_part_k<true, false>), grid, block, 0, h->stream, a);
             else
-                hipLaunchKernelGGL(espgen::fem_part_k<false>, grid, block, 0, h->stream, a);
+                hipLaunchKernelGGL((espgen::fem_part_k<false, false>), grid, block, 0, h->stream, a);
             sp.add(1);
         }
         CK(prepart_finish(h, &ps, &took));
@@ -1420,6 +1440,40 @@ static int32_t aux_ready(esp_handle *h) {
     return ESP_OK;
 }
 
+// The plan of the partition by (owner, digit inside the owner's column range): every rank derives the same one from
+// (n, P, entries_per_shard).  ok = false: small or odd problem (the plain exchange serves it).
+static inline i64 shard_col0(i64 n, int P, int r) { return (i64)(((__int128)r * (__int128)n + P - 1) / P); }  // ceil(r*n/P)
+struct MwPlan {
+    bool ok = false;
+    int K = 0, shift = 0, pb = 0;
+    u64 nb64 = 0;
+    i64 NB = 0;
+    std::vector<u64> base;
+};
+static MwPlan shard_mw_plan(const esp_handle *h, int P, i64 entries_per_shard) {
+    MwPlan m;
+    m.base.resize((size_t)P);
+    u64 maxspan = 1;
+    for (int r = 0; r < P; r++) {
+        const i64 c0 = shard_col0(h->n, P, r), c1 = shard_col0(h->n, P, r + 1);
+        m.base[(size_t)r] = (u64)c0 << h->L.rb;
+        maxspan = std::max(maxspan, (u64)(c1 - c0) << h->L.rb);
+    }
+    int K = 1;
+    while (K < 62 && ((u64)1 << K) < maxspan) K++;
+    const int pbw = plan_run_bits(std::max<i64>(entries_per_shard, 1), K, maxspan);
+    if (pbw == 0 || K - pbw > esplocal::MAX_REM_BITS) return m;
+    m.K = K;
+    m.shift = K - pbw;
+    m.nb64 = ((maxspan - 1) >> m.shift) + 1;
+    m.NB = (i64)m.nb64 * P;
+    if (m.NB > ((i64)1 << 24)) return m;
+    m.pb = 1;
+    while (((i64)1 << m.pb) < m.NB) m.pb++;
+    m.ok = true;
+    return m;
+}
+
 // ---- producer-side partition: host side (the kernels: runpart.hpp "the append IS the partition") ----------
 // prepart_begin: a device-side producer is about to append E entries in `chunks` chunks (= its workgroups, at most
 // esprun::TILE entries each) -- kind >= 0: all of that kind.  ps->on = true when the append can be the partition:
@@ -1429,16 +1483,32 @@ static int32_t aux_ready(esp_handle *h) {
 static int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSetup *ps) {
     ps->on = false;
     memset(&ps->out, 0, sizeof ps->out);
-    if (h->count != 0 || h->shard_user || E <= esplocal::CAP || chunks >= ((i64)1 << 38)) return ESP_OK;
+    if (h->count != 0 || E <= esplocal::CAP || chunks >= ((i64)1 << 38)) return ESP_OK;
     if (h->force_path == 2 || h->force_path == 5 || h->force_path == 12 || h->force_path == 16) return ESP_OK;
     if (h->runs_skip > 0) return ESP_OK;  // (the handle's last streams were not pre-sorted: back-off, see sort_msd)
-    const int K = window_bits(h);
+    int K, pb, shift;
+    i64 NB;
     double Ee = 0.0;
-    const int planned = plan_prefix_bits(h, E, K, &Ee);
-    const int pb = planned;
-    const int shift = K - pb;
-    if (pb <= 8 || pb > 20 || shift < h->L.rb || shift > esplocal::MAX_REM_BITS) return ESP_OK;
-    const i64 NB = (i64)1 << pb;
+    MwPlan mw;
+    if (h->shard_user) {
+        // a shard: partition by (owner, digit inside the owner's column range) -- what the next esp_shard_partition
+        // would do in a pass of its own -- if the caller announced that call (esp_shard_plan)
+        if (!h->shard_plan.valid || h->force_path == 11) return ESP_OK;
+        const int P = h->shard_plan.P;
+        if (P > esprun::MW_MAX || P > esplocal::MAX_PIECES || (double)h->n * (double)P >= 9.0e18) return ESP_OK;
+        mw = shard_mw_plan(h, P, h->shard_plan.eps);
+        if (!mw.ok || mw.shift < h->L.rb) return ESP_OK;
+        K = mw.K, pb = mw.pb, shift = mw.shift, NB = mw.NB;
+        const size_t o_cnt = 256 * 8;  // (the table layout of esp_shard_partition: window bases | owner offsets | counts)
+        CK(ensure(h, h->parttab, o_cnt + sizeof(i64) * (size_t)(NB + 1)));
+        HIPCK(h, hipMemcpyAsync(h->parttab.p, mw.base.data(), sizeof(u64) * (size_t)P, hipMemcpyHostToDevice, h->stream));
+    } else {
+        K = window_bits(h);
+        pb = plan_prefix_bits(h, E, K, &Ee);
+        shift = K - pb;
+        if (pb <= 8 || pb > 20 || shift < h->L.rb || shift > esplocal::MAX_REM_BITS) return ESP_OK;
+        NB = (i64)1 << pb;
+    }
     ChunkArrays ca;
     CK(chunk_arrays(h, chunks + 64, pb, &ca));
     CK(ensure(h, h->runbuf, sizeof(i64) * (size_t)chunks * esprun::RMAX));
@@ -1457,6 +1527,14 @@ static int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSet
     ps->E = E;
     ps->chunks = chunks;
     ps->Ee = Ee;
+    ps->NB = NB;
+    if (mw.ok) {
+        ps->mw_P = h->shard_plan.P;
+        ps->mw_me = h->shard_plan.me;
+        ps->mw_shift = mw.shift;
+        ps->mw_nb = (u32)mw.nb64;
+        ps->mw_eps = h->shard_plan.eps;
+    }
     ps->seg_out = (i64 *)h->seg[1].p;
     ps->runs_off = (i64 *)h->runbuf.p;
     ps->bucket_count = ca.bucket_count;
@@ -1470,7 +1548,12 @@ static int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSet
     o.flags = flags;
     o.maxlen = d_maxlen;
     o.cap = esplocal::CAP;
-    o.k32 = (kind >= 0 && h->force_path != 14 && shift <= 32) ? 1 : 0;
+    // (a shard's ranges travel to other ranks as packed keys: 4-byte keys only without windows)
+    o.k32 = (!mw.ok && kind >= 0 && h->force_path != 14 && shift <= 32) ? 1 : 0;
+    o.s32 = shift <= 32 ? 1 : 0;
+    o.mw_P = mw.ok ? ps->mw_P : 0;
+    o.mw_nb = ps->mw_nb;
+    o.mw_base = (const u64 *)h->parttab.p;
     o.shift = shift;
     o.base = h->win_base;
     o.span = h->win_span;
@@ -1482,7 +1565,7 @@ static int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSet
 }
 // between the COUNT and the PART launch: bucket starts and run offsets (the two ranking launches of run_partition)
 static int32_t prepart_rank(esp_handle *h, PartSetup *ps) {
-    const i64 NB = (i64)1 << ps->pb;
+    const i64 NB = ps->NB;
     unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
     u32 *flags = (u32 *)h->misc.p + 60;
     {
@@ -1524,6 +1607,11 @@ static int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took) {
     pp.base = h->win_base;
     pp.span = h->win_span;
     pp.Ee = ps->Ee;
+    pp.mw_P = ps->mw_P;
+    pp.mw_me = ps->mw_me;
+    pp.mw_shift = ps->mw_shift;
+    pp.mw_nb = ps->mw_nb;
+    pp.mw_eps = ps->mw_eps;
     *took = true;  // (the caller sets pre.valid once the entries are counted in)
     return ESP_OK;
 }
@@ -2262,7 +2350,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
     if (h->ones_pending && windowed(h)) CK(fix_tail(h));  // (cannot happen: a window is declared through fix_tail)
     if (h->pre.valid) {  // the producer's partition serves this flush if nothing changed since
         const esp_handle::PrePart &pp = h->pre;
-        const bool usable = use_local && !h->part_assembled && pp.E == E && pp.base == h->win_base && pp.span == h->win_span &&
+        const bool usable = use_local && !h->part_assembled && pp.mw_P == 0 && pp.E == E && pp.base == h->win_base && pp.span == h->win_span &&
                             pp.maxlen <= (i64)esplocal::CAP && pp.K - pp.pb <= esplocal::MAX_REM_BITS;
         if (!usable) CK(pending_materialize(h));
     }
@@ -2834,8 +2922,6 @@ extern "C" int32_t esp_ilu0_setup(esp_handle *h, double *xdiag, int64_t *idiag, 
 // of one piece per source rank (rank order, source order inside: the same deterministic order as one
 // buffer fed the ranks' streams in turn).  Nothing is moved a second time and the own range is
 // never copied.
-static inline i64 shard_col0(i64 n, int P, int r) { return (i64)(((__int128)r * (__int128)n + P - 1) / P); }  // ceil(r*n/P)
-
 __global__ void gather_stride_k(const i64 *__restrict__ src, i64 stride, int count, i64 *__restrict__ dst) {
     const int i = threadIdx.x;
     if (i < count) dst[i] = src[(size_t)i * (size_t)stride];
@@ -2920,6 +3006,21 @@ __global__ void piece_totals_k(const i64 *__restrict__ pstart, int P, i64 nb, un
     if ((threadIdx.x & 63) == 0 && tot > 0) atomicMax(maxlen, (unsigned long long)tot);
 }
 
+extern "C" int32_t esp_shard_plan(esp_handle *h, int32_t nshards, int32_t self, int64_t entries_per_shard) {
+    if (!h) return ESP_ERR_INVALID;
+    h->shard_user = true;
+    h->shard_plan.valid = nshards >= 1 && self >= 0 && self < nshards && entries_per_shard >= 0;
+    h->shard_plan.P = nshards;
+    h->shard_plan.me = self;
+    h->shard_plan.eps = entries_per_shard;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_last_shard_source(const esp_handle *h, int32_t *kind) {
+    if (!h || !kind) return ESP_ERR_INVALID;
+    *kind = h->last_shard_source;
+    return ESP_OK;
+}
+
 extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t self, int64_t entries_per_shard, int32_t *ok,
                                        uint64_t **d_keys, double **d_vals, int64_t **d_counts, int64_t *entry_offsets,
                                        int64_t *digits_per_shard) {
@@ -2929,31 +3030,27 @@ extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t s
     if (P < 1 || self < 0 || self >= P || entries_per_shard < 0) FAIL(h, ESP_ERR_INVALID, "esp_shard_partition: arguments");
     (void)hipSetDevice(h->device);
     h->shard_user = true;
-    CK(pending_materialize(h));
+    const i64 E = h->count;
+    // the producer already partitioned this very batch for this very call (esp_shard_plan): nothing to move
+    const bool from_producer = h->pre.valid && h->pre.mw_P == nshards && h->pre.mw_me == self && h->pre.mw_eps == entries_per_shard &&
+                               h->pre.E == E && h->pre.key_bytes == 8 && h->force_path != 11;
+    if (!from_producer) CK(pending_materialize(h));
+    h->pre.valid = false;
+    h->last_shard_source = 0;
     h->part_valid = h->part_assembled = false;
     h->part_own_update = h->kind_uniform == ESP_UPDATE && h->kind_noted == h->count;
     if (P > esprun::MW_MAX || P > esplocal::MAX_PIECES || h->force_path == 11) return ESP_OK;  // caller uses the plain exchange
     if ((double)h->n * (double)P >= 9.0e18) FAIL(h, ESP_ERR_UNSUPPORTED, "shards: n*nshards overflows");
-    const i64 E = h->count;
     if (E >= 0xFFFFFFF0ll) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_shard_partition: too many pending entries");
     // every rank derives the same plan from (n, P, entries_per_shard)
-    std::vector<u64> base((size_t)P);
-    u64 maxspan = 1;
-    for (int r = 0; r < P; r++) {
-        const i64 c0 = shard_col0(h->n, P, r), c1 = shard_col0(h->n, P, r + 1);
-        base[(size_t)r] = (u64)c0 << h->L.rb;
-        maxspan = std::max(maxspan, (u64)(c1 - c0) << h->L.rb);
-    }
-    int K = 1;
-    while (K < 62 && ((u64)1 << K) < maxspan) K++;
-    const int pbw = plan_run_bits(std::max<i64>(entries_per_shard, 1), K, maxspan);
-    if (pbw == 0 || K - pbw > esplocal::MAX_REM_BITS) return ESP_OK;  // small or odd problem: plain exchange
-    const int shift = K - pbw;
-    const u64 nb64 = ((maxspan - 1) >> shift) + 1;
-    const i64 NB = (i64)nb64 * P;
-    if (NB > ((i64)1 << 24)) return ESP_OK;
-    int pb = 1;
-    while (((i64)1 << pb) < NB) pb++;
+    const MwPlan plan = shard_mw_plan(h, P, entries_per_shard);
+    if (!plan.ok) return ESP_OK;  // small or odd problem: plain exchange
+    const std::vector<u64> &base = plan.base;
+    const int K = plan.K, shift = plan.shift, pb = plan.pb;
+    const u64 nb64 = plan.nb64;
+    const i64 NB = plan.NB;
+    if (from_producer && (h->pre.mw_shift != shift || h->pre.mw_nb != (u32)nb64))
+        FAIL(h, ESP_ERR_STATE, "esp_shard_partition: internal error (the producer's plan differs)");
     // tables: bases (<= 64 u64) | owner offsets (<= 65 i64) | counts (NB i64)
     const size_t o_cnt = 256 * 8;
     CK(ensure(h, h->parttab, o_cnt + sizeof(i64) * (size_t)(NB + 1)));
@@ -2964,7 +3061,12 @@ extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t s
     CK(ensure(h, h->tilef[1], sizeof(u64) * (size_t)(NB + 1 + espscan::workspace_elems(NB + 1))));
     i64 *bstart = (i64 *)h->seg[1].p;
     std::vector<i64> off((size_t)P + 1, 0);
-    if (E > 0) {
+    if (from_producer) {
+        h->last_shard_source = 2;  // (bucket starts in seg[1], entries in place: the PART launch wrote them)
+        h->last_run_order = 0;
+        h->shard_valid = false;
+    } else if (E > 0) {
+        h->last_shard_source = 1;
         CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
         CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
         CK(ensure(h, h->misc, 256));

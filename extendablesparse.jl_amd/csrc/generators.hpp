@@ -211,10 +211,10 @@ __device__ __forceinline__ void fd_items(const FdArgs &a, i64 g, FdItems &it, u3
     it.wt[1] = 2u * (u32)it.px;
     it.wt[2] = 2u * (u32)it.py;
     it.wt[3] = 2u * (u32)it.pz;
-    it.dig[0] = esprun::column_digit(g, a.L.rb, p.base, p.span, p.shift, err);
-    if (it.px) it.dig[1] = esprun::column_digit(g + 1, a.L.rb, p.base, p.span, p.shift, err);
-    if (it.py) it.dig[2] = esprun::column_digit(g + a.nx, a.L.rb, p.base, p.span, p.shift, err);
-    if (it.pz) it.dig[3] = esprun::column_digit(g + a.nx * a.ny, a.L.rb, p.base, p.span, p.shift, err);
+    it.dig[0] = esprun::column_digit(p, g, a.L.rb, err);
+    if (it.px) it.dig[1] = esprun::column_digit(p, g + 1, a.L.rb, err);
+    if (it.py) it.dig[2] = esprun::column_digit(p, g + a.nx, a.L.rb, err);
+    if (it.pz) it.dig[3] = esprun::column_digit(p, g + a.nx * a.ny, a.L.rb, err);
 }
 
 // COUNT launch of the stencil producer: no update is formed.  Same chunks (workgroups of 256 nodes) as the PART launch.
@@ -237,27 +237,27 @@ __global__ __launch_bounds__(THREADS) void fd_count_k(FdArgs a, esprun::RunSink 
 
 // PART launch: every update goes straight to its bucket -- the flush needs no partition pass.  The workgroup's updates
 // are staged in LDS run by run (esprun::tile_slots: a node's updates for one column lie together, in call order) and
-// every run is copied to `run offset` with consecutive stores.  K32: 4-byte keys (the bits below the bucket prefix;
-// 12 B per update, 46 KiB of LDS: 3 workgroups per CU); else packed keys.
-template <bool K32>
+// every run is copied to `run offset` with consecutive stores.  S32: the staging area holds the low 32 bits of a key
+// (46 KiB of LDS: 3 workgroups per CU; buckets narrower than 2^32 keys), OUT32: 4-byte keys go out (12 B per update).
+template <bool S32, bool OUT32>
 __global__ __launch_bounds__(THREADS) void fdrand_part_k(FdArgs a) {
-    typedef typename std::conditional<K32, u32, u64>::type KT;
+    static_assert(S32 || !OUT32, "4-byte keys come from a 4-byte staging area");
+    typedef typename std::conditional<S32, u32, u64>::type KT;
     __shared__ KT lk[THREADS * FD_MAX_PER_NODE];
     __shared__ double lv[THREADS * FD_MAX_PER_NODE];
     __shared__ esprun::TileLds<THREADS / ESP_WAVE> S;
     const esprun::PartOut &p = a.part;
-    if (K32 && *p.maxlen > (unsigned long long)p.cap) return;  // (uniform; the host issues the plain producer instead)
+    if (OUT32 && *p.maxlen > (unsigned long long)p.cap) return;  // (uniform; the host issues the plain producer instead)
     const i64 g = a.g_begin + (i64)blockIdx.x * THREADS + threadIdx.x;
     FdItems it;
     fd_items(a, g, it, nullptr);  // (the COUNT launch checked the window)
     u32 slot[4];
     int total;
     if (!esprun::tile_slots<4, THREADS / ESP_WAVE>(p, p.chunk_base + blockIdx.x, it.dig, it.wt, slot, S, &total)) return;
-    const u32 kmask = p.shift >= 32 ? 0xFFFFFFFFu : ((1u << p.shift) - 1u);
     auto put = [&](u32 at, double v, i64 row, i64 col) {
         const u64 kp = ((u64)(col - 1) << a.L.rb) | (u64)(row - 1);
-        if constexpr (K32)
-            lk[at] = (u32)(kp - p.base) & kmask;
+        if constexpr (S32)
+            lk[at] = (u32)kp;
         else
             lk[at] = (kp << ESP_TAG_BITS) | (u64)a.kind;
         lv[at] = v;
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(THREADS) void fdrand_part_k(FdArgs a) {
         if (it.bz) put(own++, fd_rand(a.rand_mode, a.seed, c + 5) * a.hx * a.hy, l, l);
     }
     __syncthreads();
-    esprun::copy_out_runs<KT, THREADS>(p, lk, lv, total, S.lstart, S.roff);
+    esprun::copy_out_runs<KT, OUT32, THREADS, THREADS / ESP_WAVE>(p, lk, lv, total, S, (u32)a.kind);
 }
 
 // ---- P1 FEM stream (test/femtools.jl:45-72) on a Kuhn-triangulated tensor grid --------
@@ -419,10 +419,9 @@ __device__ __forceinline__ void fem_stage(const FemArgs &a, KT *lk, double *lv, 
             }
         }
     int o = o0;
-    const u32 kmask = a.part.shift >= 32 ? 0xFFFFFFFFu : ((1u << a.part.shift) - 1u);
     auto put = [&](int at, i64 row, i64 col, double v) {
         if constexpr (sizeof(KT) == 4)
-            lk[at] = (u32)((((u64)(col - 1) << a.L.rb) | (u64)(row - 1)) - a.part.base) & kmask;
+            lk[at] = (u32)(((u64)(col - 1) << a.L.rb) | (u64)(row - 1));  // (low 32 bits: see esprun::copy_out_runs)
         else
             lk[at] = esp_pack(a.L, row, col, ESP_RAWUPDATE);
         lv[at] = v;
@@ -467,7 +466,7 @@ __device__ __forceinline__ void fem_items(const FemArgs &a, i64 pos, u32 (&dig)[
     for (int k = 0; k < 4; k++)
         if (k <= a.dim) {
             wt[k] = (u32)(a.dim + 2);
-            dig[k] = esprun::column_digit(nodes[k] - 1, a.L.rb, a.part.base, a.part.span, a.part.shift, err);
+            dig[k] = esprun::column_digit(a.part, nodes[k] - 1, a.L.rb, err);
         }
 }
 
@@ -490,14 +489,14 @@ __global__ __launch_bounds__(FEM_CELLS) void fem_count_k(FemArgs a, esprun::RunS
 
 // PART launch of the FEM producer (see fdrand_part_k): the updates of a cell for vertex column jl lie together, in
 // call order: row il's term at il (+1 from the diagonal's row on: the mass term comes right before the diagonal)
-template <bool K32>
+template <bool S32, bool OUT32>
 __global__ __launch_bounds__(FEM_CELLS) void fem_part_k(FemArgs a) {
-    typedef typename std::conditional<K32, u32, u64>::type KT;
+    typedef typename std::conditional<S32, u32, u64>::type KT;
     __shared__ KT lk[FEM_CELLS * FEM_MAX_PER_CELL];
     __shared__ double lv[FEM_CELLS * FEM_MAX_PER_CELL];
     __shared__ esprun::TileLds<FEM_CELLS / ESP_WAVE> S;
     const esprun::PartOut &p = a.part;
-    if (K32 && *p.maxlen > (unsigned long long)p.cap) return;
+    if (OUT32 && *p.maxlen > (unsigned long long)p.cap) return;
     const i64 pos = (i64)blockIdx.x * FEM_CELLS + threadIdx.x;
     u32 dig[4], wt[4], slot[4];
     fem_items(a, pos, dig, wt, nullptr);
@@ -505,7 +504,7 @@ __global__ __launch_bounds__(FEM_CELLS) void fem_part_k(FemArgs a) {
     if (!esprun::tile_slots<4, FEM_CELLS / ESP_WAVE>(p, p.chunk_base + blockIdx.x, dig, wt, slot, S, &total)) return;
     fem_stage(a, lk, lv, 0, slot, pos);
     __syncthreads();
-    esprun::copy_out_runs<KT, FEM_CELLS>(p, lk, lv, total, S.lstart, S.roff);
+    esprun::copy_out_runs<KT, OUT32, FEM_CELLS, FEM_CELLS / ESP_WAVE>(p, lk, lv, total, S, (u32)ESP_RAWUPDATE);
 }
 
 }  // namespace espgen

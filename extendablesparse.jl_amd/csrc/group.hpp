@@ -291,10 +291,14 @@ static int32_t group_exchange_partitioned(esp_group *g, bool *done) {
         g->part_penalty = std::min(16, 2 * g->part_penalty + 1);
         g->part_skip = g->part_penalty;
         g->eps = -1;
+        (void)esp_shard_plan(h, P, me, -1);
         return ESP_OK;
     }
     g->part_penalty = 0;
     g->eps = total ? (total + P - 1) / P : -1;
+    // the producers of the NEXT assembly partition for the next flush's esp_shard_partition themselves (the append is
+    // the partition, as on one GPU): every rank knows the same entries-per-shard from this flush's all-gather
+    (void)esp_shard_plan(h, P, me, g->eps);
     std::vector<i64> in_x((size_t)P, 0), out_x((size_t)P, 0), ro((size_t)P + 1, 0);
     i64 sent = 0;
     for (int r = 0; r < P; r++) {

@@ -567,13 +567,19 @@ struct PartOut {
                            // or [3] (too many runs of a digit) is set: the host then runs the plain producer
     const unsigned long long *maxlen;  // longest bucket (run_rank_k)
     i64 cap;               // a K32 launch leaves without a store when *maxlen > cap (the host applies the same rule)
-    int k32;               // the batch has one known kind and <= 32 key bits lie below the prefix: the K32 kernels
-                           // stage and store 4-byte keys = the bits below the prefix
+    int k32;               // the batch has one known kind and <= 32 key bits lie below the prefix: 4-byte keys (the
+                           // bits below the prefix) go out
+    int s32;               // <= 32 key bits lie below the prefix: the staging area holds 4 bytes per key
     int shift;             // digit = ((key >> 2) - base) >> shift
     u64 base, span;
     u64 *keys_out;
     double *vals_out;
     i64 chunk_base;        // chunk index of the launch's first workgroup
+    // several key windows side by side (column shards: window r = owner r's column range, see Args::mw_*): global digit
+    // = r * mw_nb + digit inside window r; mw_P == 0: the one window [base, base + span)
+    int mw_P;
+    u32 mw_nb;
+    const u64 *mw_base;    // first key of every window, ascending
 };
 
 // LDS tables of one producer workgroup (tile = chunk)
@@ -582,6 +588,7 @@ struct TileLds {
     u32 cnt[NWAVES][RMAX];  // entries of wave w in run j of the tile
     i64 roff[RMAX];         // global offset of run j (run_rank_k)
     u32 lstart[RMAX + 1];   // first LDS slot of run j: the tile is staged run by run
+    u64 rbase[RMAX];        // first key of run j's bucket (window base + digit << shift)
 };
 
 // Where a thread's entries go inside the tile's LDS staging area.  A thread (a stencil node, a FEM cell) holds NQ
@@ -648,6 +655,16 @@ __device__ __forceinline__ bool tile_slots(const PartOut &p, i64 chunk, const u3
         S.lstart[lane] = lst;
         if (lane == 63) S.lstart[RMAX] = inc;
         S.roff[lane] = lane < nr ? p.runs_off[chunk * RMAX + lane] : 0;
+        u64 rb = 0;
+        if (lane < nr) {
+            if (p.mw_P) {
+                const u32 r = my_run_digit / p.mw_nb;
+                rb = p.mw_base[r] + ((u64)(my_run_digit - r * p.mw_nb) << p.shift);
+            } else {
+                rb = p.base + ((u64)my_run_digit << p.shift);
+            }
+        }
+        S.rbase[lane] = rb;
     }
 #pragma unroll
     for (int q = 0; q < NQ; q++) slot[q] = (u32)__shfl((int)sb, (int)jq[q], ESP_WAVE) + pq[q];
@@ -657,28 +674,53 @@ __device__ __forceinline__ bool tile_slots(const PartOut &p, i64 chunk, const u3
 
 // staged tile (run by run, see tile_slots) -> its runs' places in the buffer; consecutive threads store consecutive
 // entries of a run.  A barrier lies between the last staging store and this call.
-template <typename KT, int NT>
-__device__ __forceinline__ void copy_out_runs(const PartOut &p, const KT *lk, const double *lv, int total, const u32 *lstart,
-                                              const i64 *roff) {
-    KT *gk = reinterpret_cast<KT *>(p.keys_out);
+// KT = u32: the staging area holds the LOW 32 bits of every (col,row) key -- the keys of a bucket span less than 2^32
+// (shift <= 32), so key - first key of the bucket = (low bits - low bits of that first key) mod 2^32: OUT32 stores that
+// difference (the 4-byte key the bucket kernel reads), else the packed key is put together again from it.
+// KT = u64: packed keys staged and stored as they are.
+template <typename KT, bool OUT32, int NT, int NWAVES>
+__device__ __forceinline__ void copy_out_runs(const PartOut &p, const KT *lk, const double *lv, int total, const TileLds<NWAVES> &S,
+                                              u32 kind) {
     int j = 0;
     for (int q = threadIdx.x; q < total; q += NT) {
-        while (q >= (int)lstart[j + 1]) j++;
-        const i64 dst = roff[j] + (i64)(q - (int)lstart[j]);
-        gk[dst] = lk[q];
+        while (q >= (int)S.lstart[j + 1]) j++;
+        const i64 dst = S.roff[j] + (i64)(q - (int)S.lstart[j]);
+        if constexpr (sizeof(KT) == 4) {
+            const u64 rb = S.rbase[j];
+            const u32 delta = (u32)lk[q] - (u32)rb;
+            if constexpr (OUT32)
+                reinterpret_cast<u32 *>(p.keys_out)[dst] = delta;
+            else
+                p.keys_out[dst] = ((rb + (u64)delta) << ESP_TAG_BITS) | (u64)kind;
+        } else {
+            p.keys_out[dst] = lk[q];
+        }
         p.vals_out[dst] = lv[q];
     }
 }
 
-// digit of a column for a count launch (the digit must not reach into the row bits: shift >= rb); columns outside
-// the key window raise *err
-__device__ __forceinline__ u32 column_digit(i64 col0, int rb, u64 base, u64 span, int shift, u32 *err) {
-    u64 kn = ((u64)col0 << rb) - base;
-    if (kn >= span) {
+// digit of a column for the producers' launches (the digit must not reach into the row bits: shift >= rb); columns
+// outside the key window raise *err.  Several windows: the window by binary search over their first keys (they cover
+// every column), then the digit inside it.
+__device__ __forceinline__ u32 column_digit(const PartOut &p, i64 col0, int rb, u32 *err) {
+    const u64 key = (u64)col0 << rb;
+    if (p.mw_P) {
+        int r = 0;
+#pragma unroll
+        for (int step = MW_MAX / 2; step; step >>= 1) {
+            const int c = r + step;
+            if (c < p.mw_P && key >= p.mw_base[c]) r = c;
+        }
+        u64 dl = (key - p.mw_base[r]) >> p.shift;
+        dl = dl < (u64)p.mw_nb ? dl : (u64)p.mw_nb - 1;
+        return (u32)r * p.mw_nb + (u32)dl;
+    }
+    u64 kn = key - p.base;
+    if (kn >= p.span) {
         if (err) *err = 1u;
         kn = 0;
     }
-    return (u32)(kn >> shift);
+    return (u32)(kn >> p.shift);
 }
 
 // 4-byte keys of a bucket-ordered pending buffer back to packed keys (any call that reads or extends the pending

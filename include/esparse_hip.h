@@ -249,6 +249,13 @@ int32_t esp_shard_exchange_place(esp_handle *h, int64_t position, const uint64_t
 int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t self, int64_t entries_per_shard,
                             int32_t *ok, uint64_t **d_keys, double **d_vals, int64_t **d_counts,
                             int64_t *entry_offsets /* nshards+1 */, int64_t *digits_per_shard);
+/* esp_shard_plan announces the next esp_shard_partition(nshards, self, entries_per_shard): a device-side producer
+ * (esp_generate_*) that finds the buffer empty then writes every entry straight to its (owner, digit) bucket -- the
+ * append is the partition, as on one GPU -- and that esp_shard_partition call, given exactly these arguments, has nothing
+ * left to move.  entries_per_shard < 0: no announcement.  esp_group_flush does this for the flush after it. */
+int32_t esp_shard_plan(esp_handle *h, int32_t nshards, int32_t self, int64_t entries_per_shard);
+/* 1: the last esp_shard_partition moved the entries in a pass of its own, 2: the producer had partitioned them, 0: neither */
+int32_t esp_debug_last_shard_source(const esp_handle *h, int32_t *kind);
 int32_t esp_shard_assemble(esp_handle *h, const uint64_t *const *d_recv_keys,
                            const double *const *d_recv_vals, const int64_t *const *d_recv_counts,
                            const int64_t *recv_entries /* nshards */, int32_t *ok);
