@@ -61,6 +61,12 @@ __device__ __forceinline__ double fd_rand(int mode, u64 seed, u64 ctr) {
     if (mode == 1) return 0.1 + esp_uniform(seed, ctr);
     return esp_uniform(seed, ctr);
 }
+// draw k (0..5) of a node whose draw 0 has z0 = seed + (6 g + 1) * golden: the same bits as fd_rand(mode, seed, 6 g + k)
+__device__ __forceinline__ double fd_rand_z(int mode, u64 z0, int k) {
+    if (mode == 0) return 1.0;
+    const double u = esp_uniform_z(z0 + (u64)k * ESP_GOLDEN);
+    return mode == 1 ? 0.1 + u : u;
+}
 
 // number of update calls issued by nodes that precede node (i,j,k) (1-based) in the
 // k,j,i loop nest -- closed form, so every node writes at its exact stream position
@@ -247,19 +253,22 @@ __global__ __launch_bounds__(THREADS) void fdrand_part_k(FdArgs a) {
     __shared__ double lv[THREADS * FD_MAX_PER_NODE];
     __shared__ esprun::TileLds<THREADS / ESP_WAVE> S;
     const esprun::PartOut &p = a.part;
-    if (OUT32 && *p.maxlen > (unsigned long long)p.cap) return;  // (uniform; the host issues the plain producer instead)
+    const esprun::TileLoads tl = esprun::tile_loads(p, p.chunk_base + blockIdx.x);
     const i64 g = a.g_begin + (i64)blockIdx.x * THREADS + threadIdx.x;
     FdItems it;
     fd_items(a, g, it, nullptr);  // (the COUNT launch checked the window)
     u32 slot[4];
     int total;
-    if (!esprun::tile_slots<4, THREADS / ESP_WAVE>(p, p.chunk_base + blockIdx.x, it.dig, it.wt, slot, S, &total)) return;
+    // (leaves -- uniformly -- when a flag is set or 4-byte keys do not apply: the host issues the plain producer instead)
+    if (!esprun::tile_slots<4, THREADS / ESP_WAVE>(p, tl, it.dig, it.wt, slot, S, &total, OUT32)) return;
+    const int rb = a.L.rb;
     auto put = [&](u32 at, double v, i64 row, i64 col) {
-        const u64 kp = ((u64)(col - 1) << a.L.rb) | (u64)(row - 1);
-        if constexpr (S32)
-            lk[at] = (u32)kp;
-        else
+        if constexpr (S32) {  // (the low 32 bits of (col-1) << rb | (row-1), in 32-bit arithmetic)
+            lk[at] = (rb < 32 ? (u32)(col - 1) << rb : 0u) | (u32)(row - 1);
+        } else {
+            const u64 kp = ((u64)(col - 1) << rb) | (u64)(row - 1);
             lk[at] = (kp << ESP_TAG_BITS) | (u64)a.kind;
+        }
         lv[at] = v;
     };
     // update_pair (sprand.jl:87-92): (l,l2) (l2,l) (l,l) (l2,l2) -- column l2 gets the first and the last one
@@ -271,14 +280,15 @@ __global__ __launch_bounds__(THREADS) void fdrand_part_k(FdArgs a) {
     };
     if (g < a.g_end) {
         const i64 l = g + 1;
-        const u64 c = 6ull * (u64)g;
+        const u64 z0 = a.seed + (6ull * (u64)g + 1ull) * ESP_GOLDEN;  // (draw k of this node: counter 6 g + k)
+        const int md = a.rand_mode;
         u32 own = slot[0];
-        if (it.px) pair(own, slot[1], fd_rand(a.rand_mode, a.seed, c + 0) * a.hy * a.hz / a.hx, l, l + 1);
-        if (it.bx) put(own++, fd_rand(a.rand_mode, a.seed, c + 1) * a.hy * a.hz, l, l);
-        if (it.py) pair(own, slot[2], fd_rand(a.rand_mode, a.seed, c + 2) * a.hx * a.hz / a.hy, l, l + a.nx);
-        if (it.by) put(own++, fd_rand(a.rand_mode, a.seed, c + 3) * a.hx * a.hz, l, l);
-        if (it.pz) pair(own, slot[3], fd_rand(a.rand_mode, a.seed, c + 4) * a.hx * a.hy / a.hz, l, l + a.nx * a.ny);
-        if (it.bz) put(own++, fd_rand(a.rand_mode, a.seed, c + 5) * a.hx * a.hy, l, l);
+        if (it.px) pair(own, slot[1], fd_rand_z(md, z0, 0) * a.hy * a.hz / a.hx, l, l + 1);
+        if (it.bx) put(own++, fd_rand_z(md, z0, 1) * a.hy * a.hz, l, l);
+        if (it.py) pair(own, slot[2], fd_rand_z(md, z0, 2) * a.hx * a.hz / a.hy, l, l + a.nx);
+        if (it.by) put(own++, fd_rand_z(md, z0, 3) * a.hx * a.hz, l, l);
+        if (it.pz) pair(own, slot[3], fd_rand_z(md, z0, 4) * a.hx * a.hy / a.hz, l, l + a.nx * a.ny);
+        if (it.bz) put(own++, fd_rand_z(md, z0, 5) * a.hx * a.hy, l, l);
     }
     __syncthreads();
     esprun::copy_out_runs<KT, OUT32, THREADS, THREADS / ESP_WAVE>(p, lk, lv, total, S, (u32)a.kind);
@@ -496,12 +506,12 @@ __global__ __launch_bounds__(FEM_CELLS) void fem_part_k(FemArgs a) {
     __shared__ double lv[FEM_CELLS * FEM_MAX_PER_CELL];
     __shared__ esprun::TileLds<FEM_CELLS / ESP_WAVE> S;
     const esprun::PartOut &p = a.part;
-    if (OUT32 && *p.maxlen > (unsigned long long)p.cap) return;
+    const esprun::TileLoads tl = esprun::tile_loads(p, p.chunk_base + blockIdx.x);
     const i64 pos = (i64)blockIdx.x * FEM_CELLS + threadIdx.x;
     u32 dig[4], wt[4], slot[4];
     fem_items(a, pos, dig, wt, nullptr);
     int total;
-    if (!esprun::tile_slots<4, FEM_CELLS / ESP_WAVE>(p, p.chunk_base + blockIdx.x, dig, wt, slot, S, &total)) return;
+    if (!esprun::tile_slots<4, FEM_CELLS / ESP_WAVE>(p, tl, dig, wt, slot, S, &total, OUT32)) return;
     fem_stage(a, lk, lv, 0, slot, pos);
     __syncthreads();
     esprun::copy_out_runs<KT, OUT32, FEM_CELLS, FEM_CELLS / ESP_WAVE>(p, lk, lv, total, S, (u32)ESP_RAWUPDATE);

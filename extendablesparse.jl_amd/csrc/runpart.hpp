@@ -598,13 +598,35 @@ struct TileLds {
 // order there, and of two threads the earlier one's come first -- entries of different columns may trade places
 // freely (the bucket kernel sorts by column anyway).  slot[q] = first LDS slot of item q.  Two barriers.
 // Returns false (uniform) when the launch has to leave without a store (see PartOut::flags).
+// Everything a tile needs from global memory, requested as the FIRST thing its kernel does, in one round trip (a
+// workgroup lives for a few microseconds: dependent loads in the middle of it would be a third of that).
+struct TileLoads {
+    u32 stop;                    // a flag is set: leave
+    unsigned long long longest;  // longest bucket
+    int nr;                      // runs of the tile
+    u32 run_digit;               // lane j: digit of run j (garbage for j >= nr)
+    i64 run_off;                 // lane j: global offset of run j
+};
+__device__ __forceinline__ TileLoads tile_loads(const PartOut &p, i64 chunk) {
+    const int lane = threadIdx.x & 63;
+    TileLoads L;
+    L.stop = p.flags[0] | p.flags[1] | p.flags[3];
+    L.longest = *p.maxlen;
+    L.nr = (int)p.nruns[chunk];
+    L.run_digit = p.runs_d[chunk * RMAX + lane];
+    L.run_off = p.runs_off[chunk * RMAX + lane];
+    return L;
+}
+
+// (out32: the launch stores 4-byte keys and leaves when the longest bucket does not fit the bucket kernel)
 template <int NQ, int NWAVES>
-__device__ __forceinline__ bool tile_slots(const PartOut &p, i64 chunk, const u32 (&dig)[NQ], const u32 (&wt)[NQ], u32 (&slot)[NQ],
-                                           TileLds<NWAVES> &S, int *total_out) {
+__device__ __forceinline__ bool tile_slots(const PartOut &p, const TileLoads &L, const u32 (&dig)[NQ], const u32 (&wt)[NQ],
+                                           u32 (&slot)[NQ], TileLds<NWAVES> &S, int *total_out, bool out32) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    if ((p.flags[0] | p.flags[1] | p.flags[3]) != 0u) return false;
-    const int nr = (int)p.nruns[chunk];
-    const u32 my_run_digit = lane < nr ? p.runs_d[chunk * RMAX + lane] : EMPTY;  // lane j holds the digit of run j
+    if (L.stop != 0u || (out32 && L.longest > (unsigned long long)p.cap)) return false;
+    const int nr = L.nr;
+    const u32 my_run_digit = lane < nr ? L.run_digit : EMPTY;  // lane j holds the digit of run j
+    const i64 run_off_raw = L.run_off;
     S.cnt[w][lane] = 0;
     u32 dg[NQ], pq[NQ], jq[NQ];
 #pragma unroll
@@ -654,7 +676,7 @@ __device__ __forceinline__ bool tile_slots(const PartOut &p, i64 chunk, const u3
     if (w == 0) {
         S.lstart[lane] = lst;
         if (lane == 63) S.lstart[RMAX] = inc;
-        S.roff[lane] = lane < nr ? p.runs_off[chunk * RMAX + lane] : 0;
+        S.roff[lane] = lane < nr ? run_off_raw : 0;
         u64 rb = 0;
         if (lane < nr) {
             if (p.mw_P) {
@@ -681,21 +703,47 @@ __device__ __forceinline__ bool tile_slots(const PartOut &p, i64 chunk, const u3
 template <typename KT, bool OUT32, int NT, int NWAVES>
 __device__ __forceinline__ void copy_out_runs(const PartOut &p, const KT *lk, const double *lv, int total, const TileLds<NWAVES> &S,
                                               u32 kind) {
-    int j = 0;
-    for (int q = threadIdx.x; q < total; q += NT) {
-        while (q >= (int)S.lstart[j + 1]) j++;
-        const i64 dst = S.roff[j] + (i64)(q - (int)S.lstart[j]);
-        if constexpr (sizeof(KT) == 4) {
-            const u64 rb = S.rbase[j];
-            const u32 delta = (u32)lk[q] - (u32)rb;
+    typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+    typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    const int t = threadIdx.x;
+    // run by run (a handful per tile, hundreds of entries each): two entries per store instruction -- 8-byte / 16-byte
+    // key stores and 16-byte value stores on the aligned body of the run, the odd entry at either end on its own
+    for (int j = 0; j < RMAX; j++) {
+        const int b = (int)S.lstart[j], len = (int)S.lstart[j + 1] - b;
+        if (b >= total) break;
+        if (len == 0) continue;
+        const i64 ro = S.roff[j];
+        const u64 rb = S.rbase[j];
+        auto key_of = [&](int q) -> u64 {  // what goes out for staged entry q: the 4-byte key, or the packed key
+            if constexpr (sizeof(KT) == 4) {
+                const u32 delta = (u32)lk[q] - (u32)rb;
+                if constexpr (OUT32) return (u64)delta;
+                return ((rb + (u64)delta) << ESP_TAG_BITS) | (u64)kind;
+            } else {
+                return (u64)lk[q];
+            }
+        };
+        auto store1 = [&](int q, i64 dst) {
             if constexpr (OUT32)
-                reinterpret_cast<u32 *>(p.keys_out)[dst] = delta;
+                reinterpret_cast<u32 *>(p.keys_out)[dst] = (u32)key_of(q);
             else
-                p.keys_out[dst] = ((rb + (u64)delta) << ESP_TAG_BITS) | (u64)kind;
-        } else {
-            p.keys_out[dst] = lk[q];
+                p.keys_out[dst] = key_of(q);
+            p.vals_out[dst] = lv[q];
+        };
+        const int head = (int)(ro & 1);  // the run starts at an odd place: its first entry goes alone
+        if (t == 0 && head) store1(b, ro);
+        const int npair = (len - head) >> 1;
+        for (int q = t; q < npair; q += NT) {
+            const int e = b + head + 2 * q;
+            const i64 dst = ro + head + 2 * q;  // even
+            if constexpr (OUT32)
+                *reinterpret_cast<u32x2 *>(reinterpret_cast<u32 *>(p.keys_out) + dst) = u32x2{(u32)key_of(e), (u32)key_of(e + 1)};
+            else
+                *reinterpret_cast<u64x2 *>(p.keys_out + dst) = u64x2{key_of(e), key_of(e + 1)};
+            *reinterpret_cast<f64x2 *>(p.vals_out + dst) = f64x2{lv[e], lv[e + 1]};
         }
-        p.vals_out[dst] = lv[q];
+        if (t == NT - 1 && ((len - head) & 1)) store1(b + len - 1, ro + len - 1);
     }
 }
 
