@@ -254,6 +254,7 @@ __global__ __launch_bounds__(THREADS) void fdrand_part_k(FdArgs a) {
     __shared__ esprun::TileLds<THREADS / ESP_WAVE> S;
     const esprun::PartOut &p = a.part;
     const esprun::TileLoads tl = esprun::tile_loads(p, p.chunk_base + blockIdx.x);
+    if (esprun::tile_stop(p, tl, OUT32)) return;
     const i64 g = a.g_begin + (i64)blockIdx.x * THREADS + threadIdx.x;
     FdItems it;
     fd_items(a, g, it, nullptr);  // (the COUNT launch checked the window)
@@ -507,6 +508,7 @@ __global__ __launch_bounds__(FEM_CELLS) void fem_part_k(FemArgs a) {
     __shared__ esprun::TileLds<FEM_CELLS / ESP_WAVE> S;
     const esprun::PartOut &p = a.part;
     const esprun::TileLoads tl = esprun::tile_loads(p, p.chunk_base + blockIdx.x);
+    if (esprun::tile_stop(p, tl, OUT32)) return;
     const i64 pos = (i64)blockIdx.x * FEM_CELLS + threadIdx.x;
     u32 dig[4], wt[4], slot[4];
     fem_items(a, pos, dig, wt, nullptr);

@@ -618,6 +618,12 @@ __device__ __forceinline__ TileLoads tile_loads(const PartOut &p, i64 chunk) {
     return L;
 }
 
+// true: the launch leaves without a store (uniform) -- a flag is set, or it would store 4-byte keys (out32) and the
+// longest bucket does not fit the bucket kernel.  Checked before the tile's entries are formed.
+__device__ __forceinline__ bool tile_stop(const PartOut &p, const TileLoads &L, bool out32) {
+    return L.stop != 0u || (out32 && L.longest > (unsigned long long)p.cap);
+}
+
 // (out32: the launch stores 4-byte keys and leaves when the longest bucket does not fit the bucket kernel)
 template <int NQ, int NWAVES>
 __device__ __forceinline__ bool tile_slots(const PartOut &p, const TileLoads &L, const u32 (&dig)[NQ], const u32 (&wt)[NQ],

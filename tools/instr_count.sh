@@ -2,7 +2,7 @@
 # dynamic instruction counts per wave of the pipeline's kernels (rocprofv3 PMC; run through gpurun)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/ic
-rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES --kernel-trace --output-format csv -d gpurun_out/ic -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/ic.log 2>&1
+rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVE_CYCLES --kernel-trace --output-format csv -d gpurun_out/ic -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-extra > gpurun_out/ic.log 2>&1
 python3 - <<'PY'
 import collections, csv, glob
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
