@@ -2134,9 +2134,11 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     // esp_flush normalised the buffers: data in keys/vals, scratch pair = keys2/vals2
     u64 *tk = (u64 *)h->keys2.p;
     double *tv = (double *)h->vals2.p;
-    CK(ensure(h, h->segout, sizeof(u64) * (size_t)(S + 4)));
+    // look-back granules: one per segment | ticket, error flag | longest run | one per group of 64 segments
+    const i64 G = ((i64)S + 63) / 64 + 1;
+    CK(ensure(h, h->segout, sizeof(u64) * (size_t)(S + 4 + G)));
     u64 *status = (u64 *)h->segout.p;
-    HIPCK(h, hipMemsetAsync(status, 0, sizeof(u64) * (size_t)(S + 2), h->stream));
+    HIPCK(h, hipMemsetAsync(status, 0, sizeof(u64) * (size_t)(S + 2 + G), h->stream));
     CK(ensure(h, h->colend, sizeof(u64) * (size_t)(N1 + espscan::workspace_elems(N1))));
     esplocal::Args a;
     const char *stop_env = getenv("ESP_LOCAL_STOP");
@@ -2193,6 +2195,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         a.out_val = tv;
         a.colend = (u64 *)h->colend.p;
         a.status = status;
+        a.gstatus = status + S + 2;
         a.npieces = st.npieces;
         a.pstart = st.pstart;
         a.ptab = st.ptab;

@@ -111,6 +111,7 @@ struct Args {
     double *out_val;
     u64 *colend;     // per column: output index just past its last emitted entry (0 = none)
     u64 *status;     // S look-back granules, zeroed before launch
+    u64 *gstatus;    // one more per group of 64 segments (see the two-level look-back), zeroed as well
     u32 *ticket;     // zeroed before launch
     u32 *err;        // set to 1 if a look-back spin ran into its bound
     int stop_after;  // timing ablation only (0 = run everything)
@@ -412,44 +413,63 @@ __device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval,
         if (j >= e && j < len) skey[rs + j] = NOREC;
 }
 
-// ---- decoupled look-back, run by ONE wave --------------------------------------------------
-// State: `top` = nearest predecessor not yet accounted for, `excl` = sum so far.
+// ---- two-level look-back, run by ONE wave --------------------------------------------------------------
+// A segment's output offset = the emitted entries of all segments with a lower ticket.  Segments are taken in groups
+// of 64 consecutive tickets:
+//   status[s]   = AGG | total of segment s                 (published as soon as the total is known)
+//   gstatus[g]  = PRE | total of the groups 0..g            (published by the LAST segment of group g)
+//   offset(s)   = gstatus[g-1] + the totals of the segments of its own group in front of it
+// i.e. ONE 64-wide poll of the own group (its members hold neighbouring tickets: they publish at about the same
+// time) and ONE granule of the previous group, whose last segment started 64 tickets earlier.  The chain that
+// remains is over groups only -- a link is one poll long, the groups start several polls apart -- where the linear
+// decoupled look-back of round 1 walked back over every segment in flight (446 at 256^3: seven dependent 64-wide
+// polls, 4.5 us per segment).  Granules: 8 bytes {flag, value}, relaxed agent-scope atomics on both sides (MI355X L2s
+// are per XCD), spins bounded (a timeout surfaces as ESP_ERR_HIP); a segment waits for lower tickets only, and
+// tickets are drawn in start order: no deadlock.
 struct LbState {
-    int top;
-    u64 excl;
-    bool finished;
+    u64 group_part;  // totals of the own group's segments in front of this one
+    u64 prefix;      // gstatus of the previous group
+    bool have_part, have_prefix, finished;
     u32 spins;
 };
 __device__ __forceinline__ void lb_init(LbState &st, int s) {
-    st.top = s - 1;
-    st.excl = 0;
-    st.finished = s == 0;
+    st.group_part = 0;
+    st.prefix = 0;
+    st.have_part = (s & 63) == 0;   // first of its group: nobody in front
+    st.have_prefix = (s >> 6) == 0; // first group: no previous one
+    st.finished = st.have_part && st.have_prefix;
     st.spins = 0;
 }
-// at most `iters` polls of the 64 nearest unresolved predecessors; returns when the chain is resolved
-__device__ __forceinline__ void lb_poll(const Args &a, LbState &st, int lane, u32 iters, bool block) {
+// at most `iters` polls (block: until resolved)
+__device__ __forceinline__ void lb_poll(const Args &a, LbState &st, int s, int lane, u32 iters, bool block) {
+    const int g = s >> 6, gbase = g << 6, need = s - gbase;
     while (!st.finished && (block || iters-- > 0)) {
-        const int j = st.top - lane;
-        u64 v = ST_PRE;  // lanes before segment 0 act as a zero prefix
-        if (j >= 0) v = __hip_atomic_load(&a.status[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const u64 ready = __ballot((v >> 62) != 0);
-        const u64 pre = __ballot((v >> 62) == 2);
-        // usable lanes: a contiguous run of ready lanes starting at lane 0, cut after the first PRE
-        const u64 notready = ~ready;
-        const int nrun = notready ? __builtin_ctzll(notready) : 64;
-        const u64 runmask = nrun >= 64 ? ~0ull : ((1ull << nrun) - 1ull);
-        const u64 prein = pre & runmask;
-        int use = nrun;
-        if (prein) {
-            use = __builtin_ctzll(prein) + 1;
-            st.finished = true;
+        bool progress = false;
+        u64 v = ST_AGG;  // lanes beyond the segments in front act as ready zeros
+        u64 gp = ST_PRE;
+        // both granule loads of a round are in flight together
+        if (!st.have_part && lane < need) v = __hip_atomic_load(&a.status[gbase + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!st.have_prefix && lane == 0) gp = __hip_atomic_load(&a.gstatus[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (!st.have_part) {
+            if (__ballot((v >> 62) == 0) == 0ull) {
+                // (totals are < 2^32 each and 64 of them < 2^38: two 32-bit DPP sums)
+                const u32 lo = esp_wave_sum((u32)(v & 0xFFFFFFFFull));
+                const u32 hi = esp_wave_sum((u32)((v & ST_VAL) >> 32));
+                st.group_part = ((u64)hi << 32) + (u64)lo;
+                st.have_part = true;
+                progress = true;
+            }
         }
-        u64 part = lane < use ? (v & ST_VAL) : 0ull;
-#pragma unroll
-        for (int dlt = 32; dlt > 0; dlt >>= 1) part += __shfl_xor(part, dlt, ESP_WAVE);
-        st.excl += part;
-        st.top -= use;
-        if (!st.finished && use == 0) {
+        if (!st.have_prefix) {
+            const u64 g0 = esp_uniform_u64(gp);
+            if ((g0 >> 62) != 0) {
+                st.prefix = g0 & ST_VAL;
+                st.have_prefix = true;
+                progress = true;
+            }
+        }
+        st.finished = st.have_part && st.have_prefix;
+        if (!st.finished && !progress) {
             if (++st.spins > SPIN_LIMIT) {
                 if (lane == 0) atomicOr(a.err, 1u);
                 st.finished = true;  // give up (the host reports the error)
@@ -459,37 +479,31 @@ __device__ __forceinline__ void lb_poll(const Args &a, LbState &st, int lane, u3
         }
     }
 }
-// publishes the total (aggregate first, so that successors can move on), resolves what is left of the
-// chain and publishes the inclusive prefix; returns the exclusive prefix
-__device__ __forceinline__ u64 lb_finish(const Args &a, LbState &st, int s, u32 total, int lane) {
-    if (s == 0) {
-        if (lane == 0) __hip_atomic_store(&a.status[0], ST_PRE | (u64)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return 0;
-    }
-    if (!st.finished && lane == 0)
-        __hip_atomic_store(&a.status[s], ST_AGG | (u64)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    lb_poll(a, st, lane, 0, true);
-    if (lane == 0)
-        __hip_atomic_store(&a.status[s], ST_PRE | ((st.excl + (u64)total) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return st.excl;
-}
-// the same in two steps, so that the wave can do other work (and pass barriers) in between
+// the segment's total becomes visible to its group (call once, as early as the total is known)
 __device__ __forceinline__ void lb_publish(const Args &a, LbState &st, int s, u32 total, int lane) {
     lb_init(st, s);
-    if (lane == 0)  // (segment 0 has no predecessors: its total is the inclusive prefix already)
-        __hip_atomic_store(&a.status[s], (s > 0 ? ST_AGG : ST_PRE) | (u64)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane == 0) __hip_atomic_store(&a.status[s], ST_AGG | (u64)total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// resolves what is left, publishes the group's prefix if this is its last segment; returns the exclusive prefix
 __device__ __forceinline__ u64 lb_complete(const Args &a, LbState &st, int s, u32 total, int lane) {
-    lb_poll(a, st, lane, 0, true);
-    if (lane == 0)
-        __hip_atomic_store(&a.status[s], ST_PRE | ((st.excl + (u64)total) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    return st.excl;
+    lb_poll(a, st, s, lane, 0, true);
+    const u64 excl = st.prefix + st.group_part;
+    if (lane == 0) {
+        if ((s & 63) == 63 || s == a.S - 1)
+            __hip_atomic_store(&a.gstatus[s >> 6], ST_PRE | ((excl + (u64)total) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // the last segment leaves the grand total where the host reads it (nobody polls its granule)
+        if (s == a.S - 1) __hip_atomic_store(&a.status[s], ST_PRE | ((excl + (u64)total) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return excl;
 }
 __device__ __forceinline__ u64 lookback_wave(const Args &a, int s, u32 total, int lane) {
     LbState st;
-    lb_init(st, s);
-    return lb_finish(a, st, s, total, lane);
+    lb_publish(a, st, s, total, lane);
+    return lb_complete(a, st, s, total, lane);
 }
+// a segment that emits nothing and is not the last of its group has no use for its offset: it publishes its zero total
+// and leaves (the group's last segment always resolves, so the chain over the groups never breaks)
+__device__ __forceinline__ bool lb_may_skip(const Args &a, int s) { return (s & 63) != 63 && s != a.S - 1; }
 
 // Register tier of the bucket kernel: one lane per column, the whole run (<= R entries) in registers.
 // Returns true when the look-back already ran (early publication of the segment total).
@@ -527,7 +541,7 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
             // (measured: polling already while the other waves sort costs more in contention than the
             // shorter chain saves -- local 2.52 vs 2.33 ms)
             lb_publish(a, lb, s, *s_early, lane);
-            lb_poll(a, lb, lane, 1, false);
+            lb_poll(a, lb, s, lane, 1, false);
         } else if (t < ncl) {
             // (measured: keeping the sorted keys in registers across the barrier and re-reading
             // only the values beats writing the run back to LDS)
@@ -923,7 +937,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             // predecessors.  Every 64th segment and the last one still resolve their chain and publish
             // the inclusive prefix, so nobody ever walks back more than 64 + the segments in flight.
             // (a segment that writes its columns' colptr itself needs its offset even then)
-            if (total == 0 && (s & 63) != 63 && s != a.S - 1 && s != 0 && !(FRESH && a.colptr_out)) {
+            if (total == 0 && lb_may_skip(a, s) && !(FRESH && a.colptr_out)) {
                 if (lane == 0) {
                     __hip_atomic_store(&a.status[s], ST_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     s_dst = 0;
@@ -937,7 +951,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         }
         if (lane == 0) lw[0] = total;
     } else if (lb_done && w == WAVES - 1) {
-        lb_poll(a, lbs, lane, 1, false);
+        lb_poll(a, lbs, s, lane, 1, false);
     }
     __syncthreads();
 #ifdef ESP_LOCAL_STAMPS
