@@ -69,6 +69,7 @@ struct esp_handle {
     } pre;
     bool shard_user = false;     // the handle is driven through esp_shard_*: its flushes partition by owner first
     int last_shard_source = 0;   // esp_shard_partition: 1 = its own pass moved the entries, 2 = the producer had
+    int last_local_small = 0;    // the last flush's bucket kernel was the small variant (3 workgroups per CU)
     // esp_shard_plan: the producers that find the buffer empty partition for the next esp_shard_partition(P, me, eps)
     struct ShardPlan {
         bool valid = false;
@@ -1309,6 +1310,7 @@ struct Sorted {
     bool all_update = false;  // PIECES: every entry of every piece is an UPDATE (esp_shard_assemble checked)
     int key_bytes = 8;  // 4: sk holds 32-bit keys (the bits below the prefix); every entry has the kind `kind`
     int kind = 0;
+    i64 maxlen = esplocal::CAP;  // longest segment
     // PIECES (partitioned shard exchange): segments are concatenations of per-source pieces
     int npieces = 0;
     const i64 *pstart = nullptr;
@@ -2017,6 +2019,7 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     out->seg_start = (const i64 *)h->seg[cur].p;
     out->rem_bits = K - done;
     out->local_ok = ok && (K - done) <= esplocal::MAX_REM_BITS && maxlen <= esplocal::CAP;
+    out->maxlen = maxlen;
     h->seen_spread = (done > 0 && Ee > 0.0) ? (double)maxlen * std::ldexp(1.0, done) / Ee : 0.0;
     return ESP_OK;
 }
@@ -2168,6 +2171,23 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
             h->ones_pending = false;
         }
     };
+    // The small variant of the bucket kernel (3 workgroups per CU) serves a fresh, unsharded build whose segments hold
+    // at most 3072 entries over at most 256 columns with column runs the register tiers take; a segment with a longer
+    // run raises err bit 8 (it cannot know before it counts) and the flush runs again with the regular kernel -- only
+    // scratch arrays were written.  force_path 18: never.
+    bool small_variant = false;
+    {
+        const int clb = st.rem_bits - h->L.rb;
+        small_variant = Z0 == 0 && st.npieces == 0 && st.maxlen <= 6 * esplocal::THREADS && clb >= 0 && clb <= 8 &&
+                        st.rem_bits <= esplocal::REG_MAX_REM && h->seen_maxrun <= esplocal::REG_RUN && h->force_path != 3 &&
+                        h->force_path != 18 && !stop_env && !getenv("ESP_LOCAL_STAMPS");
+    }
+    for (int attempt = 0; attempt < 2; attempt++) {
+    if (attempt == 1) {  // (the small variant met a long column run)
+        small_variant = false;
+        HIPCK(h, hipMemsetAsync(status, 0, sizeof(u64) * (size_t)(S + 2 + G), h->stream));
+    }
+    h->last_local_small = small_variant ? 1 : 0;
     {
         Span sp(h, ESP_ST_LOCAL);
         a.kind32 = (u32)(st.key_bytes == 4 ? st.kind : 0);
@@ -2229,6 +2249,15 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
             } else if (st.npieces > 0) {
                 if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 0); else ESP_LAUNCH_LOCAL(true, true, false, 0); }
                 else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 0); else ESP_LAUNCH_LOCAL(false, true, false, 0); }
+            } else if (small_variant && keys == 2) {
+                if (big) hipLaunchKernelGGL((esplocal::local_k<true, false, true, 2, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+                else hipLaunchKernelGGL((esplocal::local_k<true, false, false, 2, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+            } else if (small_variant && keys == 1) {
+                if (big) hipLaunchKernelGGL((esplocal::local_k<true, false, true, 1, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+                else hipLaunchKernelGGL((esplocal::local_k<true, false, false, 1, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+            } else if (small_variant) {
+                if (big) hipLaunchKernelGGL((esplocal::local_k<true, false, true, 0, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+                else hipLaunchKernelGGL((esplocal::local_k<true, false, false, 0, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
             } else if (keys == 2) {
                 if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, false, true, 2); else ESP_LAUNCH_LOCAL(true, false, false, 2); }
                 else { if (big) ESP_LAUNCH_LOCAL(false, false, true, 2); else ESP_LAUNCH_LOCAL(false, false, false, 2); }
@@ -2247,6 +2276,9 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (S - 1), 24, hipMemcpyDeviceToHost, h->stream));  // last granule | ticket, err | maxrun
     HIPCK(h, hipMemcpyAsync(h->pin_scalar + 3, (u32 *)h->misc.p + 60, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
+    if (small_variant && ((u32)(h->pin_scalar[1] >> 32) & 8u)) continue;
+    break;
+    }
     if ((u32)h->pin_scalar[3]) {
         restore_colptr();
         FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window");
@@ -2369,6 +2401,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         st.local_ok = true;
         st.key_bytes = pp.key_bytes;
         st.kind = pp.kind;
+        st.maxlen = pp.maxlen;
         CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
         CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
         CK(flush_local(h, st, mode, &Zn));
@@ -3016,6 +3049,11 @@ extern "C" int32_t esp_shard_plan(esp_handle *h, int32_t nshards, int32_t self, 
     h->shard_plan.P = nshards;
     h->shard_plan.me = self;
     h->shard_plan.eps = entries_per_shard;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_last_local_small(const esp_handle *h, int32_t *small) {
+    if (!h || !small) return ESP_ERR_INVALID;
+    *small = h->last_local_small;
     return ESP_OK;
 }
 extern "C" int32_t esp_debug_last_shard_source(const esp_handle *h, int32_t *kind) {

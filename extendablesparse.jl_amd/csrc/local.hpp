@@ -268,7 +268,7 @@ __device__ __forceinline__ void sort_run_keys(const u64 *skey, int rs, int len, 
     // finite and ordered like the integers (denormals are not flushed for f64), so a compare-exchange
     // is v_min_f64 + v_max_f64 -- two full-rate instructions instead of a 64-bit compare and four
     // selects.  Padding = the largest finite double.
-    constexpr u64 PAD = 0x7FEFFFFFFFFFFFFFull;
+    constexpr u64 PAD = 0x7FEFFFFFFFFFC003ull;  // (slot-index bits zero: a padded key reads value slot 0)
     double d[R];
 #pragma unroll
     for (int j = 0; j < R; j++) d[j] = __longlong_as_double((long long)(j < len ? x[j] : PAD));
@@ -287,7 +287,7 @@ __device__ __forceinline__ void sort_run_keys(const u64 *skey, int rs, int len, 
 template <int R>
 __device__ __forceinline__ void load_run_values(const double *sval, const u64 (&x)[R], double (&xv)[R]) {
 #pragma unroll
-    for (int j = 0; j < R; j++) xv[j] = sval[(x[j] >> ESP_TAG_BITS) & (CAP - 1)];  // (padding reads slot CAP-1)
+    for (int j = 0; j < R; j++) xv[j] = sval[(x[j] >> ESP_TAG_BITS) & (CAP - 1)];  // (padding reads slot 0)
 }
 template <int R>
 __device__ __forceinline__ void load_sorted_run(const u64 *skey, const double *sval, int rs, int len, u64 (&x)[R],
@@ -570,16 +570,27 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
 // share one kind); 2 = the same and that kind is UPDATE (an assembly loop of updateindex! calls): the register
 // tiers fold without decoding a kind; 3 = packed keys whose kinds are all UPDATE (the pieces of a shard whose
 // received blocks were checked): the same fold
-template <bool FRESH, bool PIECES, bool BIG, int KEYS>
-__global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
+// SMALL: segments of at most 3072 entries (6 per thread) over at most 256 columns, register tiers only: 51 KiB of LDS
+// instead of 74, i.e. THREE workgroups per CU (measured at 256^3: one workgroup per CU 2.70 ms, two 1.70 ms).  A segment
+// that turns out to need the radix tier raises err bit 8 and emits nothing; the host then runs the flush again with
+// the regular kernel -- nothing but scratch arrays was written (fresh matrix only: no stored value is ever touched).
+template <bool FRESH, bool PIECES, bool BIG, int KEYS, bool SMALL = false>
+__global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     constexpr bool K32 = KEYS == 1 || KEYS == 2, UPD = KEYS >= 2;
     static_assert(!(PIECES && K32), "pieces arrive as packed keys");
-    __shared__ u64 skey[CAP];
-    __shared__ double sval[CAP];
+    static_assert(!SMALL || (FRESH && !PIECES), "the small variant serves fresh, unsharded builds");
+    constexpr int NI = SMALL ? 6 : ITEMS;
+    constexpr int CAPK = THREADS * NI;
+    __shared__ u64 skey[CAPK];
+    __shared__ double sval[CAPK];
     // radix tail: cnt[WAVES][256]; column tiers: ccnt[CL_MAX+1] (same storage)
-    __shared__ u32 cntraw[WAVES * 256 + 64];
+    __shared__ u32 cntraw[SMALL ? 256 + 64 : WAVES * 256 + 64];
     __shared__ u32 lw[16];
-    __shared__ u32 gcount[WAVES * ITEMS];
+    __shared__ u32 gcount[WAVES * NI];
+#ifdef ESP_LOCAL_PAD
+    __shared__ char s_pad[ESP_LOCAL_PAD];  // (occupancy experiment: forces fewer workgroups per CU)
+    if (threadIdx.x == 0 && a.S < 0) s_pad[0] = 1;
+#endif
     __shared__ u64 s_dst;
     __shared__ int s_seg;
     __shared__ u32 s_early;
@@ -604,11 +615,11 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     __syncthreads();
     const int s = esp_uniform_i32(s_seg);
     if (s >= a.S) return;
-    const int wbase = w * (ITEMS * ESP_WAVE) + lane;
+    const int wbase = w * (NI * ESP_WAVE) + lane;
     const u64 lt = (1ull << lane) - 1ull;
     const u64 rowmask = (1ull << a.rb) - 1ull;
-    u64 k[ITEMS];
-    double vraw[ITEMS];
+    u64 k[NI];
+    double vraw[NI];
     u64 hi;
     int n;
     if constexpr (!PIECES) {
@@ -635,13 +646,13 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         if constexpr (K32) {
             const u32 *k32 = reinterpret_cast<const u32 *>(a.keys_in);
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++) k[i] = (u64)k32[lbeg + min(wbase + i * ESP_WAVE, nlast)];
+            for (int i = 0; i < NI; i++) k[i] = (u64)k32[lbeg + min(wbase + i * ESP_WAVE, nlast)];
         } else {
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++) k[i] = a.keys_in[lbeg + min(wbase + i * ESP_WAVE, nlast)];
+            for (int i = 0; i < NI; i++) k[i] = a.keys_in[lbeg + min(wbase + i * ESP_WAVE, nlast)];
         }
 #pragma unroll
-        for (int i = 0; i < ITEMS; i++) vraw[i] = a.vals_in[lbeg + min(wbase + i * ESP_WAVE, nlast)];
+        for (int i = 0; i < NI; i++) vraw[i] = a.vals_in[lbeg + min(wbase + i * ESP_WAVE, nlast)];
     } else {
         // the segment's pieces, one per source rank (most segments of a slab-wise assembly have one)
         __shared__ i64 p_beg[MAX_PIECES];
@@ -671,7 +682,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         }
         __syncthreads();
         n = p_pre[a.npieces];
-        n = min(n, CAP);  // (the host checked the merged length; never index past the LDS arrays)
+        n = min(n, CAPK);  // (the host checked the merged length; never index past the LDS arrays)
         hi = ((u64)s << a.rem_bits) + a.base;
         const int nlast = n > 0 ? n - 1 : 0;
         const int single = p_single;
@@ -680,14 +691,14 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
             const double *pv = p_v[single];
             const i64 beg = p_beg[single];
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++) k[i] = pk[beg + min(wbase + i * ESP_WAVE, nlast)];
+            for (int i = 0; i < NI; i++) k[i] = pk[beg + min(wbase + i * ESP_WAVE, nlast)];
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++) vraw[i] = pv[beg + min(wbase + i * ESP_WAVE, nlast)];
+            for (int i = 0; i < NI; i++) vraw[i] = pv[beg + min(wbase + i * ESP_WAVE, nlast)];
         } else {
-            const u64 *ak[ITEMS];
-            const double *av[ITEMS];
+            const u64 *ak[NI];
+            const double *av[NI];
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++) {
+            for (int i = 0; i < NI; i++) {
                 const int p = min(wbase + i * ESP_WAVE, nlast);
                 int q = 0;
                 while (q + 1 < a.npieces && p >= p_pre[q + 1]) q++;
@@ -696,9 +707,9 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
                 av[i] = p_v[q] + at;
             }
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++) k[i] = n > 0 ? *ak[i] : 0ull;
+            for (int i = 0; i < NI; i++) k[i] = n > 0 ? *ak[i] : 0ull;
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++) vraw[i] = n > 0 ? *av[i] : 0.0;
+            for (int i = 0; i < NI; i++) vraw[i] = n > 0 ? *av[i] : 0.0;
         }
     }
     const u64 hi4 = hi << ESP_TAG_BITS;  // the segment's prefix as it sits in a packed key
@@ -709,7 +720,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     u64 bad = 0;
     const u64 relmask = (((u64)1 << (a.rem_bits + ESP_TAG_BITS - 1)) << 1) - 1ull;  // (rem_bits + 2 may be 64)
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
+    for (int i = 0; i < NI; i++) {
         const int p = wbase + i * ESP_WAVE;
         const u64 key = k[i];
         sval[p] = vraw[i];
@@ -747,9 +758,9 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         const int ncl = 1 << a.cl_bits;
         const int csh = SUB_SHIFT + a.rb;  // packed >> csh = local column
         __syncthreads();  // ccnt is zero (cleared while the loads were in flight)
-        unsigned short slot[ITEMS];
+        unsigned short slot[NI];
 #pragma unroll
-        for (int i = 0; i < ITEMS; i++) {
+        for (int i = 0; i < NI; i++) {
             slot[i] = 0;
             if (wbase + i * ESP_WAVE < n) slot[i] = (unsigned short)atomicAdd(&ccnt[(u32)(k[i] >> csh)], 1u);
         }
@@ -801,7 +812,7 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         if (t == 0 && maxrun > 16) atomicMax(a.maxrun_seen, maxrun);  // (tells the host which kernel variant suits this matrix)
         if (!done && maxrun <= reg_max && a.rem_bits <= REG_MAX_REM) {
 #pragma unroll
-            for (int i = 0; i < ITEMS; i++)
+            for (int i = 0; i < NI; i++)
                 if (wbase + i * ESP_WAVE < n) skey[ccnt[(u32)(k[i] >> csh)] + slot[i]] = k[i];
             __syncthreads();
 #ifdef ESP_LOCAL_STAMPS
@@ -823,6 +834,13 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
         __syncthreads();  // records are in place (or: ccnt storage is free for the radix counters)
     }
 
+    if constexpr (SMALL) {
+        if (!done) {  // (long column runs / too many key bits for the register tiers: not this variant's business)
+            if (t == 0) atomicOr(a.err, 8u);
+            for (int q = t; q < CAPK; q += THREADS) skey[q] = NOREC;  // the segment emits nothing
+            __syncthreads();
+        }
+    } else
     if (!done) {
         // ---- radix tier (long runs / wide column ranges): stable LSD sort of all remaining bits
         const int npass = radix_tail(k, skey, cnt, lw, a.rem_bits, t, lane, w, wbase, n, reinterpret_cast<u64 *>(s_win));
@@ -911,24 +929,24 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     }
 
     // ---- compaction: records (skey[p] != NOREC, value in sval[idx]) -> dense prefix
-    u64 rec[ITEMS];
-    double rv[ITEMS];
+    u64 rec[NI];
+    double rv[NI];
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
+    for (int i = 0; i < NI; i++) {
         const int p = wbase + i * ESP_WAVE;
         rec[i] = (p < n && a.stop_after == 0) ? skey[p] : NOREC;
         rv[i] = rec[i] != NOREC ? sval[(rec[i] >> ESP_TAG_BITS) & (CAP - 1)] : 0.0;
         const u64 bal = __ballot(rec[i] != NOREC);
-        if (lane == 0) gcount[w * ITEMS + i] = (u32)__popcll(bal);
+        if (lane == 0) gcount[w * NI + i] = (u32)__popcll(bal);
     }
     __syncthreads();
     if (w == 0) {
 #ifdef ESP_LOCAL_STAMPS
         if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 5] = wall_clock64();
 #endif
-        const u32 c = lane < WAVES * ITEMS ? gcount[lane] : 0u;
+        const u32 c = lane < WAVES * NI ? gcount[lane] : 0u;
         const u32 inc = esp_wave_scan_add(c);
-        if (lane < WAVES * ITEMS) gcount[lane] = inc - c;
+        if (lane < WAVES * NI) gcount[lane] = inc - c;
         const u32 total = (u32)__builtin_amdgcn_readlane((int)inc, 63);
         // ---- decoupled look-back (wave 0) unless the register tier already ran it
         if (!lb_done) {
@@ -960,10 +978,10 @@ __global__ __launch_bounds__(THREADS, 4) void local_k(Args a) {
     const int total = (int)lw[0];
     // dense prefix in LDS (all records and values are in registers: in-place is safe)
 #pragma unroll
-    for (int i = 0; i < ITEMS; i++) {
+    for (int i = 0; i < NI; i++) {
         const u64 bal = __ballot(rec[i] != NOREC);
         if (rec[i] != NOREC) {
-            const u32 e = gcount[w * ITEMS + i] + (u32)__popcll(bal & lt);
+            const u32 e = gcount[w * NI + i] + (u32)__popcll(bal & lt);
             skey[e] = hi + (rec[i] >> SUB_SHIFT);
             sval[e] = rv[i];
         }

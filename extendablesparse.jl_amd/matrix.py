@@ -519,6 +519,12 @@ class ExtendableSparseMatrix:
         self._d.ck(self._d.lib.esp_debug_last_path(self._d.h, C.byref(p)))
         return p.value
 
+    def debug_last_local_small(self):
+        """1: the last flush's bucket kernel was the small variant (three workgroups per CU)"""
+        p = C.c_int32()
+        self._d.ck(self._d.lib.esp_debug_last_local_small(self._d.h, C.byref(p)))
+        return p.value
+
     def debug_last_shard_source(self):
         """1: the last esp_shard_partition moved the entries itself, 2: the producer had partitioned them"""
         p = C.c_int32()
