@@ -128,7 +128,7 @@ struct esp_handle {
     int part_P = 0, part_me = 0, part_shift = 0;
     u32 part_nb = 0;
     u64 part_base = 0, part_span = 0;
-    i64 part_total = 0;
+    i64 part_total = 0, part_maxlen = 0;
     DevBuf parttab, piecetab;
     // row-wise view of the device CSC for mul! (built on first use after a pattern change)
     unsigned long long pattern_version = 1, csr_version = 0;
@@ -2178,7 +2178,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     bool small_variant = false;
     {
         const int clb = st.rem_bits - h->L.rb;
-        small_variant = Z0 == 0 && st.npieces == 0 && st.maxlen <= 6 * esplocal::THREADS && clb >= 0 && clb <= 8 &&
+        small_variant = Z0 == 0 && st.maxlen <= 6 * esplocal::THREADS && clb >= 0 && clb <= 8 &&
                         st.rem_bits <= esplocal::REG_MAX_REM && h->seen_maxrun <= esplocal::REG_RUN && h->force_path != 3 &&
                         h->force_path != 18 && !stop_env && !getenv("ESP_LOCAL_STAMPS");
     }
@@ -2243,7 +2243,15 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
             const int keys = st.npieces > 0 ? (st.all_update && h->force_path != 15 ? 3 : 0)
                                             : st.key_bytes != 4 ? 0 : (st.kind == ESP_UPDATE && h->force_path != 15 ? 2 : 1);
             h->last_fold_update = keys >= 2 ? 1 : 0;
-            if (st.npieces > 0 && keys == 3) {
+            if (small_variant && st.npieces > 0) {
+                if (keys == 3) {
+                    if (big) hipLaunchKernelGGL((esplocal::local_k<true, true, true, 3, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+                    else hipLaunchKernelGGL((esplocal::local_k<true, true, false, 3, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+                } else {
+                    if (big) hipLaunchKernelGGL((esplocal::local_k<true, true, true, 0, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+                    else hipLaunchKernelGGL((esplocal::local_k<true, true, false, 0, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
+                }
+            } else if (st.npieces > 0 && keys == 3) {
                 if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 3); else ESP_LAUNCH_LOCAL(true, true, false, 3); }
                 else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 3); else ESP_LAUNCH_LOCAL(false, true, false, 3); }
             } else if (st.npieces > 0) {
@@ -2425,6 +2433,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         st.all_update = h->part_all_update;
         st.ptab = (const void *const *)T;
         st.pstart = (const i64 *)(T + 256 * 8);
+        st.maxlen = h->part_maxlen;
         CK(ensure(h, h->keys2, sizeof(u64) * (size_t)std::max<i64>(h->part_total, 1)));
         CK(ensure(h, h->vals2, sizeof(double) * (size_t)std::max<i64>(h->part_total, 1)));
         CK(flush_local(h, st, mode, &Zn));
@@ -3247,6 +3256,7 @@ extern "C" int32_t esp_shard_assemble(esp_handle *h, const uint64_t *const *d_re
     }
     h->count = total;
     h->part_total = total;
+    h->part_maxlen = (i64)mx[0];
     h->part_assembled = true;
     *ok = 1;
     return ESP_OK;

@@ -324,7 +324,7 @@ int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear);
  * over all columns builds colptr (instead of every segment writing the colptr of its own columns),
  * 16 = the device-side producers (esp_generate_*) always append in stream order (never the producer-side partition),
  * 17 = the join with an existing CSC runs as a merge-path over a per-entry column array (a second implementation of the
- *      column-tiled join);
+ *      column-tiled join), 18 = never the small variant of the bucket kernel (see esp_debug_last_local_small);
  * last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general) */
 int32_t esp_debug_force_path(esp_handle *h, int32_t path);
 int32_t esp_debug_last_path(const esp_handle *h, int32_t *path);

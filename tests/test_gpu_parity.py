@@ -1414,13 +1414,15 @@ def test_fdrand_full_size_digest(esp, n):
     oracle's (tests/golden/make_digests_large.py).  Producer-side partition and, with the hook, the flush's own."""
     d = gu.digests("digests_large.txt")["fd_%d_m1" % n]
     N = n ** 3
-    for force in ((0, 16) if n < 256 else (0,)):
+    for force in ((0, 16, 18) if n < 256 else (0, 18)):
         A = esp.ExtendableSparseMatrix(N, N)
         A.debug_force_path(force)
         A.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1)
         A.flush()
-        assert A.debug_last_partition() == (4 if force == 0 else 1)
+        assert A.debug_last_partition() == (1 if force == 16 else 4)
         assert A.debug_last_key_bytes() == 4
+        if n == 256:   # segments of 256 columns x 12 updates: the small variant of the bucket kernel (18: the regular one)
+            assert A.debug_last_local_small() == (1 if force == 0 else 0)
         arrs = hip_arrays(A)
         assert len(arrs[1]) == int(d["nnz"])
         assert gu.digest(*arrs) == d["csc"], (n, force)
@@ -1683,3 +1685,31 @@ def test_join_dense_columns_empty_columns_and_rectangular(esp, orc, force):
     got = X + esp.SparseMatrixCSC(m, n, cp, rv, nz)
     want = L + orc.CSC(m, n, cp, rv, nz)
     assert_csc_equal(got.arrays(), want.arrays())
+
+
+def test_small_bucket_kernel_gives_up_on_long_runs(esp, orc):
+    """The small variant of the bucket kernel (three workgroups per CU: register tiers only) is chosen from what the
+    host knows BEFORE the flush (a fresh build, segments of at most 3072 entries over at most 256 columns); a segment
+    whose column runs are longer than the register tiers take raises a flag, emits nothing, and the flush runs again
+    with the regular kernel: same bits as the oracle, on the first flush of a handle and on later ones."""
+    rng = np.random.default_rng(31)
+    m, n = 2 ** 20, 60000
+    for per_col in (40, 90):
+        A = esp.ExtendableSparseMatrix(m, n)
+        O = orc.ExtendableSparseMatrix(m, n)
+        for rnd in range(2):
+            ncols_used = 40000
+            cols = np.sort(rng.choice(n, ncols_used, replace=False)) + 1
+            J = np.repeat(cols, per_col)
+            # a few rows per column, many duplicates: long column runs, few records
+            I = np.clip(J[:, None] * 7 % m + rng.integers(0, 5, (len(J), 1)), 1, m).ravel()
+            V = rng.standard_normal(len(J))
+            A.reset()
+            O = orc.ExtendableSparseMatrix(m, n)
+            A.append(UPDATE, I, J, V)
+            O.apply(np.full(len(I), UPDATE, np.uint8), I, J, V)
+            A.flush()
+            O.flush()
+            assert A.debug_last_path() == 1
+            assert A.debug_last_local_small() == 0      # (first flush: tried and gave up; second: not tried)
+            assert_csc_equal(hip_arrays(A), O.arrays(), "per_col %d round %d" % (per_col, rnd))

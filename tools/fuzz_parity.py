@@ -35,9 +35,9 @@ while time.time() < t_end:
         m = int(rng.choice([3, 100, 4097, 60000]))
     A = esp.ExtendableSparseMatrix(m, n)
     O = orc.ExtendableSparseMatrix(m, n)
-    force = int(rng.choice([0, 0, 0, 2, 3, 4, 5, 12, 13, 14, 15, 17]))
+    force = int(rng.choice([0, 0, 0, 2, 3, 4, 5, 12, 13, 14, 15, 17, 18]))
     if focus:
-        force = int(rng.choice([0, 0, 13, 15, 4]))
+        force = int(rng.choice([0, 0, 13, 15, 4, 18]))
     A.debug_force_path(force)
     nflush = int(rng.integers(1, 4))
     for f in range(nflush):
