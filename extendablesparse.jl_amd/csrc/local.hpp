@@ -193,9 +193,11 @@ __device__ __forceinline__ int radix_tail(u64 (&k)[ITEMS], u64 *skey, u32 (*cnt)
             u64 m = ~0ull;
 #pragma unroll
             for (int b = 0; b < 8; b++) {
-                const bool bit = (d >> b) & 1u;
-                const u64 bb = __ballot(bit);
-                m &= bit ? bb : ~bb;
+                if (b < bA + bB) {  // (uniform: a digit of 5 varying bits pays 5 ballots)
+                    const bool bit = (d >> b) & 1u;
+                    const u64 bb = __ballot(bit);
+                    m &= bit ? bb : ~bb;
+                }
             }
             const u32 prev = cnt[w][d];
             rank[i] = (unsigned short)(prev + (u32)__popcll(m & lt));

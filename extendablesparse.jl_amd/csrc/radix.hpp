@@ -182,9 +182,11 @@ __global__ __launch_bounds__(THREADS, 2) void scatter_k(Pass p) {
             if (__ballot(valid && d == d0) != vm) {
 #pragma unroll
                 for (int b = 0; b < 8; b++) {
-                    const bool bit = (d >> b) & 1u;
-                    const u64 bb = __ballot(bit);
-                    m &= bit ? bb : ~bb;
+                    if (b < p.bits) {  // (uniform: a pass of 6 bits pays 6 ballots)
+                        const bool bit = (d >> b) & 1u;
+                        const u64 bb = __ballot(bit);
+                        m &= bit ? bb : ~bb;
+                    }
                 }
             }
         }
