@@ -2138,7 +2138,8 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     u64 *tk = (u64 *)h->keys2.p;
     double *tv = (double *)h->vals2.p;
     // look-back granules: one per segment | ticket, error flag | longest run | one per group of 64 segments
-    const i64 G = ((i64)S + 63) / 64 + 1;
+    // (cleared as a multiple of 256 bytes: the runtime splits an odd-sized memset into two launches)
+    const i64 G = ((((i64)S + 63) / 64 + 1 + S + 2 + 31) & ~(i64)31) - (S + 2);
     CK(ensure(h, h->segout, sizeof(u64) * (size_t)(S + 4 + G)));
     u64 *status = (u64 *)h->segout.p;
     HIPCK(h, hipMemsetAsync(status, 0, sizeof(u64) * (size_t)(S + 2 + G), h->stream));
@@ -2178,8 +2179,12 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     bool small_variant = false;
     {
         const int clb = st.rem_bits - h->L.rb;
+        // (what the handle's last flush saw decides; a handle without history tries it when the columns hold few entries
+        // on average -- a stencil's 12, not a 3-D FEM mesh's 120)
+        const double per_col = (double)h->count / (double)std::max<i64>(col_end - col_begin, 1);
+        const bool runs_fit = h->seen_maxrun > 0 ? h->seen_maxrun <= esplocal::REG_RUN : per_col <= 16.0;
         small_variant = Z0 == 0 && st.maxlen <= 6 * esplocal::THREADS && clb >= 0 && clb <= 8 &&
-                        st.rem_bits <= esplocal::REG_MAX_REM && h->seen_maxrun <= esplocal::REG_RUN && h->force_path != 3 &&
+                        st.rem_bits <= esplocal::REG_MAX_REM && runs_fit && h->force_path != 3 &&
                         h->force_path != 18 && !stop_env && !getenv("ESP_LOCAL_STAMPS");
     }
     for (int attempt = 0; attempt < 2; attempt++) {
