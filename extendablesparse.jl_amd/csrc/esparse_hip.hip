@@ -2185,7 +2185,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         const bool runs_fit = h->seen_maxrun > 0 ? h->seen_maxrun <= esplocal::REG_RUN : per_col <= 16.0;
         small_variant = Z0 == 0 && st.maxlen <= 6 * esplocal::THREADS && clb >= 0 && clb <= 8 &&
                         st.rem_bits <= esplocal::REG_MAX_REM && runs_fit && h->force_path != 3 &&
-                        h->force_path != 18 && !stop_env && !getenv("ESP_LOCAL_STAMPS");
+                        h->force_path != 18 && !stop_env;
     }
     for (int attempt = 0; attempt < 2; attempt++) {
     if (attempt == 1) {  // (the small variant met a long column run)

@@ -417,17 +417,21 @@ __device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval,
 
 // ---- two-level look-back, run by ONE wave --------------------------------------------------------------
 // A segment's output offset = the emitted entries of all segments with a lower ticket.  Segments are taken in groups
-// of 64 consecutive tickets:
+// of LB_GROUP = 256 consecutive tickets:
 //   status[s]   = AGG | total of segment s                 (published as soon as the total is known)
 //   gstatus[g]  = PRE | total of the groups 0..g            (published by the LAST segment of group g)
 //   offset(s)   = gstatus[g-1] + the totals of the segments of its own group in front of it
-// i.e. ONE 64-wide poll of the own group (its members hold neighbouring tickets: they publish at about the same
-// time) and ONE granule of the previous group, whose last segment started 64 tickets earlier.  The chain that
-// remains is over groups only -- a link is one poll long, the groups start several polls apart -- where the linear
-// decoupled look-back of round 1 walked back over every segment in flight (446 at 256^3: seven dependent 64-wide
-// polls, 4.5 us per segment).  Granules: 8 bytes {flag, value}, relaxed agent-scope atomics on both sides (MI355X L2s
-// are per XCD), spins bounded (a timeout surfaces as ESP_ERR_HIP); a segment waits for lower tickets only, and
-// tickets are drawn in start order: no deadlock.
+// i.e. ONE round of polls of the own group (up to four 64-wide loads in flight together; its members hold
+// neighbouring tickets: they publish at about the same time) and ONE granule of the previous group, whose last
+// segment started 256 tickets earlier.  The chain that remains is over groups only: a link is one cross-XCD round
+// trip (about 1.5 us), and there are S/256 of them -- with groups of 64 the 1024 links of a 256^3 flush added up to
+// the kernel's whole run time once three workgroups per CU were resident (look-back 8.6 us per segment); a decoupled
+// look-back over the group granules instead (64 granule loads per poll and segment) was slower still.  The linear
+// decoupled look-back of round 1 walked back over every segment in flight (seven dependent polls).  Granules: 8 bytes
+// {flag, value}, relaxed agent-scope atomics on both sides (MI355X L2s are per XCD), spins bounded (a timeout surfaces
+// as ESP_ERR_HIP); a segment waits for lower tickets only, and tickets are drawn in start order: no deadlock.
+constexpr int LB_SHIFT = 8;
+constexpr int LB_GROUP = 1 << LB_SHIFT;
 struct LbState {
     u64 group_part;  // totals of the own group's segments in front of this one
     u64 prefix;      // gstatus of the previous group
@@ -437,27 +441,40 @@ struct LbState {
 __device__ __forceinline__ void lb_init(LbState &st, int s) {
     st.group_part = 0;
     st.prefix = 0;
-    st.have_part = (s & 63) == 0;   // first of its group: nobody in front
-    st.have_prefix = (s >> 6) == 0; // first group: no previous one
+    st.have_part = (s & (LB_GROUP - 1)) == 0;  // first of its group: nobody in front
+    st.have_prefix = (s >> LB_SHIFT) == 0;     // first group: no previous one
     st.finished = st.have_part && st.have_prefix;
     st.spins = 0;
 }
+__device__ __forceinline__ bool lb_last_of_group(const Args &a, int s) { return (s & (LB_GROUP - 1)) == LB_GROUP - 1 || s == a.S - 1; }
 // at most `iters` polls (block: until resolved)
 __device__ __forceinline__ void lb_poll(const Args &a, LbState &st, int s, int lane, u32 iters, bool block) {
-    const int g = s >> 6, gbase = g << 6, need = s - gbase;
+    const int g = s >> LB_SHIFT, gbase = g << LB_SHIFT, need = s - gbase;
     while (!st.finished && (block || iters-- > 0)) {
         bool progress = false;
-        u64 v = ST_AGG;  // lanes beyond the segments in front act as ready zeros
+        u64 v[LB_GROUP / 64];
         u64 gp = ST_PRE;
-        // both granule loads of a round are in flight together
-        if (!st.have_part && lane < need) v = __hip_atomic_load(&a.status[gbase + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        // all granule loads of a round are in flight together (lanes beyond the segments in front: ready zeros)
+#pragma unroll
+        for (int c = 0; c < LB_GROUP / 64; c++) {
+            v[c] = ST_AGG;
+            if (!st.have_part && c * 64 + lane < need)
+                v[c] = __hip_atomic_load(&a.status[gbase + c * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
         if (!st.have_prefix && lane == 0) gp = __hip_atomic_load(&a.gstatus[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (!st.have_part) {
-            if (__ballot((v >> 62) == 0) == 0ull) {
-                // (totals are < 2^32 each and 64 of them < 2^38: two 32-bit DPP sums)
-                const u32 lo = esp_wave_sum((u32)(v & 0xFFFFFFFFull));
-                const u32 hi = esp_wave_sum((u32)((v & ST_VAL) >> 32));
-                st.group_part = ((u64)hi << 32) + (u64)lo;
+            bool miss = false;
+            u64 sum = 0;
+#pragma unroll
+            for (int c = 0; c < LB_GROUP / 64; c++) {
+                miss = miss || (v[c] >> 62) == 0;
+                sum += v[c] & ST_VAL;
+            }
+            if (__ballot(miss) == 0ull) {
+                // (totals are < 2^32 each and 256 of them < 2^40: two 32-bit DPP sums of the per-lane sums' halves)
+                const u32 lo = esp_wave_sum((u32)(sum & 0xFFFFFFull));
+                const u32 hi = esp_wave_sum((u32)(sum >> 24));
+                st.group_part = ((u64)hi << 24) + (u64)lo;
                 st.have_part = true;
                 progress = true;
             }
@@ -491,8 +508,8 @@ __device__ __forceinline__ u64 lb_complete(const Args &a, LbState &st, int s, u3
     lb_poll(a, st, s, lane, 0, true);
     const u64 excl = st.prefix + st.group_part;
     if (lane == 0) {
-        if ((s & 63) == 63 || s == a.S - 1)
-            __hip_atomic_store(&a.gstatus[s >> 6], ST_PRE | ((excl + (u64)total) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (lb_last_of_group(a, s))
+            __hip_atomic_store(&a.gstatus[s >> LB_SHIFT], ST_PRE | ((excl + (u64)total) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         // the last segment leaves the grand total where the host reads it (nobody polls its granule)
         if (s == a.S - 1) __hip_atomic_store(&a.status[s], ST_PRE | ((excl + (u64)total) & ST_VAL), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
@@ -505,7 +522,7 @@ __device__ __forceinline__ u64 lookback_wave(const Args &a, int s, u32 total, in
 }
 // a segment that emits nothing and is not the last of its group has no use for its offset: it publishes its zero total
 // and leaves (the group's last segment always resolves, so the chain over the groups never breaks)
-__device__ __forceinline__ bool lb_may_skip(const Args &a, int s) { return (s & 63) != 63 && s != a.S - 1; }
+__device__ __forceinline__ bool lb_may_skip(const Args &a, int s) { return !lb_last_of_group(a, s); }
 
 // Register tier of the bucket kernel: one lane per column, the whole run (<= R entries) in registers.
 // Returns true when the look-back already ran (early publication of the segment total).
