@@ -2172,10 +2172,10 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
             h->ones_pending = false;
         }
     };
-    // The small variant of the bucket kernel (3 workgroups per CU) serves a fresh, unsharded build whose segments hold
-    // at most 3072 entries over at most 256 columns with column runs the register tiers take; a segment with a longer
-    // run raises err bit 8 (it cannot know before it counts) and the flush runs again with the regular kernel -- only
-    // scratch arrays were written.  force_path 18: never.
+    // The small variant of the bucket kernel (3 workgroups per CU) serves segments of at most 3072 entries over at most
+    // 256 columns whose column runs the register tiers take; a segment with longer runs (it cannot know before it counts)
+    // goes through the variant's slow tier, and what it reports sends the next flushes to the regular kernel.
+    // force_path 18: never.
     bool small_variant = false;
     {
         const int clb = st.rem_bits - h->L.rb;
@@ -2183,14 +2183,9 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         // on average -- a stencil's 12, not a 3-D FEM mesh's 120)
         const double per_col = (double)h->count / (double)std::max<i64>(col_end - col_begin, 1);
         const bool runs_fit = h->seen_maxrun > 0 ? h->seen_maxrun <= esplocal::REG_RUN : per_col <= 16.0;
-        small_variant = Z0 == 0 && st.maxlen <= 6 * esplocal::THREADS && clb >= 0 && clb <= 8 &&
+        small_variant = st.maxlen <= 6 * esplocal::THREADS && clb >= 0 && clb <= 8 &&
                         st.rem_bits <= esplocal::REG_MAX_REM && runs_fit && h->force_path != 3 &&
                         h->force_path != 18 && !stop_env;
-    }
-    for (int attempt = 0; attempt < 2; attempt++) {
-    if (attempt == 1) {  // (the small variant met a long column run)
-        small_variant = false;
-        HIPCK(h, hipMemsetAsync(status, 0, sizeof(u64) * (size_t)(S + 2 + G), h->stream));
     }
     h->last_local_small = small_variant ? 1 : 0;
     {
@@ -2248,29 +2243,24 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
             const int keys = st.npieces > 0 ? (st.all_update && h->force_path != 15 ? 3 : 0)
                                             : st.key_bytes != 4 ? 0 : (st.kind == ESP_UPDATE && h->force_path != 15 ? 2 : 1);
             h->last_fold_update = keys >= 2 ? 1 : 0;
+#define ESP_LAUNCH_SMALL(F, P, B, K) hipLaunchKernelGGL((esplocal::local_k<F, P, B, K, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a)
+#define ESP_LAUNCH_SMALL_FB(P, K)                                                              \
+    do {                                                                                       \
+        if (Z0 == 0) { if (big) ESP_LAUNCH_SMALL(true, P, true, K); else ESP_LAUNCH_SMALL(true, P, false, K); }   \
+        else { if (big) ESP_LAUNCH_SMALL(false, P, true, K); else ESP_LAUNCH_SMALL(false, P, false, K); }         \
+    } while (0)
             if (small_variant && st.npieces > 0) {
-                if (keys == 3) {
-                    if (big) hipLaunchKernelGGL((esplocal::local_k<true, true, true, 3, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
-                    else hipLaunchKernelGGL((esplocal::local_k<true, true, false, 3, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
-                } else {
-                    if (big) hipLaunchKernelGGL((esplocal::local_k<true, true, true, 0, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
-                    else hipLaunchKernelGGL((esplocal::local_k<true, true, false, 0, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
-                }
+                if (keys == 3) ESP_LAUNCH_SMALL_FB(true, 3); else ESP_LAUNCH_SMALL_FB(true, 0);
+            } else if (small_variant) {
+                if (keys == 2) ESP_LAUNCH_SMALL_FB(false, 2);
+                else if (keys == 1) ESP_LAUNCH_SMALL_FB(false, 1);
+                else ESP_LAUNCH_SMALL_FB(false, 0);
             } else if (st.npieces > 0 && keys == 3) {
                 if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 3); else ESP_LAUNCH_LOCAL(true, true, false, 3); }
                 else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 3); else ESP_LAUNCH_LOCAL(false, true, false, 3); }
             } else if (st.npieces > 0) {
                 if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 0); else ESP_LAUNCH_LOCAL(true, true, false, 0); }
                 else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 0); else ESP_LAUNCH_LOCAL(false, true, false, 0); }
-            } else if (small_variant && keys == 2) {
-                if (big) hipLaunchKernelGGL((esplocal::local_k<true, false, true, 2, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
-                else hipLaunchKernelGGL((esplocal::local_k<true, false, false, 2, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
-            } else if (small_variant && keys == 1) {
-                if (big) hipLaunchKernelGGL((esplocal::local_k<true, false, true, 1, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
-                else hipLaunchKernelGGL((esplocal::local_k<true, false, false, 1, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
-            } else if (small_variant) {
-                if (big) hipLaunchKernelGGL((esplocal::local_k<true, false, true, 0, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
-                else hipLaunchKernelGGL((esplocal::local_k<true, false, false, 0, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a);
             } else if (keys == 2) {
                 if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, false, true, 2); else ESP_LAUNCH_LOCAL(true, false, false, 2); }
                 else { if (big) ESP_LAUNCH_LOCAL(false, false, true, 2); else ESP_LAUNCH_LOCAL(false, false, false, 2); }
@@ -2283,15 +2273,15 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
                 if (big) ESP_LAUNCH_LOCAL(false, false, true, 0); else ESP_LAUNCH_LOCAL(false, false, false, 0);
             }
 #undef ESP_LAUNCH_LOCAL
+#undef ESP_LAUNCH_SMALL
+#undef ESP_LAUNCH_SMALL_FB
         }
         sp.add(1);
     }
     HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (S - 1), 24, hipMemcpyDeviceToHost, h->stream));  // last granule | ticket, err | maxrun
     HIPCK(h, hipMemcpyAsync(h->pin_scalar + 3, (u32 *)h->misc.p + 60, 4, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
-    if (small_variant && ((u32)(h->pin_scalar[1] >> 32) & 8u)) continue;
-    break;
-    }
+
     if ((u32)h->pin_scalar[3]) {
         restore_colptr();
         FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window");

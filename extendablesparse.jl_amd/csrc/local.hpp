@@ -415,6 +415,51 @@ __device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval,
         if (j >= e && j < len) skey[rs + j] = NOREC;
 }
 
+// The same fold for a run of ANY length that lies sorted in LDS (skey[rs .. rs+len)): the slow tier of the small
+// kernel variant.  Records go to the run's front (a record is written behind the keys already read), NOREC behind them.
+template <bool NOCSC, bool UPD>
+__device__ __forceinline__ void fold_run_lds(const Args &a, u64 *skey, double *sval, int rs, int len, u64 hi, u64 rowmask) {
+    int e = 0;
+    bool present = false;
+    double acc = 0.0;
+    u64 psub = 0;
+    u32 idx0 = 0;
+    i64 pos = -1;
+    i64 ccur = 0, cend = 0;
+    if (!NOCSC && a.csc.nnz > 0 && len > 0) {
+        const i64 col0 = (i64)((hi + (skey[rs] >> SUB_SHIFT)) >> a.rb);
+        ccur = a.csc.colptr[col0] - 1;
+        cend = a.csc.colptr[col0 + 1] - 1;
+    }
+    for (int j = 0; j <= len; j++) {
+        const bool valid = j < len;
+        const u64 kj = valid ? skey[rs + j] : NOREC;
+        const u64 sub = kj >> SUB_SHIFT;
+        const bool fresh = j == 0 || !valid || sub != psub;
+        if (fresh && j > 0) close_group(a, skey, sval, rs, e, pos, present, acc, psub, idx0);
+        if (valid) {
+            if (fresh) {
+                psub = sub;
+                idx0 = (u32)(kj >> ESP_TAG_BITS) & (CAP - 1);
+                pos = -1;
+                if (ccur < cend) {
+                    const i64 want = (i64)((hi + sub) & rowmask) + 1;
+                    while (ccur < cend && a.csc.rowval[ccur] < want) ccur++;
+                    if (ccur < cend && a.csc.rowval[ccur] == want) pos = ccur;
+                }
+                present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
+                acc = present ? a.csc.nzval[pos] : 0.0;
+            }
+            const double v = sval[(kj >> ESP_TAG_BITS) & (CAP - 1)];
+            if constexpr (UPD)
+                espfold::fold_step_update(present, acc, v);
+            else
+                espfold::fold_step_sel(present, acc, (u32)(kj & ESP_TAG_MASK), v);
+        }
+    }
+    for (int j = e; j < len; j++) skey[rs + j] = NOREC;
+}
+
 // ---- two-level look-back, run by ONE wave --------------------------------------------------------------
 // A segment's output offset = the emitted entries of all segments with a lower ticket.  Segments are taken in groups
 // of LB_GROUP = 256 consecutive tickets:
@@ -589,15 +634,15 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
 // share one kind); 2 = the same and that kind is UPDATE (an assembly loop of updateindex! calls): the register
 // tiers fold without decoding a kind; 3 = packed keys whose kinds are all UPDATE (the pieces of a shard whose
 // received blocks were checked): the same fold
-// SMALL: segments of at most 3072 entries (6 per thread) over at most 256 columns, register tiers only: 51 KiB of LDS
-// instead of 74, i.e. THREE workgroups per CU (measured at 256^3: one workgroup per CU 2.70 ms, two 1.70 ms).  A segment
-// that turns out to need the radix tier raises err bit 8 and emits nothing; the host then runs the flush again with
-// the regular kernel -- nothing but scratch arrays was written (fresh matrix only: no stored value is ever touched).
+// SMALL: segments of at most 3072 entries (6 per thread) over at most 256 columns, no radix tier: 51 KiB of LDS instead
+// of 74, i.e. THREE workgroups per CU (measured at 256^3: one workgroup per CU 2.70 ms, two 1.70 ms, three 1.48 ms).
+// The host picks it from what it knows before the flush; a segment whose column runs turn out longer than the register
+// tiers take is served by a slow tier (one lane per column: insertion sort of its run in LDS, sequential fold), and
+// the longest run it reports sends the handle's next flushes to the regular kernel.
 template <bool FRESH, bool PIECES, bool BIG, int KEYS, bool SMALL = false>
 __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     constexpr bool K32 = KEYS == 1 || KEYS == 2, UPD = KEYS >= 2;
     static_assert(!(PIECES && K32), "pieces arrive as packed keys");
-    static_assert(!SMALL || FRESH, "the small variant serves fresh builds (a run again must find every stored value untouched)");
     constexpr int NI = SMALL ? 6 : ITEMS;
     constexpr int CAPK = THREADS * NI;
     __shared__ u64 skey[CAPK];
@@ -849,17 +894,36 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
                     lb_done = reg_tier<REG_RUN, FRESH, UPD>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
                 done = true;
             }
+        } else if constexpr (SMALL) {
+            if (!done) {
+                // slow tier of the small variant (column runs longer than the register tiers take; the host sends the
+                // handle's next flushes to the regular kernel): one lane per column sorts its run in LDS by insertion
+                // -- keys are unique: sub-key | slot index | kind -- and folds it sequentially
+#pragma unroll
+                for (int i = 0; i < NI; i++)
+                    if (wbase + i * ESP_WAVE < n) skey[ccnt[(u32)(k[i] >> csh)] + slot[i]] = k[i];
+                __syncthreads();
+                for (int c = t; c < ncl; c += THREADS) {
+                    const int rs = (int)ccnt[c];
+                    const int len = (int)ccnt[c + 1] - rs;
+                    for (int i = 1; i < len; i++) {
+                        const u64 x = skey[rs + i];
+                        int j = i - 1;
+                        while (j >= 0 && skey[rs + j] > x) {
+                            skey[rs + j + 1] = skey[rs + j];
+                            j--;
+                        }
+                        skey[rs + j + 1] = x;
+                    }
+                    fold_run_lds<FRESH, UPD>(a, skey, sval, rs, len, hi, rowmask);
+                }
+                done = true;
+            }
         }
         __syncthreads();  // records are in place (or: ccnt storage is free for the radix counters)
     }
 
-    if constexpr (SMALL) {
-        if (!done) {  // (long column runs / too many key bits for the register tiers: not this variant's business)
-            if (t == 0) atomicOr(a.err, 8u);
-            for (int q = t; q < CAPK; q += THREADS) skey[q] = NOREC;  // the segment emits nothing
-            __syncthreads();
-        }
-    } else
+    if constexpr (!SMALL)
     if (!done) {
         // ---- radix tier (long runs / wide column ranges): stable LSD sort of all remaining bits
         const int npass = radix_tail(k, skey, cnt, lw, a.rem_bits, t, lane, w, wbase, n, reinterpret_cast<u64 *>(s_win));

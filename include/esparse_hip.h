@@ -342,9 +342,10 @@ int32_t esp_debug_last_key_bytes(const esp_handle *h, int32_t *bytes);
 /* 1 when the register tiers of the last flush's bucket kernel ran the UPDATE-only fold (every entry known to be an
  * updateindex! call: the batch's bookkeeping, for a shard also a device check of the received blocks) */
 int32_t esp_debug_last_fold_update(const esp_handle *h, int32_t *on);
-/* 1 when the bucket kernel of the last flush was its small variant: a fresh, unsharded build whose segments hold at most
- * 3072 entries over at most 256 columns, register tiers only, 51 KiB of LDS = three workgroups per CU instead of two (a
- * segment that needs the radix tier makes the flush run again with the regular kernel); esp_debug_force_path(18): never */
+/* 1 when the bucket kernel of the last flush was its small variant: segments of at most 3072 entries over at most 256
+ * columns, no radix tier, 51 KiB of LDS = three workgroups per CU instead of two (column runs longer than its register
+ * tiers take go through a slow tier and send the handle's next flushes to the regular kernel); esp_debug_force_path(18):
+ * never */
 int32_t esp_debug_last_local_small(const esp_handle *h, int32_t *small);
 /* which partition the last flush used: 1 = run-based single pass (pre-sorted stream), 2 = 8-bit passes,
  * 4 = none: the producer wrote every entry straight to its bucket (esp_generate_* on an empty buffer: a COUNT launch

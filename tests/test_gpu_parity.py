@@ -1687,29 +1687,51 @@ def test_join_dense_columns_empty_columns_and_rectangular(esp, orc, force):
     assert_csc_equal(got.arrays(), want.arrays())
 
 
-def test_small_bucket_kernel_gives_up_on_long_runs(esp, orc):
-    """The small variant of the bucket kernel (three workgroups per CU: register tiers only) is chosen from what the
-    host knows BEFORE the flush (a fresh build, segments of at most 3072 entries over at most 256 columns); a segment
-    whose column runs are longer than the register tiers take raises a flag, emits nothing, and the flush runs again
-    with the regular kernel: same bits as the oracle, on the first flush of a handle and on later ones."""
+def test_small_bucket_kernel_slow_tier_on_long_runs(esp, orc):
+    """The small variant of the bucket kernel (three workgroups per CU, no radix tier) is chosen from what the host
+    knows BEFORE the flush (segments of at most 3072 entries over at most 256 columns, few entries per column on average
+    or what the handle's last flush saw).  Column runs longer than its register tiers take go through its slow tier
+    (insertion sort of the run in LDS + sequential fold) and send the handle's next flushes to the regular kernel: the
+    oracle's bits both times, on a fresh matrix and over a stored pattern."""
     rng = np.random.default_rng(31)
-    m, n = 2 ** 20, 60000
-    for per_col in (40, 90):
-        A = esp.ExtendableSparseMatrix(m, n)
-        O = orc.ExtendableSparseMatrix(m, n)
-        for rnd in range(2):
-            ncols_used = 6000       # (few entries per column on average: a handle without history tries the variant)
-            cols = np.sort(rng.choice(n, ncols_used, replace=False)) + 1
-            J = np.repeat(cols, per_col)
-            # a few rows per column, many duplicates: long column runs, few records
-            I = np.clip(J[:, None] * 7 % m + rng.integers(0, 5, (len(J), 1)), 1, m).ravel()
-            V = rng.standard_normal(len(J))
-            A.reset()
-            O = orc.ExtendableSparseMatrix(m, n)
+    m, n = 2 ** 20, 2 ** 16
+    A = esp.ExtendableSparseMatrix(m, n)
+    O = orc.ExtendableSparseMatrix(m, n)
+    per_col, ncols_used = 50, 19000
+    for rnd in range(3):
+        cols = np.sort(rng.choice(n, ncols_used, replace=False)) + 1
+        J = np.repeat(cols, per_col)
+        # a few rows per column, many duplicates: long column runs, few records
+        I = np.clip(J[:, None] * 7 % m + rng.integers(0, 5, (len(J), 1)), 1, m).ravel()
+        V = rng.standard_normal(len(J))
+        kinds = rng.integers(0, 3, len(J)).astype(np.uint8) if rnd == 2 else np.full(len(J), UPDATE, np.uint8)
+        if rnd == 2:
+            A.append(0, I, J, V, kinds=kinds)
+        else:
             A.append(UPDATE, I, J, V)
-            O.apply(np.full(len(I), UPDATE, np.uint8), I, J, V)
-            A.flush()
-            O.flush()
-            assert A.debug_last_path() == 1
-            assert A.debug_last_local_small() == 0      # (first flush: tried and gave up; second: not tried)
-            assert_csc_equal(hip_arrays(A), O.arrays(), "per_col %d round %d" % (per_col, rnd))
+        O.apply(kinds, I, J, V)
+        A.flush()
+        O.flush()
+        assert A.debug_last_path() == 1
+        # first flush: no history, 14 entries per column on average -> the small variant, whose slow tier serves the
+        # runs of 50; it reports them, so the later flushes (over the stored pattern) take the regular kernel
+        assert A.debug_last_local_small() == (1 if rnd == 0 else 0), (rnd, A.debug_last_local_small())
+        assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
+    # the same through the routed fold of the small variant: a stored pattern, short runs, then one flush with long runs
+    B = esp.ExtendableSparseMatrix(m, n)
+    Ob = orc.ExtendableSparseMatrix(m, n)
+    used = []
+    for rnd, pc in enumerate((8, 8, 50)):
+        cols = np.sort(rng.choice(n, 60000 if pc == 8 else 19000, replace=False)) + 1
+        J = np.repeat(cols, pc)
+        I = np.clip(J[:, None] * 7 % m + rng.integers(0, 5, (len(J), 1)), 1, m).ravel()
+        V = rng.standard_normal(len(J))
+        B.append(UPDATE, I, J, V)
+        Ob.apply(np.full(len(J), UPDATE, np.uint8), I, J, V)
+        B.flush()
+        Ob.flush()
+        used.append(B.debug_last_local_small())
+        assert_csc_equal(hip_arrays(B), Ob.arrays(), "routed round %d" % rnd)
+    # (the partition plan of a later flush may cut wider segments than the small variant takes; the first flush and the
+    # one with the long runs -- history says short runs -- use it)
+    assert used[0] == 1 and used[2] == 1, used
