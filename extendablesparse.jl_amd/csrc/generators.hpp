@@ -233,11 +233,13 @@ __global__ __launch_bounds__(THREADS) void fd_count_k(FdArgs a, esprun::RunSink 
         rc[threadIdx.x] = 0;
     }
     if (threadIdx.x == 0) over = 0;
-    // a stream that is not pre-sorted is recognised by the first workgroups: the rest leave at once
-    if (__hip_atomic_load(sink.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
-    __syncthreads();
+    // a stream that is not pre-sorted is recognised by the first workgroups: the rest leave at once (the flag is
+    // requested first and looked at after the node's items are formed: its round trip is not waited for)
+    const u32 give_up = __hip_atomic_load(sink.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     FdItems it;
     fd_items(a, a.g_begin + (i64)blockIdx.x * THREADS + threadIdx.x, it, err);
+    if (give_up != 0u) return;
+    __syncthreads();
     esprun::count_runs_weighted<4>(it.dig, it.wt, a.part.chunk_base + blockIdx.x, sink, rd, rc, &over);
 }
 
