@@ -2182,7 +2182,9 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         // (what the handle's last flush saw decides; a handle without history tries it when the columns hold few entries
         // on average -- a stencil's 12, not a 3-D FEM mesh's 120)
         const double per_col = (double)h->count / (double)std::max<i64>(col_end - col_begin, 1);
-        const bool runs_fit = h->seen_maxrun > 0 ? h->seen_maxrun <= esplocal::REG_RUN : per_col <= 16.0;
+        // (runs of 17..24 want the 24-input network, which does not fit the variant's 80 registers: measured 4.7 against
+        // 4.0 ms on 2-D FEM)
+        const bool runs_fit = h->seen_maxrun > 0 ? h->seen_maxrun <= 16 : per_col <= 16.0;
         small_variant = st.maxlen <= 6 * esplocal::THREADS && clb >= 0 && clb <= 8 &&
                         st.rem_bits <= esplocal::REG_MAX_REM && runs_fit && h->force_path != 3 &&
                         h->force_path != 18 && !stop_env;
@@ -2246,8 +2248,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
 #define ESP_LAUNCH_SMALL(F, P, B, K) hipLaunchKernelGGL((esplocal::local_k<F, P, B, K, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a)
 #define ESP_LAUNCH_SMALL_FB(P, K)                                                              \
     do {                                                                                       \
-        if (Z0 == 0) { if (big) ESP_LAUNCH_SMALL(true, P, true, K); else ESP_LAUNCH_SMALL(true, P, false, K); }   \
-        else { if (big) ESP_LAUNCH_SMALL(false, P, true, K); else ESP_LAUNCH_SMALL(false, P, false, K); }         \
+        if (Z0 == 0) ESP_LAUNCH_SMALL(true, P, false, K); else ESP_LAUNCH_SMALL(false, P, false, K);   \
     } while (0)
             if (small_variant && st.npieces > 0) {
                 if (keys == 3) ESP_LAUNCH_SMALL_FB(true, 3); else ESP_LAUNCH_SMALL_FB(true, 0);
