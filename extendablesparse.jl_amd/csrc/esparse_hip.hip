@@ -561,6 +561,10 @@ extern "C" int32_t esp_nnz(const esp_handle *h, int64_t *nnz) {
 
 // ------------------------------------------------------------------------ append
 static int32_t reserve_append(esp_handle *h, i64 add) {
+    // between esp_shard_assemble and esp_flush the pending entries are spread over the caller's receive buffers
+    // (the handle's count is their logical total): nothing can be appended behind them
+    if (h->part_assembled)
+        FAIL(h, ESP_ERR_STATE, "append: the pending entries are assembled shard pieces (esp_shard_assemble): esp_flush first");
     CK(pending_materialize(h));  // (an append behind a bucket-ordered batch: back to packed keys first)
     const i64 need = h->count + add;
     if (need <= h->cap) return ESP_OK;

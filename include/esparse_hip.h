@@ -244,7 +244,8 @@ int32_t esp_shard_exchange_place(esp_handle *h, int64_t position, const uint64_t
  *     values).  The buffers must stay alive until esp_flush returns: the bucket kernel reads a segment
  *     as the concatenation of one piece per source (rank order), nothing is copied.  *ok = 0: a merged
  *     segment is too long for the bucket kernel; the entries were copied into a plain pending buffer
- *     (rank order) instead and esp_flush works as usual.
+ *     (rank order) instead and esp_flush works as usual.  *ok = 1: until that esp_flush no append is accepted
+ *     (ESP_ERR_STATE): the pending entries live in the caller's receive buffers.
  * esp_set_column_window(own column range) must be in force, as for the other exchange. */
 int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t self, int64_t entries_per_shard,
                             int32_t *ok, uint64_t **d_keys, double **d_vals, int64_t **d_counts,

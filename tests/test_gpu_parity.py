@@ -1735,3 +1735,33 @@ def test_small_bucket_kernel_slow_tier_on_long_runs(esp, orc):
     # (the partition plan of a later flush may cut wider segments than the small variant takes; the first flush and the
     # one with the long runs -- history says short runs -- use it)
     assert used[0] == 1 and used[2] == 1, used
+
+
+def test_no_append_between_shard_assemble_and_flush(esp, orc):
+    """Between esp_shard_assemble and esp_flush the pending entries are the caller's receive buffers (the handle's count
+    is their logical total): an append must be refused (ESP_ERR_STATE), the flush afterwards gives the oracle's bits."""
+    import ctypes as C
+    n = 48
+    N = n ** 3
+    A = esp.ExtendableSparseMatrix(N, N)
+    d = A._d
+    A.generate_fdrand(n, n, n, seed=9, rand_mode=1)
+    E = A.nnznew()
+    ok = C.c_int32()
+    pk, pv, pc = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    eoff = np.zeros(2, np.int64)
+    nb = C.c_int64()
+    d.ck(d.lib.esp_set_column_window(d.h, 1, N))
+    d.ck(d.lib.esp_shard_partition(d.h, 1, 0, E, C.byref(ok), C.byref(pk), C.byref(pv), C.byref(pc),
+                                   eoff.ctypes.data_as(C.c_void_p), C.byref(nb)))
+    assert ok.value == 1 and eoff[1] == E
+    none = (C.c_void_p * 1)()
+    ne = np.zeros(1, np.int64)
+    d.ck(d.lib.esp_shard_assemble(d.h, none, none, none, ne.ctypes.data_as(C.c_void_p), C.byref(ok)))
+    assert ok.value == 1
+    with pytest.raises(esp.EspError):
+        A.append(UPDATE, [1], [1], [1.0])
+    A.flush()
+    assert A.debug_last_partition() == 7
+    O = orc.fdrand(n, n, n, rand_mode=1, seed=9, style=orc.KIND_UPDATE)
+    assert_csc_equal(hip_arrays(A), O.arrays())
