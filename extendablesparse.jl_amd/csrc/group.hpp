@@ -311,8 +311,8 @@ static int32_t group_exchange_partitioned(esp_group *g, bool *done) {
     CK(ensure(h, g->rkeys, sizeof(u64) * (size_t)std::max<i64>(nrecv, 1)));
     CK(ensure(h, g->rvals, sizeof(double) * (size_t)std::max<i64>(nrecv, 1)));
     CK(ensure(h, g->rcnts, sizeof(i64) * (size_t)P * (size_t)std::max<i64>(nb, 1)));
-    // keys, values and counts of a pair travel in ONE grouped launch (stream-ordered behind the partition's scatter
-    // kernel: no host synchronisation)
+    // three grouped launches -- keys, values, counts -- each with every pair's send and receive, stream-ordered behind
+    // the partition's scatter kernel: no host synchronisation
     std::vector<const void *> sp((size_t)P, nullptr);
     std::vector<void *> rp((size_t)P, nullptr);
     std::vector<i64> sb((size_t)P, 0), rb((size_t)P, 0);

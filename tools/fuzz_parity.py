@@ -26,7 +26,71 @@ rng = np.random.default_rng(seed)
 t_end = time.time() + budget
 cases = 0
 paths = {}
+def generator_case():
+    """Device-side producers: the producer-side partition (append = partition), its fall-backs and what follows it --
+    a second producer call, a host append, a flush over the stored pattern -- on grids whose lines and planes do not line
+    up with the 256-node chunks."""
+    shape = rng.choice(["cube", "slab", "line", "plane"])
+    if shape == "cube":
+        nx, ny, nz = (int(rng.integers(20, 90)) for _ in range(3))
+    elif shape == "slab":
+        nx, ny, nz = int(rng.integers(2, 9)), int(rng.integers(100, 600)), int(rng.integers(100, 600))
+    elif shape == "line":
+        nx, ny, nz = int(rng.integers(300000, 2000000)), 1, 1
+    else:
+        nx, ny, nz = int(rng.integers(300, 1500)), int(rng.integers(300, 1500)), 1
+    N = nx * ny * nz
+    if N > 3000000:
+        return None
+    force = int(rng.choice([0, 0, 0, 14, 15, 16, 18, 13, 4]))
+    kind = int(rng.choice([1, 1, 2]))
+    mode = int(rng.choice([0, 1, 2]))
+    A = esp.ExtendableSparseMatrix(N, N)
+    A.debug_force_path(force)
+    O = orc.ExtendableSparseMatrix(N, N)
+    nrounds = int(rng.integers(1, 4))
+    for rnd in range(nrounds):
+        seed = int(rng.integers(1, 1 << 30))
+        I, J, V = orc.fdrand_stream(nx, ny, nz, rand_mode=mode, seed=seed)
+        kk = np.full(len(I), kind, np.uint8)
+        how = rng.choice(["whole", "two_calls", "host_after", "host_before"])
+        if how == "whole":
+            A.generate_fdrand(nx, ny, nz, seed=seed, rand_mode=mode, kind=kind)
+            O.apply(kk, I, J, V)
+        elif how == "two_calls":
+            cut_node = int(rng.integers(1, N)) if N > 1 else 0
+            A.generate_fdrand_range(nx, ny, nz, 0, cut_node, seed=seed, rand_mode=mode, kind=kind)
+            A.generate_fdrand_range(nx, ny, nz, cut_node, N, seed=seed, rand_mode=mode, kind=kind)
+            O.apply(kk, I, J, V)
+        else:
+            cnt = int(rng.choice([1, 7, 5000]))
+            Ih, Jh, Vh = rng.integers(1, N + 1, cnt), rng.integers(1, N + 1, cnt), rng.standard_normal(cnt)
+            kh = rng.integers(0, 3, cnt).astype(np.uint8)
+            if how == "host_before":
+                A.append(0, Ih, Jh, Vh, kinds=kh)
+                O.apply(kh, Ih, Jh, Vh)
+            A.generate_fdrand(nx, ny, nz, seed=seed, rand_mode=mode, kind=kind)
+            O.apply(kk, I, J, V)
+            if how == "host_after":
+                A.append(0, Ih, Jh, Vh, kinds=kh)
+                O.apply(kh, Ih, Jh, Vh)
+        A.flush()
+        O.flush()
+        key = ("gen", A.debug_last_partition(), A.debug_last_key_bytes(), A.debug_last_local_small())
+        paths[key] = paths.get(key, 0) + 1
+        try:
+            assert_csc_equal(A.sparse().arrays(), O.arrays())
+        except AssertionError:
+            print("MISMATCH seed", seed, "generator case", dict(nx=nx, ny=ny, nz=nz, force=force, kind=kind, mode=mode, rnd=rnd, how=str(how)))
+            raise
+    return True
+
+
 while time.time() < t_end:
+    if rng.random() < 0.35 and os.environ.get("ESP_FUZZ_FOCUS") != "k32":
+        if generator_case():
+            cases += 1
+        continue
     n = int(rng.choice([1, 3, 64, 257, 5000, 70000, 400000]))
     m = int(rng.choice([1, 2, 100, 4097, 10 ** 6, 2 ** 31 - 1, 2 ** 33, 2 ** 40]))
     focus = os.environ.get("ESP_FUZZ_FOCUS") == "k32"   # few row bits, many columns: <= 32 key bits below the prefix
@@ -76,7 +140,8 @@ while time.time() < t_end:
                     O.apply(np.full(hi_ - lo_, kd, np.uint8), I[lo_:hi_], J[lo_:hi_], V[lo_:hi_])
         A.flush()
         O.flush()
-        key = (A.debug_last_path(), A.debug_last_partition(), A.debug_last_key_bytes(), int(A.debug_last_fold_update()))
+        key = (A.debug_last_path(), A.debug_last_partition(), A.debug_last_key_bytes(), int(A.debug_last_fold_update()),
+               A.debug_last_local_small())
         paths[key] = paths.get(key, 0) + 1
         try:
             assert_csc_equal(A.sparse().arrays(), O.arrays())
@@ -84,4 +149,4 @@ while time.time() < t_end:
             print("MISMATCH seed", seed, "case", cases, dict(m=m, n=n, force=force, flush=f, cnt=cnt, per_col=per_col, order=str(order)))
             raise
     cases += 1
-print("fuzz ok: cases", cases, "paths (pipeline, partition, key bytes, update-only fold):", paths)
+print("fuzz ok: cases", cases, "paths (pipeline, partition, key bytes, update-only fold, small bucket kernel | gen, partition, key bytes, small):", paths)
