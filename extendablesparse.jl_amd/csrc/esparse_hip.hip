@@ -66,6 +66,7 @@ struct esp_handle {
         int mw_P = 0, mw_me = 0, mw_shift = 0;
         u32 mw_nb = 0;
         i64 mw_eps = 0;
+        bool own32 = false;      // ... and the shard's OWN range holds 4-byte keys of kind `kind` (the sent ranges: packed)
     } pre;
     bool shard_user = false;     // the handle is driven through esp_shard_*: its flushes partition by owner first
     int last_shard_source = 0;   // esp_shard_partition: 1 = its own pass moved the entries, 2 = the producer had
@@ -113,6 +114,8 @@ struct esp_handle {
     // segment still fits the bucket kernel -- half-full segments cost that kernel up to 1.8x
     double seen_spread = 0.0;
     int last_fold_update = 0;    // the register tiers of the last flush ran their UPDATE-only fold
+    bool part_own32 = false;       // the own range of the partitioned buffer holds 4-byte keys (kind part_kind32)
+    int part_kind32 = 0;
     bool part_own_update = false;  // esp_shard_partition: every pending entry was appended as an UPDATE
     bool part_all_update = false;  // esp_shard_assemble: ... and so is every received entry (checked on the device)
     int last_run_order = 0;      // esp_debug_last_run_order
@@ -128,7 +131,7 @@ struct esp_handle {
     int part_P = 0, part_me = 0, part_shift = 0;
     u32 part_nb = 0;
     u64 part_base = 0, part_span = 0;
-    i64 part_total = 0, part_maxlen = 0;
+    i64 part_total = 0, part_maxlen = 0, part_own_lo = 0;
     DevBuf parttab, piecetab;
     // row-wise view of the device CSC for mul! (built on first use after a pattern change)
     unsigned long long pattern_version = 1, csr_version = 0;
@@ -1315,6 +1318,8 @@ struct Sorted {
     int key_bytes = 8;  // 4: sk holds 32-bit keys (the bits below the prefix); every entry has the kind `kind`
     int kind = 0;
     i64 maxlen = esplocal::CAP;  // longest segment
+    int p32_piece = -1;          // PIECES: the piece that holds 4-byte keys of kind `kind` from position p32_lo on
+    i64 p32_lo = 0;
     // PIECES (partitioned shard exchange): segments are concatenations of per-source pieces
     int npieces = 0;
     const i64 *pstart = nullptr;
@@ -1557,6 +1562,10 @@ static int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSet
     // (a shard's ranges travel to other ranks as packed keys: 4-byte keys only without windows)
     o.k32 = (!mw.ok && kind >= 0 && h->force_path != 14 && shift <= 32) ? 1 : 0;
     o.s32 = shift <= 32 ? 1 : 0;
+    // (a shard's own range never leaves the GPU: 4-byte keys there -- force_path 14: packed keys everywhere)
+    o.own32 = (mw.ok && kind >= 0 && h->force_path != 14 && shift <= 32) ? 1 : 0;
+    o.mw_me = ps->mw_me;
+    o.own_lo = (const i64 *)h->seg[1].p + (size_t)ps->mw_me * (size_t)ps->mw_nb;
     o.mw_P = mw.ok ? ps->mw_P : 0;
     o.mw_nb = ps->mw_nb;
     o.mw_base = (const u64 *)h->parttab.p;
@@ -1618,6 +1627,7 @@ static int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took) {
     pp.mw_shift = ps->mw_shift;
     pp.mw_nb = ps->mw_nb;
     pp.mw_eps = ps->mw_eps;
+    pp.own32 = ps->out.own32 != 0;
     *took = true;  // (the caller sets pre.valid once the entries are counted in)
     return ESP_OK;
 }
@@ -1626,6 +1636,30 @@ static int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took) {
 static int32_t pending_materialize(esp_handle *h) {
     if (!h->pre.valid) return ESP_OK;
     h->pre.valid = false;
+    h->part_own32 = false;
+    if (h->pre.mw_P > 0 && h->pre.own32 && h->count > 0) {
+        // a shard's batch: the own range holds 4-byte keys -> packed keys; the other ranges are copied as they are
+        const esp_handle::PrePart &pp = h->pre;
+        const i64 nb = (i64)pp.mw_nb, d0 = (i64)pp.mw_me * nb;
+        CK(ensure(h, h->keys2, std::max(h->keys.bytes, sizeof(u64) * (size_t)h->count)));
+        std::vector<i64> lohi(2);
+        HIPCK(h, hipMemcpyAsync(&lohi[0], (const i64 *)h->seg[1].p + d0, sizeof(i64), hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipMemcpyAsync(&lohi[1], (const i64 *)h->seg[1].p + d0 + nb, sizeof(i64), hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        const i64 lo = lohi[0], hi_ = lohi[1], E = pp.E;
+        Span sp(h, ESP_ST_COPY);
+        if (lo > 0) HIPCK(h, hipMemcpyAsync(h->keys2.p, h->keys.p, sizeof(u64) * (size_t)lo, hipMemcpyDeviceToDevice, h->stream));
+        if (E > hi_)
+            HIPCK(h, hipMemcpyAsync((u64 *)h->keys2.p + hi_, (const u64 *)h->keys.p + hi_, sizeof(u64) * (size_t)(E - hi_), hipMemcpyDeviceToDevice, h->stream));
+        const u64 base = (u64)shard_col0(h->n, pp.mw_P, pp.mw_me) << h->L.rb;
+        hipLaunchKernelGGL(esprun::expand_own_keys_k, dim3((unsigned)nb), dim3(esprun::THREADS), 0, h->stream, (const u64 *)h->keys.p,
+                           (const i64 *)h->seg[1].p, d0, pp.mw_shift, base, (u32)pp.kind, (u64 *)h->keys2.p);
+        sp.add(3);
+        HIPCK(h, hipGetLastError());
+        std::swap(h->keys, h->keys2);
+        h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
+        return ESP_OK;
+    }
     if (h->pre.key_bytes != 4 || h->count == 0) return ESP_OK;
     const esp_handle::PrePart &pp = h->pre;
     CK(ensure(h, h->keys2, std::max(h->keys.bytes, sizeof(u64) * (size_t)h->count)));
@@ -2196,8 +2230,10 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     h->last_local_small = small_variant ? 1 : 0;
     {
         Span sp(h, ESP_ST_LOCAL);
-        a.kind32 = (u32)(st.key_bytes == 4 ? st.kind : 0);
-        h->last_key_bytes = st.key_bytes;
+        a.kind32 = (u32)((st.key_bytes == 4 || st.p32_piece >= 0) ? st.kind : 0);
+        a.k32_piece = st.p32_piece;
+        a.k32_lo = st.p32_lo;
+        h->last_key_bytes = st.p32_piece >= 0 ? 4 : st.key_bytes;
         a.colptr_out = direct ? (i64 *)h->colptr.p : nullptr;
         a.col_end = col_end;
         a.n_cols = h->n;
@@ -2246,7 +2282,9 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
 #define ESP_LAUNCH_LOCAL(F, P, B, K) hipLaunchKernelGGL((esplocal::local_k<F, P, B, K>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a)
             // (key format: 0 packed, 1 four-byte keys of one kind, 2 four-byte keys that are all UPDATEs)
             // (3: packed keys whose kinds are all UPDATE -- the pieces of a shard)
-            const int keys = st.npieces > 0 ? (st.all_update && h->force_path != 15 ? 3 : 0)
+            // (4 / 5: pieces of which one -- a shard's own range -- holds 4-byte keys; 5: everything is an UPDATE)
+            const int keys = st.npieces > 0 ? (st.p32_piece >= 0 ? (st.all_update && h->force_path != 15 ? 5 : 4)
+                                                                 : (st.all_update && h->force_path != 15 ? 3 : 0))
                                             : st.key_bytes != 4 ? 0 : (st.kind == ESP_UPDATE && h->force_path != 15 ? 2 : 1);
             h->last_fold_update = keys >= 2 ? 1 : 0;
 #define ESP_LAUNCH_SMALL(F, P, B, K) hipLaunchKernelGGL((esplocal::local_k<F, P, B, K, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a)
@@ -2255,7 +2293,18 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         if (Z0 == 0) ESP_LAUNCH_SMALL(true, P, false, K); else ESP_LAUNCH_SMALL(false, P, false, K);   \
     } while (0)
             if (small_variant && st.npieces > 0) {
-                if (keys == 3) ESP_LAUNCH_SMALL_FB(true, 3); else ESP_LAUNCH_SMALL_FB(true, 0);
+                if (keys == 5) ESP_LAUNCH_SMALL_FB(true, 5);
+                else if (keys == 4) ESP_LAUNCH_SMALL_FB(true, 4);
+                else if (keys == 3) ESP_LAUNCH_SMALL_FB(true, 3);
+                else ESP_LAUNCH_SMALL_FB(true, 0);
+            } else if (st.npieces > 0 && keys >= 4) {
+                if (keys == 5) {
+                    if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 5); else ESP_LAUNCH_LOCAL(true, true, false, 5); }
+                    else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 5); else ESP_LAUNCH_LOCAL(false, true, false, 5); }
+                } else {
+                    if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 4); else ESP_LAUNCH_LOCAL(true, true, false, 4); }
+                    else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 4); else ESP_LAUNCH_LOCAL(false, true, false, 4); }
+                }
             } else if (small_variant) {
                 if (keys == 2) ESP_LAUNCH_SMALL_FB(false, 2);
                 else if (keys == 1) ESP_LAUNCH_SMALL_FB(false, 1);
@@ -2434,6 +2483,11 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         st.ptab = (const void *const *)T;
         st.pstart = (const i64 *)(T + 256 * 8);
         st.maxlen = h->part_maxlen;
+        if (h->part_own32) {
+            st.p32_piece = h->part_me;
+            st.p32_lo = h->part_own_lo;
+            st.kind = h->part_kind32;
+        }
         CK(ensure(h, h->keys2, sizeof(u64) * (size_t)std::max<i64>(h->part_total, 1)));
         CK(ensure(h, h->vals2, sizeof(double) * (size_t)std::max<i64>(h->part_total, 1)));
         CK(flush_local(h, st, mode, &Zn));
@@ -3085,7 +3139,11 @@ extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t s
     const bool from_producer = h->pre.valid && h->pre.mw_P == nshards && h->pre.mw_me == self && h->pre.mw_eps == entries_per_shard &&
                                h->pre.E == E && h->pre.key_bytes == 8 && h->force_path != 11;
     if (!from_producer) CK(pending_materialize(h));
-    h->pre.valid = false;
+    // (a producer's batch whose own range holds 4-byte keys stays described by `pre` until esp_shard_assemble hands it
+    // to the bucket kernel: every other reader of the pending keys goes through pending_materialize)
+    h->part_own32 = from_producer && h->pre.own32;
+    h->part_kind32 = h->pre.kind;
+    if (!h->part_own32) h->pre.valid = false;
     h->last_shard_source = 0;
     h->part_valid = h->part_assembled = false;
     h->part_own_update = h->kind_uniform == ESP_UPDATE && h->kind_noted == h->count;
@@ -3229,6 +3287,10 @@ extern "C" int32_t esp_shard_assemble(esp_handle *h, const uint64_t *const *d_re
     if ((i64)mx[0] > esplocal::CAP) {
         // a merged segment does not fit the bucket kernel: hand the entries over as a plain pending
         // buffer (lower ranks, own range, higher ranks) -- the next flush partitions it as usual
+        if (h->part_own32) {  // (packed keys for the own range first)
+            h->count = h->pre.E;
+            CK(pending_materialize(h));
+        }
         CK(ensure(h, h->keys2, sizeof(u64) * (size_t)std::max<i64>(total, 1)));
         CK(ensure(h, h->vals2, sizeof(double) * (size_t)std::max<i64>(total, 1)));
         i64 at = 0;
@@ -3257,6 +3319,8 @@ extern "C" int32_t esp_shard_assemble(esp_handle *h, const uint64_t *const *d_re
     h->count = total;
     h->part_total = total;
     h->part_maxlen = (i64)mx[0];
+    h->part_own_lo = own[0];
+    h->pre.valid = false;  // (the batch is the bucket kernel's now; part_own32 says how its own range is stored)
     h->part_assembled = true;
     *ok = 1;
     return ESP_OK;

@@ -126,7 +126,9 @@ struct Args {
     u32 *maxrun_seen;  // longest column run any segment of this flush met (atomicMax)
     // FRESH kernels on whole-column segments that cover the flush's column range: the segment writes colptr (1-based)
     // for its own columns itself -- no column-end marks, no scan over the columns afterwards (nullptr: marks in colend)
-    u32 kind32;  // K32 kernels: the kind of every entry
+    u32 kind32;  // K32 kernels: the kind of every entry; KEYS 4 / 5: of the entries of piece k32_piece
+    int k32_piece;  // KEYS 4 / 5: the piece that holds 4-byte keys ...
+    i64 k32_lo;     // ... from its position k32_lo on: key of position p at ((u32 *)(keys + k32_lo))[p - k32_lo]
     i64 *colptr_out;
     i64 n_cols;   // columns of the matrix (column-end marks of a failing flush -- keys outside the window -- stay inside colend)
     i64 col_end;  // end of the column range (colptr_out[col_end] = 1 + nnz comes from the last segment)
@@ -641,8 +643,9 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
 // the longest run it reports sends the handle's next flushes to the regular kernel.
 template <bool FRESH, bool PIECES, bool BIG, int KEYS, bool SMALL = false>
 __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
-    constexpr bool K32 = KEYS == 1 || KEYS == 2, UPD = KEYS >= 2;
-    static_assert(!(PIECES && K32), "pieces arrive as packed keys");
+    constexpr bool K32 = KEYS == 1 || KEYS == 2, UPD = KEYS == 2 || KEYS == 3 || KEYS == 5, P32 = KEYS == 4 || KEYS == 5;
+    static_assert(!(PIECES && K32), "pieces: packed keys, or one piece of 4-byte keys (KEYS 4 / 5)");
+    static_assert(!P32 || PIECES, "KEYS 4 / 5 are piece formats");
     constexpr int NI = SMALL ? 6 : ITEMS;
     constexpr int CAPK = THREADS * NI;
     __shared__ u64 skey[CAPK];
@@ -750,28 +753,47 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
         hi = ((u64)s << a.rem_bits) + a.base;
         const int nlast = n > 0 ? n - 1 : 0;
         const int single = p_single;
+        // P32: piece a.k32_piece holds 4-byte keys -- the bits below the segment's prefix, kind a.kind32 (a shard's own
+        // range, written by its producer) -- which become packed keys as they are loaded; the others are packed
         if (single >= 0) {
             const u64 *pk = p_k[single];
             const double *pv = p_v[single];
             const i64 beg = p_beg[single];
+            if (P32 && single == a.k32_piece) {
+                // (the 4-byte key of position p of the piece sits at ((u32 *)(keys + k32_lo))[p - k32_lo])
+                const u32 *pk4 = reinterpret_cast<const u32 *>(pk + a.k32_lo) - a.k32_lo;
 #pragma unroll
-            for (int i = 0; i < NI; i++) k[i] = pk[beg + min(wbase + i * ESP_WAVE, nlast)];
+                for (int i = 0; i < NI; i++)
+                    k[i] = ((hi + (u64)pk4[beg + min(wbase + i * ESP_WAVE, nlast)]) << ESP_TAG_BITS) | (u64)a.kind32;
+            } else {
+#pragma unroll
+                for (int i = 0; i < NI; i++) k[i] = pk[beg + min(wbase + i * ESP_WAVE, nlast)];
+            }
 #pragma unroll
             for (int i = 0; i < NI; i++) vraw[i] = pv[beg + min(wbase + i * ESP_WAVE, nlast)];
         } else {
             const u64 *ak[NI];
             const double *av[NI];
+            bool k4[NI];
 #pragma unroll
             for (int i = 0; i < NI; i++) {
                 const int p = min(wbase + i * ESP_WAVE, nlast);
                 int q = 0;
                 while (q + 1 < a.npieces && p >= p_pre[q + 1]) q++;
                 const i64 at = p_beg[q] + (i64)(p - p_pre[q]);
-                ak[i] = p_k[q] + at;
+                k4[i] = P32 && q == a.k32_piece;
+                ak[i] = k4[i] ? reinterpret_cast<const u64 *>(reinterpret_cast<const u32 *>(p_k[q] + a.k32_lo) + (at - a.k32_lo)) : p_k[q] + at;
                 av[i] = p_v[q] + at;
             }
 #pragma unroll
-            for (int i = 0; i < NI; i++) k[i] = n > 0 ? *ak[i] : 0ull;
+            for (int i = 0; i < NI; i++) {
+                if (n <= 0)
+                    k[i] = 0ull;
+                else if (k4[i])
+                    k[i] = ((hi + (u64) * reinterpret_cast<const u32 *>(ak[i])) << ESP_TAG_BITS) | (u64)a.kind32;
+                else
+                    k[i] = *ak[i];
+            }
 #pragma unroll
             for (int i = 0; i < NI; i++) vraw[i] = n > 0 ? *av[i] : 0.0;
         }

@@ -580,6 +580,12 @@ struct PartOut {
     int mw_P;
     u32 mw_nb;
     const u64 *mw_base;    // first key of every window, ascending
+    // a shard's OWN window goes out as 4-byte keys (the bits below the bucket prefix, one kind for the batch), the
+    // ranges it sends to other ranks as packed keys: own32 != 0, window mw_me; the 4-byte keys of bucket position p of
+    // the own range [*own_lo, ...) live at ((u32 *)(keys_out + *own_lo))[p - *own_lo], inside the range's own bytes
+    int own32;
+    int mw_me;
+    const i64 *own_lo;     // bucket start of the own window's first digit (written by run_rank_k)
 };
 
 // LDS tables of one producer workgroup (tile = chunk)
@@ -589,6 +595,8 @@ struct TileLds {
     i64 roff[RMAX];         // global offset of run j (run_rank_k)
     u32 lstart[RMAX + 1];   // first LDS slot of run j: the tile is staged run by run
     u64 rbase[RMAX];        // first key of run j's bucket (window base + digit << shift)
+    u32 rown[RMAX];         // own32: run j lies in the shard's own window
+    i64 own_lo;
 };
 
 // Where a thread's entries go inside the tile's LDS staging area.  A thread (a stencil node, a FEM cell) holds NQ
@@ -606,6 +614,7 @@ struct TileLoads {
     int nr;                      // runs of the tile
     u32 run_digit;               // lane j: digit of run j (garbage for j >= nr)
     i64 run_off;                 // lane j: global offset of run j
+    i64 own_lo;                  // own32: first position of the shard's own range
 };
 __device__ __forceinline__ TileLoads tile_loads(const PartOut &p, i64 chunk) {
     const int lane = threadIdx.x & 63;
@@ -615,6 +624,7 @@ __device__ __forceinline__ TileLoads tile_loads(const PartOut &p, i64 chunk) {
     L.nr = (int)p.nruns[chunk];
     L.run_digit = p.runs_d[chunk * RMAX + lane];
     L.run_off = p.runs_off[chunk * RMAX + lane];
+    L.own_lo = p.own32 ? *p.own_lo : 0;
     return L;
 }
 
@@ -684,15 +694,19 @@ __device__ __forceinline__ bool tile_slots(const PartOut &p, const TileLoads &L,
         if (lane == 63) S.lstart[RMAX] = inc;
         S.roff[lane] = lane < nr ? run_off_raw : 0;
         u64 rb = 0;
+        u32 own = 0;
         if (lane < nr) {
             if (p.mw_P) {
                 const u32 r = my_run_digit / p.mw_nb;
                 rb = p.mw_base[r] + ((u64)(my_run_digit - r * p.mw_nb) << p.shift);
+                own = (p.own32 && (int)r == p.mw_me) ? 1u : 0u;
             } else {
                 rb = p.base + ((u64)my_run_digit << p.shift);
             }
         }
         S.rbase[lane] = rb;
+        S.rown[lane] = own;
+        if (lane == 0) S.own_lo = L.own_lo;
     }
 #pragma unroll
     for (int q = 0; q < NQ; q++) slot[q] = (u32)__shfl((int)sb, (int)jq[q], ESP_WAVE) + pq[q];
@@ -721,18 +735,29 @@ __device__ __forceinline__ void copy_out_runs(const PartOut &p, const KT *lk, co
         if (len == 0) continue;
         const i64 ro = S.roff[j];
         const u64 rb = S.rbase[j];
+        // 4-byte keys for this run: every run (OUT32), or the runs of a shard's own window (own32; KT = u32 then)
+        bool run32 = OUT32;
+        u32 *k4 = reinterpret_cast<u32 *>(p.keys_out);
+        i64 k4off = 0;  // index of the 4-byte key of bucket position q: q - k4off
+        if constexpr (sizeof(KT) == 4 && !OUT32) {
+            if (S.rown[j]) {
+                run32 = true;
+                k4 = reinterpret_cast<u32 *>(p.keys_out + S.own_lo);
+                k4off = S.own_lo;
+            }
+        }
         auto key_of = [&](int q) -> u64 {  // what goes out for staged entry q: the 4-byte key, or the packed key
             if constexpr (sizeof(KT) == 4) {
                 const u32 delta = (u32)lk[q] - (u32)rb;
-                if constexpr (OUT32) return (u64)delta;
+                if (run32) return (u64)delta;
                 return ((rb + (u64)delta) << ESP_TAG_BITS) | (u64)kind;
             } else {
                 return (u64)lk[q];
             }
         };
         auto store1 = [&](int q, i64 dst) {
-            if constexpr (OUT32)
-                reinterpret_cast<u32 *>(p.keys_out)[dst] = (u32)key_of(q);
+            if (run32)
+                k4[dst - k4off] = (u32)key_of(q);
             else
                 p.keys_out[dst] = key_of(q);
             p.vals_out[dst] = lv[q];
@@ -740,13 +765,21 @@ __device__ __forceinline__ void copy_out_runs(const PartOut &p, const KT *lk, co
         const int head = (int)(ro & 1);  // the run starts at an odd place: its first entry goes alone
         if (t == 0 && head) store1(b, ro);
         const int npair = (len - head) >> 1;
+        // (4-byte keys of the own window: the pair's key store is 8-byte aligned when its index is even)
+        const bool pair32 = run32 && (((ro + head - k4off) & 1) == 0);
         for (int q = t; q < npair; q += NT) {
             const int e = b + head + 2 * q;
             const i64 dst = ro + head + 2 * q;  // even
-            if constexpr (OUT32)
-                *reinterpret_cast<u32x2 *>(reinterpret_cast<u32 *>(p.keys_out) + dst) = u32x2{(u32)key_of(e), (u32)key_of(e + 1)};
-            else
+            if (run32) {
+                if (pair32) {
+                    *reinterpret_cast<u32x2 *>(k4 + (dst - k4off)) = u32x2{(u32)key_of(e), (u32)key_of(e + 1)};
+                } else {
+                    k4[dst - k4off] = (u32)key_of(e);
+                    k4[dst - k4off + 1] = (u32)key_of(e + 1);
+                }
+            } else {
                 *reinterpret_cast<u64x2 *>(p.keys_out + dst) = u64x2{key_of(e), key_of(e + 1)};
+            }
             *reinterpret_cast<f64x2 *>(p.vals_out + dst) = f64x2{lv[e], lv[e + 1]};
         }
         if (t == NT - 1 && ((len - head) & 1)) store1(b + len - 1, ro + len - 1);
@@ -759,6 +792,15 @@ __device__ __forceinline__ void copy_out_runs(const PartOut &p, const KT *lk, co
 __device__ __forceinline__ u32 column_digit(const PartOut &p, i64 col0, int rb, u32 *err) {
     const u64 key = (u64)col0 << rb;
     if (p.mw_P) {
+        // (a rank mostly produces entries of its own column range: that window is tried first)
+        const u64 b_own = p.mw_base[p.mw_me];
+        const u64 rel_own = key - b_own;
+        const u64 w_own = p.mw_me + 1 < p.mw_P ? p.mw_base[p.mw_me + 1] - b_own : ~0ull - b_own;
+        if (rel_own < w_own) {
+            u64 dl = rel_own >> p.shift;
+            dl = dl < (u64)p.mw_nb ? dl : (u64)p.mw_nb - 1;
+            return (u32)p.mw_me * p.mw_nb + (u32)dl;
+        }
         int r = 0;
 #pragma unroll
         for (int step = MW_MAX / 2; step; step >>= 1) {
@@ -785,6 +827,18 @@ __global__ __launch_bounds__(THREADS) void expand_keys_k(const u32 *__restrict__
     const i64 b = seg_start[s], e = seg_start[s + 1];
     const u64 hi = ((u64)s << shift) + base;
     for (i64 i = b + threadIdx.x; i < e; i += THREADS) out[i] = ((hi + (u64)k32[i]) << ESP_TAG_BITS) | (u64)kind;
+}
+
+// the same for a shard's own window (digits [d0, d0 + nb) of the multi-window partition): 4-byte keys at
+// ((u32 *)(keys + own_lo))[p - own_lo] -> packed keys at out[p]
+__global__ __launch_bounds__(THREADS) void expand_own_keys_k(const u64 *__restrict__ keys, const i64 *__restrict__ seg_start, i64 d0,
+                                                             int shift, u64 base, u32 kind, u64 *__restrict__ out) {
+    const i64 s = blockIdx.x;
+    const i64 own_lo = seg_start[d0];
+    const i64 b = seg_start[d0 + s], e = seg_start[d0 + s + 1];
+    const u32 *k32 = reinterpret_cast<const u32 *>(keys + own_lo);
+    const u64 hi = ((u64)s << shift) + base;
+    for (i64 i = b + threadIdx.x; i < e; i += THREADS) out[i] = ((hi + (u64)k32[i - own_lo]) << ESP_TAG_BITS) | (u64)kind;
 }
 
 }  // namespace esprun
