@@ -3196,7 +3196,8 @@ extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t s
     // kernel started: they are produced on the second stream (it already waits for the ranking kernel) and this call
     // returns while the entries are still being moved -- the caller's consensus round runs beside the scatter
     // kernel; esp_synchronize() before the key/value arrays are read.
-    hipStream_t qs = (E > 0 && h->last_run_order == 1) ? h->aux : h->stream;
+    // (a producer's batch: the bucket starts were final behind ITS ranking kernel, the PART launch may still run)
+    hipStream_t qs = (E > 0 && (h->last_run_order == 1 || from_producer) && h->aux && h->aux_ev) ? h->aux : h->stream;
     if (qs == h->aux) HIPCK(h, hipStreamWaitEvent(h->aux, h->aux_ev, 0));  // (recorded right behind the ranking kernel)
     hipLaunchKernelGGL(diff_counts_k, dim3(grid_for(NB, 256)), dim3(256), 0, qs, (const i64 *)bstart, NB, cnt);
     // owner ranges = bucket starts at every multiple of nb
