@@ -184,10 +184,12 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
             A.timing_enable(1 if it == steps + 1 else 0)
             A.timing(clear=True)
             t0 = time.perf_counter()
+            # (the stencil's stream, then the new couplings behind it: the producer's bucket-ordered batch stays as it
+            # is, the flush partitions the new couplings alone)
+            A.generate_fdrand(n, n, n, seed=0x5EED0012, rand_mode=1)
             d.ck(d.lib.esp_append_device(d.h, C.c_void_p(rows.data_ptr()), C.c_void_p(cols.data_ptr()),
                                          C.c_void_p(vals.data_ptr()), None, esp.ESP_UPDATE, 0, Zn))
             A._touch()
-            A.generate_fdrand(n, n, n, seed=0x5EED0012, rand_mode=1)
             A.flush()
             A.synchronize()
             if it == steps + 1:
@@ -203,7 +205,8 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
             "workload": "existing %d^3 stencil CSC (%d nnz) + the full update stream again + %d new positions "
                         "(%.1f %% of the stored nnz): append + flush! with merge-path join" % (n, Z0, Zn, 100.0 * Zn / Z0),
             "ms": dt * 1e3, "nnz_per_s": Z1 / dt, "appended_per_s": Ea / dt, "algorithmic_bytes": algo,
-            "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS, "stage_ms": stages(tm, 1), "steps": len(dts)}
+            "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS, "partition": A.debug_last_partition(),
+            "stage_ms": stages(tm, 1), "steps": len(dts)}
         del A, rows, cols, vals
     except Exception as ex:
         out["cfg3_reassembly"] = {"error": repr(ex)}

@@ -59,6 +59,7 @@ struct esp_handle {
         int key_bytes = 8;       // 4: `keys` holds u32 keys (the bits below the prefix); every entry has the kind `kind`
         int kind = 0;
         i64 E = 0, maxlen = 0;   // entries, longest bucket
+        i64 tail = 0;            // packed entries appended BEHIND the E bucket-ordered ones (count = E + tail)
         u64 base = 0, span = 0;  // the key window it was made for
         double Ee = 0.0;         // (plan_entries of the batch: spread bookkeeping)
         // column shards: the batch was partitioned by (owner, digit inside the owner's column range) -- what
@@ -68,6 +69,7 @@ struct esp_handle {
         i64 mw_eps = 0;
         bool own32 = false;      // ... and the shard's OWN range holds 4-byte keys of kind `kind` (the sent ranges: packed)
     } pre;
+    bool pre_keep = false;       // reserve_append: the append that follows goes behind the bucket-ordered batch
     bool shard_user = false;     // the handle is driven through esp_shard_*: its flushes partition by owner first
     int last_shard_source = 0;   // esp_shard_partition: 1 = its own pass moved the entries, 2 = the producer had
     int last_local_small = 0;    // the last flush's bucket kernel was the small variant (3 workgroups per CU)
@@ -160,7 +162,12 @@ static inline void pending_changed(esp_handle *h) {
     h->shard_valid = false;
     h->part_valid = false;
     h->part_assembled = false;
-    h->pre.valid = false;  // (whoever changes a bucket-ordered buffer called pending_materialize first)
+    // (whoever changes a bucket-ordered buffer called pending_materialize first -- or appends behind it)
+    if (h->pre.valid && h->pre_keep && h->count >= h->pre.E)
+        h->pre.tail = h->count - h->pre.E;
+    else
+        h->pre.valid = false;
+    h->pre_keep = false;
 }
 static int32_t pending_materialize(esp_handle *h);
 
@@ -568,7 +575,11 @@ static int32_t reserve_append(esp_handle *h, i64 add) {
     // (the handle's count is their logical total): nothing can be appended behind them
     if (h->part_assembled)
         FAIL(h, ESP_ERR_STATE, "append: the pending entries are assembled shard pieces (esp_shard_assemble): esp_flush first");
-    CK(pending_materialize(h));  // (an append behind a bucket-ordered batch: back to packed keys first)
+    // An append behind a bucket-ordered batch: the batch stays as it is (its 4-byte keys fill the front half of their
+    // slots), the new entries follow it as packed keys, and the flush partitions only them (flush_pre_tail).  A shard's
+    // batch, or force_path 19: back to packed keys first.
+    h->pre_keep = h->pre.valid && h->pre.mw_P == 0 && h->force_path != 19 && h->count == h->pre.E + h->pre.tail;
+    if (!h->pre_keep) CK(pending_materialize(h));
     const i64 need = h->count + add;
     if (need <= h->cap) return ESP_OK;
     i64 ncap = std::max<i64>(need, h->cap + h->cap / 2);
@@ -868,7 +879,7 @@ extern "C" int32_t esp_generate_fdrand_range(esp_handle *h, int64_t nx, int64_t 
     note_kind(h, kind, E);
     h->count += E;
     pending_changed(h);
-    h->pre.valid = took;
+    if (took) h->pre.valid = true;  // (else: whatever pending_changed left -- an earlier batch with this call as its tail)
     return ESP_OK;
 }
 
@@ -951,7 +962,7 @@ extern "C" int32_t esp_generate_fem(esp_handle *h, int32_t dim, int64_t npd, uin
     note_kind(h, ESP_RAWUPDATE, E);
     h->count += E;
     pending_changed(h);
-    h->pre.valid = took;
+    if (took) h->pre.valid = true;  // (else: whatever pending_changed left -- an earlier batch with this call as its tail)
     return ESP_OK;
 }
 
@@ -1319,11 +1330,14 @@ struct Sorted {
     int kind = 0;
     i64 maxlen = esplocal::CAP;  // longest segment
     int p32_piece = -1;          // PIECES: the piece that holds 4-byte keys of kind `kind` from position p32_lo on
+    bool all32 = false;          // PIECES: EVERY piece holds 4-byte keys of kind `kind`
     i64 p32_lo = 0;
     // PIECES (partitioned shard exchange): segments are concatenations of per-source pieces
     int npieces = 0;
     const i64 *pstart = nullptr;
     const void *const *ptab = nullptr;
+    bool has_base = false;  // the segments' key base, if it is not the handle's window / shard range
+    u64 base = 0;
 };
 
 // ---- run lists of the pending entries (runpart.hpp) -------------------------------------------
@@ -1619,6 +1633,7 @@ static int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took) {
     pp.key_bytes = ps->out.k32 ? 4 : 8;
     pp.kind = ps->kind;
     pp.E = ps->E;
+    pp.tail = 0;
     pp.base = h->win_base;
     pp.span = h->win_span;
     pp.Ee = ps->Ee;
@@ -1667,6 +1682,11 @@ static int32_t pending_materialize(esp_handle *h) {
     hipLaunchKernelGGL(esprun::expand_keys_k, dim3((unsigned)((i64)1 << pp.pb)), dim3(esprun::THREADS), 0, h->stream, (const u32 *)h->keys.p,
                        (const i64 *)h->seg[1].p, pp.K - pp.pb, pp.base, (u32)pp.kind, (u64 *)h->keys2.p);
     sp.add(1);
+    if (h->count > pp.E) {  // (the packed entries behind the batch)
+        HIPCK(h, hipMemcpyAsync((u64 *)h->keys2.p + pp.E, (const u64 *)h->keys.p + pp.E, sizeof(u64) * (size_t)(h->count - pp.E),
+                                hipMemcpyDeviceToDevice, h->stream));
+        sp.add(1);
+    }
     HIPCK(h, hipGetLastError());
     std::swap(h->keys, h->keys2);
     h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
@@ -1676,8 +1696,9 @@ static int32_t pending_materialize(esp_handle *h) {
 // mw != nullptr: buckets = mw->P * mw->nb (window r = digits [r*nb, (r+1)*nb)), pb = bits covering them
 static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u64 *kout, double *vout, int K, int pb,
                              i64 *seg_out, u64 *tile_first_out, bool *tiles_ready, bool *ok, i64 *maxlen_out,
-                             const MultiWin *mw = nullptr, int mw_shift = 0, bool allow_k32 = false, int *key_bytes_out = nullptr) {
-    const i64 E = h->count;
+                             const MultiWin *mw = nullptr, int mw_shift = 0, bool allow_k32 = false, int *key_bytes_out = nullptr,
+                             i64 E_in = -1) {
+    const i64 E = E_in >= 0 ? E_in : h->count;  // (E_in: the entries behind a producer's batch, flush_pre_tail)
     const i64 NB = mw ? (i64)mw->P * (i64)mw->nb : (i64)1 << pb;
     CK(ensure(h, h->misc, 256));
     const i64 C = ceil_div<i64>(E, esprun::TILE);
@@ -1773,8 +1794,8 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
         a.flags = flags;
         // 4-byte keys for the bucket kernel: one kind for all pending entries, <= 32 key bits below the prefix, no
         // further pass (force_path 14: packed keys always)
-        const bool k32 = allow_k32 && key_bytes_out && !mw && h->force_path != 14 && h->kind_uniform >= 0 && h->kind_noted == E &&
-                         a.shift <= 32;
+        const bool k32 = allow_k32 && key_bytes_out && !mw && h->force_path != 14 && h->kind_uniform >= 0 &&
+                         h->kind_noted == h->count && a.shift <= 32;
         a.maxlen = d_maxlen;
         a.cap = esplocal::CAP;
         {
@@ -2192,7 +2213,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     const i64 col_begin = windowed(h) ? h->wc0 : 0, col_end = windowed(h) ? h->wc1 : h->n;
     {
         const int clb = st.rem_bits - h->L.rb;
-        const u64 seg_base = st.npieces > 0 ? h->part_base : h->win_base;
+        const u64 seg_base = st.has_base ? st.base : st.npieces > 0 ? h->part_base : h->win_base;
         direct = Z0 == 0 && clb >= 0 && clb <= esplocal::CL_MAX_BITS && h->force_path != 3 && h->force_path != 13 && !stop_env &&
                  seg_base == ((u64)col_begin << h->L.rb) && col_begin + ((i64)S << clb) >= col_end;
     }
@@ -2230,10 +2251,10 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
     h->last_local_small = small_variant ? 1 : 0;
     {
         Span sp(h, ESP_ST_LOCAL);
-        a.kind32 = (u32)((st.key_bytes == 4 || st.p32_piece >= 0) ? st.kind : 0);
+        a.kind32 = (u32)((st.key_bytes == 4 || st.p32_piece >= 0 || st.all32) ? st.kind : 0);
         a.k32_piece = st.p32_piece;
         a.k32_lo = st.p32_lo;
-        h->last_key_bytes = st.p32_piece >= 0 ? 4 : st.key_bytes;
+        h->last_key_bytes = (st.p32_piece >= 0 || st.all32) ? 4 : st.key_bytes;
         a.colptr_out = direct ? (i64 *)h->colptr.p : nullptr;
         a.col_end = col_end;
         a.n_cols = h->n;
@@ -2242,7 +2263,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         a.seg_start = st.seg_start;
         a.S = S;
         a.rem_bits = st.rem_bits;
-        a.base = st.npieces > 0 ? h->part_base : h->win_base;
+        a.base = st.has_base ? st.base : st.npieces > 0 ? h->part_base : h->win_base;
         a.rb = h->L.rb;
         {
             const int clb = st.rem_bits - h->L.rb;
@@ -2283,8 +2304,10 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
             // (key format: 0 packed, 1 four-byte keys of one kind, 2 four-byte keys that are all UPDATEs)
             // (3: packed keys whose kinds are all UPDATE -- the pieces of a shard)
             // (4 / 5: pieces of which one -- a shard's own range -- holds 4-byte keys; 5: everything is an UPDATE)
-            const int keys = st.npieces > 0 ? (st.p32_piece >= 0 ? (st.all_update && h->force_path != 15 ? 5 : 4)
-                                                                 : (st.all_update && h->force_path != 15 ? 3 : 0))
+            // (6 / 7: pieces that all hold 4-byte keys of one kind -- a producer's batch and its tail; 7: UPDATE)
+            const int keys = st.npieces > 0 ? (st.all32 ? (st.kind == ESP_UPDATE && h->force_path != 15 ? 7 : 6)
+                                               : st.p32_piece >= 0 ? (st.all_update && h->force_path != 15 ? 5 : 4)
+                                                                   : (st.all_update && h->force_path != 15 ? 3 : 0))
                                             : st.key_bytes != 4 ? 0 : (st.kind == ESP_UPDATE && h->force_path != 15 ? 2 : 1);
             h->last_fold_update = keys >= 2 ? 1 : 0;
 #define ESP_LAUNCH_SMALL(F, P, B, K) hipLaunchKernelGGL((esplocal::local_k<F, P, B, K, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a)
@@ -2293,12 +2316,20 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         if (Z0 == 0) ESP_LAUNCH_SMALL(true, P, false, K); else ESP_LAUNCH_SMALL(false, P, false, K);   \
     } while (0)
             if (small_variant && st.npieces > 0) {
-                if (keys == 5) ESP_LAUNCH_SMALL_FB(true, 5);
+                if (keys == 7) ESP_LAUNCH_SMALL_FB(true, 7);
+                else if (keys == 6) ESP_LAUNCH_SMALL_FB(true, 6);
+                else if (keys == 5) ESP_LAUNCH_SMALL_FB(true, 5);
                 else if (keys == 4) ESP_LAUNCH_SMALL_FB(true, 4);
                 else if (keys == 3) ESP_LAUNCH_SMALL_FB(true, 3);
                 else ESP_LAUNCH_SMALL_FB(true, 0);
             } else if (st.npieces > 0 && keys >= 4) {
-                if (keys == 5) {
+                if (keys == 7) {
+                    if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 7); else ESP_LAUNCH_LOCAL(true, true, false, 7); }
+                    else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 7); else ESP_LAUNCH_LOCAL(false, true, false, 7); }
+                } else if (keys == 6) {
+                    if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 6); else ESP_LAUNCH_LOCAL(true, true, false, 6); }
+                    else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 6); else ESP_LAUNCH_LOCAL(false, true, false, 6); }
+                } else if (keys == 5) {
                     if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 5); else ESP_LAUNCH_LOCAL(true, true, false, 5); }
                     else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 5); else ESP_LAUNCH_LOCAL(false, true, false, 5); }
                 } else {
@@ -2421,6 +2452,146 @@ static int32_t flush_global(esp_handle *h, int mode, i64 *Zn_out) {
     return finish_csc(h, Z0, Zn, (const u64 *)h->newkey.p, (const double *)h->newval.p);
 }
 
+__global__ void piece_totals_k(const i64 *__restrict__ pstart, int P, i64 nb, unsigned long long *__restrict__ maxlen,
+                               unsigned long long *__restrict__ negative);
+
+// bucket starts of a tail sorted by its prefix digit: first position whose digit is >= d, for d = 0 .. NB
+__global__ void tail_bucket_starts_k(const u64 *__restrict__ keys, i64 T, u64 base, u64 span, int shift, i64 NB, i64 *__restrict__ out) {
+    const i64 d = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > NB) return;
+    i64 lo = 0, hi = T;
+    while (lo < hi) {
+        const i64 mid = (lo + hi) >> 1;
+        u64 kn = (keys[mid] >> ESP_TAG_BITS) - base;
+        kn = kn < span ? kn : span - 1;
+        if ((i64)(kn >> shift) < d)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    out[d] = lo;
+}
+
+// A producer's bucket-ordered batch with packed entries appended behind it (a re-assembly whose mesh gained a few
+// couplings: the generator's batch, then the new positions): the tail alone goes through the run-based partition with
+// the batch's prefix bits, and the bucket kernel reads every segment as two pieces -- the batch's bucket (4-byte keys
+// when the producer wrote them), then the tail's.  Stream order is kept: the tail's entries come after the batch's.
+static int32_t flush_pre_tail(esp_handle *h, int mode, i64 *Zn, bool *served) {
+    *served = false;
+    const esp_handle::PrePart pp = h->pre;
+    const i64 E0 = pp.E, T = pp.tail, NB = (i64)1 << pp.pb;
+    CK(ensure(h, h->newkey, sizeof(u64) * (size_t)T));
+    CK(ensure(h, h->newval, sizeof(double) * (size_t)T));
+    CK(ensure(h, h->seg[0], sizeof(i64) * (size_t)(NB + 1)));
+    CK(ensure(h, h->tilef[0], sizeof(u64) * (size_t)(NB + 1 + espscan::workspace_elems(NB + 1))));
+    CK(ensure(h, h->misc, 256));
+    unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
+    HIPCK(h, hipMemsetAsync(d_maxlen, 0, 64, h->stream));  // maxlen .. the four flag words (run_partition)
+    bool took = false, tiles = false;
+    i64 ml = 0;
+    // (a tail of the batch's kind goes out as 4-byte keys too: the bucket kernel then reads nothing but such keys)
+    const bool tail32 = pp.key_bytes == 4 && h->kind_uniform == pp.kind && h->kind_noted == h->count;
+    int tail_bytes = 8;
+    CK(run_partition(h, (const u64 *)h->keys.p + E0, (const double *)h->vals.p + E0, (u64 *)h->newkey.p, (double *)h->newval.p, pp.K,
+                     pp.pb, (i64 *)h->seg[0].p, (u64 *)h->tilef[0].p, &tiles, &took, &ml, nullptr, 0, tail32, &tail_bytes, T));
+    if (!took) {
+        // no pre-sorted stream (a few entries spread over many buckets, say): stable 8-bit passes over the prefix bits of the
+        // tail alone, least significant first; the last one lands in newkey/newval (keys2/vals2, the bucket kernel's
+        // output, serve as the other half of the ping-pong until then)
+        CK(ensure(h, h->keys2, sizeof(u64) * (size_t)(E0 + T)));
+        CK(ensure(h, h->vals2, sizeof(double) * (size_t)(E0 + T)));
+        CK(ensure(h, h->segs, sizeof(i64) * 8));
+        i64 *segs = (i64 *)h->segs.p;
+        const i64 TR = ceil_div<i64>(T, espradix::TILE);
+        hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, segs, (i64)0, T, (i64)0, TR);
+        HIPCK(h, hipMemsetAsync(d_maxlen, 0, 64, h->stream));
+        const int npass = (pp.pb + 7) / 8;
+        const u64 *ki = (const u64 *)h->keys.p + E0;
+        const double *vi = (const double *)h->vals.p + E0;
+        bool to_new = (npass & 1) != 0;
+        for (int done = 0; done < pp.pb; done += 8) {
+            espradix::Pass p;
+            p.keys_in = ki;
+            p.vals_in = vi;
+            p.keys_out = to_new ? (u64 *)h->newkey.p : (u64 *)h->keys2.p;
+            p.vals_out = to_new ? (double *)h->newval.p : (double *)h->vals2.p;
+            p.seg_start = segs;
+            p.tile_first = segs + 2;
+            p.S = 1;
+            p.owner_P = 0;
+            p.owner_n = 1;
+            p.colshift = 0;
+            p.base = h->win_base;
+            p.span = h->win_span;
+            p.err = (u32 *)h->misc.p + 60;
+            p.shift = pp.K - pp.pb + done;
+            p.bits = std::min(8, pp.pb - done);
+            CK(partition_pass(h, p, TR));
+            ki = p.keys_out;
+            vi = p.vals_out;
+            to_new = !to_new;
+        }
+        {
+            Span sp(h, ESP_ST_SCAN);
+            hipLaunchKernelGGL(tail_bucket_starts_k, dim3(grid_for(NB + 1, 256)), dim3(256), 0, h->stream, (const u64 *)h->newkey.p, T,
+                               h->win_base, h->win_span, pp.K - pp.pb, NB, (i64 *)h->seg[0].p);
+            sp.add(1);
+        }
+        HIPCK(h, hipMemcpyAsync(h->pin_scalar, (u32 *)h->misc.p + 60, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        if ((u32)h->pin_scalar[0]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (partition)");
+        h->last_run_order = 0;
+    }
+    // pointer table (keys | values) | piece starts: batch, tail
+    const size_t o_ps = 256 * 8;
+    CK(ensure(h, h->piecetab, o_ps + sizeof(i64) * 2 * (size_t)(NB + 1)));
+    char *TB = (char *)h->piecetab.p;
+    const void *tab[4] = {h->keys.p, h->newkey.p, h->vals.p, h->newval.p};
+    i64 *pstart = (i64 *)(TB + o_ps);
+    HIPCK(h, hipMemcpyAsync(TB, tab, sizeof(tab), hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(pstart, h->seg[1].p, sizeof(i64) * (size_t)(NB + 1), hipMemcpyDeviceToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(pstart + (NB + 1), h->seg[0].p, sizeof(i64) * (size_t)(NB + 1), hipMemcpyDeviceToDevice, h->stream));
+    HIPCK(h, hipMemsetAsync(d_maxlen, 0, 16, h->stream));
+    {
+        Span sp(h, ESP_ST_SCAN);
+        hipLaunchKernelGGL(piece_totals_k, dim3(grid_for(NB, 256)), dim3(256), 0, h->stream, (const i64 *)pstart, 2, NB, d_maxlen, d_maxlen + 1);
+        sp.add(1);
+    }
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_maxlen, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));  // (tab is read by the copy above)
+    const i64 merged = (i64)h->pin_scalar[0];
+    if (merged > (i64)esplocal::CAP) return ESP_OK;
+    HIPCK(h, hipMemsetAsync((u32 *)h->misc.p + 60, 0, 4, h->stream));
+    Sorted st;
+    st.sk = (const u64 *)h->keys.p;
+    st.sv = (const double *)h->vals.p;
+    st.in_primary = true;
+    st.S = (int)NB;
+    st.seg_start = nullptr;
+    st.rem_bits = pp.K - pp.pb;
+    st.local_ok = true;
+    st.npieces = 2;
+    st.all_update = h->kind_uniform == ESP_UPDATE && h->kind_noted == h->count;
+    st.ptab = (const void *const *)TB;
+    st.pstart = pstart;
+    st.maxlen = merged;
+    st.has_base = true;
+    st.base = h->win_base;
+    if (pp.key_bytes == 4 && tail_bytes == 4) {
+        st.all32 = true;
+        st.kind = pp.kind;
+    } else if (pp.key_bytes == 4) {
+        st.p32_piece = 0;
+        st.p32_lo = 0;
+        st.kind = pp.kind;
+    }
+    CK(ensure(h, h->keys2, sizeof(u64) * (size_t)(E0 + T)));
+    CK(ensure(h, h->vals2, sizeof(double) * (size_t)(E0 + T)));
+    CK(flush_local(h, st, mode, Zn));
+    *served = true;
+    return ESP_OK;
+}
+
 extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int32_t *pattern_changed) {
     if (!h) return ESP_ERR_INVALID;
     if (mode != ESP_FLUSH_ROUTED && mode != ESP_FLUSH_PLUS) FAIL(h, ESP_ERR_INVALID, "esp_flush: mode");
@@ -2440,13 +2611,21 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
     i64 Zn = 0;
     bool use_local = h->force_path != 2;
     if (h->ones_pending && windowed(h)) CK(fix_tail(h));  // (cannot happen: a window is declared through fix_tail)
-    if (h->pre.valid) {  // the producer's partition serves this flush if nothing changed since
+    if (h->pre.valid) {  // the producer's partition serves this flush if nothing changed since (appends BEHIND it may have)
         const esp_handle::PrePart &pp = h->pre;
-        const bool usable = use_local && !h->part_assembled && pp.mw_P == 0 && pp.E == E && pp.base == h->win_base && pp.span == h->win_span &&
-                            pp.maxlen <= (i64)esplocal::CAP && pp.K - pp.pb <= esplocal::MAX_REM_BITS;
+        const bool usable = use_local && !h->part_assembled && pp.mw_P == 0 && pp.E + pp.tail == E && pp.base == h->win_base &&
+                            pp.span == h->win_span && pp.maxlen <= (i64)esplocal::CAP && pp.K - pp.pb <= esplocal::MAX_REM_BITS;
         if (!usable) CK(pending_materialize(h));
     }
-    if (h->pre.valid) {
+    bool served = false;
+    if (h->pre.valid && h->pre.tail > 0) {
+        // batch + tail: only the tail is partitioned, the bucket kernel reads every segment as two pieces
+        CK(flush_pre_tail(h, mode, &Zn, &served));
+        if (!served) CK(pending_materialize(h));  // (a merged segment is too long, or the tail is no pre-sorted stream)
+    }
+    if (served) {
+        h->last_partition = 5;
+    } else if (h->pre.valid) {
         const esp_handle::PrePart &pp = h->pre;
         Sorted st;
         st.sk = (const u64 *)h->keys.p;

@@ -635,7 +635,8 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
 // prefix -- and every entry has the kind a.kind32 (the run-based partition writes them when all pending entries
 // share one kind); 2 = the same and that kind is UPDATE (an assembly loop of updateindex! calls): the register
 // tiers fold without decoding a kind; 3 = packed keys whose kinds are all UPDATE (the pieces of a shard whose
-// received blocks were checked): the same fold
+// received blocks were checked): the same fold; 4 / 5 = pieces of which one holds 4-byte keys (5: all UPDATE); 6 / 7 = pieces
+// that ALL hold 4-byte keys of the kind a.kind32 (a producer's batch and the tail behind it; 7: UPDATE)
 // SMALL: segments of at most 3072 entries (6 per thread) over at most 256 columns, no radix tier: 51 KiB of LDS instead
 // of 74, i.e. THREE workgroups per CU (measured at 256^3: one workgroup per CU 2.70 ms, two 1.70 ms, three 1.48 ms).
 // The host picks it from what it knows before the flush; a segment whose column runs turn out longer than the register
@@ -643,9 +644,9 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
 // the longest run it reports sends the handle's next flushes to the regular kernel.
 template <bool FRESH, bool PIECES, bool BIG, int KEYS, bool SMALL = false>
 __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
-    constexpr bool K32 = KEYS == 1 || KEYS == 2, UPD = KEYS == 2 || KEYS == 3 || KEYS == 5, P32 = KEYS == 4 || KEYS == 5;
-    static_assert(!(PIECES && K32), "pieces: packed keys, or one piece of 4-byte keys (KEYS 4 / 5)");
-    static_assert(!P32 || PIECES, "KEYS 4 / 5 are piece formats");
+    constexpr bool K32 = KEYS == 1 || KEYS == 2 || KEYS == 6 || KEYS == 7, UPD = KEYS == 2 || KEYS == 3 || KEYS == 5 || KEYS == 7,
+                   P32 = KEYS == 4 || KEYS == 5;
+    static_assert(PIECES == (KEYS >= 3) || KEYS == 0, "KEYS 3 .. 7 are piece formats, 1 / 2 are not");
     constexpr int NI = SMALL ? 6 : ITEMS;
     constexpr int CAPK = THREADS * NI;
     __shared__ u64 skey[CAPK];
@@ -755,13 +756,22 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
         const int single = p_single;
         // P32: piece a.k32_piece holds 4-byte keys -- the bits below the segment's prefix, kind a.kind32 (a shard's own
         // range, written by its producer) -- which become packed keys as they are loaded; the others are packed
+        // (pointers read from a table are generic to the compiler: say that they are global memory, or every load of
+        // the pieces is a flat load)
+        typedef const u64 __attribute__((address_space(1))) *g_u64;
+        typedef const u32 __attribute__((address_space(1))) *g_u32;
+        typedef const double __attribute__((address_space(1))) *g_f64;
         if (single >= 0) {
-            const u64 *pk = p_k[single];
-            const double *pv = p_v[single];
+            const g_u64 pk = (g_u64)p_k[single];
+            const g_f64 pv = (g_f64)p_v[single];
             const i64 beg = p_beg[single];
-            if (P32 && single == a.k32_piece) {
+            if constexpr (K32) {
+                const g_u32 pk4 = (g_u32)pk;
+#pragma unroll
+                for (int i = 0; i < NI; i++) k[i] = (u64)pk4[beg + min(wbase + i * ESP_WAVE, nlast)];
+            } else if (P32 && single == a.k32_piece) {
                 // (the 4-byte key of position p of the piece sits at ((u32 *)(keys + k32_lo))[p - k32_lo])
-                const u32 *pk4 = reinterpret_cast<const u32 *>(pk + a.k32_lo) - a.k32_lo;
+                const g_u32 pk4 = (g_u32)(pk + a.k32_lo) - a.k32_lo;
 #pragma unroll
                 for (int i = 0; i < NI; i++)
                     k[i] = ((hi + (u64)pk4[beg + min(wbase + i * ESP_WAVE, nlast)]) << ESP_TAG_BITS) | (u64)a.kind32;
@@ -772,8 +782,8 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
 #pragma unroll
             for (int i = 0; i < NI; i++) vraw[i] = pv[beg + min(wbase + i * ESP_WAVE, nlast)];
         } else {
-            const u64 *ak[NI];
-            const double *av[NI];
+            g_u64 ak[NI];
+            g_f64 av[NI];
             bool k4[NI];
 #pragma unroll
             for (int i = 0; i < NI; i++) {
@@ -782,15 +792,21 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
                 while (q + 1 < a.npieces && p >= p_pre[q + 1]) q++;
                 const i64 at = p_beg[q] + (i64)(p - p_pre[q]);
                 k4[i] = P32 && q == a.k32_piece;
-                ak[i] = k4[i] ? reinterpret_cast<const u64 *>(reinterpret_cast<const u32 *>(p_k[q] + a.k32_lo) + (at - a.k32_lo)) : p_k[q] + at;
-                av[i] = p_v[q] + at;
+                const g_u64 base_k = (g_u64)p_k[q];
+                if constexpr (K32)
+                    ak[i] = (g_u64)((g_u32)base_k + at);
+                else
+                    ak[i] = k4[i] ? (g_u64)((g_u32)(base_k + a.k32_lo) + (at - a.k32_lo)) : base_k + at;
+                av[i] = (g_f64)p_v[q] + at;
             }
 #pragma unroll
             for (int i = 0; i < NI; i++) {
                 if (n <= 0)
                     k[i] = 0ull;
+                else if constexpr (K32)
+                    k[i] = (u64) * (g_u32)ak[i];
                 else if (k4[i])
-                    k[i] = ((hi + (u64) * reinterpret_cast<const u32 *>(ak[i])) << ESP_TAG_BITS) | (u64)a.kind32;
+                    k[i] = ((hi + (u64) * (g_u32)ak[i]) << ESP_TAG_BITS) | (u64)a.kind32;
                 else
                     k[i] = *ak[i];
             }

@@ -824,7 +824,7 @@ def test_producer_side_partition_mixed_with_other_appends(esp, orc):
             A.append(UPDATE, [3, 4, 3], [5, 6, 5], [1.5, 2.5, -0.25])
             upd(I, J, V)
             upd(np.array([3, 4, 3]), np.array([5, 6, 5]), np.array([1.5, 2.5, -0.25]))
-            expect = 1
+            expect = 5   # (batch + tail: only the three entries are partitioned at the flush)
         elif variant == "clone":
             A.generate_fdrand(n, n, n, seed=31, rand_mode=1)
             A2 = A.copy()
@@ -855,6 +855,101 @@ def test_producer_side_partition_mixed_with_other_appends(esp, orc):
         A.flush()
         O.flush()
         assert A.debug_last_partition() == expect, variant
+        assert_csc_equal(hip_arrays(A), O.arrays(), variant)
+
+
+def test_producer_batch_with_a_tail(esp, orc):
+    """Entries appended BEHIND a producer's bucket-ordered batch leave it as it is: the flush partitions the tail alone
+    and the bucket kernel reads every segment as two pieces (last_partition 5).  Kinds of the tail are free (the batch's
+    4-byte keys carry one kind); a tail that overfills a segment, or force_path 19, sends the flush back to packed keys and the ordinary
+    partition; a tail that is no pre-sorted stream is ordered by 8-bit passes of its own.  Stream order (batch first) decides SET against UPDATE."""
+    n = 48
+    N = n ** 3
+    rng = np.random.default_rng(77)
+    I, J, V = orc.fdrand_stream(n, n, n, rand_mode=1, seed=31)
+    upd = lambda O, I, J, V: O.apply(np.full(len(I), UPDATE, np.uint8), I, J, V)
+
+    def tail(k, kinds=None, sort=True):
+        Jn = rng.integers(1, N + 1, k)
+        if sort:
+            Jn = np.sort(Jn)
+        In = rng.integers(1, N + 1, k)
+        Vn = rng.standard_normal(k)
+        kn = np.full(k, UPDATE, np.uint8) if kinds is None else rng.choice(np.array(kinds, np.uint8), k)
+        return kn, In, Jn, Vn
+
+    for variant in ("fresh_mixed", "two_tails", "stored", "stored_routed_kinds", "overfull", "unsorted", "force19", "getindex",
+                    "fem"):
+        A = esp.ExtendableSparseMatrix(N, N)
+        O = orc.ExtendableSparseMatrix(N, N)
+        expect = 5
+        if variant in ("stored", "stored_routed_kinds"):
+            A.generate_fdrand(n, n, n, seed=30, rand_mode=1)
+            A.flush()
+            upd(O, *orc.fdrand_stream(n, n, n, rand_mode=1, seed=30))
+            O.flush()
+        if variant == "fem":
+            m = 400
+            Nf = m * m
+            A = esp.ExtendableSparseMatrix(Nf, Nf)
+            O = orc.ExtendableSparseMatrix(Nf, Nf)
+            A.generate_fem(2, m, seed=5, order_mode=0)
+            If, Jf, Vf = orc.fem_stream(2, m, seed=5, order_mode=0)
+            O.apply(np.full(len(If), RAW, np.uint8), If, Jf, Vf)
+            k = 300
+            kn, In, Jn, Vn = np.full(k, UPDATE, np.uint8), rng.integers(1, Nf + 1, k), np.sort(rng.integers(1, Nf + 1, k)), rng.standard_normal(k)
+            A.append(0, In, Jn, Vn, kinds=kn)
+            O.apply(kn, In, Jn, Vn)
+        else:
+            A.generate_fdrand(n, n, n, seed=31, rand_mode=1)
+            upd(O, I, J, V)
+        if variant == "fresh_mixed":
+            kn, In, Jn, Vn = tail(5000, kinds=[UPDATE, orc.KIND_SET, orc.KIND_RAWUPDATE])
+            A.append(0, In, Jn, Vn, kinds=kn)
+            O.apply(kn, In, Jn, Vn)
+        elif variant == "two_tails":
+            for k in (700, 1):
+                kn, In, Jn, Vn = tail(k)
+                A.append(UPDATE, In, Jn, Vn)
+                O.apply(kn, In, Jn, Vn)
+        elif variant in ("stored", "stored_routed_kinds"):
+            kn, In, Jn, Vn = tail(4000, kinds=None if variant == "stored" else [UPDATE, orc.KIND_SET])
+            A.append(0, In, Jn, Vn, kinds=kn)
+            O.apply(kn, In, Jn, Vn)
+        elif variant == "overfull":                        # 6000 further entries in the columns of one segment
+            k = 6000
+            In, Jn, Vn = rng.integers(1, N + 1, k), np.sort(rng.integers(1000, 1004, k)), rng.standard_normal(k)
+            A.append(UPDATE, In, Jn, Vn)
+            upd(O, In, Jn, Vn)
+            expect = None
+        elif variant == "unsorted":
+            kn, In, Jn, Vn = tail(300000, sort=False)   # (no pre-sorted stream: 8-bit passes over the tail alone)
+            A.append(UPDATE, In, Jn, Vn)
+            O.apply(kn, In, Jn, Vn)
+        elif variant == "force19":
+            A.debug_force_path(19)
+            kn, In, Jn, Vn = tail(500)
+            A.append(UPDATE, In, Jn, Vn)
+            O.apply(kn, In, Jn, Vn)
+            expect = None
+        elif variant == "getindex":
+            kn, In, Jn, Vn = tail(500)
+            A.append(UPDATE, In, Jn, Vn)
+            O.apply(kn, In, Jn, Vn)
+            X = esp.SparseMatrixHIPCOO(N, N)               # (the buffer's API on the same handle)
+            X._d = A._d
+            i, j = int(In[7]), int(Jn[7])
+            want = float(Vn[(In == i) & (Jn == j)].sum())
+            assert abs(X[i, j] - want) <= 1e-12 * max(1.0, abs(want))  # (reads the pending entries: packed keys again, tail kept)
+            l = int(I[1000]), int(J[1000])
+            assert X[l] != 0.0
+            expect = None
+        A.flush()
+        O.flush()
+        if expect is not None:
+            assert A.debug_last_partition() == expect, variant
+        else:
+            assert A.debug_last_partition() != 5, variant
         assert_csc_equal(hip_arrays(A), O.arrays(), variant)
 
 

@@ -42,7 +42,7 @@ def generator_case():
     N = nx * ny * nz
     if N > 3000000:
         return None
-    force = int(rng.choice([0, 0, 0, 14, 15, 16, 18, 13, 4]))
+    force = int(rng.choice([0, 0, 0, 14, 15, 16, 18, 13, 4, 19]))
     kind = int(rng.choice([1, 1, 2]))
     mode = int(rng.choice([0, 1, 2]))
     A = esp.ExtendableSparseMatrix(N, N)
@@ -63,8 +63,10 @@ def generator_case():
             A.generate_fdrand_range(nx, ny, nz, cut_node, N, seed=seed, rand_mode=mode, kind=kind)
             O.apply(kk, I, J, V)
         else:
-            cnt = int(rng.choice([1, 7, 5000]))
+            cnt = int(rng.choice([1, 7, 5000, 200000]))
             Ih, Jh, Vh = rng.integers(1, N + 1, cnt), rng.integers(1, N + 1, cnt), rng.standard_normal(cnt)
+            if rng.random() < 0.5:                       # (a tail behind the producer's batch: pre-sorted or not)
+                Jh = np.sort(Jh)
             kh = rng.integers(0, 3, cnt).astype(np.uint8)
             if how == "host_before":
                 A.append(0, Ih, Jh, Vh, kinds=kh)
@@ -74,7 +76,15 @@ def generator_case():
             if how == "host_after":
                 A.append(0, Ih, Jh, Vh, kinds=kh)
                 O.apply(kh, Ih, Jh, Vh)
-        A.flush()
+        t_case = time.time()
+        try:
+            A.flush()
+            if os.environ.get("ESP_FUZZ_VERBOSE"):
+                print("gen", dict(nx=nx, ny=ny, nz=nz, force=force, kind=kind, mode=mode, rnd=rnd, how=str(how)), "flush %.2f s" % (time.time() - t_case),
+                      "partition", A.debug_last_partition(), flush=True)
+        except Exception:
+            print("FLUSH FAILED generator case", dict(nx=nx, ny=ny, nz=nz, force=force, kind=kind, mode=mode, rnd=rnd, how=str(how), seed=seed))
+            raise
         O.flush()
         key = ("gen", A.debug_last_partition(), A.debug_last_key_bytes(), A.debug_last_local_small())
         paths[key] = paths.get(key, 0) + 1
