@@ -247,12 +247,16 @@ __global__ __launch_bounds__(THREADS) void fd_count_k(FdArgs a, esprun::RunSink 
 // are staged in LDS run by run (esprun::tile_slots: a node's updates for one column lie together, in call order) and
 // every run is copied to `run offset` with consecutive stores.  S32: the staging area holds the low 32 bits of a key
 // (46 KiB of LDS: 3 workgroups per CU; buckets narrower than 2^32 keys), OUT32: 4-byte keys go out (12 B per update).
+// Staging capacity of the PART launch: an interior tile holds 256 * 12 = 3072 updates, a tile along the domain boundary
+// up to 15 per node.  With room for 3168 (S32: 12 B each) the kernel needs 40 KiB of LDS -- FOUR workgroups per CU -- and
+// the few tiles above that go out in two rounds (staged window [lo, lo + FD_STAGE) of the tile's slots).
+constexpr int FD_STAGE = 3168;
 template <bool S32, bool OUT32>
 __global__ __launch_bounds__(THREADS) void fdrand_part_k(FdArgs a) {
     static_assert(S32 || !OUT32, "4-byte keys come from a 4-byte staging area");
     typedef typename std::conditional<S32, u32, u64>::type KT;
-    __shared__ KT lk[THREADS * FD_MAX_PER_NODE];
-    __shared__ double lv[THREADS * FD_MAX_PER_NODE];
+    __shared__ KT lk[FD_STAGE];
+    __shared__ double lv[FD_STAGE];
     __shared__ esprun::TileLds<THREADS / ESP_WAVE> S;
     const esprun::PartOut &p = a.part;
     const esprun::TileLoads tl = esprun::tile_loads(p, p.chunk_base + blockIdx.x);
@@ -265,36 +269,41 @@ __global__ __launch_bounds__(THREADS) void fdrand_part_k(FdArgs a) {
     // (leaves -- uniformly -- when a flag is set or 4-byte keys do not apply: the host issues the plain producer instead)
     if (!esprun::tile_slots<4, THREADS / ESP_WAVE>(p, tl, it.dig, it.wt, slot, S, &total, OUT32)) return;
     const int rb = a.L.rb;
-    auto put = [&](u32 at, double v, i64 row, i64 col) {
-        if constexpr (S32) {  // (the low 32 bits of (col-1) << rb | (row-1), in 32-bit arithmetic)
-            lk[at] = (rb < 32 ? (u32)(col - 1) << rb : 0u) | (u32)(row - 1);
-        } else {
-            const u64 kp = ((u64)(col - 1) << rb) | (u64)(row - 1);
-            lk[at] = (kp << ESP_TAG_BITS) | (u64)a.kind;
+    for (int lo = 0; lo < total; lo += FD_STAGE) {  // (one round, but for a boundary tile)
+        if (lo > 0) __syncthreads();                // (the previous round's copy has read the staging area)
+        auto put = [&](u32 at, double v, i64 row, i64 col) {
+            at -= (u32)lo;
+            if (at >= (u32)FD_STAGE) return;
+            if constexpr (S32) {  // (the low 32 bits of (col-1) << rb | (row-1), in 32-bit arithmetic)
+                lk[at] = (rb < 32 ? (u32)(col - 1) << rb : 0u) | (u32)(row - 1);
+            } else {
+                const u64 kp = ((u64)(col - 1) << rb) | (u64)(row - 1);
+                lk[at] = (kp << ESP_TAG_BITS) | (u64)a.kind;
+            }
+            lv[at] = v;
+        };
+        // update_pair (sprand.jl:87-92): (l,l2) (l2,l) (l,l) (l2,l2) -- column l2 gets the first and the last one
+        auto pair = [&](u32 &own, u32 other, double v, i64 l, i64 l2) {
+            put(other, -v, l, l2);
+            put(own++, -v, l2, l);
+            put(own++, v, l, l);
+            put(other + 1, v, l2, l2);
+        };
+        if (g < a.g_end) {
+            const i64 l = g + 1;
+            const u64 z0 = a.seed + (6ull * (u64)g + 1ull) * ESP_GOLDEN;  // (draw k of this node: counter 6 g + k)
+            const int md = a.rand_mode;
+            u32 own = slot[0];
+            if (it.px) pair(own, slot[1], fd_rand_z(md, z0, 0) * a.hy * a.hz / a.hx, l, l + 1);
+            if (it.bx) put(own++, fd_rand_z(md, z0, 1) * a.hy * a.hz, l, l);
+            if (it.py) pair(own, slot[2], fd_rand_z(md, z0, 2) * a.hx * a.hz / a.hy, l, l + a.nx);
+            if (it.by) put(own++, fd_rand_z(md, z0, 3) * a.hx * a.hz, l, l);
+            if (it.pz) pair(own, slot[3], fd_rand_z(md, z0, 4) * a.hx * a.hy / a.hz, l, l + a.nx * a.ny);
+            if (it.bz) put(own++, fd_rand_z(md, z0, 5) * a.hx * a.hy, l, l);
         }
-        lv[at] = v;
-    };
-    // update_pair (sprand.jl:87-92): (l,l2) (l2,l) (l,l) (l2,l2) -- column l2 gets the first and the last one
-    auto pair = [&](u32 &own, u32 other, double v, i64 l, i64 l2) {
-        put(other, -v, l, l2);
-        put(own++, -v, l2, l);
-        put(own++, v, l, l);
-        put(other + 1, v, l2, l2);
-    };
-    if (g < a.g_end) {
-        const i64 l = g + 1;
-        const u64 z0 = a.seed + (6ull * (u64)g + 1ull) * ESP_GOLDEN;  // (draw k of this node: counter 6 g + k)
-        const int md = a.rand_mode;
-        u32 own = slot[0];
-        if (it.px) pair(own, slot[1], fd_rand_z(md, z0, 0) * a.hy * a.hz / a.hx, l, l + 1);
-        if (it.bx) put(own++, fd_rand_z(md, z0, 1) * a.hy * a.hz, l, l);
-        if (it.py) pair(own, slot[2], fd_rand_z(md, z0, 2) * a.hx * a.hz / a.hy, l, l + a.nx);
-        if (it.by) put(own++, fd_rand_z(md, z0, 3) * a.hx * a.hz, l, l);
-        if (it.pz) pair(own, slot[3], fd_rand_z(md, z0, 4) * a.hx * a.hy / a.hz, l, l + a.nx * a.ny);
-        if (it.bz) put(own++, fd_rand_z(md, z0, 5) * a.hx * a.hy, l, l);
+        __syncthreads();
+        esprun::copy_out_runs<KT, OUT32, THREADS, THREADS / ESP_WAVE>(p, lk, lv, total, S, (u32)a.kind, lo, lo + FD_STAGE);
     }
-    __syncthreads();
-    esprun::copy_out_runs<KT, OUT32, THREADS, THREADS / ESP_WAVE>(p, lk, lv, total, S, (u32)a.kind);
 }
 
 // ---- P1 FEM stream (test/femtools.jl:45-72) on a Kuhn-triangulated tensor grid --------

@@ -722,7 +722,7 @@ __device__ __forceinline__ bool tile_slots(const PartOut &p, const TileLoads &L,
 // KT = u64: packed keys staged and stored as they are.
 template <typename KT, bool OUT32, int NT, int NWAVES>
 __device__ __forceinline__ void copy_out_runs(const PartOut &p, const KT *lk, const double *lv, int total, const TileLds<NWAVES> &S,
-                                              u32 kind) {
+                                              u32 kind, int lo = 0, int hi = 0x7FFFFFFF) {
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -730,10 +730,15 @@ __device__ __forceinline__ void copy_out_runs(const PartOut &p, const KT *lk, co
     // run by run (a handful per tile, hundreds of entries each): two entries per store instruction -- 8-byte / 16-byte
     // key stores and 16-byte value stores on the aligned body of the run, the odd entry at either end on its own
     for (int j = 0; j < RMAX; j++) {
-        const int b = (int)S.lstart[j], len = (int)S.lstart[j + 1] - b;
-        if (b >= total) break;
-        if (len == 0) continue;
-        const i64 ro = S.roff[j];
+        // (staging window [lo, hi) of the tile's slots: a tile that does not fit the staging area goes out in rounds;
+        // slot q of the window sits at lk[q - lo])
+        const int b0 = (int)S.lstart[j], e0 = (int)S.lstart[j + 1];
+        if (b0 >= total || b0 >= hi) break;
+        const int bw = max(b0, lo), ew = min(e0, hi);
+        const int len = ew - bw;
+        if (len <= 0) continue;
+        const int b = bw - lo;
+        const i64 ro = S.roff[j] + (i64)(bw - b0);
         const u64 rb = S.rbase[j];
         // 4-byte keys for this run: every run (OUT32), or the runs of a shard's own window (own32; KT = u32 then)
         bool run32 = OUT32;

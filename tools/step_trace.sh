@@ -14,9 +14,10 @@ for f in glob.glob('gpurun_out/trc/**/*memory_copy_trace.csv', recursive=True):
     for r in csv.DictReader(open(f)):
         rows.append((int(r['Start_Timestamp']), int(r['End_Timestamp']), 'COPY ' + r.get('Direction', '')))
 rows.sort()
-# last step = from the last fdrand_k on
-last = max(i for i, r in enumerate(rows) if 'fdrand_k' in r[2])
-prev = [i for i, r in enumerate(rows) if 'fdrand_k' in r[2]][-2]
+# last step = between the last two launches of the producer's first kernel (COUNT launch, or the plain producer)
+mark = 'fd_count_k' if any('fd_count_k' in r[2] for r in rows) else 'fdrand_k'
+hits = [i for i, r in enumerate(rows) if mark in r[2]]
+last, prev = hits[-1], hits[-2]
 out = open('gpurun_out/step_trace.txt', 'w')
 t0 = rows[prev][0]
 pe = t0
