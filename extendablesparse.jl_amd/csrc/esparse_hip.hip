@@ -1583,6 +1583,10 @@ static int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSet
     o.mw_P = mw.ok ? ps->mw_P : 0;
     o.mw_nb = ps->mw_nb;
     o.mw_base = (const u64 *)h->parttab.p;
+    if (mw.ok) {
+        o.mw_own_base = mw.base[(size_t)ps->mw_me];
+        o.mw_own_width = ps->mw_me + 1 < ps->mw_P ? mw.base[(size_t)ps->mw_me + 1] - o.mw_own_base : ~0ull - o.mw_own_base;
+    }
     o.shift = shift;
     o.base = h->win_base;
     o.span = h->win_span;
@@ -3342,7 +3346,8 @@ extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t s
     const size_t o_cnt = 256 * 8;
     CK(ensure(h, h->parttab, o_cnt + sizeof(i64) * (size_t)(NB + 1)));
     char *T = (char *)h->parttab.p;
-    HIPCK(h, hipMemcpyAsync(T, base.data(), sizeof(u64) * (size_t)P, hipMemcpyHostToDevice, h->stream));
+    // (a producer's batch: prepart_begin wrote the window bases; the copy would queue behind the PART launch)
+    if (!from_producer) HIPCK(h, hipMemcpyAsync(T, base.data(), sizeof(u64) * (size_t)P, hipMemcpyHostToDevice, h->stream));
     i64 *cnt = (i64 *)(T + o_cnt);
     CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(NB + 1)));
     CK(ensure(h, h->tilef[1], sizeof(u64) * (size_t)(NB + 1 + espscan::workspace_elems(NB + 1))));

@@ -302,6 +302,13 @@ __global__ __launch_bounds__(THREADS) void fdrand_part_k(FdArgs a) {
             if (it.bz) put(own++, fd_rand_z(md, z0, 5) * a.hx * a.hy, l, l);
         }
         __syncthreads();
+        if constexpr (S32 && !OUT32) {
+            if (S.all_own) {  // (a shard's usual tile: the 4-byte-key copy loop of the unsharded producer)
+                esprun::copy_out_runs<KT, true, THREADS, THREADS / ESP_WAVE>(p, lk, lv, total, S, (u32)a.kind, lo, lo + FD_STAGE,
+                                                                           esprun::own_keys32(p.keys_out, S.own_lo));
+                continue;
+            }
+        }
         esprun::copy_out_runs<KT, OUT32, THREADS, THREADS / ESP_WAVE>(p, lk, lv, total, S, (u32)a.kind, lo, lo + FD_STAGE);
     }
 }

@@ -128,7 +128,7 @@ struct Args {
     // for its own columns itself -- no column-end marks, no scan over the columns afterwards (nullptr: marks in colend)
     u32 kind32;  // K32 kernels: the kind of every entry; KEYS 4 / 5: of the entries of piece k32_piece
     int k32_piece;  // KEYS 4 / 5: the piece that holds 4-byte keys ...
-    i64 k32_lo;     // ... from its position k32_lo on: key of position p at ((u32 *)(keys + k32_lo))[p - k32_lo]
+    i64 k32_lo;     // ... from its position k32_lo on: key of position p at esprun::own_keys32(keys, k32_lo)[p]
     i64 *colptr_out;
     i64 n_cols;   // columns of the matrix (column-end marks of a failing flush -- keys outside the window -- stay inside colend)
     i64 col_end;  // end of the column range (colptr_out[col_end] = 1 + nnz comes from the last segment)
@@ -770,8 +770,8 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
 #pragma unroll
                 for (int i = 0; i < NI; i++) k[i] = (u64)pk4[beg + min(wbase + i * ESP_WAVE, nlast)];
             } else if (P32 && single == a.k32_piece) {
-                // (the 4-byte key of position p of the piece sits at ((u32 *)(keys + k32_lo))[p - k32_lo])
-                const g_u32 pk4 = (g_u32)(pk + a.k32_lo) - a.k32_lo;
+                // (the 4-byte key of position p of the piece sits at esprun::own_keys32(keys, k32_lo)[p])
+                const g_u32 pk4 = (g_u32)(pk + a.k32_lo) + (a.k32_lo & 1) - a.k32_lo;  // (esprun::own_keys32)
 #pragma unroll
                 for (int i = 0; i < NI; i++)
                     k[i] = ((hi + (u64)pk4[beg + min(wbase + i * ESP_WAVE, nlast)]) << ESP_TAG_BITS) | (u64)a.kind32;
@@ -796,7 +796,7 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
                 if constexpr (K32)
                     ak[i] = (g_u64)((g_u32)base_k + at);
                 else
-                    ak[i] = k4[i] ? (g_u64)((g_u32)(base_k + a.k32_lo) + (at - a.k32_lo)) : base_k + at;
+                    ak[i] = k4[i] ? (g_u64)((g_u32)(base_k + a.k32_lo) + ((a.k32_lo & 1) + at - a.k32_lo)) : base_k + at;
                 av[i] = (g_f64)p_v[q] + at;
             }
 #pragma unroll

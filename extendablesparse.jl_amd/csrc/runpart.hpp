@@ -580,6 +580,7 @@ struct PartOut {
     int mw_P;
     u32 mw_nb;
     const u64 *mw_base;    // first key of every window, ascending
+    u64 mw_own_base, mw_own_width;  // ... and the own window's first key / key count (arguments: no load in the common case)
     // a shard's OWN window goes out as 4-byte keys (the bits below the bucket prefix, one kind for the batch), the
     // ranges it sends to other ranks as packed keys: own32 != 0, window mw_me; the 4-byte keys of bucket position p of
     // the own range [*own_lo, ...) live at ((u32 *)(keys_out + *own_lo))[p - *own_lo], inside the range's own bytes
@@ -589,6 +590,14 @@ struct PartOut {
 };
 
 // LDS tables of one producer workgroup (tile = chunk)
+// 4-byte keys of a shard's own range: the key of batch position p sits at own_keys32(keys, own_lo)[p] -- inside the
+// range's own bytes (8 per entry, 4 used), one slot further when own_lo is odd, so that an even p is 8-byte aligned and
+// pairs of keys go out aligned together with pairs of values
+__device__ __forceinline__ u32 *own_keys32(u64 *keys, i64 own_lo) { return reinterpret_cast<u32 *>(keys + own_lo) + (own_lo & 1) - own_lo; }
+__device__ __forceinline__ const u32 *own_keys32(const u64 *keys, i64 own_lo) {
+    return reinterpret_cast<const u32 *>(keys + own_lo) + (own_lo & 1) - own_lo;
+}
+
 template <int NWAVES>
 struct TileLds {
     u32 cnt[NWAVES][RMAX];  // entries of wave w in run j of the tile
@@ -597,6 +606,7 @@ struct TileLds {
     u64 rbase[RMAX];        // first key of run j's bucket (window base + digit << shift)
     u32 rown[RMAX];         // own32: run j lies in the shard's own window
     i64 own_lo;
+    u32 all_own;            // own32: every run of the tile does (the usual tile of a slab-wise assembly)
 };
 
 // Where a thread's entries go inside the tile's LDS staging area.  A thread (a stencil node, a FEM cell) holds NQ
@@ -698,7 +708,7 @@ __device__ __forceinline__ bool tile_slots(const PartOut &p, const TileLoads &L,
         if (lane < nr) {
             if (p.mw_P) {
                 const u32 r = my_run_digit / p.mw_nb;
-                rb = p.mw_base[r] + ((u64)(my_run_digit - r * p.mw_nb) << p.shift);
+                rb = ((int)r == p.mw_me ? p.mw_own_base : p.mw_base[r]) + ((u64)(my_run_digit - r * p.mw_nb) << p.shift);
                 own = (p.own32 && (int)r == p.mw_me) ? 1u : 0u;
             } else {
                 rb = p.base + ((u64)my_run_digit << p.shift);
@@ -706,7 +716,11 @@ __device__ __forceinline__ bool tile_slots(const PartOut &p, const TileLoads &L,
         }
         S.rbase[lane] = rb;
         S.rown[lane] = own;
-        if (lane == 0) S.own_lo = L.own_lo;
+        const u64 foreign = __ballot(lane < nr && !own);
+        if (lane == 0) {
+            S.own_lo = L.own_lo;
+            S.all_own = (p.own32 && foreign == 0ull) ? 1u : 0u;
+        }
     }
 #pragma unroll
     for (int q = 0; q < NQ; q++) slot[q] = (u32)__shfl((int)sb, (int)jq[q], ESP_WAVE) + pq[q];
@@ -722,7 +736,7 @@ __device__ __forceinline__ bool tile_slots(const PartOut &p, const TileLoads &L,
 // KT = u64: packed keys staged and stored as they are.
 template <typename KT, bool OUT32, int NT, int NWAVES>
 __device__ __forceinline__ void copy_out_runs(const PartOut &p, const KT *lk, const double *lv, int total, const TileLds<NWAVES> &S,
-                                              u32 kind, int lo = 0, int hi = 0x7FFFFFFF) {
+                                              u32 kind, int lo = 0, int hi = 0x7FFFFFFF, u32 *k4_all = nullptr) {
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -741,14 +755,14 @@ __device__ __forceinline__ void copy_out_runs(const PartOut &p, const KT *lk, co
         const i64 ro = S.roff[j] + (i64)(bw - b0);
         const u64 rb = S.rbase[j];
         // 4-byte keys for this run: every run (OUT32), or the runs of a shard's own window (own32; KT = u32 then)
+        // (k4_all: OUT32 for a tile whose runs all lie in the shard's own window -- the keys go to own_keys32)
         bool run32 = OUT32;
-        u32 *k4 = reinterpret_cast<u32 *>(p.keys_out);
-        i64 k4off = 0;  // index of the 4-byte key of bucket position q: q - k4off
+        u32 *k4 = OUT32 && k4_all ? k4_all : reinterpret_cast<u32 *>(p.keys_out);
+        const i64 k4off = 0;  // index of the 4-byte key of bucket position q: q - k4off
         if constexpr (sizeof(KT) == 4 && !OUT32) {
             if (S.rown[j]) {
                 run32 = true;
-                k4 = reinterpret_cast<u32 *>(p.keys_out + S.own_lo);
-                k4off = S.own_lo;
+                k4 = own_keys32(p.keys_out, S.own_lo);
             }
         }
         auto key_of = [&](int q) -> u64 {  // what goes out for staged entry q: the 4-byte key, or the packed key
@@ -798,10 +812,8 @@ __device__ __forceinline__ u32 column_digit(const PartOut &p, i64 col0, int rb, 
     const u64 key = (u64)col0 << rb;
     if (p.mw_P) {
         // (a rank mostly produces entries of its own column range: that window is tried first)
-        const u64 b_own = p.mw_base[p.mw_me];
-        const u64 rel_own = key - b_own;
-        const u64 w_own = p.mw_me + 1 < p.mw_P ? p.mw_base[p.mw_me + 1] - b_own : ~0ull - b_own;
-        if (rel_own < w_own) {
+        const u64 rel_own = key - p.mw_own_base;
+        if (rel_own < p.mw_own_width) {
             u64 dl = rel_own >> p.shift;
             dl = dl < (u64)p.mw_nb ? dl : (u64)p.mw_nb - 1;
             return (u32)p.mw_me * p.mw_nb + (u32)dl;
@@ -835,15 +847,15 @@ __global__ __launch_bounds__(THREADS) void expand_keys_k(const u32 *__restrict__
 }
 
 // the same for a shard's own window (digits [d0, d0 + nb) of the multi-window partition): 4-byte keys at
-// ((u32 *)(keys + own_lo))[p - own_lo] -> packed keys at out[p]
+// own_keys32(keys, own_lo)[p] -> packed keys at out[p]
 __global__ __launch_bounds__(THREADS) void expand_own_keys_k(const u64 *__restrict__ keys, const i64 *__restrict__ seg_start, i64 d0,
                                                              int shift, u64 base, u32 kind, u64 *__restrict__ out) {
     const i64 s = blockIdx.x;
     const i64 own_lo = seg_start[d0];
     const i64 b = seg_start[d0 + s], e = seg_start[d0 + s + 1];
-    const u32 *k32 = reinterpret_cast<const u32 *>(keys + own_lo);
+    const u32 *k32 = own_keys32(keys, own_lo);
     const u64 hi = ((u64)s << shift) + base;
-    for (i64 i = b + threadIdx.x; i < e; i += THREADS) out[i] = ((hi + (u64)k32[i - own_lo]) << ESP_TAG_BITS) | (u64)kind;
+    for (i64 i = b + threadIdx.x; i < e; i += THREADS) out[i] = ((hi + (u64)k32[i]) << ESP_TAG_BITS) | (u64)kind;
 }
 
 }  // namespace esprun
