@@ -128,9 +128,14 @@ struct ColArgs {
     double *out_val;
 };
 
+// The tile's new keys are staged in LDS (a tile of 256 stencil columns gains a few hundred; a tile with more than
+// NEWCAP of them searches global memory), every thread handles MB entries per round with all their loads requested
+// first, and the searches of a round's entries advance together (a binary search is a chain of dependent loads).
+constexpr int NEWCAP = 2048, MB = 4;
 __global__ __launch_bounds__(THREADS) void colmerge_k(ColArgs a) {
     __shared__ i64 s_cp[CT + 1];
     __shared__ u64 s_ns[CT + 1];
+    __shared__ u64 s_new[NEWCAP];
     const int t = threadIdx.x;
     const i64 c0 = a.c_begin + (i64)blockIdx.x * CT;
     const int nc = (int)min((i64)CT, a.c_begin + a.ncols - c0);
@@ -141,44 +146,102 @@ __global__ __launch_bounds__(THREADS) void colmerge_k(ColArgs a) {
     __syncthreads();
     const i64 op0 = s_cp[0], op1 = s_cp[nc];
     const i64 np0 = (i64)s_ns[0], np1 = (i64)s_ns[nc];
+    const bool staged = np1 - np0 <= (i64)NEWCAP;
+    if (staged)
+        for (i64 q = np0 + t; q < np1; q += THREADS) s_new[q - np0] = a.new_key[q];
+    __syncthreads();
     const u64 rowmask = (1ull << a.rb) - 1ull;
-    for (i64 p = op0 + t; p < op1; p += THREADS) {
-        int lo = 0, hi = nc;  // the column: largest c with s_cp[c] <= p
-        while (hi - lo > 1) {
-            const int mid = (lo + hi) >> 1;
-            if (s_cp[mid] <= p)
-                lo = mid;
-            else
-                hi = mid;
+    // ---- stored entries
+    for (i64 base = op0; base < op1; base += (i64)MB * THREADS) {
+        i64 row[MB], pos[MB];
+        double val[MB];
+#pragma unroll
+        for (int i = 0; i < MB; i++) {
+            const i64 p = base + (i64)i * THREADS + t;
+            pos[i] = p < op1 ? p : -1;
+            const i64 pc = p < op1 ? p : op1 - 1;  // (clamped: the loads need no branch)
+            row[i] = a.old_row[pc];
+            val[i] = a.old_val[pc];
         }
-        const i64 row = a.old_row[p];
-        i64 b = (i64)s_ns[lo], e = (i64)s_ns[lo + 1];
-        while (b < e) {  // new entries of the column with a smaller row
-            const i64 mid = b + ((e - b) >> 1);
-            if ((i64)(a.new_key[mid] & rowmask) + 1 < row)
-                b = mid + 1;
-            else
-                e = mid;
+#pragma unroll
+        for (int i = 0; i < MB; i++) {
+            if (pos[i] < 0) continue;
+            const i64 p = pos[i];
+            int lo = 0, hi = nc;  // the column: largest c with s_cp[c] <= p
+            while (hi - lo > 1) {
+                const int mid = (lo + hi) >> 1;
+                if (s_cp[mid] <= p)
+                    lo = mid;
+                else
+                    hi = mid;
+            }
+            i64 b = (i64)s_ns[lo], e = (i64)s_ns[lo + 1];
+            if (staged) {
+                while (b < e) {  // new entries of the column with a smaller row
+                    const i64 mid = b + ((e - b) >> 1);
+                    if ((i64)(s_new[mid - np0] & rowmask) + 1 < row[i])
+                        b = mid + 1;
+                    else
+                        e = mid;
+                }
+            } else {
+                while (b < e) {
+                    const i64 mid = b + ((e - b) >> 1);
+                    if ((i64)(a.new_key[mid] & rowmask) + 1 < row[i])
+                        b = mid + 1;
+                    else
+                        e = mid;
+                }
+            }
+            const i64 out = p + b;  // = p + newstart[c] + count
+            a.out_row[out] = row[i];
+            a.out_val[out] = val[i];
         }
-        const i64 out = p + b;  // = p + newstart[c] + count
-        a.out_row[out] = row;
-        a.out_val[out] = a.old_val[p];
     }
-    for (i64 q = np0 + t; q < np1; q += THREADS) {
-        const u64 key = a.new_key[q];
-        const int lc = (int)((i64)(key >> a.rb) - c0);
-        const i64 row = (i64)(key & rowmask) + 1;
-        i64 b = s_cp[lc], e = s_cp[lc + 1];
-        while (b < e) {  // stored entries of the column with a smaller row
-            const i64 mid = b + ((e - b) >> 1);
-            if (a.old_row[mid] < row)
-                b = mid + 1;
-            else
-                e = mid;
+    // ---- new entries
+    for (i64 base = np0; base < np1; base += (i64)MB * THREADS) {
+        i64 row[MB], b[MB], e[MB], pos[MB];
+        double val[MB];
+#pragma unroll
+        for (int i = 0; i < MB; i++) {
+            const i64 q = base + (i64)i * THREADS + t;
+            pos[i] = q < np1 ? q : -1;
+            const i64 qc = q < np1 ? q : np1 - 1;
+            const u64 key = staged ? s_new[qc - np0] : a.new_key[qc];
+            val[i] = a.new_val[qc];
+            const int lc = (int)((i64)(key >> a.rb) - c0);
+            row[i] = (i64)(key & rowmask) + 1;
+            b[i] = s_cp[lc];
+            e[i] = pos[i] >= 0 ? s_cp[lc + 1] : b[i];
         }
-        const i64 out = q + b;  // = q + (colptr[c]-1) + count
-        a.out_row[out] = row;
-        a.out_val[out] = a.new_val[q];
+        // stored entries of the column with a smaller row: the MB searches step together
+        bool more = true;
+        while (more) {
+            more = false;
+            i64 mid[MB], r[MB];
+#pragma unroll
+            for (int i = 0; i < MB; i++) {
+                mid[i] = b[i] + ((e[i] - b[i]) >> 1);
+                r[i] = b[i] < e[i] ? a.old_row[mid[i]] : 0;
+            }
+#pragma unroll
+            for (int i = 0; i < MB; i++) {
+                if (b[i] < e[i]) {
+                    if (r[i] < row[i])
+                        b[i] = mid[i] + 1;
+                    else
+                        e[i] = mid[i];
+                }
+                more |= b[i] < e[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MB; i++) {
+            if (pos[i] < 0) continue;
+            const i64 out = pos[i] + b[i];  // = q + (colptr[c]-1) + count
+            a.out_row[out] = row[i];
+            a.out_val[out] = val[i];
+        }
     }
 }
 
