@@ -879,9 +879,11 @@ def test_producer_batch_with_a_tail(esp, orc):
         return kn, In, Jn, Vn
 
     for variant in ("fresh_mixed", "two_tails", "stored", "stored_routed_kinds", "overfull", "unsorted", "force19", "getindex",
-                    "fem"):
+                    "fem", "packed", "packed_update"):
         A = esp.ExtendableSparseMatrix(N, N)
         O = orc.ExtendableSparseMatrix(N, N)
+        if variant.startswith("packed"):
+            A.debug_force_path(14)                         # (the batch holds packed keys: two packed pieces, KEYS 0 / 3)
         expect = 5
         if variant in ("stored", "stored_routed_kinds"):
             A.generate_fdrand(n, n, n, seed=30, rand_mode=1)
@@ -903,11 +905,11 @@ def test_producer_batch_with_a_tail(esp, orc):
         else:
             A.generate_fdrand(n, n, n, seed=31, rand_mode=1)
             upd(O, I, J, V)
-        if variant == "fresh_mixed":
+        if variant in ("fresh_mixed", "packed"):
             kn, In, Jn, Vn = tail(5000, kinds=[UPDATE, orc.KIND_SET, orc.KIND_RAWUPDATE])
             A.append(0, In, Jn, Vn, kinds=kn)
             O.apply(kn, In, Jn, Vn)
-        elif variant == "two_tails":
+        elif variant in ("two_tails", "packed_update"):
             for k in (700, 1):
                 kn, In, Jn, Vn = tail(k)
                 A.append(UPDATE, In, Jn, Vn)
@@ -1531,10 +1533,12 @@ def test_config3_digest_128(esp):
     N = n ** 3
     d = gu.digests("digests_large.txt")["cfg3_%d" % n]
     I2, J2, V2 = gu.cfg3_new_positions(n)
-    for order in ("append_first", "generate_first"):
+    for order in ("append_first", "generate_first", "generate_first_19"):
         A = esp.ExtendableSparseMatrix(N, N)
         A.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1)
         A.flush()
+        if order.endswith("_19"):
+            A.debug_force_path(19)                   # (no batch + tail flush: packed keys, the ordinary partition)
         if order == "append_first":
             A.append(UPDATE, I2, J2, V2)
             A.generate_fdrand(n, n, n, seed=0x5EED0012, rand_mode=1)
@@ -1543,6 +1547,8 @@ def test_config3_digest_128(esp):
             A.generate_fdrand(n, n, n, seed=0x5EED0012, rand_mode=1)
             A.append(UPDATE, I2, J2, V2)
         A.flush()
+        # (the bench's order: the producer's batch stays, the flush partitions the new couplings alone)
+        assert (A.debug_last_partition() == 5) == (order == "generate_first"), (order, A.debug_last_partition())
         arrs = hip_arrays(A)
         assert len(arrs[1]) == int(d["nnz"])
         assert gu.digest(*arrs) == d["csc"], order
