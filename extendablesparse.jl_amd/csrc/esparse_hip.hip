@@ -2601,7 +2601,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
     if (mode != ESP_FLUSH_ROUTED && mode != ESP_FLUSH_PLUS) FAIL(h, ESP_ERR_INVALID, "esp_flush: mode");
     (void)hipSetDevice(h->device);
     if (pattern_changed) *pattern_changed = 0;
-    const i64 E = h->count;
+    i64 E = h->count;
     if (E == 0) {
         if (new_nnz) *new_nnz = h->nnz;
         return ESP_OK;
@@ -2621,7 +2621,52 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
                             pp.span == h->win_span && pp.maxlen <= (i64)esplocal::CAP && pp.K - pp.pb <= esplocal::MAX_REM_BITS;
         if (!usable) CK(pending_materialize(h));
     }
-    bool served = false;
+    bool served = false, split = false;
+    i64 Zsplit = 0;  // new entries of the batch's own flush
+    if (h->pre.valid && h->pre.tail > 0 && h->nnz > 0 && h->force_path != 22) {
+        // Batch + tail over a stored pattern (a re-assembly whose mesh gained couplings): the batch by itself -- its buckets
+        // fit the small variant of the bucket kernel, and a batch of hits emits nothing and needs no join -- then the tail
+        // as a flush of its own.  A flush may be cut at any stream position: flush! between two calls never changes a
+        // result (extendable.jl:248-255).  force_path 22: one flush over two pieces, as on a fresh matrix.
+        const esp_handle::PrePart pp = h->pre;
+        Sorted st;
+        st.sk = (const u64 *)h->keys.p;
+        st.sv = (const double *)h->vals.p;
+        st.in_primary = true;
+        st.S = 1 << pp.pb;
+        st.seg_start = (const i64 *)h->seg[1].p;
+        st.rem_bits = pp.K - pp.pb;
+        st.local_ok = true;
+        st.key_bytes = pp.key_bytes;
+        st.kind = pp.kind;
+        st.maxlen = pp.maxlen;
+        CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
+        CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
+        CK(flush_local(h, st, mode, &Zsplit));  // (on failure everything is still pending)
+        // the tail is the pending buffer now: packed keys, moved to the front (chunks of at most E0 entries: source and
+        // destination of one copy never overlap)
+        const i64 E0 = pp.E, T = pp.tail;
+        {
+            Span sp(h, ESP_ST_COPY);
+            for (i64 at = 0; at < T; at += E0) {
+                const i64 c = std::min(E0, T - at);
+                HIPCK(h, hipMemcpyAsync((u64 *)h->keys.p + at, (const u64 *)h->keys.p + E0 + at, sizeof(u64) * (size_t)c, hipMemcpyDeviceToDevice, h->stream));
+                HIPCK(h, hipMemcpyAsync((double *)h->vals.p + at, (const double *)h->vals.p + E0 + at, sizeof(double) * (size_t)c, hipMemcpyDeviceToDevice, h->stream));
+                sp.add(2);
+            }
+        }
+        const bool one_kind = h->kind_uniform >= 0 && h->kind_noted == h->count;
+        h->count = T;
+        h->pre.valid = false;
+        h->kind_noted = one_kind ? T : 0;
+        if (!one_kind) h->kind_uniform = -2;
+        h->shard_valid = h->part_valid = false;
+        h->values_version++;
+        E = T;
+        split = true;
+        // (the tail gets a plan of its own: fewer, fuller segments -- with the batch's 2^16 buckets, small variant and 4-byte
+        // keys included, its bucket kernel took 1.4 instead of 0.9 ms at config 3: time follows the number of segments)
+    }
     if (h->pre.valid && h->pre.tail > 0) {
         // batch + tail: only the tail is partitioned, the bucket kernel reads every segment as two pieces
         CK(flush_pre_tail(h, mode, &Zn, &served));
@@ -2699,8 +2744,9 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         }
     }
     if (!use_local && !h->part_assembled) CK(flush_global(h, mode, &Zn));
+    if (split) h->last_partition = 6;
     h->last_path = (use_local || h->part_assembled) ? 1 : 2;
-    if (Zn > 0 && pattern_changed) *pattern_changed = 1;
+    if ((Zn > 0 || Zsplit > 0) && pattern_changed) *pattern_changed = 1;
     h->values_version++;  // (hits were applied in place)
     HIPCK(h, hipGetLastError());
     h->count = 0;

@@ -326,7 +326,8 @@ int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear);
  * 16 = the device-side producers (esp_generate_*) always append in stream order (never the producer-side partition),
  * 17 = the join with an existing CSC runs as a merge-path over a per-entry column array (a second implementation of the
  *      column-tiled join), 18 = never the small variant of the bucket kernel (see esp_debug_last_local_small),
- * 19 = an append behind a producer's bucket-ordered batch turns it back into packed keys (no "batch + tail" flush);
+ * 19 = an append behind a producer's bucket-ordered batch turns it back into packed keys (no "batch + tail" flush),
+ * 22 = a batch + tail over a stored pattern is ONE flush over two pieces (as on a fresh matrix) instead of two flushes;
  * last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general) */
 int32_t esp_debug_force_path(esp_handle *h, int32_t path);
 int32_t esp_debug_last_path(const esp_handle *h, int32_t *path);
@@ -354,6 +355,7 @@ int32_t esp_debug_last_local_small(const esp_handle *h, int32_t *small);
  *     of the producer, then its stores go to `bucket start + stable rank`; the flush starts at the bucket kernel),
  * 5 = such a batch with entries appended behind it: the run-based pass over those entries only, the bucket kernel
  *     reads every segment as two pieces (batch, tail),
+ * 6 = such a batch + tail over a stored pattern: the batch flushed by itself (as 4), then the tail as a flush of its own,
  * 7 = none: the segments came assembled from esp_shard_assemble */
 int32_t esp_debug_last_partition(const esp_handle *h, int32_t *kind);
 

@@ -878,14 +878,14 @@ def test_producer_batch_with_a_tail(esp, orc):
         kn = np.full(k, UPDATE, np.uint8) if kinds is None else rng.choice(np.array(kinds, np.uint8), k)
         return kn, In, Jn, Vn
 
-    for variant in ("fresh_mixed", "two_tails", "stored", "stored_routed_kinds", "overfull", "unsorted", "force19", "getindex",
+    for variant in ("fresh_mixed", "two_tails", "stored", "stored_routed_kinds", "stored_one_flush", "overfull", "unsorted", "force19", "getindex",
                     "fem", "packed", "packed_update"):
         A = esp.ExtendableSparseMatrix(N, N)
         O = orc.ExtendableSparseMatrix(N, N)
         if variant.startswith("packed"):
             A.debug_force_path(14)                         # (the batch holds packed keys: two packed pieces, KEYS 0 / 3)
         expect = 5
-        if variant in ("stored", "stored_routed_kinds"):
+        if variant.startswith("stored"):
             A.generate_fdrand(n, n, n, seed=30, rand_mode=1)
             A.flush()
             upd(O, *orc.fdrand_stream(n, n, n, rand_mode=1, seed=30))
@@ -914,10 +914,13 @@ def test_producer_batch_with_a_tail(esp, orc):
                 kn, In, Jn, Vn = tail(k)
                 A.append(UPDATE, In, Jn, Vn)
                 O.apply(kn, In, Jn, Vn)
-        elif variant in ("stored", "stored_routed_kinds"):
-            kn, In, Jn, Vn = tail(4000, kinds=None if variant == "stored" else [UPDATE, orc.KIND_SET])
+        elif variant in ("stored", "stored_routed_kinds", "stored_one_flush"):
+            kn, In, Jn, Vn = tail(4000, kinds=None if variant != "stored_routed_kinds" else [UPDATE, orc.KIND_SET])
+            if variant == "stored_one_flush":
+                A.debug_force_path(22)                     # (two pieces in one flush, as on a fresh matrix)
             A.append(0, In, Jn, Vn, kinds=kn)
             O.apply(kn, In, Jn, Vn)
+            expect = 5 if variant == "stored_one_flush" else 6   # (over a stored pattern: the batch alone, then the tail)
         elif variant == "overfull":                        # 6000 further entries in the columns of one segment
             k = 6000
             In, Jn, Vn = rng.integers(1, N + 1, k), np.sort(rng.integers(1000, 1004, k)), rng.standard_normal(k)
@@ -1547,8 +1550,8 @@ def test_config3_digest_128(esp):
             A.generate_fdrand(n, n, n, seed=0x5EED0012, rand_mode=1)
             A.append(UPDATE, I2, J2, V2)
         A.flush()
-        # (the bench's order: the producer's batch stays, the flush partitions the new couplings alone)
-        assert (A.debug_last_partition() == 5) == (order == "generate_first"), (order, A.debug_last_partition())
+        # (the bench's order: the producer's batch is flushed as it is, the new couplings as a flush of their own)
+        assert (A.debug_last_partition() == 6) == (order == "generate_first"), (order, A.debug_last_partition())
         arrs = hip_arrays(A)
         assert len(arrs[1]) == int(d["nnz"])
         assert gu.digest(*arrs) == d["csc"], order
