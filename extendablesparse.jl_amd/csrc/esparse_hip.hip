@@ -2650,8 +2650,14 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
             Span sp(h, ESP_ST_COPY);
             for (i64 at = 0; at < T; at += E0) {
                 const i64 c = std::min(E0, T - at);
-                HIPCK(h, hipMemcpyAsync((u64 *)h->keys.p + at, (const u64 *)h->keys.p + E0 + at, sizeof(u64) * (size_t)c, hipMemcpyDeviceToDevice, h->stream));
-                HIPCK(h, hipMemcpyAsync((double *)h->vals.p + at, (const double *)h->vals.p + E0 + at, sizeof(double) * (size_t)c, hipMemcpyDeviceToDevice, h->stream));
+                hipError_t e1 = hipMemcpyAsync((u64 *)h->keys.p + at, (const u64 *)h->keys.p + E0 + at, sizeof(u64) * (size_t)c, hipMemcpyDeviceToDevice, h->stream);
+                if (e1 == hipSuccess)
+                    e1 = hipMemcpyAsync((double *)h->vals.p + at, (const double *)h->vals.p + E0 + at, sizeof(double) * (size_t)c, hipMemcpyDeviceToDevice, h->stream);
+                if (e1 != hipSuccess) {  // (the batch is in the matrix already: it must not stay pending and be applied again)
+                    h->count = 0;
+                    pending_changed(h);
+                    FAIL(h, ESP_ERR_HIP, "esp_flush: %s while moving the entries behind a flushed batch; they were dropped", hipGetErrorString(e1));
+                }
                 sp.add(2);
             }
         }
