@@ -1251,7 +1251,7 @@ static int32_t partition_pass(esp_handle *h, espradix::Pass &p, i64 max_tiles) {
     HIPCK(h, hipMemsetAsync(p.hist, 0, sizeof(u64) * (size_t)hn, h->stream));
     {
         Span sp(h, ESP_ST_HIST);
-        hipLaunchKernelGGL(espradix::tile_hist_k, dim3((unsigned)max_tiles), dim3(espradix::THREADS), 0, h->stream, p);
+        hipLaunchKernelGGL(espradix::tile_hist_k, dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
         sp.add(1);
     }
     {
@@ -1260,7 +1260,7 @@ static int32_t partition_pass(esp_handle *h, espradix::Pass &p, i64 max_tiles) {
     }
     {
         Span sp(h, ESP_ST_SCATTER);
-        hipLaunchKernelGGL(espradix::scatter_k, dim3((unsigned)max_tiles), dim3(espradix::THREADS), 0, h->stream, p);
+        hipLaunchKernelGGL(espradix::scatter_k, dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
         sp.add(1);
     }
     return ESP_OK;
@@ -2845,7 +2845,7 @@ static int32_t shard_prepare(esp_handle *h, int P, espradix::Pass *out) {
         HIPCK(h, hipMemsetAsync(p.hist, 0, sizeof(u64) * (size_t)hn, h->stream));
         if (E > 0) {
             Span sp(h, ESP_ST_HIST);
-            hipLaunchKernelGGL(espradix::tile_hist_k, dim3((unsigned)T), dim3(espradix::THREADS), 0, h->stream, p);
+            hipLaunchKernelGGL(espradix::tile_hist_k, dim3(espradix::scatter_grid(T)), dim3(espradix::THREADS), 0, h->stream, p);
             sp.add(1);
         }
         {
@@ -2895,7 +2895,7 @@ extern "C" int32_t esp_shard_export(esp_handle *h, int32_t nshards, uint64_t *d_
         p.keys_out = (u64 *)d_keys;
         p.vals_out = d_vals;
         Span sp(h, ESP_ST_SCATTER);
-        hipLaunchKernelGGL(espradix::scatter_k, dim3((unsigned)ceil_div<i64>(h->count, espradix::TILE)), dim3(espradix::THREADS), 0,
+        hipLaunchKernelGGL(espradix::scatter_k, dim3(espradix::scatter_grid(ceil_div<i64>(h->count, espradix::TILE))), dim3(espradix::THREADS), 0,
                            h->stream, p);
         sp.add(1);
         HIPCK(h, hipGetLastError());
@@ -2954,7 +2954,7 @@ extern "C" int32_t esp_shard_exchange_begin(esp_handle *h, int32_t nshards, int3
         p.keys_out = (u64 *)h->keys2.p;
         p.vals_out = (double *)h->vals2.p;
         Span sp(h, ESP_ST_SCATTER);
-        hipLaunchKernelGGL(espradix::scatter_k, dim3((unsigned)T), dim3(espradix::THREADS), 0, h->stream, p);
+        hipLaunchKernelGGL(espradix::scatter_k, dim3(espradix::scatter_grid(T)), dim3(espradix::THREADS), 0, h->stream, p);
         sp.add(1);
         HIPCK(h, hipGetLastError());
     }

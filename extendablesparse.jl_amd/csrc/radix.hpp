@@ -21,6 +21,18 @@ constexpr int ITEMS = 16;
 constexpr int TILE = THREADS * ITEMS;
 constexpr int RADIX = 256;
 
+constexpr int XCDS = 8;  // L2s of an MI355X (scatter_k's tile order)
+// grid of scatter_k for `tiles` tiles: a multiple of XCDS (workgroups whose tile does not exist leave at once)
+static inline unsigned scatter_grid(long long tiles) { return (unsigned)(((tiles + XCDS - 1) / XCDS) * XCDS); }
+// XCD-aware tile order: workgroups go round-robin to the 8 XCDs, each with an L2 of its own.  Workgroup i takes tile
+// (i mod 8) * (grid / 8) + i / 8 (the grid is a multiple of 8, scatter_grid): an XCD works through a contiguous range of
+// tiles, so what consecutive tiles write side by side -- the 128-byte pieces they append to a digit's output range, their
+// 8-byte counts in the digit-major histogram -- meets in ONE L2 and leaves it as full lines (with tile = i the
+// neighbours of a piece were written through seven other L2s: 3-D FEM 31 -> 22 ms for the scatter kernels)
+__device__ __forceinline__ long long xcd_tile() {
+    const long long per_xcd = (long long)gridDim.x / XCDS;
+    return (long long)(blockIdx.x % XCDS) * per_xcd + (long long)(blockIdx.x / XCDS);
+}
 struct Pass {
     const u64 *keys_in;
     const double *vals_in;
@@ -69,7 +81,7 @@ __device__ __forceinline__ int find_segment(const i64 *__restrict__ tile_first, 
 __global__ __launch_bounds__(THREADS) void tile_hist_k(Pass p) {
     __shared__ u32 cnt[RADIX];
     const int t = threadIdx.x;
-    const i64 tile = blockIdx.x;
+    const i64 tile = xcd_tile();
     const int s = p.S == 1 ? (tile < p.tile_first[1] ? 0 : -1) : find_segment(p.tile_first, p.S, tile);
     if (s < 0) return;
     const i64 tf = p.tile_first[s];
@@ -136,7 +148,7 @@ __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
     __shared__ unsigned char ldig[TILE];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
-    const i64 tile = blockIdx.x;
+    const i64 tile = xcd_tile();
     const int s = p.S == 1 ? (tile < p.tile_first[1] ? 0 : -1) : find_segment(p.tile_first, p.S, tile);
     if (s < 0) return;
     const i64 tf = p.tile_first[s];
