@@ -114,7 +114,7 @@ __global__ __launch_bounds__(THREADS) void merge_k(Args a) {
 // The two lists of a column are disjoint (hits were folded into the stored values) and short, so the counts are
 // binary searches of a few steps in cached memory; consecutive lanes take consecutive entries and write nearly
 // consecutive places.  Reads 16 B per stored and per new entry + 16 B per column, writes 16 B per output entry.
-constexpr int CT = 256;
+constexpr int CT = 128;  // (measured at config 3: 64 -> 1.69, 128 -> 1.54, 256 -> 1.61, 512 -> 1.85, 1024 -> 1.98 ms)
 struct ColArgs {
     const i64 *old_colptr;  // 1-based values, n + 1
     const i64 *old_row;     // 1-based
@@ -131,7 +131,7 @@ struct ColArgs {
 // The tile's new keys are staged in LDS (a tile of 256 stencil columns gains a few hundred; a tile with more than
 // NEWCAP of them searches global memory), every thread handles MB entries per round with all their loads requested
 // first, and the searches of a round's entries advance together (a binary search is a chain of dependent loads).
-constexpr int NEWCAP = 2048, MB = 4;
+constexpr int NEWCAP = 1024, MB = 4;
 __global__ __launch_bounds__(THREADS) void colmerge_k(ColArgs a) {
     __shared__ i64 s_cp[CT + 1];
     __shared__ u64 s_ns[CT + 1];
