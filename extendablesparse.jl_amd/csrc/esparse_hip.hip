@@ -1260,7 +1260,10 @@ static int32_t partition_pass(esp_handle *h, espradix::Pass &p, i64 max_tiles) {
     }
     {
         Span sp(h, ESP_ST_SCATTER);
-        hipLaunchKernelGGL(espradix::scatter_k, dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
+        if (p.bits > 8)
+            hipLaunchKernelGGL((espradix::scatter_k<true>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
+        else
+            hipLaunchKernelGGL((espradix::scatter_k<false>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
         sp.add(1);
     }
     return ESP_OK;
@@ -1421,7 +1424,10 @@ static int plan_prefix_bits(const esp_handle *h, i64 E, int K, double *Ee_out) {
     int planned = 0;
     const double Ee = plan_entries(E, K, h->win_span);  // (see plan_entries: the window fills only part of its 2^K keys)
     if (E > esplocal::CAP) {
-        const double target = plan_fill() * esplocal::CAP;
+        double target = plan_fill() * esplocal::CAP;
+        // (test hook: plan as if the bucket kernel took segments of this many entries -- many prefix bits, i.e. the 9-bit
+        // passes, at sizes a CPU oracle can follow)
+        if (const char *e = getenv("ESP_DEBUG_PLAN_CAP")) target = std::min(target, std::max(8.0, atof(e)));
         while (planned < K && Ee / (double)((i64)1 << planned) > target) planned++;
     }
     if (planned > 0 && h->seen_spread > 0.0 && h->seen_spread < 2.0 &&
@@ -1938,7 +1944,10 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     // trying with one pass less (the longest segment is checked after the planned passes and a
     // further pass is added only if a segment really overflows)
     if (planned > 8 && planned % 8 == 1 && Ee / (double)((i64)1 << (planned - 1)) <= 0.95 * esplocal::CAP) planned--;
-    const int npass = (planned + 7) / 8;
+    // (digits of 9 bits only where they save a whole pass -- 17 or 18 bits in two passes: a tile then holds 8 entries per
+    // digit instead of 16; force_path 23: never)
+    const int npass8 = (planned + 7) / 8, npass9 = (planned + espradix::MAX_BITS - 1) / espradix::MAX_BITS;
+    const int npass = (npass9 < npass8 && h->force_path != 23) ? npass9 : npass8;
 
     int cur = 0, S = 1, done = 0;
     CK(ensure(h, h->seg[0], sizeof(i64) * 4));
@@ -2895,7 +2904,7 @@ extern "C" int32_t esp_shard_export(esp_handle *h, int32_t nshards, uint64_t *d_
         p.keys_out = (u64 *)d_keys;
         p.vals_out = d_vals;
         Span sp(h, ESP_ST_SCATTER);
-        hipLaunchKernelGGL(espradix::scatter_k, dim3(espradix::scatter_grid(ceil_div<i64>(h->count, espradix::TILE))), dim3(espradix::THREADS), 0,
+        hipLaunchKernelGGL((espradix::scatter_k<false>), dim3(espradix::scatter_grid(ceil_div<i64>(h->count, espradix::TILE))), dim3(espradix::THREADS), 0,
                            h->stream, p);
         sp.add(1);
         HIPCK(h, hipGetLastError());
@@ -2954,7 +2963,7 @@ extern "C" int32_t esp_shard_exchange_begin(esp_handle *h, int32_t nshards, int3
         p.keys_out = (u64 *)h->keys2.p;
         p.vals_out = (double *)h->vals2.p;
         Span sp(h, ESP_ST_SCATTER);
-        hipLaunchKernelGGL(espradix::scatter_k, dim3(espradix::scatter_grid(T)), dim3(espradix::THREADS), 0, h->stream, p);
+        hipLaunchKernelGGL((espradix::scatter_k<false>), dim3(espradix::scatter_grid(T)), dim3(espradix::THREADS), 0, h->stream, p);
         sp.add(1);
         HIPCK(h, hipGetLastError());
     }

@@ -19,7 +19,8 @@ constexpr int THREADS = 256;
 constexpr int WAVES = THREADS / ESP_WAVE;
 constexpr int ITEMS = 16;
 constexpr int TILE = THREADS * ITEMS;
-constexpr int RADIX = 256;
+constexpr int RADIX = 512;     // digits of up to 9 bits: thread t owns the digits 2t and 2t + 1 (t and t + THREADS in tile_hist_k)
+constexpr int MAX_BITS = 9;
 
 constexpr int XCDS = 8;  // L2s of an MI355X (scatter_k's tile order)
 // grid of scatter_k for `tiles` tiles: a multiple of XCDS (workgroups whose tile does not exist leave at once)
@@ -45,7 +46,7 @@ struct Pass {
     u64 base;   // key window: every (col,row) key lies in [base, base+span)
     u64 span;
     u32 *err;   // set when a key falls outside the window (digit clamped, no stray access)
-    int bits;   // 1..8
+    int bits;   // 1..9 (MAX_BITS)
     // owner mode (column-range shards): digit = floor(col0 * owner_P / owner_n), col0 = key >> colshift
     int owner_P;
     i64 owner_n;
@@ -90,6 +91,7 @@ __global__ __launch_bounds__(THREADS) void tile_hist_k(Pass p) {
     const i64 beg = p.seg_start[s] + tin * TILE;
     const i64 end = min(p.seg_start[s + 1], beg + (i64)TILE);
     cnt[t] = 0;
+    cnt[t + THREADS] = 0;
     __syncthreads();
     const u32 mask = (1u << p.bits) - 1u;
     // 16-byte loads (two keys per lane; counting does not care about order), all loads of a
@@ -133,19 +135,24 @@ __global__ __launch_bounds__(THREADS) void tile_hist_k(Pass p) {
     // the histogram array is zeroed before the launch: only non-zero counts are stored (the
     // digit-major layout makes every store its own cache line)
     if (t < R && cnt[t] != 0) p.hist[tf * R + (i64)t * nts + tin] = cnt[t];
+    if (t + THREADS < R && cnt[t + THREADS] != 0) p.hist[tf * R + (i64)(t + THREADS) * nts + tin] = cnt[t + THREADS];
 }
 
 // The tile is reordered through ONE 32 KiB LDS buffer, keys first, values second: 43 KiB of LDS and 144 VGPRs = three
 // workgroups per CU (keys and values staged side by side: 73 KiB = two).  Worth 5 % on the shuffled FEM streams (2.6 ->
 // 2.5 ms per pass over 2.4 10^8 entries): the pass is bound by its 128-byte write runs -- a tile of 4096 shuffled
 // entries holds 16 per digit -- more than by the bytes it has in flight.
+// NINE: digits of 9 bits (two per thread, the digit of an output slot recomputed from its key); else at most 8 bits (one
+// digit per thread, the slot's digit kept in an LDS byte): the 8-bit passes of 3-D FEM lost 5 % in the general form.
+template <bool NINE>
 __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
+    constexpr int RDX = NINE ? RADIX : 256;
     __shared__ u64 lbuf[TILE];
-    __shared__ u32 cnt[WAVES][RADIX];
-    __shared__ u32 dstart[RADIX];
-    __shared__ i64 goff[RADIX];
+    __shared__ u32 cnt[WAVES][RDX];
+    __shared__ u32 dstart[RDX];
+    __shared__ i64 goff[RDX];
     __shared__ u32 lw[WAVES];
-    __shared__ unsigned char ldig[TILE];
+    __shared__ unsigned char ldig[NINE ? 1 : TILE];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const i64 tile = xcd_tile();
@@ -161,7 +168,10 @@ __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
     const int R = 1 << p.bits;
 
 #pragma unroll
-    for (int i = 0; i < WAVES; i++) cnt[i][t] = 0;
+    for (int i = 0; i < WAVES; i++) {
+        cnt[i][t] = 0;
+        if constexpr (NINE) cnt[i][t + THREADS] = 0;
+    }
 
     // wave-striped arrangement: memory order == (wave, k, lane) order.  Keys AND values are
     // loaded up front: 32 independent 8-byte loads per lane in flight (the kernel runs at two
@@ -183,20 +193,20 @@ __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
 
     // stable rank inside the wave by ballot matching; one-digit waves skip the 8 ballots
     unsigned short rank[ITEMS];
-    unsigned char dig[ITEMS];
+    unsigned short dig[ITEMS];
     const u64 lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         const bool valid = (wbase + k * ESP_WAVE) < end;
         const u32 d = valid ? digit_of<false>(p, key[k], mask) : 0u;
-        dig[k] = (unsigned char)d;
+        dig[k] = (unsigned short)d;
         const u64 vm = __ballot(valid);
         u64 m = vm;
         if (vm) {
             const u32 d0 = (u32)__shfl((int)d, __builtin_ctzll(vm), ESP_WAVE);
             if (__ballot(valid && d == d0) != vm) {
 #pragma unroll
-                for (int b = 0; b < 8; b++) {
+                for (int b = 0; b < MAX_BITS; b++) {
                     if (b < p.bits) {  // (uniform: a pass of 6 bits pays 6 ballots)
                         const bool bit = (d >> b) & 1u;
                         const u64 bb = __ballot(bit);
@@ -214,9 +224,27 @@ __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
     }
     __syncthreads();
 
-    // per-digit: exclusive prefix over the waves, tile total, LDS start, global offset
-    u32 tot = 0;
-    {
+    // per-digit: exclusive prefix over the waves, tile total, LDS start, global offset (NINE: a thread owns two
+    // neighbouring digits and the block scan runs over their sum)
+    if constexpr (NINE) {
+        const int d0 = 2 * t, d1 = 2 * t + 1;
+        u32 tot0 = 0, tot1 = 0;
+#pragma unroll
+        for (int i = 0; i < WAVES; i++) {
+            const u32 c0 = cnt[i][d0], c1 = cnt[i][d1];
+            cnt[i][d0] = tot0;
+            cnt[i][d1] = tot1;
+            tot0 += c0;
+            tot1 += c1;
+        }
+        u32 blocktot;
+        const u32 ds = espscan::block_exclusive<u32, false>(tot0 + tot1, lw, &blocktot);
+        dstart[d0] = ds;
+        dstart[d1] = ds + tot0;
+        if (d0 < R && tot0 != 0) goff[d0] = (i64)p.hist[tf * R + (i64)d0 * nts + tin] - (i64)ds;
+        if (d1 < R && tot1 != 0) goff[d1] = (i64)p.hist[tf * R + (i64)d1 * nts + tin] - (i64)(ds + tot0);
+    } else {
+        u32 tot = 0;
         u32 c[WAVES];
 #pragma unroll
         for (int i = 0; i < WAVES; i++) c[i] = cnt[i][t];
@@ -225,11 +253,11 @@ __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
             cnt[i][t] = tot;
             tot += c[i];
         }
+        u32 blocktot;
+        const u32 ds = espscan::block_exclusive<u32, false>(tot, lw, &blocktot);
+        dstart[t] = ds;
+        if (t < R && tot != 0) goff[t] = (i64)p.hist[tf * R + (i64)t * nts + tin] - (i64)ds;
     }
-    u32 blocktot;
-    const u32 ds = espscan::block_exclusive<u32, false>(tot, lw, &blocktot);
-    dstart[t] = ds;
-    if (t < R && tot != 0) goff[t] = (i64)p.hist[tf * R + (i64)t * nts + tin] - (i64)ds;
     __syncthreads();
 
 #pragma unroll
@@ -240,25 +268,51 @@ __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
             const u32 slot = dstart[d] + cnt[w][d] + rank[k];
             rank[k] = (unsigned short)slot;  // (kept for the values)
             lbuf[slot] = key[k];
-            ldig[slot] = dig[k];
+            if constexpr (!NINE) ldig[slot] = (unsigned char)d;
         }
     }
     __syncthreads();
-#pragma unroll 4
-    for (int j = 0; j < ITEMS; j++) {
-        const int slot = t + j * THREADS;
-        if (slot < ntile) p.keys_out[goff[ldig[slot]] + slot] = lbuf[slot];
-    }
-    __syncthreads();  // (every key has been read)
     double *lvals = reinterpret_cast<double *>(lbuf);
+    if constexpr (NINE) {
+        // (the digit of an output slot: from its key once, kept in a register for the values)
+        unsigned short sdig[ITEMS];
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++)
-        if (wbase + k * ESP_WAVE < end) lvals[rank[k]] = val[k];
-    __syncthreads();
+        for (int j = 0; j < ITEMS; j++) {
+            const int slot = t + j * THREADS;
+            sdig[j] = 0;
+            if (slot < ntile) {
+                const u64 kk = lbuf[slot];
+                const u32 d = digit_of<false>(p, kk, mask);
+                sdig[j] = (unsigned short)d;
+                p.keys_out[goff[d] + slot] = kk;
+            }
+        }
+        __syncthreads();  // (every key has been read)
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++)
+            if (wbase + k * ESP_WAVE < end) lvals[rank[k]] = val[k];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < ITEMS; j++) {
+            const int slot = t + j * THREADS;
+            if (slot < ntile) p.vals_out[goff[sdig[j]] + slot] = lvals[slot];
+        }
+    } else {
 #pragma unroll 4
-    for (int j = 0; j < ITEMS; j++) {
-        const int slot = t + j * THREADS;
-        if (slot < ntile) p.vals_out[goff[ldig[slot]] + slot] = lvals[slot];
+        for (int j = 0; j < ITEMS; j++) {
+            const int slot = t + j * THREADS;
+            if (slot < ntile) p.keys_out[goff[ldig[slot]] + slot] = lbuf[slot];
+        }
+        __syncthreads();  // (every key has been read)
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++)
+            if (wbase + k * ESP_WAVE < end) lvals[rank[k]] = val[k];
+        __syncthreads();
+#pragma unroll 4
+        for (int j = 0; j < ITEMS; j++) {
+            const int slot = t + j * THREADS;
+            if (slot < ntile) p.vals_out[goff[ldig[slot]] + slot] = lvals[slot];
+        }
     }
 }
 

@@ -327,7 +327,8 @@ int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear);
  * 17 = the join with an existing CSC runs as a merge-path over a per-entry column array (a second implementation of the
  *      column-tiled join), 18 = never the small variant of the bucket kernel (see esp_debug_last_local_small),
  * 19 = an append behind a producer's bucket-ordered batch turns it back into packed keys (no "batch + tail" flush),
- * 22 = a batch + tail over a stored pattern is ONE flush over two pieces (as on a fresh matrix) instead of two flushes;
+ * 22 = a batch + tail over a stored pattern is ONE flush over two pieces (as on a fresh matrix) instead of two flushes,
+ * 23 = partition passes of at most 8 bits (no 9-bit digits where they would save a pass);
  * last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general) */
 int32_t esp_debug_force_path(esp_handle *h, int32_t path);
 int32_t esp_debug_last_path(const esp_handle *h, int32_t *path);

@@ -858,6 +858,29 @@ def test_producer_side_partition_mixed_with_other_appends(esp, orc):
         assert_csc_equal(hip_arrays(A), O.arrays(), variant)
 
 
+def test_nine_bit_partition_passes(esp, orc, monkeypatch):
+    """Shuffled streams whose plan needs 17 or 18 prefix bits take TWO passes of 9-bit digits instead of three of at most
+    8 (espradix::scatter_k<true>: two digits per thread).  The test hook ESP_DEBUG_PLAN_CAP makes the plan ask for that
+    many bits at a size the oracle can follow; force_path 23 = 8-bit passes only; both must equal the oracle."""
+    rng = np.random.default_rng(123)
+    m, n, cnt = 3000, 200003, 2500000
+    I, J, V = rng.integers(1, m + 1, cnt), rng.integers(1, n + 1, cnt), rng.standard_normal(cnt)
+    kinds = rng.choice(np.array([0, 1, 1, 2], np.uint8), cnt)
+    O = orc.ExtendableSparseMatrix(m, n)
+    O.apply(kinds, I, J, V)
+    O.flush()
+    want = O.arrays()
+    for cap, force in ((24, 0), (12, 0), (24, 23)):
+        monkeypatch.setenv("ESP_DEBUG_PLAN_CAP", str(cap))
+        A = esp.ExtendableSparseMatrix(m, n)
+        A.debug_force_path(force)
+        A.append(0, I, J, V, kinds=kinds)
+        A.flush()
+        assert A.debug_last_partition() == 2 and A.debug_last_path() == 1
+        assert_csc_equal(hip_arrays(A), want, "cap %d force %d" % (cap, force))
+    monkeypatch.delenv("ESP_DEBUG_PLAN_CAP")
+
+
 def test_producer_batch_with_a_tail(esp, orc):
     """Entries appended BEHIND a producer's bucket-ordered batch leave it as it is: the flush partitions the tail alone
     and the bucket kernel reads every segment as two pieces (last_partition 5).  Kinds of the tail are free (the batch's
