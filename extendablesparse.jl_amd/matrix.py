@@ -511,7 +511,8 @@ class ExtendableSparseMatrix:
         self._d.ck(self._d.lib.esp_generate_fem(self._d.h, dim, npd, seed, order_mode))
 
     def debug_force_path(self, path):
-        """Test hook: 0 automatic, 2 force the general path (global LSD sort + global fold)."""
+        """Test hook: 0 automatic, 2 force the general path (global LSD sort + global fold); the other values select
+        one implementation where the library has two (include/esparse_hip.h, esp_debug_force_path)."""
         self._d.ck(self._d.lib.esp_debug_force_path(self._d.h, path))
 
     def debug_last_path(self):
