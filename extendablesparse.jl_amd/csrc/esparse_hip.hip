@@ -2632,11 +2632,13 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
     }
     bool served = false, split = false;
     i64 Zsplit = 0;  // new entries of the batch's own flush
-    if (h->pre.valid && h->pre.tail > 0 && h->nnz > 0 && h->force_path != 22) {
+    if (h->pre.valid && h->pre.tail > 0 && h->nnz > 0 && mode == ESP_FLUSH_ROUTED && h->force_path != 22) {
         // Batch + tail over a stored pattern (a re-assembly whose mesh gained couplings): the batch by itself -- its buckets
         // fit the small variant of the bucket kernel, and a batch of hits emits nothing and needs no join -- then the tail
-        // as a flush of its own.  A flush may be cut at any stream position: flush! between two calls never changes a
-        // result (extendable.jl:248-255).  force_path 22: one flush over two pieces, as on a fresh matrix.
+        // as a flush of its own.  A ROUTED flush may be cut at any stream position: flush! between two calls of an
+        // ExtendableSparseMatrix never changes a result (extendable.jl:159-255: a call either hits the CSC or goes to the
+        // buffer, which the flush adds as it is).  Not so csc + buffer (ESP_FLUSH_PLUS): the buffer is folded by itself
+        // first.  force_path 22: one flush over two pieces, as on a fresh matrix.
         const esp_handle::PrePart pp = h->pre;
         Sorted st;
         st.sk = (const u64 *)h->keys.p;

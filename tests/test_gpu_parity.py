@@ -858,6 +858,40 @@ def test_producer_side_partition_mixed_with_other_appends(esp, orc):
         assert_csc_equal(hip_arrays(A), O.arrays(), variant)
 
 
+def test_csc_plus_buffer_with_batch_and_tail(esp, orc):
+    """csc + buffer (ESP_FLUSH_PLUS, Base.:+(lnk, csc): sparsematrixlnk.jl:294-383) folds the buffer by itself and adds
+    the result to the stored value ONCE: a producer's batch with entries behind it must go through ONE fold (two pieces),
+    never through the split flush of the routed mode -- (csc + (b1 + b2)) + t differs from csc + ((b1 + b2) + t) in the
+    last bit."""
+    n = 48
+    N = n ** 3
+    rng = np.random.default_rng(31)
+    A0 = esp.ExtendableSparseMatrix(N, N)
+    A0.generate_fdrand(n, n, n, seed=30, rand_mode=1)
+    A0.flush()
+    cp, rv, nz = hip_arrays(A0)
+    csc = esp.SparseMatrixCSC(N, N, cp, rv, nz)
+    I, J, V = orc.fdrand_stream(n, n, n, rand_mode=1, seed=31)
+    pick = np.sort(rng.choice(len(I), 20000, replace=False))        # the tail: positions the batch holds too, and new ones
+    It = np.concatenate([I[pick], rng.integers(1, N + 1, 500)])
+    Jt = np.concatenate([J[pick], rng.integers(1, N + 1, 500)])
+    Vt = rng.standard_normal(len(It))
+    x = esp.SparseMatrixHIPCOO(N, N)
+    A = esp.ExtendableSparseMatrix(N, N)           # (the device generator appends into the buffer's handle)
+    A._d = x._d
+    A.generate_fdrand(n, n, n, seed=31, rand_mode=1)
+    x.append(UPDATE, It, Jt, Vt)
+    got = x + csc
+    assert A.debug_last_partition() == 5
+    B = orc.ExtendableSparseMatrix(N, N)           # the buffer's own fold: every call lands in the LNK of an empty matrix
+    B.apply(np.full(len(I), UPDATE, np.uint8), I, J, V)
+    B.apply(np.full(len(It), UPDATE, np.uint8), It, Jt, Vt)
+    B.flush()
+    bcp, brv, bnz = B.arrays()
+    want = orc.SparseMatrixLNK(orc.CSC(N, N, bcp, brv, bnz)) + orc.CSC(N, N, cp, rv, nz)
+    assert_csc_equal((got.colptr, got.rowval, got.nzval), want.arrays(), "csc + (batch + tail)")
+
+
 def test_nine_bit_partition_passes(esp, orc, monkeypatch):
     """Shuffled streams whose plan needs 17 or 18 prefix bits take TWO passes of 9-bit digits instead of three of at most
     8 (espradix::scatter_k<true>: two digits per thread).  The test hook ESP_DEBUG_PLAN_CAP makes the plan ask for that
