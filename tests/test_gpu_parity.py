@@ -1586,6 +1586,36 @@ def test_fdrand_full_size_digest(esp, n):
         del A, arrs
 
 
+def test_more_than_32_key_bits_below_the_prefix(esp):
+    """A 256^3 stencil leaves exactly 32 key bits below its 16-bit prefix (4-byte keys everywhere); a larger problem --
+    322^3: 33 bits; the 8-GPU weak-scaling run: 36 -- takes the packed-key forms of the producer-side partition
+    (fdrand_part_k<false,false>), alone and with the multi-window digits of a column shard.  No CPU oracle at this size:
+    three device results -- plain producer + the flush's own partition, producer-side partition, shard producer through
+    the group API -- must agree bit for bit."""
+    n = 322
+    N = n ** 3
+    E = 12 * n * n * (n - 1) + 6 * n * n
+    seen = {}
+    for name, force in (("flush_partition", 16), ("producer_partition", 0)):
+        A = esp.ExtendableSparseMatrix(N, N, capacity_hint=E)
+        A.debug_force_path(force)
+        A.generate_fdrand(n, n, n, seed=7, rand_mode=1)
+        A.flush()
+        assert A.debug_last_key_bytes() == 8
+        assert A.debug_last_partition() == (4 if force == 0 else 1)
+        seen[name] = gu.digest(*hip_arrays(A))
+        del A
+    SA = esp.GroupShardedMatrix(N, N, nranks=1, rank=0, capacity_hint=E)
+    A = SA.local
+    for it in range(2):                 # (the second assembly finds the plan of the first flush: the producer partitions)
+        A.reset()
+        A.generate_fdrand(n, n, n, seed=7, rand_mode=1)
+        SA.flush()
+    assert A.debug_last_shard_source() == 2 and A.debug_last_key_bytes() == 8
+    seen["shard_producer"] = gu.digest(*hip_arrays(A))
+    assert len(set(seen.values())) == 1, seen
+
+
 def test_config3_digest_128(esp):
     """BASELINE config 3 at 128^3: stored stencil CSC + new second-neighbour positions + the full stream again, one
     flush through the routed fold and the merge-path join; digest of the oracle's result."""
