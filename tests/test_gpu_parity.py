@@ -935,7 +935,7 @@ def test_producer_batch_with_a_tail(esp, orc):
         kn = np.full(k, UPDATE, np.uint8) if kinds is None else rng.choice(np.array(kinds, np.uint8), k)
         return kn, In, Jn, Vn
 
-    for variant in ("fresh_mixed", "two_tails", "stored", "stored_routed_kinds", "stored_one_flush", "overfull", "unsorted", "force19", "getindex",
+    for variant in ("fresh_mixed", "two_tails", "stored", "stored_routed_kinds", "stored_one_flush", "stored_packed", "overfull", "unsorted", "force19", "getindex",
                     "fem", "packed", "packed_update"):
         A = esp.ExtendableSparseMatrix(N, N)
         O = orc.ExtendableSparseMatrix(N, N)
@@ -947,6 +947,8 @@ def test_producer_batch_with_a_tail(esp, orc):
             A.flush()
             upd(O, *orc.fdrand_stream(n, n, n, rand_mode=1, seed=30))
             O.flush()
+            if variant == "stored_packed":
+                A.debug_force_path(14)                     # (the batch of the split flush holds packed keys)
         if variant == "fem":
             m = 400
             Nf = m * m
@@ -971,7 +973,7 @@ def test_producer_batch_with_a_tail(esp, orc):
                 kn, In, Jn, Vn = tail(k)
                 A.append(UPDATE, In, Jn, Vn)
                 O.apply(kn, In, Jn, Vn)
-        elif variant in ("stored", "stored_routed_kinds", "stored_one_flush"):
+        elif variant in ("stored", "stored_routed_kinds", "stored_one_flush", "stored_packed"):
             kn, In, Jn, Vn = tail(4000, kinds=None if variant != "stored_routed_kinds" else [UPDATE, orc.KIND_SET])
             if variant == "stored_one_flush":
                 A.debug_force_path(22)                     # (two pieces in one flush, as on a fresh matrix)
