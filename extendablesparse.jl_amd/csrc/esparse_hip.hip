@@ -1332,6 +1332,7 @@ struct Sorted {
     int key_bytes = 8;  // 4: sk holds 32-bit keys (the bits below the prefix); every entry has the kind `kind`
     int kind = 0;
     i64 maxlen = esplocal::CAP;  // longest segment
+    i64 total = -1;              // entries of all segments, if the caller knows (lets flush_local drop the segments behind the last column)
     int p32_piece = -1;          // PIECES: the piece that holds 4-byte keys of kind `kind` from position p32_lo on
     bool all32 = false;          // PIECES: EVERY piece holds 4-byte keys of kind `kind`
     i64 p32_lo = 0;
@@ -2088,6 +2089,7 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     out->sv = vin;
     out->in_primary = (kin == (u64 *)h->keys.p);
     out->S = S;
+    out->total = E;
     out->seg_start = (const i64 *)h->seg[cur].p;
     out->rem_bits = K - done;
     out->local_ok = ok && (K - done) <= esplocal::MAX_REM_BITS && maxlen <= esplocal::CAP;
@@ -2204,8 +2206,22 @@ static int32_t prepare_outputs(esp_handle *h, i64 Z0, i64 Zn) {
 // fast path: LDS bucket kernel over the MSD segments; writes the final arrays itself
 static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
     const i64 Z0 = h->nnz;
-    const int S = st.S;
     const i64 N1 = h->n + 1;
+    // Segments behind the last column hold nothing (a matrix of 10^7 columns fills 60 % of the 2^24 its column bits span:
+    // 40 % of the segments, each of which would still draw a ticket, resolve its offset and leave): the launch ends at
+    // the segment of the last column; that segment checks that every entry lies in front of its end (Args::total).
+    int S = st.S;
+    i64 total_check = -1;
+    if (st.npieces == 0 && st.total >= 0 && st.seg_start && st.rem_bits >= h->L.rb && st.rem_bits - h->L.rb < 40 && S > 1) {
+        const int clb0 = st.rem_bits - h->L.rb;
+        // (the segments cut the key window: its first column, and the column behind its last)
+        const i64 c_first = (i64)(h->win_base >> h->L.rb), c_last = (i64)((h->win_base + h->win_span) >> h->L.rb);
+        const i64 need = ceil_div<i64>(c_last - c_first, (i64)1 << clb0);
+        if (need >= 1 && need < (i64)S) {
+            S = (int)need;
+            total_check = st.total;
+        }
+    }
     // esp_flush normalised the buffers: data in keys/vals, scratch pair = keys2/vals2
     u64 *tk = (u64 *)h->keys2.p;
     double *tv = (double *)h->vals2.p;
@@ -2293,6 +2309,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         a.status = status;
         a.gstatus = status + S + 2;
         a.npieces = st.npieces;
+        a.total = total_check;
         a.pstart = st.pstart;
         a.ptab = st.ptab;
         a.ticket = (u32 *)(status + S);
@@ -2645,6 +2662,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         st.sv = (const double *)h->vals.p;
         st.in_primary = true;
         st.S = 1 << pp.pb;
+        st.total = pp.E;
         st.seg_start = (const i64 *)h->seg[1].p;
         st.rem_bits = pp.K - pp.pb;
         st.local_ok = true;
@@ -2698,6 +2716,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         st.sv = (const double *)h->vals.p;
         st.in_primary = true;
         st.S = 1 << pp.pb;
+        st.total = pp.E;
         st.seg_start = (const i64 *)h->seg[1].p;
         st.rem_bits = pp.K - pp.pb;
         st.local_ok = true;

@@ -115,6 +115,7 @@ struct Args {
     u32 *ticket;     // zeroed before launch
     u32 *err;        // set to 1 if a look-back spin ran into its bound
     int stop_after;  // timing ablation only (0 = run everything)
+    i64 total;       // >= 0: the launch ends before the table's last segment -- the last launched segment must end at this entry
     i64 first;       // ticket value the first workgroup of this launch is expected to draw
     unsigned long long *stamps;  // diagnostics (builds with -DESP_LOCAL_STAMPS only): 8 wall-clock stamps per segment
     // PIECES variant (column shards after the partitioned exchange): segment s is the concatenation, in
@@ -698,6 +699,7 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
         if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 0] = wall_clock64();
 #endif
         n = (int)(seg_end - beg);
+        if (a.total >= 0 && s == a.S - 1 && seg_end != a.total && t == 0) atomicOr(a.err, 2u);  // (an entry behind the last column)
         // shared prefix of the segment (window-relative), turned back into an absolute key prefix
         // (an empty segment has no key to take it from: its index is the prefix)
         if constexpr (K32)
