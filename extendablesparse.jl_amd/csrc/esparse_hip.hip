@@ -12,11 +12,16 @@
 #include "common.hpp"
 #include "fold.hpp"
 #include "generators.hpp"
-#include "local.hpp"
+#include "local_args.hpp"
 #include "merge.hpp"
 #include "radix.hpp"
 #include "runpart.hpp"
 #include "scan.hpp"
+
+bool esplocal::launch(const Variant &v, unsigned grid, hipStream_t stream, const Args &a) {
+    if (v.pieces) return v.small_variant ? launch_pieces_small(v, grid, stream, a) : v.fresh ? launch_pieces_fresh(v, grid, stream, a) : launch_pieces_stored(v, grid, stream, a);
+    return v.small_variant ? launch_small(v, grid, stream, a) : launch_regular(v, grid, stream, a);
+}
 
 // ------------------------------------------------------------------------ handle
 struct DevBuf {
@@ -106,6 +111,8 @@ struct esp_handle {
         DevBuf d_rows, d_cols, d_vals, d_kinds;
     } stage, bulk;
     unsigned long long *pin_scalar = nullptr;  // pinned, 8 slots
+    u64 *pin_mw = nullptr;  // pinned source of prepart_begin's asynchronous upload of the window bases (<= MW_MAX)
+    hipEvent_t pin_mw_done = nullptr;
     // kind bookkeeping of the pending batch: when every pending entry was appended with ONE known kind the run-based
     // partition hands the bucket kernel 4-byte keys (the key bits below the partition prefix) instead of packed keys
     i64 kind_noted = 0;     // pending entries appended with a single known kind
@@ -448,6 +455,8 @@ extern "C" int32_t esp_destroy(esp_handle *h) {
     (void)hipStreamSynchronize(h->stream);
     release_all(h);
     if (h->pin_scalar) (void)hipHostFree(h->pin_scalar);
+    if (h->pin_mw) (void)hipHostFree(h->pin_mw);
+    if (h->pin_mw_done) (void)hipEventDestroy(h->pin_mw_done);
     for (auto &s : h->spans) {
         (void)hipEventDestroy(s.a);
         (void)hipEventDestroy(s.b);
@@ -1533,7 +1542,17 @@ static int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSet
         K = mw.K, pb = mw.pb, shift = mw.shift, NB = mw.NB;
         const size_t o_cnt = 256 * 8;  // (the table layout of esp_shard_partition: window bases | owner offsets | counts)
         CK(ensure(h, h->parttab, o_cnt + sizeof(i64) * (size_t)(NB + 1)));
-        HIPCK(h, hipMemcpyAsync(h->parttab.p, mw.base.data(), sizeof(u64) * (size_t)P, hipMemcpyHostToDevice, h->stream));
+        // (the copy is asynchronous: its source lives in the handle, not in this function's frame -- and a flush that
+        // still reads an earlier table from the same vector has been synchronised by then: every flush ends in a wait)
+        if (!h->pin_mw) {
+            HIPCK(h, hipHostMalloc((void **)&h->pin_mw, sizeof(u64) * esprun::MW_MAX, hipHostMallocDefault));
+            HIPCK(h, hipEventCreateWithFlags(&h->pin_mw_done, hipEventDisableTiming));
+        } else {
+            HIPCK(h, hipEventSynchronize(h->pin_mw_done));  // (the previous upload has read the buffer)
+        }
+        memcpy(h->pin_mw, mw.base.data(), sizeof(u64) * (size_t)P);
+        HIPCK(h, hipMemcpyAsync(h->parttab.p, h->pin_mw, sizeof(u64) * (size_t)P, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipEventRecord(h->pin_mw_done, h->stream));
     } else {
         K = window_bits(h);
         pb = plan_prefix_bits(h, E, K, &Ee);
@@ -2285,6 +2304,9 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
         a.k32_lo = st.p32_lo;
         h->last_key_bytes = (st.p32_piece >= 0 || st.all32) ? 4 : st.key_bytes;
         a.colptr_out = direct ? (i64 *)h->colptr.p : nullptr;
+        a.no_group = h->force_path == 24 ? 1 : 0;  // 24: test hook, long column runs through the radix tier
+        // (every pending entry was noted with one kind; pieces of other ranks carry kinds this handle has not seen)
+        a.kind_all = (st.npieces == 0 && h->kind_uniform >= 0 && h->kind_noted == h->count && h->force_path != 15) ? h->kind_uniform : -1;
         a.col_end = col_end;
         a.n_cols = h->n;
         a.keys_in = st.sk;
@@ -2330,7 +2352,6 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
             a.first = first;
             // (the variant with the 24-input register tier for a matrix whose last flush met such runs)
             const bool big = h->seen_maxrun > 16 && h->seen_maxrun <= esplocal::REG_RUN;
-#define ESP_LAUNCH_LOCAL(F, P, B, K) hipLaunchKernelGGL((esplocal::local_k<F, P, B, K>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a)
             // (key format: 0 packed, 1 four-byte keys of one kind, 2 four-byte keys that are all UPDATEs)
             // (3: packed keys whose kinds are all UPDATE -- the pieces of a shard)
             // (4 / 5: pieces of which one -- a shard's own range -- holds 4-byte keys; 5: everything is an UPDATE)
@@ -2340,56 +2361,9 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
                                                                    : (st.all_update && h->force_path != 15 ? 3 : 0))
                                             : st.key_bytes != 4 ? 0 : (st.kind == ESP_UPDATE && h->force_path != 15 ? 2 : 1);
             h->last_fold_update = keys >= 2 ? 1 : 0;
-#define ESP_LAUNCH_SMALL(F, P, B, K) hipLaunchKernelGGL((esplocal::local_k<F, P, B, K, true>), dim3(grid), dim3(esplocal::THREADS), 0, h->stream, a)
-#define ESP_LAUNCH_SMALL_FB(P, K)                                                              \
-    do {                                                                                       \
-        if (Z0 == 0) ESP_LAUNCH_SMALL(true, P, false, K); else ESP_LAUNCH_SMALL(false, P, false, K);   \
-    } while (0)
-            if (small_variant && st.npieces > 0) {
-                if (keys == 7) ESP_LAUNCH_SMALL_FB(true, 7);
-                else if (keys == 6) ESP_LAUNCH_SMALL_FB(true, 6);
-                else if (keys == 5) ESP_LAUNCH_SMALL_FB(true, 5);
-                else if (keys == 4) ESP_LAUNCH_SMALL_FB(true, 4);
-                else if (keys == 3) ESP_LAUNCH_SMALL_FB(true, 3);
-                else ESP_LAUNCH_SMALL_FB(true, 0);
-            } else if (st.npieces > 0 && keys >= 4) {
-                if (keys == 7) {
-                    if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 7); else ESP_LAUNCH_LOCAL(true, true, false, 7); }
-                    else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 7); else ESP_LAUNCH_LOCAL(false, true, false, 7); }
-                } else if (keys == 6) {
-                    if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 6); else ESP_LAUNCH_LOCAL(true, true, false, 6); }
-                    else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 6); else ESP_LAUNCH_LOCAL(false, true, false, 6); }
-                } else if (keys == 5) {
-                    if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 5); else ESP_LAUNCH_LOCAL(true, true, false, 5); }
-                    else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 5); else ESP_LAUNCH_LOCAL(false, true, false, 5); }
-                } else {
-                    if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 4); else ESP_LAUNCH_LOCAL(true, true, false, 4); }
-                    else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 4); else ESP_LAUNCH_LOCAL(false, true, false, 4); }
-                }
-            } else if (small_variant) {
-                if (keys == 2) ESP_LAUNCH_SMALL_FB(false, 2);
-                else if (keys == 1) ESP_LAUNCH_SMALL_FB(false, 1);
-                else ESP_LAUNCH_SMALL_FB(false, 0);
-            } else if (st.npieces > 0 && keys == 3) {
-                if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 3); else ESP_LAUNCH_LOCAL(true, true, false, 3); }
-                else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 3); else ESP_LAUNCH_LOCAL(false, true, false, 3); }
-            } else if (st.npieces > 0) {
-                if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, true, true, 0); else ESP_LAUNCH_LOCAL(true, true, false, 0); }
-                else { if (big) ESP_LAUNCH_LOCAL(false, true, true, 0); else ESP_LAUNCH_LOCAL(false, true, false, 0); }
-            } else if (keys == 2) {
-                if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, false, true, 2); else ESP_LAUNCH_LOCAL(true, false, false, 2); }
-                else { if (big) ESP_LAUNCH_LOCAL(false, false, true, 2); else ESP_LAUNCH_LOCAL(false, false, false, 2); }
-            } else if (keys == 1) {
-                if (Z0 == 0) { if (big) ESP_LAUNCH_LOCAL(true, false, true, 1); else ESP_LAUNCH_LOCAL(true, false, false, 1); }
-                else { if (big) ESP_LAUNCH_LOCAL(false, false, true, 1); else ESP_LAUNCH_LOCAL(false, false, false, 1); }
-            } else if (Z0 == 0) {
-                if (big) ESP_LAUNCH_LOCAL(true, false, true, 0); else ESP_LAUNCH_LOCAL(true, false, false, 0);
-            } else {
-                if (big) ESP_LAUNCH_LOCAL(false, false, true, 0); else ESP_LAUNCH_LOCAL(false, false, false, 0);
-            }
-#undef ESP_LAUNCH_LOCAL
-#undef ESP_LAUNCH_SMALL
-#undef ESP_LAUNCH_SMALL_FB
+            // (the instantiations live in local_*.hip)
+            const esplocal::Variant var{Z0 == 0, st.npieces > 0, big && !small_variant, small_variant, keys};
+            if (!esplocal::launch(var, grid, h->stream, a)) FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (no bucket kernel for this flush)");
         }
         sp.add(1);
     }

@@ -86,7 +86,7 @@ __device__ __forceinline__ i64 csc_find(const Csc &c, i64 col0, i64 row0) {
 
 // one thread per sorted entry; segment heads fold their whole run left to right.
 // flag[i]=1 when head i emits a new entry (value in fval[i]); flag has E+1 slots.
-__global__ __launch_bounds__(THREADS) void fold_k(const u64 *__restrict__ sk,
+static __global__ __launch_bounds__(THREADS) void fold_k(const u64 *__restrict__ sk,
                                                   const double *__restrict__ sv, i64 E, Csc csc,
                                                   int rb, int mode, u32 *__restrict__ flag,
                                                   double *__restrict__ fval) {
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(THREADS) void fold_k(const u64 *__restrict__ sk,
 // column the number of emitted entries up to the end of its run (colend, zeroed before).
 // FRESH: write the final CSC arrays (rowval 1-based); else write (key,val) of new entries.
 template <bool FRESH>
-__global__ __launch_bounds__(THREADS) void compact_k(const u64 *__restrict__ sk,
+static __global__ __launch_bounds__(THREADS) void compact_k(const u64 *__restrict__ sk,
                                                      const double *__restrict__ fval, i64 E,
                                                      const u32 *__restrict__ pos, int rb,
                                                      i64 *__restrict__ out_row,
@@ -151,7 +151,7 @@ __global__ __launch_bounds__(THREADS) void compact_k(const u64 *__restrict__ sk,
 }
 
 // colptr[c] = base(c) + scanned[c] + 1 ; scanned = exclusive max-scan of colend (n+1 entries)
-__global__ void colptr_finish_k(const u64 *__restrict__ scanned, const i64 *__restrict__ old_colptr,
+static __global__ void colptr_finish_k(const u64 *__restrict__ scanned, const i64 *__restrict__ old_colptr,
                                 i64 n1, i64 *__restrict__ colptr) {
     const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n1) return;
@@ -161,7 +161,7 @@ __global__ void colptr_finish_k(const u64 *__restrict__ scanned, const i64 *__re
 // column index of every stored entry: heads[start(c)] = c for non-empty columns, then an
 // exclusive max-scan over Z+1 slots gives colidx[p] at scanned[p+1]
 // (columns [c0, c0+n): a shard's window, else all)
-__global__ void col_heads_k(const i64 *__restrict__ colptr, i64 c0, i64 n, u32 *__restrict__ heads) {
+static __global__ void col_heads_k(const i64 *__restrict__ colptr, i64 c0, i64 n, u32 *__restrict__ heads) {
     const i64 c = c0 + (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= c0 + n) return;
     const i64 a = colptr[c] - 1, b = colptr[c + 1] - 1;
@@ -169,12 +169,12 @@ __global__ void col_heads_k(const i64 *__restrict__ colptr, i64 c0, i64 n, u32 *
 }
 
 // dropzeros!: keep[k] = nzval != 0 (Z+1 slots)
-__global__ void nonzero_flags_k(const double *__restrict__ nzval, i64 Z, u32 *__restrict__ flag) {
+static __global__ void nonzero_flags_k(const double *__restrict__ nzval, i64 Z, u32 *__restrict__ flag) {
     const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (k > Z) return;
     flag[k] = (k < Z && nzval[k] != 0.0) ? 1u : 0u;
 }
-__global__ void dropzeros_compact_k(const i64 *__restrict__ rowval, const double *__restrict__ nzval,
+static __global__ void dropzeros_compact_k(const i64 *__restrict__ rowval, const double *__restrict__ nzval,
                                     i64 Z, const u32 *__restrict__ pos, i64 *__restrict__ out_row,
                                     double *__restrict__ out_val) {
     const i64 k = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -184,7 +184,7 @@ __global__ void dropzeros_compact_k(const i64 *__restrict__ rowval, const double
         out_val[pos[k]] = nzval[k];
     }
 }
-__global__ void dropzeros_colptr_k(const i64 *__restrict__ old_colptr, i64 n1,
+static __global__ void dropzeros_colptr_k(const i64 *__restrict__ old_colptr, i64 n1,
                                    const u32 *__restrict__ pos, i64 *__restrict__ colptr) {
     const i64 c = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n1) return;
@@ -192,7 +192,7 @@ __global__ void dropzeros_colptr_k(const i64 *__restrict__ old_colptr, i64 n1,
 }
 
 // single-entry lookup (getindex slow path)
-__global__ void getindex_k(Csc csc, i64 row0, i64 col0, double *out /* [value, found] */) {
+static __global__ void getindex_k(Csc csc, i64 row0, i64 col0, double *out /* [value, found] */) {
     const i64 pos = csc.nnz > 0 ? csc_find(csc, col0, row0) : -1;
     out[0] = pos >= 0 ? csc.nzval[pos] : 0.0;
     out[1] = pos >= 0 ? 1.0 : 0.0;
@@ -200,7 +200,7 @@ __global__ void getindex_k(Csc csc, i64 row0, i64 col0, double *out /* [value, f
 
 // pattern hash partial sums: acc[0] over colptr, acc[1] over rowval (same formula as
 // oracle/esparse_oracle.c:orc_csc_pattern_hash; integer adds commute -> deterministic)
-__global__ __launch_bounds__(THREADS) void pattern_hash_k(const i64 *__restrict__ colptr, i64 n1,
+static __global__ __launch_bounds__(THREADS) void pattern_hash_k(const i64 *__restrict__ colptr, i64 n1,
                                                           const i64 *__restrict__ rowval, i64 Z,
                                                           unsigned long long *__restrict__ acc) {
     __shared__ u64 red[2][THREADS / 64];

@@ -40,7 +40,8 @@ static bool rccl_load() {
     if (!lib) lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!lib) lib = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
     if (!lib) {
-        g_rccl_err = std::string("cannot load librccl.so.1 (") + (dlerror() ? dlerror() : "?") + "); set ESP_RCCL_LIB";
+        const char *why = dlerror();  // (one call: dlerror() clears the pending message)
+        g_rccl_err = std::string("cannot load librccl.so.1 (") + (why ? why : "?") + "); set ESP_RCCL_LIB";
         return false;
     }
     RcclApi a;

@@ -38,32 +38,9 @@
 //               scan over the columns afterwards); else column-end marks
 // Bound: instruction issue and barrier latency at 4 waves per SIMD (128 VGPRs), not HBM bytes; see DESIGN.md.
 #pragma once
-#include "common.hpp"
-#include "fold.hpp"
+#include "local_args.hpp"
 
 namespace esplocal {
-
-constexpr int THREADS = 512;
-constexpr int WAVES = THREADS / ESP_WAVE;
-constexpr int ITEMS = 8;
-constexpr int CAP = THREADS * ITEMS;  // 4096 entries per segment
-constexpr int IDX_BITS = 12;
-constexpr int SUB_SHIFT = ESP_TAG_BITS + IDX_BITS;  // packed: sub << 14 | idx << 2 | kind
-constexpr int MAX_REM_BITS = 64 - SUB_SHIFT;
-static_assert((1 << IDX_BITS) == CAP, "slot index must cover the segment capacity");
-
-constexpr int CL_MAX_BITS = 11;  // up to 2048 local columns counted in LDS
-constexpr int CL_MAX = 1 << CL_MAX_BITS;
-constexpr int REG_RUN = 24;   // longest column run sorted in registers
-constexpr int REG_MAX_REM = 62 - SUB_SHIFT;  // ... when the packed sort keys stay below 2^62 (see load_sorted_run)
-constexpr u64 NOREC = ~0ull;
-
-// look-back status granule: [63:62] flag, [61:0] value
-constexpr u64 ST_AGG = 1ull << 62;
-constexpr u64 ST_PRE = 2ull << 62;
-constexpr u64 ST_VAL = (1ull << 62) - 1ull;
-constexpr u32 SPIN_LIMIT = 1u << 24;
-constexpr i64 MAX_GRID = 1 << 22;  // workgroups per launch (HIP caps a grid at 2^32 threads)
 
 // Batcher's merge-exchange sorting network for 16 keys (63 compare-exchanges), generated at
 // compile time; used to sort one short column run per lane entirely in registers.
@@ -94,47 +71,6 @@ static_assert(NetOf<16>::net.n == 63, "merge-exchange network for 16 inputs has 
 static_assert(NetOf<12>::net.n == 42, "merge-exchange network for 12 inputs has 42 comparators");
 static_assert(NetOf<24>::net.n == 132, "merge-exchange network for 24 inputs has 132 comparators");
 
-struct Args {
-    const u64 *keys_in;
-    const double *vals_in;
-    const i64 *seg_start;  // S+1
-    int S;
-    int rem_bits;  // key bits below the partition prefix (col/row bits, without the kind bits)
-    u64 base;      // key window base: keys are sorted as (key>>2) - base
-    int rb;
-    int cl_bits;  // local column bits (rem_bits - rb) when 0..CL_MAX_BITS, else -1: radix tail only
-    int col_aligned;  // a segment is a whole number of columns (column-end marks need no atomics)
-    espfold::Csc csc;
-    int mode;
-    i64 *out_row;    // FRESH: rowval (1-based) of the new CSC
-    u64 *out_key;    // !FRESH: (col0<<rb | row0) of new entries
-    double *out_val;
-    u64 *colend;     // per column: output index just past its last emitted entry (0 = none)
-    u64 *status;     // S look-back granules, zeroed before launch
-    u64 *gstatus;    // one more per group of 64 segments (see the two-level look-back), zeroed as well
-    u32 *ticket;     // zeroed before launch
-    u32 *err;        // set to 1 if a look-back spin ran into its bound
-    int stop_after;  // timing ablation only (0 = run everything)
-    i64 total;       // >= 0: the launch ends before the table's last segment -- the last launched segment must end at this entry
-    i64 first;       // ticket value the first workgroup of this launch is expected to draw
-    unsigned long long *stamps;  // diagnostics (builds with -DESP_LOCAL_STAMPS only): 8 wall-clock stamps per segment
-    // PIECES variant (column shards after the partitioned exchange): segment s is the concatenation, in
-    // source-rank order, of one piece per source: entries [pstart[q*(S+1)+s], pstart[q*(S+1)+s+1]) of the
-    // arrays ptab[q] (keys) / ptab[npieces+q] (values)
-    int npieces;
-    const i64 *pstart;
-    const void *const *ptab;
-    u32 *maxrun_seen;  // longest column run any segment of this flush met (atomicMax)
-    // FRESH kernels on whole-column segments that cover the flush's column range: the segment writes colptr (1-based)
-    // for its own columns itself -- no column-end marks, no scan over the columns afterwards (nullptr: marks in colend)
-    u32 kind32;  // K32 kernels: the kind of every entry; KEYS 4 / 5: of the entries of piece k32_piece
-    int k32_piece;  // KEYS 4 / 5: the piece that holds 4-byte keys ...
-    i64 k32_lo;     // ... from its position k32_lo on: key of position p at esprun::own_keys32(keys, k32_lo)[p]
-    i64 *colptr_out;
-    i64 n_cols;   // columns of the matrix (column-end marks of a failing flush -- keys outside the window -- stay inside colend)
-    i64 col_end;  // end of the column range (colptr_out[col_end] = 1 + nnz comes from the last segment)
-};
-constexpr int MAX_PIECES = 64;
 
 // Stable LSD radix tail on the packed keys held in registers (wave-striped arrangement):
 // sorts on bits [SUB_SHIFT, SUB_SHIFT+rem_bits); result in k[] and skey[].
@@ -629,6 +565,341 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
     return false;
 }
 
+// ---- group tier: column runs of 17 .. 256 entries (P1 FEM: 24 per column in 2-D, 120 in 3-D) ---------------------
+// After the counting sort by column every run is sorted by G = 2 / 4 / 8 / 16 neighbouring lanes, 16 keys per lane
+// in REGISTERS: the lane's 16 keys by the 63-comparator network, then bitonic merges ACROSS the lanes of the group
+// whose partner is always reachable by one DPP modifier (quad_perm for lane ^ 1 / ^ 2 / ^ 3, row_half_mirror for
+// lane ^ 7, row_mirror for lane ^ 15, two bank-masked row shifts for lane ^ 4) -- no LDS traffic, no barrier inside
+// the sort, and a wave sorts 64 / G columns at once.  Sort keys are 32 bits: (row - smallest row of the segment) in
+// 18 bits | slot index | kind, i.e. a compare-exchange is v_min_u32 + v_max_u32 (in registers) or the same two on a
+// DPP operand + a select (across lanes).  Against the 8-bit LSD radix passes over every varying key bit (three passes
+// of ballots, LDS counters and five barriers each for 3-D FEM): 700 instead of about 4500 instructions per wave; the
+// ordered fold follows in the same lanes (group_columns).
+constexpr int GROUP_MAX = 256;    // longest column run the group tier takes (16 lanes x 16 keys)
+constexpr int GROUP_ROW_BITS = 32 - SUB_SHIFT;  // 18: the rows of a segment must span less than 2^18
+
+template <int CTRL>
+__device__ __forceinline__ u32 dpp_perm(u32 x) {
+    return (u32)__builtin_amdgcn_update_dpp(0, (int)x, CTRL, 0xf, 0xf, false);
+}
+// lane ^ 4 inside a row of 16: lanes 0-3 / 8-11 read four lanes up, lanes 4-7 / 12-15 four lanes down
+__device__ __forceinline__ u32 dpp_xor4(u32 x) {
+    int y = __builtin_amdgcn_update_dpp((int)x, (int)x, 0x104 /* row_shl:4 */, 0xf, 0x5, false);
+    y = __builtin_amdgcn_update_dpp(y, (int)x, 0x114 /* row_shr:4 */, 0xf, 0xa, false);
+    return (u32)y;
+}
+__device__ __forceinline__ u32 keep_side(u32 x, u32 y, bool lower) {
+    const u32 lo = x < y ? x : y, hi = x < y ? y : x;
+    return lower ? lo : hi;
+}
+// first step of a merge of two sorted blocks: element e against its mirror image in the block pair (partner lane
+// through CTRL, register 15 - r); the lower block keeps the minima
+template <int CTRL>
+__device__ __forceinline__ void group_mirror(u32 (&x)[16], bool lower) {
+#pragma unroll
+    for (int r = 0; r < 8; r++) {
+        const u32 a = dpp_perm<CTRL>(x[15 - r]), b = dpp_perm<CTRL>(x[r]);
+        x[r] = keep_side(x[r], a, lower);
+        x[15 - r] = keep_side(x[15 - r], b, lower);
+    }
+}
+template <int CTRL>
+__device__ __forceinline__ void group_cross(u32 (&x)[16], bool lower) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = keep_side(x[r], dpp_perm<CTRL>(x[r]), lower);
+}
+__device__ __forceinline__ void group_cross4(u32 (&x)[16], bool lower) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) x[r] = keep_side(x[r], dpp_xor4(x[r]), lower);
+}
+// the half cleaners inside a lane (distances 8, 4, 2, 1 between registers)
+__device__ __forceinline__ void group_clean(u32 (&x)[16]) {
+#pragma unroll
+    for (int j = 8; j >= 1; j >>= 1)
+#pragma unroll
+        for (int r = 0; r < 16; r++)
+            if ((r & j) == 0) {
+                const u32 lo = x[r] < x[r | j] ? x[r] : x[r | j], hi = x[r] < x[r | j] ? x[r | j] : x[r];
+                x[r] = lo;
+                x[r | j] = hi;
+            }
+}
+// sorts the 16 * G keys held by G neighbouring lanes (lane q of the group: sorted positions 16 q .. 16 q + 15)
+template <int G>
+__device__ __forceinline__ void group_sort(u32 (&x)[16], int q) {
+#pragma unroll
+    for (int c = 0; c < NetOf<16>::net.n; c++) {
+        const u32 lo = x[NetOf<16>::net.a[c]], hi = x[NetOf<16>::net.b[c]];
+        x[NetOf<16>::net.a[c]] = lo < hi ? lo : hi;
+        x[NetOf<16>::net.b[c]] = lo < hi ? hi : lo;
+    }
+    if constexpr (G >= 2) {
+        group_mirror<0xB1>(x, (q & 1) == 0);  // quad_perm [1,0,3,2]: lane ^ 1
+        group_clean(x);
+    }
+    if constexpr (G >= 4) {
+        group_mirror<0x1B>(x, (q & 2) == 0);  // quad_perm [3,2,1,0]: lane ^ 3
+        group_cross<0xB1>(x, (q & 1) == 0);
+        group_clean(x);
+    }
+    if constexpr (G >= 8) {
+        group_mirror<0x141>(x, (q & 4) == 0);  // row_half_mirror: lane ^ 7
+        group_cross<0x4E>(x, (q & 2) == 0);    // quad_perm [2,3,0,1]: lane ^ 2
+        group_cross<0xB1>(x, (q & 1) == 0);
+        group_clean(x);
+    }
+    if constexpr (G >= 16) {
+        group_mirror<0x140>(x, (q & 8) == 0);  // row_mirror: lane ^ 15
+        group_cross4(x, (q & 4) == 0);
+        group_cross<0x4E>(x, (q & 2) == 0);
+        group_cross<0xB1>(x, (q & 1) == 0);
+        group_clean(x);
+    }
+}
+// ---- sort + ordered fold of every column run of the segment by its group of G lanes -----------------------------
+// in : skey[ccnt[c] .. ccnt[c+1]) packed keys of column c in any order, sval[slot] the values
+// out: the records of column c at the front of its run (skey[rs + e] = sub << SUB_SHIFT | slot << 2, sval[slot] = value),
+//      NOREC behind them -- what every tier of the bucket kernel leaves for the compaction
+// After the sort a lane holds 16 consecutive sorted entries of its column in registers and gathers their values.
+// PASS A folds, without a branch per entry, every (col,row) that STARTS among the lane's entries (running fold, reset at
+// every first entry of a (col,row)); a (col,row) that ends in the lane is closed there.  A (col,row) that runs on into
+// the next lanes -- the diagonal of a 3-D FEM column holds 48 updates: three or four lanes -- is handed over: PASS B,
+// a few rounds: a lane whose first entries continue its neighbour's (col,row) takes the neighbour's accumulator
+// through DPP once that is final, folds those entries behind it (left to right: the stream's order) and either closes
+// the (col,row) or, when all its 16 entries belong to it, hands it on.  Everything stays in registers; LDS sees the
+// gather, the records and nothing else; no barrier.
+constexpr int GROUP_CL_BITS = 11;
+// UPDATE / RAWUPDATE entries only: an absent position holds +0.0 and +0.0 + v is the value a creating update leaves
+// (fold_step_update); a RAWUPDATE creates whatever its value
+__device__ __forceinline__ void group_step(bool &present, double &acc, u32 kind, double v, bool adds, bool raws) {
+    if (adds) {
+        acc = acc + v;
+        present = present || raws || v != 0.0;
+    } else {
+        espfold::fold_step_sel(present, acc, kind, v);
+    }
+}
+// closes a (col,row): stored position -> in place; else a record whose value sits in the slot of entry `key`
+template <bool FRESH>
+__device__ __forceinline__ bool group_close(const Args &a, double *sval, i64 pos, bool present, double acc, u32 key) {
+    if (!FRESH && pos >= 0) {
+        if (a.mode == ESP_FLUSH_ROUTED)
+            a.csc.nzval[pos] = acc;
+        else if (present)
+            a.csc.nzval[pos] = a.csc.nzval[pos] + acc;  // csc operand first, sparsematrixlnk.jl:363
+        return false;
+    }
+    if (present) sval[(key >> ESP_TAG_BITS) & (CAP - 1)] = acc;  // (a slot of one of its own entries: nobody else's)
+    return present;
+}
+__device__ __forceinline__ double dpp_shr1_f64(double x) {
+    const long long b = __double_as_longlong(x);
+    const u32 lo = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)b, 0x111, 0xf, 0xf, true);
+    const u32 hi = (u32)__builtin_amdgcn_update_dpp(0, (int)(u32)(b >> 32), 0x111, 0xf, 0xf, true);
+    return __longlong_as_double((long long)(((u64)hi << 32) | lo));
+}
+// MODE: 0 = entries of any kind; 1 = all UPDATE, 2 = all RAWUPDATE (known to the kernel's instantiation or to the host's
+// bookkeeping): the fold is an addition, and on a fresh matrix pass A has no branch at all
+template <int G, int CAPK, bool FRESH, int MODE>
+__device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *sval, const u32 *ccnt, int ncl, u32 rmin, u64 hi,
+                                              u64 rowmask, unsigned long long *stamp) {
+    const int t = threadIdx.x, q = t & (G - 1), lane = t & (ESP_WAVE - 1);
+    constexpr int CPB = THREADS / G;  // columns the workgroup takes at a time
+    constexpr u32 LOWMASK = (1u << SUB_SHIFT) - 1u;
+    constexpr bool raws = MODE == 2, adds = MODE != 0;
+    for (int c0 = 0; c0 < ncl; c0 += CPB) {
+        if (c0 + (t & ~(ESP_WAVE - 1)) / G >= ncl) break;  // (the whole wave has no column left: all 64 lanes leave together)
+        const int c = c0 + t / G;
+        int rs = 0, len = 0;
+        if (c < ncl) {
+            rs = (int)ccnt[c];
+            len = (int)ccnt[c + 1] - rs;
+        }
+        const int lastj = len > 0 ? len - 1 : 0;
+        u32 x[16];
+        // (the network does not care where an entry starts: the group's lanes read neighbouring slots -- with 16
+        // consecutive slots per lane all lanes of a group would meet in one LDS bank)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int p = r * G + q;
+            const u64 kk = skey[min(rs + min(p, lastj), CAPK - 1)];  // (all reads in flight; clamped, never past the array)
+            const u32 rel = (u32)((kk >> SUB_SHIFT) & rowmask) - rmin;
+            x[r] = p < len ? ((rel << SUB_SHIFT) | ((u32)kk & LOWMASK)) : ~0u;
+        }
+        group_sort<G>(x, q);
+#ifdef ESP_LOCAL_STAMPS
+        if (stamp && t == 0 && c0 == 0) stamp[13] = wall_clock64();
+#endif
+        double v[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) v[r] = sval[(x[r] >> ESP_TAG_BITS) & (CAP - 1)];  // (padding reads the last slot)
+        const int nv = max(0, min(16, len - q * 16));               // this lane's entries
+        const int nvn = q == G - 1 ? 0 : max(0, min(16, len - (q + 1) * 16));  // the next lane's
+        // first entry of its (col,row)?  (the entry in front of a lane's first one sits in the lane before it)
+        const u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)x[15], 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+        u32 heads = 0;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const u32 prev = r == 0 ? before : x[r - 1];
+            const bool h = r < nv && ((r == 0 && q == 0) || (prev >> SUB_SHIFT) != (x[r] >> SUB_SHIFT));
+            heads |= h ? 1u << r : 0u;
+        }
+        const int f = heads ? (int)__builtin_ctz(heads) : nv;  // entries in front of the lane's first own (col,row)
+        const u32 next_head0 = (u32)__builtin_amdgcn_update_dpp(0, (int)(heads & 1u), 0x101 /* row_shl:1 */, 0xf, 0xf, true);
+        // the (col,row) of the lane's last entry goes on in the next lane
+        const bool open_end = nv == 16 && nvn > 0 && !next_head0;
+        const u64 colbase = hi + ((u64)c << a.rb);
+        u32 emit = 0;
+        if constexpr (FRESH && MODE != 0) {
+            // ---- pass A, additions on a fresh matrix: running sums, restarted at every first entry of a (col,row); every
+            // entry's slot takes the sum up to it -- the slot of a (col,row)'s LAST entry is its record's value slot
+            double acc = 0.0;
+            u32 np = 0, pres = 0;  // UPDATEs: a (col,row) is present once one of its values is not zero
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const bool is_head = (heads >> r) & 1u;
+                acc = (is_head ? 0.0 : acc) + v[r];
+                if (r < nv) sval[(x[r] >> ESP_TAG_BITS) & (CAP - 1)] = acc;
+                if constexpr (!raws) {
+                    const u32 nz = v[r] != 0.0 ? 1u : 0u;
+                    np = is_head ? nz : (np | nz);
+                    pres |= np << r;
+                }
+            }
+            // last entries of the (col,row)s that started in this lane: the entry in front of a first entry, and the
+            // lane's last entry unless its (col,row) goes on
+            const u32 valid = nv >= 16 ? 0xFFFFu : ((1u << nv) - 1u);
+            const u32 lastbit = (nv > 0 && !open_end) ? 1u << (nv - 1) : 0u;
+            const u32 tails = ((heads >> 1) | lastbit) & valid & ~((1u << f) - 1u);
+            emit = raws ? tails : (tails & pres);
+            // ---- pass B
+            double t_acc = acc;
+            u32 t_present = raws ? 1u : np;
+            bool final = f < 16, need = f > 0;
+            while (__ballot(need) != 0ull) {
+                const double in_acc = dpp_shr1_f64(t_acc);
+                const u32 in_present = (u32)__builtin_amdgcn_update_dpp(0, (int)t_present, 0x111, 0xf, 0xf, true);
+                const bool in_final = __builtin_amdgcn_update_dpp(0, (int)final, 0x111, 0xf, 0xf, true) != 0;
+                if (need && in_final) {
+                    double acc2 = in_acc;
+                    u32 p2 = in_present;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const double a3 = acc2 + v[r];
+                        acc2 = r < f ? a3 : acc2;
+                        if constexpr (!raws) p2 |= (r < f && v[r] != 0.0) ? 1u : 0u;
+                    }
+                    if (f == 16 && open_end) {  // every entry of the lane belongs to it and it goes on
+                        t_acc = acc2, t_present = p2;
+                        final = true;
+                    } else if (p2) {
+                        sval[(x[0] >> ESP_TAG_BITS) & (CAP - 1)] = acc2;
+                        emit |= 1u;  // (entry 0 stands for it: the same row, a slot of its own, in front of the lane's other records)
+                    }
+                    need = false;
+                }
+            }
+        } else {
+            // ---- pass A
+            double acc = 0.0;
+            bool present = false;
+            i64 pos = -1;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const bool is_head = (heads >> r) & 1u;
+                if constexpr (FRESH) {
+                    acc = is_head ? 0.0 : acc;
+                    present = is_head ? false : present;
+                } else {
+                    if (is_head) {
+                        acc = 0.0, present = false, pos = -1;
+                        if (a.csc.nnz > 0) {
+                            const u64 full = colbase + (u64)((x[r] >> SUB_SHIFT) + rmin);
+                            pos = espfold::csc_find(a.csc, (i64)(full >> a.rb), (i64)(full & rowmask));
+                            present = pos >= 0 && a.mode == ESP_FLUSH_ROUTED;
+                            acc = present ? a.csc.nzval[pos] : 0.0;
+                        }
+                    }
+                }
+                group_step(present, acc, x[r] & (u32)ESP_TAG_MASK, v[r], adds, raws);  // (entries in front of the first own one: discarded)
+                const bool nexth = r == 15 ? false : ((heads >> (r + 1)) & 1u) != 0u;
+                const bool tail = r >= f && r < nv && (r == nv - 1 ? !open_end : nexth);
+                if (tail && group_close<FRESH>(a, sval, pos, present, acc, x[r])) emit |= 1u << r;
+            }
+            // ---- pass B: what the lane hands on (final at once when its last (col,row) started in the lane itself)
+            double t_acc = acc;
+            bool t_present = present;
+            i64 t_pos = pos;
+            bool final = f < 16;
+            bool need = f > 0;  // (q > 0: the first lane's first entry starts a (col,row))
+            while (__ballot(need) != 0ull) {
+                const double in_acc = dpp_shr1_f64(t_acc);
+                const bool in_present = __builtin_amdgcn_update_dpp(0, (int)t_present, 0x111, 0xf, 0xf, true) != 0;
+                const bool in_final = __builtin_amdgcn_update_dpp(0, (int)final, 0x111, 0xf, 0xf, true) != 0;
+                i64 in_pos = -1;
+                if constexpr (!FRESH) in_pos = (i64)__double_as_longlong(dpp_shr1_f64(__longlong_as_double((long long)t_pos)));
+                if (need && in_final) {
+                    double acc2 = in_acc;
+                    bool present2 = in_present;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        double a3 = acc2;
+                        bool p3 = present2;
+                        group_step(p3, a3, x[r] & (u32)ESP_TAG_MASK, v[r], adds, raws);
+                        acc2 = r < f ? a3 : acc2;
+                        present2 = r < f ? p3 : present2;
+                    }
+                    if (f == 16 && open_end) {  // every entry of the lane belongs to it and it goes on
+                        t_acc = acc2, t_present = present2, t_pos = in_pos;
+                        final = true;
+                    } else if (group_close<FRESH>(a, sval, in_pos, present2, acc2, x[0])) {
+                        emit |= 1u;  // (entry 0 stands for it: the same row, a slot of its own, in front of the lane's other records)
+                    }
+                    need = false;
+                }
+            }
+        }
+#ifdef ESP_LOCAL_STAMPS
+        if (stamp && t == 0 && c0 == 0) stamp[14] = wall_clock64();
+#endif
+        __builtin_amdgcn_wave_barrier();  // (every key of the wave's runs has been read: their slots take the records)
+        // records to the front of the run: exclusive scan of the lanes' record counts inside the group
+        const u32 mine = (u32)__popc(emit);
+        u32 inc = mine;
+        if constexpr (G >= 2) {
+            const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x111, 0xf, 0xf, true);
+            inc += q >= 1 ? o : 0u;
+        }
+        if constexpr (G >= 4) {
+            const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x112, 0xf, 0xf, true);
+            inc += q >= 2 ? o : 0u;
+        }
+        if constexpr (G >= 8) {
+            const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x114, 0xf, 0xf, true);
+            inc += q >= 4 ? o : 0u;
+        }
+        if constexpr (G >= 16) {
+            const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)inc, 0x118, 0xf, 0xf, true);
+            inc += q >= 8 ? o : 0u;
+        }
+        const int total = (int)__shfl((int)inc, lane | (G - 1), ESP_WAVE);
+        int e = (int)(inc - mine);
+        const u64 colpart = (u64)c << a.rb;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            if ((emit >> r) & 1u) {
+                skey[rs + e] = ((colpart | (u64)((x[r] >> SUB_SHIFT) + rmin)) << SUB_SHIFT) | (u64)(x[r] & (LOWMASK & ~(u32)ESP_TAG_MASK));
+                e++;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int p = q * 16 + r;
+            if (p >= total && p < len) skey[rs + p] = NOREC;
+        }
+    }
+}
+
 // BIG: the kernel also carries the 24-input register tier.  It is a separate instantiation because the
 // extra code costs the common path registers (measured: +25 % on the 12-input tier when both live in one
 // kernel); the host picks it for a handle whose last flush met runs of 17..24 (a.maxrun_seen).
@@ -663,6 +934,7 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     __shared__ u64 s_dst;
     __shared__ int s_seg;
     __shared__ u32 s_early;
+    __shared__ u32 s_rmin, s_rmax;  // group tier: smallest / largest row of the segment
     __shared__ i64 s_win[66];
     u32(*cnt)[256] = reinterpret_cast<u32(*)[256]>(cntraw);
     u32 *ccnt = cntraw;
@@ -680,6 +952,8 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     if (t == 0) {
         s_seg = (int)atomicAdd(a.ticket, 1u);
         s_early = 0;
+        s_rmin = ~0u;
+        s_rmax = 0u;
     }
     __syncthreads();
     const int s = esp_uniform_i32(s_seg);
@@ -933,6 +1207,57 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
                 else if constexpr (BIG)
                     lb_done = reg_tier<REG_RUN, FRESH, UPD>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
                 done = true;
+            }
+        } else if constexpr (!SMALL && !BIG) {
+            // ---- group tier: runs of up to 256 entries sorted by 2 .. 16 lanes each, keys in registers (see group_sort)
+            if (!done && maxrun <= GROUP_MAX && a.rb <= 30 && a.cl_bits <= GROUP_CL_BITS && !a.no_group) {
+                u32 rmin = ~0u, rmax = 0u;
+#pragma unroll
+                for (int i = 0; i < NI; i++)
+                    if (wbase + i * ESP_WAVE < n) {
+                        const u32 row = (u32)(k[i] >> SUB_SHIFT) & (u32)rowmask;
+                        rmin = min(rmin, row);
+                        rmax = max(rmax, row);
+                        skey[ccnt[(u32)(k[i] >> csh)] + slot[i]] = k[i];
+                    }
+                rmin = ~esp_wave_max(~rmin);
+                rmax = esp_wave_max(rmax);
+                if (lane == 0) {
+                    atomicMin(&s_rmin, rmin);
+                    atomicMax(&s_rmax, rmax);
+                }
+                __syncthreads();
+                rmin = s_rmin;
+                if (s_rmax - rmin < (1u << GROUP_ROW_BITS)) {
+                    unsigned long long *gstamp = nullptr;
+#ifdef ESP_LOCAL_STAMPS
+                    if (a.stamps) {
+                        gstamp = a.stamps + (size_t)s * 16;
+                        if (t == 0) gstamp[12] = wall_clock64();
+                    }
+#endif
+                    // (one kind for every entry, known to the kernel's instantiation or to the host: the fold is an addition)
+                    const int gmode = (UPD || a.kind_all == ESP_UPDATE) ? 1 : a.kind_all == ESP_RAWUPDATE ? 2 : 0;
+#define ESP_GROUP_GO(GG)                                                                                             \
+    do {                                                                                                             \
+        if (gmode == 1)                                                                                              \
+            group_columns<GG, CAPK, FRESH, 1>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp);                  \
+        else if (gmode == 2)                                                                                         \
+            group_columns<GG, CAPK, FRESH, 2>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp);                  \
+        else                                                                                                         \
+            group_columns<GG, CAPK, FRESH, 0>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp);                  \
+    } while (0)
+                    if (maxrun <= 32)
+                        ESP_GROUP_GO(2);
+                    else if (maxrun <= 64)
+                        ESP_GROUP_GO(4);
+                    else if (maxrun <= 128)
+                        ESP_GROUP_GO(8);
+                    else
+                        ESP_GROUP_GO(16);
+#undef ESP_GROUP_GO
+                    done = true;
+                }
             }
         } else if constexpr (SMALL) {
             if (!done) {

@@ -1131,10 +1131,12 @@ static void fem_local(int dim, i64 npd, i64 cell, i64 *nodes, double *vol_out, d
         }
 }
 
-void orc_fem_stream(int dim, i64 npd, uint64_t seed, int order_mode, i64 *I, i64 *J, double *V) {
+/* stream positions [p0, p1) in cells (the whole stream in chunks: bench-size digests) */
+void orc_fem_stream_range(int dim, i64 npd, uint64_t seed, int order_mode, i64 p0, i64 p1, i64 *I, i64 *J,
+                          double *V) {
     i64 nc = orc_fem_ncells(dim, npd);
     i64 pos = 0;
-    for (i64 p = 0; p < nc; p++) {
+    for (i64 p = p0; p < p1; p++) {
         i64 cell = (i64)orc_fem_cell_at(p, nc, seed, order_mode);
         i64 nodes[4];
         double vol, S[4][4];
@@ -1152,4 +1154,8 @@ void orc_fem_stream(int dim, i64 npd, uint64_t seed, int order_mode, i64 *I, i64
             }
         }
     }
+}
+
+void orc_fem_stream(int dim, i64 npd, uint64_t seed, int order_mode, i64 *I, i64 *J, double *V) {
+    orc_fem_stream_range(dim, npd, seed, order_mode, 0, orc_fem_ncells(dim, npd), I, J, V);
 }

@@ -132,6 +132,9 @@ i64 orc_fem_count(int dim, i64 npd);
 uint64_t orc_fem_cell_at(i64 pos, i64 ncells, uint64_t seed, int order_mode);
 void orc_fem_cell_nodes(int dim, i64 npd, i64 cell, i64 *nodes /* dim+1 */);
 void orc_fem_stream(int dim, i64 npd, uint64_t seed, int order_mode, i64 *I, i64 *J, double *V);
+/* the updates of the cells at stream positions [p0, p1): (p1-p0)*(dim+1)*(dim+2) triples */
+void orc_fem_stream_range(int dim, i64 npd, uint64_t seed, int order_mode, i64 p0, i64 p1, i64 *I, i64 *J,
+                          double *V);
 
 #ifdef __cplusplus
 }

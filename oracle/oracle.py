@@ -158,6 +158,7 @@ def lib():
     sig("orc_fem_cell_at", C.c_uint64, i64, i64, C.c_uint64, C.c_int)
     sig("orc_fem_cell_nodes", None, C.c_int, i64, i64, p_i64)
     sig("orc_fem_stream", None, C.c_int, i64, C.c_uint64, C.c_int, p_i64, p_i64, p_f64)
+    sig("orc_fem_stream_range", None, C.c_int, i64, C.c_uint64, C.c_int, i64, i64, p_i64, p_i64, p_f64)
     _lib = L
     return L
 
@@ -499,6 +500,16 @@ def fem_cell_nodes(dim, npd, cell):
     out = np.empty(dim + 1, np.int64)
     lib().orc_fem_cell_nodes(dim, npd, cell, _pi(out))
     return out
+
+
+def fem_stream_range(dim, npd, p0, p1, seed=0x5EED0004, order_mode=1):
+    """The updates of the cells at stream positions [p0, p1) (bench-size digests feed the oracle in chunks)."""
+    e = (p1 - p0) * (dim + 1) * (dim + 2)
+    I = np.empty(e, np.int64)
+    J = np.empty(e, np.int64)
+    V = np.empty(e, np.float64)
+    lib().orc_fem_stream_range(dim, npd, seed, order_mode, p0, p1, _pi(I), _pi(J), _pf(V))
+    return I, J, V
 
 
 def fem_stream(dim, npd, seed=0x5EED0004, order_mode=1):

@@ -1,7 +1,10 @@
 """Full-size parity pins: sha256 digests of the ORACLE's CSC for the bench configurations, committed as
 tests/golden/digests_large.txt (the GPU tests digest the device arrays and compare).
 
-Run:  python tests/golden/make_digests_large.py        (about 8 GB of host memory, a minute or two)
+Run:  python tests/golden/make_digests_large.py [tag-prefix ...]   (all, or only the lines whose tag starts with a prefix;
+                                                                     lines of other tags are kept from the file)
+The bench-size pins (cfg3_256, fem2d_3163, fem3d_216: what bench.py's extra.configs time) take about 20 GB of host
+memory and a quarter of an hour; the FEM streams are fed to the oracle in chunks of cells (orc_fem_stream_range).
 Like make_golden.py these are oracle outputs (the Julia reference cannot run here).
 """
 import os
@@ -19,16 +22,40 @@ from golden_util import digest, cfg3_new_positions  # noqa: E402
 UPDATE, RAW = 1, 2
 
 
+def fem_chunked(dim, npd, order, chunk_cells=1 << 22):
+    """P1 FEM through the oracle's ExtendableSparseMatrix, the stream generated and applied chunk by chunk."""
+    nn, nc, cnt = orc.fem_sizes(dim, npd)
+    A = orc.ExtendableSparseMatrix(nn, nn)
+    for p0 in range(0, nc, chunk_cells):
+        p1 = min(nc, p0 + chunk_cells)
+        I, J, V = orc.fem_stream_range(dim, npd, p0, p1, seed=0x5EED0004, order_mode=order)
+        A.apply(np.full(len(I), RAW, np.uint8), I, J, V)
+        del I, J, V
+    return A
+
+
 def main():
+    only = sys.argv[1:]
+    want = lambda tag: not only or any(tag.startswith(p) for p in only)  # noqa: E731
+    path = os.path.join(HERE, "digests_large.txt")
+    kept = {}
+    if only and os.path.exists(path):
+        with open(path) as f:
+            for ln in f:
+                if ln.strip():
+                    kept[ln.split()[0]] = ln.strip()
     lines = []
     # BASELINE config 2 at full size (the bench configuration: rand_mode 1, seed 0x5EED0002, updateindex! style) and
     # two smaller cubes
     for n in (128, 192, 256):
+        if not (want("fd_%d_m1" % n) or want("cfg3_%d" % n)):
+            continue
         O = orc.fdrand(n, n, n, rand_mode=1, seed=0x5EED0002, style=orc.KIND_UPDATE)
         cp, rv, nz = O.arrays()
-        lines.append("fd_%d_m1 nnz=%d csc=%s" % (n, len(rv), digest(cp, rv, nz)))
-        print(lines[-1], flush=True)
-        if n == 128:
+        if want("fd_%d_m1" % n):
+            lines.append("fd_%d_m1 nnz=%d csc=%s" % (n, len(rv), digest(cp, rv, nz)))
+            print(lines[-1], flush=True)
+        if n in (128, 256) and want("cfg3_%d" % n):
             # BASELINE config 3 at 128^3: the stored stencil + new x second-neighbour positions + the full stream again
             I2, J2, V2 = cfg3_new_positions(n)
             O.apply(np.full(len(I2), UPDATE, np.uint8), I2, J2, V2)
@@ -40,18 +67,21 @@ def main():
             print(lines[-1], flush=True)
         del O, cp, rv, nz
     # BASELINE config 4: P1 FEM in random and in natural cell order
-    for dim, npd in ((2, 1000), (3, 64)):
-        for order in (0, 1):
-            nn, nc, cnt = orc.fem_sizes(dim, npd)
-            I, J, V = orc.fem_stream(dim, npd, seed=0x5EED0004, order_mode=order)
-            A = orc.ExtendableSparseMatrix(nn, nn)
-            A.apply(np.full(cnt, RAW, np.uint8), I, J, V)
+    # (3163^2 and 216^3 in random order: the sizes bench.py's extra.configs time)
+    for dim, npd, orders in ((2, 1000, (0, 1)), (3, 64, (0, 1)), (2, 3163, (1,)), (3, 216, (1,))):
+        for order in orders:
+            tag = "fem%dd_%d_o%d" % (dim, npd, order)
+            if not want(tag):
+                continue
+            A = fem_chunked(dim, npd, order)
             cp, rv, nz = A.arrays()
-            lines.append("fem%dd_%d_o%d nnz=%d csc=%s" % (dim, npd, order, len(rv), digest(cp, rv, nz)))
+            lines.append("%s nnz=%d csc=%s" % (tag, len(rv), digest(cp, rv, nz)))
             print(lines[-1], flush=True)
-            del A, I, J, V
-    with open(os.path.join(HERE, "digests_large.txt"), "w") as f:
-        f.write("\n".join(lines) + "\n")
+            del A, cp, rv, nz
+    for ln in lines:
+        kept[ln.split()[0]] = ln
+    with open(path, "w") as f:
+        f.write("\n".join(kept.values() if only else lines) + "\n")
 
 
 if __name__ == "__main__":

@@ -577,6 +577,39 @@ def test_bucket_kernel_24_input_tier(esp, orc):
         assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
 
 
+@pytest.mark.parametrize("per_col", [20, 28, 50, 100, 120, 200, 250])
+@pytest.mark.parametrize("force", [0, 24])
+def test_bucket_kernel_group_tier(esp, orc, per_col, force):
+    """Column runs of 17 .. 256 entries (P1 FEM: 24 per column in 2-D, 120 in 3-D): the group tier -- 2, 4, 8 or 16
+    lanes per column, 16 keys each in registers, merged across lanes by DPP (local.hpp, group_sort) -- against the
+    radix tier (force_path 24) and the oracle; mixed kinds, zeros, duplicates, columns of different lengths (some
+    empty), first on a fresh matrix, then over the stored CSC, then with rows more than 2^18 apart (the tier's 32-bit
+    sort keys do not apply: radix tier)."""
+    rng = np.random.default_rng(per_col * 31 + force)
+    for m, n in ((5000, 600), (3000000, 96)):
+        cnt = per_col * n * 2 // 3
+        A = esp.ExtendableSparseMatrix(m, n)
+        A.debug_force_path(force)
+        O = orc.ExtendableSparseMatrix(m, n)
+        for rnd in range(2):
+            kinds = rng.choice(np.array([0, 1, 1, 1, 2], np.uint8), cnt)
+            # two thirds of the columns, per_col entries each at most (exactly per_col in a few)
+            cols = rng.permutation(n)[: 2 * n // 3] + 1
+            J = rng.permutation(np.repeat(cols, per_col))[:cnt]
+            J[: per_col] = cols[0]
+            span = 200 if m == 5000 else m
+            I = np.minimum(m, np.maximum(1, (J * (m // n)) + rng.integers(-span, span, cnt)))
+            dup = rng.random(cnt) < 0.5
+            I[dup] = np.minimum(m, J[dup] * (m // n) + rng.integers(0, 5, dup.sum()))
+            V = np.where(rng.random(cnt) < 0.1, 0.0, rng.standard_normal(cnt))
+            A.append(0, I, J, V, kinds=kinds)
+            O.apply(kinds, I, J, V)
+            A.flush()
+            O.flush()
+            assert A.debug_last_path() == 1
+            assert_csc_equal(hip_arrays(A), O.arrays(), "m %d round %d" % (m, rnd))
+
+
 def test_general_path_fdrand_and_plus_mode(esp, orc):
     A = esp.ExtendableSparseMatrix(20 ** 3, 20 ** 3)
     A.debug_force_path(2)

@@ -71,6 +71,8 @@ def config4(dim, npd):
     nn = npd ** dim
     A = esp.ExtendableSparseMatrix(nn, nn)
     A.timing_enable(2)
+    if os.environ.get("ESP_BENCH_FORCE_PATH"):      # experiments only (see esp_debug_force_path)
+        A.debug_force_path(int(os.environ["ESP_BENCH_FORCE_PATH"]))
 
     def step():
         A.reset()

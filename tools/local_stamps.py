@@ -46,8 +46,13 @@ if st16[:, 8].any():
     for nm, a, b in (("sort + count (wave 0)", 3, 8), ("barrier wait", 8, 9), ("fold (wave 0)", 9, 10),
                      ("look-back (last wave)", 9, 11), ("phase end after fold", 10, 4), ("phase end after look-back", 11, 4)):
         x = (st16[:, b] - st16[:, a]) * 0.01
-        print("  %-28s median %6.2f  p90 %6.2f" % (nm, np.median(x), np.percentile(x, 90)))
-if st16[:, 12].any():   # radix tier: 2 = counts scanned, 12 = radix sort done, 13 = fold walks done, 4 = records written
+        print("  %-36s median %6.2f  p90 %6.2f" % (nm, np.median(x), np.percentile(x, 90)))
+if st16[:, 14].any():   # group tier: 2 = counts scanned, 12 = keys scattered + row range known, 13 = sorted (wave 0), 14 = folded (wave 0)
+    for nm, a, b in (("scatter + row range", 2, 12), ("group sort (wave 0)", 12, 13), ("gather + fold (wave 0)", 13, 14),
+                     ("records + barrier", 14, 4)):
+        x = (st16[:, b] - st16[:, a]) * 0.01
+        print("  %-36s median %6.2f  p90 %6.2f" % (nm, np.median(x), np.percentile(x, 90)))
+elif st16[:, 12].any():   # radix tier: 2 = counts scanned, 12 = radix sort done, 13 = fold walks done, 4 = records written
     for nm, a, b in (("radix sort", 2, 12), ("fold walks", 12, 13), ("records", 13, 4)):
         x = (st16[:, b] - st16[:, a]) * 0.01
-        print("  %-28s median %6.2f  p90 %6.2f" % (nm, np.median(x), np.percentile(x, 90)))
+        print("  %-36s median %6.2f  p90 %6.2f" % (nm, np.median(x), np.percentile(x, 90)))
