@@ -12,6 +12,7 @@
 #include "common.hpp"
 #include "fold.hpp"
 #include "generators.hpp"
+#include "femitems.hpp"
 #include "local_args.hpp"
 #include "merge.hpp"
 #include "radix.hpp"
@@ -75,6 +76,10 @@ struct esp_handle {
         bool own32 = false;      // ... and the shard's OWN range holds 4-byte keys of kind `kind` (the sent ranges: packed)
     } pre;
     bool pre_keep = false;       // reserve_append: the append that follows goes behind the bucket-ordered batch
+    // sort_msd over ITEM records (femitems.hpp): a segment may hold plan_cap records (the bucket kernel's capacity in
+    // updates / updates per item), and a shuffled stream need not be tried as a pre-sorted one
+    i64 plan_cap = 0;
+    bool item_mode = false;
     bool shard_user = false;     // the handle is driven through esp_shard_*: its flushes partition by owner first
     int last_shard_source = 0;   // esp_shard_partition: 1 = its own pass moved the entries, 2 = the producer had
     int last_local_small = 0;    // the last flush's bucket kernel was the small variant (3 workgroups per CU)
@@ -914,6 +919,8 @@ extern "C" int32_t esp_set_column_window(esp_handle *h, int64_t col_lo, int64_t 
     return ESP_OK;
 }
 
+static int32_t item_produce_fem(esp_handle *h, const espgen::FemArgs &fa, i64 E, bool *took);
+
 extern "C" int32_t esp_generate_fem(esp_handle *h, int32_t dim, int64_t npd, uint64_t seed, int32_t order_mode) {
     if (!h) return ESP_ERR_INVALID;
     if ((dim != 2 && dim != 3) || npd < 2) FAIL(h, ESP_ERR_INVALID, "fem: dim must be 2 or 3 and npd >= 2");
@@ -933,6 +940,7 @@ extern "C" int32_t esp_generate_fem(esp_handle *h, int32_t dim, int64_t npd, uin
     int bits = 2;
     while (((u64)1 << bits) < (u64)nc) bits += 2;
     a.bits = bits;
+    espgen::fem_fill_magic(a);
     a.h = 1.0 / (double)(npd - 1);
     a.L = h->L;
     a.keys = (u64 *)h->keys.p + h->count;
@@ -962,6 +970,8 @@ extern "C" int32_t esp_generate_fem(esp_handle *h, int32_t dim, int64_t npd, uin
         }
         CK(prepart_finish(h, &ps, &took));
     }
+    // a shuffled stream: the producer partitions its ITEMS and stores every update at its bucket position (femitems.hpp)
+    if (!took) CK(item_produce_fem(h, a, E, &took));
     if (!took) {
         Span sp(h, ESP_ST_APPEND);
         hipLaunchKernelGGL(espgen::fem_k, grid, block, 0, h->stream, a);
@@ -1415,6 +1425,8 @@ static double plan_fill() {
     }();
     return f;
 }
+// records a segment of the partition may hold: the bucket kernel's capacity, or what an item partition says (plan_cap)
+static inline i64 seg_cap(const esp_handle *h) { return h->plan_cap > 0 ? h->plan_cap : (i64)esplocal::CAP; }
 static double plan_entries(i64 E, int K, u64 span) {
     const double full = std::ldexp(1.0, K);
     return span > 0 && (double)span < full ? (double)E * full / (double)span : (double)E;
@@ -1433,20 +1445,20 @@ static int plan_run_bits(i64 E, int K, u64 span) {
 static int plan_prefix_bits(const esp_handle *h, i64 E, int K, double *Ee_out) {
     int planned = 0;
     const double Ee = plan_entries(E, K, h->win_span);  // (see plan_entries: the window fills only part of its 2^K keys)
-    if (E > esplocal::CAP) {
-        double target = plan_fill() * esplocal::CAP;
+    if (E > seg_cap(h)) {
+        double target = plan_fill() * (double)seg_cap(h);
         // (test hook: plan as if the bucket kernel took segments of this many entries -- many prefix bits, i.e. the 9-bit
         // passes, at sizes a CPU oracle can follow)
         if (const char *e = getenv("ESP_DEBUG_PLAN_CAP")) target = std::min(target, std::max(8.0, atof(e)));
         while (planned < K && Ee / (double)((i64)1 << planned) > target) planned++;
     }
     if (planned > 0 && h->seen_spread > 0.0 && h->seen_spread < 2.0 &&
-        Ee / (double)((i64)1 << (planned - 1)) * h->seen_spread <= 0.98 * esplocal::CAP)
+        Ee / (double)((i64)1 << (planned - 1)) * h->seen_spread <= 0.98 * (double)seg_cap(h))
         planned--;  // (see seen_spread; a wrong guess costs one further pass and corrects itself)
     // ... and irregular data (the longest segment well above the average) gets the bits up front that the last flush
     // had to add in a further pass
     for (int extra = 0; extra < 3 && planned > 0 && planned < K && h->seen_spread >= 1.0 && h->seen_spread < 8.0 &&
-                        Ee / (double)((i64)1 << planned) * h->seen_spread > (double)esplocal::CAP;
+                        Ee / (double)((i64)1 << planned) * h->seen_spread > (double)seg_cap(h);
          extra++)
         planned++;
     *Ee_out = Ee;
@@ -1963,7 +1975,7 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     // one bit short of a whole number of 8-bit passes: an average fill of up to 95 % is worth
     // trying with one pass less (the longest segment is checked after the planned passes and a
     // further pass is added only if a segment really overflows)
-    if (planned > 8 && planned % 8 == 1 && Ee / (double)((i64)1 << (planned - 1)) <= 0.95 * esplocal::CAP) planned--;
+    if (planned > 8 && planned % 8 == 1 && Ee / (double)((i64)1 << (planned - 1)) <= 0.95 * (double)seg_cap(h)) planned--;
     // (digits of 9 bits only where they save a whole pass -- 17 or 18 bits in two passes: a tile then holds 8 entries per
     // digit instead of 16; force_path 23: never)
     const int npass8 = (planned + 7) / 8, npass9 = (planned + espradix::MAX_BITS - 1) / espradix::MAX_BITS;
@@ -1983,7 +1995,7 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     bool window_checked = false;
     h->last_partition = 2;
     // pre-sorted streams: the first (up to) 16 bits in ONE pass (runpart.hpp)
-    if (planned_run > 8 && h->force_path != 5) {
+    if (planned_run > 8 && h->force_path != 5 && !h->item_mode) {
         if (h->runs_skip > 0) {
             h->runs_skip--;
         } else {
@@ -2026,14 +2038,14 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
             // spread the planned bits evenly over the planned passes
             bits = (planned - done + (npass_eff - pass_idx) - 1) / (npass_eff - pass_idx);
         } else {
-            if (maxlen <= esplocal::CAP) break;
+            if (maxlen <= seg_cap(h)) break;
             if (done >= K || done >= 24) {
                 ok = false;
                 break;
             }
             // just enough further bits to bring the longest segment under the capacity
             bits = 1;
-            while (bits < 8 && (double)maxlen / (double)(1 << bits) > 0.8 * esplocal::CAP) bits++;
+            while (bits < 8 && (double)maxlen / (double)(1 << bits) > 0.8 * (double)seg_cap(h)) bits++;
             bits = std::min(bits, K - done);
         }
         if (!tiles_ready) {
@@ -2111,9 +2123,93 @@ static int32_t sort_msd(esp_handle *h, Sorted *out) {
     out->total = E;
     out->seg_start = (const i64 *)h->seg[cur].p;
     out->rem_bits = K - done;
-    out->local_ok = ok && (K - done) <= esplocal::MAX_REM_BITS && maxlen <= esplocal::CAP;
+    out->local_ok = ok && (K - done) <= esplocal::MAX_REM_BITS && maxlen <= seg_cap(h);
     out->maxlen = maxlen;
     h->seen_spread = (done > 0 && Ee > 0.0) ? (double)maxlen * std::ldexp(1.0, done) / Ee : 0.0;
+    return ESP_OK;
+}
+
+// Shuffled FEM stream on an empty buffer (femitems.hpp): item records -> the flush's own partition passes over them ->
+// every update stored once at its bucket position; the handle is left as after a producer-side partition (h->pre).
+// *took = false: not applicable, the caller appends in stream order.
+static int32_t item_produce_fem(esp_handle *h, const espgen::FemArgs &fa, i64 E, bool *took) {
+    *took = false;
+    if (h->count != 0 || E <= esplocal::CAP || windowed(h) || h->shard_user) return ESP_OK;
+    // (test hooks that pin another path: 2 general, 5 / 12 / 16 partition flavours, 19 plain pending buffer, 25 this one off)
+    if (h->force_path == 2 || h->force_path == 5 || h->force_path == 12 || h->force_path == 16 || h->force_path == 19 || h->force_path == 25)
+        return ESP_OK;
+    const int W = fa.dim + 2, ni = fa.dim + 1;
+    const i64 NI = fa.ncells * ni;
+    if (NI >= 0xFFFFFFF0ll || (fa.ncells >> 40) != 0 || 2 * NI > E) return ESP_OK;
+    // two ping-pong pairs of item records inside the flush's scratch pair (sized for E updates: E / W items each)
+    CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
+    CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
+    espitem::Args a;
+    a.fem = fa;
+    a.nitems = NI;
+    a.ikeys = (u64 *)h->keys2.p;
+    a.ivals = (double *)h->vals2.p;
+    {
+        Span sp(h, ESP_ST_APPEND);
+        hipLaunchKernelGGL(espitem::fem_items_k, dim3(grid_for(fa.ncells, espitem::THREADS)), dim3(espitem::THREADS), 0, h->stream, a);
+        sp.add(1);
+    }
+    // the flush's partition over the items: a temporary view of the handle (sort_msd reads count, keys/vals, keys2/vals2)
+    const DevBuf k0 = h->keys, v0 = h->vals, k2 = h->keys2, v2 = h->vals2;
+    const i64 count0 = h->count;
+    const double spread0 = h->seen_spread;
+    h->keys.p = a.ikeys, h->keys.bytes = sizeof(u64) * (size_t)NI;
+    h->vals.p = a.ivals, h->vals.bytes = sizeof(double) * (size_t)NI;
+    h->keys2.p = a.ikeys + NI, h->keys2.bytes = sizeof(u64) * (size_t)NI;
+    h->vals2.p = a.ivals + NI, h->vals2.bytes = sizeof(double) * (size_t)NI;
+    h->count = NI;
+    h->plan_cap = (i64)esplocal::CAP / W;
+    h->item_mode = true;
+    Sorted st;
+    const int32_t rc = sort_msd(h, &st);
+    h->keys = k0, h->vals = v0, h->keys2 = k2, h->vals2 = v2;
+    h->count = count0;
+    h->plan_cap = 0;
+    h->item_mode = false;
+    if (rc != ESP_OK) return rc;
+    const int K = window_bits(h);
+    if (!st.local_ok || st.S < 2 || st.rem_bits < h->L.rb || st.maxlen * W > (i64)esplocal::CAP) {
+        h->seen_spread = spread0;
+        return ESP_OK;  // (no segment table the bucket kernel takes: the plain producer and the flush's own passes)
+    }
+    const bool k32 = st.rem_bits <= 32 && h->force_path != 14;
+    a.sorted = st.sv;
+    a.rem_bits = st.rem_bits;
+    a.base = h->win_base;
+    a.keys_out = (u64 *)h->keys.p;
+    a.vals_out = (double *)h->vals.p;
+    CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(st.S + 1)));
+    {
+        Span sp(h, ESP_ST_APPEND);
+        const dim3 grid(grid_for(NI, espitem::THREADS)), block(espitem::THREADS);
+        if (k32)
+            hipLaunchKernelGGL(espitem::fem_expand_k<true>, grid, block, 0, h->stream, a);
+        else
+            hipLaunchKernelGGL(espitem::fem_expand_k<false>, grid, block, 0, h->stream, a);
+        hipLaunchKernelGGL(espitem::scale_segments_k, dim3(grid_for((i64)st.S + 1, 256)), dim3(256), 0, h->stream, st.seg_start, (i64)st.S + 1,
+                           (i64)W, (i64 *)h->seg[1].p);
+        sp.add(2);
+    }
+    HIPCK(h, hipGetLastError());
+    esp_handle::PrePart &pp = h->pre;
+    pp.K = K;
+    pp.pb = K - st.rem_bits;
+    pp.maxlen = st.maxlen * W;
+    pp.key_bytes = k32 ? 4 : 8;
+    pp.kind = ESP_RAWUPDATE;
+    pp.E = E;
+    pp.tail = 0;
+    pp.base = h->win_base;
+    pp.span = h->win_span;
+    pp.Ee = plan_entries(E, K, h->win_span);
+    pp.mw_P = 0, pp.mw_me = 0, pp.mw_shift = 0, pp.mw_nb = 0, pp.mw_eps = 0;
+    pp.own32 = false;
+    *took = true;  // (the caller sets pre.valid once the entries are counted in)
     return ESP_OK;
 }
 

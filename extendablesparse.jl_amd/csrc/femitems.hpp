@@ -1,0 +1,102 @@
+// femitems.hpp -- shuffled P1 FEM streams (BASELINE config 4: random cell order): the producer partitions ITEMS, not
+// updates, and stores every update once, at its final bucket position.
+//
+// A stream in random cell order defeats the run-based producer partition (runpart.hpp: a chunk of 128 cells touches
+// ~500 column blocks, not a handful), and so far such a producer wrote its updates in stream order and the flush
+// paid three histogram + scatter passes over them: 16 B written, then 3 x (8 B + 16 B read, 16 B written) per update.
+// But a cell sends its (dim+1)(dim+2) updates to only dim+1 columns -- dim+2 updates each, one ITEM -- and the bucket
+// of an update is a function of its column alone.  So:
+//   fem_items_k  : one 16-byte record per item, in stream order: the column as a packed sort key | the cell's number
+//                  and the vertex number (no update is formed: ALU + 16 B per item = 3.2 B per update)
+//   partition    : the flush's own stable passes (radix.hpp) over the ITEM records down to the bucket kernel's segments --
+//                  a fifth (3-D) or a quarter (2-D) of the records, each 16 B: what cost 120 B per update costs 24
+//   fem_expand_k : sorted item g -> its dim+2 updates at entries [g (dim+2), (g+1)(dim+2)) of the append buffer, staged
+//                  through LDS and stored with full-line coalesced stores; 4-byte keys (the bits below the segment
+//                  prefix) when they fit: the buffer is written ONCE, bucket by bucket, 12 B per update
+// The buffer is a stable permutation of the stream (inside a segment: items in stream order, an item's updates in call
+// order -- all a (row,col) ever sees of its updates is their relative order), the segment table follows from the
+// items' (x dim+2), and esp_flush starts at the bucket kernel: "the append is the partition" (esp_handle::PrePart).
+// Price: the element matrix of a cell is computed once per vertex column (dim+1 times) instead of once.
+#pragma once
+#include "common.hpp"
+#include "generators.hpp"
+
+namespace espitem {
+
+constexpr int THREADS = 256;
+constexpr int MAX_W = 5;  // 3-D: 5 updates per item
+
+struct Args {
+    espgen::FemArgs fem;
+    i64 nitems;           // ncells * (dim + 1)
+    u64 *ikeys;           // item records: packed key of (row 0, the item's column), kind bits zero
+    double *ivals;        // ... | bit pattern of (cell << 2 | vertex)
+    // fem_expand_k
+    const double *sorted;  // the partitioned records' second halves
+    int rem_bits;          // K32: key bits below the segment prefix
+    u64 base;              // key window base
+    u64 *keys_out;         // (K32: u32 keys)
+    double *vals_out;
+};
+
+__global__ __launch_bounds__(THREADS) void fem_items_k(Args a) {
+    const i64 pos = (i64)blockIdx.x * THREADS + threadIdx.x;
+    if (pos >= a.fem.ncells) return;
+    i64 vx[4][3];
+    i64 nodes[4];
+    const i64 cell = (i64)espgen::fem_cell_at(a.fem, pos);
+    espgen::fem_vertices(a.fem, cell, vx, nodes);
+    const int ni = a.fem.dim + 1;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+        if (k < ni) {
+            a.ikeys[pos * ni + k] = esp_pack(a.fem.L, 1, nodes[k], 0);
+            a.ivals[pos * ni + k] = __longlong_as_double((long long)(((u64)cell << 2) | (u64)k));  // (the cell, not its stream position: the expansion need not walk the permutation again)
+        }
+}
+
+// K32: 4-byte keys (the bits below the segment prefix; every entry is a RAWUPDATE), else packed keys
+template <bool K32>
+__global__ __launch_bounds__(THREADS) void fem_expand_k(Args a) {
+    typedef typename std::conditional<K32, u32, u64>::type KT;
+    __shared__ KT lk[THREADS * MAX_W];
+    __shared__ double lv[THREADS * MAX_W];
+    const int t = threadIdx.x;
+    const i64 g0 = (i64)blockIdx.x * THREADS, g = g0 + t;
+    const int W = a.fem.dim + 2;
+    if (g < a.nitems) {
+        const u64 id = (u64)__double_as_longlong(a.sorted[g]);
+        const int k = (int)(id & 3ull);
+        const u64 lowmask = a.rem_bits >= 64 ? ~0ull : ((1ull << a.rem_bits) - 1ull);
+        // the item's updates in call order: row il's term at il, +1 from the diagonal's row on (the mass term of the
+        // diagonal comes right before it)
+        espgen::fem_updates_of_cell(a.fem, (i64)(id >> 2), [&](int il, int jl, i64 row, i64 col, double v) {
+            if (jl < 0 ? il != k : jl != k) return;
+            const int at = t * W + (jl < 0 ? il : il + (il >= jl ? 1 : 0));
+            if constexpr (K32)
+                lk[at] = (u32)(((((u64)(col - 1) << a.fem.L.rb) | (u64)(row - 1)) - a.base) & lowmask);
+            else
+                lk[at] = esp_pack(a.fem.L, row, col, ESP_RAWUPDATE);
+            lv[at] = v;
+        });
+    }
+    __syncthreads();
+    const int cnt = (int)min((i64)THREADS, a.nitems - g0) * W;
+    if constexpr (K32) {
+        // (4-byte keys: plain coalesced stores; the values as pairs where aligned)
+        u32 *gk = reinterpret_cast<u32 *>(a.keys_out) + g0 * W;
+        for (int q = t; q < cnt; q += THREADS) gk[q] = lk[q];
+        double *gv = a.vals_out + g0 * W;
+        for (int q = t; q < cnt; q += THREADS) gv[q] = lv[q];
+    } else {
+        espgen::copy_out_staged<THREADS>(lk, lv, cnt, a.keys_out + g0 * W, a.vals_out + g0 * W);
+    }
+}
+
+// entries = items * (dim + 2): the segment table of the append buffer from the items'
+__global__ void scale_segments_k(const i64 *__restrict__ in, i64 n, i64 w, i64 *__restrict__ out) {
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) out[g] = in[g] * w;
+}
+
+}  // namespace espitem

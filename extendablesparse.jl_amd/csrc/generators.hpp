@@ -320,6 +320,7 @@ struct FemArgs {
     u64 seed;
     int order_mode;
     int bits;  // even bit count of the Feistel domain
+    u64 mq;    // fem_fill_magic: ceil(2^64 / (npd - 1)) when every cell number and (npd - 1)^2 fit 32 bits, else 0
     double h;
     KeyLayout L;
     esprun::PartOut part;  // part.on: the append is the partition (runpart.hpp)
@@ -346,16 +347,37 @@ __device__ __forceinline__ u64 fem_cell_at(const FemArgs &a, i64 pos) {
     return x;
 }
 
+// x / d for 32-bit x and d through one multiplication by m = ceil(2^64 / d) (exact for every 32-bit x: the error term
+// x (m d - 2^64) / (d 2^64) stays below 1 / d): the integer divisions of the vertex arithmetic below cost over a
+// hundred instructions each as 64-bit divisions -- a third of a cell's work
+__host__ __device__ inline u64 fem_magic(u64 d) { return d > 1 ? ~0ull / d + 1ull : 0ull; }
+__device__ __forceinline__ u32 fem_div32(u32 x, u64 m) {
+    return (u32)__umul64hi(m, (u64)x);
+}
+static inline void fem_fill_magic(struct FemArgs &a);
+
 // vertices of a cell of the Kuhn triangulation: grid coordinates vx[k][d] and node numbers (1-based)
 __device__ __forceinline__ void fem_vertices(const FemArgs &a, i64 cell, i64 (&vx)[4][3], i64 (&nodes)[4]) {
     const int dim = a.dim;
     const int K = dim == 2 ? 2 : 6;
     const i64 q = a.npd - 1;
-    const i64 cube = cell / K;
-    const int s = (int)(cell % K);
-    vx[0][0] = cube % q;
-    vx[0][1] = (cube / q) % q;
-    vx[0][2] = dim == 3 ? cube / (q * q) : 0;
+    int s;
+    if (a.mq) {  // (32-bit arithmetic, divisions by multiplication: the same integers)
+        const u32 c32 = (u32)cell;
+        const u32 cube = dim == 2 ? c32 >> 1 : c32 / 6u;
+        s = (int)(c32 - cube * (u32)K);
+        const u32 t1 = q > 1 ? fem_div32(cube, a.mq) : cube;
+        const u32 t2 = q > 1 ? fem_div32(t1, a.mq) : t1;
+        vx[0][0] = (i64)(cube - t1 * (u32)q);
+        vx[0][1] = (i64)(t1 - t2 * (u32)q);
+        vx[0][2] = dim == 3 ? (i64)t2 : 0;
+    } else {
+        const i64 cube = cell / K;
+        s = (int)(cell % K);
+        vx[0][0] = cube % q;
+        vx[0][1] = (cube / q) % q;
+        vx[0][2] = dim == 3 ? cube / (q * q) : 0;
+    }
     // Kuhn simplices: vertex k+1 = vertex k + e_{perm[k]}
     const int perm3[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
     const int perm2[2][2] = {{0, 1}, {1, 0}};
@@ -371,17 +393,26 @@ __device__ __forceinline__ void fem_vertices(const FemArgs &a, i64 cell, i64 (&v
     for (int k = 0; k < 4; k++)
         if (k <= dim) nodes[k] = 1 + vx[k][0] + a.npd * (vx[k][1] + a.npd * vx[k][2]);
 }
+static inline void fem_fill_magic(FemArgs &a) {
+    const u64 q = (u64)(a.npd - 1);
+    a.mq = ((u64)a.ncells < (1ull << 32) && q * q < (1ull << 32)) ? fem_magic(q) : 0ull;
+}
 
 // One workgroup = FEM_CELLS consecutive stream positions; the (dim+1)(dim+2) updates of a cell are
 // staged in LDS in stream order.
 constexpr int FEM_CELLS = 128;
 constexpr int FEM_MAX_PER_CELL = 20;
-// slot == nullptr: stream order from LDS position o0 on (packed keys); else entry (il,jl) goes to the column's item
-// (esprun::tile_slots) and KT = u32 stages the key bits below the bucket prefix
-template <typename KT>
-__device__ __forceinline__ void fem_stage(const FemArgs &a, KT *lk, double *lv, int o0, const u32 *slot, i64 p) {
-    if (p >= a.ncells) return;
-    const i64 cell = (i64)fem_cell_at(a, p);
+// The updates of the cell at stream position p, in call order (test/femtools.jl:62-69): for every local row il the mass
+// term on the diagonal, then the row of the element matrix.  emit(il, jl, row, col, v); jl = -1 for the mass term.
+// ONE copy of the element arithmetic for every producer (fixed operation order, no FMA: the oracle's sequence).
+template <typename F>
+__device__ __forceinline__ void fem_updates_of_cell(const FemArgs &a, i64 cell, F emit);
+template <typename F>
+__device__ __forceinline__ void fem_cell_updates(const FemArgs &a, i64 p, F emit) {
+    fem_updates_of_cell(a, (i64)fem_cell_at(a, p), emit);
+}
+template <typename F>
+__device__ __forceinline__ void fem_updates_of_cell(const FemArgs &a, i64 cell, F emit) {
     const int dim = a.dim;
     i64 vx[4][3];
     i64 nodes[4];
@@ -447,28 +478,33 @@ __device__ __forceinline__ void fem_stage(const FemArgs &a, KT *lk, double *lv, 
                 S[jl][il] = sacc;
             }
         }
+#pragma unroll
+    for (int il = 0; il < 4; il++) {
+        if (il <= dim) {
+            emit(il, -1, nodes[il], nodes[il], 0.1 * vol / (double)(dim + 1));
+#pragma unroll
+            for (int jl = 0; jl < 4; jl++)
+                if (jl <= dim) emit(il, jl, nodes[il], nodes[jl], vol * S[il][jl]);
+        }
+    }
+}
+
+// slot == nullptr: stream order from LDS position o0 on (packed keys); else entry (il,jl) goes to the column's item
+// (esprun::tile_slots) and KT = u32 stages the key bits below the bucket prefix
+template <typename KT>
+__device__ __forceinline__ void fem_stage(const FemArgs &a, KT *lk, double *lv, int o0, const u32 *slot, i64 p) {
+    if (p >= a.ncells) return;
     int o = o0;
-    auto put = [&](int at, i64 row, i64 col, double v) {
+    fem_cell_updates(a, p, [&](int il, int jl, i64 row, i64 col, double v) {
+        // (within a column's item: row il's term at il, +1 from the diagonal's row on -- the mass term comes right before it)
+        const int at = !slot ? o : jl < 0 ? (int)slot[il] + il : (int)slot[jl] + il + (il >= jl ? 1 : 0);
         if constexpr (sizeof(KT) == 4)
             lk[at] = (u32)(((u64)(col - 1) << a.L.rb) | (u64)(row - 1));  // (low 32 bits: see esprun::copy_out_runs)
         else
             lk[at] = esp_pack(a.L, row, col, ESP_RAWUPDATE);
         lv[at] = v;
-    };
-#pragma unroll
-    for (int il = 0; il < 4; il++) {
-        if (il <= dim) {
-            put(slot ? (int)slot[il] + il : o, nodes[il], nodes[il], 0.1 * vol / (double)(dim + 1));
-            o++;
-#pragma unroll
-            for (int jl = 0; jl < 4; jl++) {
-                if (jl <= dim) {
-                    put(slot ? (int)slot[jl] + il + (il >= jl ? 1 : 0) : o, nodes[il], nodes[jl], vol * S[il][jl]);
-                    o++;
-                }
-            }
-        }
-    }
+        o++;
+    });
 }
 
 __global__ __launch_bounds__(FEM_CELLS) void fem_k(FemArgs a) {

@@ -610,6 +610,61 @@ def test_bucket_kernel_group_tier(esp, orc, per_col, force):
             assert_csc_equal(hip_arrays(A), O.arrays(), "m %d round %d" % (m, rnd))
 
 
+def test_item_producer_shuffled_fem(esp, orc):
+    """A shuffled FEM stream on an empty buffer: the producer partitions its ITEMS (a cell's updates for one vertex
+    column) and stores every update once, at its bucket position (femitems.hpp; the flush starts at the bucket kernel:
+    esp_debug_last_partition 4).  Against the oracle fed the same stream: by itself, with the producer in stream order
+    (force_path 25: the flush's own passes), with further appends behind the batch, twice in a row, over a stored CSC,
+    after reset!, and with packed instead of 4-byte keys (force_path 14)."""
+    rng = np.random.default_rng(8)
+    for dim, npd in ((2, 300), (3, 31), (3, 18)):
+        nn = npd ** dim
+        I, J, V = orc.fem_stream(dim, npd, seed=0x5EED0004, order_mode=1)
+        O = orc.ExtendableSparseMatrix(nn, nn)
+        O.apply(np.full(len(I), RAW, np.uint8), I, J, V)
+        want = O.arrays()
+        A = esp.ExtendableSparseMatrix(nn, nn)
+        A.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
+        A.flush()
+        assert A.debug_last_partition() == 4 and A.debug_last_key_bytes() == 4, A.debug_last_partition()
+        assert_csc_equal(hip_arrays(A), want, "fem %d-D %d" % (dim, npd))
+        C = esp.ExtendableSparseMatrix(nn, nn)
+        C.debug_force_path(14)
+        C.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
+        C.flush()
+        assert C.debug_last_partition() == 4 and C.debug_last_key_bytes() == 8
+        assert_csc_equal(hip_arrays(C), want, "packed keys")
+        B = esp.ExtendableSparseMatrix(nn, nn)
+        B.debug_force_path(25)
+        B.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
+        B.flush()
+        assert B.debug_last_partition() in (1, 2)
+        assert_csc_equal(hip_arrays(B), want, "stream order")
+        # re-assembly over the stored pattern (all hits), then appends behind the buckets, then the stream twice
+        cnt = 3000
+        I2 = rng.integers(1, nn + 1, cnt)
+        J2 = rng.integers(1, nn + 1, cnt)
+        V2 = rng.standard_normal(cnt)
+        k2 = rng.choice(np.array([0, 1, 2], np.uint8), cnt)
+        A.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
+        A.append(0, I2, J2, V2, kinds=k2)
+        A.flush()
+        O.apply(np.full(len(I), RAW, np.uint8), I, J, V)
+        O.apply(k2, I2, J2, V2)
+        O.flush()
+        assert_csc_equal(hip_arrays(A), O.arrays(), "stored + tail")
+        A.reset()
+        O.reset()
+        A.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
+        A.generate_fem(dim, npd, seed=0x5EED0005, order_mode=1)
+        A.flush()
+        Ib, Jb, Vb = orc.fem_stream(dim, npd, seed=0x5EED0005, order_mode=1)
+        O.apply(np.full(len(I), RAW, np.uint8), I, J, V)
+        O.apply(np.full(len(Ib), RAW, np.uint8), Ib, Jb, Vb)
+        O.flush()
+        assert_csc_equal(hip_arrays(A), O.arrays(), "twice")
+
+
 def test_general_path_fdrand_and_plus_mode(esp, orc):
     A = esp.ExtendableSparseMatrix(20 ** 3, 20 ** 3)
     A.debug_force_path(2)
@@ -1064,7 +1119,7 @@ def test_producer_side_partition_fem_and_fallbacks(esp, orc):
             B.debug_force_path(16)
             B.generate_fem(dim, npd, seed=0x5EED0004, order_mode=order)
             B.flush()
-            assert A.debug_last_partition() == (4 if order == 0 else 2), (dim, order, A.debug_last_partition())
+            assert A.debug_last_partition() == 4, (dim, order, A.debug_last_partition())   # natural order: run lists; random: item partition
             assert B.debug_last_partition() in (1, 2)
             if order == 0:
                 assert A.debug_last_key_bytes() == 4
@@ -1688,7 +1743,7 @@ def test_fem_digest(esp, dim, npd, order):
     A = esp.ExtendableSparseMatrix(nn, nn)
     A.generate_fem(dim, npd, seed=0x5EED0004, order_mode=order)
     A.flush()
-    assert A.debug_last_partition() == (4 if order == 0 else 2)
+    assert A.debug_last_partition() == 4   # natural order: run lists; random: item partition (femitems.hpp)
     arrs = hip_arrays(A)
     assert len(arrs[1]) == int(d["nnz"])
     assert gu.digest(*arrs) == d["csc"]
