@@ -43,6 +43,46 @@ def pmc_traffic(kernel_stage):
         return None, None
 
 
+def golden_digests():
+    """tests/golden/digests_large.txt: sha256 of the ORACLE's CSC for the bench configurations (data only; made by
+    tests/golden/make_digests_large.py on the build host)."""
+    out = {}
+    try:
+        with open(os.path.join(ROOT, "tests", "golden", "digests_large.txt")) as f:
+            for line in f:
+                parts = line.split()
+                if parts:
+                    out[parts[0]] = dict(p.split("=") for p in parts[1:])
+    except Exception:
+        pass
+    return out
+
+
+def csc_digest_ok(A, tag, pins):
+    """Untimed self-check: sha256 over the device CSC (colptr, rowval, nzval as Julia would see them) against the
+    oracle's pin for this configuration.  True / False, or None when there is no pin for `tag`."""
+    import hashlib
+    if tag not in pins:
+        return None
+    cp, rv, nz = A.sparse().arrays()
+    if len(rv) != int(pins[tag]["nnz"]):
+        return False
+    h = hashlib.sha256()
+    for a in (cp, rv, nz):
+        h.update(memoryview(a).cast("B"))
+    return h.hexdigest() == pins[tag]["csc"]
+
+
+def cfg3_new_positions(n, seed=0x5EED0003):
+    """Config 3's new entries (same generator as tests/golden_util.cfg3_new_positions, which made the pin): the x
+    second-neighbour pairs (l,l+2),(l+2,l), values U[0,1) from numpy's default_rng(seed)."""
+    import numpy as np
+    g = np.arange(n ** 3, dtype=np.int64)
+    l = g[(g % n) < n - 2] + 1
+    v = np.random.default_rng(seed).random(len(l))
+    return np.concatenate([l, l + 2]), np.concatenate([l + 2, l]), np.concatenate([v, v])
+
+
 def fd_counts(n):
     E = 12 * n * n * (n - 1) + 6 * n * n
     Z = n ** 3 + 6 * n * n * (n - 1)
@@ -150,6 +190,7 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
     loop).  Algorithmic bytes as in SURVEY.md 8d; frac = bytes / time / 8 TB/s."""
     import ctypes as C
     out = {}
+    pins = golden_digests()
 
     def stages(tm, reps):
         return {k: round(v[0] / reps, 3) for k, v in tm.items() if isinstance(v, tuple) and v[0] > 0}
@@ -160,16 +201,12 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
         n = n_cfg3
         N = n ** 3
         E, Z0 = fd_counts(n)
-        g = torch.arange(N, device="cuda", dtype=torch.int64)
-        l = g[(g % n) < n - 2] + 1
-        rows = torch.cat([l, l + 2])
-        cols = torch.cat([l + 2, l])
-        gen = torch.Generator(device="cuda")
-        gen.manual_seed(0x5EED0003)
-        v = torch.rand(l.numel(), device="cuda", dtype=torch.float64, generator=gen)
-        vals = torch.cat([v, v])
+        I2, J2, V2 = cfg3_new_positions(n)           # (host-made: the very values the oracle's pin was made from)
+        rows = torch.from_numpy(I2).cuda()
+        cols = torch.from_numpy(J2).cuda()
+        vals = torch.from_numpy(V2).cuda()
         Zn = rows.numel()
-        del g, l, v
+        del I2, J2, V2
         A = esp.ExtendableSparseMatrix(N, N, device=local, capacity_hint=E + Zn)
         d = A._d
         torch.cuda.synchronize()
@@ -198,6 +235,7 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
                 dts.append(time.perf_counter() - t0)
         Z1 = A.nnz()
         assert Z1 == Z0 + Zn, (Z1, Z0, Zn)
+        ok3 = csc_digest_ok(A, "cfg3_%d" % n, pins)
         dt = sum(dts) / len(dts)
         Ea = E + Zn
         algo = 2 * 16.0 * Ea + (16.0 * Z0 + 8.0 * (N + 1)) + (16.0 * Z1 + 8.0 * (N + 1))
@@ -206,7 +244,7 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
                         "(%.1f %% of the stored nnz): append + flush! with merge-path join" % (n, Z0, Zn, 100.0 * Zn / Z0),
             "ms": dt * 1e3, "nnz_per_s": Z1 / dt, "appended_per_s": Ea / dt, "algorithmic_bytes": algo,
             "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS, "partition": A.debug_last_partition(),
-            "stage_ms": stages(tm, 1), "steps": len(dts)}
+            "stage_ms": stages(tm, 1), "steps": len(dts), "digest_ok": ok3}
         del A, rows, cols, vals
     except Exception as ex:
         out["cfg3_reassembly"] = {"error": repr(ex)}
@@ -236,13 +274,14 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
                 elif it > 0:
                     dts.append(time.perf_counter() - t0)
             Z = A.nnz()
+            ok4 = csc_digest_ok(A, "fem%dd_%d_o1" % (dim, npd), pins)
             dt = sum(dts) / len(dts)
             algo = 2 * 16.0 * E + 16.0 * Z + 8.0 * (nn + 1)
             out[tag] = {"workload": "P1 FEM %d-D, %d^%d nodes (%d DoF), Kuhn grid, random cell order: %d rawupdateindex! "
                                     "calls -> fresh CSC" % (dim, npd, dim, nn, E),
                         "ms": dt * 1e3, "nnz_per_s": Z / dt, "appended_per_s": E / dt, "final_nnz": Z,
                         "algorithmic_bytes": algo, "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS,
-                        "partition": A.debug_last_partition(), "stage_ms": stages(tm, 1), "steps": len(dts)}
+                        "partition": A.debug_last_partition(), "stage_ms": stages(tm, 1), "steps": len(dts), "digest_ok": ok4}
             del A
         except Exception as ex:
             out[tag] = {"error": repr(ex)}
@@ -262,6 +301,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra.configs measurements (configs 3 and 4)")
     ap.add_argument("--sharded", action="store_true",
                     help="use the column-shard exchange path even on one GPU (always used for --gpus > 1)")
+    ap.add_argument("--global-n", type=int, default=int(os.environ.get("ESP_BENCH_GLOBAL_N", "0")),
+                    help="STRONG scaling on a fixed global G^3 grid (BASELINE.json configs[4]: --gpus 8 --global-n 512): rank r "
+                         "assembles the z-slab of G/N planes it owns; default (0): weak scaling, n x n x (n*N)")
     args = ap.parse_args()
     if args.gpus < 1:
         raise SystemExit("bench.py: --gpus must be >= 1")
@@ -302,24 +344,34 @@ def main():
             A.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1, kind=esp.ESP_UPDATE)
             A.flush()
     else:
-        # weak scaling: the global grid is n x n x (n*world); rank r assembles the z-slab of nodes
+        # weak scaling (default): the global grid is n x n x (n*world); rank r assembles the z-slab of nodes
         # it owns (fixed work per GPU), columns are range-sharded, entries of the cross-slab pairs
-        # travel through the all-to-all
-        nzg = n * world
-        N = n * n * nzg
+        # travel through the all-to-all.  --global-n G: the fixed G^3 grid of BASELINE.json configs[4]
+        # (strong scaling), rank r = the z-slab of G / world planes
+        if args.global_n:
+            gx = gy = nzg = args.global_n
+            if nzg % world:
+                raise SystemExit("bench.py: --global-n %d is not a multiple of the %d ranks" % (nzg, world))
+        else:
+            gx = gy = n
+            nzg = n * world
+        N = gx * gy * nzg
+        nodes = N // world
+        Eg = 4 * ((gx - 1) * gy * nzg + gx * (gy - 1) * nzg + gx * gy * (nzg - 1)) + 2 * (gy * nzg + gx * nzg + gx * gy)
+        E = Eg // world                        # (per rank: the bytes of the roofline lines)
+        E_hint = E + 8 * gx * gy               # (... with room for the slab's boundary planes)
         # the C group API: exchange policy and RCCL all-to-all-v (grouped ncclSend/ncclRecv on the library's stream)
         # live inside libesparse_hip.so; torch.distributed only carries the 128-byte id, the barrier and the timing
         uid = [esp.GroupShardedMatrix.unique_id() if rank == 0 else None]
         if world > 1:
             dist.broadcast_object_list(uid, src=0)
-        SA = esp.GroupShardedMatrix(N, N, nranks=world, rank=rank, device=local, capacity_hint=E + 4 * n * n, unique_id=uid[0])
+        SA = esp.GroupShardedMatrix(N, N, nranks=world, rank=rank, device=local, capacity_hint=E_hint, unique_id=uid[0])
         A = SA.local
-        Z_total = N + 2 * ((n - 1) * n * nzg + n * (n - 1) * nzg + n * n * (nzg - 1))
-        nodes = n ** 3
+        Z_total = N + 2 * ((gx - 1) * gy * nzg + gx * (gy - 1) * nzg + gx * gy * (nzg - 1))
 
         def step():
             A.reset()
-            A.generate_fdrand_range(n, n, nzg, rank * nodes, (rank + 1) * nodes, seed=0x5EED0002, rand_mode=1,
+            A.generate_fdrand_range(gx, gy, nzg, rank * nodes, (rank + 1) * nodes, seed=0x5EED0002, rand_mode=1,
                                     kind=esp.ESP_UPDATE)
             SA.flush()
     # Timed region: HIP events around the bucket kernel only (level 3; every bracketed kernel costs two event records
@@ -356,6 +408,10 @@ def main():
     assert total_nnz == Z_total or os.environ.get("ESP_LOCAL_STOP"), (total_nnz, Z_total)   # (ablation runs produce nothing)
     tm = A.timing(clear=True)
     partition_kind = A.debug_last_partition()
+    # untimed self-check of what the timed loop produced: the device CSC against the oracle's pin (fd_<n>_m1)
+    digest_ok = None
+    if not sharded and rank == 0 and not os.environ.get("ESP_LOCAL_STOP") and not os.environ.get("ESP_BENCH_NO_DIGEST"):
+        digest_ok = csc_digest_ok(A, "fd_%d_m1" % n, golden_digests())
     breakdown_steps = 0
     tm_all = tm
     if timing_level == 3:   # stage breakdown: separate untimed steps with events around every big kernel
@@ -382,12 +438,12 @@ def main():
             "scatter": 32.0 * E,          # read 16 B (key+value), write 16 B per entry
             "hist": 8.0 * E,              # read the keys
             "append": 16.0 * E,           # write key+value
-            "local": 16.0 * E + 16.0 * Z + 8.0 * (N + 1),
+            "local": 16.0 * E + 16.0 * Z + 8.0 * (N / world + 1),
             "fold": 16.0 * E + 16.0 * Z,
         }.get(dom, 16.0 * E)
         avg_ms = max(dom_ms / max(dom_launches, 1), 1e-9)
         achieved = per_launch_bytes / (avg_ms * 1e-3) / 1e9
-        algo_bytes = 2 * 16.0 * E + 16.0 * Z + 8.0 * (N + 1)   # 72.08 B per final nnz
+        algo_bytes = 2 * 16.0 * E + 16.0 * Z + 8.0 * (N / world + 1)   # 72.08 B per final nnz (per rank)
         ms_step = dt / args.steps * 1e3
         traffic, traffic_round = pmc_traffic(dom) if (n == 256 and not sharded) else (None, None)
         out = {
@@ -399,10 +455,11 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": ms_step,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if (sharded and args.global_n) else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "digest_ok": digest_ok,   # sha256 of the device CSC == the CPU oracle's (tests/golden/digests_large.txt); None: no pin for this size
             "config": {"workload": "fdrand %d^3 Float64/Int64 fresh build: device COO append (the producer writes every "
                                    "update to its radix bucket) -> LDS bucket sort + ordered fold -> CSC "
                                    "(BASELINE.json configs[1])" % n,
@@ -410,8 +467,9 @@ def main():
                        "partition": {1: "run-based single pass in flush!", 2: "8-bit passes in flush!",
                                      4: "producer-side (append = partition)", 7: "shard pieces"}.get(partition_kind, str(partition_kind)),
                        "parallelism": ("column-range shards x%d, all-to-all-v entry routing (RCCL world size %d), z-slab "
-                                       "producers, global grid %dx%dx%d, at most %d entries sent off-rank per flush"
-                                       % (world, world, n, n, n * world, sent)) if sharded else "1 GPU"},
+                                       "producers, global grid %dx%dx%d%s, at most %d entries sent off-rank per flush"
+                                       % (world, world, gx, gy, nzg, " (BASELINE.json configs[4])" if args.global_n == 512 else "", sent))
+                                      if sharded else "1 GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                          "traffic_from": ("profiles/pmc_traffic.json (%s)" % traffic_round) if traffic else None,

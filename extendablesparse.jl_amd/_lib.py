@@ -103,6 +103,7 @@ SIGNATURES = {
     "esp_group_nnz": (i32, [vp, P(i64), P(i64)]),
     "esp_group_get_csc": (i32, [vp, vp, vp, vp]),
     "esp_group_last_exchange": (i32, [vp, P(i32), P(i64)]),
+    "esp_debug_group_loopback": (i32, [vp, i32, P(i64)]),
     "esp_timing_enable": (i32, [vp, i32]),
     "esp_timing": (i32, [vp, P(esp_timing_t), i32]),
     "esp_debug_force_path": (i32, [vp, i32]),

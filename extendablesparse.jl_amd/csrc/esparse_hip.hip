@@ -2447,7 +2447,7 @@ static int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_ou
             const unsigned grid = (unsigned)std::min<i64>(max_grid, S - first);
             a.first = first;
             // (the variant with the 24-input register tier for a matrix whose last flush met such runs)
-            const bool big = h->seen_maxrun > 16 && h->seen_maxrun <= esplocal::REG_RUN;
+            const bool big = h->seen_maxrun > 16 && h->seen_maxrun <= esplocal::REG_RUN && h->force_path != 26;  // (26: test hook, runs of 17..24 through the group tier)
             // (key format: 0 packed, 1 four-byte keys of one kind, 2 four-byte keys that are all UPDATEs)
             // (3: packed keys whose kinds are all UPDATE -- the pieces of a shard)
             // (4 / 5: pieces of which one -- a shard's own range -- holds 4-byte keys; 5: everything is an UPDATE)

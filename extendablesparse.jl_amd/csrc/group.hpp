@@ -82,6 +82,13 @@ struct esp_group {
     std::vector<i64> nnz_offsets;  // P + 1, valid when offsets_valid
     bool offsets_valid = false;
     DevBuf rkeys, rvals, rcnts;    // receive buffers: alive until the local flush has read them
+    // test hook (esp_debug_group_loopback; a single-rank group over the library's RCCL transport): nothing is skipped
+    // because there is only one rank -- the small agreements run as a real ncclAllGather on the second stream, and every
+    // flush sends the rank's own range to ITSELF through rccl_alltoallv (grouped ncclSend / ncclRecv to self, 1 GiB
+    // rounds), wipes the range and restores it from what arrived.  The transport then really runs on a one-GPU box.
+    bool loopback = false;
+    DevBuf loop;
+    i64 loop_bytes = 0;            // bytes that travelled through RCCL in the last flush
     std::string err;
 };
 
@@ -99,7 +106,7 @@ struct esp_group {
 static int32_t rccl_allgather_i64(void *ctx, const int64_t *send, int32_t count, int64_t *recv) {
     esp_group *g = static_cast<esp_group *>(ctx);
     esp_handle *h = g->h;
-    if (g->P == 1) {
+    if (g->P == 1 && !g->loopback) {
         memcpy(recv, send, sizeof(int64_t) * (size_t)count);
         return ESP_OK;
     }
@@ -122,15 +129,16 @@ static int32_t rccl_alltoallv(void *ctx, const void *const *send, const int64_t 
     esp_group *g = static_cast<esp_group *>(ctx);
     const i64 ROUND = (i64)1 << 30;
     i64 big = 0;
+    const bool self_too = g->loopback;  // (test hook: the rank is its own peer)
     for (int q = 0; q < g->P; q++)
-        if (q != g->me) big = std::max(big, std::max<i64>(send_bytes[q], recv_bytes[q]));
+        if (q != g->me || self_too) big = std::max(big, std::max<i64>(send_bytes[q], recv_bytes[q]));
     // (the number of rounds must be the same on both ends of a pair: every send of `big` bytes is matched by a
     // receive of the same size, so max over my own pairs is enough for each pair taken alone; rounds beyond a pair's
     // size move nothing)
     for (i64 off = 0; off < big; off += ROUND) {
         ncclResult_t r = g_rccl.GroupStart();
         for (int q = 0; q < g->P && r == ncclSuccess; q++) {
-            if (q == g->me) continue;
+            if (q == g->me && !self_too) continue;
             const i64 s = std::min(ROUND, send_bytes[q] - off), t = std::min(ROUND, recv_bytes[q] - off);
             if (s > 0) r = g_rccl.Send((const char *)send[q] + off, (size_t)s, ncclChar, q, g->nccl, (hipStream_t)hip_stream);
             if (t > 0 && r == ncclSuccess) r = g_rccl.Recv((char *)recv[q] + off, (size_t)t, ncclChar, q, g->nccl, (hipStream_t)hip_stream);
@@ -217,6 +225,7 @@ extern "C" int32_t esp_group_destroy(esp_group *g) {
     release(g->rkeys);
     release(g->rvals);
     release(g->rcnts);
+    release(g->loop);
     if (g->own_rccl && g->nccl) (void)g_rccl.CommDestroy(g->nccl);
     delete g;
     return ESP_OK;
@@ -252,6 +261,33 @@ static int32_t exchange(esp_group *g, const std::vector<const void *> &sp, const
     return ESP_OK;
 }
 
+// loop-back test hook: `bytes` at `ptr` (device) go to this very rank through the library's RCCL all-to-all-v, the source
+// is wiped and then restored from what arrived -- all on the handle's stream, like a real exchange
+static int32_t loopback_roundtrip(esp_group *g, void *ptr, i64 bytes) {
+    if (!g->loopback || bytes <= 0) return ESP_OK;
+    if (!g->own_rccl || g->P != 1) GFAIL(g, ESP_ERR_STATE, "esp_debug_group_loopback: a single-rank group over the RCCL transport only");
+    esp_handle *h = g->h;
+    CK(ensure(h, g->loop, (size_t)bytes));
+    const void *sp[1] = {ptr};
+    void *rp[1] = {g->loop.p};
+    const i64 sb[1] = {bytes}, rb[1] = {bytes};
+    HIPCK(h, hipMemsetAsync(g->loop.p, 0xA5, (size_t)bytes, h->stream));
+    CK(rccl_alltoallv(g, sp, sb, rp, rb, (void *)h->stream));
+    HIPCK(h, hipMemsetAsync(ptr, 0, (size_t)bytes, h->stream));
+    HIPCK(h, hipMemcpyAsync(ptr, g->loop.p, (size_t)bytes, hipMemcpyDeviceToDevice, h->stream));
+    g->loop_bytes += bytes;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_group_loopback(esp_group *g, int32_t on, int64_t *bytes_last_flush) {
+    if (!g) return ESP_ERR_INVALID;
+    if (on >= 0) {
+        if (on && (!g->own_rccl || g->P != 1)) GFAIL(g, ESP_ERR_STATE, "esp_debug_group_loopback: a single-rank group over the RCCL transport only");
+        g->loopback = on != 0;
+    }
+    if (bytes_last_flush) *bytes_last_flush = g->loop_bytes;
+    return ESP_OK;
+}
+
 // One partition pass per rank (owner split + first pass of the local flush: esp_shard_partition), ranges and per-digit
 // counts to the owners, pieces assembled without a copy (esp_shard_assemble).  *done = false when the ranks agreed to
 // use the in-place exchange for this flush (some rank's stream is not pre-sorted, or the plan does not apply).
@@ -277,6 +313,10 @@ static int32_t group_exchange_partitioned(esp_group *g, bool *done) {
     std::vector<i64> eoff((size_t)P + 1, 0);
     int64_t nb = 0;
     CK(esp_shard_partition(h, P, me, g->eps, &ok, &dk, &dv, &dc, eoff.data(), &nb));
+    if (ok) {  // (loop-back hook: the partitioned ranges -- all the rank's own -- travel through RCCL; 4-byte keys lie inside them)
+        CK(loopback_roundtrip(g, dk, 8 * eoff[(size_t)P]));
+        CK(loopback_roundtrip(g, dv, 8 * eoff[(size_t)P]));
+    }
     std::vector<i64> mine((size_t)P + 1, 0);
     mine[0] = ok ? 1 : 0;
     for (int r = 0; r < P; r++) mine[(size_t)r + 1] = ok ? eoff[(size_t)r + 1] - eoff[(size_t)r] : 0;
@@ -369,6 +409,10 @@ static int32_t group_exchange_inplace(esp_group *g) {
     double *sv = nullptr;
     std::vector<i64> soff((size_t)P + 1, 0);
     CK(esp_shard_exchange_begin(h, P, me, lower, higher, &sk, &sv, soff.data()));
+    if (g->loopback) {  // (loop-back hook, one rank: the pending buffer is the own chunk)
+        CK(loopback_roundtrip(g, h->keys.p, 8 * h->count));
+        CK(loopback_roundtrip(g, h->vals.p, 8 * h->count));
+    }
     const i64 nrecv = lower + higher;
     CK(ensure(h, g->rkeys, sizeof(u64) * (size_t)std::max<i64>(nrecv, 1)));
     CK(ensure(h, g->rvals, sizeof(double) * (size_t)std::max<i64>(nrecv, 1)));
@@ -403,6 +447,7 @@ extern "C" int32_t esp_group_flush(esp_group *g, int32_t mode, int64_t *local_nn
     esp_handle *h = g->h;
     (void)hipSetDevice(h->device);
     g->err.clear();
+    g->loop_bytes = 0;
     bool done = false;
     CK(group_exchange_partitioned(g, &done));
     if (!done) CK(group_exchange_inplace(g));

@@ -544,6 +544,16 @@ class GroupShardedMatrix:
 
     matrix = local
 
+    def debug_loopback(self, on=True):
+        """Test hook (one rank, RCCL transport): every flush sends the own ranges to this very rank through the library's
+        all-to-all-v and restores them from what arrived (include/esparse_hip.h, esp_debug_group_loopback)."""
+        self._ck(self.A._d.lib.esp_debug_group_loopback(self._g, 1 if on else 0, None))
+
+    def loopback_bytes(self):
+        b = C.c_int64()
+        self._ck(self.A._d.lib.esp_debug_group_loopback(self._g, -1, C.byref(b)))
+        return b.value
+
     def _ck(self, rc):
         if rc != 0:
             msg = self.A._d.lib.esp_group_last_error(self._g)

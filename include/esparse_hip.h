@@ -300,6 +300,12 @@ int32_t esp_group_nnz(esp_group *g, int64_t *global_nnz, int64_t *nnz_before_me)
 int32_t esp_group_get_csc(esp_group *g, int64_t *colptr_own, int64_t *rowval, double *nzval);
 /* kind: 1 = partitioned exchange (pre-sorted streams), 2 = in-place exchange; entries sent to other ranks */
 int32_t esp_group_last_exchange(const esp_group *g, int32_t *kind, int64_t *sent_off_rank);
+/* Test hook for one-GPU boxes (a single-rank group made with esp_group_create, i.e. over the library's own RCCL
+ * transport): on = 1 -- every esp_group_flush sends the rank's own partitioned ranges to ITSELF through the all-to-all-v
+ * (grouped ncclSend / ncclRecv, 1 GiB rounds, on the handle's stream), wipes them and restores them from what arrived,
+ * and the flush's small agreements run as a real ncclAllGather on the second stream; on = 0 -- off; on < 0 -- query only.
+ * bytes_last_flush: what travelled through RCCL in the last flush.  Results never change. */
+int32_t esp_debug_group_loopback(esp_group *g, int32_t on, int64_t *bytes_last_flush);
 
 /* promise: every pending entry of the following flushes has its column in [col_lo, col_hi]
  * (1-based); the partition then works on that window only.  Violations -> ESP_ERR_STATE from esp_flush: the

@@ -1734,10 +1734,45 @@ def test_config3_digest_128(esp):
         assert gu.digest(*arrs) == d["csc"], order
 
 
+def test_config3_digest_bench_size(esp):
+    """BASELINE config 3 at the size bench.py times (256^3 stored + the stream again + 33 M new positions): the call
+    order of bench.py's extra.configs (batch flushed by itself, then the tail with the column-tiled join)."""
+    n = 256
+    N = n ** 3
+    d = gu.digests("digests_large.txt")["cfg3_%d" % n]
+    I2, J2, V2 = gu.cfg3_new_positions(n)
+    A = esp.ExtendableSparseMatrix(N, N)
+    A.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1)
+    A.flush()
+    A.generate_fdrand(n, n, n, seed=0x5EED0012, rand_mode=1)
+    A.append(UPDATE, I2, J2, V2)
+    A.flush()
+    assert A.debug_last_partition() == 6
+    arrs = hip_arrays(A)
+    assert len(arrs[1]) == int(d["nnz"])
+    assert gu.digest(*arrs) == d["csc"]
+
+
+@pytest.mark.parametrize("dim,npd", [(2, 3163), (3, 216)])
+def test_fem_digest_bench_size(esp, dim, npd):
+    """BASELINE config 4 at the sizes bench.py times (10^7 DoF, random cell order; the oracle was fed the stream in
+    chunks, tests/golden/make_digests_large.py): item partition + expansion + group tier of the bucket kernel."""
+    d = gu.digests("digests_large.txt")["fem%dd_%d_o1" % (dim, npd)]
+    nn = npd ** dim
+    A = esp.ExtendableSparseMatrix(nn, nn)
+    A.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
+    A.flush()
+    assert A.debug_last_partition() == 4
+    arrs = hip_arrays(A)
+    assert len(arrs[1]) == int(d["nnz"])
+    assert gu.digest(*arrs) == d["csc"]
+
+
 @pytest.mark.parametrize("dim,npd", [(2, 1000), (3, 64)])
 @pytest.mark.parametrize("order", [0, 1])
 def test_fem_digest(esp, dim, npd, order):
-    """BASELINE config 4 at 10^6 / 2.6 10^5 DoF, natural (producer-side partition) and random cell order (8-bit passes)."""
+    """BASELINE config 4 at 10^6 / 2.6 10^5 DoF, natural (producer-side partition by run lists) and random cell order
+    (item partition + expansion, femitems.hpp)."""
     d = gu.digests("digests_large.txt")["fem%dd_%d_o%d" % (dim, npd, order)]
     nn = npd ** dim
     A = esp.ExtendableSparseMatrix(nn, nn)
@@ -1894,6 +1929,59 @@ def test_group_api_world1_rccl(esp, orc):
         assert A.nnz() == O.nnz() and A.column_range() == (1, N)
         c0, c1, cp, rv, nz = A.local_slice()
         assert_csc_equal((cp, rv, nz), O.arrays())
+
+
+def test_group_rccl_loopback(esp, orc):
+    """The library's RCCL transport really moving data on a one-GPU box (esp_debug_group_loopback): a single-rank group
+    sends its own partitioned ranges to itself through rccl_alltoallv (grouped ncclSend / ncclRecv to self on the handle's
+    stream), wipes them and restores them from what arrived; the flush's agreements run as ncclAllGather on the second
+    stream.  Partitioned exchange (a flush's own pass, then the producer's), in-place exchange (a shuffled stream:
+    consensus fall-back), re-assembly with new entries -- against the oracle."""
+    n = 64
+    N = n ** 3
+    A = esp.GroupShardedMatrix(N, N, nranks=1, rank=0)
+    A.debug_loopback(True)
+    O = orc.ExtendableSparseMatrix(N, N)
+    rng = np.random.default_rng(3)
+    kinds_seen = []
+    for rnd in range(5):
+        moved = 0
+        if rnd < 4:                                # the stencil's pre-sorted stream: partitioned exchange
+            A.local.generate_fdrand(n, n, n, seed=5 + rnd, rand_mode=1)
+            I, J, V = orc.fdrand_stream(n, n, n, rand_mode=1, seed=5 + rnd)
+            O.apply(np.full(len(I), UPDATE, np.uint8), I, J, V)
+            moved += len(I)
+        if rnd >= 2:                               # ... with a shuffled tail / a shuffled stream by itself: in place
+            cnt = 3000 if rnd < 4 else 200000
+            Ix, Jx, Vx = rng.integers(1, N + 1, cnt), rng.integers(1, N + 1, cnt), rng.standard_normal(cnt)
+            A.local.append(RAW, Ix, Jx, Vx)
+            O.apply(np.full(cnt, RAW, np.uint8), Ix, Jx, Vx)
+            moved += cnt
+        A.flush()
+        O.flush()
+        kinds_seen.append(A.last_exchange)
+        assert A.loopback_bytes() >= 12 * moved, (rnd, A.loopback_bytes(), moved)
+        c0, c1, cp, rv, nz = A.local_slice()
+        assert_csc_equal((cp, rv, nz), O.arrays(), "round %d" % rnd)
+    assert kinds_seen[:2] == ["partitioned", "partitioned"] and "inplace" in kinds_seen, kinds_seen
+
+
+def test_group_rccl_loopback_large_message(esp):
+    """... and with messages above the 1 GiB of one round (256^3: 1.6 GB of keys, 1.6 GB of values per flush): the
+    device CSC's digest equals the oracle's pin of the bench configuration."""
+    n = 256
+    N = n ** 3
+    d = gu.digests("digests_large.txt")["fd_%d_m1" % n]
+    A = esp.GroupShardedMatrix(N, N, nranks=1, rank=0, capacity_hint=12 * n * n * (n - 1) + 6 * n * n)
+    A.debug_loopback(True)
+    for rnd in range(2):                     # (the second assembly: the producer partitions for the exchange itself)
+        A.local.reset()
+        A.local.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1)
+        A.flush()
+        assert A.loopback_bytes() == 16 * (12 * n * n * (n - 1) + 6 * n * n), A.loopback_bytes()   # two messages of 1.6 GB: two rounds each
+        arrs = hip_arrays(A.local)
+        assert len(arrs[1]) == int(d["nnz"])
+        assert gu.digest(*arrs) == d["csc"], rnd
 
 
 def test_jacobi_and_ilu0_setup(esp, orc):
