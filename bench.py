@@ -195,6 +195,89 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
     def stages(tm, reps):
         return {k: round(v[0] / reps, 3) for k, v in tm.items() if isinstance(v, tuple) and v[0] > 0}
 
+    # ---- config 2 through the path every caller other than the built-in generators takes: the 256^3 stream as resident
+    # Int64/Int64/Float64 device arrays -> esp_append_device -> flush!  (cfg2_generic_append), and from pageable HOST arrays
+    # -> esp_append_host -> flush! -> esp_get_csc into host arrays (cfg2_host: what a Julia caller of extendable.jl:159-218 +
+    # 258-261 sees; PCIe-inclusive, never the headline value)
+    try:
+        import numpy as np
+        n = n_cfg3
+        N = n ** 3
+        E, Z = fd_counts(n)
+        G = esp.ExtendableSparseMatrix(N, N, device=local, capacity_hint=E)
+        G.debug_force_path(16)                      # (the plain producer: packed keys in STREAM order, as a caller's loop emits them)
+        G.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1, kind=esp.ESP_UPDATE)
+        keys = torch.empty(E, dtype=torch.int64, device="cuda")
+        vals = torch.empty(E, dtype=torch.float64, device="cuda")
+        offs = (C.c_int64 * 2)()
+        rbits, cbits = C.c_int32(), C.c_int32()
+        gd = G._d
+        gd.ck(gd.lib.esp_key_layout(gd.h, C.byref(rbits), C.byref(cbits)))
+        gd.ck(gd.lib.esp_shard_export(gd.h, 1, C.c_void_p(keys.data_ptr()), C.c_void_p(vals.data_ptr()), offs))   # (one owner: a copy)
+        assert offs[1] == E
+        rb = rbits.value
+        rows = ((keys >> 2) & ((1 << rb) - 1)) + 1
+        cols = (keys >> (2 + rb)) + 1
+        del keys, G, gd
+        A = esp.ExtendableSparseMatrix(N, N, device=local, capacity_hint=E)
+        d = A._d
+        torch.cuda.synchronize()
+        dts, tm = [], None
+        for it in range(steps + 2):
+            A.timing_enable(1 if it == steps + 1 else 0)
+            A.timing(clear=True)
+            A.synchronize()
+            t0 = time.perf_counter()
+            A.reset()
+            d.ck(d.lib.esp_append_device(d.h, C.c_void_p(rows.data_ptr()), C.c_void_p(cols.data_ptr()),
+                                         C.c_void_p(vals.data_ptr()), None, esp.ESP_UPDATE, 0, E))
+            A._touch()
+            A.flush()
+            A.synchronize()
+            if it == steps + 1:
+                tm = A.timing(clear=True)
+            elif it > 0:
+                dts.append(time.perf_counter() - t0)
+        assert A.nnz() == Z
+        okg = csc_digest_ok(A, "fd_%d_m1" % n, pins)
+        dt = sum(dts) / len(dts)
+        algo = 24.0 * E + 2 * 16.0 * E + 16.0 * Z + 8.0 * (N + 1)     # + the caller's triplets, read once
+        out["cfg2_generic_append"] = {
+            "workload": "fdrand %d^3 stream from resident Int64/Int64/Float64 device arrays: esp_append_device + flush!" % n,
+            "ms": dt * 1e3, "nnz_per_s": Z / dt, "algorithmic_bytes": algo, "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS,
+            "partition": A.debug_last_partition(), "stage_ms": stages(tm, 1), "steps": len(dts), "digest_ok": okg}
+        # host-visible: pageable host arrays in, host arrays out
+        hr, hc, hv = rows.cpu().numpy(), cols.cpu().numpy(), vals.cpu().numpy()
+        del rows, cols, vals
+        cp = np.empty(N + 1, np.int64)
+        rv = np.empty(Z, np.int64)
+        nz = np.empty(Z, np.float64)
+        rv[:] = 0
+        nz[:] = 0                                   # (touched: the first D2H into fresh pages pays the page faults)
+        dts = []
+        for it in range(3):
+            t0 = time.perf_counter()
+            A.reset()
+            A.append(esp.ESP_UPDATE, hr, hc, hv)
+            A.flush()
+            A.synchronize()
+            t1 = time.perf_counter()
+            d.ck(d.lib.esp_get_csc(d.h, C.c_void_p(cp.ctypes.data), C.c_void_p(rv.ctypes.data), C.c_void_p(nz.ctypes.data)))
+            t2 = time.perf_counter()
+            if it > 0:
+                dts.append((t1 - t0, t2 - t1))
+        ta = sum(x[0] for x in dts) / len(dts)
+        tg = sum(x[1] for x in dts) / len(dts)
+        out["cfg2_host"] = {
+            "workload": "the same stream from pageable host arrays (esp_append_host), flush!, then esp_get_csc into host arrays: "
+                        "the host-visible end point of SURVEY.md 8d (PCIe-inclusive)",
+            "append_flush_ms": ta * 1e3, "get_csc_ms": tg * 1e3, "ms": (ta + tg) * 1e3, "nnz_per_s": Z / (ta + tg),
+            "h2d_GBs": 24.0 * E / ta / 1e9, "d2h_GBs": (16.0 * Z + 8.0 * (N + 1)) / tg / 1e9, "steps": len(dts)}
+        del A, hr, hc, hv, cp, rv, nz
+    except Exception as ex:
+        out["cfg2_generic_append"] = out.get("cfg2_generic_append", {"error": repr(ex)})
+        out["cfg2_host"] = out.get("cfg2_host", {"error": repr(ex)})
+
     # ---- config 3: existing CSC = the config-2 result; the full stencil stream again (all hits) plus the x
     # second-neighbour pairs (l,l+2),(l+2,l) as new positions (28.4 % of Z0), one flush (merge-path join hot)
     try:

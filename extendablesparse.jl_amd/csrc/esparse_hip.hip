@@ -616,11 +616,18 @@ static int32_t reserve_append(esp_handle *h, i64 add) {
 }
 
 // pack count triples that already sit in device memory; checks bounds before committing
+static int32_t append_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const double *d_vals, int kind, int op, i64 count,
+                                  bool *took);
 static int32_t pack_device(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const double *d_vals,
                            const uint8_t *d_kinds, int kind_all, int op, i64 count) {
     if (count == 0) return ESP_OK;
     if (!d_kinds && (kind_all < 0 || kind_all > 3)) FAIL(h, ESP_ERR_INVALID, "append: kind %d invalid", kind_all);
     if (op != ESP_OP_ADD && op != ESP_OP_SUB) FAIL(h, ESP_ERR_UNSUPPORTED, "append: op %d not supported on the device path", op);
+    if (!d_kinds) {  // an empty buffer and one kind: the append is the partition (no packed stream is written)
+        bool took = false;
+        CK(append_partitioned(h, d_rows, d_cols, d_vals, kind_all, op, count, &took));
+        if (took) return ESP_OK;
+    }
     CK(reserve_append(h, count));
     h->pin_scalar[0] = ~0ull;
     CK(ensure(h, h->misc, 256));
@@ -1736,11 +1743,17 @@ static int32_t pending_materialize(esp_handle *h) {
 }
 
 // mw != nullptr: buckets = mw->P * mw->nb (window r = digits [r*nb, (r+1)*nb)), pb = bits covering them
+// triplets of one kind as the source of a partition (esprun::Args::raw_*)
+struct RawSource {
+    const i64 *rows, *cols;
+    int kind, negate;
+    unsigned long long *d_err;
+};
 static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u64 *kout, double *vout, int K, int pb,
                              i64 *seg_out, u64 *tile_first_out, bool *tiles_ready, bool *ok, i64 *maxlen_out,
                              const MultiWin *mw = nullptr, int mw_shift = 0, bool allow_k32 = false, int *key_bytes_out = nullptr,
-                             i64 E_in = -1) {
-    const i64 E = E_in >= 0 ? E_in : h->count;  // (E_in: the entries behind a producer's batch, flush_pre_tail)
+                             i64 E_in = -1, const RawSource *raw = nullptr) {
+    const i64 E = E_in >= 0 ? E_in : h->count;  // (E_in: the entries behind a producer's batch, flush_pre_tail; a raw batch)
     const i64 NB = mw ? (i64)mw->P * (i64)mw->nb : (i64)1 << pb;
     CK(ensure(h, h->misc, 256));
     const i64 C = ceil_div<i64>(E, esprun::TILE);
@@ -1773,6 +1786,12 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
     a.mw_P = mw ? mw->P : 0;
     a.mw_nb = mw ? mw->nb : 0;
     a.mw_base = mw ? mw->d_base : nullptr;
+    if (raw) {
+        a.raw_rows = raw->rows, a.raw_cols = raw->cols;
+        a.raw_m = h->m, a.raw_n = h->n;
+        a.raw_rb = h->L.rb, a.raw_kind = raw->kind, a.raw_negate = raw->negate;
+        a.raw_err = raw->d_err;
+    }
     a.err = (u32 *)h->misc.p + 60;
     a.overflow = ca.overflow;
     a.runs_d = ca.runs_d;
@@ -1810,7 +1829,9 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
             HIPCK(h, hipMemsetAsync(bstart, 0, sizeof(u64) * (size_t)(NB + 1), h->stream));
         }
         Span sp(h, ESP_ST_HIST);
-        if (mw)
+        if (raw)
+            hipLaunchKernelGGL((esprun::run_hist_k<false, true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a, (i64)0);
+        else if (mw)
             hipLaunchKernelGGL((esprun::run_hist_k<true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a, (i64)0);
         else
             hipLaunchKernelGGL((esprun::run_hist_k<false>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a, (i64)0);
@@ -1836,13 +1857,17 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
         a.flags = flags;
         // 4-byte keys for the bucket kernel: one kind for all pending entries, <= 32 key bits below the prefix, no
         // further pass (force_path 14: packed keys always)
-        const bool k32 = allow_k32 && key_bytes_out && !mw && h->force_path != 14 && h->kind_uniform >= 0 &&
-                         h->kind_noted == h->count && a.shift <= 32;
+        const bool k32 = allow_k32 && key_bytes_out && !mw && h->force_path != 14 &&
+                         (raw || (h->kind_uniform >= 0 && h->kind_noted == h->count)) && a.shift <= 32;
         a.maxlen = d_maxlen;
         a.cap = esplocal::CAP;
         {
             Span sp(h, ESP_ST_SCATTER);
-            if (mw)
+            if (raw && k32)
+                hipLaunchKernelGGL((esprun::run_scatter_k<false, true, true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
+            else if (raw)
+                hipLaunchKernelGGL((esprun::run_scatter_k<false, false, true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
+            else if (mw)
                 hipLaunchKernelGGL((esprun::run_scatter_k<true, false>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
             else if (k32)
                 hipLaunchKernelGGL((esprun::run_scatter_k<false, true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
@@ -1946,7 +1971,9 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
     }
     {
         Span sp(h, ESP_ST_SCATTER);
-        if (mw)
+        if (raw)
+            hipLaunchKernelGGL((esprun::run_scatter_k<false, false, true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
+        else if (mw)
             hipLaunchKernelGGL((esprun::run_scatter_k<true, false>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
         else
             hipLaunchKernelGGL((esprun::run_scatter_k<false, false>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
@@ -1954,6 +1981,71 @@ static int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u
     }
     HIPCK(h, hipGetLastError());
     *ok = true;
+    return ESP_OK;
+}
+
+// esp_append_device / esp_append_host / esp_commit on an EMPTY buffer, all entries of one kind: the run-based single pass
+// (runpart.hpp) reads the caller's triplets directly -- a count pass over the columns, then one kernel that reads rows,
+// columns and values and stores key and value at their bucket position (4-byte keys when they fit).  What used to be
+// pack (24 B read, 16 B written) + histogram (8 B) + scatter (16 B + 12 B) per entry is 8 B + 24 B read, 12 B written,
+// and the flush starts at the bucket kernel (h->pre, as after a device-side producer).  *took = false: the stream is
+// no pre-sorted one (or the plan does not apply): nothing was appended, the caller packs in stream order.
+static int32_t append_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const double *d_vals, int kind, int op, i64 count,
+                                  bool *took) {
+    *took = false;
+    if (h->count != 0 || count <= esplocal::CAP || h->shard_user || h->runs_skip > 0) return ESP_OK;
+    // (test hooks that pin another path; 27: this one off)
+    if (h->force_path == 2 || h->force_path == 5 || h->force_path == 12 || h->force_path == 16 || h->force_path == 19 || h->force_path == 27)
+        return ESP_OK;
+    const int K = window_bits(h);
+    double Ee = 0.0;
+    const int pb = plan_prefix_bits(h, count, K, &Ee);
+    const int shift = K - pb;
+    if (pb <= 8 || pb > 20 || shift < h->L.rb || shift > esplocal::MAX_REM_BITS) return ESP_OK;
+    CK(reserve_append(h, count));
+    const i64 NB = (i64)1 << pb;
+    CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(NB + 1)));
+    CK(ensure(h, h->tilef[1], sizeof(u64) * (size_t)(NB + 1 + espscan::workspace_elems(NB + 1))));
+    CK(ensure(h, h->misc, 256));
+    unsigned long long *d_err = (unsigned long long *)h->misc.p;
+    h->pin_scalar[0] = ~0ull;
+    HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 8, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemsetAsync((unsigned long long *)h->misc.p + 24, 0, 64, h->stream));  // maxlen .. the four flag words (run_partition)
+    const RawSource raw{d_rows, d_cols, kind, (op == ESP_OP_SUB && kind != ESP_SET) ? 1 : 0, d_err};
+    bool tr = false, ok = false;
+    i64 ml = count;
+    int kb = 8;
+    CK(run_partition(h, nullptr, d_vals, (u64 *)h->keys.p, (double *)h->vals.p, K, pb, (i64 *)h->seg[1].p, (u64 *)h->tilef[1].p, &tr, &ok, &ml,
+                     nullptr, 0, /*allow_k32=*/true, &kb, count, &raw));
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (h->pin_scalar[0] != ~0ull)
+        FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
+             (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
+    if (!ok) {  // not a pre-sorted stream: neither this handle's appends nor its next flushes try again soon
+        h->runs_penalty = std::min(16, 2 * h->runs_penalty + 1);
+        h->runs_skip = h->runs_penalty + 1;
+        return ESP_OK;
+    }
+    h->runs_penalty = 0;
+    esp_handle::PrePart &pp = h->pre;
+    pp.K = K;
+    pp.pb = pb;
+    pp.maxlen = ml;
+    pp.key_bytes = kb;
+    pp.kind = kind;
+    pp.E = count;
+    pp.tail = 0;
+    pp.base = h->win_base;
+    pp.span = h->win_span;
+    pp.Ee = Ee;
+    pp.mw_P = 0, pp.mw_me = 0, pp.mw_shift = 0, pp.mw_nb = 0, pp.mw_eps = 0;
+    pp.own32 = false;
+    note_kind(h, kind, count);
+    h->count += count;
+    pending_changed(h);
+    h->pre.valid = true;
+    *took = true;
     return ESP_OK;
 }
 

@@ -65,6 +65,15 @@ struct Args {
     int mw_P;
     u32 mw_nb;
     const u64 *mw_base;
+    // raw source (esp_append_device / esp_append_host / esp_commit on an empty buffer: the append is the partition):
+    // raw_cols != nullptr -- the keys are formed on the fly from 1-based (row, col) arrays, every entry of the kind
+    // raw_kind, vals_in holds the caller's values (negated for op = SUB unless the kind is SET); nothing is read twice
+    // and the packed stream is never written: run_hist_k reads the columns (8 B per entry), run_scatter_k rows, columns
+    // and values (24 B) and stores key and value at their bucket position
+    const i64 *raw_rows = nullptr, *raw_cols = nullptr;
+    i64 raw_m = 0, raw_n = 0;
+    int raw_rb = 0, raw_kind = 0, raw_negate = 0;
+    unsigned long long *raw_err = nullptr;  // atomicMin(position + 1) of the first entry outside m x n (BoundsError)
 };
 constexpr int MW_MAX = 64;  // windows the MULTI kernels take
 
@@ -267,7 +276,7 @@ __device__ __forceinline__ void count_runs_weighted(const u32 (&dig)[NITEMS], co
     emit_run_table(chunk, sink, rd, rc, over);
 }
 
-template <bool MULTI>
+template <bool MULTI, bool RAW = false>
 __global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_chunk) {
     __shared__ u32 rd[RMAX];
     __shared__ u32 rc[RMAX];
@@ -287,10 +296,23 @@ __global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_chunk) {
     }
     if (t == 0) over = 0;
     u64 key[ITEMS];
+    if constexpr (RAW) {  // (the digit is a function of the column: row 0 stands in; a column outside the matrix is reported)
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        const i64 idx = beg + k * THREADS + t;
-        key[k] = idx < end ? a.keys_in[idx] : 0ull;
+        for (int k = 0; k < ITEMS; k++) {
+            const i64 idx = beg + k * THREADS + t;
+            i64 c = idx < end ? a.raw_cols[idx] : 1;
+            if (!(1 <= c && c <= a.raw_n)) {
+                atomicMin(a.raw_err, (unsigned long long)(idx + 1));
+                c = 1;
+            }
+            key[k] = ((u64)(c - 1) << a.raw_rb) << ESP_TAG_BITS;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const i64 idx = beg + k * THREADS + t;
+            key[k] = idx < end ? a.keys_in[idx] : 0ull;
+        }
     }
     if (give_up != 0u) return;
     __syncthreads();
@@ -454,7 +476,9 @@ __device__ __forceinline__ void rank_in_runs(u32 (&dig)[NI], const u32 *hd, cons
     }
 }
 
-template <bool MULTI, bool K32>
+// (tried for RAW: four workgroups per CU through __launch_bounds__ -- 128 VGPRs instead of the K32 store loop's 152 -- costs
+// 76 bytes of scratch per lane)
+template <bool MULTI, bool K32, bool RAW = false>
 __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
     __shared__ u64 s_mw[MULTI ? MW_MAX : 1];
     __shared__ u32 hd[RMAX];  // open-addressing map digit -> run index of this tile
@@ -478,15 +502,45 @@ __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
     u64 key[ITEMS];
     double val[ITEMS];
     const i64 wbase = beg + (i64)w * (ESP_WAVE * ITEMS) + lane;
+    if constexpr (RAW) {
+        // (see Args: the packed key of (row, col) of the one kind; indices outside the matrix are reported.  Columns and
+        // rows first, the values once the keys are formed: three arrays of 16 loads each in flight would cost the kernel
+        // a wave per SIMD)
+        {
+            i64 cc[ITEMS];
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        const i64 idx = wbase + k * ESP_WAVE;
-        key[k] = idx < end ? a.keys_in[idx] : 0ull;
-    }
+            for (int k = 0; k < ITEMS; k++) {
+                const i64 idx = wbase + k * ESP_WAVE;
+                cc[k] = idx < end ? a.raw_cols[idx] : 1;
+            }
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        const i64 idx = wbase + k * ESP_WAVE;
-        val[k] = idx < end ? a.vals_in[idx] : 0.0;
+            for (int k = 0; k < ITEMS; k++) {
+                const i64 idx = wbase + k * ESP_WAVE;
+                i64 r = idx < end ? a.raw_rows[idx] : 1;
+                if (!(1 <= cc[k] && cc[k] <= a.raw_n) || !(1 <= r && r <= a.raw_m)) {
+                    atomicMin(a.raw_err, (unsigned long long)(idx + 1));
+                    cc[k] = 1, r = 1;
+                }
+                key[k] = ((((u64)(cc[k] - 1) << a.raw_rb) | (u64)(r - 1)) << ESP_TAG_BITS) | (u64)a.raw_kind;
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const i64 idx = wbase + k * ESP_WAVE;
+            const double v = idx < end ? a.vals_in[idx] : 0.0;
+            val[k] = a.raw_negate ? -v : v;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const i64 idx = wbase + k * ESP_WAVE;
+            key[k] = idx < end ? a.keys_in[idx] : 0ull;
+        }
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const i64 idx = wbase + k * ESP_WAVE;
+            val[k] = idx < end ? a.vals_in[idx] : 0.0;
+        }
     }
     __syncthreads();
     const int nr = s_nr;
