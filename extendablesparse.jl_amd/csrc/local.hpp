@@ -78,8 +78,10 @@ static_assert(NetOf<24>::net.n == 132, "merge-exchange network for 24 inputs has
 // segment usually agree in a block of middle bits (rows near the diagonal: the high row bits), and a
 // digit may be put together from two runs of varying bits, so such a block costs no pass.  Returns the
 // number of passes (0: all entries share one (col,row); skey is not written then).
+// lowshift: the lowest key bit that takes part (SUB_SHIFT: the (col,row) bits, entries arrive in append order; ESP_TAG_BITS:
+// the slot index too -- entries may then arrive in any order)
 __device__ __forceinline__ int radix_tail(u64 (&k)[ITEMS], u64 *skey, u32 (*cnt)[256], u32 *lw, int rem_bits, int t, int lane,
-                                          int w, int wbase, int n, u64 *scratch /* 2*WAVES words */) {
+                                          int w, int wbase, int n, u64 *scratch /* 2*WAVES words */, int lowshift = SUB_SHIFT) {
     const u64 lt = (1ull << lane) - 1ull;
     // varying bits = AND ^ OR over the real entries
     u64 vand = ~0ull, vor = 0ull;
@@ -104,8 +106,8 @@ __device__ __forceinline__ int radix_tail(u64 (&k)[ITEMS], u64 *skey, u32 (*cnt)
         vand &= scratch[i];
         vor |= scratch[WAVES + i];
     }
-    const u64 sortmask = rem_bits >= 64 - SUB_SHIFT ? ~0ull : (((u64)1 << rem_bits) - 1ull);
-    u64 rest = ((vand ^ vor) >> SUB_SHIFT) & sortmask;  // bit j: key bit SUB_SHIFT + j varies
+    const u64 sortmask = rem_bits >= 64 - lowshift ? ~0ull : (((u64)1 << rem_bits) - 1ull);
+    u64 rest = ((vand ^ vor) >> lowshift) & sortmask;  // bit j: key bit lowshift + j varies
     int npass = 0;
     while (rest) {
         // a digit of up to 8 bits from the lowest one or two runs of varying bits (A below B)
@@ -120,7 +122,7 @@ __device__ __forceinline__ int radix_tail(u64 (&k)[ITEMS], u64 *skey, u32 (*cnt)
             bB = min(lenB, 8 - bA);
             rest &= ~((((u64)1 << bB) - 1ull) << sB);
         }
-        const int shA = SUB_SHIFT + sA, shB = SUB_SHIFT + sB;
+        const int shA = lowshift + sA, shB = lowshift + sB;
         const u32 mA = (1u << bA) - 1u, mB = (1u << bB) - 1u;
         npass++;
         for (int q = t; q < WAVES * 256; q += THREADS) (&cnt[0][0])[q] = 0;
@@ -1126,6 +1128,7 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 1] = wall_clock64();
 #endif
     bool done = n == 0;
+    bool refill = false;  // the group tier scattered the keys by column and gave up: the radix tier reads them back
     bool lb_done = false;  // the look-back was started by the last wave (early publication, see the register tier)
     LbState lbs;
     lb_init(lbs, 0);
@@ -1257,6 +1260,8 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
                         ESP_GROUP_GO(16);
 #undef ESP_GROUP_GO
                     done = true;
+                } else {
+                    refill = true;  // (the rows of the segment lie too far apart for 32-bit sort keys: radix tier)
                 }
             }
         } else if constexpr (SMALL) {
@@ -1291,7 +1296,15 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     if constexpr (!SMALL)
     if (!done) {
         // ---- radix tier (long runs / wide column ranges): stable LSD sort of all remaining bits
-        const int npass = radix_tail(k, skey, cnt, lw, a.rem_bits, t, lane, w, wbase, n, reinterpret_cast<u64 *>(s_win));
+        // (after the group tier's scatter the registers no longer hold the keys -- the tier needs them for its own 48 --:
+        // they come back from LDS in column order, and the sort takes the slot-index bits along to restore the append order)
+        if (refill) {
+#pragma unroll
+            for (int i = 0; i < ITEMS; i++) k[i] = wbase + i * ESP_WAVE < n ? skey[wbase + i * ESP_WAVE] : NOREC;
+            __syncthreads();
+        }
+        const int npass = radix_tail(k, skey, cnt, lw, refill ? a.rem_bits + IDX_BITS : a.rem_bits, t, lane, w, wbase, n,
+                                     reinterpret_cast<u64 *>(s_win), refill ? ESP_TAG_BITS : SUB_SHIFT);
         if (npass == 0) {
 #pragma unroll
             for (int i = 0; i < ITEMS; i++) skey[wbase + i * ESP_WAVE] = k[i];

@@ -1,0 +1,330 @@
+/*
+ * abi_host.c -- a plain C99 host of libesparse_hip.so (TEST INFRASTRUCTURE).
+ *
+ * Julia is not in this image, so extendablesparse.jl_amd/julia/ESparseHIP.jl has never run.  This program is the
+ * closest executable stand-in: it drives the C ABI of include/esparse_hip.h with exactly the call sequences the shim
+ * makes, from a language that is not Python and through the header itself (gcc -std=c99 -pedantic), and checks every
+ * result against an in-order accumulation done here in C (the semantics of test/test_assembly.jl:19-32):
+ *
+ *   A. esp_stage_begin / esp_commit chunk loop (ESparseHIP.jl: push! into the pinned chunk, one ccall per chunk) of a
+ *      7-point stencil stream with duplicates, flush!(ROUTED), esp_get_csc into caller-owned arrays, a second assembly
+ *      over the stored pattern (hits) with a few new positions;
+ *   B. the Generic wrapper's buffer-per-flush life cycle (genericextendablesparsematrixcsc.jl:31-37): esp_set_csc ->
+ *      esp_flush(PLUS) -> esp_get_csc -> esp_release_buffers, 200 times on ONE handle and 20 times with a fresh handle,
+ *      with the device's free memory (hipMemGetInfo, resolved with dlsym: no HIP headers here) returning to its level;
+ *   C. the group calls in the order of INTEGRATION.md section 3 (single rank, the library's own RCCL transport):
+ *      esp_group_unique_id -> esp_group_create -> appends -> esp_group_flush -> esp_group_nnz -> esp_group_get_csc.
+ *
+ * Exit code 0 and "abi_host: ok" on success; any mismatch prints what differs and exits 1.
+ * Built and run by tests/test_abi_host.py (compile-only without a GPU).
+ */
+#include <dlfcn.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "esparse_hip.h"
+
+#define CHECK(h, call)                                                                                   \
+    do {                                                                                                 \
+        int32_t rc_ = (call);                                                                            \
+        if (rc_ != ESP_OK) {                                                                             \
+            fprintf(stderr, "abi_host: %s -> %d (%s) at line %d\n", #call, (int)rc_, esp_last_error(h), __LINE__); \
+            exit(1);                                                                                     \
+        }                                                                                                \
+    } while (0)
+#define REQUIRE(cond, ...)                                      \
+    do {                                                        \
+        if (!(cond)) {                                          \
+            fprintf(stderr, "abi_host: line %d: ", __LINE__);   \
+            fprintf(stderr, __VA_ARGS__);                       \
+            fprintf(stderr, "\n");                              \
+            exit(1);                                            \
+        }                                                       \
+    } while (0)
+
+/* ---- a tiny host model: dense accumulation in call order (n is small) ------------------------------------------- */
+typedef struct {
+    int64_t n;
+    double *val;           /* n x n, column-major */
+    unsigned char *present;
+} dense_t;
+static dense_t dense_new(int64_t n) {
+    dense_t d;
+    d.n = n;
+    d.val = (double *)calloc((size_t)(n * n), sizeof(double));
+    d.present = (unsigned char *)calloc((size_t)(n * n), 1);
+    if (!d.val || !d.present) {
+        fprintf(stderr, "abi_host: out of memory\n");
+        exit(1);
+    }
+    return d;
+}
+static void dense_free(dense_t *d) {
+    free(d->val);
+    free(d->present);
+}
+/* updateindex!(A, +, v, i, j): sparsematrixlnk.jl:210-228 (nothing is created by a zero) */
+static void dense_update(dense_t *d, int64_t i, int64_t j, double v) {
+    size_t at = (size_t)((j - 1) * d->n + (i - 1));
+    if (!d->present[at]) {
+        if (v == 0.0) return;
+        d->present[at] = 1;
+        d->val[at] = 0.0 + v;
+    } else {
+        d->val[at] = d->val[at] + v;
+    }
+}
+/* csc + buffer (sparsematrixlnk.jl:363): the buffer's folded value meets the stored one, csc operand first */
+static void dense_plus(dense_t *d, int64_t i, int64_t j, double bufval) {
+    size_t at = (size_t)((j - 1) * d->n + (i - 1));
+    if (d->present[at]) {
+        d->val[at] = d->val[at] + bufval;
+    } else {
+        d->present[at] = 1;
+        d->val[at] = bufval;
+    }
+}
+static int64_t dense_nnz(const dense_t *d) {
+    int64_t z = 0, k;
+    for (k = 0; k < d->n * d->n; k++) z += d->present[k];
+    return z;
+}
+static void compare_csc(const dense_t *d, const int64_t *colptr, const int64_t *rowval, const double *nzval, int64_t nnz,
+                        const char *what) {
+    int64_t j, k, i;
+    REQUIRE(colptr[0] == 1, "%s: colptr[1] = %lld", what, (long long)colptr[0]);
+    REQUIRE(colptr[d->n] == nnz + 1, "%s: colptr[n+1] = %lld, nnz = %lld", what, (long long)colptr[d->n], (long long)nnz);
+    REQUIRE(nnz == dense_nnz(d), "%s: nnz %lld, expected %lld", what, (long long)nnz, (long long)dense_nnz(d));
+    for (j = 1; j <= d->n; j++) {
+        int64_t seen = 0;
+        REQUIRE(colptr[j] >= colptr[j - 1], "%s: colptr decreases at column %lld", what, (long long)j);
+        for (k = colptr[j - 1]; k < colptr[j]; k++) {
+            size_t at;
+            i = rowval[k - 1];
+            REQUIRE(i >= 1 && i <= d->n, "%s: row %lld in column %lld", what, (long long)i, (long long)j);
+            if (k > colptr[j - 1]) REQUIRE(rowval[k - 2] < i, "%s: rows of column %lld not strictly increasing", what, (long long)j);
+            at = (size_t)((j - 1) * d->n + (i - 1));
+            REQUIRE(d->present[at], "%s: (%lld,%lld) is stored but was never updated", what, (long long)i, (long long)j);
+            REQUIRE(memcmp(&d->val[at], &nzval[k - 1], sizeof(double)) == 0, "%s: value at (%lld,%lld): %.17g, expected %.17g", what,
+                    (long long)i, (long long)j, nzval[k - 1], d->val[at]);
+            seen++;
+        }
+        for (i = 1; i <= d->n; i++) seen -= d->present[(size_t)((j - 1) * d->n + (i - 1))];
+        REQUIRE(seen == 0, "%s: column %lld misses entries", what, (long long)j);
+    }
+}
+
+/* ---- the staged chunk of the shim ------------------------------------------------------------------------------- */
+typedef struct {
+    esp_handle *h;
+    int64_t *rows, *cols;
+    double *vals;
+    uint8_t *kinds;
+    int64_t cap, fill;
+} stage_t;
+static void stage_open(stage_t *s, esp_handle *h) {
+    s->h = h;
+    s->fill = 0;
+    CHECK(h, esp_stage_begin(h, 1 << 12, &s->rows, &s->cols, &s->vals, &s->kinds, &s->cap));
+    REQUIRE(s->cap >= 1, "stage capacity %lld", (long long)s->cap);
+}
+static void stage_commit(stage_t *s) {
+    if (s->fill) CHECK(s->h, esp_commit(s->h, s->fill, -1, ESP_OP_ADD));
+    s->fill = 0;
+}
+static void stage_push(stage_t *s, int kind, double v, int64_t i, int64_t j) {
+    s->rows[s->fill] = i;
+    s->cols[s->fill] = j;
+    s->vals[s->fill] = v;
+    s->kinds[s->fill] = (uint8_t)kind;
+    if (++s->fill == s->cap) stage_commit(s);
+}
+
+static double lcg(uint64_t *st) {
+    *st = *st * 6364136223846793005ull + 1442695040888963407ull;
+    return (double)(*st >> 11) * (1.0 / 9007199254740992.0);
+}
+
+/* the 7-point stencil stream of fdrand! (sprand.jl:87-124) on an q x q x q grid, values from the generator above */
+static void stencil_stream(int q, uint64_t seed, stage_t *st, dense_t *d) {
+    int64_t i, j, k, dirs[3];
+    uint64_t rng = seed;
+    dirs[0] = 1;
+    dirs[1] = q;
+    dirs[2] = (int64_t)q * q;
+    for (k = 0; k < q; k++)
+        for (j = 0; j < q; j++)
+            for (i = 0; i < q; i++) {
+                int64_t l = 1 + i + q * (j + (int64_t)q * k), c[3];
+                int a;
+                c[0] = i, c[1] = j, c[2] = k;
+                for (a = 0; a < 3; a++) {
+                    if (c[a] < q - 1) { /* update_pair: sprand.jl:87-92 */
+                        double v = 0.1 + lcg(&rng);
+                        int64_t l2 = l + dirs[a];
+                        stage_push(st, ESP_UPDATE, -v, l, l2), dense_update(d, l, l2, -v);
+                        stage_push(st, ESP_UPDATE, -v, l2, l), dense_update(d, l2, l, -v);
+                        stage_push(st, ESP_UPDATE, v, l, l), dense_update(d, l, l, v);
+                        stage_push(st, ESP_UPDATE, v, l2, l2), dense_update(d, l2, l2, v);
+                    }
+                    if (c[a] == 0 || c[a] == q - 1) {
+                        double v = 0.1 + lcg(&rng);
+                        stage_push(st, ESP_UPDATE, v, l, l), dense_update(d, l, l, v);
+                    }
+                }
+            }
+}
+
+typedef int (*mem_info_fn)(size_t *, size_t *);
+static size_t device_free_bytes(mem_info_fn f) {
+    size_t fr = 0, tot = 0;
+    if (!f || f(&fr, &tot) != 0) return 0;
+    return fr;
+}
+
+int main(void) {
+    const int q = 9; /* 729 unknowns: the dense model stays small */
+    const int64_t n = (int64_t)q * q * q;
+    esp_handle *h = NULL;
+    int64_t nnz = 0, *colptr, *rowval;
+    int32_t changed = 0;
+    double *nzval;
+    dense_t D = dense_new(n);
+    stage_t st;
+    int64_t m_, n_;
+    int rep;
+
+    /* ---------------------------------------------------------------- A: staged chunks, flush!, get_csc, re-assembly */
+    CHECK(NULL, esp_create(n, n, 0, 0, &h));
+    CHECK(h, esp_size(h, &m_, &n_));
+    REQUIRE(m_ == n && n_ == n, "esp_size");
+    stage_open(&st, h);
+    stencil_stream(q, 1u, &st, &D);
+    stage_commit(&st);
+    CHECK(h, esp_pending(h, &nnz));
+    REQUIRE(nnz > 0, "pending entries after the commits");
+    CHECK(h, esp_flush(h, ESP_FLUSH_ROUTED, &nnz, &changed));
+    REQUIRE(changed == 1, "the first flush! builds the pattern");
+    colptr = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1));
+    rowval = (int64_t *)malloc(sizeof(int64_t) * (size_t)(nnz + 64));
+    nzval = (double *)malloc(sizeof(double) * (size_t)(nnz + 64));
+    CHECK(h, esp_get_csc(h, colptr, rowval, nzval));
+    compare_csc(&D, colptr, rowval, nzval, nnz, "A: fresh assembly");
+    /* second assembly: every update hits the stored pattern (applied in place, no rebuild) ... */
+    stencil_stream(q, 2u, &st, &D);
+    stage_commit(&st);
+    CHECK(h, esp_flush(h, ESP_FLUSH_ROUTED, &nnz, &changed));
+    REQUIRE(changed == 0, "a re-assembly of hits must not rebuild the pattern");
+    CHECK(h, esp_get_csc(h, colptr, rowval, nzval));
+    compare_csc(&D, colptr, rowval, nzval, nnz, "A: re-assembly");
+    /* ... then a few new couplings (and a zero update, which creates nothing) */
+    stage_push(&st, ESP_UPDATE, 2.5, 1, n), dense_update(&D, 1, n, 2.5);
+    stage_push(&st, ESP_UPDATE, -1.25, n, 1), dense_update(&D, n, 1, -1.25);
+    stage_push(&st, ESP_UPDATE, 0.0, 2, n), dense_update(&D, 2, n, 0.0);
+    stage_commit(&st);
+    CHECK(h, esp_flush(h, ESP_FLUSH_ROUTED, &nnz, &changed));
+    REQUIRE(changed == 1, "new positions rebuild the pattern");
+    CHECK(h, esp_get_csc(h, colptr, rowval, nzval));
+    compare_csc(&D, colptr, rowval, nzval, nnz, "A: new couplings");
+    /* out-of-range index: BoundsError, nothing appended */
+    stage_push(&st, ESP_UPDATE, 1.0, n + 1, 1);
+    REQUIRE(esp_commit(h, st.fill, -1, ESP_OP_ADD) == ESP_ERR_BOUNDS, "an index outside the matrix must be refused");
+    st.fill = 0;
+    CHECK(h, esp_pending(h, &m_));
+    REQUIRE(m_ == 0, "a refused chunk leaves nothing pending");
+
+    /* ---------------------------------------------------------------- B: csc + buffer, 200 buffer life cycles */
+    {
+        void *hip = dlopen("libamdhip64.so", RTLD_NOW | RTLD_GLOBAL);
+        mem_info_fn mem_info = (mem_info_fn)0;
+        if (hip) { /* (POSIX's way around ISO C's missing object-to-function pointer conversion) */
+            void *sym = dlsym(hip, "hipMemGetInfo");
+            memcpy(&mem_info, &sym, sizeof sym);
+        }
+        size_t base_free = 0, low_free = (size_t)-1;
+        esp_handle *x = NULL;
+        int64_t z = 0;
+        CHECK(NULL, esp_create(n, n, 0, 0, &x));
+        for (rep = 0; rep < 200; rep++) {
+            int64_t i = 1 + (rep * 37) % n, j = 1 + (rep * 101) % n;
+            CHECK(x, esp_set_csc(x, colptr, rowval, nzval, nnz)); /* the wrapper's cscmatrix */
+            stage_open(&st, x);
+            stage_push(&st, ESP_RAWUPDATE, 1.0 + rep, i, j);
+            stage_push(&st, ESP_RAWUPDATE, 0.5, i, j);
+            dense_plus(&D, i, j, (0.0 + (1.0 + rep)) + 0.5); /* the buffer folds by itself first (rawupdateindex!: 0 + v, then + v) */
+            stage_commit(&st);
+            CHECK(x, esp_flush(x, ESP_FLUSH_PLUS, &z, &changed)); /* csc = x + csc */
+            if (z > nnz) {
+                rowval = (int64_t *)realloc(rowval, sizeof(int64_t) * (size_t)(z + 64));
+                nzval = (double *)realloc(nzval, sizeof(double) * (size_t)(z + 64));
+            }
+            nnz = z;
+            CHECK(x, esp_get_csc(x, colptr, rowval, nzval));
+            CHECK(x, esp_release_buffers(x)); /* x = Tm(m,n): the old buffer is dropped NOW */
+            if (rep == 3) base_free = device_free_bytes(mem_info);
+            if (rep > 3) {
+                size_t f = device_free_bytes(mem_info);
+                if (f < low_free) low_free = f;
+            }
+        }
+        compare_csc(&D, colptr, rowval, nzval, nnz, "B: 200 x (csc + buffer)");
+        if (mem_info)
+            REQUIRE(base_free - low_free < ((size_t)64 << 20), "device memory creeps: %zu bytes free after 3 cycles, %zu at the lowest",
+                    base_free, low_free);
+        CHECK(x, esp_destroy(x));
+        for (rep = 0; rep < 20; rep++) { /* a fresh handle per flush (the shim before it reused one) */
+            CHECK(NULL, esp_create(n, n, 0, 0, &x));
+            CHECK(x, esp_set_csc(x, colptr, rowval, nzval, nnz));
+            CHECK(x, esp_flush(x, ESP_FLUSH_PLUS, &z, &changed)); /* nothing pending: the flush! gate */
+            REQUIRE(z == nnz && changed == 0, "an empty buffer leaves the CSC alone");
+            CHECK(x, esp_destroy(x));
+        }
+        if (mem_info) {
+            size_t f = device_free_bytes(mem_info);
+            REQUIRE(base_free <= f + ((size_t)64 << 20), "handles leak device memory: %zu -> %zu bytes free", base_free, f);
+        }
+    }
+
+    /* ---------------------------------------------------------------- C: the group calls of INTEGRATION.md section 3 */
+    {
+        uint8_t id[128];
+        esp_handle *hs = NULL, *back = NULL;
+        esp_group *g = NULL;
+        int64_t lo = 0, hi = 0, z = 0, gz = 0, before = 0, *cp2;
+        dense_t E = dense_new(n);
+        CHECK(NULL, esp_group_unique_id(id));
+        CHECK(NULL, esp_create(n, n, 0, 0, &hs));
+        CHECK(hs, esp_group_create(hs, 1, 0, id, &g));
+        CHECK(hs, esp_group_handle(g, &back));
+        REQUIRE(back == hs, "esp_group_handle");
+        CHECK(hs, esp_group_column_range(g, &lo, &hi));
+        REQUIRE(lo == 1 && hi == n, "column range of the only rank");
+        stage_open(&st, hs);
+        stencil_stream(q, 3u, &st, &E);
+        stage_commit(&st);
+        CHECK(hs, esp_group_flush(g, ESP_FLUSH_ROUTED, &z, &changed));
+        CHECK(hs, esp_group_nnz(g, &gz, &before));
+        REQUIRE(gz == z && before == 0, "global nnz of a single rank");
+        cp2 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(hi - lo + 2));
+        if (z > nnz) {
+            rowval = (int64_t *)realloc(rowval, sizeof(int64_t) * (size_t)(z + 64));
+            nzval = (double *)realloc(nzval, sizeof(double) * (size_t)(z + 64));
+        }
+        CHECK(hs, esp_group_get_csc(g, cp2, rowval, nzval));
+        compare_csc(&E, cp2, rowval, nzval, z, "C: group flush");
+        free(cp2);
+        CHECK(hs, esp_group_destroy(g));
+        CHECK(hs, esp_destroy(hs));
+        dense_free(&E);
+    }
+
+    CHECK(h, esp_destroy(h));
+    free(colptr);
+    free(rowval);
+    free(nzval);
+    dense_free(&D);
+    printf("abi_host: ok (%s)\n", esp_version());
+    return 0;
+}
