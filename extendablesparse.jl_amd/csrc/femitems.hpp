@@ -39,7 +39,7 @@ struct Args {
     double *vals_out;
 };
 
-__global__ __launch_bounds__(THREADS) void fem_items_k(Args a) {
+static __global__ __launch_bounds__(THREADS) void fem_items_k(Args a) {
     const i64 pos = (i64)blockIdx.x * THREADS + threadIdx.x;
     if (pos >= a.fem.ncells) return;
     i64 vx[4][3];
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(THREADS) void fem_items_k(Args a) {
 
 // K32: 4-byte keys (the bits below the segment prefix; every entry is a RAWUPDATE), else packed keys
 template <bool K32>
-__global__ __launch_bounds__(THREADS) void fem_expand_k(Args a) {
+static __global__ __launch_bounds__(THREADS) void fem_expand_k(Args a) {
     typedef typename std::conditional<K32, u32, u64>::type KT;
     __shared__ KT lk[THREADS * MAX_W];
     __shared__ double lv[THREADS * MAX_W];
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(THREADS) void fem_expand_k(Args a) {
 }
 
 // entries = items * (dim + 2): the segment table of the append buffer from the items'
-__global__ void scale_segments_k(const i64 *__restrict__ in, i64 n, i64 w, i64 *__restrict__ out) {
+static __global__ void scale_segments_k(const i64 *__restrict__ in, i64 n, i64 w, i64 *__restrict__ out) {
     const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (g < n) out[g] = in[g] * w;
 }

@@ -1,0 +1,662 @@
+// flush.hip -- libesparse_hip: esp_flush and what it drives (see internal.hpp for the map of the translation units)
+#include "internal.hpp"
+
+bool esplocal::launch(const Variant &v, unsigned grid, hipStream_t stream, const Args &a) {
+    if (v.pieces) return v.small_variant ? launch_pieces_small(v, grid, stream, a) : v.fresh ? launch_pieces_fresh(v, grid, stream, a) : launch_pieces_stored(v, grid, stream, a);
+    return v.small_variant ? launch_small(v, grid, stream, a) : launch_regular(v, grid, stream, a);
+}
+
+
+// colend (u64, n+1, zero-initialised, filled with column ends) -> colptr; merges with the old
+// CSC when there is one.  New entries are in h->newkey/h->newval (Z0>0) or already in
+// h->rowval/h->nzval (Z0==0).
+int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn, const u64 *new_key, const double *new_val) {
+    const i64 N1 = h->n + 1;
+    u64 *colend = (u64 *)h->colend.p;
+    i64 c0, ccnt;  // the columns this flush can have touched (a shard's window, else all)
+    col_range(h, &c0, &ccnt);
+    if (windowed(h)) h->tail_stale = h->wc1 < h->n;
+    if (Z0 == 0) {
+        // colptr = 1 + exclusive max-scan of the column ends, written by the scan's last pass
+        Span sp(h, ESP_ST_COLPTR);
+        sp.add(espscan::exclusive<u64, true>(h->stream, colend + c0, (u64 *)h->colptr.p + c0, ccnt, colend + N1, (u64)1));
+        if (!windowed(h)) h->ones_pending = false;  // (every entry of colptr was written)
+        h->nnz = Zn;
+        h->pattern_version++, h->values_version++;
+        return ESP_OK;
+    }
+    const i64 Zt = Z0 + Zn;
+    {
+        Span sp(h, ESP_ST_COLPTR);
+        sp.add(espscan::exclusive<u64, true>(h->stream, colend + c0, colend + c0, ccnt, colend + N1));
+    }
+    CK(ensure(h, h->rowval2, sizeof(i64) * (size_t)Zt));
+    CK(ensure(h, h->nzval2, sizeof(double) * (size_t)Zt));
+    if (h->force_path == ESP_PATH_MERGE_PATH_JOIN) {
+        // (test hook: the merge-path join over a per-entry column array, kept as a second implementation of the same join)
+        if (Z0 >= 0xFFFFFFF0ll) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_flush: CSC too large for the 32-bit column index");
+        {
+            Span sp(h, ESP_ST_COLPTR);
+            const i64 hn = Z0 + 1;  // column index of every stored entry
+            CK(ensure(h, h->heads, sizeof(u32) * (size_t)(hn + espscan::workspace_elems(hn))));
+            u32 *heads = (u32 *)h->heads.p;
+            HIPCK(h, hipMemsetAsync(heads, 0, sizeof(u32) * (size_t)hn, h->stream));
+            hipLaunchKernelGGL(espfold::col_heads_k, dim3(grid_for(ccnt - 1, 256)), dim3(256), 0, h->stream, (const i64 *)h->colptr.p, c0, ccnt - 1,
+                               heads);
+            sp.add(1 + espscan::exclusive<u32, true>(h->stream, heads, heads, hn, heads + hn));
+        }
+        Span sp(h, ESP_ST_MERGE);
+        espmerge::Args a;
+        a.old_col = (const u32 *)h->heads.p + 1;
+        a.old_row = (const i64 *)h->rowval.p;
+        a.old_val = (const double *)h->nzval.p;
+        a.Z0 = Z0;
+        a.new_key = new_key;
+        a.new_val = new_val;
+        a.Zn = Zn;
+        a.rb = h->L.rb;
+        a.out_row = (i64 *)h->rowval2.p;
+        a.out_val = (double *)h->nzval2.p;
+        hipLaunchKernelGGL(espmerge::merge_k, dim3(grid_for(Zt, espmerge::TILE)), dim3(espmerge::THREADS), 0, h->stream, a);
+        sp.add(1);
+    } else {
+        // column-tiled join: every stored and every new entry finds its own place in its merged column.  The stored
+        // entries outside the flush's column range (a shard's window) keep their order: in front of the range they
+        // stay where they are, behind it they move up by Zn.
+        Span sp(h, ESP_ST_MERGE);
+        const i64 ncols = ccnt - 1;
+        if (windowed(h)) {
+            // (win_excl: nothing is stored outside the window)
+        } else if (c0 != 0 || ncols != h->n) {
+            FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (column range of the join)");
+        }
+        espmerge::ColArgs a;
+        a.old_colptr = (const i64 *)h->colptr.p;
+        a.old_row = (const i64 *)h->rowval.p;
+        a.old_val = (const double *)h->nzval.p;
+        a.newstart = (const u64 *)colend;
+        a.new_key = new_key;
+        a.new_val = new_val;
+        a.rb = h->L.rb;
+        a.c_begin = c0;
+        a.ncols = ncols;
+        a.out_row = (i64 *)h->rowval2.p;
+        a.out_val = (double *)h->nzval2.p;
+        hipLaunchKernelGGL(espmerge::colmerge_k, dim3(grid_for(ncols, espmerge::CT)), dim3(espmerge::THREADS), 0, h->stream, a);
+        sp.add(1);
+    }
+    {
+        Span sp(h, ESP_ST_COLPTR);
+        hipLaunchKernelGGL(espfold::colptr_finish_k, dim3(grid_for(ccnt, 256)), dim3(256), 0, h->stream, (const u64 *)colend + c0,
+                           (const i64 *)h->colptr.p + c0, ccnt, (i64 *)h->colptr.p + c0);
+        sp.add(1);
+    }
+    std::swap(h->rowval, h->rowval2);
+    std::swap(h->nzval, h->nzval2);
+    h->nnz = Zt;
+    h->pattern_version++, h->values_version++;
+    return ESP_OK;
+}
+
+int32_t prepare_outputs(esp_handle *h, i64 Z0, i64 Zn) {
+    const i64 N1 = h->n + 1;
+    CK(ensure(h, h->colend, sizeof(u64) * (size_t)(N1 + espscan::workspace_elems(N1))));
+    HIPCK(h, hipMemsetAsync(h->colend.p, 0, sizeof(u64) * (size_t)N1, h->stream));
+    if (Z0 == 0) {
+        CK(ensure(h, h->rowval, sizeof(i64) * (size_t)Zn));
+        CK(ensure(h, h->nzval, sizeof(double) * (size_t)Zn));
+    } else {
+        CK(ensure(h, h->newkey, sizeof(u64) * (size_t)Zn));
+        CK(ensure(h, h->newval, sizeof(double) * (size_t)Zn));
+    }
+    return ESP_OK;
+}
+
+// fast path: LDS bucket kernel over the MSD segments; writes the final arrays itself
+int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
+    const i64 Z0 = h->nnz;
+    const i64 N1 = h->n + 1;
+    // Segments behind the last column hold nothing (a matrix of 10^7 columns fills 60 % of the 2^24 its column bits span:
+    // 40 % of the segments, each of which would still draw a ticket, resolve its offset and leave): the launch ends at
+    // the segment of the last column; that segment checks that every entry lies in front of its end (Args::total).
+    int S = st.S;
+    i64 total_check = -1;
+    if (st.npieces == 0 && st.total >= 0 && st.seg_start && st.rem_bits >= h->L.rb && st.rem_bits - h->L.rb < 40 && S > 1) {
+        const int clb0 = st.rem_bits - h->L.rb;
+        // (the segments cut the key window: its first column, and the column behind its last)
+        const i64 c_first = (i64)(h->win_base >> h->L.rb), c_last = (i64)((h->win_base + h->win_span) >> h->L.rb);
+        const i64 need = ceil_div<i64>(c_last - c_first, (i64)1 << clb0);
+        if (need >= 1 && need < (i64)S) {
+            S = (int)need;
+            total_check = st.total;
+        }
+    }
+    // esp_flush normalised the buffers: data in keys/vals, scratch pair = keys2/vals2
+    u64 *tk = (u64 *)h->keys2.p;
+    double *tv = (double *)h->vals2.p;
+    // look-back granules: one per segment | ticket, error flag | longest run | one per group of 64 segments
+    // (cleared as a multiple of 256 bytes: the runtime splits an odd-sized memset into two launches)
+    const i64 G = ((((i64)S + 63) / 64 + 1 + S + 2 + 31) & ~(i64)31) - (S + 2);
+    CK(ensure(h, h->segout, sizeof(u64) * (size_t)(S + 4 + G)));
+    u64 *status = (u64 *)h->segout.p;
+    HIPCK(h, hipMemsetAsync(status, 0, sizeof(u64) * (size_t)(S + 2 + G), h->stream));
+    CK(ensure(h, h->colend, sizeof(u64) * (size_t)(N1 + espscan::workspace_elems(N1))));
+    esplocal::Args a;
+    const char *stop_env = getenv("ESP_LOCAL_STOP");
+    // A fresh matrix whose segments are whole blocks of <= CL_MAX columns that start at the first column of the
+    // range this flush can touch (all columns, or the column window of a shard) and cover it: every segment writes
+    // the colptr of its own columns (no column-end marks, no memset and no scan over the columns).
+    // force_path 13: marks + scan.
+    bool direct = false;
+    const i64 col_begin = windowed(h) ? h->wc0 : 0, col_end = windowed(h) ? h->wc1 : h->n;
+    {
+        const int clb = st.rem_bits - h->L.rb;
+        const u64 seg_base = st.has_base ? st.base : st.npieces > 0 ? h->part_base : h->win_base;
+        direct = Z0 == 0 && clb >= 0 && clb <= esplocal::CL_MAX_BITS && h->force_path != ESP_PATH_RADIX_TAIL_ONLY && h->force_path != ESP_PATH_COLPTR_BY_SCAN && !stop_env &&
+                 seg_base == ((u64)col_begin << h->L.rb) && col_begin + ((i64)S << clb) >= col_end;
+    }
+    h->last_colptr_direct = direct ? 1 : 0;
+    if (!direct) {
+        i64 c0, cnt;
+        col_range(h, &c0, &cnt);
+        HIPCK(h, hipMemsetAsync((u64 *)h->colend.p + c0, 0, sizeof(u64) * (size_t)cnt, h->stream));
+    }
+    // (a failed flush must not leave a half-written colptr behind)
+    auto restore_colptr = [&]() {
+        if (direct) {
+            hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(N1, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p, N1, (i64)1);
+            h->tail_stale = false;
+            h->ones_pending = false;
+        }
+    };
+    // The small variant of the bucket kernel (3 workgroups per CU) serves segments of at most 3072 entries over at most
+    // 256 columns whose column runs the register tiers take; a segment with longer runs (it cannot know before it counts)
+    // goes through the variant's slow tier, and what it reports sends the next flushes to the regular kernel.
+    // force_path 18: never.
+    bool small_variant = false;
+    {
+        const int clb = st.rem_bits - h->L.rb;
+        // (what the handle's last flush saw decides; a handle without history tries it when the columns hold few entries
+        // on average -- a stencil's 12, not a 3-D FEM mesh's 120)
+        const double per_col = (double)h->count / (double)std::max<i64>(col_end - col_begin, 1);
+        // (runs of 17..24 want the 24-input network, which does not fit the variant's 80 registers: measured 4.7 against
+        // 4.0 ms on 2-D FEM)
+        const bool runs_fit = h->seen_maxrun > 0 ? h->seen_maxrun <= 16 : per_col <= 16.0;
+        small_variant = st.maxlen <= 6 * esplocal::THREADS && clb >= 0 && clb <= 8 &&
+                        st.rem_bits <= esplocal::REG_MAX_REM && runs_fit && h->force_path != ESP_PATH_RADIX_TAIL_ONLY &&
+                        h->force_path != ESP_PATH_NO_SMALL_VARIANT && !stop_env;
+    }
+    h->last_local_small = small_variant ? 1 : 0;
+    {
+        Span sp(h, ESP_ST_LOCAL);
+        a.kind32 = (u32)((st.key_bytes == 4 || st.p32_piece >= 0 || st.all32) ? st.kind : 0);
+        a.k32_piece = st.p32_piece;
+        a.k32_lo = st.p32_lo;
+        h->last_key_bytes = (st.p32_piece >= 0 || st.all32) ? 4 : st.key_bytes;
+        a.colptr_out = direct ? (i64 *)h->colptr.p : nullptr;
+        a.no_group = h->force_path == ESP_PATH_NO_GROUP_TIER ? 1 : 0;  // 24: test hook, long column runs through the radix tier
+        // (every pending entry was noted with one kind; pieces of other ranks carry kinds this handle has not seen)
+        a.kind_all = (st.npieces == 0 && h->kind_uniform >= 0 && h->kind_noted == h->count && h->force_path != ESP_PATH_GENERIC_FOLD) ? h->kind_uniform : -1;
+        a.col_end = col_end;
+        a.n_cols = h->n;
+        a.keys_in = st.sk;
+        a.vals_in = st.sv;
+        a.seg_start = st.seg_start;
+        a.S = S;
+        a.rem_bits = st.rem_bits;
+        a.base = st.has_base ? st.base : st.npieces > 0 ? h->part_base : h->win_base;
+        a.rb = h->L.rb;
+        {
+            const int clb = st.rem_bits - h->L.rb;
+            a.cl_bits = (clb >= 0 && clb <= esplocal::CL_MAX_BITS && h->force_path != ESP_PATH_RADIX_TAIL_ONLY) ? clb : -1;
+        }
+        // a segment is a whole number of columns when the prefix does not reach into the row bits
+        a.col_aligned = st.rem_bits >= h->L.rb ? 1 : 0;
+        a.csc = espfold::Csc{(const i64 *)h->colptr.p, (const i64 *)h->rowval.p, (double *)h->nzval.p, Z0};
+        a.mode = mode;
+        a.out_row = (i64 *)tk;
+        a.out_key = tk;
+        a.out_val = tv;
+        a.colend = (u64 *)h->colend.p;
+        a.status = status;
+        a.gstatus = status + S + 2;
+        a.npieces = st.npieces;
+        a.total = total_check;
+        a.pstart = st.pstart;
+        a.ptab = st.ptab;
+        a.ticket = (u32 *)(status + S);
+        a.err = (u32 *)(status + S) + 1;
+        a.maxrun_seen = (u32 *)(status + S) + 2;  // (zeroed with the granules)
+        {
+            a.stop_after = stop_env ? atoi(stop_env) : 0;
+            a.stamps = nullptr;
+            if (getenv("ESP_LOCAL_STAMPS")) {  // diagnostics: per-segment phase stamps, dumped to a file
+                CK(ensure(h, h->heads, sizeof(u64) * (size_t)S * 16));
+                HIPCK(h, hipMemsetAsync(h->heads.p, 0, sizeof(u64) * (size_t)S * 16, h->stream));
+                a.stamps = (unsigned long long *)h->heads.p;
+            }
+        }
+        const i64 max_grid = h->force_path == ESP_PATH_MANY_LAUNCHES ? 64 : esplocal::MAX_GRID;  // 4: test hook, many launches
+        for (i64 first = 0; first < S; first += max_grid) {
+            const unsigned grid = (unsigned)std::min<i64>(max_grid, S - first);
+            a.first = first;
+            // (the variant with the 24-input register tier for a matrix whose last flush met such runs)
+            const bool big = h->seen_maxrun > 16 && h->seen_maxrun <= esplocal::REG_RUN && h->force_path != ESP_PATH_NO_BIG_VARIANT;  // (26: test hook, runs of 17..24 through the group tier)
+            // (key format: 0 packed, 1 four-byte keys of one kind, 2 four-byte keys that are all UPDATEs)
+            // (3: packed keys whose kinds are all UPDATE -- the pieces of a shard)
+            // (4 / 5: pieces of which one -- a shard's own range -- holds 4-byte keys; 5: everything is an UPDATE)
+            // (6 / 7: pieces that all hold 4-byte keys of one kind -- a producer's batch and its tail; 7: UPDATE)
+            const int keys = st.npieces > 0 ? (st.all32 ? (st.kind == ESP_UPDATE && h->force_path != ESP_PATH_GENERIC_FOLD ? 7 : 6)
+                                               : st.p32_piece >= 0 ? (st.all_update && h->force_path != ESP_PATH_GENERIC_FOLD ? 5 : 4)
+                                                                   : (st.all_update && h->force_path != ESP_PATH_GENERIC_FOLD ? 3 : 0))
+                                            : st.key_bytes != 4 ? 0 : (st.kind == ESP_UPDATE && h->force_path != ESP_PATH_GENERIC_FOLD ? 2 : 1);
+            h->last_fold_update = keys >= 2 ? 1 : 0;
+            // (the instantiations live in local_*.hip)
+            const esplocal::Variant var{Z0 == 0, st.npieces > 0, big && !small_variant, small_variant, keys};
+            if (!esplocal::launch(var, grid, h->stream, a)) FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (no bucket kernel for this flush)");
+        }
+        sp.add(1);
+    }
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (S - 1), 24, hipMemcpyDeviceToHost, h->stream));  // last granule | ticket, err | maxrun
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar + 3, (u32 *)h->misc.p + 60, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+
+    if ((u32)h->pin_scalar[3]) {
+        restore_colptr();
+        FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window");
+    }
+    if (a.stamps) {
+        std::vector<u64> st((size_t)S * 16);
+        HIPCK(h, hipMemcpy(st.data(), a.stamps, sizeof(u64) * st.size(), hipMemcpyDeviceToHost));
+        if (FILE *f = fopen(getenv("ESP_LOCAL_STAMPS"), "wb")) {
+            fwrite(st.data(), sizeof(u64), st.size(), f);
+            fclose(f);
+        }
+    }
+    if (direct && !windowed(h)) h->ones_pending = false;  // (the bucket kernel wrote every entry of colptr)
+    const u32 lookback_err = (u32)(h->pin_scalar[1] >> 32);
+    h->seen_maxrun = (int)(u32)(h->pin_scalar[2] >> 0 & 0xFFFFFFFFull);
+    if (lookback_err & 7u) restore_colptr();
+    if (lookback_err & 2u) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (bucket)");
+    if (lookback_err & 1u) FAIL(h, ESP_ERR_HIP, "esp_flush: look-back chain timed out inside the bucket kernel");
+    if (lookback_err & 4u) FAIL(h, ESP_ERR_HIP, "esp_flush: internal error (early segment total differs from the folded total)");
+    const i64 Zn = (i64)(h->pin_scalar[0] & esplocal::ST_VAL);
+    *Zn_out = Zn;
+    if (a.stop_after || Zn == 0) return ESP_OK;
+    if (Z0 == 0) {
+        // the scratch pair now holds rowval/nzval: rotate the buffers instead of copying.  The old
+        // (empty) CSC arrays become the next flush's scratch pair: bring them to the same capacity
+        // once, so that the rotation never shrinks the scratch pair (a 10 GB hipMalloc per flush
+        // costs more than the flush itself)
+        CK(ensure(h, h->rowval, h->keys2.bytes));
+        CK(ensure(h, h->nzval, h->vals2.bytes));
+        std::swap(h->rowval, h->keys2);
+        std::swap(h->nzval, h->vals2);
+        if (direct) {  // colptr is complete (behind a column window it is refreshed lazily, as after the scan)
+            if (windowed(h)) h->tail_stale = h->wc1 < h->n;
+            h->nnz = Zn;
+            h->pattern_version++, h->values_version++;
+            return ESP_OK;
+        }
+        return finish_csc(h, 0, Zn, nullptr, nullptr);
+    }
+    return finish_csc(h, Z0, Zn, (const u64 *)tk, (const double *)tv);
+}
+
+// general path: finish with a full stable LSD sort and the global fold (any run length)
+int32_t flush_global(esp_handle *h, int mode, i64 *Zn_out) {
+    const i64 E = h->count;
+    const i64 Z0 = h->nnz;
+    const u64 *sk;
+    const double *sv;
+    CK(sort_pending_lsd(h, &sk, &sv));  // sorted data now in h->keys/h->vals; keys2/vals2 are scratch
+    u32 *flag = (u32 *)h->vals2.p;        // E+1 u32 fits in E doubles (E>=1)
+    double *fval = (double *)h->keys2.p;  // E doubles
+    espfold::Csc csc{(const i64 *)h->colptr.p, (const i64 *)h->rowval.p, (double *)h->nzval.p, Z0};
+    {
+        Span sp(h, ESP_ST_FOLD);
+        hipLaunchKernelGGL(espfold::fold_k, dim3(grid_for(E + 1, espfold::THREADS)), dim3(espfold::THREADS), 0, h->stream, sk, sv, E,
+                           csc, h->L.rb, mode, flag, fval);
+        sp.add(1);
+    }
+    {
+        Span sp(h, ESP_ST_SCAN);
+        int l = 0;
+        CK(scan_inplace<u32, false>(h, flag, E + 1, h->hist, &l));
+        sp.add(l);
+    }
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, flag + E, 4, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    const i64 Zn = (i64) * (u32 *)h->pin_scalar;
+    *Zn_out = Zn;
+    if (Zn == 0) return ESP_OK;
+    CK(prepare_outputs(h, Z0, Zn));
+    {
+        Span sp(h, ESP_ST_FOLD);
+        if (Z0 == 0)
+            hipLaunchKernelGGL((espfold::compact_k<true>), dim3(grid_for(E, espfold::THREADS)), dim3(espfold::THREADS), 0, h->stream, sk,
+                               (const double *)fval, E, (const u32 *)flag, h->L.rb, (i64 *)h->rowval.p, (u64 *)nullptr,
+                               (double *)h->nzval.p, (u64 *)h->colend.p);
+        else
+            hipLaunchKernelGGL((espfold::compact_k<false>), dim3(grid_for(E, espfold::THREADS)), dim3(espfold::THREADS), 0, h->stream, sk,
+                               (const double *)fval, E, (const u32 *)flag, h->L.rb, (i64 *)nullptr, (u64 *)h->newkey.p,
+                               (double *)h->newval.p, (u64 *)h->colend.p);
+        sp.add(1);
+    }
+    return finish_csc(h, Z0, Zn, (const u64 *)h->newkey.p, (const double *)h->newval.p);
+}
+
+__global__ void piece_totals_k(const i64 *__restrict__ pstart, int P, i64 nb, unsigned long long *__restrict__ maxlen,
+                               unsigned long long *__restrict__ negative);
+
+// bucket starts of a tail sorted by its prefix digit: first position whose digit is >= d, for d = 0 .. NB
+__global__ void tail_bucket_starts_k(const u64 *__restrict__ keys, i64 T, u64 base, u64 span, int shift, i64 NB, i64 *__restrict__ out) {
+    const i64 d = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (d > NB) return;
+    i64 lo = 0, hi = T;
+    while (lo < hi) {
+        const i64 mid = (lo + hi) >> 1;
+        u64 kn = (keys[mid] >> ESP_TAG_BITS) - base;
+        kn = kn < span ? kn : span - 1;
+        if ((i64)(kn >> shift) < d)
+            lo = mid + 1;
+        else
+            hi = mid;
+    }
+    out[d] = lo;
+}
+
+// A producer's bucket-ordered batch with packed entries appended behind it (a re-assembly whose mesh gained a few
+// couplings: the generator's batch, then the new positions): the tail alone goes through the run-based partition with
+// the batch's prefix bits, and the bucket kernel reads every segment as two pieces -- the batch's bucket (4-byte keys
+// when the producer wrote them), then the tail's.  Stream order is kept: the tail's entries come after the batch's.
+int32_t flush_pre_tail(esp_handle *h, int mode, i64 *Zn, bool *served) {
+    *served = false;
+    const esp_handle::PrePart pp = h->pre;
+    const i64 E0 = pp.E, T = pp.tail, NB = (i64)1 << pp.pb;
+    CK(ensure(h, h->newkey, sizeof(u64) * (size_t)T));
+    CK(ensure(h, h->newval, sizeof(double) * (size_t)T));
+    CK(ensure(h, h->seg[0], sizeof(i64) * (size_t)(NB + 1)));
+    CK(ensure(h, h->tilef[0], sizeof(u64) * (size_t)(NB + 1 + espscan::workspace_elems(NB + 1))));
+    CK(ensure(h, h->misc, 256));
+    unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
+    HIPCK(h, hipMemsetAsync(d_maxlen, 0, 64, h->stream));  // maxlen .. the four flag words (run_partition)
+    bool took = false, tiles = false;
+    i64 ml = 0;
+    // (a tail of the batch's kind goes out as 4-byte keys too: the bucket kernel then reads nothing but such keys)
+    const bool tail32 = pp.key_bytes == 4 && h->kind_uniform == pp.kind && h->kind_noted == h->count;
+    int tail_bytes = 8;
+    CK(run_partition(h, (const u64 *)h->keys.p + E0, (const double *)h->vals.p + E0, (u64 *)h->newkey.p, (double *)h->newval.p, pp.K,
+                     pp.pb, (i64 *)h->seg[0].p, (u64 *)h->tilef[0].p, &tiles, &took, &ml, nullptr, 0, tail32, &tail_bytes, T));
+    if (!took) {
+        // no pre-sorted stream (a few entries spread over many buckets, say): stable 8-bit passes over the prefix bits of the
+        // tail alone, least significant first; the last one lands in newkey/newval (keys2/vals2, the bucket kernel's
+        // output, serve as the other half of the ping-pong until then)
+        CK(ensure(h, h->keys2, sizeof(u64) * (size_t)(E0 + T)));
+        CK(ensure(h, h->vals2, sizeof(double) * (size_t)(E0 + T)));
+        CK(ensure(h, h->segs, sizeof(i64) * 8));
+        i64 *segs = (i64 *)h->segs.p;
+        const i64 TR = ceil_div<i64>(T, espradix::TILE);
+        hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, segs, (i64)0, T, (i64)0, TR);
+        HIPCK(h, hipMemsetAsync(d_maxlen, 0, 64, h->stream));
+        const int npass = (pp.pb + 7) / 8;
+        const u64 *ki = (const u64 *)h->keys.p + E0;
+        const double *vi = (const double *)h->vals.p + E0;
+        bool to_new = (npass & 1) != 0;
+        for (int done = 0; done < pp.pb; done += 8) {
+            espradix::Pass p;
+            p.keys_in = ki;
+            p.vals_in = vi;
+            p.keys_out = to_new ? (u64 *)h->newkey.p : (u64 *)h->keys2.p;
+            p.vals_out = to_new ? (double *)h->newval.p : (double *)h->vals2.p;
+            p.seg_start = segs;
+            p.tile_first = segs + 2;
+            p.S = 1;
+            p.owner_P = 0;
+            p.owner_n = 1;
+            p.colshift = 0;
+            p.base = h->win_base;
+            p.span = h->win_span;
+            p.err = (u32 *)h->misc.p + 60;
+            p.shift = pp.K - pp.pb + done;
+            p.bits = std::min(8, pp.pb - done);
+            CK(partition_pass(h, p, TR));
+            ki = p.keys_out;
+            vi = p.vals_out;
+            to_new = !to_new;
+        }
+        {
+            Span sp(h, ESP_ST_SCAN);
+            hipLaunchKernelGGL(tail_bucket_starts_k, dim3(grid_for(NB + 1, 256)), dim3(256), 0, h->stream, (const u64 *)h->newkey.p, T,
+                               h->win_base, h->win_span, pp.K - pp.pb, NB, (i64 *)h->seg[0].p);
+            sp.add(1);
+        }
+        HIPCK(h, hipMemcpyAsync(h->pin_scalar, (u32 *)h->misc.p + 60, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        if ((u32)h->pin_scalar[0]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (partition)");
+        h->last_run_order = 0;
+    }
+    // pointer table (keys | values) | piece starts: batch, tail
+    const size_t o_ps = 256 * 8;
+    CK(ensure(h, h->piecetab, o_ps + sizeof(i64) * 2 * (size_t)(NB + 1)));
+    char *TB = (char *)h->piecetab.p;
+    const void *tab[4] = {h->keys.p, h->newkey.p, h->vals.p, h->newval.p};
+    i64 *pstart = (i64 *)(TB + o_ps);
+    HIPCK(h, hipMemcpyAsync(TB, tab, sizeof(tab), hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(pstart, h->seg[1].p, sizeof(i64) * (size_t)(NB + 1), hipMemcpyDeviceToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(pstart + (NB + 1), h->seg[0].p, sizeof(i64) * (size_t)(NB + 1), hipMemcpyDeviceToDevice, h->stream));
+    HIPCK(h, hipMemsetAsync(d_maxlen, 0, 16, h->stream));
+    {
+        Span sp(h, ESP_ST_SCAN);
+        hipLaunchKernelGGL(piece_totals_k, dim3(grid_for(NB, 256)), dim3(256), 0, h->stream, (const i64 *)pstart, 2, NB, d_maxlen, d_maxlen + 1);
+        sp.add(1);
+    }
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_maxlen, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));  // (tab is read by the copy above)
+    const i64 merged = (i64)h->pin_scalar[0];
+    if (merged > (i64)esplocal::CAP) return ESP_OK;
+    HIPCK(h, hipMemsetAsync((u32 *)h->misc.p + 60, 0, 4, h->stream));
+    Sorted st;
+    st.sk = (const u64 *)h->keys.p;
+    st.sv = (const double *)h->vals.p;
+    st.in_primary = true;
+    st.S = (int)NB;
+    st.seg_start = nullptr;
+    st.rem_bits = pp.K - pp.pb;
+    st.local_ok = true;
+    st.npieces = 2;
+    st.all_update = h->kind_uniform == ESP_UPDATE && h->kind_noted == h->count;
+    st.ptab = (const void *const *)TB;
+    st.pstart = pstart;
+    st.maxlen = merged;
+    st.has_base = true;
+    st.base = h->win_base;
+    if (pp.key_bytes == 4 && tail_bytes == 4) {
+        st.all32 = true;
+        st.kind = pp.kind;
+    } else if (pp.key_bytes == 4) {
+        st.p32_piece = 0;
+        st.p32_lo = 0;
+        st.kind = pp.kind;
+    }
+    CK(ensure(h, h->keys2, sizeof(u64) * (size_t)(E0 + T)));
+    CK(ensure(h, h->vals2, sizeof(double) * (size_t)(E0 + T)));
+    CK(flush_local(h, st, mode, Zn));
+    *served = true;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int32_t *pattern_changed) {
+    if (!h) return ESP_ERR_INVALID;
+    if (mode != ESP_FLUSH_ROUTED && mode != ESP_FLUSH_PLUS) FAIL(h, ESP_ERR_INVALID, "esp_flush: mode");
+    (void)hipSetDevice(h->device);
+    if (pattern_changed) *pattern_changed = 0;
+    i64 E = h->count;
+    if (E == 0) {
+        if (new_nnz) *new_nnz = h->nnz;
+        return ESP_OK;
+    }
+    if (E >= 0xFFFFFFF0ll) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_flush: %lld pending entries exceed the 2^32 limit of one flush", (long long)E);
+    hipEvent_t fa = nullptr;
+    if (h->timing) {
+        fa = ev_get(h);
+        (void)hipEventRecord(fa, h->stream);
+    }
+    i64 Zn = 0;
+    bool use_local = h->force_path != ESP_PATH_GENERAL;
+    if (h->ones_pending && windowed(h)) CK(fix_tail(h));  // (cannot happen: a window is declared through fix_tail)
+    if (h->pre.valid) {  // the producer's partition serves this flush if nothing changed since (appends BEHIND it may have)
+        const esp_handle::PrePart &pp = h->pre;
+        const bool usable = use_local && !h->part_assembled && pp.mw_P == 0 && pp.E + pp.tail == E && pp.base == h->win_base &&
+                            pp.span == h->win_span && pp.maxlen <= (i64)esplocal::CAP && pp.K - pp.pb <= esplocal::MAX_REM_BITS;
+        if (!usable) CK(pending_materialize(h));
+    }
+    bool served = false, split = false;
+    i64 Zsplit = 0;  // new entries of the batch's own flush
+    if (h->pre.valid && h->pre.tail > 0 && h->nnz > 0 && mode == ESP_FLUSH_ROUTED && h->force_path != ESP_PATH_BATCH_TAIL_ONE_FLUSH) {
+        // Batch + tail over a stored pattern (a re-assembly whose mesh gained couplings): the batch by itself -- its buckets
+        // fit the small variant of the bucket kernel, and a batch of hits emits nothing and needs no join -- then the tail
+        // as a flush of its own.  A ROUTED flush may be cut at any stream position: flush! between two calls of an
+        // ExtendableSparseMatrix never changes a result (extendable.jl:159-255: a call either hits the CSC or goes to the
+        // buffer, which the flush adds as it is).  Not so csc + buffer (ESP_FLUSH_PLUS): the buffer is folded by itself
+        // first.  force_path 22: one flush over two pieces, as on a fresh matrix.
+        const esp_handle::PrePart pp = h->pre;
+        Sorted st;
+        st.sk = (const u64 *)h->keys.p;
+        st.sv = (const double *)h->vals.p;
+        st.in_primary = true;
+        st.S = 1 << pp.pb;
+        st.total = pp.E;
+        st.seg_start = (const i64 *)h->seg[1].p;
+        st.rem_bits = pp.K - pp.pb;
+        st.local_ok = true;
+        st.key_bytes = pp.key_bytes;
+        st.kind = pp.kind;
+        st.maxlen = pp.maxlen;
+        CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
+        CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
+        CK(flush_local(h, st, mode, &Zsplit));  // (on failure everything is still pending)
+        // the tail is the pending buffer now: packed keys, moved to the front (chunks of at most E0 entries: source and
+        // destination of one copy never overlap)
+        const i64 E0 = pp.E, T = pp.tail;
+        {
+            Span sp(h, ESP_ST_COPY);
+            for (i64 at = 0; at < T; at += E0) {
+                const i64 c = std::min(E0, T - at);
+                hipError_t e1 = hipMemcpyAsync((u64 *)h->keys.p + at, (const u64 *)h->keys.p + E0 + at, sizeof(u64) * (size_t)c, hipMemcpyDeviceToDevice, h->stream);
+                if (e1 == hipSuccess)
+                    e1 = hipMemcpyAsync((double *)h->vals.p + at, (const double *)h->vals.p + E0 + at, sizeof(double) * (size_t)c, hipMemcpyDeviceToDevice, h->stream);
+                if (e1 != hipSuccess) {  // (the batch is in the matrix already: it must not stay pending and be applied again)
+                    h->count = 0;
+                    pending_changed(h);
+                    FAIL(h, ESP_ERR_HIP, "esp_flush: %s while moving the entries behind a flushed batch; they were dropped", hipGetErrorString(e1));
+                }
+                sp.add(2);
+            }
+        }
+        const bool one_kind = h->kind_uniform >= 0 && h->kind_noted == h->count;
+        h->count = T;
+        h->pre.valid = false;
+        h->kind_noted = one_kind ? T : 0;
+        if (!one_kind) h->kind_uniform = -2;
+        h->shard_valid = h->part_valid = false;
+        h->values_version++;
+        E = T;
+        split = true;
+        // (the tail gets a plan of its own: fewer, fuller segments -- with the batch's 2^16 buckets, small variant and 4-byte
+        // keys included, its bucket kernel took 1.4 instead of 0.9 ms at config 3: time follows the number of segments)
+    }
+    if (h->pre.valid && h->pre.tail > 0) {
+        // batch + tail: only the tail is partitioned, the bucket kernel reads every segment as two pieces
+        CK(flush_pre_tail(h, mode, &Zn, &served));
+        if (!served) CK(pending_materialize(h));  // (a merged segment is too long, or the tail is no pre-sorted stream)
+    }
+    if (served) {
+        h->last_partition = 5;
+    } else if (h->pre.valid) {
+        const esp_handle::PrePart &pp = h->pre;
+        Sorted st;
+        st.sk = (const u64 *)h->keys.p;
+        st.sv = (const double *)h->vals.p;
+        st.in_primary = true;
+        st.S = 1 << pp.pb;
+        st.total = pp.E;
+        st.seg_start = (const i64 *)h->seg[1].p;
+        st.rem_bits = pp.K - pp.pb;
+        st.local_ok = true;
+        st.key_bytes = pp.key_bytes;
+        st.kind = pp.kind;
+        st.maxlen = pp.maxlen;
+        CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
+        CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
+        CK(flush_local(h, st, mode, &Zn));
+        h->last_partition = 4;
+        h->runs_penalty = 0;
+        h->seen_spread = pp.Ee > 0.0 ? (double)pp.maxlen * std::ldexp(1.0, pp.pb) / pp.Ee : 0.0;
+    } else if (h->part_assembled) {
+        // partitioned shard exchange: the segments are already formed (esp_shard_assemble)
+        CK(ensure(h, h->misc, 256));
+        HIPCK(h, hipMemsetAsync((u32 *)h->misc.p + 60, 0, 4, h->stream));
+        Sorted st;
+        char *T = (char *)h->piecetab.p;
+        st.sk = (const u64 *)h->keys.p;
+        st.sv = (const double *)h->vals.p;
+        st.in_primary = true;
+        st.S = (int)h->part_nb;
+        st.seg_start = nullptr;
+        st.rem_bits = h->part_shift;
+        st.local_ok = true;
+        st.npieces = h->part_P;
+        st.all_update = h->part_all_update;
+        st.ptab = (const void *const *)T;
+        st.pstart = (const i64 *)(T + 256 * 8);
+        st.maxlen = h->part_maxlen;
+        if (h->part_own32) {
+            st.p32_piece = h->part_me;
+            st.p32_lo = h->part_own_lo;
+            st.kind = h->part_kind32;
+        }
+        CK(ensure(h, h->keys2, sizeof(u64) * (size_t)std::max<i64>(h->part_total, 1)));
+        CK(ensure(h, h->vals2, sizeof(double) * (size_t)std::max<i64>(h->part_total, 1)));
+        CK(flush_local(h, st, mode, &Zn));
+        h->last_partition = 7;
+    } else if (use_local) {
+        Sorted st;
+        CK(sort_msd(h, &st));
+        if (!st.in_primary) {  // keep "pending data lives in keys/vals" true for the general path
+            std::swap(h->keys, h->keys2);
+            std::swap(h->vals, h->vals2);
+            h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
+            st.in_primary = true;
+        }
+        if (st.local_ok) {
+            const int32_t rc = flush_local(h, st, mode, &Zn);
+            if (rc != ESP_OK && st.key_bytes == 4) {
+                // the batch stays pending: its packed keys are intact in the scratch pair (the partition wrote the 4-byte
+                // keys into the other one)
+                std::swap(h->keys, h->keys2);
+                std::swap(h->vals, h->vals2);
+                h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
+            }
+            CK(rc);
+        } else {
+            use_local = false;
+        }
+    }
+    if (!use_local && !h->part_assembled) CK(flush_global(h, mode, &Zn));
+    if (split) h->last_partition = 6;
+    h->last_path = (use_local || h->part_assembled) ? 1 : 2;
+    if ((Zn > 0 || Zsplit > 0) && pattern_changed) *pattern_changed = 1;
+    h->values_version++;  // (hits were applied in place)
+    HIPCK(h, hipGetLastError());
+    h->count = 0;
+    pending_changed(h);
+    if (h->timing && fa) {
+        hipEvent_t fb = ev_get(h);
+        (void)hipEventRecord(fb, h->stream);
+        h->spans.push_back({-1, fa, fb, 0});
+    }
+    if (new_nnz) *new_nnz = h->nnz;
+    return ESP_OK;
+}
+

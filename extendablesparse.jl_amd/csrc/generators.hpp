@@ -16,7 +16,7 @@ constexpr int THREADS = 256;
 // (rows, cols, vals, kinds) -> packed keys.  Out-of-range indices raise *err (first bad
 // position + 1) and nothing of the batch is committed by the host side
 // (BoundsError, sparsematrixcsc.jl:8-10).
-__global__ __launch_bounds__(THREADS) void pack_k(const i64 *__restrict__ rows,
+static __global__ __launch_bounds__(THREADS) void pack_k(const i64 *__restrict__ rows,
                                                   const i64 *__restrict__ cols,
                                                   const double *__restrict__ vals,
                                                   const uint8_t *__restrict__ kinds, int kind_all,
@@ -183,7 +183,7 @@ __device__ __forceinline__ void copy_out_staged(const u64 *lk, const double *lv,
 
 // The stream goes to the buffer as it is (coalesced 16-byte stores: K1, "coalesced HBM stores on the append path";
 // writes 16 B per update, reads nothing).
-__global__ __launch_bounds__(THREADS) void fdrand_k(FdArgs a) {
+static __global__ __launch_bounds__(THREADS) void fdrand_k(FdArgs a) {
     __shared__ u64 lk[THREADS * FD_MAX_PER_NODE];
     __shared__ double lv[THREADS * FD_MAX_PER_NODE];
     i64 off0;
@@ -224,7 +224,7 @@ __device__ __forceinline__ void fd_items(const FdArgs &a, i64 g, FdItems &it, u3
 }
 
 // COUNT launch of the stencil producer: no update is formed.  Same chunks (workgroups of 256 nodes) as the PART launch.
-__global__ __launch_bounds__(THREADS) void fd_count_k(FdArgs a, esprun::RunSink sink, u32 *err) {
+static __global__ __launch_bounds__(THREADS) void fd_count_k(FdArgs a, esprun::RunSink sink, u32 *err) {
     __shared__ u32 rd[esprun::RMAX];
     __shared__ u32 rc[esprun::RMAX];
     __shared__ u32 over;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(THREADS) void fd_count_k(FdArgs a, esprun::RunSink 
 // the few tiles above that go out in two rounds (staged window [lo, lo + FD_STAGE) of the tile's slots).
 constexpr int FD_STAGE = 3168;
 template <bool S32, bool OUT32>
-__global__ __launch_bounds__(THREADS) void fdrand_part_k(FdArgs a) {
+static __global__ __launch_bounds__(THREADS) void fdrand_part_k(FdArgs a) {
     static_assert(S32 || !OUT32, "4-byte keys come from a 4-byte staging area");
     typedef typename std::conditional<S32, u32, u64>::type KT;
     __shared__ KT lk[FD_STAGE];
@@ -507,7 +507,7 @@ __device__ __forceinline__ void fem_stage(const FemArgs &a, KT *lk, double *lv, 
     });
 }
 
-__global__ __launch_bounds__(FEM_CELLS) void fem_k(FemArgs a) {
+static __global__ __launch_bounds__(FEM_CELLS) void fem_k(FemArgs a) {
     __shared__ u64 lk[FEM_CELLS * FEM_MAX_PER_CELL];
     __shared__ double lv[FEM_CELLS * FEM_MAX_PER_CELL];
     const i64 p0 = (i64)blockIdx.x * FEM_CELLS;
@@ -536,7 +536,7 @@ __device__ __forceinline__ void fem_items(const FemArgs &a, i64 pos, u32 (&dig)[
 }
 
 // COUNT launch of the FEM producer (same chunks -- workgroups of 128 cells -- as the PART launch)
-__global__ __launch_bounds__(FEM_CELLS) void fem_count_k(FemArgs a, esprun::RunSink sink, u32 *err) {
+static __global__ __launch_bounds__(FEM_CELLS) void fem_count_k(FemArgs a, esprun::RunSink sink, u32 *err) {
     __shared__ u32 rd[esprun::RMAX];
     __shared__ u32 rc[esprun::RMAX];
     __shared__ u32 over;
@@ -555,7 +555,7 @@ __global__ __launch_bounds__(FEM_CELLS) void fem_count_k(FemArgs a, esprun::RunS
 // PART launch of the FEM producer (see fdrand_part_k): the updates of a cell for vertex column jl lie together, in
 // call order: row il's term at il (+1 from the diagonal's row on: the mass term comes right before the diagonal)
 template <bool S32, bool OUT32>
-__global__ __launch_bounds__(FEM_CELLS) void fem_part_k(FemArgs a) {
+static __global__ __launch_bounds__(FEM_CELLS) void fem_part_k(FemArgs a) {
     typedef typename std::conditional<S32, u32, u64>::type KT;
     __shared__ KT lk[FEM_CELLS * FEM_MAX_PER_CELL];
     __shared__ double lv[FEM_CELLS * FEM_MAX_PER_CELL];

@@ -1,0 +1,715 @@
+// handle.hip -- libesparse_hip: lifetime, buffers, append, CSC in and out, timing, debug getters (see internal.hpp for the map of the translation units)
+#include "internal.hpp"
+
+thread_local std::string g_err;
+
+int32_t ensure(esp_handle *h, DevBuf &b, size_t need, bool keep) {
+    if (b.bytes >= need && b.p) return ESP_OK;
+    size_t want = need;
+    if (keep && b.bytes) want = std::max(need, b.bytes + b.bytes / 2);
+    want = (want + 255) & ~(size_t)255;
+    void *np = nullptr;
+    HIPCK(h, hipMalloc(&np, want));
+    if (keep && b.p && b.bytes) {
+        HIPCK(h, hipMemcpyAsync(np, b.p, b.bytes, hipMemcpyDeviceToDevice, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+    }
+    if (b.p) (void)hipFree(b.p);
+    b.p = np;
+    b.bytes = want;
+    return ESP_OK;
+}
+void release(DevBuf &b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.bytes = 0;
+}
+
+void release_all(esp_handle *h) {
+    for (DevBuf *b : {&h->keys, &h->vals, &h->keys2, &h->vals2, &h->hist, &h->segs, &h->colend, &h->newkey,
+                      &h->newval, &h->heads, &h->misc, &h->colptr, &h->rowval, &h->nzval, &h->rowval2,
+                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->runbuf, &h->chunkbuf, &h->parttab, &h->piecetab, &h->csr_rowptr, &h->csr_perm, &h->csr_col, &h->csr_tmp, &h->csr_val, &h->mul_x, &h->mul_r, &h->stage.d_rows, &h->stage.d_cols, &h->stage.d_vals, &h->stage.d_kinds, &h->bulk.d_rows, &h->bulk.d_cols, &h->bulk.d_vals, &h->bulk.d_kinds})
+        release(*b);
+    for (esp_handle::StageArea *sa : {&h->stage, &h->bulk}) {
+        if (sa->rows) (void)hipHostFree(sa->rows);
+        if (sa->cols) (void)hipHostFree(sa->cols);
+        if (sa->vals) (void)hipHostFree(sa->vals);
+        if (sa->kinds) (void)hipHostFree(sa->kinds);
+        sa->rows = sa->cols = nullptr;
+        sa->vals = nullptr;
+        sa->kinds = nullptr;
+        sa->cap = 0;
+    }
+}
+
+// ------------------------------------------------------------------------ timing
+hipEvent_t ev_get(esp_handle *h) {
+    if (!h->ev_pool.empty()) {
+        hipEvent_t e = h->ev_pool.back();
+        h->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+void timing_collect(esp_handle *h) {
+    if (h->spans.empty()) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (auto &s : h->spans) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) {
+            if (s.stage >= 0) {
+                h->acc.ms[s.stage] += ms;
+                h->acc.launches[s.stage] += s.launches;
+            } else {
+                h->acc.flush_ms += ms;
+                h->acc.flushes += 1;
+            }
+        }
+        h->ev_pool.push_back(s.a);
+        h->ev_pool.push_back(s.b);
+    }
+    h->spans.clear();
+}
+
+// ------------------------------------------------------------------------ lifetime
+extern "C" const char *esp_version(void) { return "esparse-hip 0.1 (gfx950)"; }
+
+extern "C" const char *esp_last_error(const esp_handle *h) { return h ? h->err.c_str() : g_err.c_str(); }
+
+// colptr behind the window := nnz+1, if it was left stale by windowed flushes
+int32_t fix_tail(esp_handle *h) {
+    if (h->ones_pending) {
+        h->ones_pending = false;
+        h->tail_stale = false;
+        if (h->colptr.p)
+            hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(h->n + 1, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p, h->n + 1, (i64)1);
+        HIPCK(h, hipGetLastError());
+        return ESP_OK;
+    }
+    if (!h->tail_stale) return ESP_OK;
+    h->tail_stale = false;
+    const i64 from = h->wc1 + 1, cnt = h->n + 1 - from;
+    if (cnt > 0 && h->colptr.p)
+        hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(cnt, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p + from, cnt, h->nnz + 1);
+    HIPCK(h, hipGetLastError());
+    return ESP_OK;
+}
+
+int32_t init_empty_csc(esp_handle *h) {
+    CK(ensure(h, h->colptr, sizeof(i64) * (size_t)(h->n + 1)));
+    if (h->csc_valid && windowed(h)) {
+        // every entry was inside the window: colptr is 1 up to it already, the part behind it is refreshed lazily
+        i64 c0, cnt;
+        col_range(h, &c0, &cnt);
+        hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(cnt, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p + c0, cnt, (i64)1);
+        h->tail_stale = h->wc1 < h->n;
+    } else if (h->csc_valid && !windowed(h) && h->n > 4096) {
+        h->ones_pending = true;  // (filled on first use unless a fresh flush writes all of colptr before)
+        h->tail_stale = false;
+    } else {
+        hipLaunchKernelGGL(fill_i64_k, dim3(grid_for(h->n + 1, 256)), dim3(256), 0, h->stream, (i64 *)h->colptr.p,
+                           h->n + 1, (i64)1);
+        h->tail_stale = false;
+        h->ones_pending = false;
+    }
+    h->nnz = 0;
+    h->pattern_version++, h->values_version++;
+    h->csc_valid = true;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_create(int64_t m, int64_t n, int32_t device, int64_t capacity_hint, esp_handle **out) {
+    if (!out) FAIL((esp_handle *)nullptr, ESP_ERR_INVALID, "esp_create: out is NULL");
+    *out = nullptr;
+    if (m < 0 || n < 0) FAIL((esp_handle *)nullptr, ESP_ERR_INVALID, "esp_create: negative dimension");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        FAIL((esp_handle *)nullptr, ESP_ERR_NODEVICE, "esp_create: no HIP device available (libesparse_hip has no CPU path)");
+    if (device < 0 || device >= ndev)
+        FAIL((esp_handle *)nullptr, ESP_ERR_INVALID, "esp_create: device %d out of range (0..%d)", device, ndev - 1);
+    const int rb = bits_for(m), cb = bits_for(n);
+    if (rb + cb + ESP_TAG_BITS > 64)
+        FAIL((esp_handle *)nullptr, ESP_ERR_UNSUPPORTED, "esp_create: %lld x %lld needs %d key bits (max 62)",
+             (long long)m, (long long)n, rb + cb);
+    esp_handle *h = new esp_handle();
+    h->m = m;
+    h->n = n;
+    h->device = device;
+    h->L = KeyLayout{rb, cb};
+    h->win_base = 0;
+    h->win_span = (u64)std::max<i64>(n, 1) << rb;
+    h->wc0 = 0;
+    h->wc1 = n;
+    h->hint = capacity_hint > 0 ? capacity_hint : 0;
+    memset(&h->acc, 0, sizeof h->acc);
+    if (const char *e = getenv("ESP_DEBUG_FORCE_PATH")) h->force_path = atoi(e);  // (same-box A/B of the test hooks)
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete h;
+        FAIL((esp_handle *)nullptr, ESP_ERR_HIP, "esp_create: cannot create a stream on device %d", device);
+    }
+    h->own_stream = true;
+    if (hipHostMalloc((void **)&h->pin_scalar, 64, hipHostMallocDefault) != hipSuccess) {
+        (void)hipStreamDestroy(h->stream);
+        delete h;
+        FAIL((esp_handle *)nullptr, ESP_ERR_NOMEM, "esp_create: pinned scalar allocation failed");
+    }
+    int32_t st = init_empty_csc(h);
+    if (st == ESP_OK && capacity_hint > 0) {
+        st = ensure(h, h->keys, sizeof(u64) * (size_t)capacity_hint);
+        if (st == ESP_OK) st = ensure(h, h->vals, sizeof(double) * (size_t)capacity_hint);
+        if (st == ESP_OK) h->cap = capacity_hint;
+    }
+    if (st != ESP_OK) {
+        g_err = h->err;
+        esp_destroy(h);
+        return st;
+    }
+    *out = h;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_destroy(esp_handle *h) {
+    if (!h) return ESP_OK;
+    (void)hipSetDevice(h->device);
+    (void)hipStreamSynchronize(h->stream);
+    release_all(h);
+    if (h->pin_scalar) (void)hipHostFree(h->pin_scalar);
+    if (h->pin_mw) (void)hipHostFree(h->pin_mw);
+    if (h->pin_mw_done) (void)hipEventDestroy(h->pin_mw_done);
+    for (auto &s : h->spans) {
+        (void)hipEventDestroy(s.a);
+        (void)hipEventDestroy(s.b);
+    }
+    for (auto e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->aux_ev) (void)hipEventDestroy(h->aux_ev);
+    if (h->aux) (void)hipStreamDestroy(h->aux);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return ESP_OK;
+}
+
+// The Generic wrappers of the reference replace their buffer by a fresh T_ext(m,n) after every flush!
+// (genericextendablesparsematrixcsc.jl:34, genericmt...:47-49) and leave the old one to the garbage collector, which
+// does not see device or pinned memory: the shim calls this on the old buffer right after `buffer + csc` returned.
+// The handle stays valid (an empty matrix with an empty buffer; the staging chunk pointers of esp_stage_begin are
+// gone); everything is allocated again on next use.
+extern "C" int32_t esp_release_buffers(esp_handle *h) {
+    if (!h) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    timing_collect(h);
+    release_all(h);
+    h->cap = 0;
+    h->count = 0;
+    h->chunk_cap = 0;
+    h->chunk_pb = 0;
+    pending_changed(h);
+    h->csc_valid = false;
+    h->ones_pending = false;
+    h->tail_stale = false;
+    h->csr_version = 0;
+    h->csr_val_version = 0;
+    return init_empty_csc(h);
+}
+
+// Base.copy(ext) (extendable.jl:279-285): a second handle with the same CSC, the same pending entries
+// (the copy of lnkmatrix) and the same column window; device-to-device copies only.
+extern "C" int32_t esp_clone(esp_handle *h, esp_handle **out) {
+    if (!h || !out) return ESP_ERR_INVALID;
+    *out = nullptr;
+    (void)hipSetDevice(h->device);
+    esp_handle *c = nullptr;
+    CK(esp_create(h->m, h->n, h->device, h->hint, &c));
+    auto fail = [&](int32_t st) {
+        h->err = c->err;
+        esp_destroy(c);
+        return st;
+    };
+    int32_t st = ESP_OK;
+    if ((st = pending_materialize(h)) != ESP_OK) return fail(st);
+    HIPCK(h, hipStreamSynchronize(h->stream));  // everything the copy reads is complete
+    if (h->count > 0) {
+        if ((st = reserve_append(c, h->count)) != ESP_OK) return fail(st);
+        if (hipMemcpyAsync(c->keys.p, h->keys.p, sizeof(u64) * (size_t)h->count, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(c->vals.p, h->vals.p, sizeof(double) * (size_t)h->count, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+            return fail(ESP_ERR_HIP);
+        c->count = h->count;
+    }
+    if ((st = fix_tail(h)) != ESP_OK) return fail(st);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (hipMemcpyAsync(c->colptr.p, h->colptr.p, sizeof(i64) * (size_t)(h->n + 1), hipMemcpyDeviceToDevice, c->stream) != hipSuccess) return fail(ESP_ERR_HIP);
+    if (h->nnz > 0) {
+        if ((st = ensure(c, c->rowval, sizeof(i64) * (size_t)h->nnz)) != ESP_OK) return fail(st);
+        if ((st = ensure(c, c->nzval, sizeof(double) * (size_t)h->nnz)) != ESP_OK) return fail(st);
+        if (hipMemcpyAsync(c->rowval.p, h->rowval.p, sizeof(i64) * (size_t)h->nnz, hipMemcpyDeviceToDevice, c->stream) != hipSuccess ||
+            hipMemcpyAsync(c->nzval.p, h->nzval.p, sizeof(double) * (size_t)h->nnz, hipMemcpyDeviceToDevice, c->stream) != hipSuccess)
+            return fail(ESP_ERR_HIP);
+    }
+    c->nnz = h->nnz;
+    c->pattern_version++, c->values_version++;
+    c->win_base = h->win_base;
+    c->win_span = h->win_span;
+    c->wc0 = h->wc0;
+    c->wc1 = h->wc1;
+    c->win_excl = h->win_excl;
+    c->seen_maxrun = h->seen_maxrun;
+    if (hipStreamSynchronize(c->stream) != hipSuccess) return fail(ESP_ERR_HIP);
+    *out = c;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_set_stream(esp_handle *h, void *hip_stream) {
+    if (!h) return ESP_ERR_INVALID;
+    (void)hipStreamSynchronize(h->stream);
+    timing_collect(h);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    h->stream = (hipStream_t)hip_stream;
+    h->own_stream = false;
+    return ESP_OK;
+}
+extern "C" int32_t esp_synchronize(esp_handle *h) {
+    if (!h) return ESP_ERR_INVALID;
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    return ESP_OK;
+}
+extern "C" int32_t esp_size(const esp_handle *h, int64_t *m, int64_t *n) {
+    if (!h) return ESP_ERR_INVALID;
+    if (m) *m = h->m;
+    if (n) *n = h->n;
+    return ESP_OK;
+}
+extern "C" int32_t esp_key_layout(const esp_handle *h, int32_t *row_bits, int32_t *col_bits) {
+    if (!h) return ESP_ERR_INVALID;
+    if (row_bits) *row_bits = h->L.rb;
+    if (col_bits) *col_bits = h->L.cb;
+    return ESP_OK;
+}
+extern "C" int32_t esp_pending(const esp_handle *h, int64_t *count) {
+    if (!h || !count) return ESP_ERR_INVALID;
+    *count = h->count;
+    return ESP_OK;
+}
+extern "C" int32_t esp_nnz(const esp_handle *h, int64_t *nnz) {
+    if (!h || !nnz) return ESP_ERR_INVALID;
+    *nnz = h->nnz;
+    return ESP_OK;
+}
+
+// ------------------------------------------------------------------------ append
+int32_t reserve_append(esp_handle *h, i64 add) {
+    // between esp_shard_assemble and esp_flush the pending entries are spread over the caller's receive buffers
+    // (the handle's count is their logical total): nothing can be appended behind them
+    if (h->part_assembled)
+        FAIL(h, ESP_ERR_STATE, "append: the pending entries are assembled shard pieces (esp_shard_assemble): esp_flush first");
+    // An append behind a bucket-ordered batch: the batch stays as it is (its 4-byte keys fill the front half of their
+    // slots), the new entries follow it as packed keys, and the flush partitions only them (flush_pre_tail).  A shard's
+    // batch, or force_path 19: back to packed keys first.
+    h->pre_keep = h->pre.valid && h->pre.mw_P == 0 && h->force_path != ESP_PATH_NO_BATCH_TAIL && h->count == h->pre.E + h->pre.tail;
+    if (!h->pre_keep) CK(pending_materialize(h));
+    const i64 need = h->count + add;
+    if (need <= h->cap) return ESP_OK;
+    i64 ncap = std::max<i64>(need, h->cap + h->cap / 2);
+    ncap = std::max<i64>(ncap, 1024);
+    // keep contents: only the first count entries matter
+    DevBuf nk, nv;
+    CK(ensure(h, nk, sizeof(u64) * (size_t)ncap));
+    CK(ensure(h, nv, sizeof(double) * (size_t)ncap));
+    if (h->count > 0) {
+        HIPCK(h, hipMemcpyAsync(nk.p, h->keys.p, sizeof(u64) * (size_t)h->count, hipMemcpyDeviceToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(nv.p, h->vals.p, sizeof(double) * (size_t)h->count, hipMemcpyDeviceToDevice, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+    }
+    release(h->keys);
+    release(h->vals);
+    h->keys = nk;
+    h->vals = nv;
+    h->cap = ncap;
+    return ESP_OK;
+}
+
+// pack count triples that already sit in device memory; checks bounds before committing
+int32_t pack_device(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const double *d_vals,
+                           const uint8_t *d_kinds, int kind_all, int op, i64 count) {
+    if (count == 0) return ESP_OK;
+    if (!d_kinds && (kind_all < 0 || kind_all > 3)) FAIL(h, ESP_ERR_INVALID, "append: kind %d invalid", kind_all);
+    if (op != ESP_OP_ADD && op != ESP_OP_SUB) FAIL(h, ESP_ERR_UNSUPPORTED, "append: op %d not supported on the device path", op);
+    if (!d_kinds) {  // an empty buffer and one kind: the append is the partition (no packed stream is written)
+        bool took = false;
+        CK(append_partitioned(h, d_rows, d_cols, d_vals, kind_all, op, count, &took));
+        if (took) return ESP_OK;
+    }
+    CK(reserve_append(h, count));
+    h->pin_scalar[0] = ~0ull;
+    CK(ensure(h, h->misc, 256));
+    unsigned long long *d_err = (unsigned long long *)h->misc.p;
+    HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 8, hipMemcpyHostToDevice, h->stream));
+    {
+        Span sp(h, ESP_ST_APPEND);
+        hipLaunchKernelGGL(espgen::pack_k, dim3(grid_for(count, espgen::THREADS)), dim3(espgen::THREADS), 0, h->stream,
+                           d_rows, d_cols, d_vals, d_kinds, kind_all, op == ESP_OP_SUB ? 1 : 0, count, h->m, h->n, h->L,
+                           (u64 *)h->keys.p + h->count, (double *)h->vals.p + h->count, d_err, (i64)0);
+        sp.add(1);
+    }
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (h->pin_scalar[0] != ~0ull)
+        FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
+             (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
+    if (!d_kinds) note_kind(h, kind_all, count);
+    h->count += count;
+    pending_changed(h);
+    return ESP_OK;
+}
+
+int32_t ensure_stage(esp_handle *h, esp_handle::StageArea &sa, i64 want) {
+    if (want <= sa.cap) return ESP_OK;
+    i64 cap = std::max<i64>(want, 1 << 16);
+    HIPCK(h, hipStreamSynchronize(h->stream));  // (a transfer out of the old area may be in flight)
+    if (sa.rows) (void)hipHostFree(sa.rows);
+    if (sa.cols) (void)hipHostFree(sa.cols);
+    if (sa.vals) (void)hipHostFree(sa.vals);
+    if (sa.kinds) (void)hipHostFree(sa.kinds);
+    sa.rows = sa.cols = nullptr;
+    sa.vals = nullptr;
+    sa.kinds = nullptr;
+    sa.cap = 0;
+    HIPCK(h, hipHostMalloc((void **)&sa.rows, sizeof(i64) * (size_t)cap, hipHostMallocDefault));
+    HIPCK(h, hipHostMalloc((void **)&sa.cols, sizeof(i64) * (size_t)cap, hipHostMallocDefault));
+    HIPCK(h, hipHostMalloc((void **)&sa.vals, sizeof(double) * (size_t)cap, hipHostMallocDefault));
+    HIPCK(h, hipHostMalloc((void **)&sa.kinds, (size_t)cap, hipHostMallocDefault));
+    CK(ensure(h, sa.d_rows, sizeof(i64) * (size_t)cap));
+    CK(ensure(h, sa.d_cols, sizeof(i64) * (size_t)cap));
+    CK(ensure(h, sa.d_vals, sizeof(double) * (size_t)cap));
+    CK(ensure(h, sa.d_kinds, (size_t)cap));
+    sa.cap = cap;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_stage_begin(esp_handle *h, int64_t want, int64_t **rows, int64_t **cols, double **vals,
+                                   uint8_t **kinds, int64_t *got) {
+    if (!h || !rows || !cols || !vals || !got) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    if (want <= 0) want = 1 << 20;
+    want = std::min<i64>(want, (i64)1 << 26);
+    CK(ensure_stage(h, h->stage, want));
+    *rows = h->stage.rows;
+    *cols = h->stage.cols;
+    *vals = h->stage.vals;
+    if (kinds) *kinds = h->stage.kinds;
+    *got = h->stage.cap;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_commit(esp_handle *h, int64_t count, int32_t kind_all, int32_t op) {
+    if (!h) return ESP_ERR_INVALID;
+    if (count < 0 || count > h->stage.cap) FAIL(h, ESP_ERR_INVALID, "esp_commit: count %lld exceeds the staged chunk", (long long)count);
+    if (count == 0) return ESP_OK;
+    (void)hipSetDevice(h->device);
+    {
+        Span sp(h, ESP_ST_COPY);
+        HIPCK(h, hipMemcpyAsync(h->stage.d_rows.p, h->stage.rows, sizeof(i64) * (size_t)count, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(h->stage.d_cols.p, h->stage.cols, sizeof(i64) * (size_t)count, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(h->stage.d_vals.p, h->stage.vals, sizeof(double) * (size_t)count, hipMemcpyHostToDevice, h->stream));
+        sp.add(3);
+        if (kind_all < 0) {
+            HIPCK(h, hipMemcpyAsync(h->stage.d_kinds.p, h->stage.kinds, (size_t)count, hipMemcpyHostToDevice, h->stream));
+            sp.add(1);
+        }
+    }
+    return pack_device(h, (const i64 *)h->stage.d_rows.p, (const i64 *)h->stage.d_cols.p, (const double *)h->stage.d_vals.p,
+                       kind_all < 0 ? (const uint8_t *)h->stage.d_kinds.p : nullptr, kind_all, op, count);
+}
+
+// host memcpy with a few threads: one core moves ~10 GB/s, PCIe takes ~55 GB/s
+void par_memcpy(void *dst, const void *src, size_t bytes) {
+    const size_t min_part = (size_t)4 << 20;
+    int nt = (int)std::min<size_t>(4, bytes / min_part);
+    if (nt <= 1) {
+        memcpy(dst, src, bytes);
+        return;
+    }
+    std::thread th[4];
+    const size_t part = ((bytes / (size_t)nt) + 63) & ~(size_t)63;
+    for (int i = 0; i < nt; i++) {
+        const size_t o = (size_t)i * part;
+        const size_t c = i == nt - 1 ? bytes - o : part;
+        th[i] = std::thread([=] { memcpy((char *)dst + o, (const char *)src + o, c); });
+    }
+    for (int i = 0; i < nt; i++) th[i].join();
+}
+
+// Bulk append from host arrays: the batch goes through the pinned staging area in chunks, two halves in
+// flight (the host copy of chunk i+1 overlaps the PCIe transfer and the pack kernel of chunk i); bounds
+// are checked on the device and read back ONCE: the call is one batch, nothing is committed on error.
+extern "C" int32_t esp_append_host(esp_handle *h, const int64_t *rows, const int64_t *cols, const double *vals,
+                                   const uint8_t *kinds, int32_t kind_all, int32_t op, int64_t count) {
+    if (!h || count < 0 || (count > 0 && (!rows || !cols || !vals))) return ESP_ERR_INVALID;
+    if (count == 0) return ESP_OK;
+    (void)hipSetDevice(h->device);
+    if (!kinds && (kind_all < 0 || kind_all > 3)) FAIL(h, ESP_ERR_INVALID, "append: kind %d invalid", kind_all);
+    if (op != ESP_OP_ADD && op != ESP_OP_SUB) FAIL(h, ESP_ERR_UNSUPPORTED, "append: op %d not supported on the device path", op);
+    const i64 chunk = std::min<i64>((i64)1 << 22, std::max<i64>(count, 1));
+    esp_handle::StageArea &sa = h->bulk;
+    CK(ensure_stage(h, sa, 2 * chunk));
+    CK(reserve_append(h, count));
+    CK(ensure(h, h->misc, 256));
+    unsigned long long *d_err = (unsigned long long *)h->misc.p;
+    h->pin_scalar[0] = ~0ull;
+    HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 8, hipMemcpyHostToDevice, h->stream));
+    hipEvent_t done[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; i++) HIPCK(h, hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    int32_t rc = ESP_OK;
+    i64 it = 0;
+    for (i64 off = 0; off < count && rc == ESP_OK; off += chunk, it++) {
+        const i64 c = std::min<i64>(chunk, count - off);
+        const int half = (int)(it & 1);
+        const i64 so = half ? chunk : 0;  // this half of the staging arrays (host and device)
+        if (it >= 2 && hipEventSynchronize(done[half]) != hipSuccess) rc = ESP_ERR_HIP;
+        par_memcpy(sa.rows + so, rows + off, sizeof(i64) * (size_t)c);
+        par_memcpy(sa.cols + so, cols + off, sizeof(i64) * (size_t)c);
+        par_memcpy(sa.vals + so, vals + off, sizeof(double) * (size_t)c);
+        if (kinds) memcpy(sa.kinds + so, kinds + off, (size_t)c);
+        i64 *dr = (i64 *)sa.d_rows.p + so, *dc = (i64 *)sa.d_cols.p + so;
+        double *dv = (double *)sa.d_vals.p + so;
+        uint8_t *dk = (uint8_t *)sa.d_kinds.p + so;
+        Span sp(h, ESP_ST_COPY);
+        if (hipMemcpyAsync(dr, sa.rows + so, sizeof(i64) * (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(dc, sa.cols + so, sizeof(i64) * (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync(dv, sa.vals + so, sizeof(double) * (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            (kinds && hipMemcpyAsync(dk, sa.kinds + so, (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess))
+            rc = ESP_ERR_HIP;
+        sp.add(kinds ? 4 : 3);
+        hipLaunchKernelGGL(espgen::pack_k, dim3(grid_for(c, espgen::THREADS)), dim3(espgen::THREADS), 0, h->stream, (const i64 *)dr,
+                           (const i64 *)dc, (const double *)dv, kinds ? (const uint8_t *)dk : nullptr, kind_all, op == ESP_OP_SUB ? 1 : 0, c,
+                           h->m, h->n, h->L, (u64 *)h->keys.p + h->count + off, (double *)h->vals.p + h->count + off, d_err, off);
+        (void)hipEventRecord(done[half], h->stream);
+    }
+    hipError_t e1 = hipMemcpyAsync(h->pin_scalar, d_err, 8, hipMemcpyDeviceToHost, h->stream);
+    hipError_t e2 = hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 2; i++) (void)hipEventDestroy(done[i]);
+    if (rc != ESP_OK || e1 != hipSuccess || e2 != hipSuccess || hipGetLastError() != hipSuccess)
+        FAIL(h, ESP_ERR_HIP, "esp_append_host: transfer failed");
+    if (h->pin_scalar[0] != ~0ull)
+        FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
+             (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
+    if (!kinds) note_kind(h, kind_all, count);
+    h->count += count;
+    pending_changed(h);
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_append_device(esp_handle *h, const int64_t *d_rows, const int64_t *d_cols, const double *d_vals,
+                                     const uint8_t *d_kinds, int32_t kind_all, int32_t op, int64_t count) {
+    if (!h || count < 0 || (count > 0 && (!d_rows || !d_cols || !d_vals))) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    return pack_device(h, d_rows, d_cols, d_vals, d_kinds, kind_all, op, count);
+}
+
+extern "C" int32_t esp_append_packed(esp_handle *h, const uint64_t *d_keys, const double *d_vals, int64_t count) {
+    if (!h || count < 0 || (count > 0 && (!d_keys || !d_vals))) return ESP_ERR_INVALID;
+    if (count == 0) return ESP_OK;
+    (void)hipSetDevice(h->device);
+    CK(reserve_append(h, count));
+    Span sp(h, ESP_ST_COPY);
+    HIPCK(h, hipMemcpyAsync((u64 *)h->keys.p + h->count, d_keys, sizeof(u64) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync((double *)h->vals.p + h->count, d_vals, sizeof(double) * (size_t)count, hipMemcpyDeviceToDevice, h->stream));
+    sp.add(2);
+    h->count += count;
+    pending_changed(h);
+    return ESP_OK;
+}
+
+
+// All pending entries of the following flushes have their column in [col_lo, col_hi] (1-based).
+// The radix partition then spends its bits on that window only (a column shard after the
+// exchange).  Entries outside the window make esp_flush return ESP_ERR_STATE.
+extern "C" int32_t esp_set_column_window(esp_handle *h, int64_t col_lo, int64_t col_hi) {
+    if (!h) return ESP_ERR_INVALID;
+    if (col_lo < 1 || col_hi > h->n || col_lo > col_hi) FAIL(h, ESP_ERR_INVALID, "column window [%lld,%lld] outside 1..%lld", (long long)col_lo, (long long)col_hi, (long long)h->n);
+    (void)hipSetDevice(h->device);
+    CK(fix_tail(h));  // (with the old window)
+    h->win_base = (u64)(col_lo - 1) << h->L.rb;
+    h->win_span = (u64)(col_hi - col_lo + 1) << h->L.rb;
+    h->wc0 = col_lo - 1;
+    h->wc1 = col_hi;
+    h->win_excl = h->nnz == 0 && h->count == 0;  // nothing stored or pending outside it, and flushes enforce it from now on
+    return ESP_OK;
+}
+
+
+// ------------------------------------------------------------------------ CSC side
+extern "C" int32_t esp_set_csc(esp_handle *h, const int64_t *colptr, const int64_t *rowval, const double *nzval, int64_t nnz) {
+    if (!h || !colptr || nnz < 0 || (nnz > 0 && (!rowval || !nzval))) return ESP_ERR_INVALID;
+    if (colptr[0] != 1 || colptr[h->n] != nnz + 1) FAIL(h, ESP_ERR_INVALID, "esp_set_csc: colptr[1]=%lld colptr[n+1]=%lld nnz=%lld violate the CSC invariants", (long long)colptr[0], (long long)colptr[h->n], (long long)nnz);
+    (void)hipSetDevice(h->device);
+    CK(ensure(h, h->colptr, sizeof(i64) * (size_t)(h->n + 1)));
+    CK(ensure(h, h->rowval, sizeof(i64) * (size_t)std::max<i64>(nnz, 1)));
+    CK(ensure(h, h->nzval, sizeof(double) * (size_t)std::max<i64>(nnz, 1)));
+    Span sp(h, ESP_ST_COPY);
+    HIPCK(h, hipMemcpyAsync(h->colptr.p, colptr, sizeof(i64) * (size_t)(h->n + 1), hipMemcpyHostToDevice, h->stream));
+    if (nnz > 0) {
+        HIPCK(h, hipMemcpyAsync(h->rowval.p, rowval, sizeof(i64) * (size_t)nnz, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(h->nzval.p, nzval, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, h->stream));
+    }
+    sp.add(3);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    h->nnz = nnz;
+    h->pattern_version++, h->values_version++;
+    h->csc_valid = true;
+    h->win_excl = false;  // (the uploaded CSC may hold entries outside a declared window)
+    h->tail_stale = false;
+    h->ones_pending = false;
+    return ESP_OK;
+}
+
+// Device -> pageable host memory (a Julia Vector, a NumPy array) through two pinned bounce buffers: the
+// PCIe transfer of chunk i+1 overlaps the (multi-threaded) host copy of chunk i.  A plain hipMemcpy into
+// pageable memory runs at ~10 GB/s here, this at ~45 GB/s.
+int32_t d2h_pipelined(esp_handle *h, void *dst, const void *d_src, size_t bytes) {
+    if (bytes == 0) return ESP_OK;
+    const size_t small = (size_t)8 << 20;
+    if (bytes <= small) {
+        HIPCK(h, hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        return ESP_OK;
+    }
+    CK(ensure_stage(h, h->bulk, (i64)1 << 22));  // rows / cols of the bulk area: 2 x 32 MiB pinned
+    char *pin[2] = {(char *)h->bulk.rows, (char *)h->bulk.cols};
+    const size_t chunk = (size_t)h->bulk.cap * 8;
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; i++) HIPCK(h, hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    const size_t nchunks = (bytes + chunk - 1) / chunk;
+    int32_t rc = ESP_OK;
+    for (size_t c = 0; c <= nchunks && rc == ESP_OK; c++) {
+        if (c < nchunks) {  // issue the transfer of chunk c
+            const size_t o = c * chunk, len = std::min(chunk, bytes - o);
+            if (hipMemcpyAsync(pin[c & 1], (const char *)d_src + o, len, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                hipEventRecord(ev[c & 1], h->stream) != hipSuccess)
+                rc = ESP_ERR_HIP;
+        }
+        if (c > 0 && rc == ESP_OK) {  // ... while chunk c-1 moves from its bounce buffer to the caller
+            const size_t o = (c - 1) * chunk, len = std::min(chunk, bytes - o);
+            if (hipEventSynchronize(ev[(c - 1) & 1]) != hipSuccess) rc = ESP_ERR_HIP;
+            else par_memcpy((char *)dst + o, pin[(c - 1) & 1], len);
+        }
+    }
+    (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 2; i++) (void)hipEventDestroy(ev[i]);
+    if (rc != ESP_OK) FAIL(h, ESP_ERR_HIP, "device-to-host transfer failed");
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_get_csc(esp_handle *h, int64_t *colptr, int64_t *rowval, double *nzval) {
+    if (!h || !colptr) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    CK(fix_tail(h));
+    if (h->nnz > 0 && (!rowval || !nzval)) FAIL(h, ESP_ERR_INVALID, "esp_get_csc: rowval/nzval NULL with nnz>0");
+    Span sp(h, ESP_ST_COPY);
+    CK(d2h_pipelined(h, colptr, h->colptr.p, sizeof(i64) * (size_t)(h->n + 1)));
+    if (h->nnz > 0) {
+        CK(d2h_pipelined(h, rowval, h->rowval.p, sizeof(i64) * (size_t)h->nnz));
+        CK(d2h_pipelined(h, nzval, h->nzval.p, sizeof(double) * (size_t)h->nnz));
+    }
+    sp.add(3);
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_get_nzval(esp_handle *h, double *nzval) {
+    if (!h) return ESP_ERR_INVALID;
+    if (h->nnz == 0) return ESP_OK;
+    if (!nzval) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    return d2h_pipelined(h, nzval, h->nzval.p, sizeof(double) * (size_t)h->nnz);
+}
+
+extern "C" int32_t esp_csc_device(esp_handle *h, const int64_t **d_colptr, const int64_t **d_rowval, const double **d_nzval) {
+    if (!h) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    CK(fix_tail(h));
+    if (d_colptr) *d_colptr = (const i64 *)h->colptr.p;
+    if (d_rowval) *d_rowval = (const i64 *)h->rowval.p;
+    if (d_nzval) *d_nzval = (const double *)h->nzval.p;
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_clear_pending(esp_handle *h) {
+    if (!h) return ESP_ERR_INVALID;
+    h->count = 0;
+    pending_changed(h);
+    return ESP_OK;
+}
+
+extern "C" int32_t esp_reset(esp_handle *h) {
+    if (!h) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    h->count = 0;
+    pending_changed(h);
+    return init_empty_csc(h);
+}
+
+extern "C" int32_t esp_zero_values(esp_handle *h) {
+    if (!h) return ESP_ERR_INVALID;
+    if (h->nnz == 0) return ESP_OK;
+    (void)hipSetDevice(h->device);
+    HIPCK(h, hipMemsetAsync(h->nzval.p, 0, sizeof(double) * (size_t)h->nnz, h->stream));
+    h->values_version++;
+    return ESP_OK;
+}
+
+
+// test/bench hook: 0 = automatic, 1 = (same as 0), 2 = force the general global path
+extern "C" int32_t esp_debug_force_path(esp_handle *h, int32_t path) {
+    if (!h) return ESP_ERR_INVALID;
+    h->force_path = path;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_last_run_order(const esp_handle *h, int32_t *kind) {
+    if (!h || !kind) return ESP_ERR_INVALID;
+    *kind = h->last_run_order;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_last_fold_update(const esp_handle *h, int32_t *on) {
+    if (!h || !on) return ESP_ERR_INVALID;
+    *on = h->last_fold_update;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_last_key_bytes(const esp_handle *h, int32_t *bytes) {
+    if (!h || !bytes) return ESP_ERR_INVALID;
+    *bytes = h->last_key_bytes;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_last_colptr_direct(const esp_handle *h, int32_t *direct) {
+    if (!h || !direct) return ESP_ERR_INVALID;
+    *direct = h->last_colptr_direct;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_last_partition(const esp_handle *h, int32_t *kind) {
+    if (!h || !kind) return ESP_ERR_INVALID;
+    *kind = h->last_partition;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_last_path(const esp_handle *h, int32_t *path) {
+    if (!h || !path) return ESP_ERR_INVALID;
+    *path = h->last_path;
+    return ESP_OK;
+}
+
+
+// ------------------------------------------------------------------------ measurement
+extern "C" int32_t esp_timing_enable(esp_handle *h, int32_t on) {
+    if (!h) return ESP_ERR_INVALID;
+    timing_collect(h);
+    h->timing = on != 0;
+    h->timing_level = (on == 1 || on == 3) ? on : 2;  // 1: big kernels; 3: bucket / fold kernel only; else every stage
+    return ESP_OK;
+}
+extern "C" int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear) {
+    if (!h || !out) return ESP_ERR_INVALID;
+    timing_collect(h);
+    *out = h->acc;
+    if (clear) memset(&h->acc, 0, sizeof h->acc);
+    return ESP_OK;
+}
+

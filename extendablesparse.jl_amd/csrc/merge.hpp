@@ -46,7 +46,7 @@ __device__ __forceinline__ i64 diag_search(const Args &a, i64 diag) {
     return lo;
 }
 
-__global__ __launch_bounds__(THREADS) void merge_k(Args a) {
+static __global__ __launch_bounds__(THREADS) void merge_k(Args a) {
     __shared__ u64 lk[TILE];
     __shared__ double lv[TILE];
     __shared__ i64 split[2];
@@ -132,7 +132,7 @@ struct ColArgs {
 // NEWCAP of them searches global memory), every thread handles MB entries per round with all their loads requested
 // first, and the searches of a round's entries advance together (a binary search is a chain of dependent loads).
 constexpr int NEWCAP = 1024, MB = 4;
-__global__ __launch_bounds__(THREADS) void colmerge_k(ColArgs a) {
+static __global__ __launch_bounds__(THREADS) void colmerge_k(ColArgs a) {
     __shared__ i64 s_cp[CT + 1];
     __shared__ u64 s_ns[CT + 1];
     __shared__ u64 s_new[NEWCAP];

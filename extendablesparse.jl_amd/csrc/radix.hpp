@@ -79,7 +79,7 @@ __device__ __forceinline__ int find_segment(const i64 *__restrict__ tile_first, 
     return lo;
 }
 
-__global__ __launch_bounds__(THREADS) void tile_hist_k(Pass p) {
+static __global__ __launch_bounds__(THREADS) void tile_hist_k(Pass p) {
     __shared__ u32 cnt[RADIX];
     const int t = threadIdx.x;
     const i64 tile = xcd_tile();
@@ -145,7 +145,7 @@ __global__ __launch_bounds__(THREADS) void tile_hist_k(Pass p) {
 // NINE: digits of 9 bits (two per thread, the digit of an output slot recomputed from its key); else at most 8 bits (one
 // digit per thread, the slot's digit kept in an LDS byte): the 8-bit passes of 3-D FEM lost 5 % in the general form.
 template <bool NINE>
-__global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
+static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
     constexpr int RDX = NINE ? RADIX : 256;
     __shared__ u64 lbuf[TILE];
     __shared__ u32 cnt[WAVES][RDX];
@@ -317,7 +317,7 @@ __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
 }
 
 // after the scan: start of segment (s,d) = hist[tile_first[s]*R + d*ntiles_s]
-__global__ void new_segments_k(const u64 *__restrict__ hist, const i64 *__restrict__ seg_start,
+static __global__ void new_segments_k(const u64 *__restrict__ hist, const i64 *__restrict__ seg_start,
                                const i64 *__restrict__ tile_first, int S, int bits,
                                i64 *__restrict__ new_seg_start, i64 total) {
     const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -336,7 +336,7 @@ __global__ void new_segments_k(const u64 *__restrict__ hist, const i64 *__restri
 }
 
 // tiles per segment -> tile_first by exclusive scan (caller scans); also max segment length
-__global__ void seg_tiles_k(const i64 *__restrict__ seg_start, i64 S, i64 tile, u64 *__restrict__ ntiles,
+static __global__ void seg_tiles_k(const i64 *__restrict__ seg_start, i64 S, i64 tile, u64 *__restrict__ ntiles,
                             unsigned long long *__restrict__ maxlen) {
     const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (g > S) return;

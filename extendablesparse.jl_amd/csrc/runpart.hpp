@@ -277,7 +277,7 @@ __device__ __forceinline__ void count_runs_weighted(const u32 (&dig)[NITEMS], co
 }
 
 template <bool MULTI, bool RAW = false>
-__global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_chunk) {
+static __global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_chunk) {
     __shared__ u32 rd[RMAX];
     __shared__ u32 rc[RMAX];
     __shared__ u32 over;
@@ -331,7 +331,7 @@ __global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_chunk) {
 }
 
 // dense run list in tile order: sortable records (key = digit << 2, payload = tile|j|count)
-__global__ void run_pack_k(const u32 *__restrict__ runs_d, const u32 *__restrict__ runs_c,
+static __global__ void run_pack_k(const u32 *__restrict__ runs_d, const u32 *__restrict__ runs_c,
                            const u64 *__restrict__ run_base /* exclusive scan of nruns, T+1 */, i64 T,
                            u64 *__restrict__ lk, double *__restrict__ lv) {
     const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -346,21 +346,21 @@ __global__ void run_pack_k(const u32 *__restrict__ runs_d, const u32 *__restrict
     lv[b + j] = __longlong_as_double((long long)payload);
 }
 
-__global__ void run_counts_k(const double *__restrict__ lv, i64 R, u64 *__restrict__ cnt) {
+static __global__ void run_counts_k(const double *__restrict__ lv, i64 R, u64 *__restrict__ cnt) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i > R) return;
     cnt[i] = i < R ? ((u64)__double_as_longlong(lv[i]) & 0xFFFFull) : 0ull;
 }
 
 // head[d] = scanned count at the first record of digit d
-__global__ void run_heads_k(const u64 *__restrict__ lk, const u64 *__restrict__ sc, i64 R, u64 *__restrict__ head) {
+static __global__ void run_heads_k(const u64 *__restrict__ lk, const u64 *__restrict__ sc, i64 R, u64 *__restrict__ head) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= R) return;
     const u64 d = lk[i] >> ESP_TAG_BITS;
     if (i == 0 || (lk[i - 1] >> ESP_TAG_BITS) != d) head[d] = sc[i];
 }
 
-__global__ void run_offsets_k(const u64 *__restrict__ lk, const double *__restrict__ lv, const u64 *__restrict__ sc,
+static __global__ void run_offsets_k(const u64 *__restrict__ lk, const double *__restrict__ lv, const u64 *__restrict__ sc,
                               const u64 *__restrict__ head, const u64 *__restrict__ bucket_start, i64 R,
                               i64 *__restrict__ runs_off) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -381,7 +381,7 @@ __global__ void run_offsets_k(const u64 *__restrict__ lk, const double *__restri
 //                   (<= DCAP of them, a handful on a pre-sorted stream: quadratic walk over an LDS copy)
 //     maxlen      = the longest bucket; *too_many = 1 when some digit has more than DCAP runs (the host
 //                   then orders the run list with the radix passes instead)
-__global__ __launch_bounds__(THREADS) void run_coarse_k(const unsigned long long *__restrict__ bucket_count, i64 nb,
+static __global__ __launch_bounds__(THREADS) void run_coarse_k(const unsigned long long *__restrict__ bucket_count, i64 nb,
                                                          u64 *__restrict__ coarse) {
     __shared__ u64 lw[WAVES];
     const i64 d = (i64)blockIdx.x * THREADS + threadIdx.x;
@@ -390,7 +390,7 @@ __global__ __launch_bounds__(THREADS) void run_coarse_k(const unsigned long long
     if (threadIdx.x == 0) coarse[blockIdx.x] = tot;
 }
 
-__global__ __launch_bounds__(THREADS) void run_rank_k(const unsigned long long *__restrict__ bucket_count,
+static __global__ __launch_bounds__(THREADS) void run_rank_k(const unsigned long long *__restrict__ bucket_count,
                                                        const u64 *__restrict__ coarse, const u32 *__restrict__ dcount,
                                                        const u64 *__restrict__ dlist, i64 nb, i64 *__restrict__ seg_out,
                                                        i64 *__restrict__ runs_off, unsigned long long *maxlen, u32 *too_many) {
@@ -479,7 +479,7 @@ __device__ __forceinline__ void rank_in_runs(u32 (&dig)[NI], const u32 *hd, cons
 // (tried for RAW: four workgroups per CU through __launch_bounds__ -- 128 VGPRs instead of the K32 store loop's 152 -- costs
 // 76 bytes of scratch per lane)
 template <bool MULTI, bool K32, bool RAW = false>
-__global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
+static __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
     __shared__ u64 s_mw[MULTI ? MW_MAX : 1];
     __shared__ u32 hd[RMAX];  // open-addressing map digit -> run index of this tile
     __shared__ u32 hj[RMAX];
@@ -892,7 +892,7 @@ __device__ __forceinline__ u32 column_digit(const PartOut &p, i64 col0, int rb, 
 
 // 4-byte keys of a bucket-ordered pending buffer back to packed keys (any call that reads or extends the pending
 // entries other than the flush they were written for): one workgroup per bucket
-__global__ __launch_bounds__(THREADS) void expand_keys_k(const u32 *__restrict__ k32, const i64 *__restrict__ seg_start, int shift,
+static __global__ __launch_bounds__(THREADS) void expand_keys_k(const u32 *__restrict__ k32, const i64 *__restrict__ seg_start, int shift,
                                                          u64 base, u32 kind, u64 *__restrict__ out) {
     const i64 s = blockIdx.x;
     const i64 b = seg_start[s], e = seg_start[s + 1];
@@ -902,7 +902,7 @@ __global__ __launch_bounds__(THREADS) void expand_keys_k(const u32 *__restrict__
 
 // the same for a shard's own window (digits [d0, d0 + nb) of the multi-window partition): 4-byte keys at
 // own_keys32(keys, own_lo)[p] -> packed keys at out[p]
-__global__ __launch_bounds__(THREADS) void expand_own_keys_k(const u64 *__restrict__ keys, const i64 *__restrict__ seg_start, i64 d0,
+static __global__ __launch_bounds__(THREADS) void expand_own_keys_k(const u64 *__restrict__ keys, const i64 *__restrict__ seg_start, i64 d0,
                                                              int shift, u64 base, u32 kind, u64 *__restrict__ out) {
     const i64 s = blockIdx.x;
     const i64 own_lo = seg_start[d0];

@@ -49,7 +49,7 @@ __device__ __forceinline__ T block_exclusive(T v, T *lds_wave /*THREADS/64*/, T 
 }
 
 template <typename T, bool MAX>
-__global__ __launch_bounds__(THREADS) void reduce_k(const T *__restrict__ in, i64 n,
+static __global__ __launch_bounds__(THREADS) void reduce_k(const T *__restrict__ in, i64 n,
                                                     T *__restrict__ partial) {
     __shared__ T lw[THREADS / 64];
     const i64 base = (i64)blockIdx.x * CHUNK;
@@ -66,7 +66,7 @@ __global__ __launch_bounds__(THREADS) void reduce_k(const T *__restrict__ in, i6
 
 // addend: added to every output (e.g. the 1 of a 1-based colptr), outside the scan operation
 template <typename T, bool MAX>
-__global__ __launch_bounds__(THREADS) void apply_k(const T *in, T *out, i64 n,
+static __global__ __launch_bounds__(THREADS) void apply_k(const T *in, T *out, i64 n,
                                                    const T *__restrict__ carry_in, T addend) {
     __shared__ T tile[CHUNK + ITEMS];
     __shared__ T lw[THREADS / 64];

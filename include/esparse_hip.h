@@ -320,22 +320,40 @@ int32_t esp_set_column_window(esp_handle *h, int64_t col_lo, int64_t col_hi);
  * records of about 6 us on the stream; 0: off */
 int32_t esp_timing_enable(esp_handle *h, int32_t on);
 int32_t esp_timing(esp_handle *h, esp_timing_t *out, int32_t clear);
-/* test hooks: path 0 = automatic, 2 = force the general path (global LSD sort + global fold),
- * 3 = LDS bucket path with its radix tail only (no column tiers), 4 = bucket kernel issued in
- * launches of 64 workgroups (exercises the carry-over of the look-back state), 5 = never use the
- * run-based single-pass partition (8-bit passes only; the producers append in stream order), 11 = esp_shard_partition reports "not applicable",
- * 12 = the run-based partition orders its run list with radix passes (several small launches and a host round
- * trip) instead of the one ranking kernel, 14 = packed 8-byte keys for the bucket kernel always, 15 = 4-byte keys but the generic fold (no UPDATE-only
- * variant of the register tiers),
- * 13 = the bucket kernel of a fresh matrix marks column ends and a scan
- * over all columns builds colptr (instead of every segment writing the colptr of its own columns),
- * 16 = the device-side producers (esp_generate_*) always append in stream order (never the producer-side partition),
- * 17 = the join with an existing CSC runs as a merge-path over a per-entry column array (a second implementation of the
- *      column-tiled join), 18 = never the small variant of the bucket kernel (see esp_debug_last_local_small),
- * 19 = an append behind a producer's bucket-ordered batch turns it back into packed keys (no "batch + tail" flush),
- * 22 = a batch + tail over a stored pattern is ONE flush over two pieces (as on a fresh matrix) instead of two flushes,
- * 23 = partition passes of at most 8 bits (no 9-bit digits where they would save a pass);
- * last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general) */
+/* Test hooks: esp_debug_force_path(h, path) pins ONE implementation where the library has two (results never change,
+ * timings do); path 0 = automatic.  The numbers are part of the ABI (the tests and tools pass them). */
+typedef enum {
+    ESP_PATH_AUTO = 0,
+    ESP_PATH_GENERAL = 2,            /* the general path: global LSD sort + global fold (no bucket kernel)                  */
+    ESP_PATH_RADIX_TAIL_ONLY = 3,    /* bucket kernel with its radix tier only (no column tiers, no small variant)          */
+    ESP_PATH_MANY_LAUNCHES = 4,      /* bucket kernel issued in launches of 64 workgroups (carry-over of the look-back state) */
+    ESP_PATH_NO_RUN_PARTITION = 5,   /* never the run-based single-pass partition: 8/9-bit passes only; producers append in
+                                        stream order                                                                        */
+    ESP_PATH_SHARD_NOT_APPLICABLE = 11, /* esp_shard_partition reports "not applicable" (consensus fall-back of the exchange) */
+    ESP_PATH_RUN_LIST_BY_RADIX = 12, /* the run-based partition orders its run list with radix passes (several small launches
+                                        and a host round trip) instead of the one ranking kernel                            */
+    ESP_PATH_COLPTR_BY_SCAN = 13,    /* fresh matrix: the bucket kernel marks column ends and a scan over all columns builds
+                                        colptr (instead of every segment writing the colptr of its own columns)             */
+    ESP_PATH_PACKED_KEYS = 14,       /* packed 8-byte keys for the bucket kernel always (never 4-byte keys)                  */
+    ESP_PATH_GENERIC_FOLD = 15,      /* 4-byte keys but the generic fold (no UPDATE-only / one-kind variants)                */
+    ESP_PATH_PRODUCER_STREAM_ORDER = 16, /* device-side producers and bulk appends always write in stream order (never the
+                                        producer-side partition); the flush partitions                                      */
+    ESP_PATH_MERGE_PATH_JOIN = 17,   /* the join with a stored CSC as a merge-path over a per-entry column array (a second
+                                        implementation of the column-tiled join)                                            */
+    ESP_PATH_NO_SMALL_VARIANT = 18,  /* never the small variant of the bucket kernel (see esp_debug_last_local_small)        */
+    ESP_PATH_NO_BATCH_TAIL = 19,     /* an append behind a producer's bucket-ordered batch turns it back into packed keys
+                                        (no "batch + tail" flush)                                                           */
+    ESP_PATH_BATCH_TAIL_ONE_FLUSH = 22, /* a batch + tail over a stored pattern is ONE flush over two pieces (as on a fresh
+                                        matrix) instead of two flushes                                                      */
+    ESP_PATH_EIGHT_BIT_PASSES = 23,  /* partition passes of at most 8 bits (no 9-bit digits where they would save a pass)    */
+    ESP_PATH_NO_GROUP_TIER = 24,     /* bucket kernel: column runs of more than 24 entries through the radix tier, never the
+                                        group tier (2 .. 16 lanes per column)                                               */
+    ESP_PATH_NO_ITEM_PARTITION = 25, /* esp_generate_fem in a shuffled order appends in stream order (no item partition)     */
+    ESP_PATH_NO_BIG_VARIANT = 26,    /* never the bucket-kernel variant with the 24-input register tier                      */
+    ESP_PATH_NO_APPEND_PARTITION = 27 /* esp_append_* / esp_commit on an empty buffer pack in stream order (the append is not
+                                        the partition)                                                                      */
+} esp_debug_path;
+/* last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general) */
 int32_t esp_debug_force_path(esp_handle *h, int32_t path);
 int32_t esp_debug_last_path(const esp_handle *h, int32_t *path);
 /* how the last run-based partition turned its run lists into offsets: 1 = one ranking kernel over per-digit run
