@@ -11,7 +11,7 @@ from .matrix import (ExtendableSparseMatrix, GenericExtendableSparseMatrixCSC,
                      GenericMTExtendableSparseMatrixCSC, SparseMatrixCSC, SparseMatrixHIPCOO)
 from . import fdrand as fdrand_module
 from .fdrand import fdrand, fdrand_, fdrand_coo, fdrand_device_
-from .sharded import GroupShardedMatrix, HipShardBackend, ShardedExtendableSparseMatrix, owner_ranges
+from .sharded import GroupShardedMatrix, owner_ranges
 
 # aliases mirroring src/ExtendableSparse.jl:34-39
 ExtendableSparseMatrixCSC = ExtendableSparseMatrix

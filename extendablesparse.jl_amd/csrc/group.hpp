@@ -1,5 +1,6 @@
 // group.hpp -- column-range shards across the GPUs of a node, one process per GPU: the
-// esp_group_* entry points.  Included at the end of esparse_hip.hip (it drives the esp_shard_* calls of one handle).
+// esp_group_* entry points.  Included at the end of shard.hip (it drives the esp_shard_* calls of one handle); the exchange
+// POLICY is group_policy.hpp (host-only), this file binds it to the device and holds the RCCL transport.
 //
 // What the reference does with threads -- GenericMTExtendableSparseMatrixCSC: one buffer per `tid`, flush! =
 // Base.sum(xmatrices, csc) (src/matrix/genericmtextendablesparsematrixcsc.jl:45-51,87-99) -- happens here across
@@ -16,6 +17,8 @@
 #pragma once
 #include <dlfcn.h>
 #include <rccl/rccl.h>
+
+#include "group_policy.hpp"
 
 struct RcclApi {
     void *lib = nullptr;
@@ -69,18 +72,10 @@ static bool rccl_load() {
 struct esp_group {
     esp_handle *h = nullptr;
     int P = 1, me = 0;
-    esp_comm_t comm{};       // the transport in use (RCCL-backed table or the host's)
+    espgroup::Policy pol;    // the exchange policy (group_policy.hpp: host-only, also run under sanitizers by a CPU test)
     bool own_rccl = false;
     ncclComm_t nccl = nullptr;
     DevBuf ag;               // staging of the small all-gathers (RCCL transport)
-    // exchange policy (every decision that changes the communication pattern is taken from all-gathered data)
-    i64 eps = -1;            // entries per shard of the previous flush: fixes the digit width of the partitioned exchange
-    int part_skip = 0, part_penalty = 0;
-    int last_exchange = 0;   // 1 partitioned, 2 in place
-    i64 sent_off_rank = 0;
-    i64 local_nnz = 0;
-    std::vector<i64> nnz_offsets;  // P + 1, valid when offsets_valid
-    bool offsets_valid = false;
     DevBuf rkeys, rvals, rcnts;    // receive buffers: alive until the local flush has read them
     // test hook (esp_debug_group_loopback; a single-rank group over the library's RCCL transport): nothing is skipped
     // because there is only one rank -- the small agreements run as a real ncclAllGather on the second stream, and every
@@ -162,6 +157,7 @@ extern "C" int32_t esp_group_unique_id(uint8_t *id128) {
     return ESP_OK;
 }
 
+static void bind_shard_ops(esp_group *g);
 static int32_t group_common(esp_handle *h, int32_t nranks, int32_t rank, esp_group **out, esp_group **made) {
     if (!h || !out) return ESP_ERR_INVALID;
     *out = nullptr;
@@ -171,7 +167,8 @@ static int32_t group_common(esp_handle *h, int32_t nranks, int32_t rank, esp_gro
     g->h = h;
     g->P = nranks;
     g->me = rank;
-    g->nnz_offsets.assign((size_t)nranks + 1, 0);
+    g->pol.init(nranks, rank);
+    bind_shard_ops(g);
     h->shard_user = true;
     const i64 c0 = shard_col0(h->n, nranks, rank), c1 = shard_col0(h->n, nranks, rank + 1);
     if (c1 > c0) {  // after the exchange every pending column is owned: flushes and reset! work on the own range only
@@ -199,9 +196,9 @@ extern "C" int32_t esp_group_create(esp_handle *h, int32_t nranks, int32_t rank,
         FAIL(h, ESP_ERR_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
     }
     g->own_rccl = true;
-    g->comm.ctx = g;
-    g->comm.allgather_i64 = rccl_allgather_i64;
-    g->comm.alltoallv_dev = rccl_alltoallv;
+    g->pol.comm.ctx = g;
+    g->pol.comm.allgather_i64 = rccl_allgather_i64;
+    g->pol.comm.alltoallv_dev = rccl_alltoallv;
     *out = g;
     return ESP_OK;
 }
@@ -210,7 +207,7 @@ extern "C" int32_t esp_group_create_comm(esp_handle *h, int32_t nranks, int32_t 
     if (!comm || !comm->allgather_i64 || !comm->alltoallv_dev) return ESP_ERR_INVALID;
     esp_group *g = nullptr;
     CK(group_common(h, nranks, rank, out, &g));
-    g->comm = *comm;
+    g->pol.comm = *comm;
     *out = g;
     return ESP_OK;
 }
@@ -246,20 +243,8 @@ extern "C" int32_t esp_group_column_range(const esp_group *g, int64_t *col_lo, i
 }
 
 // ---- the exchange -----------------------------------------------------------------------------------
-// all_gather of a small int64 vector -> P x len (same on every rank)
-static int32_t gather_ints(esp_group *g, const std::vector<i64> &mine, std::vector<i64> *all) {
-    all->assign(mine.size() * (size_t)g->P, 0);
-    const int32_t st = g->comm.allgather_i64(g->comm.ctx, mine.data(), (int32_t)mine.size(), all->data());
-    if (st != ESP_OK) GFAIL(g, st, "esp_group: all-gather failed (%d)%s%s", st, g->err.empty() ? "" : ": ", g->err.c_str());
-    return ESP_OK;
-}
-static int32_t exchange(esp_group *g, const std::vector<const void *> &sp, const std::vector<i64> &sb, const std::vector<void *> &rp,
-                        const std::vector<i64> &rb) {
-    if (g->P == 1) return ESP_OK;
-    const int32_t st = g->comm.alltoallv_dev(g->comm.ctx, sp.data(), sb.data(), rp.data(), rb.data(), (void *)g->h->stream);
-    if (st != ESP_OK) GFAIL(g, st, "esp_group: all-to-all-v failed (%d)%s%s", st, g->err.empty() ? "" : ": ", g->err.c_str());
-    return ESP_OK;
-}
+// The policy (consensus, back-off, offsets, who sends what to whom) is espgroup::Policy (group_policy.hpp); here: what it
+// asks of the shard, bound to the esp_shard_* calls on the device, and the loop-back test hook.
 
 // loop-back test hook: `bytes` at `ptr` (device) go to this very rank through the library's RCCL all-to-all-v, the source
 // is wiped and then restored from what arrived -- all on the handle's stream, like a real exchange
@@ -288,157 +273,58 @@ extern "C" int32_t esp_debug_group_loopback(esp_group *g, int32_t on, int64_t *b
     return ESP_OK;
 }
 
-// One partition pass per rank (owner split + first pass of the local flush: esp_shard_partition), ranges and per-digit
-// counts to the owners, pieces assembled without a copy (esp_shard_assemble).  *done = false when the ranks agreed to
-// use the in-place exchange for this flush (some rank's stream is not pre-sorted, or the plan does not apply).
-static int32_t group_exchange_partitioned(esp_group *g, bool *done) {
-    *done = false;
-    esp_handle *h = g->h;
-    const int P = g->P, me = g->me;
-    if (g->part_skip > 0) {
-        g->part_skip--;
+static void bind_shard_ops(esp_group *g) {
+    espgroup::ShardOps &o = g->pol.ops;
+    o.ctx = g;
+    o.pending = [](void *c, i64 *count) -> int32_t {
+        *count = static_cast<esp_group *>(c)->h->count;
         return ESP_OK;
-    }
-    std::vector<i64> all;
-    if (g->eps < 0) {  // first flush: the digit width comes from the global number of entries
-        CK(gather_ints(g, {h->count}, &all));
-        i64 sum = 0;
-        for (i64 x : all) sum += x;
-        g->eps = (sum + P - 1) / P;
-    }
-    int32_t ok = 0;
-    uint64_t *dk = nullptr;
-    double *dv = nullptr;
-    int64_t *dc = nullptr;
-    std::vector<i64> eoff((size_t)P + 1, 0);
-    int64_t nb = 0;
-    CK(esp_shard_partition(h, P, me, g->eps, &ok, &dk, &dv, &dc, eoff.data(), &nb));
-    if (ok) {  // (loop-back hook: the partitioned ranges -- all the rank's own -- travel through RCCL; 4-byte keys lie inside them)
-        CK(loopback_roundtrip(g, dk, 8 * eoff[(size_t)P]));
-        CK(loopback_roundtrip(g, dv, 8 * eoff[(size_t)P]));
-    }
-    std::vector<i64> mine((size_t)P + 1, 0);
-    mine[0] = ok ? 1 : 0;
-    for (int r = 0; r < P; r++) mine[(size_t)r + 1] = ok ? eoff[(size_t)r + 1] - eoff[(size_t)r] : 0;
-    CK(gather_ints(g, mine, &all));
-    const size_t W = (size_t)P + 1;
-    bool all_ok = true;
-    i64 total = 0;
-    for (int q = 0; q < P; q++) {
-        all_ok = all_ok && all[(size_t)q * W] != 0;
-        for (int r = 0; r < P; r++) total += all[(size_t)q * W + 1 + (size_t)r];
-    }
-    if (!all_ok) {  // plain exchange now and for the next few flushes (the pending entries are intact)
-        g->part_penalty = std::min(16, 2 * g->part_penalty + 1);
-        g->part_skip = g->part_penalty;
-        g->eps = -1;
-        (void)esp_shard_plan(h, P, me, -1);
+    };
+    o.partition = [](void *c, int P, int me, i64 eps, int32_t *ok, void **k, void **v, void **cnt, i64 *eoff, i64 *nb) -> int32_t {
+        return esp_shard_partition(static_cast<esp_group *>(c)->h, P, me, eps, ok, reinterpret_cast<uint64_t **>(k), reinterpret_cast<double **>(v),
+                                   reinterpret_cast<int64_t **>(cnt), eoff, nb);
+    };
+    o.plan = [](void *c, int P, int me, i64 eps) -> int32_t { return esp_shard_plan(static_cast<esp_group *>(c)->h, P, me, eps); };
+    o.assemble = [](void *c, const void *const *rk, const void *const *rv, const void *const *rc, const i64 *n, int32_t *ok) -> int32_t {
+        return esp_shard_assemble(static_cast<esp_group *>(c)->h, reinterpret_cast<const uint64_t *const *>(rk), reinterpret_cast<const double *const *>(rv),
+                                  reinterpret_cast<const int64_t *const *>(rc), n, ok);
+    };
+    o.counts = [](void *c, int P, i64 *counts) -> int32_t { return esp_shard_counts(static_cast<esp_group *>(c)->h, P, counts); };
+    o.exchange_begin = [](void *c, int P, int me, i64 lower, i64 higher, void **sk, void **sv, i64 *soff) -> int32_t {
+        return esp_shard_exchange_begin(static_cast<esp_group *>(c)->h, P, me, lower, higher, reinterpret_cast<uint64_t **>(sk),
+                                        reinterpret_cast<double **>(sv), soff);
+    };
+    o.exchange_place = [](void *c, i64 pos, const void *k, const void *v, i64 n) -> int32_t {
+        return esp_shard_exchange_place(static_cast<esp_group *>(c)->h, pos, static_cast<const uint64_t *>(k), static_cast<const double *>(v), n);
+    };
+    o.recv_buffers = [](void *c, i64 nrecv, i64 ncounts, void **rk, void **rv, void **rc) -> int32_t {
+        esp_group *g = static_cast<esp_group *>(c);
+        esp_handle *h = g->h;
+        CK(ensure(h, g->rkeys, sizeof(u64) * (size_t)std::max<i64>(nrecv, 1)));
+        CK(ensure(h, g->rvals, sizeof(double) * (size_t)std::max<i64>(nrecv, 1)));
+        CK(ensure(h, g->rcnts, sizeof(i64) * (size_t)std::max<i64>(ncounts, 1)));
+        *rk = g->rkeys.p, *rv = g->rvals.p, *rc = g->rcnts.p;
         return ESP_OK;
-    }
-    g->part_penalty = 0;
-    g->eps = total ? (total + P - 1) / P : -1;
-    // the producers of the NEXT assembly partition for the next flush's esp_shard_partition themselves (the append is
-    // the partition, as on one GPU): every rank knows the same entries-per-shard from this flush's all-gather
-    (void)esp_shard_plan(h, P, me, g->eps);
-    std::vector<i64> in_x((size_t)P, 0), out_x((size_t)P, 0), ro((size_t)P + 1, 0);
-    i64 sent = 0;
-    for (int r = 0; r < P; r++) {
-        in_x[(size_t)r] = r == me ? 0 : mine[(size_t)r + 1];
-        out_x[(size_t)r] = r == me ? 0 : all[(size_t)r * W + 1 + (size_t)me];
-        sent += in_x[(size_t)r];
-        ro[(size_t)r + 1] = ro[(size_t)r] + out_x[(size_t)r];
-    }
-    const i64 nrecv = ro[(size_t)P];
-    CK(ensure(h, g->rkeys, sizeof(u64) * (size_t)std::max<i64>(nrecv, 1)));
-    CK(ensure(h, g->rvals, sizeof(double) * (size_t)std::max<i64>(nrecv, 1)));
-    CK(ensure(h, g->rcnts, sizeof(i64) * (size_t)P * (size_t)std::max<i64>(nb, 1)));
-    // three grouped launches -- keys, values, counts -- each with every pair's send and receive, stream-ordered behind
-    // the partition's scatter kernel: no host synchronisation
-    std::vector<const void *> sp((size_t)P, nullptr);
-    std::vector<void *> rp((size_t)P, nullptr);
-    std::vector<i64> sb((size_t)P, 0), rb((size_t)P, 0);
-    for (int pass = 0; pass < 3; pass++) {
-        for (int q = 0; q < P; q++) {
-            if (q == me) continue;
-            if (pass == 0) {
-                sp[(size_t)q] = dk + eoff[(size_t)q], sb[(size_t)q] = 8 * in_x[(size_t)q];
-                rp[(size_t)q] = (u64 *)g->rkeys.p + ro[(size_t)q], rb[(size_t)q] = 8 * out_x[(size_t)q];
-            } else if (pass == 1) {
-                sp[(size_t)q] = dv + eoff[(size_t)q], sb[(size_t)q] = 8 * in_x[(size_t)q];
-                rp[(size_t)q] = (double *)g->rvals.p + ro[(size_t)q], rb[(size_t)q] = 8 * out_x[(size_t)q];
-            } else {
-                sp[(size_t)q] = dc + (size_t)q * (size_t)nb, sb[(size_t)q] = 8 * nb;
-                rp[(size_t)q] = (i64 *)g->rcnts.p + (size_t)q * (size_t)nb, rb[(size_t)q] = 8 * nb;
-            }
+    };
+    o.flush = [](void *c, int32_t mode, i64 *local_nnz, int32_t *changed) -> int32_t {
+        esp_handle *h = static_cast<esp_group *>(c)->h;
+        int64_t z = 0;
+        CK(esp_flush(h, mode, &z, changed));  // (returns after the bucket kernel has read the receive buffers)
+        *local_nnz = h->nnz;
+        return ESP_OK;
+    };
+    o.stream = [](void *c) -> void * { return (void *)static_cast<esp_group *>(c)->h->stream; };
+    o.after_split = [](void *c, int partitioned, void *keys, void *vals, i64 entries) -> int32_t {
+        esp_group *g = static_cast<esp_group *>(c);
+        if (!g->loopback) return ESP_OK;
+        esp_handle *h = g->h;
+        if (partitioned) {  // (the partitioned ranges -- all the rank's own -- travel through RCCL; 4-byte keys lie inside them)
+            CK(loopback_roundtrip(g, keys, 8 * entries));
+            return loopback_roundtrip(g, vals, 8 * entries);
         }
-        CK(exchange(g, sp, sb, rp, rb));
-    }
-    std::vector<const uint64_t *> rk((size_t)P, nullptr);
-    std::vector<const double *> rv((size_t)P, nullptr);
-    std::vector<const int64_t *> rc((size_t)P, nullptr);
-    for (int q = 0; q < P; q++) {
-        rk[(size_t)q] = (const u64 *)g->rkeys.p + ro[(size_t)q];
-        rv[(size_t)q] = (const double *)g->rvals.p + ro[(size_t)q];
-        rc[(size_t)q] = (const i64 *)g->rcnts.p + (size_t)q * (size_t)nb;
-    }
-    int32_t ok2 = 0;
-    CK(esp_shard_assemble(h, rk.data(), rv.data(), rc.data(), out_x.data(), &ok2));  // (ok2 = 0: plain pending buffer instead)
-    g->sent_off_rank = sent;
-    g->last_exchange = 1;
-    *done = true;
-    return ESP_OK;
-}
-
-// any stream: stable partition by owner, the own chunk stays where it is (esp_shard_exchange_begin / _place)
-static int32_t group_exchange_inplace(esp_group *g) {
-    esp_handle *h = g->h;
-    const int P = g->P, me = g->me;
-    std::vector<i64> counts((size_t)P, 0), all;
-    CK(esp_shard_counts(h, P, counts.data()));
-    CK(gather_ints(g, counts, &all));
-    std::vector<i64> in_x((size_t)P, 0), out_x((size_t)P, 0), ro((size_t)P + 1, 0);
-    i64 lower = 0, higher = 0, sent = 0;
-    for (int q = 0; q < P; q++) {
-        in_x[(size_t)q] = q == me ? 0 : counts[(size_t)q];
-        out_x[(size_t)q] = q == me ? 0 : all[(size_t)q * (size_t)P + (size_t)me];
-        (q < me ? lower : higher) += out_x[(size_t)q];
-        sent += in_x[(size_t)q];
-        ro[(size_t)q + 1] = ro[(size_t)q] + out_x[(size_t)q];
-    }
-    uint64_t *sk = nullptr;
-    double *sv = nullptr;
-    std::vector<i64> soff((size_t)P + 1, 0);
-    CK(esp_shard_exchange_begin(h, P, me, lower, higher, &sk, &sv, soff.data()));
-    if (g->loopback) {  // (loop-back hook, one rank: the pending buffer is the own chunk)
-        CK(loopback_roundtrip(g, h->keys.p, 8 * h->count));
-        CK(loopback_roundtrip(g, h->vals.p, 8 * h->count));
-    }
-    const i64 nrecv = lower + higher;
-    CK(ensure(h, g->rkeys, sizeof(u64) * (size_t)std::max<i64>(nrecv, 1)));
-    CK(ensure(h, g->rvals, sizeof(double) * (size_t)std::max<i64>(nrecv, 1)));
-    std::vector<const void *> sp((size_t)P, nullptr);
-    std::vector<void *> rp((size_t)P, nullptr);
-    std::vector<i64> sb((size_t)P, 0), rb((size_t)P, 0);
-    for (int pass = 0; pass < 2; pass++) {
-        for (int q = 0; q < P; q++) {
-            if (q == me) continue;
-            sb[(size_t)q] = 8 * in_x[(size_t)q];
-            rb[(size_t)q] = 8 * out_x[(size_t)q];
-            if (pass == 0) {
-                sp[(size_t)q] = sk + soff[(size_t)q];
-                rp[(size_t)q] = (u64 *)g->rkeys.p + ro[(size_t)q];
-            } else {
-                sp[(size_t)q] = sv + soff[(size_t)q];
-                rp[(size_t)q] = (double *)g->rvals.p + ro[(size_t)q];
-            }
-        }
-        CK(exchange(g, sp, sb, rp, rb));
-    }
-    CK(esp_shard_exchange_place(h, 0, (const u64 *)g->rkeys.p, (const double *)g->rvals.p, lower));
-    CK(esp_shard_exchange_place(h, lower + counts[(size_t)me], (const u64 *)g->rkeys.p + lower, (const double *)g->rvals.p + lower, higher));
-    g->sent_off_rank = sent;
-    g->last_exchange = 2;
-    return ESP_OK;
+        CK(loopback_roundtrip(g, h->keys.p, 8 * h->count));  // (one rank: the pending buffer is the own chunk)
+        return loopback_roundtrip(g, h->vals.p, 8 * h->count);
+    };
 }
 
 // COLLECTIVE: every rank of the group calls it (like flush! of the MT wrapper it is the synchronisation point)
@@ -448,24 +334,17 @@ extern "C" int32_t esp_group_flush(esp_group *g, int32_t mode, int64_t *local_nn
     (void)hipSetDevice(h->device);
     g->err.clear();
     g->loop_bytes = 0;
-    bool done = false;
-    CK(group_exchange_partitioned(g, &done));
-    if (!done) CK(group_exchange_inplace(g));
-    int64_t z = 0;
-    CK(esp_flush(h, mode, &z, pattern_changed));  // (returns after the bucket kernel has read the receive buffers)
-    g->local_nnz = h->nnz;
-    g->offsets_valid = false;
-    if (local_nnz) *local_nnz = h->nnz;
+    const int32_t st = g->pol.flush(mode, local_nnz, pattern_changed);
+    if (st != ESP_OK) {
+        const std::string why = g->pol.err + (h->err.empty() ? "" : ": " + h->err) + (g->err.empty() ? "" : ": " + g->err);
+        GFAIL(g, st, "%s", why.c_str());
+    }
     return ESP_OK;
 }
 
 static int32_t group_offsets(esp_group *g) {
-    if (g->offsets_valid) return ESP_OK;
-    std::vector<i64> all;
-    CK(gather_ints(g, {g->local_nnz}, &all));
-    g->nnz_offsets[0] = 0;
-    for (int q = 0; q < g->P; q++) g->nnz_offsets[(size_t)q + 1] = g->nnz_offsets[(size_t)q] + all[(size_t)q];
-    g->offsets_valid = true;
+    const int32_t st = g->pol.offsets();
+    if (st != ESP_OK) GFAIL(g, st, "%s", g->pol.err.c_str());
     return ESP_OK;
 }
 
@@ -473,8 +352,8 @@ static int32_t group_offsets(esp_group *g) {
 extern "C" int32_t esp_group_nnz(esp_group *g, int64_t *global_nnz, int64_t *nnz_before_me) {
     if (!g) return ESP_ERR_INVALID;
     CK(group_offsets(g));
-    if (global_nnz) *global_nnz = g->nnz_offsets[(size_t)g->P];
-    if (nnz_before_me) *nnz_before_me = g->nnz_offsets[(size_t)g->me];
+    if (global_nnz) *global_nnz = g->pol.nnz_offsets[(size_t)g->P];
+    if (nnz_before_me) *nnz_before_me = g->pol.nnz_offsets[(size_t)g->me];
     return ESP_OK;
 }
 
@@ -491,7 +370,7 @@ extern "C" int32_t esp_group_get_csc(esp_group *g, int64_t *colptr_own, int64_t 
     HIPCK(h, hipStreamSynchronize(h->stream));
     if (colptr_own[0] != 1 || colptr_own[c1 - c0] != h->nnz + 1)
         GFAIL(g, ESP_ERR_STATE, "esp_group_get_csc: entries outside the owned column range");
-    const i64 off = g->nnz_offsets[(size_t)g->me];
+    const i64 off = g->pol.nnz_offsets[(size_t)g->me];
     for (i64 c = 0; c <= c1 - c0; c++) colptr_own[c] += off;
     if (h->nnz > 0) {
         if (!rowval || !nzval) return ESP_ERR_INVALID;
@@ -504,7 +383,7 @@ extern "C" int32_t esp_group_get_csc(esp_group *g, int64_t *colptr_own, int64_t 
 // 1 = partitioned exchange, 2 = in-place exchange; entries this rank sent to other ranks in the last flush
 extern "C" int32_t esp_group_last_exchange(const esp_group *g, int32_t *kind, int64_t *sent_off_rank) {
     if (!g) return ESP_ERR_INVALID;
-    if (kind) *kind = g->last_exchange;
-    if (sent_off_rank) *sent_off_rank = g->sent_off_rank;
+    if (kind) *kind = g->pol.last_exchange;
+    if (sent_off_rank) *sent_off_rank = g->pol.sent_off_rank;
     return ESP_OK;
 }

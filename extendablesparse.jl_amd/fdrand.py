@@ -45,19 +45,16 @@ def update_rawupdateindex(A, v, i, j):
     A.rawupdateindex("+", v, i, j)
 
 
-def fdrand_(A, nx, ny=1, nz=1, update=update_updateindex, rand_mode=2, seed=0x5EED0002):
-    """fdrand!(A,nx,ny,nz;update,rand): sprand.jl:58-126."""
-    N = nx * ny * nz
-    if A.shape != (N, N):
-        raise ValueError("Matrix size mismatch")
-    rand = make_rand(rand_mode, seed)
-    A.zero_values()
-
+def stencil_updates(nx, ny, nz, rand, update):
+    """The update stream of fdrand! (sprand.jl:87-124) as calls update(v, i, j), in the reference's order: per node l
+    (x fastest) the x-pair if i < nx, the x-boundary term, the y-pair, the y-boundary term (ny > 2), the z-pair, the
+    z-boundary term (nz > 2); a pair is (-v,l,l'), (-v,l',l), (v,l,l), (v,l',l') (:87-92); draw k of node l has the
+    counter 6 (l - 1) + k.  The one host-side statement of the stream: fdrand_ and fdrand_coo both use it."""
     def update_pair(v, i, j):
-        update(A, -v, i, j)
-        update(A, -v, j, i)
-        update(A, v, i, i)
-        update(A, v, j, j)
+        update(-v, i, j)
+        update(-v, j, i)
+        update(v, i, i)
+        update(v, j, j)
 
     hx, hy, hz = 1.0 / nx, 1.0 / ny, 1.0 / nz
     nxy = nx * ny
@@ -69,16 +66,25 @@ def fdrand_(A, nx, ny=1, nz=1, update=update_updateindex, rand_mode=2, seed=0x5E
                 if i < nx:
                     update_pair(rand(c + 0) * hy * hz / hx, l, l + 1)
                 if i == 1 or i == nx:
-                    update(A, rand(c + 1) * hy * hz, l, l)
+                    update(rand(c + 1) * hy * hz, l, l)
                 if j < ny:
                     update_pair(rand(c + 2) * hx * hz / hy, l, l + nx)
                 if ny > 2 and (j == 1 or j == ny):
-                    update(A, rand(c + 3) * hx * hz, l, l)
+                    update(rand(c + 3) * hx * hz, l, l)
                 if k < nz:
                     update_pair(rand(c + 4) * hx * hy / hz, l, l + nxy)
                 if nz > 2 and (k == 1 or k == nz):
-                    update(A, rand(c + 5) * hx * hy, l, l)
+                    update(rand(c + 5) * hx * hy, l, l)
                 l += 1
+
+
+def fdrand_(A, nx, ny=1, nz=1, update=update_updateindex, rand_mode=2, seed=0x5EED0002):
+    """fdrand!(A,nx,ny,nz;update,rand): sprand.jl:58-126."""
+    N = nx * ny * nz
+    if A.shape != (N, N):
+        raise ValueError("Matrix size mismatch")
+    A.zero_values()
+    stencil_updates(nx, ny, nz, make_rand(rand_mode, seed), lambda v, i, j: update(A, v, i, j))
     A.flush()
     return A
 
@@ -113,38 +119,12 @@ def fdrand_coo(nx, ny=1, nz=1, rand_mode=2, seed=0x5EED0002, device=True, **kw):
         A.generate_fdrand(nx, ny, nz, seed=seed, rand_mode=rand_mode, kind=ESP_COO)
         A.flush()
         return A
-    rand = make_rand(rand_mode, seed)
     I, J, V = [], [], []
 
-    def update(v, i, j):
+    def triplet(v, i, j):
         I.append(i)
         J.append(j)
         V.append(v)
 
-    def update_pair(v, i, j):
-        update(-v, i, j)
-        update(-v, j, i)
-        update(v, i, i)
-        update(v, j, j)
-
-    hx, hy, hz = 1.0 / nx, 1.0 / ny, 1.0 / nz
-    nxy = nx * ny
-    l = 1
-    for k in range(1, nz + 1):
-        for j in range(1, ny + 1):
-            for i in range(1, nx + 1):
-                c = 6 * (l - 1)
-                if i < nx:
-                    update_pair(rand(c + 0) * hy * hz / hx, l, l + 1)
-                if i == 1 or i == nx:
-                    update(rand(c + 1) * hy * hz, l, l)
-                if j < ny:
-                    update_pair(rand(c + 2) * hx * hz / hy, l, l + nx)
-                if ny > 2 and (j == 1 or j == ny):
-                    update(rand(c + 3) * hx * hz, l, l)
-                if k < nz:
-                    update_pair(rand(c + 4) * hx * hy / hz, l, l + nxy)
-                if nz > 2 and (k == 1 or k == nz):
-                    update(rand(c + 5) * hx * hy, l, l)
-                l += 1
+    stencil_updates(nx, ny, nz, make_rand(rand_mode, seed), triplet)
     return ExtendableSparseMatrix.from_coo(I, J, V, N, N, **kw)

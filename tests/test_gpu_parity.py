@@ -10,6 +10,7 @@ import numpy as np
 import pytest
 
 import golden_util as gu
+import sharded_model   # (test infrastructure: the Python model of the sharded flush over torch.distributed)
 from refmodel import assert_csc_equal, bits, check_julia_invariants
 
 pytestmark = pytest.mark.gpu
@@ -791,7 +792,7 @@ def test_four_byte_keys_only_for_a_batch_of_one_kind(esp, orc):
                 A.append(0, I, J, V, kinds=np.full(len(I), kd, np.uint8))
             elif special == "packed":
                 import ctypes
-                src = esp.HipShardBackend(m, n)
+                src = sharded_model.HipShardBackend(m, n)
                 src.A.append(kd, I, J, V)
                 kk, vv, _ = src.shard_export(1)             # packed keys + values on the device, append order
                 d = A._d
@@ -1169,7 +1170,7 @@ def test_shard_export_is_a_stable_partition_by_owner(esp, P):
     rng = np.random.default_rng(P)
     m, n = 900, 1000
     cnt = 50000
-    be = esp.HipShardBackend(m, n)
+    be = sharded_model.HipShardBackend(m, n)
     I = rng.integers(1, m + 1, cnt)
     J = rng.integers(1, n + 1, cnt)
     V = rng.standard_normal(cnt)
@@ -1201,7 +1202,7 @@ def test_sharded_matrix_world1_nccl(esp, orc):
     try:
         nx, ny, nz = 12, 11, 10
         N = nx * ny * nz
-        A = esp.ShardedExtendableSparseMatrix(N, N, esp.HipShardBackend(N, N, device=0))
+        A = sharded_model.ShardedExtendableSparseMatrix(N, N, sharded_model.HipShardBackend(N, N, device=0))
         A.local.generate_fdrand(nx, ny, nz, seed=3, rand_mode=1)
         A.flush()
         O = orc.fdrand(nx, ny, nz, rand_mode=1, seed=3, style=orc.KIND_UPDATE)
@@ -1385,8 +1386,8 @@ def _sharded_ranks_run(esp, orc, world, deal, n=44, rounds=2, overflow=False, on
         return Ii, Jj, Vv, kk
 
     def body(rank, dist):
-        be = esp.HipShardBackend(N, N, device=0)
-        A = esp.ShardedExtendableSparseMatrix(N, N, be, dist=dist)
+        be = sharded_model.HipShardBackend(N, N, device=0)
+        A = sharded_model.ShardedExtendableSparseMatrix(N, N, be, dist=dist)
         hist, folds = [], []
         for rnd in range(rounds):
             if deal == "slab":
@@ -1402,7 +1403,7 @@ def _sharded_ranks_run(esp, orc, world, deal, n=44, rounds=2, overflow=False, on
         G = A.gather_sparse(0)
         return hist, (G.arrays() if rank == 0 else None), A.nnz(), folds
 
-    shmod = sys.modules[esp.ShardedExtendableSparseMatrix.__module__]
+    shmod = sys.modules[sharded_model.ShardedExtendableSparseMatrix.__module__]
     keep = shmod.ONE_MESSAGE_MAX_ELEMS
     if not one_message:
         shmod.ONE_MESSAGE_MAX_ELEMS = 0   # counts, keys, values as three collectives (large exchanges)
@@ -1583,7 +1584,7 @@ def test_all_to_all_large_message(esp):
     size delivers only part of the data on this stack: the helper splits it into rounds)."""
     import torch
     import torch.distributed as dist
-    from extendablesparse_jl_amd.sharded import all_to_all_v
+    from sharded_model import all_to_all_v
     if dist.is_initialized():
         pytest.skip("process group already initialised")
     os_env = __import__("os").environ
@@ -1609,7 +1610,7 @@ def test_inplace_exchange_three_shards_on_one_gpu(esp, orc):
     P = 3
     m, n = 500, 900
     rng = np.random.default_rng(77)
-    bes = [esp.HipShardBackend(m, n) for _ in range(P)]
+    bes = [sharded_model.HipShardBackend(m, n) for _ in range(P)]
     streams = []
     for r in range(P):
         cnt = 20000 + 3000 * r

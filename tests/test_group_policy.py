@@ -1,0 +1,17 @@
+"""The exchange policy of esp_group_flush (csrc/group_policy.hpp -- the code the library itself runs) on the CPU:
+tests/group_policy_test.cpp drives it with 1 / 2 / 3 / 8 ranks as threads over a host model of a shard and an in-process
+transport, built with -fsanitize=address,undefined."""
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EXE = os.path.join(ROOT, "tests", "group_policy_test.bin")
+
+
+def test_group_policy_threads_as_ranks_under_sanitizers():
+    cmd = ["g++", "-std=c++17", "-O1", "-g", "-Wall", "-Wextra", "-Werror", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+           "-fno-omit-frame-pointer", "-pthread", os.path.join(ROOT, "tests", "group_policy_test.cpp"), "-o", EXE]
+    subprocess.check_call(cmd)
+    r = subprocess.run([EXE], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-4000:])
+    assert "group_policy_test: ok" in r.stdout

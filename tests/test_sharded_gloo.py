@@ -1,5 +1,5 @@
 """CPU, world_size 2, gloo: the column-shard exchange (counts, all-to-all-v, ordering, colptr stitch)
-of extendablesparse.jl_amd/sharded.py with a CPU stand-in for the local device operations.
+of tests/sharded_model.py (the Python model of the sharded flush) with a CPU stand-in for the local device operations.
 The stand-in lives HERE (tests may use the oracle); the product backend is HipShardBackend."""
 import os
 import socket
@@ -129,6 +129,8 @@ def _worker(rank, world, port, variant, q):
     from esparse_loader import load
     from oracle import oracle as orc
     esp = load()
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import sharded_model
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         nx, ny, nz = 7, 6, 5
@@ -146,7 +148,7 @@ def _worker(rank, world, port, variant, q):
             os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
             ctrl = dist.new_group(backend="gloo")
             mode = "partitioned"
-        A = esp.ShardedExtendableSparseMatrix(N, N, be, ctrl_group=ctrl)
+        A = sharded_model.ShardedExtendableSparseMatrix(N, N, be, ctrl_group=ctrl)
         if mode == "partitioned3":   # counts, keys and values as three collectives (the path of large exchanges)
             sys.modules[type(A).__module__].ONE_MESSAGE_MAX_ELEMS = 0
             mode = "partitioned"

@@ -10,9 +10,11 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER
 dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
 from esparse_loader import load
 esp = load()
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import sharded_model  # noqa: E402
 n = 256; N = n**3; E = 12*n*n*(n-1)+6*n*n
-be = esp.HipShardBackend(N, N, device=0, capacity_hint=E + 4*n*n)
-SA = esp.ShardedExtendableSparseMatrix(N, N, be)
+be = sharded_model.HipShardBackend(N, N, device=0, capacity_hint=E + 4*n*n)
+SA = sharded_model.ShardedExtendableSparseMatrix(N, N, be)
 A = be.matrix
 dev = be.device
 pin = torch.empty(8, dtype=torch.int64).pin_memory()
