@@ -1211,7 +1211,11 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
                     lb_done = reg_tier<REG_RUN, FRESH, UPD>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
                 done = true;
             }
-        } else if constexpr (!SMALL && !BIG) {
+        } else if constexpr (!SMALL && !BIG && (FRESH || K32)) {
+            // (over a stored CSC only the 4-byte-key forms carry it -- what a producer's or a bulk append's partition hands over;
+            // packed keys over a stored pattern: the radix tier.  The stored-CSC fold looks every (col,row) up in its column,
+            // and inlined into the packed-key kernel that code cost segments that never come here 200 bytes of scratch per
+            // lane: the tail flush of config 3 0.88 -> 1.06 ms)
             // ---- group tier: runs of up to 256 entries sorted by 2 .. 16 lanes each, keys in registers (see group_sort)
             if (!done && maxrun <= GROUP_MAX && a.rb <= 30 && a.cl_bits <= GROUP_CL_BITS && !a.no_group) {
                 u32 rmin = ~0u, rmax = 0u;
