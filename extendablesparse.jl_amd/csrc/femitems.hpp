@@ -31,6 +31,10 @@ struct Args {
     i64 nitems;           // ncells * (dim + 1)
     u64 *ikeys;           // item records: packed key of (row 0, the item's column), kind bits zero
     double *ivals;        // ... | bit pattern of (cell << 2 | vertex)
+    int single;           // single-word records: the cell's number sits in the key's row and kind bits (it fits when
+                          // ncells <= 2^(rb+2)); no second array, the passes move 8 bytes per item (Pass::keys_only), and
+                          // the expansion finds the vertex by comparing the column with the cell's nodes
+    const u64 *sorted_keys;
     // fem_expand_k
     const double *sorted;  // the partitioned records' second halves
     int rem_bits;          // K32: key bits below the segment prefix
@@ -50,8 +54,12 @@ static __global__ __launch_bounds__(THREADS) void fem_items_k(Args a) {
 #pragma unroll
     for (int k = 0; k < 4; k++)
         if (k < ni) {
-            a.ikeys[pos * ni + k] = esp_pack(a.fem.L, 1, nodes[k], 0);
-            a.ivals[pos * ni + k] = __longlong_as_double((long long)(((u64)cell << 2) | (u64)k));  // (the cell, not its stream position: the expansion need not walk the permutation again)
+            if (a.single) {
+                a.ikeys[pos * ni + k] = esp_pack(a.fem.L, 1, nodes[k], 0) | (u64)cell;
+            } else {
+                a.ikeys[pos * ni + k] = esp_pack(a.fem.L, 1, nodes[k], 0);
+                a.ivals[pos * ni + k] = __longlong_as_double((long long)(((u64)cell << 2) | (u64)k));  // (the cell, not its stream position: the expansion need not walk the permutation again)
+            }
         }
 }
 
@@ -65,13 +73,22 @@ static __global__ __launch_bounds__(THREADS) void fem_expand_k(Args a) {
     const i64 g0 = (i64)blockIdx.x * THREADS, g = g0 + t;
     const int W = a.fem.dim + 2;
     if (g < a.nitems) {
-        const u64 id = (u64)__double_as_longlong(a.sorted[g]);
-        const int k = (int)(id & 3ull);
+        // the item: a cell and one of its vertex columns (single-word record: both in the key)
+        i64 cell, icol;
+        if (a.single) {
+            const u64 rec = a.sorted_keys[g];
+            const int low = a.fem.L.rb + ESP_TAG_BITS;
+            cell = (i64)(rec & ((1ull << low) - 1ull));
+            icol = (i64)(rec >> low) + 1;
+        } else {
+            cell = (i64)((u64)__double_as_longlong(a.sorted[g]) >> 2);
+            icol = (i64)((a.sorted_keys[g] >> ESP_TAG_BITS) >> a.fem.L.rb) + 1;
+        }
         const u64 lowmask = a.rem_bits >= 64 ? ~0ull : ((1ull << a.rem_bits) - 1ull);
         // the item's updates in call order: row il's term at il, +1 from the diagonal's row on (the mass term of the
         // diagonal comes right before it)
-        espgen::fem_updates_of_cell(a.fem, (i64)(id >> 2), [&](int il, int jl, i64 row, i64 col, double v) {
-            if (jl < 0 ? il != k : jl != k) return;
+        espgen::fem_updates_of_cell(a.fem, cell, [&](int il, int jl, i64 row, i64 col, double v) {
+            if (col != icol) return;  // (the updates of the item's column; the mass term of row il has the column nodes[il])
             const int at = t * W + (jl < 0 ? il : il + (il >= jl ? 1 : 0));
             if constexpr (K32)
                 lk[at] = (u32)(((((u64)(col - 1) << a.fem.L.rb) | (u64)(row - 1)) - a.base) & lowmask);

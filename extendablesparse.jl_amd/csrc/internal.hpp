@@ -84,6 +84,7 @@ struct esp_handle {
     // updates / updates per item), and a shuffled stream need not be tried as a pre-sorted one
     i64 plan_cap = 0;
     bool item_mode = false;
+    bool item_keys_only = false;  // ... whose records are single words (the value arrays are not touched)
     bool shard_user = false;     // the handle is driven through esp_shard_*: its flushes partition by owner first
     int last_shard_source = 0;   // esp_shard_partition: 1 = its own pass moved the entries, 2 = the producer had
     int last_local_small = 0;    // the last flush's bucket kernel was the small variant (3 workgroups per CU)

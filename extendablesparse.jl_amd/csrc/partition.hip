@@ -22,7 +22,11 @@ int32_t partition_pass(esp_handle *h, espradix::Pass &p, i64 max_tiles) {
     }
     {
         Span sp(h, ESP_ST_SCATTER);
-        if (p.bits > 8)
+        if (p.keys_only && p.bits > 8)
+            hipLaunchKernelGGL((espradix::scatter_k<true, true>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
+        else if (p.keys_only)
+            hipLaunchKernelGGL((espradix::scatter_k<false, true>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
+        else if (p.bits > 8)
             hipLaunchKernelGGL((espradix::scatter_k<true>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
         else
             hipLaunchKernelGGL((espradix::scatter_k<false>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
@@ -597,6 +601,7 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
         p.err = d_werr;
         p.bits = bits;
         p.shift = K - done - bits;
+        p.keys_only = h->item_mode && h->item_keys_only ? 1 : 0;
         const i64 max_tiles = S == 1 ? T : T + S;
         CK(partition_pass(h, p, max_tiles));
         const int S2 = S << bits;

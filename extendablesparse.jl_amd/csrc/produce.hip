@@ -398,6 +398,9 @@ int32_t item_produce_fem(esp_handle *h, const espgen::FemArgs &fa, i64 E, bool *
     a.nitems = NI;
     a.ikeys = (u64 *)h->keys2.p;
     a.ivals = (double *)h->vals2.p;
+    // single-word records when the cell's number fits below the column bits of the key (28: test hook, never)
+    a.single = ((u64)fa.ncells <= ((u64)1 << (h->L.rb + ESP_TAG_BITS)) && h->force_path != ESP_PATH_TWO_WORD_ITEMS) ? 1 : 0;
+    a.sorted_keys = nullptr;
     {
         Span sp(h, ESP_ST_APPEND);
         hipLaunchKernelGGL(espitem::fem_items_k, dim3(grid_for(fa.ncells, espitem::THREADS)), dim3(espitem::THREADS), 0, h->stream, a);
@@ -414,12 +417,14 @@ int32_t item_produce_fem(esp_handle *h, const espgen::FemArgs &fa, i64 E, bool *
     h->count = NI;
     h->plan_cap = (i64)esplocal::CAP / W;
     h->item_mode = true;
+    h->item_keys_only = a.single != 0;
     Sorted st;
     const int32_t rc = sort_msd(h, &st);
     h->keys = k0, h->vals = v0, h->keys2 = k2, h->vals2 = v2;
     h->count = count0;
     h->plan_cap = 0;
     h->item_mode = false;
+    h->item_keys_only = false;
     if (rc != ESP_OK) return rc;
     const int K = window_bits(h);
     if (!st.local_ok || st.S < 2 || st.rem_bits < h->L.rb || st.maxlen * W > (i64)esplocal::CAP) {
@@ -428,6 +433,7 @@ int32_t item_produce_fem(esp_handle *h, const espgen::FemArgs &fa, i64 E, bool *
     }
     const bool k32 = st.rem_bits <= 32 && h->force_path != ESP_PATH_PACKED_KEYS;
     a.sorted = st.sv;
+    a.sorted_keys = st.sk;
     a.rem_bits = st.rem_bits;
     a.base = h->win_base;
     a.keys_out = (u64 *)h->keys.p;

@@ -52,6 +52,7 @@ struct Pass {
     i64 owner_n;
     int colshift;
     u64 *hist;  // [tile_first[s]*R + d*ntiles_s + tile_in_seg]; scanned in place
+    int keys_only = 0;  // the records are their keys (single-word item records, femitems.hpp): no value array is read or written
 };
 
 // CHECK: report keys outside the window (the histogram kernel sees every key of a pass with the
@@ -144,7 +145,8 @@ static __global__ __launch_bounds__(THREADS) void tile_hist_k(Pass p) {
 // entries holds 16 per digit -- more than by the bytes it has in flight.
 // NINE: digits of 9 bits (two per thread, the digit of an output slot recomputed from its key); else at most 8 bits (one
 // digit per thread, the slot's digit kept in an LDS byte): the 8-bit passes of 3-D FEM lost 5 % in the general form.
-template <bool NINE>
+// NOVAL: the records are 8-byte keys by themselves (Pass::keys_only): half the traffic of a pass
+template <bool NINE, bool NOVAL = false>
 static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
     constexpr int RDX = NINE ? RADIX : 256;
     __shared__ u64 lbuf[TILE];
@@ -184,10 +186,15 @@ static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
         const i64 idx = wbase + k * ESP_WAVE;
         key[k] = idx < end ? p.keys_in[idx] : ~0ull;
     }
+    if constexpr (!NOVAL) {
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        const i64 idx = wbase + k * ESP_WAVE;
-        val[k] = idx < end ? p.vals_in[idx] : 0.0;
+        for (int k = 0; k < ITEMS; k++) {
+            const i64 idx = wbase + k * ESP_WAVE;
+            val[k] = idx < end ? p.vals_in[idx] : 0.0;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) val[k] = 0.0;
     }
     __syncthreads();
 
@@ -287,6 +294,7 @@ static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
                 p.keys_out[goff[d] + slot] = kk;
             }
         }
+        if constexpr (NOVAL) return;
         __syncthreads();  // (every key has been read)
 #pragma unroll
         for (int k = 0; k < ITEMS; k++)
@@ -303,6 +311,7 @@ static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
             const int slot = t + j * THREADS;
             if (slot < ntile) p.keys_out[goff[ldig[slot]] + slot] = lbuf[slot];
         }
+        if constexpr (NOVAL) return;
         __syncthreads();  // (every key has been read)
 #pragma unroll
         for (int k = 0; k < ITEMS; k++)

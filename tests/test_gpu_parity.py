@@ -635,6 +635,12 @@ def test_item_producer_shuffled_fem(esp, orc):
         C.flush()
         assert C.debug_last_partition() == 4 and C.debug_last_key_bytes() == 8
         assert_csc_equal(hip_arrays(C), want, "packed keys")
+        D = esp.ExtendableSparseMatrix(nn, nn)
+        D.debug_force_path(28)        # 16-byte item records (the cell's number in a second word)
+        D.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
+        D.flush()
+        assert D.debug_last_partition() == 4
+        assert_csc_equal(hip_arrays(D), want, "two-word items")
         B = esp.ExtendableSparseMatrix(nn, nn)
         B.debug_force_path(25)
         B.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
