@@ -595,67 +595,71 @@ __device__ __forceinline__ u32 keep_side(u32 x, u32 y, bool lower) {
     return lower ? lo : hi;
 }
 // first step of a merge of two sorted blocks: element e against its mirror image in the block pair (partner lane
-// through CTRL, register 15 - r); the lower block keeps the minima
-template <int CTRL>
-__device__ __forceinline__ void group_mirror(u32 (&x)[16], bool lower) {
+// through CTRL, register R - 1 - r); the lower block keeps the minima
+template <int CTRL, int R>
+__device__ __forceinline__ void group_mirror(u32 (&x)[R], bool lower) {
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
-        const u32 a = dpp_perm<CTRL>(x[15 - r]), b = dpp_perm<CTRL>(x[r]);
+    for (int r = 0; r < R / 2; r++) {
+        const u32 a = dpp_perm<CTRL>(x[R - 1 - r]), b = dpp_perm<CTRL>(x[r]);
         x[r] = keep_side(x[r], a, lower);
-        x[15 - r] = keep_side(x[15 - r], b, lower);
+        x[R - 1 - r] = keep_side(x[R - 1 - r], b, lower);
     }
 }
-template <int CTRL>
-__device__ __forceinline__ void group_cross(u32 (&x)[16], bool lower) {
+template <int CTRL, int R>
+__device__ __forceinline__ void group_cross(u32 (&x)[R], bool lower) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) x[r] = keep_side(x[r], dpp_perm<CTRL>(x[r]), lower);
+    for (int r = 0; r < R; r++) x[r] = keep_side(x[r], dpp_perm<CTRL>(x[r]), lower);
 }
-__device__ __forceinline__ void group_cross4(u32 (&x)[16], bool lower) {
+template <int R>
+__device__ __forceinline__ void group_cross4(u32 (&x)[R], bool lower) {
 #pragma unroll
-    for (int r = 0; r < 16; r++) x[r] = keep_side(x[r], dpp_xor4(x[r]), lower);
+    for (int r = 0; r < R; r++) x[r] = keep_side(x[r], dpp_xor4(x[r]), lower);
 }
-// the half cleaners inside a lane (distances 8, 4, 2, 1 between registers)
-__device__ __forceinline__ void group_clean(u32 (&x)[16]) {
+// the half cleaners inside a lane (distances R/2 .. 1 between registers)
+template <int R>
+__device__ __forceinline__ void group_clean(u32 (&x)[R]) {
 #pragma unroll
-    for (int j = 8; j >= 1; j >>= 1)
+    for (int j = R / 2; j >= 1; j >>= 1)
 #pragma unroll
-        for (int r = 0; r < 16; r++)
+        for (int r = 0; r < R; r++)
             if ((r & j) == 0) {
                 const u32 lo = x[r] < x[r | j] ? x[r] : x[r | j], hi = x[r] < x[r | j] ? x[r | j] : x[r];
                 x[r] = lo;
                 x[r | j] = hi;
             }
 }
-// sorts the 16 * G keys held by G neighbouring lanes (lane q of the group: sorted positions 16 q .. 16 q + 15)
-template <int G>
-__device__ __forceinline__ void group_sort(u32 (&x)[16], int q) {
+// sorts the R * G keys held by G neighbouring lanes (lane q of the group: sorted positions R q .. R q + R - 1).
+// R = 16 keys per lane, or 8: twice the lanes per column -- a segment of 32 columns x 120 entries (3-D FEM) then keeps all
+// eight waves of the workgroup busy instead of four, and a lane's 8 keys + 8 values leave room in the register file
+template <int G, int R>
+__device__ __forceinline__ void group_sort(u32 (&x)[R], int q) {
 #pragma unroll
-    for (int c = 0; c < NetOf<16>::net.n; c++) {
-        const u32 lo = x[NetOf<16>::net.a[c]], hi = x[NetOf<16>::net.b[c]];
-        x[NetOf<16>::net.a[c]] = lo < hi ? lo : hi;
-        x[NetOf<16>::net.b[c]] = lo < hi ? hi : lo;
+    for (int c = 0; c < NetOf<R>::net.n; c++) {
+        const u32 lo = x[NetOf<R>::net.a[c]], hi = x[NetOf<R>::net.b[c]];
+        x[NetOf<R>::net.a[c]] = lo < hi ? lo : hi;
+        x[NetOf<R>::net.b[c]] = lo < hi ? hi : lo;
     }
     if constexpr (G >= 2) {
-        group_mirror<0xB1>(x, (q & 1) == 0);  // quad_perm [1,0,3,2]: lane ^ 1
-        group_clean(x);
+        group_mirror<0xB1, R>(x, (q & 1) == 0);  // quad_perm [1,0,3,2]: lane ^ 1
+        group_clean<R>(x);
     }
     if constexpr (G >= 4) {
-        group_mirror<0x1B>(x, (q & 2) == 0);  // quad_perm [3,2,1,0]: lane ^ 3
-        group_cross<0xB1>(x, (q & 1) == 0);
-        group_clean(x);
+        group_mirror<0x1B, R>(x, (q & 2) == 0);  // quad_perm [3,2,1,0]: lane ^ 3
+        group_cross<0xB1, R>(x, (q & 1) == 0);
+        group_clean<R>(x);
     }
     if constexpr (G >= 8) {
-        group_mirror<0x141>(x, (q & 4) == 0);  // row_half_mirror: lane ^ 7
-        group_cross<0x4E>(x, (q & 2) == 0);    // quad_perm [2,3,0,1]: lane ^ 2
-        group_cross<0xB1>(x, (q & 1) == 0);
-        group_clean(x);
+        group_mirror<0x141, R>(x, (q & 4) == 0);  // row_half_mirror: lane ^ 7
+        group_cross<0x4E, R>(x, (q & 2) == 0);    // quad_perm [2,3,0,1]: lane ^ 2
+        group_cross<0xB1, R>(x, (q & 1) == 0);
+        group_clean<R>(x);
     }
     if constexpr (G >= 16) {
-        group_mirror<0x140>(x, (q & 8) == 0);  // row_mirror: lane ^ 15
-        group_cross4(x, (q & 4) == 0);
-        group_cross<0x4E>(x, (q & 2) == 0);
-        group_cross<0xB1>(x, (q & 1) == 0);
-        group_clean(x);
+        group_mirror<0x140, R>(x, (q & 8) == 0);  // row_mirror: lane ^ 15
+        group_cross4<R>(x, (q & 4) == 0);
+        group_cross<0x4E, R>(x, (q & 2) == 0);
+        group_cross<0xB1, R>(x, (q & 1) == 0);
+        group_clean<R>(x);
     }
 }
 // ---- sort + ordered fold of every column run of the segment by its group of G lanes -----------------------------
@@ -702,7 +706,7 @@ __device__ __forceinline__ double dpp_shr1_f64(double x) {
 }
 // MODE: 0 = entries of any kind; 1 = all UPDATE, 2 = all RAWUPDATE (known to the kernel's instantiation or to the host's
 // bookkeeping): the fold is an addition, and on a fresh matrix pass A has no branch at all
-template <int G, int CAPK, bool FRESH, int MODE>
+template <int G, int R, int CAPK, bool FRESH, int MODE>
 __device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *sval, const u32 *ccnt, int ncl, u32 rmin, u64 hi,
                                               u64 rowmask, unsigned long long *stamp) {
     const int t = threadIdx.x, q = t & (G - 1), lane = t & (ESP_WAVE - 1);
@@ -718,30 +722,30 @@ __device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *
             len = (int)ccnt[c + 1] - rs;
         }
         const int lastj = len > 0 ? len - 1 : 0;
-        u32 x[16];
+        u32 x[R];
         // (the network does not care where an entry starts: the group's lanes read neighbouring slots -- with 16
         // consecutive slots per lane all lanes of a group would meet in one LDS bank)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
+        for (int r = 0; r < R; r++) {
             const int p = r * G + q;
             const u64 kk = skey[min(rs + min(p, lastj), CAPK - 1)];  // (all reads in flight; clamped, never past the array)
             const u32 rel = (u32)((kk >> SUB_SHIFT) & rowmask) - rmin;
             x[r] = p < len ? ((rel << SUB_SHIFT) | ((u32)kk & LOWMASK)) : ~0u;
         }
-        group_sort<G>(x, q);
+        group_sort<G, R>(x, q);
 #ifdef ESP_LOCAL_STAMPS
         if (stamp && t == 0 && c0 == 0) stamp[13] = wall_clock64();
 #endif
-        double v[16];
+        double v[R];
 #pragma unroll
-        for (int r = 0; r < 16; r++) v[r] = sval[(x[r] >> ESP_TAG_BITS) & (CAP - 1)];  // (padding reads the last slot)
-        const int nv = max(0, min(16, len - q * 16));               // this lane's entries
-        const int nvn = q == G - 1 ? 0 : max(0, min(16, len - (q + 1) * 16));  // the next lane's
+        for (int r = 0; r < R; r++) v[r] = sval[(x[r] >> ESP_TAG_BITS) & (CAP - 1)];  // (padding reads the last slot)
+        const int nv = max(0, min(R, len - q * R));               // this lane's entries
+        const int nvn = q == G - 1 ? 0 : max(0, min(R, len - (q + 1) * R));  // the next lane's
         // first entry of its (col,row)?  (the entry in front of a lane's first one sits in the lane before it)
-        const u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)x[15], 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+        const u32 before = (u32)__builtin_amdgcn_update_dpp(0, (int)x[R - 1], 0x111 /* row_shr:1 */, 0xf, 0xf, true);
         u32 heads = 0;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
+        for (int r = 0; r < R; r++) {
             const u32 prev = r == 0 ? before : x[r - 1];
             const bool h = r < nv && ((r == 0 && q == 0) || (prev >> SUB_SHIFT) != (x[r] >> SUB_SHIFT));
             heads |= h ? 1u << r : 0u;
@@ -749,7 +753,7 @@ __device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *
         const int f = heads ? (int)__builtin_ctz(heads) : nv;  // entries in front of the lane's first own (col,row)
         const u32 next_head0 = (u32)__builtin_amdgcn_update_dpp(0, (int)(heads & 1u), 0x101 /* row_shl:1 */, 0xf, 0xf, true);
         // the (col,row) of the lane's last entry goes on in the next lane
-        const bool open_end = nv == 16 && nvn > 0 && !next_head0;
+        const bool open_end = nv == R && nvn > 0 && !next_head0;
         const u64 colbase = hi + ((u64)c << a.rb);
         u32 emit = 0;
         if constexpr (FRESH && MODE != 0) {
@@ -758,7 +762,7 @@ __device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *
             double acc = 0.0;
             u32 np = 0, pres = 0;  // UPDATEs: a (col,row) is present once one of its values is not zero
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
+            for (int r = 0; r < R; r++) {
                 const bool is_head = (heads >> r) & 1u;
                 acc = (is_head ? 0.0 : acc) + v[r];
                 if (r < nv) sval[(x[r] >> ESP_TAG_BITS) & (CAP - 1)] = acc;
@@ -770,14 +774,14 @@ __device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *
             }
             // last entries of the (col,row)s that started in this lane: the entry in front of a first entry, and the
             // lane's last entry unless its (col,row) goes on
-            const u32 valid = nv >= 16 ? 0xFFFFu : ((1u << nv) - 1u);
+            const u32 valid = (1u << nv) - 1u;
             const u32 lastbit = (nv > 0 && !open_end) ? 1u << (nv - 1) : 0u;
             const u32 tails = ((heads >> 1) | lastbit) & valid & ~((1u << f) - 1u);
             emit = raws ? tails : (tails & pres);
             // ---- pass B
             double t_acc = acc;
             u32 t_present = raws ? 1u : np;
-            bool final = f < 16, need = f > 0;
+            bool final = f < R, need = f > 0;
             while (__ballot(need) != 0ull) {
                 const double in_acc = dpp_shr1_f64(t_acc);
                 const u32 in_present = (u32)__builtin_amdgcn_update_dpp(0, (int)t_present, 0x111, 0xf, 0xf, true);
@@ -786,12 +790,12 @@ __device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *
                     double acc2 = in_acc;
                     u32 p2 = in_present;
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
+                    for (int r = 0; r < R; r++) {
                         const double a3 = acc2 + v[r];
                         acc2 = r < f ? a3 : acc2;
                         if constexpr (!raws) p2 |= (r < f && v[r] != 0.0) ? 1u : 0u;
                     }
-                    if (f == 16 && open_end) {  // every entry of the lane belongs to it and it goes on
+                    if (f == R && open_end) {  // every entry of the lane belongs to it and it goes on
                         t_acc = acc2, t_present = p2;
                         final = true;
                     } else if (p2) {
@@ -807,7 +811,7 @@ __device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *
             bool present = false;
             i64 pos = -1;
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
+            for (int r = 0; r < R; r++) {
                 const bool is_head = (heads >> r) & 1u;
                 if constexpr (FRESH) {
                     acc = is_head ? 0.0 : acc;
@@ -824,7 +828,7 @@ __device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *
                     }
                 }
                 group_step(present, acc, x[r] & (u32)ESP_TAG_MASK, v[r], adds, raws);  // (entries in front of the first own one: discarded)
-                const bool nexth = r == 15 ? false : ((heads >> (r + 1)) & 1u) != 0u;
+                const bool nexth = r == R - 1 ? false : ((heads >> (r + 1)) & 1u) != 0u;
                 const bool tail = r >= f && r < nv && (r == nv - 1 ? !open_end : nexth);
                 if (tail && group_close<FRESH>(a, sval, pos, present, acc, x[r])) emit |= 1u << r;
             }
@@ -832,7 +836,7 @@ __device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *
             double t_acc = acc;
             bool t_present = present;
             i64 t_pos = pos;
-            bool final = f < 16;
+            bool final = f < R;
             bool need = f > 0;  // (q > 0: the first lane's first entry starts a (col,row))
             while (__ballot(need) != 0ull) {
                 const double in_acc = dpp_shr1_f64(t_acc);
@@ -844,14 +848,14 @@ __device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *
                     double acc2 = in_acc;
                     bool present2 = in_present;
 #pragma unroll
-                    for (int r = 0; r < 16; r++) {
+                    for (int r = 0; r < R; r++) {
                         double a3 = acc2;
                         bool p3 = present2;
                         group_step(p3, a3, x[r] & (u32)ESP_TAG_MASK, v[r], adds, raws);
                         acc2 = r < f ? a3 : acc2;
                         present2 = r < f ? p3 : present2;
                     }
-                    if (f == 16 && open_end) {  // every entry of the lane belongs to it and it goes on
+                    if (f == R && open_end) {  // every entry of the lane belongs to it and it goes on
                         t_acc = acc2, t_present = present2, t_pos = in_pos;
                         final = true;
                     } else if (group_close<FRESH>(a, sval, in_pos, present2, acc2, x[0])) {
@@ -888,15 +892,15 @@ __device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *
         int e = (int)(inc - mine);
         const u64 colpart = (u64)c << a.rb;
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
+        for (int r = 0; r < R; r++) {
             if ((emit >> r) & 1u) {
                 skey[rs + e] = ((colpart | (u64)((x[r] >> SUB_SHIFT) + rmin)) << SUB_SHIFT) | (u64)(x[r] & (LOWMASK & ~(u32)ESP_TAG_MASK));
                 e++;
             }
         }
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int p = q * 16 + r;
+        for (int r = 0; r < R; r++) {
+            const int p = q * R + r;
             if (p >= total && p < len) skey[rs + p] = NOREC;
         }
     }
@@ -1245,23 +1249,25 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
 #endif
                     // (one kind for every entry, known to the kernel's instantiation or to the host: the fold is an addition)
                     const int gmode = (UPD || a.kind_all == ESP_UPDATE) ? 1 : a.kind_all == ESP_RAWUPDATE ? 2 : 0;
-#define ESP_GROUP_GO(GG)                                                                                             \
+#define ESP_GROUP_GO(GG, RR)                                                                                         \
     do {                                                                                                             \
         if (gmode == 1)                                                                                              \
-            group_columns<GG, CAPK, FRESH, 1>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp);                  \
+            group_columns<GG, RR, CAPK, FRESH, 1>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp);              \
         else if (gmode == 2)                                                                                         \
-            group_columns<GG, CAPK, FRESH, 2>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp);                  \
+            group_columns<GG, RR, CAPK, FRESH, 2>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp);              \
         else                                                                                                         \
-            group_columns<GG, CAPK, FRESH, 0>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp);                  \
+            group_columns<GG, RR, CAPK, FRESH, 0>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp);              \
     } while (0)
                     if (maxrun <= 32)
-                        ESP_GROUP_GO(2);
+                        ESP_GROUP_GO(2, 16);
                     else if (maxrun <= 64)
-                        ESP_GROUP_GO(4);
+                        ESP_GROUP_GO(4, 16);
+                    else if (maxrun <= 128 && ncl * 16 <= THREADS)
+                        ESP_GROUP_GO(16, 8);  // (few long columns, 3-D FEM: 16 lanes x 8 keys keep every wave busy)
                     else if (maxrun <= 128)
-                        ESP_GROUP_GO(8);
+                        ESP_GROUP_GO(8, 16);
                     else
-                        ESP_GROUP_GO(16);
+                        ESP_GROUP_GO(16, 16);
 #undef ESP_GROUP_GO
                     done = true;
                 } else {

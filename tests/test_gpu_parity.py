@@ -587,7 +587,7 @@ def test_bucket_kernel_group_tier(esp, orc, per_col, force):
     empty), first on a fresh matrix, then over the stored CSC, then with rows more than 2^18 apart (the tier's 32-bit
     sort keys do not apply: radix tier)."""
     rng = np.random.default_rng(per_col * 31 + force)
-    for m, n in ((5000, 600), (3000000, 96)):
+    for m, n in ((5000, 600), (6000, 30), (3000000, 96)):      # (30 columns: 16 lanes x 8 keys per column for runs of 65 .. 128)
         cnt = per_col * n * 2 // 3
         A = esp.ExtendableSparseMatrix(m, n)
         A.debug_force_path(force)
