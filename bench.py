@@ -135,28 +135,79 @@ def baseline_metric():
 
 
 # ---------------------------------------------------------------------------------------- launcher
+def gpu_count_without_hip():
+    """GPUs of this node from the KFD topology in sysfs (nodes with SIMDs), so that the launcher never brings up a HIP
+    runtime of its own; None when /sys/class/kfd is not there (then torch counts, which may initialise HIP -- harmless
+    here: the launcher only spawns fresh children and never re-executes itself)."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(line.split() for line in f if len(line.split()) == 2)
+            n += int(props.get("simd_count", "0")) > 0
+        return n
+    except Exception:
+        return None
+
+
 def launch(args, argv):
-    """Parent of a plain `python bench.py --gpus N`: spawns the N ranks, never initialises the GPU."""
-    import torch
-    have = torch.cuda.device_count()          # (counting devices does not initialise the GPU)
+    """Parent of a plain `python bench.py --gpus N`: spawns the N ranks and supervises ALL of them -- the first rank that
+    exits with an error (or the wall-clock limit) ends the others, so a rank that dies at start-up cannot leave rank 0
+    waiting in the rendezvous for ever; every rank's stderr is kept and shown on failure."""
+    have = gpu_count_without_hip()
+    if have is None:
+        import torch
+        have = torch.cuda.device_count()
     if have < args.gpus:
         print("bench.py: --gpus %d but this node shows %d GPU(s); refusing to run a smaller job under that name"
               % (args.gpus, have), file=sys.stderr)
         return 2
+    import tempfile
     port = int(os.environ.get("MASTER_PORT", "29541"))
-    procs = []
+    limit = float(os.environ.get("ESP_BENCH_LAUNCH_TIMEOUT", "1800"))
+    procs, errs = [], []
+    out0 = tempfile.TemporaryFile(mode="w+")
     for r in range(args.gpus):
         env = dict(os.environ)
         env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(args.gpus), "LOCAL_WORLD_SIZE": str(args.gpus),
                     "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+        errs.append(tempfile.TemporaryFile(mode="w+"))
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
-                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
-    out0, _ = procs[0].communicate()
-    rc = procs[0].returncode
-    for p in procs[1:]:
-        p.wait()
-        rc = rc or p.returncode
-    lines = [ln for ln in (out0 or "").splitlines() if ln.strip()]
+                                      stdout=out0 if r == 0 else subprocess.DEVNULL, stderr=errs[-1], text=True))
+    t0 = time.time()
+    rc = 0
+    alive = set(range(args.gpus))
+    while alive:
+        for r in sorted(alive):
+            code = procs[r].poll()
+            if code is not None:
+                alive.discard(r)
+                if code != 0 and rc == 0:
+                    rc = code
+                    print("bench.py: rank %d exited with code %d" % (r, code), file=sys.stderr)
+        if rc != 0 or time.time() - t0 > limit:
+            if rc == 0:
+                rc = 124
+                print("bench.py: ranks still running after %.0f s" % limit, file=sys.stderr)
+            for r in alive:
+                procs[r].terminate()
+            for r in alive:
+                try:
+                    procs[r].wait(timeout=10)
+                except Exception:
+                    procs[r].kill()
+            alive.clear()
+        elif alive:
+            time.sleep(0.05)
+    if rc != 0:
+        for r, e in enumerate(errs):
+            e.seek(0)
+            tail = e.read()[-2000:]
+            if tail.strip():
+                print("---- stderr of rank %d ----\n%s" % (r, tail), file=sys.stderr)
+    out0.seek(0)
+    lines = [ln for ln in out0.read().splitlines() if ln.strip()]
     if lines:
         print(lines[-1], flush=True)
     return rc

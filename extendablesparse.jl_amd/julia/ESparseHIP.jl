@@ -33,10 +33,11 @@ mutable struct SparseMatrixHIPCOO{Tv, Ti <: Integer} <: AbstractSparseMatrixExte
     vals::Vector{Float64}
     kinds::Vector{UInt8}
     nstaged::Int
+    released::Bool           # consumed by a flush! (plus_consume!): any further use is an error, not a silent empty buffer
 end
 
 function wrap_handle(m, n, h::Ptr{Cvoid})
-    x = SparseMatrixHIPCOO{Float64, Int64}(m, n, h, Int64[], Int64[], Float64[], UInt8[], 0)
+    x = SparseMatrixHIPCOO{Float64, Int64}(m, n, h, Int64[], Int64[], Float64[], UInt8[], 0, false)
     finalizer(y -> (y.handle == C_NULL || ccall((:esp_destroy, libesparse), Int32, (Ptr{Cvoid},), y.handle); y.handle = C_NULL), x)
 end
 
@@ -108,12 +109,32 @@ function Base.getindex(x::SparseMatrixHIPCOO, i::Integer, j::Integer)
     v[]
 end
 
+# Base.copy(buffer): same pending entries on a handle of its own (esp_clone, device-to-device)
+function Base.copy(x::SparseMatrixHIPCOO{Float64, Int64})
+    commit!(x)
+    h2 = Ref{Ptr{Cvoid}}(C_NULL)
+    esp_check(x.handle, ccall((:esp_clone, libesparse), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}), x.handle, h2))
+    wrap_handle(x.m, x.n, h2[])
+end
+
 """
 `ext + csc -> SparseMatrixCSC`: THE flush (replaces sparsematrixlnk.jl:294-383).
-Uploads `csc`, runs the HIP pipeline, downloads into Julia-owned vectors.
+Uploads `csc`, runs the HIP pipeline, downloads into Julia-owned vectors.  Like `lnk + csc` it has NO side effect on
+`x`: it works on a clone (`copy(x)`, device-to-device), so `x + csc` may be evaluated again.  The wrappers' `flush!`
+and `Base.sum` consume their buffers instead (`plus_consume!`).
 """
 function Base.:+(x::SparseMatrixHIPCOO{Float64, Int64}, csc::SparseMatrixCSC{Float64, Int64})
+    y = copy(x)                      # esp_clone: the pending entries, device-to-device; x itself is left alone
+    out = plus_consume!(y, csc)
+    out
+end
+
+# csc + buffer where the buffer is consumed: its pending entries are folded into the result and its device memory is
+# released at once (not at some later GC, which does not see device memory).  What flush! of the Generic wrappers needs:
+# they drop the buffer right after `+` (genericextendablesparsematrixcsc.jl:31-37), see the flush! methods below.
+function plus_consume!(x::SparseMatrixHIPCOO{Float64, Int64}, csc::SparseMatrixCSC{Float64, Int64})
     @assert size(csc) == size(x)
+    x.released && error("SparseMatrixHIPCOO: the buffer was consumed by an earlier flush!")
     commit!(x)
     h = x.handle
     esp_check(h, ccall((:esp_set_csc, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int64),
@@ -124,18 +145,28 @@ function Base.:+(x::SparseMatrixHIPCOO{Float64, Int64}, csc::SparseMatrixCSC{Flo
     rowval = Vector{Int64}(undef, z[])
     nzval = Vector{Float64}(undef, z[])
     esp_check(h, ccall((:esp_get_csc, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}), h, colptr, rowval, nzval))
-    # the wrapper replaces this buffer by a fresh T_ext(m,n) right after `+` (genericextendablesparsematrixcsc.jl:34):
-    # its device memory (pending buffers, scratch, the device copy of the CSC) goes now, not at some later GC
-    release!(x)
+    release!(x)                      # pending buffers, scratch, the device copy of the CSC: gone now
+    x.released = true
     SparseMatrixCSC{Float64, Int64}(x.m, x.n, colptr, rowval, nzval)
+end
+
+# flush! of the Generic wrappers with a HIP buffer: the reference's `ext.cscmatrix = ext.xmatrix + ext.cscmatrix;
+# ext.xmatrix = Tm(m, n)` (genericextendablesparsematrixcsc.jl:31-37) with the buffer consumed instead of copied
+function flush!(ext::GenericExtendableSparseMatrixCSC{SparseMatrixHIPCOO{Float64, Int64}, Float64, Int64})
+    if nnz(ext.xmatrix) > 0
+        ext.cscmatrix = plus_consume!(ext.xmatrix, ext.cscmatrix)
+        ext.xmatrix = SparseMatrixHIPCOO{Float64, Int64}(size(ext.cscmatrix)...)
+    end
+    ext
 end
 Base.:+(csc::SparseMatrixCSC, x::SparseMatrixHIPCOO) = x + csc
 
 # Base.sum(extmatrices, csc) of the plugin contract (abstractsparsematrixextension.jl:11):
-# csc + x1 + x2 + ... left to right, like sparsematrixdilnkc.jl:397-435
+# csc + x1 + x2 + ... left to right, like sparsematrixdilnkc.jl:397-435.  Called by flush! of the MT wrapper
+# (genericmtextendablesparsematrixcsc.jl:45-51), which replaces every buffer right afterwards: the buffers are consumed.
 function Base.sum(xs::Vector{SparseMatrixHIPCOO{Tv, Ti}}, csc::SparseMatrixCSC{Tv, Ti}) where {Tv, Ti}
     for x in xs
-        nnz(x) > 0 && (csc = x + csc)
+        nnz(x) > 0 && (csc = plus_consume!(x, csc))
     end
     csc
 end
