@@ -221,6 +221,9 @@ def launch_probe(args):
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         return 3
+    if os.environ.get("ESP_BENCH_PROBE_FAIL_RANK") == str(rank):   # (a rank that dies before the rendezvous)
+        print("probe: rank %d fails on purpose" % rank, file=sys.stderr)
+        return 7
     if world > 1:
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
         t = torch.tensor([float(rank)], dtype=torch.float64)

@@ -47,6 +47,24 @@ def test_launcher_starts_n_ranks(monkeypatch, capfd, n):
     assert d["local_rank"] == 0 and d["master"] == "127.0.0.1"
 
 
+def test_launcher_ends_the_job_when_a_rank_dies(monkeypatch, capfd):
+    """A rank other than 0 that exits at start-up must not leave rank 0 waiting in the rendezvous: the launcher ends the
+    others, returns the failing rank's code and shows its stderr."""
+    import time
+    import torch
+    bench = _bench()
+    monkeypatch.setattr(torch.cuda, "device_count", lambda: 8)
+    monkeypatch.setenv("ESP_BENCH_LAUNCH_PROBE", "1")
+    monkeypatch.setenv("ESP_BENCH_PROBE_FAIL_RANK", "1")
+    monkeypatch.setenv("MASTER_PORT", "29611")
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    t0 = time.time()
+    rc = bench.launch(_Args(2), ["--gpus", "2", "--steps", "1"])
+    err = capfd.readouterr().err
+    assert rc == 7 and time.time() - t0 < 120
+    assert "rank 1 exited with code 7" in err and "fails on purpose" in err
+
+
 def test_world_size_mismatch_is_an_error():
     import subprocess
     env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
