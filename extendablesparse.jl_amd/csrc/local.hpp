@@ -706,15 +706,29 @@ __device__ __forceinline__ double dpp_shr1_f64(double x) {
 }
 // MODE: 0 = entries of any kind; 1 = all UPDATE, 2 = all RAWUPDATE (known to the kernel's instantiation or to the host's
 // bookkeeping): the fold is an addition, and on a fresh matrix pass A has no branch at all
-template <int G, int R, int CAPK, bool FRESH, int MODE>
-__device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *sval, const u32 *ccnt, int ncl, u32 rmin, u64 hi,
-                                              u64 rowmask, unsigned long long *stamp) {
+// DENSE (fresh matrix, additions, every column of the segment has its group of lanes at once): the records stay in
+// registers; the columns' record counts are scanned and every lane writes its records straight to the segment's dense
+// output arrays in LDS -- no record slots, no NOREC marks, no generic compaction over the segment's 4096 slots afterwards --
+// and the segment's total is published for the look-back right after the fold (the last wave owns it from there on).
+// Returns true when it did so: the caller goes on at the final stores.
+struct DenseCtx {
+    u32 *s_early;          // LDS word, zeroed at the kernel's start: the segment's total
+    unsigned short *ctot;  // LDS, one per column of the segment (<= DENSE_COLS)
+    LbState *lb;
+    int s;
+};
+constexpr int DENSE_COLS = 512;
+template <int G, int R, int CAPK, bool FRESH, int MODE, bool DENSE = false>
+__device__ __forceinline__ bool group_columns(const Args &a, u64 *skey, double *sval, const u32 *ccnt, int ncl, u32 rmin, u64 hi,
+                                              u64 rowmask, unsigned long long *stamp, const DenseCtx *dc = nullptr) {
+    static_assert(!DENSE || (FRESH && MODE != 0), "the dense form is the fresh-matrix addition fold");
     const int t = threadIdx.x, q = t & (G - 1), lane = t & (ESP_WAVE - 1);
     constexpr int CPB = THREADS / G;  // columns the workgroup takes at a time
     constexpr u32 LOWMASK = (1u << SUB_SHIFT) - 1u;
     constexpr bool raws = MODE == 2, adds = MODE != 0;
     for (int c0 = 0; c0 < ncl; c0 += CPB) {
-        if (c0 + (t & ~(ESP_WAVE - 1)) / G >= ncl) break;  // (the whole wave has no column left: all 64 lanes leave together)
+        // (the whole wave has no column left: all 64 lanes leave together -- not in the dense form: its barriers are for all)
+        if (!DENSE && c0 + (t & ~(ESP_WAVE - 1)) / G >= ncl) break;
         const int c = c0 + t / G;
         int rs = 0, len = 0;
         if (c < ncl) {
@@ -765,7 +779,11 @@ __device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *
             for (int r = 0; r < R; r++) {
                 const bool is_head = (heads >> r) & 1u;
                 acc = (is_head ? 0.0 : acc) + v[r];
-                if (r < nv) sval[(x[r] >> ESP_TAG_BITS) & (CAP - 1)] = acc;
+                if constexpr (DENSE) {
+                    v[r] = r >= f ? acc : v[r];  // (the values in front of the lane's first own (col,row) are pass B's)
+                } else {
+                    if (r < nv) sval[(x[r] >> ESP_TAG_BITS) & (CAP - 1)] = acc;
+                }
                 if constexpr (!raws) {
                     const u32 nz = v[r] != 0.0 ? 1u : 0u;
                     np = is_head ? nz : (np | nz);
@@ -799,7 +817,10 @@ __device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *
                         t_acc = acc2, t_present = p2;
                         final = true;
                     } else if (p2) {
-                        sval[(x[0] >> ESP_TAG_BITS) & (CAP - 1)] = acc2;
+                        if constexpr (DENSE)
+                            v[0] = acc2;
+                        else
+                            sval[(x[0] >> ESP_TAG_BITS) & (CAP - 1)] = acc2;
                         emit |= 1u;  // (entry 0 stands for it: the same row, a slot of its own, in front of the lane's other records)
                     }
                     need = false;
@@ -891,6 +912,44 @@ __device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *
         const int total = (int)__shfl((int)inc, lane | (G - 1), ESP_WAVE);
         int e = (int)(inc - mine);
         const u64 colpart = (u64)c << a.rb;
+        if constexpr (DENSE) {
+            if (q == G - 1 && c < ncl) {
+                dc->ctot[c] = (unsigned short)total;
+                if (total) atomicAdd(dc->s_early, (u32)total);
+            }
+            __syncthreads();  // every run of the segment is folded, its records in registers: skey / sval are free
+            const int w = t >> 6;
+            if (w == WAVES - 1) {  // the look-back starts here; the wave carries it on after its own dense writes
+                lb_publish(a, *dc->lb, dc->s, *dc->s_early, lane);
+                lb_poll(a, *dc->lb, dc->s, lane, 1, false);
+            }
+            if (w == 0) {  // exclusive scan of the columns' record counts (<= 512 columns: eight per lane)
+                u32 pre[DENSE_COLS / ESP_WAVE], run = 0;
+#pragma unroll
+                for (int j = 0; j < DENSE_COLS / ESP_WAVE; j++) {
+                    const int cc = lane * (DENSE_COLS / ESP_WAVE) + j;
+                    pre[j] = run;
+                    run += cc < ncl ? (u32)dc->ctot[cc] : 0u;
+                }
+                const u32 base = esp_wave_scan_add(run) - run;
+#pragma unroll
+                for (int j = 0; j < DENSE_COLS / ESP_WAVE; j++) {
+                    const int cc = lane * (DENSE_COLS / ESP_WAVE) + j;
+                    if (cc < ncl) dc->ctot[cc] = (unsigned short)(base + pre[j]);
+                }
+            }
+            __syncthreads();
+            int d = (c < ncl ? (int)dc->ctot[c] : 0) + e;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                if ((emit >> r) & 1u) {
+                    skey[d] = hi + (colpart | (u64)((x[r] >> SUB_SHIFT) + rmin));
+                    sval[d] = v[r];
+                    d++;
+                }
+            }
+            return true;
+        }
 #pragma unroll
         for (int r = 0; r < R; r++) {
             if ((emit >> r) & 1u) {
@@ -904,6 +963,7 @@ __device__ __forceinline__ void group_columns(const Args &a, u64 *skey, double *
             if (p >= total && p < len) skey[rs + p] = NOREC;
         }
     }
+    return false;
 }
 
 // BIG: the kernel also carries the 24-input register tier.  It is a separate instantiation because the
@@ -1133,6 +1193,7 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
 #endif
     bool done = n == 0;
     bool refill = false;  // the group tier scattered the keys by column and gave up: the radix tier reads them back
+    bool dense_done = false;  // the group tier's dense form wrote the segment's records to their dense LDS positions itself
     bool lb_done = false;  // the look-back was started by the last wave (early publication, see the register tier)
     LbState lbs;
     lb_init(lbs, 0);
@@ -1258,7 +1319,22 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
         else                                                                                                         \
             group_columns<GG, RR, CAPK, FRESH, 0>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp);              \
     } while (0)
-                    if (maxrun <= 32)
+                    // (fresh matrix, one kind of additions, every column with its lanes at once: the dense form)
+                    bool went_dense = false;
+                    if constexpr (FRESH) {
+                        if (gmode != 0 && maxrun > 64 && maxrun <= 128 && ncl * 16 <= THREADS && a.stop_after == 0) {
+                            const DenseCtx dcx{&s_early, reinterpret_cast<unsigned short *>(cntraw + 1024), &lbs, s};
+                            if (gmode == 1)
+                                group_columns<16, 8, CAPK, true, 1, true>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp, &dcx);
+                            else
+                                group_columns<16, 8, CAPK, true, 2, true>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp, &dcx);
+                            went_dense = true;
+                            dense_done = true;
+                            lb_done = true;
+                        }
+                    }
+                    if (went_dense) {
+                    } else if (maxrun <= 32)
                         ESP_GROUP_GO(2, 16);
                     else if (maxrun <= 64)
                         ESP_GROUP_GO(4, 16);
@@ -1402,16 +1478,23 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     // ---- compaction: records (skey[p] != NOREC, value in sval[idx]) -> dense prefix
     u64 rec[NI];
     double rv[NI];
+    if (!dense_done) {
 #pragma unroll
-    for (int i = 0; i < NI; i++) {
-        const int p = wbase + i * ESP_WAVE;
-        rec[i] = (p < n && a.stop_after == 0) ? skey[p] : NOREC;
-        rv[i] = rec[i] != NOREC ? sval[(rec[i] >> ESP_TAG_BITS) & (CAP - 1)] : 0.0;
-        const u64 bal = __ballot(rec[i] != NOREC);
-        if (lane == 0) gcount[w * NI + i] = (u32)__popcll(bal);
+        for (int i = 0; i < NI; i++) {
+            const int p = wbase + i * ESP_WAVE;
+            rec[i] = (p < n && a.stop_after == 0) ? skey[p] : NOREC;
+            rv[i] = rec[i] != NOREC ? sval[(rec[i] >> ESP_TAG_BITS) & (CAP - 1)] : 0.0;
+            const u64 bal = __ballot(rec[i] != NOREC);
+            if (lane == 0) gcount[w * NI + i] = (u32)__popcll(bal);
+        }
+        __syncthreads();
+    } else {
+#pragma unroll
+        for (int i = 0; i < NI; i++) rec[i] = NOREC, rv[i] = 0.0;
     }
-    __syncthreads();
-    if (w == 0) {
+    if (dense_done) {
+        if (t == 0) lw[0] = s_early;  // (the records lie dense already; the last wave is at the look-back)
+    } else if (w == 0) {
 #ifdef ESP_LOCAL_STAMPS
         if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 5] = wall_clock64();
 #endif
