@@ -2,6 +2,7 @@
 #include "internal.hpp"
 
 bool esplocal::launch(const Variant &v, unsigned grid, hipStream_t stream, const Args &a) {
+    if (v.grp) return launch_group(v, grid, stream, a);
     if (v.pieces) return v.small_variant ? launch_pieces_small(v, grid, stream, a) : v.fresh ? launch_pieces_fresh(v, grid, stream, a) : launch_pieces_stored(v, grid, stream, a);
     return v.small_variant ? launch_small(v, grid, stream, a) : launch_regular(v, grid, stream, a);
 }
@@ -252,7 +253,13 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
                                             : st.key_bytes != 4 ? 0 : (st.kind == ESP_UPDATE && h->force_path != ESP_PATH_GENERIC_FOLD ? 2 : 1);
             h->last_fold_update = keys >= 2 ? 1 : 0;
             // (the instantiations live in local_*.hip)
-            const esplocal::Variant var{Z0 == 0, st.npieces > 0, big && !small_variant, small_variant, keys};
+            // (the group-tier kernel for a matrix whose columns hold more than 24 entries: what the last flush met, or -- no
+            // history -- the pending entries per column)
+            const double longest = h->seen_maxrun > 0 ? (double)h->seen_maxrun : (double)h->count / (double)std::max<i64>(col_end - col_begin, 1);
+            const bool grp = st.npieces == 0 && !small_variant && keys <= 2 && longest > (double)esplocal::REG_RUN && h->force_path != ESP_PATH_NO_GROUP_TIER &&
+                             h->force_path != ESP_PATH_RADIX_TAIL_ONLY;
+            esplocal::Variant var{Z0 == 0, st.npieces > 0, big && !small_variant && !grp, small_variant, keys};
+            var.grp = grp;
             if (!esplocal::launch(var, grid, h->stream, a)) FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (no bucket kernel for this flush)");
         }
         sp.add(1);

@@ -980,8 +980,14 @@ __device__ __forceinline__ bool group_columns(const Args &a, u64 *skey, double *
 // The host picks it from what it knows before the flush; a segment whose column runs turn out longer than the register
 // tiers take is served by a slow tier (one lane per column: insertion sort of its run in LDS, sequential fold), and
 // the longest run it reports sends the handle's next flushes to the regular kernel.
-template <bool FRESH, bool PIECES, bool BIG, int KEYS, bool SMALL = false>
+// GRP: the instantiation that carries the GROUP tier (column runs of 17 .. 256: 2 .. 16 lanes per column) INSTEAD of the
+// register tiers -- a kernel of its own for the same reason as BIG: with both families inlined the register allocation of
+// the common phases paid for the widest of them (40 .. 120 bytes of scratch per lane in the fresh-matrix kernels, 200 in the
+// stored-CSC ones).  The host picks it for a matrix whose columns hold more than 24 entries (the longest run its last
+// flush met; without history: pending entries per column).  Runs of at most 16 go through the tier's 2-lane form.
+template <bool FRESH, bool PIECES, bool BIG, int KEYS, bool SMALL = false, bool GRP = false>
 __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
+    static_assert(!GRP || (!PIECES && !BIG && !SMALL), "the group-tier kernel exists for the plain regular form only");
     constexpr bool K32 = KEYS == 1 || KEYS == 2 || KEYS == 6 || KEYS == 7, UPD = KEYS == 2 || KEYS == 3 || KEYS == 5 || KEYS == 7,
                    P32 = KEYS == 4 || KEYS == 5;
     static_assert(PIECES == (KEYS >= 3) || KEYS == 0, "KEYS 3 .. 7 are piece formats, 1 / 2 are not");
@@ -1256,7 +1262,7 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
         // the run by its lane 2.5 to 4 times; the insertion tier is gone)
         const int reg_max = BIG ? REG_RUN : 16;
         if (t == 0 && maxrun > 16) atomicMax(a.maxrun_seen, maxrun);  // (tells the host which kernel variant suits this matrix)
-        if (!done && maxrun <= reg_max && a.rem_bits <= REG_MAX_REM) {
+        if (!GRP && !done && maxrun <= reg_max && a.rem_bits <= REG_MAX_REM) {
 #pragma unroll
             for (int i = 0; i < NI; i++)
                 if (wbase + i * ESP_WAVE < n) skey[ccnt[(u32)(k[i] >> csh)] + slot[i]] = k[i];
@@ -1276,11 +1282,7 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
                     lb_done = reg_tier<REG_RUN, FRESH, UPD>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
                 done = true;
             }
-        } else if constexpr (!SMALL && !BIG && (FRESH || K32)) {
-            // (over a stored CSC only the 4-byte-key forms carry it -- what a producer's or a bulk append's partition hands over;
-            // packed keys over a stored pattern: the radix tier.  The stored-CSC fold looks every (col,row) up in its column,
-            // and inlined into the packed-key kernel that code cost segments that never come here 200 bytes of scratch per
-            // lane: the tail flush of config 3 0.88 -> 1.06 ms)
+        } else if constexpr (GRP) {
             // ---- group tier: runs of up to 256 entries sorted by 2 .. 16 lanes each, keys in registers (see group_sort)
             if (!done && maxrun <= GROUP_MAX && a.rb <= 30 && a.cl_bits <= GROUP_CL_BITS && !a.no_group) {
                 u32 rmin = ~0u, rmax = 0u;

@@ -80,6 +80,7 @@ struct Variant {
     bool big;     // carries the 24-input register tier
     bool small_variant;  // segments of at most 3072 entries over at most 256 columns: three workgroups per CU
     int keys;     // key format 0 .. 7
+    bool grp = false;  // the group-tier kernel (column runs of more than 24 entries): regular form only
 };
 // enqueues the kernel; false when the combination has no instantiation
 bool launch(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);
@@ -88,5 +89,6 @@ bool launch_small(const Variant &v, unsigned grid, hipStream_t stream, const Arg
 bool launch_pieces_fresh(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);   // local_c.hip
 bool launch_pieces_stored(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);  // local_d.hip
 bool launch_pieces_small(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);   // local_e.hip
+bool launch_group(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);          // local_f.hip
 
 }  // namespace esplocal
