@@ -241,21 +241,22 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         for (i64 first = 0; first < S; first += max_grid) {
             const unsigned grid = (unsigned)std::min<i64>(max_grid, S - first);
             a.first = first;
-            // (the variant with the 24-input register tier for a matrix whose last flush met such runs)
-            const bool big = h->seen_maxrun > 16 && h->seen_maxrun <= esplocal::REG_RUN && h->force_path != ESP_PATH_NO_BIG_VARIANT;  // (26: test hook, runs of 17..24 through the group tier)
             // (key format: 0 packed, 1 four-byte keys of one kind, 2 four-byte keys that are all UPDATEs)
             // (3: packed keys whose kinds are all UPDATE -- the pieces of a shard)
             // (4 / 5: pieces of which one -- a shard's own range -- holds 4-byte keys; 5: everything is an UPDATE)
             // (6 / 7: pieces that all hold 4-byte keys of one kind -- a producer's batch and its tail; 7: UPDATE)
-            const int keys = st.npieces > 0 ? (st.all32 ? (st.kind == ESP_UPDATE && h->force_path != ESP_PATH_GENERIC_FOLD ? 7 : 6)
-                                               : st.p32_piece >= 0 ? (st.all_update && h->force_path != ESP_PATH_GENERIC_FOLD ? 5 : 4)
-                                                                   : (st.all_update && h->force_path != ESP_PATH_GENERIC_FOLD ? 3 : 0))
-                                            : st.key_bytes != 4 ? 0 : (st.kind == ESP_UPDATE && h->force_path != ESP_PATH_GENERIC_FOLD ? 2 : 1);
+            const bool generic = h->force_path == ESP_PATH_GENERIC_FOLD;
+            const int keys = st.npieces > 0 ? (st.all32 ? (st.kind == ESP_UPDATE && !generic ? 7 : 6)
+                                               : st.p32_piece >= 0 ? (st.all_update && !generic ? 5 : 4)
+                                                                   : (st.all_update && !generic ? 3 : 0))
+                                            : st.key_bytes != 4 ? 0 : (st.kind == ESP_UPDATE && !generic ? 2 : 1);
             h->last_fold_update = keys >= 2 ? 1 : 0;
-            // (the instantiations live in local_*.hip)
-            // (the group-tier kernel for a matrix whose columns hold more than 24 entries: what the last flush met, or -- no
-            // history -- the pending entries per column)
+            // the longest column run: what the handle's last flush met, or -- no history -- the pending entries per column (a
+            // P1 mesh in 2-D: 24, in 3-D: 120; a wrong guess costs that one flush the radix tier)
             const double longest = h->seen_maxrun > 0 ? (double)h->seen_maxrun : (double)h->count / (double)std::max<i64>(col_end - col_begin, 1);
+            // (the variant with the 24-input register tier for runs of 17 .. 24; 26: test hook, never)
+            const bool big = longest > 16.0 && longest <= (double)esplocal::REG_RUN && h->force_path != ESP_PATH_NO_BIG_VARIANT;
+            // (the group-tier kernel for longer runs)
             const bool grp = st.npieces == 0 && !small_variant && keys <= 2 && longest > (double)esplocal::REG_RUN && h->force_path != ESP_PATH_NO_GROUP_TIER &&
                              h->force_path != ESP_PATH_RADIX_TAIL_ONLY;
             esplocal::Variant var{Z0 == 0, st.npieces > 0, big && !small_variant && !grp, small_variant, keys};
