@@ -83,7 +83,8 @@ int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn, const u64 *new_key, const doub
         a.ncols = ncols;
         a.out_row = (i64 *)h->rowval2.p;
         a.out_val = (double *)h->nzval2.p;
-        hipLaunchKernelGGL(espmerge::colmerge_k, dim3(grid_for(ncols, espmerge::CT)), dim3(espmerge::THREADS), 0, h->stream, a);
+        hipLaunchKernelGGL((espmerge::colmerge_k<espmerge::CT, espmerge::CT_SCAP>), dim3(grid_for(ncols, espmerge::CT)), dim3(espmerge::THREADS), 0,
+                           h->stream, a);
         sp.add(1);
     }
     {
@@ -357,6 +358,29 @@ int32_t flush_global(esp_handle *h, int mode, i64 *Zn_out) {
 __global__ void piece_totals_k(const i64 *__restrict__ pstart, int P, i64 nb, unsigned long long *__restrict__ maxlen,
                                unsigned long long *__restrict__ negative);
 
+// The pending entries start at pend_off of the buffer (behind a batch that was flushed by itself): move them to the front,
+// in chunks of at most pend_off entries (source and destination of one copy never overlap).  On failure they are dropped:
+// the batch in front of them is in the matrix already and must not be applied again.
+int32_t settle_offset(esp_handle *h) {
+    const i64 off = h->pend_off, T = h->count;
+    if (off == 0) return ESP_OK;
+    h->pend_off = 0;
+    Span sp(h, ESP_ST_COPY);
+    for (i64 at = 0; at < T; at += off) {
+        const i64 c = std::min(off, T - at);
+        hipError_t e1 = hipMemcpyAsync((u64 *)h->keys.p + at, (const u64 *)h->keys.p + off + at, sizeof(u64) * (size_t)c, hipMemcpyDeviceToDevice, h->stream);
+        if (e1 == hipSuccess)
+            e1 = hipMemcpyAsync((double *)h->vals.p + at, (const double *)h->vals.p + off + at, sizeof(double) * (size_t)c, hipMemcpyDeviceToDevice, h->stream);
+        if (e1 != hipSuccess) {
+            h->count = 0;
+            pending_changed(h);
+            FAIL(h, ESP_ERR_HIP, "esp_flush: %s while moving the entries behind a flushed batch; they were dropped", hipGetErrorString(e1));
+        }
+        sp.add(2);
+    }
+    return ESP_OK;
+}
+
 // bucket starts of a tail sorted by its prefix digit: first position whose digit is >= d, for d = 0 .. NB
 __global__ void tail_bucket_starts_k(const u64 *__restrict__ keys, i64 T, u64 base, u64 span, int shift, i64 NB, i64 *__restrict__ out) {
     const i64 d = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -544,26 +568,13 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
         CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
         CK(flush_local(h, st, mode, &Zsplit));  // (on failure everything is still pending)
-        // the tail is the pending buffer now: packed keys, moved to the front (chunks of at most E0 entries: source and
-        // destination of one copy never overlap)
+        // the tail is the pending buffer now: packed keys BEHIND the batch's -- the partition reads them where they lie
+        // (pend_off; settle_offset moves them to the front for the paths that expect them there)
         const i64 E0 = pp.E, T = pp.tail;
-        {
-            Span sp(h, ESP_ST_COPY);
-            for (i64 at = 0; at < T; at += E0) {
-                const i64 c = std::min(E0, T - at);
-                hipError_t e1 = hipMemcpyAsync((u64 *)h->keys.p + at, (const u64 *)h->keys.p + E0 + at, sizeof(u64) * (size_t)c, hipMemcpyDeviceToDevice, h->stream);
-                if (e1 == hipSuccess)
-                    e1 = hipMemcpyAsync((double *)h->vals.p + at, (const double *)h->vals.p + E0 + at, sizeof(double) * (size_t)c, hipMemcpyDeviceToDevice, h->stream);
-                if (e1 != hipSuccess) {  // (the batch is in the matrix already: it must not stay pending and be applied again)
-                    h->count = 0;
-                    pending_changed(h);
-                    FAIL(h, ESP_ERR_HIP, "esp_flush: %s while moving the entries behind a flushed batch; they were dropped", hipGetErrorString(e1));
-                }
-                sp.add(2);
-            }
-        }
         const bool one_kind = h->kind_uniform >= 0 && h->kind_noted == h->count;
         h->count = T;
+        h->pend_off = E0;
+        if (h->force_path == ESP_PATH_TAIL_TO_FRONT) CK(settle_offset(h));
         h->pre.valid = false;
         h->kind_noted = one_kind ? T : 0;
         if (!one_kind) h->kind_uniform = -2;
@@ -630,12 +641,20 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         h->last_partition = 7;
     } else if (use_local) {
         Sorted st;
-        CK(sort_msd(h, &st));
+        const i64 off0 = h->pend_off;
+        {
+            const int32_t rc = sort_msd(h, &st);
+            if (rc != ESP_OK) {
+                (void)settle_offset(h);
+                return rc;
+            }
+        }
         if (!st.in_primary) {  // keep "pending data lives in keys/vals" true for the general path
             std::swap(h->keys, h->keys2);
             std::swap(h->vals, h->vals2);
             h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
             st.in_primary = true;
+            h->pend_off = 0;  // (the partition wrote from the front of the other pair)
         }
         if (st.local_ok) {
             const int32_t rc = flush_local(h, st, mode, &Zn);
@@ -645,12 +664,17 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
                 std::swap(h->keys, h->keys2);
                 std::swap(h->vals, h->vals2);
                 h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
+                h->pend_off = off0;
             }
-            CK(rc);
+            if (rc != ESP_OK) {
+                (void)settle_offset(h);
+                return rc;
+            }
         } else {
             use_local = false;
         }
     }
+    if (!use_local && !h->part_assembled) CK(settle_offset(h));
     if (!use_local && !h->part_assembled) CK(flush_global(h, mode, &Zn));
     if (split) h->last_partition = 6;
     h->last_path = (use_local || h->part_assembled) ? 1 : 2;
@@ -658,6 +682,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
     h->values_version++;  // (hits were applied in place)
     HIPCK(h, hipGetLastError());
     h->count = 0;
+    h->pend_off = 0;
     pending_changed(h);
     if (h->timing && fa) {
         hipEvent_t fb = ev_get(h);

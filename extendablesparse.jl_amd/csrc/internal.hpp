@@ -83,6 +83,8 @@ struct esp_handle {
     // sort_msd over ITEM records (femitems.hpp): a segment may hold plan_cap records (the bucket kernel's capacity in
     // updates / updates per item), and a shuffled stream need not be tried as a pre-sorted one
     i64 plan_cap = 0;
+    // the pending entries start at this entry of keys/vals (behind a batch that esp_flush flushed by itself); else 0
+    i64 pend_off = 0;
     bool item_mode = false;
     bool item_keys_only = false;  // ... whose records are single words (the value arrays are not touched)
     bool shard_user = false;     // the handle is driven through esp_shard_*: its flushes partition by owner first
@@ -325,6 +327,7 @@ int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSetup *ps)
 int32_t prepart_rank(esp_handle *h, PartSetup *ps);
 int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took);
 int32_t pending_materialize(esp_handle *h);
+int32_t settle_offset(esp_handle *h);
 int32_t item_produce_fem(esp_handle *h, const espgen::FemArgs &fa, i64 E, bool *took);
 int32_t partition_pass(esp_handle *h, espradix::Pass &p, i64 max_tiles);
 int32_t sort_pending_lsd(esp_handle *h, const u64 **sk, const double **sv);

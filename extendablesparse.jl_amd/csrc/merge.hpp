@@ -114,7 +114,8 @@ static __global__ __launch_bounds__(THREADS) void merge_k(Args a) {
 // The two lists of a column are disjoint (hits were folded into the stored values) and short, so the counts are
 // binary searches of a few steps in cached memory; consecutive lanes take consecutive entries and write nearly
 // consecutive places.  Reads 16 B per stored and per new entry + 16 B per column, writes 16 B per output entry.
-constexpr int CT = 128;  // (measured at config 3: 64 -> 1.69, 128 -> 1.54, 256 -> 1.61, 512 -> 1.85, 1024 -> 1.98 ms)
+constexpr int CT = 128;  // (direct form, measured at config 3: 64 -> 1.69, 128 -> 1.54, 256 -> 1.61, 512 -> 1.85, 1024 -> 1.98 ms)
+constexpr int CT_SCAP = 2048;  // stored entries of a tile the staged form has room for (256 columns, 4096: no change)
 struct ColArgs {
     const i64 *old_colptr;  // 1-based values, n + 1
     const i64 *old_row;     // 1-based
@@ -128,28 +129,18 @@ struct ColArgs {
     double *out_val;
 };
 
-// The tile's new keys are staged in LDS (a tile of 256 stencil columns gains a few hundred; a tile with more than
-// NEWCAP of them searches global memory), every thread handles MB entries per round with all their loads requested
-// first, and the searches of a round's entries advance together (a binary search is a chain of dependent loads).
+// Direct form of a tile (kept for tiles the staged form below has no room for): the tile's new keys are staged in LDS
+// (a tile with more than NEWCAP of them searches global memory), every thread handles MB entries per round with all their
+// loads requested first, and the searches of a round's entries advance together (a binary search is a chain of
+// dependent loads).  Every entry is written straight to its place: consecutive lanes write nearly consecutive places, but
+// the holes the stored entries leave are filled by other lanes much later -- the lines leave the L2 half-written and
+// come back (config 3: 4.6 GB written for 2.4 GB of output).
 constexpr int NEWCAP = 1024, MB = 4;
-static __global__ __launch_bounds__(THREADS) void colmerge_k(ColArgs a) {
-    __shared__ i64 s_cp[CT + 1];
-    __shared__ u64 s_ns[CT + 1];
-    __shared__ u64 s_new[NEWCAP];
+template <int CTV>
+__device__ __forceinline__ void colmerge_direct(const ColArgs &a, i64 c0, int nc, const i64 *s_cp, const u64 *s_ns, const u64 *s_new, bool staged) {
     const int t = threadIdx.x;
-    const i64 c0 = a.c_begin + (i64)blockIdx.x * CT;
-    const int nc = (int)min((i64)CT, a.c_begin + a.ncols - c0);
-    for (int q = t; q <= nc; q += THREADS) {
-        s_cp[q] = a.old_colptr[c0 + q] - 1;
-        s_ns[q] = a.newstart[c0 + q];
-    }
-    __syncthreads();
     const i64 op0 = s_cp[0], op1 = s_cp[nc];
     const i64 np0 = (i64)s_ns[0], np1 = (i64)s_ns[nc];
-    const bool staged = np1 - np0 <= (i64)NEWCAP;
-    if (staged)
-        for (i64 q = np0 + t; q < np1; q += THREADS) s_new[q - np0] = a.new_key[q];
-    __syncthreads();
     const u64 rowmask = (1ull << a.rb) - 1ull;
     // ---- stored entries
     for (i64 base = op0; base < op1; base += (i64)MB * THREADS) {
@@ -241,6 +232,121 @@ static __global__ __launch_bounds__(THREADS) void colmerge_k(ColArgs a) {
             const i64 out = pos[i] + b[i];  // = q + (colptr[c]-1) + count
             a.out_row[out] = row[i];
             a.out_val[out] = val[i];
+        }
+    }
+}
+
+// Staged form (the common tile: rows below 2^32, at most SCAP stored and NEWCAP new entries): the tile's merged ORDER is
+// made in LDS first -- a 2-byte source index per output place -- and the output then leaves as whole lines, place by
+// place, each lane gathering its entry from where the index points.
+//   phase 1  stored entry sp: row -> s_row[sp] (the only read of old_row), place = sp + #new entries in front  (search in s_new)
+//   phase 2  new entry j    :                                     place = j  + #stored entries in front        (search in s_row)
+//   phase 3  place o: s_src[o] -> row from s_row / s_new, value from old_val / new_val (their only read) -> out[o]
+template <int CTV, int SCAP>
+static __global__ __launch_bounds__(THREADS) void colmerge_k(ColArgs a) {
+    __shared__ i64 s_cp[CTV + 1];
+    __shared__ u64 s_ns[CTV + 1];
+    __shared__ u64 s_new[NEWCAP];
+    __shared__ u32 s_row[SCAP];
+    __shared__ unsigned short s_src[SCAP + NEWCAP];
+    const int t = threadIdx.x;
+    const i64 c0 = a.c_begin + (i64)blockIdx.x * CTV;
+    const int nc = (int)min((i64)CTV, a.c_begin + a.ncols - c0);
+    for (int q = t; q <= nc; q += THREADS) {
+        s_cp[q] = a.old_colptr[c0 + q] - 1;
+        s_ns[q] = a.newstart[c0 + q];
+    }
+    __syncthreads();
+    const i64 op0 = s_cp[0], op1 = s_cp[nc];
+    const i64 np0 = (i64)s_ns[0], np1 = (i64)s_ns[nc];
+    const bool staged = np1 - np0 <= (i64)NEWCAP;
+    if (staged)
+        for (i64 q = np0 + t; q < np1; q += THREADS) s_new[q - np0] = a.new_key[q];
+    const bool fast = staged && op1 - op0 <= (i64)SCAP && a.rb <= 32;
+    if (!fast) {
+        __syncthreads();
+        colmerge_direct<CTV>(a, c0, nc, s_cp, s_ns, s_new, staged);
+        return;
+    }
+    const int ns = (int)(op1 - op0), nn = (int)(np1 - np0);
+    const u64 rowmask = (1ull << a.rb) - 1ull;
+    // (the rows are requested before the barrier the staged new keys need)
+    u32 row[(SCAP + THREADS - 1) / THREADS];
+    constexpr int SR = (SCAP + THREADS - 1) / THREADS;
+#pragma unroll
+    for (int i = 0; i < SR; i++) {
+        const int sp = i * THREADS + t;
+        row[i] = (u32)(a.old_row[op0 + (sp < ns ? sp : (ns > 0 ? ns - 1 : 0))] - 1);
+    }
+    __syncthreads();
+    // ---- phase 1
+#pragma unroll
+    for (int i = 0; i < SR; i++) {
+        const int sp = i * THREADS + t;
+        if (sp >= ns) break;
+        s_row[sp] = row[i];
+        const i64 p = op0 + sp;
+        int lo = 0, hi = nc;  // the column: largest c with s_cp[c] <= p
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_cp[mid] <= p)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        int b = (int)((i64)s_ns[lo] - np0), e = (int)((i64)s_ns[lo + 1] - np0);
+        while (b < e) {  // new entries of the column with a smaller row
+            const int mid = b + ((e - b) >> 1);
+            if ((u32)(s_new[mid] & rowmask) < row[i])
+                b = mid + 1;
+            else
+                e = mid;
+        }
+        s_src[sp + b] = (unsigned short)sp;
+    }
+    __syncthreads();
+    // ---- phase 2
+    for (int j = t; j < nn; j += THREADS) {
+        const u64 key = s_new[j];
+        const int lc = (int)((i64)(key >> a.rb) - c0);
+        const u32 r = (u32)(key & rowmask);
+        int b = (int)(s_cp[lc] - op0), e = (int)(s_cp[lc + 1] - op0);
+        while (b < e) {  // stored entries of the column with a smaller row
+            const int mid = b + ((e - b) >> 1);
+            if (s_row[mid] < r)
+                b = mid + 1;
+            else
+                e = mid;
+        }
+        s_src[j + b] = (unsigned short)(0x8000u | (unsigned)j);
+    }
+    __syncthreads();
+    // ---- phase 3
+    const i64 ob = op0 + np0;
+    const int no = ns + nn;
+    for (int base = 0; base < no; base += MB * THREADS) {
+        double val[MB];
+        i64 r[MB];
+#pragma unroll
+        for (int i = 0; i < MB; i++) {
+            const int o = base + i * THREADS + t;
+            const unsigned src = s_src[o < no ? o : no - 1];
+            if (src & 0x8000u) {
+                const int j = (int)(src & 0x7FFFu);
+                val[i] = a.new_val[np0 + j];
+                r[i] = (i64)(s_new[j] & rowmask) + 1;
+            } else {
+                val[i] = a.old_val[op0 + src];
+                r[i] = (i64)s_row[src] + 1;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < MB; i++) {
+            const int o = base + i * THREADS + t;
+            if (o < no) {
+                a.out_row[ob + o] = r[i];
+                a.out_val[ob + o] = val[i];
+            }
         }
     }
 }

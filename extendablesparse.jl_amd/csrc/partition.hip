@@ -508,8 +508,9 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
     CK(ensure(h, h->tilef[0], sizeof(u64) * (size_t)(4 + espscan::workspace_elems(4))));
     const i64 T = ceil_div<i64>(E, espradix::TILE);
     bool tiles_ready = false;  // seg[cur] has its tile table in tilef[cur] (only the 8-bit passes need one)
-    u64 *kin = (u64 *)h->keys.p, *kout = (u64 *)h->keys2.p;
-    double *vin = (double *)h->vals.p, *vout = (double *)h->vals2.p;
+    // (pend_off: the pending entries start behind a batch that was flushed by itself -- esp_flush)
+    u64 *kin = (u64 *)h->keys.p + h->pend_off, *kout = (u64 *)h->keys2.p;
+    double *vin = (double *)h->vals.p + h->pend_off, *vout = (double *)h->vals2.p;
     i64 maxlen = E;
     bool ok = true;
     int pass_idx = 0;
@@ -641,7 +642,7 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
         FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (4-byte keys met a further partition pass)");
     out->sk = kin;
     out->sv = vin;
-    out->in_primary = (kin == (u64 *)h->keys.p);
+    out->in_primary = (kin == (u64 *)h->keys.p + h->pend_off);
     out->S = S;
     out->total = E;
     out->seg_start = (const i64 *)h->seg[cur].p;

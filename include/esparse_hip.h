@@ -352,8 +352,10 @@ typedef enum {
     ESP_PATH_NO_BIG_VARIANT = 26,    /* never the bucket-kernel variant with the 24-input register tier                      */
     ESP_PATH_NO_APPEND_PARTITION = 27, /* esp_append_* / esp_commit on an empty buffer pack in stream order (the append is not
                                         the partition)                                                                      */
-    ESP_PATH_TWO_WORD_ITEMS = 28     /* the item partition of esp_generate_fem moves 16-byte records (key | cell and vertex)
+    ESP_PATH_TWO_WORD_ITEMS = 28,    /* the item partition of esp_generate_fem moves 16-byte records (key | cell and vertex)
                                         even where the cell's number fits into the key                                      */
+    ESP_PATH_TAIL_TO_FRONT = 29      /* the entries behind a batch that was flushed by itself are copied to the front of
+                                        the buffer before their partition (instead of being read where they lie)            */
 } esp_debug_path;
 /* last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general) */
 int32_t esp_debug_force_path(esp_handle *h, int32_t path);

@@ -1720,12 +1720,14 @@ def test_config3_digest_128(esp):
     N = n ** 3
     d = gu.digests("digests_large.txt")["cfg3_%d" % n]
     I2, J2, V2 = gu.cfg3_new_positions(n)
-    for order in ("append_first", "generate_first", "generate_first_19"):
+    for order in ("append_first", "generate_first", "generate_first_19", "generate_first_29"):
         A = esp.ExtendableSparseMatrix(N, N)
         A.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1)
         A.flush()
         if order.endswith("_19"):
             A.debug_force_path(19)                   # (no batch + tail flush: packed keys, the ordinary partition)
+        if order.endswith("_29"):
+            A.debug_force_path(29)                   # (the tail is copied to the front, not partitioned where it lies)
         if order == "append_first":
             A.append(UPDATE, I2, J2, V2)
             A.generate_fdrand(n, n, n, seed=0x5EED0012, rand_mode=1)
@@ -1735,7 +1737,7 @@ def test_config3_digest_128(esp):
             A.append(UPDATE, I2, J2, V2)
         A.flush()
         # (the bench's order: the producer's batch is flushed as it is, the new couplings as a flush of their own)
-        assert (A.debug_last_partition() == 6) == (order == "generate_first"), (order, A.debug_last_partition())
+        assert (A.debug_last_partition() == 6) == (order in ("generate_first", "generate_first_29")), (order, A.debug_last_partition())
         arrs = hip_arrays(A)
         assert len(arrs[1]) == int(d["nnz"])
         assert gu.digest(*arrs) == d["csc"], order
