@@ -199,6 +199,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         a.no_group = h->force_path == ESP_PATH_NO_GROUP_TIER ? 1 : 0;  // 24: test hook, long column runs through the radix tier
         // (every pending entry was noted with one kind; pieces of other ranks carry kinds this handle has not seen)
         a.kind_all = (st.npieces == 0 && h->kind_uniform >= 0 && h->kind_noted == h->count && h->force_path != ESP_PATH_GENERIC_FOLD) ? h->kind_uniform : -1;
+        a.expect_hits = st.expect_hits >= 0 ? st.expect_hits : (h->seen_hits ? 1 : 0);
         a.col_end = col_end;
         a.n_cols = h->n;
         a.keys_in = st.sk;
@@ -291,6 +292,8 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
     if (lookback_err & 4u) FAIL(h, ESP_ERR_HIP, "esp_flush: internal error (early segment total differs from the folded total)");
     const i64 Zn = (i64)(h->pin_scalar[0] & esplocal::ST_VAL);
     *Zn_out = Zn;
+    // (history for the next flush over a stored pattern: fewer than a quarter of the entries opened a new position)
+    if (Z0 > 0 && st.expect_hits < 0 && st.total > 0) h->seen_hits = Zn * 4 <= st.total;
     if (a.stop_after || Zn == 0) return ESP_OK;
     if (Z0 == 0) {
         // the scratch pair now holds rowval/nzval: rotate the buffers instead of copying.  The old
@@ -565,6 +568,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         st.key_bytes = pp.key_bytes;
         st.kind = pp.kind;
         st.maxlen = pp.maxlen;
+        st.expect_hits = 1;  // (the batch repeats the stream that built the pattern; what is new comes behind it)
         CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
         CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
         CK(flush_local(h, st, mode, &Zsplit));  // (on failure everything is still pending)
@@ -657,6 +661,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
             h->pend_off = 0;  // (the partition wrote from the front of the other pair)
         }
         if (st.local_ok) {
+            if (split) st.expect_hits = 0;
             const int32_t rc = flush_local(h, st, mode, &Zn);
             if (rc != ESP_OK && st.key_bytes == 4) {
                 // the batch stays pending: its packed keys are intact in the scratch pair (the partition wrote the 4-byte

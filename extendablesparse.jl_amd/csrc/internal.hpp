@@ -58,6 +58,7 @@ struct esp_handle {
     i64 chunk_cap = 0, hint = 0;
     int chunk_pb = 0;
     int runs_skip = 0, runs_penalty = 0;  // back-off after a stream turned out not to be pre-sorted
+    bool seen_hits = true;                // the last flush over a stored pattern mostly hit stored positions (re-assembly)
     int seen_maxrun = 0;                  // longest column run the bucket kernel met in the last flush
     int last_partition = 0;               // 1 = run-based single pass, 2 = 8-bit passes only, 4 = the producer's, 7 = shard pieces
     // Producer-side partition: a device-side producer appended to the empty buffer with its PART kernel (runpart.hpp,
@@ -264,6 +265,7 @@ struct Sorted {
     const i64 *pstart = nullptr;
     const void *const *ptab = nullptr;
     bool has_base = false;  // the segments' key base, if it is not the handle's window / shard range
+    int expect_hits = -1;   // 1 / 0: the caller knows what the entries will mostly do over the stored pattern; -1: the handle's history
     u64 base = 0;
 };
 

@@ -271,7 +271,7 @@ __device__ __forceinline__ u32 count_emitted(const u64 (&x)[R], const double (&x
 // NOCSC: the matrix holds no entries yet (fresh build): no position can hit the CSC
 template <int R, bool NOCSC, bool UPD>
 __device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval, const u64 (&x)[R], int rs, int len, u64 hi,
-                                         u64 rowmask) {
+                                         u64 rowmask, i64 ccur = 0, i64 cend = 0) {
     if constexpr (NOCSC) {
         double xv[R];
         load_run_values<R>(sval, x, xv);
@@ -311,20 +311,14 @@ __device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval,
     // (findindex, sparsematrixcsc.jl:7-23, restated as a merge walk; same result as the binary search).
     // (measured: fetching the column in one batch and merging in registers -- no dependent loads -- costs
     // more instructions than the walk saves in latency: 13.6 against 8.4 ms at config 3)
-    double xv[R];
-    load_run_values<R>(sval, x, xv);
+    // (the values are read from LDS where they are used: the walk's state leaves no room for R of them in registers)
     int e = 0;
     bool present = false;
     double acc = 0.0;
     u64 psub = 0;
     u32 idx0 = 0;
     i64 pos = -1;
-    i64 ccur = 0, cend = 0;
-    if (a.csc.nnz > 0 && len > 0) {
-        const i64 col0 = (i64)((hi + (x[0] >> SUB_SHIFT)) >> a.rb);
-        ccur = a.csc.colptr[col0] - 1;
-        cend = a.csc.colptr[col0 + 1] - 1;
-    }
+    // (ccur, cend: the column's range in the CSC, requested by the caller before it sorted the run -- csc_column)
 #pragma unroll
     for (int j = 0; j <= R; j++) {
         const bool valid = j < R && j < len;
@@ -345,15 +339,90 @@ __device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval,
                 present = (pos >= 0 && a.mode == ESP_FLUSH_ROUTED);
                 acc = present ? a.csc.nzval[pos] : 0.0;
             }
+            const double vj = sval[(kj >> ESP_TAG_BITS) & (CAP - 1)];
             if constexpr (UPD)
-                espfold::fold_step_update(present, acc, xv[j < R ? j : 0]);
+                espfold::fold_step_update(present, acc, vj);
             else
-                espfold::fold_step_sel(present, acc, (u32)(kj & ESP_TAG_MASK), xv[j < R ? j : 0]);
+                espfold::fold_step_sel(present, acc, (u32)(kj & ESP_TAG_MASK), vj);
         }
     }
 #pragma unroll
     for (int j = 0; j < R; j++)
         if (j >= e && j < len) skey[rs + j] = NOREC;
+}
+
+// Ordered fold of one sorted run over a SHORT stored column (at most CSC_SHORT entries, rows below 2^32): the walk of
+// fold_run is a chain of dependent global loads -- a row, then the value it hits, then the store, for every group of
+// the run (stencil re-assembly: 14 round trips, 8 of a segment's 17 us).  Here the column's rows and values are
+// requested at once (one round trip, consecutive lanes read consecutive memory) and held in registers under STATIC
+// indices: the merge runs over the stored entries in an unrolled outer loop and consumes the run -- written back to
+// LDS in sorted order, so that IT can be indexed dynamically -- in an inner loop.  Stores of hits are issued and not
+// waited for.  Same results as fold_run (the same fold steps in the same order).
+constexpr int CSC_SHORT = 8;
+// (Taken when the host expects hits -- Args::expect_hits: a tail of new positions would fetch 8 bytes per stored entry
+// for nothing; it walks.)
+template <int R, bool UPD>
+__device__ __forceinline__ void fold_run_short_csc(const Args &a, u64 *skey, double *sval, const u64 (&x)[R], int rs, int len, u64 hi,
+                                                   u64 rowmask, i64 c0, int n) {
+    u32 r0[CSC_SHORT];
+    double sv[CSC_SHORT];
+#pragma unroll
+    for (int i = 0; i < CSC_SHORT; i++) {
+        const i64 at = c0 + (i < n ? i : n - 1);
+        r0[i] = (u32)(a.csc.rowval[at] - 1);
+        sv[i] = a.csc.nzval[at];
+    }
+#pragma unroll
+    for (int j = 0; j < R; j++)
+        if (j < len) skey[rs + j] = x[j];
+    const bool routed = a.mode == ESP_FLUSH_ROUTED;
+    int p = 0, e = 0;
+    bool present = false;
+    double acc = 0.0;
+    u64 psub = 0;
+    u32 idx0 = 0;
+    i64 pos = -1;
+    auto close = [&]() {
+        if (pos >= 0) {
+            if (routed)
+                a.csc.nzval[pos] = acc;
+            else if (present)
+                a.csc.nzval[pos] = a.csc.nzval[pos] + acc;  // csc operand first, sparsematrixlnk.jl:363
+        } else if (present) {
+            skey[rs + e] = (psub << SUB_SHIFT) | ((u64)idx0 << ESP_TAG_BITS);
+            sval[idx0] = acc;
+            e++;
+        }
+    };
+#pragma unroll
+    for (int i = 0; i <= CSC_SHORT; i++) {
+        // stored entry i (behind the column: nothing bounds the rows any more)
+        const u64 ri = (i < CSC_SHORT && i < n) ? (u64)r0[i < CSC_SHORT ? i : 0] : ~0ull;
+        const double si = sv[i < CSC_SHORT ? i : 0];
+        while (p < len) {
+            const u64 kj = skey[rs + p];
+            const u64 sub = kj >> SUB_SHIFT;
+            const u64 row0 = (hi + sub) & rowmask;
+            if (row0 > ri) break;
+            if (p == 0 || sub != psub) {
+                if (p > 0) close();
+                psub = sub;
+                idx0 = (u32)(kj >> ESP_TAG_BITS) & (CAP - 1);
+                const bool hit = row0 == ri;
+                pos = hit ? c0 + i : -1;
+                present = hit && routed;
+                acc = present ? si : 0.0;
+            }
+            const double vj = sval[(kj >> ESP_TAG_BITS) & (CAP - 1)];
+            if constexpr (UPD)
+                espfold::fold_step_update(present, acc, vj);
+            else
+                espfold::fold_step_sel(present, acc, (u32)(kj & ESP_TAG_MASK), vj);
+            p++;
+        }
+    }
+    if (len > 0) close();
+    for (int j = e; j < len; j++) skey[rs + j] = NOREC;
 }
 
 // The same fold for a run of ANY length that lies sorted in LDS (skey[rs .. rs+len)): the slow tier of the small
@@ -561,8 +630,24 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
         const int rs = (int)ccnt[c];
         const int len = (int)ccnt[c + 1] - rs;
         u64 x[R];
+        // The fold of a run over a stored pattern starts a chain of dependent loads with the column's range.  The column
+        // is known from any key of the run: the range is requested BEFORE the run is sorted and arrives while the
+        // network runs.  (Requesting the first and the last line of the column's rows and values here as well, so that
+        // the walk finds them in the cache: slower, 1.75 -> 1.88 ms for the re-assembly of the 256^3 stencil.)
+        i64 ccur = 0, cend = 0;
+        if (!FRESH && a.csc.nnz > 0 && len > 0) {
+            const i64 col0 = (i64)((hi + (skey[rs] >> SUB_SHIFT)) >> a.rb);
+            ccur = a.csc.colptr[col0] - 1;
+            cend = a.csc.colptr[col0 + 1] - 1;
+        }
         sort_run_keys<R>(skey, rs, len, x);
-        fold_run<R, FRESH, UPD>(a, skey, sval, x, rs, len, hi, rowmask);  // (a FRESH launch has an empty CSC)
+#ifndef ESP_NO_SHORT_CSC
+        if (!FRESH && a.expect_hits && rowmask <= 0xFFFFFFFFull && ccur < cend && cend - ccur <= (i64)CSC_SHORT) {
+            fold_run_short_csc<R, UPD>(a, skey, sval, x, rs, len, hi, rowmask, ccur, (int)(cend - ccur));
+            continue;
+        }
+#endif
+        fold_run<R, FRESH, UPD>(a, skey, sval, x, rs, len, hi, rowmask, ccur, cend);  // (a FRESH launch has an empty CSC)
     }
     return false;
 }

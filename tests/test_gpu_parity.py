@@ -466,6 +466,65 @@ def test_bucket_kernel_tiers(esp, orc, per_col):
         assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
 
 
+def test_routed_fold_short_columns_and_history(esp, orc):
+    """The routed fold over SHORT stored columns (rows and values of a column fetched at once, merge in registers:
+    local.hpp fold_run_short_csc) and the walk, chosen by what the handle's last flush over the pattern did (hits /
+    mostly new positions): all-hit re-assembly, a flush of mostly new positions, then re-assembly twice (the first walks,
+    the second takes the short-column fold again); kinds SET / UPDATE / RAWUPDATE mixed, a zero update on an absent
+    position, and csc + buffer (ESP_FLUSH_PLUS: the stored value is the first operand).  A column that grew beyond 8
+    entries walks."""
+    n = 24
+    N = n ** 3
+    rng = np.random.default_rng(77)
+    A = esp.ExtendableSparseMatrix(N, N)
+    A.generate_fdrand(n, n, n, seed=61, rand_mode=1)
+    A.flush()
+    O = orc.fdrand(n, n, n, rand_mode=1, seed=61, style=orc.KIND_UPDATE)
+    assert_csc_equal(hip_arrays(A), O.arrays())
+
+    def both(kinds, I, J, V):
+        A.append(0, I, J, V, kinds=kinds)
+        O.apply(kinds, I, J, V)
+
+    def reassemble(seed, mixed):
+        I, J, V = orc.fdrand_stream(n, n, n, rand_mode=1, seed=seed)
+        if mixed:
+            kinds = rng.choice(np.array([UPDATE, orc.KIND_SET, orc.KIND_RAWUPDATE], np.uint8), len(I))
+            V = np.where(rng.random(len(I)) < 0.1, 0.0, V)
+            both(kinds, I, J, V)
+        else:
+            A.generate_fdrand(n, n, n, seed=seed, rand_mode=1)
+            O.apply(np.full(len(I), UPDATE, np.uint8), I, J, V)
+
+    reassemble(62, False)                                  # all hits: short-column fold, values fetched with the rows
+    A.flush(), O.flush()
+    assert_csc_equal(hip_arrays(A), O.arrays(), "all hits")
+    k = 3 * N                                              # mostly new positions, some hits, zero updates on absent positions
+    In, Jn = rng.integers(1, N + 1, k), np.sort(rng.integers(1, N + 1, k))
+    Vn = np.where(rng.random(k) < 0.2, 0.0, rng.standard_normal(k))
+    both(np.full(k, UPDATE, np.uint8), In, Jn, Vn)
+    A.flush(), O.flush()
+    assert_csc_equal(hip_arrays(A), O.arrays(), "mostly new")
+    for rnd, mixed in enumerate((False, True, True)):      # history says "new positions" once, then "hits" again
+        reassemble(70 + rnd, mixed)
+        if rnd == 2:                                       # ... with a few new positions among the hits
+            both(np.full(50, UPDATE, np.uint8), rng.integers(1, N + 1, 50), np.sort(rng.integers(1, N + 1, 50)), rng.standard_normal(50))
+        A.flush(), O.flush()
+        assert_csc_equal(hip_arrays(A), O.arrays(), "re-assembly %d" % rnd)
+    # csc + buffer over short columns (ESP_FLUSH_PLUS): the buffer is folded by itself, the stored value is the first operand
+    cp, rv, nz = O.arrays()
+    I, J, V = orc.fdrand_stream(n, n, n, rand_mode=1, seed=63)
+    I, J, V = I[:60000], J[:60000], V[:60000]
+    X = esp.SparseMatrixHIPCOO(N, N)
+    L = orc.SparseMatrixLNK(N, N)
+    X.append(UPDATE, I, J, V)
+    for i, j, v in zip(I, J, V):
+        L.updateindex(orc.OP_ADD, float(v), int(i), int(j))
+    got = X + esp.SparseMatrixCSC(N, N, cp, rv, nz)
+    want = L + orc.CSC(N, N, cp, rv, nz)
+    assert_csc_equal(got.arrays(), want.arrays())
+
+
 @pytest.mark.parametrize("force", [0, 17])
 def test_reassembly_with_a_few_new_entries(esp, orc, force):
     """Re-assembly over the stored pattern: almost every segment of the bucket kernel emits nothing (and does

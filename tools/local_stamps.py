@@ -18,6 +18,14 @@ n = 256
 N = fem ** 3 if fem else n ** 3
 A = esp.ExtendableSparseMatrix(N, N, capacity_hint=0 if fem else 12 * n * n * (n - 1) + 6 * n * n)
 reasm = int(os.environ.get("ESP_STAMP_REASM", "0"))   # 1: stamps of the SECOND flush (re-assembly over the existing CSC)
+cfg3 = int(os.environ.get("ESP_STAMP_CFG3", "0"))     # 1: config 3 -- stamps of the LAST bucket kernel of its flush (the tail's)
+if cfg3:
+    reasm = 1
+    g = torch.arange(N, device="cuda", dtype=torch.int64)
+    l = g[(g % n) < n - 2] + 1
+    rows3, cols3 = torch.cat([l, l + 2]), torch.cat([l + 2, l])
+    vals3 = torch.rand(rows3.numel(), device="cuda", dtype=torch.float64)
+    torch.cuda.synchronize()
 for it in range(3):
     A.reset()
     if reasm:
@@ -27,6 +35,12 @@ for it in range(3):
         A.generate_fem(3, fem, seed=4, order_mode=1)
     else:
         A.generate_fdrand(n, n, n, rand_mode=1)
+    if cfg3:
+        import ctypes as C
+        d = A._d
+        d.ck(d.lib.esp_append_device(d.h, C.c_void_p(rows3.data_ptr()), C.c_void_p(cols3.data_ptr()), C.c_void_p(vals3.data_ptr()), None,
+                                     esp.ESP_UPDATE, 0, rows3.numel()))
+        A._touch()
     if it == 2:
         os.environ["ESP_LOCAL_STAMPS"] = "gpurun_out/stamps.bin"
     A.flush()
