@@ -499,7 +499,7 @@ def test_routed_fold_short_columns_and_history(esp, orc):
     reassemble(62, False)                                  # all hits: short-column fold, values fetched with the rows
     A.flush(), O.flush()
     assert_csc_equal(hip_arrays(A), O.arrays(), "all hits")
-    k = 3 * N                                              # mostly new positions, some hits, zero updates on absent positions
+    k = N // 2                                             # mostly new positions, some hits, zero updates on absent positions
     In, Jn = rng.integers(1, N + 1, k), np.sort(rng.integers(1, N + 1, k))
     Vn = np.where(rng.random(k) < 0.2, 0.0, rng.standard_normal(k))
     both(np.full(k, UPDATE, np.uint8), In, Jn, Vn)
