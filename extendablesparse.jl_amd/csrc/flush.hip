@@ -546,7 +546,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
                             pp.span == h->win_span && pp.maxlen <= (i64)esplocal::CAP && pp.K - pp.pb <= esplocal::MAX_REM_BITS;
         if (!usable) CK(pending_materialize(h));
     }
-    bool served = false, split = false;
+    bool served = false, split = false, tail_direct = false;
     i64 Zsplit = 0;  // new entries of the batch's own flush
     if (h->pre.valid && h->pre.tail > 0 && h->nnz > 0 && mode == ESP_FLUSH_ROUTED && h->force_path != ESP_PATH_BATCH_TAIL_ONE_FLUSH) {
         // Batch + tail over a stored pattern (a re-assembly whose mesh gained couplings): the batch by itself -- its buckets
@@ -576,6 +576,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         // (pend_off; settle_offset moves them to the front for the paths that expect them there)
         const i64 E0 = pp.E, T = pp.tail;
         const bool one_kind = h->kind_uniform >= 0 && h->kind_noted == h->count;
+        const esp_handle::TailPart tp = h->tailpart;  // (the tail may have been partitioned as it was appended)
         h->count = T;
         h->pend_off = E0;
         if (h->force_path == ESP_PATH_TAIL_TO_FRONT) CK(settle_offset(h));
@@ -586,6 +587,28 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         h->values_version++;
         E = T;
         split = true;
+        if (tp.valid && tp.T == T && h->pend_off == E0 && tp.base == h->win_base && tp.span == h->win_span && tp.maxlen <= seg_cap(h) &&
+            tp.K - tp.pb <= esplocal::MAX_REM_BITS) {
+            // ... then its flush starts at the bucket kernel, reading the packed keys where they lie
+            Sorted st2;
+            st2.sk = (const u64 *)h->keys.p + E0;
+            st2.sv = (const double *)h->vals.p + E0;
+            st2.in_primary = true;
+            st2.S = 1 << tp.pb;
+            st2.total = T;
+            st2.seg_start = (const i64 *)h->tseg.p;
+            st2.rem_bits = tp.K - tp.pb;
+            st2.local_ok = true;
+            st2.maxlen = tp.maxlen;
+            st2.expect_hits = 0;
+            const int32_t rc = flush_local(h, st2, mode, &Zn);
+            if (rc != ESP_OK) {
+                (void)settle_offset(h);
+                return rc;
+            }
+            served = true;
+            tail_direct = true;
+        }
         // (the tail gets a plan of its own: fewer, fuller segments -- with the batch's 2^16 buckets, small variant and 4-byte
         // keys included, its bucket kernel took 1.4 instead of 0.9 ms at config 3: time follows the number of segments)
     }
@@ -595,7 +618,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         if (!served) CK(pending_materialize(h));  // (a merged segment is too long, or the tail is no pre-sorted stream)
     }
     if (served) {
-        h->last_partition = 5;
+        h->last_partition = tail_direct ? 6 : 5;
     } else if (h->pre.valid) {
         const esp_handle::PrePart &pp = h->pre;
         Sorted st;

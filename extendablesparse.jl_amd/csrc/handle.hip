@@ -28,7 +28,7 @@ void release(DevBuf &b) {
 void release_all(esp_handle *h) {
     for (DevBuf *b : {&h->keys, &h->vals, &h->keys2, &h->vals2, &h->hist, &h->segs, &h->colend, &h->newkey,
                       &h->newval, &h->heads, &h->misc, &h->colptr, &h->rowval, &h->nzval, &h->rowval2,
-                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->runbuf, &h->chunkbuf, &h->parttab, &h->piecetab, &h->csr_rowptr, &h->csr_perm, &h->csr_col, &h->csr_tmp, &h->csr_val, &h->mul_x, &h->mul_r, &h->stage.d_rows, &h->stage.d_cols, &h->stage.d_vals, &h->stage.d_kinds, &h->bulk.d_rows, &h->bulk.d_cols, &h->bulk.d_vals, &h->bulk.d_kinds})
+                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->tseg, &h->ttile, &h->runbuf, &h->chunkbuf, &h->parttab, &h->piecetab, &h->csr_rowptr, &h->csr_perm, &h->csr_col, &h->csr_tmp, &h->csr_val, &h->mul_x, &h->mul_r, &h->stage.d_rows, &h->stage.d_cols, &h->stage.d_vals, &h->stage.d_kinds, &h->bulk.d_rows, &h->bulk.d_cols, &h->bulk.d_vals, &h->bulk.d_kinds})
         release(*b);
     for (esp_handle::StageArea *sa : {&h->stage, &h->bulk}) {
         if (sa->rows) (void)hipHostFree(sa->rows);
@@ -338,6 +338,8 @@ int32_t pack_device(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const d
     if (!d_kinds) {  // an empty buffer and one kind: the append is the partition (no packed stream is written)
         bool took = false;
         CK(append_partitioned(h, d_rows, d_cols, d_vals, kind_all, op, count, &took));
+        if (took) return ESP_OK;
+        CK(append_tail_partitioned(h, d_rows, d_cols, d_vals, kind_all, op, count, &took));  // (behind a batch over a stored pattern)
         if (took) return ESP_OK;
     }
     CK(reserve_append(h, count));

@@ -52,7 +52,7 @@ struct esp_handle {
     DevBuf keys, vals;
     i64 cap = 0, count = 0;
     // ping-pong / scratch
-    DevBuf keys2, vals2, hist, segs, colend, newkey, newval, heads, misc, seg[2], tilef[2], segcnt, segout;
+    DevBuf keys2, vals2, hist, segs, colend, newkey, newval, heads, misc, seg[2], tilef[2], segcnt, segout, tseg, ttile;
     int force_path = 0, last_path = 0;
     DevBuf runbuf, chunkbuf;
     i64 chunk_cap = 0, hint = 0;
@@ -81,6 +81,16 @@ struct esp_handle {
         bool own32 = false;      // ... and the shard's OWN range holds 4-byte keys of kind `kind` (the sent ranges: packed)
     } pre;
     bool pre_keep = false;       // reserve_append: the append that follows goes behind the bucket-ordered batch
+    // The entries appended behind a batch over a STORED pattern were partitioned as they came (append_tail_partitioned):
+    // pre.tail packed keys in bucket order of a plan of their own -- still a pending stream like any other (a stable
+    // partition keeps every column's order), so whoever does not know about it loses nothing; esp_flush's split
+    // starts their flush at the bucket kernel.  Segment starts in tseg.
+    struct TailPart {
+        bool valid = false;
+        int K = 0, pb = 0;
+        i64 T = 0, maxlen = 0;
+        u64 base = 0, span = 0;
+    } tailpart;
     // sort_msd over ITEM records (femitems.hpp): a segment may hold plan_cap records (the bucket kernel's capacity in
     // updates / updates per item), and a shuffled stream need not be tried as a pre-sorted one
     i64 plan_cap = 0;
@@ -187,6 +197,7 @@ static inline void pending_changed(esp_handle *h) {
     else
         h->pre.valid = false;
     h->pre_keep = false;
+    h->tailpart.valid = false;  // (append_tail_partitioned sets it after this call)
 }
 
 // set-up of a producer-side partition (prepart_* below, next to run_partition)
@@ -343,6 +354,8 @@ int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u64 *kou
                              i64 *seg_out, u64 *tile_first_out, bool *tiles_ready, bool *ok, i64 *maxlen_out,
                              const MultiWin *mw = nullptr, int mw_shift = 0, bool allow_k32 = false, int *key_bytes_out = nullptr,
                              i64 E_in = -1, const RawSource *raw = nullptr);
+int32_t append_tail_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const double *d_vals, int kind, int op, i64 count,
+                                 bool *took);
 int32_t append_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const double *d_vals, int kind, int op, i64 count,
                                   bool *took);
 int32_t sort_msd(esp_handle *h, Sorted *out);

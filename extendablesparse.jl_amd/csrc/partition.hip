@@ -479,6 +479,65 @@ int32_t append_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_cols, 
     return ESP_OK;
 }
 
+// The same for an append BEHIND a bucket-ordered batch when a pattern is stored (a re-assembly whose mesh gained
+// couplings: esp_flush flushes the batch by itself and then what came behind it): the caller's triplets go through the
+// run-based single pass with a plan of their own and land behind the batch as PACKED keys in bucket order -- to
+// everybody else they are the packed tail they would have been (a stable partition keeps every column's order);
+// esp_flush's split finds the segment starts in tseg and starts the tail's flush at the bucket kernel.  Instead of
+// pack (24 B read, 16 B written) + histogram + scatter (16 B + 16 B): 8 B + 24 B read, 16 B written per entry.
+int32_t append_tail_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const double *d_vals, int kind, int op, i64 count,
+                                bool *took) {
+    *took = false;
+    const esp_handle::PrePart &pp0 = h->pre;
+    if (!pp0.valid || pp0.tail != 0 || pp0.mw_P != 0 || h->count != pp0.E || h->nnz == 0 || count <= esplocal::CAP || h->shard_user ||
+        h->runs_skip > 0 || windowed(h))
+        return ESP_OK;
+    if (h->force_path == ESP_PATH_GENERAL || h->force_path == ESP_PATH_NO_RUN_PARTITION || h->force_path == ESP_PATH_RUN_LIST_BY_RADIX || h->force_path == ESP_PATH_PRODUCER_STREAM_ORDER || h->force_path == ESP_PATH_NO_BATCH_TAIL || h->force_path == ESP_PATH_NO_APPEND_PARTITION || h->force_path == ESP_PATH_BATCH_TAIL_ONE_FLUSH || h->force_path == ESP_PATH_TAIL_TO_FRONT)
+        return ESP_OK;
+    const int K = window_bits(h);
+    double Ee = 0.0;
+    const int pb = plan_prefix_bits(h, count, K, &Ee);
+    const int shift = K - pb;
+    if (pb <= 8 || pb > 20 || shift < h->L.rb || shift > esplocal::MAX_REM_BITS) return ESP_OK;
+    CK(reserve_append(h, count));
+    if (!h->pre_keep) return ESP_OK;  // (the batch went back to packed keys: an ordinary append)
+    const i64 E0 = h->count;
+    const i64 NB = (i64)1 << pb;
+    CK(ensure(h, h->tseg, sizeof(i64) * (size_t)(NB + 1)));
+    CK(ensure(h, h->ttile, sizeof(u64) * (size_t)(NB + 1 + espscan::workspace_elems(NB + 1))));
+    CK(ensure(h, h->misc, 256));
+    unsigned long long *d_err = (unsigned long long *)h->misc.p;
+    h->pin_scalar[0] = ~0ull;
+    HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 8, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemsetAsync((unsigned long long *)h->misc.p + 24, 0, 64, h->stream));  // maxlen .. the four flag words (run_partition)
+    const RawSource raw{d_rows, d_cols, kind, (op == ESP_OP_SUB && kind != ESP_SET) ? 1 : 0, d_err};
+    bool tr = false, ok = false;
+    i64 ml = count;
+    int kb = 8;
+    CK(run_partition(h, nullptr, d_vals, (u64 *)h->keys.p + E0, (double *)h->vals.p + E0, K, pb, (i64 *)h->tseg.p, (u64 *)h->ttile.p, &tr, &ok, &ml,
+                     nullptr, 0, /*allow_k32=*/false, &kb, count, &raw));
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (h->pin_scalar[0] != ~0ull)
+        FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
+             (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
+    if (!ok || kb != 8) {  // no pre-sorted stream: nothing was appended, the caller packs in stream order
+        h->runs_penalty = std::min(16, 2 * h->runs_penalty + 1);
+        h->runs_skip = h->runs_penalty + 1;
+        h->pre_keep = false;
+        return ESP_OK;
+    }
+    note_kind(h, kind, count);
+    h->count += count;
+    pending_changed(h);
+    esp_handle::TailPart &tp = h->tailpart;
+    tp.K = K, tp.pb = pb, tp.T = count, tp.maxlen = ml;
+    tp.base = h->win_base, tp.span = h->win_span;
+    tp.valid = h->pre.valid && h->pre.tail == count;
+    *took = true;
+    return ESP_OK;
+}
+
 int32_t sort_msd(esp_handle *h, Sorted *out) {
     const i64 E = h->count;
     // sort bits of the key window: (key>>2) - win_base lies in [0, win_span)
