@@ -27,6 +27,7 @@ int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn, const u64 *new_key, const doub
         return ESP_OK;
     }
     const i64 Zt = Z0 + Zn;
+    bool colptr_done = false;
     {
         Span sp(h, ESP_ST_COLPTR);
         sp.add(espscan::exclusive<u64, true>(h->stream, colend + c0, colend + c0, ccnt, colend + N1));
@@ -83,11 +84,20 @@ int32_t finish_csc(esp_handle *h, i64 Z0, i64 Zn, const u64 *new_key, const doub
         a.ncols = ncols;
         a.out_row = (i64 *)h->rowval2.p;
         a.out_val = (double *)h->nzval2.p;
+        a.out_colptr = nullptr;
+        if (!windowed(h) && h->force_path != ESP_PATH_MERGE_PATH_JOIN) {
+            // (its tiles hold both summands of the new colptr: written into a second array, swapped below)
+            CK(ensure(h, h->colptr2, sizeof(i64) * (size_t)(h->n + 1)));
+            a.out_colptr = (i64 *)h->colptr2.p;
+            colptr_done = true;
+        }
         hipLaunchKernelGGL((espmerge::colmerge_k<espmerge::CT, espmerge::CT_SCAP>), dim3(grid_for(ncols, espmerge::CT)), dim3(espmerge::THREADS), 0,
                            h->stream, a);
         sp.add(1);
     }
-    {
+    if (colptr_done) {
+        std::swap(h->colptr, h->colptr2);
+    } else {
         Span sp(h, ESP_ST_COLPTR);
         hipLaunchKernelGGL(espfold::colptr_finish_k, dim3(grid_for(ccnt, 256)), dim3(256), 0, h->stream, (const u64 *)colend + c0,
                            (const i64 *)h->colptr.p + c0, ccnt, (i64 *)h->colptr.p + c0);

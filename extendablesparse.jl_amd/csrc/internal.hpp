@@ -121,6 +121,7 @@ struct esp_handle {
     bool ones_pending = false;
     // device CSC (Julia layout) + spare set for rebuilds
     DevBuf colptr, rowval, nzval, rowval2, nzval2;
+    DevBuf colptr2;  // the join writes the new colptr here (its tiles hold both summands), then the two are swapped
     i64 nnz = 0;
     bool csc_valid = false;  // colptr initialised
     // host staging (pinned) + device staging

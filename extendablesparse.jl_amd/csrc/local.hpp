@@ -359,18 +359,19 @@ __device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval,
 // LDS in sorted order, so that IT can be indexed dynamically -- in an inner loop.  Stores of hits are issued and not
 // waited for.  Same results as fold_run (the same fold steps in the same order).
 constexpr int CSC_SHORT = 8;
-// (Taken when the host expects hits -- Args::expect_hits: a tail of new positions would fetch 8 bytes per stored entry
-// for nothing; it walks.)
-template <int R, bool UPD>
+// WITHV: the values come with the rows (the host expects hits -- Args::expect_hits); else only the rows, and a hit fetches
+// its value by itself: a tail of new positions reads no value at all (the regular kernel has the registers for both
+// forms; in the small variant such a tail walks).
+template <int R, bool UPD, bool WITHV>
 __device__ __forceinline__ void fold_run_short_csc(const Args &a, u64 *skey, double *sval, const u64 (&x)[R], int rs, int len, u64 hi,
                                                    u64 rowmask, i64 c0, int n) {
     u32 r0[CSC_SHORT];
-    double sv[CSC_SHORT];
+    double sv[WITHV ? CSC_SHORT : 1];
 #pragma unroll
     for (int i = 0; i < CSC_SHORT; i++) {
         const i64 at = c0 + (i < n ? i : n - 1);
         r0[i] = (u32)(a.csc.rowval[at] - 1);
-        sv[i] = a.csc.nzval[at];
+        if constexpr (WITHV) sv[i] = a.csc.nzval[at];
     }
 #pragma unroll
     for (int j = 0; j < R; j++)
@@ -398,7 +399,8 @@ __device__ __forceinline__ void fold_run_short_csc(const Args &a, u64 *skey, dou
     for (int i = 0; i <= CSC_SHORT; i++) {
         // stored entry i (behind the column: nothing bounds the rows any more)
         const u64 ri = (i < CSC_SHORT && i < n) ? (u64)r0[i < CSC_SHORT ? i : 0] : ~0ull;
-        const double si = sv[i < CSC_SHORT ? i : 0];
+        double si = 0.0;
+        if constexpr (WITHV) si = sv[i < CSC_SHORT ? i : 0];
         while (p < len) {
             const u64 kj = skey[rs + p];
             const u64 sub = kj >> SUB_SHIFT;
@@ -411,7 +413,10 @@ __device__ __forceinline__ void fold_run_short_csc(const Args &a, u64 *skey, dou
                 const bool hit = row0 == ri;
                 pos = hit ? c0 + i : -1;
                 present = hit && routed;
-                acc = present ? si : 0.0;
+                if constexpr (WITHV)
+                    acc = present ? si : 0.0;
+                else
+                    acc = present ? a.csc.nzval[c0 + i] : 0.0;
             }
             const double vj = sval[(kj >> ESP_TAG_BITS) & (CAP - 1)];
             if constexpr (UPD)
@@ -581,7 +586,7 @@ __device__ __forceinline__ bool lb_may_skip(const Args &a, int s) { return !lb_l
 
 // Register tier of the bucket kernel: one lane per column, the whole run (<= R entries) in registers.
 // Returns true when the look-back already ran (early publication of the segment total).
-template <int R, bool FRESH, bool UPD>
+template <int R, bool FRESH, bool UPD, bool SM>
 __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval, const u32 *ccnt, int ncl, int s, u64 hi,
                                          u64 rowmask, u32 *s_early, LbState &lb) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -642,8 +647,11 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
         }
         sort_run_keys<R>(skey, rs, len, x);
 #ifndef ESP_NO_SHORT_CSC
-        if (!FRESH && a.expect_hits && rowmask <= 0xFFFFFFFFull && ccur < cend && cend - ccur <= (i64)CSC_SHORT) {
-            fold_run_short_csc<R, UPD>(a, skey, sval, x, rs, len, hi, rowmask, ccur, (int)(cend - ccur));
+        if (!FRESH && (!SM || a.expect_hits) && rowmask <= 0xFFFFFFFFull && ccur < cend && cend - ccur <= (i64)CSC_SHORT) {
+            if (SM || a.expect_hits)
+                fold_run_short_csc<R, UPD, true>(a, skey, sval, x, rs, len, hi, rowmask, ccur, (int)(cend - ccur));
+            else if constexpr (!SM)
+                fold_run_short_csc<R, UPD, false>(a, skey, sval, x, rs, len, hi, rowmask, ccur, (int)(cend - ccur));
             continue;
         }
 #endif
@@ -1360,11 +1368,11 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
                 // one lane per column: the whole run in registers, sorting network + ordered fold; the
                 // network is sized to the longest run of the segment (12 covers a 7-point stencil)
                 if (maxrun <= 12)
-                    lb_done = reg_tier<12, FRESH, UPD>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
+                    lb_done = reg_tier<12, FRESH, UPD, SMALL>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
                 else if (!BIG || maxrun <= 16)
-                    lb_done = reg_tier<16, FRESH, UPD>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
+                    lb_done = reg_tier<16, FRESH, UPD, SMALL>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
                 else if constexpr (BIG)
-                    lb_done = reg_tier<REG_RUN, FRESH, UPD>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
+                    lb_done = reg_tier<REG_RUN, FRESH, UPD, SMALL>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
                 done = true;
             }
         } else if constexpr (GRP) {

@@ -127,6 +127,7 @@ struct ColArgs {
     i64 c_begin, ncols;     // columns [c_begin, c_begin + ncols) hold every new entry
     i64 *out_row;
     double *out_val;
+    i64 *out_colptr;        // the new colptr (old + new entries in front), or null: the caller finishes colptr itself
 };
 
 // Direct form of a tile (kept for tiles the staged form below has no room for): the tile's new keys are staged in LDS
@@ -257,6 +258,10 @@ static __global__ __launch_bounds__(THREADS) void colmerge_k(ColArgs a) {
         s_ns[q] = a.newstart[c0 + q];
     }
     __syncthreads();
+    if (a.out_colptr) {  // (the last tile writes the entry behind the last column too)
+        const int last = c0 + nc == a.c_begin + a.ncols ? nc : nc - 1;
+        for (int q = t; q <= last; q += THREADS) a.out_colptr[c0 + q] = s_cp[q] + 1 + (i64)s_ns[q];
+    }
     const i64 op0 = s_cp[0], op1 = s_cp[nc];
     const i64 np0 = (i64)s_ns[0], np1 = (i64)s_ns[nc];
     const bool staged = np1 - np0 <= (i64)NEWCAP;
