@@ -87,13 +87,12 @@ static __global__ __launch_bounds__(THREADS) void fem_expand_k(Args a) {
         const u64 lowmask = a.rem_bits >= 64 ? ~0ull : ((1ull << a.rem_bits) - 1ull);
         // the item's updates in call order: row il's term at il, +1 from the diagonal's row on (the mass term of the
         // diagonal comes right before it)
-        espgen::fem_updates_of_cell(a.fem, cell, [&](int il, int jl, i64 row, i64 col, double v) {
-            if (col != icol) return;  // (the updates of the item's column; the mass term of row il has the column nodes[il])
+        espgen::fem_column_of_cell(a.fem, cell, icol, [&](int il, int jl, i64 row, double v) {
             const int at = t * W + (jl < 0 ? il : il + (il >= jl ? 1 : 0));
             if constexpr (K32)
-                lk[at] = (u32)(((((u64)(col - 1) << a.fem.L.rb) | (u64)(row - 1)) - a.base) & lowmask);
+                lk[at] = (u32)(((((u64)(icol - 1) << a.fem.L.rb) | (u64)(row - 1)) - a.base) & lowmask);
             else
-                lk[at] = esp_pack(a.fem.L, row, col, ESP_RAWUPDATE);
+                lk[at] = esp_pack(a.fem.L, row, icol, ESP_RAWUPDATE);
             lv[at] = v;
         });
     }

@@ -411,11 +411,10 @@ template <typename F>
 __device__ __forceinline__ void fem_cell_updates(const FemArgs &a, i64 p, F emit) {
     fem_updates_of_cell(a, (i64)fem_cell_at(a, p), emit);
 }
-template <typename F>
-__device__ __forceinline__ void fem_updates_of_cell(const FemArgs &a, i64 cell, F emit) {
+// vertices' node numbers, gradients of the P1 basis functions and the volume of one cell
+__device__ __forceinline__ void fem_cell_geometry(const FemArgs &a, i64 cell, i64 (&nodes)[4], double (&G)[4][3], double *vol_out) {
     const int dim = a.dim;
     i64 vx[4][3];
-    i64 nodes[4];
     fem_vertices(a, cell, vx, nodes);
     double X[4][3];
 #pragma unroll
@@ -425,7 +424,6 @@ __device__ __forceinline__ void fem_updates_of_cell(const FemArgs &a, i64 cell, 
             for (int d = 0; d < 3; d++) X[k][d] = (double)vx[k][d] * a.h;
         }
     }
-    double G[4][3];
 #pragma unroll
     for (int k = 0; k < 4; k++)
 #pragma unroll
@@ -463,7 +461,15 @@ __device__ __forceinline__ void fem_updates_of_cell(const FemArgs &a, i64 cell, 
 #pragma unroll
         for (int d = 0; d < 3; d++) G[0][d] = -((G[1][d] + G[2][d]) + G[3][d]);
     }
-    const double vol = fabs(det) / (dim == 2 ? 2.0 : 6.0);
+    *vol_out = fabs(det) / (dim == 2 ? 2.0 : 6.0);
+}
+template <typename F>
+__device__ __forceinline__ void fem_updates_of_cell(const FemArgs &a, i64 cell, F emit) {
+    const int dim = a.dim;
+    i64 nodes[4];
+    double G[4][3];
+    double vol;
+    fem_cell_geometry(a, cell, nodes, G, &vol);
     double S[4][4];
 #pragma unroll
     for (int il = 0; il < 4; il++)
@@ -485,6 +491,36 @@ __device__ __forceinline__ void fem_updates_of_cell(const FemArgs &a, i64 cell, 
 #pragma unroll
             for (int jl = 0; jl < 4; jl++)
                 if (jl <= dim) emit(il, jl, nodes[il], nodes[jl], vol * S[il][jl]);
+        }
+    }
+}
+// The updates of ONE vertex column of the cell (the item partition's expansion: femitems.hpp), the same values bit for bit:
+// S[il][jl] = sum_k G[max(il,jl)][k] * G[min(il,jl)][k] in the order k = 0, 1, 2 -- a product does not depend on the order of
+// its factors -- so only the dim + 1 scalar products of the column are formed.  emit(il, jl, row, v): jl = -1 for the mass
+// term (row il = jl's own), else the column's local index; in call order of the column's entries.
+template <typename F>
+__device__ __forceinline__ void fem_column_of_cell(const FemArgs &a, i64 cell, i64 icol, F emit) {
+    const int dim = a.dim;
+    i64 nodes[4];
+    double G[4][3];
+    double vol;
+    fem_cell_geometry(a, cell, nodes, G, &vol);
+    int jv = 0;
+#pragma unroll
+    for (int k = 1; k < 4; k++)
+        if (k <= dim && nodes[k] == icol) jv = k;
+    double Gj[3];
+#pragma unroll
+    for (int d = 0; d < 3; d++) Gj[d] = jv == 0 ? G[0][d] : jv == 1 ? G[1][d] : jv == 2 ? G[2][d] : G[3][d];
+#pragma unroll
+    for (int il = 0; il < 4; il++) {
+        if (il <= dim) {
+            if (il == jv) emit(il, -1, nodes[il], 0.1 * vol / (double)(dim + 1));
+            double sacc = 0.0;
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (k < dim) sacc += Gj[k] * G[il][k];
+            emit(il, jv, nodes[il], vol * sacc);
         }
     }
 }
