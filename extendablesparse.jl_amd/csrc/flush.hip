@@ -2,7 +2,7 @@
 #include "internal.hpp"
 
 bool esplocal::launch(const Variant &v, unsigned grid, hipStream_t stream, const Args &a) {
-    if (v.grp) return launch_group(v, grid, stream, a);
+    if (v.grp) return v.shortg ? launch_group_short(v, grid, stream, a) : launch_group(v, grid, stream, a);
     if (v.pieces) return v.small_variant ? launch_pieces_small(v, grid, stream, a) : v.fresh ? launch_pieces_fresh(v, grid, stream, a) : launch_pieces_stored(v, grid, stream, a);
     return v.small_variant ? launch_small(v, grid, stream, a) : launch_regular(v, grid, stream, a);
 }
@@ -266,12 +266,13 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
             // the longest column run: what the handle's last flush met, or -- no history -- the pending entries per column (a
             // P1 mesh in 2-D: 24, in 3-D: 120; a wrong guess costs that one flush the radix tier)
             const double longest = h->seen_maxrun > 0 ? (double)h->seen_maxrun : (double)h->count / (double)std::max<i64>(col_end - col_begin, 1);
-            // (the variant with the 24-input register tier for runs of 17 .. 24; 26: test hook, never)
-            const bool big = longest > 16.0 && longest <= (double)esplocal::REG_RUN && h->force_path != ESP_PATH_NO_BIG_VARIANT;
-            // (the group-tier kernel for longer runs)
-            const bool grp = st.npieces == 0 && !small_variant && keys <= 2 && longest > (double)esplocal::REG_RUN && h->force_path != ESP_PATH_NO_GROUP_TIER &&
+            // (the group-tier kernel for runs of more than 16 entries -- up to 32: its four-lane form; 24: test hook, never)
+            const bool grp = st.npieces == 0 && !small_variant && keys <= 2 && longest > 16.0 && h->force_path != ESP_PATH_NO_GROUP_TIER &&
                              h->force_path != ESP_PATH_RADIX_TAIL_ONLY;
+            // (else the variant with the 24-input register tier for runs of 17 .. 24 -- shard pieces; 26: test hook, never)
+            const bool big = longest > 16.0 && longest <= (double)esplocal::REG_RUN && h->force_path != ESP_PATH_NO_BIG_VARIANT;
             esplocal::Variant var{Z0 == 0, st.npieces > 0, big && !small_variant && !grp, small_variant, keys};
+            var.shortg = grp && longest <= 32.0;
             var.grp = grp;
             if (!esplocal::launch(var, grid, h->stream, a)) FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (no bucket kernel for this flush)");
         }

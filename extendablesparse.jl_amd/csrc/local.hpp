@@ -1078,9 +1078,14 @@ __device__ __forceinline__ bool group_columns(const Args &a, u64 *skey, double *
 // the common phases paid for the widest of them (40 .. 120 bytes of scratch per lane in the fresh-matrix kernels, 200 in the
 // stored-CSC ones).  The host picks it for a matrix whose columns hold more than 24 entries (the longest run its last
 // flush met; without history: pending entries per column).  Runs of at most 16 go through the tier's 2-lane form.
-template <bool FRESH, bool PIECES, bool BIG, int KEYS, bool SMALL = false, bool GRP = false>
+// SHORTG (with GRP): the group-tier kernel for runs of at most 32 entries (2-D P1 FEM: 24 per column) -- four lanes x 8
+// keys per column, so that the 128 columns of such a segment keep all eight waves busy where the 24-input register tier
+// works in two of them; again an instantiation of its own (with the shapes for long runs in the same kernel the 3-D path
+// paid 1.3 ms for their registers).  A segment with a longer run goes through the radix tier.
+template <bool FRESH, bool PIECES, bool BIG, int KEYS, bool SMALL = false, bool GRP = false, bool SHORTG = false>
 __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     static_assert(!GRP || (!PIECES && !BIG && !SMALL), "the group-tier kernel exists for the plain regular form only");
+    static_assert(!SHORTG || GRP, "SHORTG is a form of the group-tier kernel");
     constexpr bool K32 = KEYS == 1 || KEYS == 2 || KEYS == 6 || KEYS == 7, UPD = KEYS == 2 || KEYS == 3 || KEYS == 5 || KEYS == 7,
                    P32 = KEYS == 4 || KEYS == 5;
     static_assert(PIECES == (KEYS >= 3) || KEYS == 0, "KEYS 3 .. 7 are piece formats, 1 / 2 are not");
@@ -1377,7 +1382,7 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
             }
         } else if constexpr (GRP) {
             // ---- group tier: runs of up to 256 entries sorted by 2 .. 16 lanes each, keys in registers (see group_sort)
-            if (!done && maxrun <= GROUP_MAX && a.rb <= 30 && a.cl_bits <= GROUP_CL_BITS && !a.no_group) {
+            if (!done && maxrun <= (SHORTG ? 32 : GROUP_MAX) && a.rb <= 30 && a.cl_bits <= GROUP_CL_BITS && !a.no_group) {
                 u32 rmin = ~0u, rmax = 0u;
 #pragma unroll
                 for (int i = 0; i < NI; i++)
@@ -1416,7 +1421,13 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     } while (0)
                     // (fresh matrix, one kind of additions, every column with its lanes at once: the dense form)
                     bool went_dense = false;
-                    if constexpr (FRESH) {
+                    if constexpr (SHORTG) {
+                        if (ncl * 4 <= THREADS)
+                            ESP_GROUP_GO(4, 8);
+                        else
+                            ESP_GROUP_GO(2, 16);
+                        went_dense = true;  // (nothing below applies)
+                    } else if constexpr (FRESH) {
                         if (gmode != 0 && maxrun > 64 && maxrun <= 128 && ncl * 16 <= THREADS && a.stop_after == 0) {
                             const DenseCtx dcx{&s_early, reinterpret_cast<unsigned short *>(cntraw + 1024), &lbs, s};
                             if (gmode == 1)
@@ -1429,6 +1440,7 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
                         }
                     }
                     if (went_dense) {
+                    } else if constexpr (SHORTG) {
                     } else if (maxrun <= 32)
                         ESP_GROUP_GO(2, 16);
                     else if (maxrun <= 64)

@@ -81,7 +81,8 @@ struct Variant {
     bool big;     // carries the 24-input register tier
     bool small_variant;  // segments of at most 3072 entries over at most 256 columns: three workgroups per CU
     int keys;     // key format 0 .. 7
-    bool grp = false;  // the group-tier kernel (column runs of more than 24 entries): regular form only
+    bool grp = false;  // the group-tier kernel (column runs of more than 16 entries): regular form only
+    bool shortg = false;  // ... its form for runs of at most 32 entries (four lanes x 8 keys per column)
 };
 // enqueues the kernel; false when the combination has no instantiation
 bool launch(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);
@@ -91,5 +92,6 @@ bool launch_pieces_fresh(const Variant &v, unsigned grid, hipStream_t stream, co
 bool launch_pieces_stored(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);  // local_d.hip
 bool launch_pieces_small(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);   // local_e.hip
 bool launch_group(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);          // local_f.hip
+bool launch_group_short(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);    // local_g.hip
 
 }  // namespace esplocal

@@ -15,7 +15,8 @@ from esparse_loader import load  # noqa: E402
 esp = load()
 fem = int(os.environ.get("ESP_STAMP_FEM", "0"))   # e.g. 120: P1 FEM 3-D on 120^3 nodes instead of the stencil
 n = 256
-N = fem ** 3 if fem else n ** 3
+fdim = int(os.environ.get("ESP_STAMP_FEM_DIM", "3"))
+N = fem ** fdim if fem else n ** 3
 A = esp.ExtendableSparseMatrix(N, N, capacity_hint=0 if fem else 12 * n * n * (n - 1) + 6 * n * n)
 reasm = int(os.environ.get("ESP_STAMP_REASM", "0"))   # 1: stamps of the SECOND flush (re-assembly over the existing CSC)
 cfg3 = int(os.environ.get("ESP_STAMP_CFG3", "0"))     # 1: config 3 -- stamps of the LAST bucket kernel of its flush (the tail's)
@@ -32,7 +33,7 @@ for it in range(3):
         A.generate_fdrand(n, n, n, rand_mode=1)
         A.flush()
     if fem:
-        A.generate_fem(3, fem, seed=4, order_mode=1)
+        A.generate_fem(fdim, fem, seed=4, order_mode=1)
     else:
         A.generate_fdrand(n, n, n, rand_mode=1)
     if cfg3:
