@@ -1422,7 +1422,21 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
                     // (fresh matrix, one kind of additions, every column with its lanes at once: the dense form)
                     bool went_dense = false;
                     if constexpr (SHORTG) {
-                        if (ncl * 4 <= THREADS)
+                        bool dense4 = false;
+                        if constexpr (FRESH) {
+                            if (gmode != 0 && ncl * 4 <= THREADS && a.stop_after == 0) {
+                                const DenseCtx dcx{&s_early, reinterpret_cast<unsigned short *>(cntraw + 1024), &lbs, s};
+                                if (gmode == 1)
+                                    group_columns<4, 8, CAPK, true, 1, true>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp, &dcx);
+                                else
+                                    group_columns<4, 8, CAPK, true, 2, true>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp, &dcx);
+                                dense4 = true;
+                                dense_done = true;
+                                lb_done = true;
+                            }
+                        }
+                        if (dense4) {
+                        } else if (ncl * 4 <= THREADS)
                             ESP_GROUP_GO(4, 8);
                         else
                             ESP_GROUP_GO(2, 16);
