@@ -359,7 +359,7 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
             A.timing(clear=True)
             t0 = time.perf_counter()
             # (the stencil's stream, then the new couplings behind it: the producer's bucket-ordered batch is flushed as
-            # it is, the new couplings as a flush of their own -- esp_debug_last_partition 6)
+            # it is, the new couplings as a flush of their own -- esp_debug_last_partition 8: the couplings partitioned as they are appended)
             A.generate_fdrand(n, n, n, seed=0x5EED0012, rand_mode=1)
             d.ck(d.lib.esp_append_device(d.h, C.c_void_p(rows.data_ptr()), C.c_void_p(cols.data_ptr()),
                                          C.c_void_p(vals.data_ptr()), None, esp.ESP_UPDATE, 0, Zn))

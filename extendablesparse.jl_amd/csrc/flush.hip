@@ -629,7 +629,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         if (!served) CK(pending_materialize(h));  // (a merged segment is too long, or the tail is no pre-sorted stream)
     }
     if (served) {
-        h->last_partition = tail_direct ? 6 : 5;
+        h->last_partition = tail_direct ? 8 : 5;
     } else if (h->pre.valid) {
         const esp_handle::PrePart &pp = h->pre;
         Sorted st;
@@ -715,7 +715,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
     }
     if (!use_local && !h->part_assembled) CK(settle_offset(h));
     if (!use_local && !h->part_assembled) CK(flush_global(h, mode, &Zn));
-    if (split) h->last_partition = 6;
+    if (split) h->last_partition = tail_direct ? 8 : 6;
     h->last_path = (use_local || h->part_assembled) ? 1 : 2;
     if ((Zn > 0 || Zsplit > 0) && pattern_changed) *pattern_changed = 1;
     h->values_version++;  // (hits were applied in place)

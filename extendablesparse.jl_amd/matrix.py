@@ -177,6 +177,16 @@ class _Handle:
             kp = _vp(kinds)
         self.ck(self.lib.esp_append_host(self.h, _vp(I), _vp(J), _vp(V), kp, kind, op, len(I)))
 
+    def append_device(self, kind, I, J, V, op=ESP_OP_ADD, kinds=None):
+        """esp_append_device: I, J (int64), V (float64) [, kinds (uint8)] are arrays resident in this GPU's memory --
+        anything with .data_ptr() and .numel() (torch tensors); nothing is staged through the host."""
+        self.commit()
+        n = int(I.numel())
+        if int(J.numel()) != n or int(V.numel()) != n or (kinds is not None and int(kinds.numel()) != n):
+            raise ValueError("append_device: arrays of different lengths")
+        kp = C.c_void_p(kinds.data_ptr()) if kinds is not None else None
+        self.ck(self.lib.esp_append_device(self.h, C.c_void_p(I.data_ptr()), C.c_void_p(J.data_ptr()), C.c_void_p(V.data_ptr()), kp, kind, op, n))
+
     def pending(self):
         c = C.c_int64()
         self.ck(self.lib.esp_pending(self.h, C.byref(c)))
@@ -358,6 +368,11 @@ class ExtendableSparseMatrix:
     def append(self, kind, I, J, V, op="+", kinds=None):
         self._touch()
         self._d.append(kind, I, J, V, _op(op), kinds)
+
+    def append_device(self, kind, I, J, V, op="+", kinds=None):
+        """The bulk form for triplets that already lie in this GPU's memory (torch tensors: int64, int64, float64)."""
+        self._touch()
+        self._d.append_device(kind, I, J, V, _op(op), kinds)
 
     def __getitem__(self, ij):
         """getindex (extendable.jl:226-238).  Pending entries live on the device, so the lookup is

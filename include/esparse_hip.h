@@ -385,7 +385,9 @@ int32_t esp_debug_last_local_small(const esp_handle *h, int32_t *small);
  * 5 = such a batch with entries appended behind it: the run-based pass over those entries only, the bucket kernel
  *     reads every segment as two pieces (batch, tail),
  * 6 = such a batch + tail over a stored pattern: the batch flushed by itself (as 4), then the tail as a flush of its own,
- * 7 = none: the segments came assembled from esp_shard_assemble */
+ * 7 = none: the segments came assembled from esp_shard_assemble,
+ * 8 = as 6, and the tail had been partitioned as it was appended (one kind, a pre-sorted stream): both flushes start at the
+ *     bucket kernel */
 int32_t esp_debug_last_partition(const esp_handle *h, int32_t *kind);
 
 #ifdef __cplusplus
