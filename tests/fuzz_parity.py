@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised parity fuzz (GPU): random shapes (incl. very tall matrices: many row bits), kinds, duplicate
 patterns, stream orders (sorted / clustered / shuffled), multi-flush sequences, both flush modes --
-every result compared bit for bit with the CPU oracle.  usage: tools/fuzz_parity.py [seconds] [seed]
+every result compared bit for bit with the CPU oracle.  usage: tests/fuzz_parity.py [seconds] [seed]   (test infrastructure: it runs the CPU oracle)
 ESP_FUZZ_FOCUS=k32: shapes and batches that reach the 4-byte keys / UPDATE-only fold of the bucket kernel."""
 import os
 import sys

@@ -1930,7 +1930,7 @@ def test_producer_partition_odd_grids(esp, orc, dims):
 
 @pytest.mark.parametrize("focus,seed,seconds", [("", 11, 20), ("k32", 12, 12)])
 def test_bounded_fuzz(focus, seed, seconds):
-    """tools/fuzz_parity.py (random shapes, kinds, orders, flush sequences, forced paths; every result against the
+    """tests/fuzz_parity.py (random shapes, kinds, orders, flush sequences, forced paths; every result against the
     oracle bit for bit) with fixed seeds and a bounded budget."""
     import os
     import subprocess
@@ -1938,7 +1938,7 @@ def test_bounded_fuzz(focus, seed, seconds):
     env = dict(os.environ)
     if focus:
         env["ESP_FUZZ_FOCUS"] = focus
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_parity.py"), str(seconds), str(seed)], env=env,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz_parity.py"), str(seconds), str(seed)], env=env,
                        capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "fuzz ok" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
 
