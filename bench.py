@@ -378,7 +378,7 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
         algo = 2 * 16.0 * Ea + (16.0 * Z0 + 8.0 * (N + 1)) + (16.0 * Z1 + 8.0 * (N + 1))
         out["cfg3_reassembly"] = {
             "workload": "existing %d^3 stencil CSC (%d nnz) + the full update stream again + %d new positions "
-                        "(%.1f %% of the stored nnz): append + flush! with merge-path join" % (n, Z0, Zn, 100.0 * Zn / Z0),
+                        "(%.1f %% of the stored nnz): esp_append_device behind the producer's batch + flush! (batch by itself over the stored pattern, then the new couplings; column-tiled join)" % (n, Z0, Zn, 100.0 * Zn / Z0),
             "ms": dt * 1e3, "nnz_per_s": Z1 / dt, "appended_per_s": Ea / dt, "algorithmic_bytes": algo,
             "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS, "partition": A.debug_last_partition(),
             "stage_ms": stages(tm, 1), "steps": len(dts), "digest_ok": ok3}
