@@ -163,7 +163,8 @@ int32_t esp_nnz(const esp_handle *h, int64_t *nnz);
 int32_t esp_get_csc(esp_handle *h, int64_t *colptr, int64_t *rowval, double *nzval);
 /* D2H of nzval only (pattern unchanged since the caller's last esp_get_csc) */
 int32_t esp_get_nzval(esp_handle *h, double *nzval);
-/* device pointers of the resident CSC (Int64 1-based values), for device consumers */
+/* device pointers of the resident CSC (Int64 1-based values), for device consumers; valid until the next esp_flush /
+ * esp_reset / esp_set_csc of the handle (a flush that changes the pattern rotates all three arrays) */
 int32_t esp_csc_device(esp_handle *h, const int64_t **d_colptr, const int64_t **d_rowval,
                        const double **d_nzval);
 /* reset!(ext) (extendable.jl:269-272): empty CSC, empty buffer */
