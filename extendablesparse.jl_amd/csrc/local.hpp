@@ -1011,6 +1011,9 @@ __device__ __forceinline__ bool group_columns(const Args &a, u64 *skey, double *
                 if (total) atomicAdd(dc->s_early, (u32)total);
             }
             __syncthreads();  // every run of the segment is folded, its records in registers: skey / sval are free
+#ifdef ESP_LOCAL_STAMPS
+            if (stamp && t == 0) stamp[3] = wall_clock64();
+#endif
             const int w = t >> 6;
             if (w == WAVES - 1) {  // the look-back starts here; the wave carries it on after its own dense writes
                 lb_publish(a, *dc->lb, dc->s, *dc->s_early, lane);
@@ -1032,6 +1035,9 @@ __device__ __forceinline__ bool group_columns(const Args &a, u64 *skey, double *
                 }
             }
             __syncthreads();
+#ifdef ESP_LOCAL_STAMPS
+            if (stamp && t == 0) stamp[5] = wall_clock64();
+#endif
             int d = (c < ncl ? (int)dc->ctot[c] : 0) + e;
 #pragma unroll
             for (int r = 0; r < R; r++) {

@@ -63,8 +63,11 @@ if st16[:, 8].any():
         x = (st16[:, b] - st16[:, a]) * 0.01
         print("  %-36s median %6.2f  p90 %6.2f" % (nm, np.median(x), np.percentile(x, 90)))
 if st16[:, 14].any():   # group tier: 2 = counts scanned, 12 = keys scattered + row range known, 13 = sorted (wave 0), 14 = folded (wave 0)
-    for nm, a, b in (("scatter + row range", 2, 12), ("group sort (wave 0)", 12, 13), ("gather + fold (wave 0)", 13, 14),
-                     ("records + barrier", 14, 4)):
+    dense = np.median(st16[:, 3] - st16[:, 14]) > 0 and np.median(st16[:, 4] - st16[:, 5]) >= 0   # dense form: 3 = every wave folded, 5 = counts scanned
+    for nm, a, b in ((("scatter + row range", 2, 12), ("group sort (wave 0)", 12, 13), ("gather + fold (wave 0)", 13, 14)) +
+                     ((("wait for the other waves' folds", 14, 3), ("publish + scan of the columns' counts + barrier", 3, 5),
+                       ("dense records + barrier", 5, 4), ("barrier -> look-back wait starts", 4, 6), ("look-back wait + stores", 6, 7)) if dense else
+                      (("records + barrier", 14, 4),))):
         x = (st16[:, b] - st16[:, a]) * 0.01
         print("  %-36s median %6.2f  p90 %6.2f" % (nm, np.median(x), np.percentile(x, 90)))
 elif st16[:, 12].any():   # radix tier: 2 = counts scanned, 12 = radix sort done, 13 = fold walks done, 4 = records written
