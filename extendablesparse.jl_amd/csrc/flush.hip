@@ -2,6 +2,7 @@
 #include "internal.hpp"
 
 bool esplocal::launch(const Variant &v, unsigned grid, hipStream_t stream, const Args &a) {
+    if (v.g3) return launch_group3(v, grid, stream, a);
     if (v.grp) return v.shortg ? launch_group_short(v, grid, stream, a) : launch_group(v, grid, stream, a);
     if (v.pieces) return v.small_variant ? launch_pieces_small(v, grid, stream, a) : v.fresh ? launch_pieces_fresh(v, grid, stream, a) : launch_pieces_stored(v, grid, stream, a);
     return v.small_variant ? launch_small(v, grid, stream, a) : launch_regular(v, grid, stream, a);
@@ -199,6 +200,8 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
                         h->force_path != ESP_PATH_NO_SMALL_VARIANT && !stop_env;
     }
     h->last_local_small = small_variant ? 1 : 0;
+    std::function<int32_t(bool)> launch_all;
+    bool used_g3 = false;
     {
         Span sp(h, ESP_ST_LOCAL);
         a.kind32 = (u32)((st.key_bytes == 4 || st.p32_piece >= 0 || st.all32) ? st.kind : 0);
@@ -250,6 +253,8 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
             }
         }
         const i64 max_grid = h->force_path == ESP_PATH_MANY_LAUNCHES ? 64 : esplocal::MAX_GRID;  // 4: test hook, many launches
+        launch_all = [&, max_grid](bool allow_g3) -> int32_t {
+        used_g3 = false;
         for (i64 first = 0; first < S; first += max_grid) {
             const unsigned grid = (unsigned)std::min<i64>(max_grid, S - first);
             a.first = first;
@@ -274,13 +279,45 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
             esplocal::Variant var{Z0 == 0, st.npieces > 0, big && !small_variant && !grp, small_variant, keys};
             var.shortg = grp && longest <= 32.0;
             var.grp = grp;
+            // (the group tier with three workgroups per CU -- group3.hpp: a fresh matrix, 4-byte keys of one kind, segments of at
+            // most 256 whole columns whose (local column, row) fits 32 bits, runs of at most 128 entries; a segment it does not
+            // take makes the flush run again with the kernels above; 30: test hook, never)
+            var.g3 = allow_g3 && grp && Z0 == 0 && (keys == 1 || keys == 2) && a.cl_bits >= 0 && a.cl_bits <= esplocal::G3_CL_BITS &&
+                     a.cl_bits + a.rb <= 32 && a.rb <= 30 && longest <= 128.0 && !h->g3_off && !a.no_group && !a.stop_after &&
+                     h->force_path != ESP_PATH_NO_GROUP3;
+            used_g3 = used_g3 || var.g3;
             if (!esplocal::launch(var, grid, h->stream, a)) FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (no bucket kernel for this flush)");
         }
+        return ESP_OK;
+        };
+        CK(launch_all(true));
         sp.add(1);
     }
-    HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (S - 1), 24, hipMemcpyDeviceToHost, h->stream));  // last granule | ticket, err | maxrun
-    HIPCK(h, hipMemcpyAsync(h->pin_scalar + 3, (u32 *)h->misc.p + 60, 4, hipMemcpyDeviceToHost, h->stream));
-    HIPCK(h, hipStreamSynchronize(h->stream));
+    auto read_back = [&]() -> int32_t {
+        HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (S - 1), 24, hipMemcpyDeviceToHost, h->stream));  // last granule | ticket, err | maxrun
+        HIPCK(h, hipMemcpyAsync(h->pin_scalar + 3, (u32 *)h->misc.p + 60, 4, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        return ESP_OK;
+    };
+    CK(read_back());
+    if (used_g3 && ((u32)(h->pin_scalar[1] >> 32) & 8u)) {
+        // a segment the three-workgroup group kernel does not take (a longer run, rows too far apart): nothing of a
+        // fresh-matrix flush has taken effect -- once more with the general kernels, and they serve this handle from now on
+        h->g3_off = true;
+        HIPCK(h, hipMemsetAsync(status, 0, sizeof(u64) * (size_t)(S + 2 + G), h->stream));
+        if (!direct) {
+            i64 c0, cnt;
+            col_range(h, &c0, &cnt);
+            HIPCK(h, hipMemsetAsync((u64 *)h->colend.p + c0, 0, sizeof(u64) * (size_t)cnt, h->stream));
+        }
+        {
+            Span sp(h, ESP_ST_LOCAL);
+            CK(launch_all(false));
+            sp.add(1);
+        }
+        CK(read_back());
+    }
+    h->last_group3 = used_g3 ? 1 : 0;
 
     if ((u32)h->pin_scalar[3]) {
         restore_colptr();

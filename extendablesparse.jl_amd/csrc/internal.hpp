@@ -14,6 +14,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <functional>
 #include <cmath>
 #include <thread>
 
@@ -58,6 +59,8 @@ struct esp_handle {
     i64 chunk_cap = 0, hint = 0;
     int chunk_pb = 0;
     int runs_skip = 0, runs_penalty = 0;  // back-off after a stream turned out not to be pre-sorted
+    bool g3_off = false;                  // a segment of this handle's matrix did not fit the three-workgroup group kernel: not tried again
+    int last_group3 = 0;                  // the last flush's bucket kernel was group3_k (esp_debug_last_local_small reports 2)
     bool seen_hits = true;                // the last flush over a stored pattern mostly hit stored positions (re-assembly)
     int seen_maxrun = 0;                  // longest column run the bucket kernel met in the last flush
     int last_partition = 0;               // 1 = run-based single pass, 2 = 8-bit passes only, 4 = the producer's, 7 = shard pieces

@@ -811,10 +811,14 @@ struct DenseCtx {
     int s;
 };
 constexpr int DENSE_COLS = 512;
-template <int G, int R, int CAPK, bool FRESH, int MODE, bool DENSE = false>
-__device__ __forceinline__ bool group_columns(const Args &a, u64 *skey, double *sval, const u32 *ccnt, int ncl, u32 rmin, u64 hi,
+// KT = u32 (the three-workgroup kernel group3_k, dense form only): the LDS key array holds the 32-bit SORT keys already,
+// and takes the records as (local column << rb) | row.
+template <int G, int R, int CAPK, bool FRESH, int MODE, bool DENSE = false, typename KT = u64>
+__device__ __forceinline__ bool group_columns(const Args &a, KT *skey, double *sval, const u32 *ccnt, int ncl, u32 rmin, u64 hi,
                                               u64 rowmask, unsigned long long *stamp, const DenseCtx *dc = nullptr) {
     static_assert(!DENSE || (FRESH && MODE != 0), "the dense form is the fresh-matrix addition fold");
+    constexpr bool K32L = sizeof(KT) == 4;
+    static_assert(!K32L || DENSE, "32-bit LDS keys: dense form only");
     const int t = threadIdx.x, q = t & (G - 1), lane = t & (ESP_WAVE - 1);
     constexpr int CPB = THREADS / G;  // columns the workgroup takes at a time
     constexpr u32 LOWMASK = (1u << SUB_SHIFT) - 1u;
@@ -835,9 +839,14 @@ __device__ __forceinline__ bool group_columns(const Args &a, u64 *skey, double *
 #pragma unroll
         for (int r = 0; r < R; r++) {
             const int p = r * G + q;
-            const u64 kk = skey[min(rs + min(p, lastj), CAPK - 1)];  // (all reads in flight; clamped, never past the array)
-            const u32 rel = (u32)((kk >> SUB_SHIFT) & rowmask) - rmin;
-            x[r] = p < len ? ((rel << SUB_SHIFT) | ((u32)kk & LOWMASK)) : ~0u;
+            if constexpr (K32L) {
+                const u32 kk = skey[min(rs + min(p, lastj), CAPK - 1)];
+                x[r] = p < len ? kk : ~0u;
+            } else {
+                const u64 kk = skey[min(rs + min(p, lastj), CAPK - 1)];  // (all reads in flight; clamped, never past the array)
+                const u32 rel = (u32)((kk >> SUB_SHIFT) & rowmask) - rmin;
+                x[r] = p < len ? ((rel << SUB_SHIFT) | ((u32)kk & LOWMASK)) : ~0u;
+            }
         }
         group_sort<G, R>(x, q);
 #ifdef ESP_LOCAL_STAMPS
@@ -1042,24 +1051,29 @@ __device__ __forceinline__ bool group_columns(const Args &a, u64 *skey, double *
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 if ((emit >> r) & 1u) {
-                    skey[d] = hi + (colpart | (u64)((x[r] >> SUB_SHIFT) + rmin));
+                    if constexpr (K32L)
+                        skey[d] = (u32)colpart | ((x[r] >> SUB_SHIFT) + rmin);
+                    else
+                        skey[d] = hi + (colpart | (u64)((x[r] >> SUB_SHIFT) + rmin));
                     sval[d] = v[r];
                     d++;
                 }
             }
             return true;
         }
+        if constexpr (!K32L) {
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            if ((emit >> r) & 1u) {
-                skey[rs + e] = ((colpart | (u64)((x[r] >> SUB_SHIFT) + rmin)) << SUB_SHIFT) | (u64)(x[r] & (LOWMASK & ~(u32)ESP_TAG_MASK));
-                e++;
+            for (int r = 0; r < R; r++) {
+                if ((emit >> r) & 1u) {
+                    skey[rs + e] = ((colpart | (u64)((x[r] >> SUB_SHIFT) + rmin)) << SUB_SHIFT) | (u64)(x[r] & (LOWMASK & ~(u32)ESP_TAG_MASK));
+                    e++;
+                }
             }
-        }
 #pragma unroll
-        for (int r = 0; r < R; r++) {
-            const int p = q * R + r;
-            if (p >= total && p < len) skey[rs + p] = NOREC;
+            for (int r = 0; r < R; r++) {
+                const int p = q * R + r;
+                if (p >= total && p < len) skey[rs + p] = NOREC;
+            }
         }
     }
     return false;

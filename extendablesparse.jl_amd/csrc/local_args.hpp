@@ -16,6 +16,7 @@ constexpr int SUB_SHIFT = ESP_TAG_BITS + IDX_BITS;  // packed: sub << 14 | idx <
 constexpr int MAX_REM_BITS = 64 - SUB_SHIFT;
 static_assert((1 << IDX_BITS) == CAP, "slot index must cover the segment capacity");
 
+constexpr int G3_CL_BITS = 8;   // group3_k: segments of at most 256 whole columns
 constexpr int CL_MAX_BITS = 11;  // up to 2048 local columns counted in LDS
 constexpr int CL_MAX = 1 << CL_MAX_BITS;
 constexpr int REG_RUN = 24;   // longest column run sorted in registers
@@ -83,6 +84,7 @@ struct Variant {
     int keys;     // key format 0 .. 7
     bool grp = false;  // the group-tier kernel (column runs of more than 16 entries): regular form only
     bool shortg = false;  // ... its form for runs of at most 32 entries (four lanes x 8 keys per column)
+    bool g3 = false;      // ... the group tier as a kernel of its own with three workgroups per CU (group3.hpp)
 };
 // enqueues the kernel; false when the combination has no instantiation
 bool launch(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);
@@ -93,5 +95,7 @@ bool launch_pieces_stored(const Variant &v, unsigned grid, hipStream_t stream, c
 bool launch_pieces_small(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);   // local_e.hip
 bool launch_group(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);          // local_f.hip
 bool launch_group_short(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);    // local_g.hip
+bool launch_group3(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);         // local_h.hip
+
 
 }  // namespace esplocal

@@ -1,0 +1,19 @@
+// local_h.hip -- the group tier as a kernel of its own with three workgroups per CU (group3.hpp)
+#include "group3.hpp"
+
+namespace esplocal {
+
+bool launch_group3(const Variant &v, unsigned grid, hipStream_t stream, const Args &a) {
+    if (!v.fresh || v.pieces) return false;
+    if (v.keys == 1) {
+        hipLaunchKernelGGL((group3_k<1>), dim3(grid), dim3(THREADS), 0, stream, a);
+        return true;
+    }
+    if (v.keys == 2) {
+        hipLaunchKernelGGL((group3_k<2>), dim3(grid), dim3(THREADS), 0, stream, a);
+        return true;
+    }
+    return false;
+}
+
+}  // namespace esplocal

@@ -355,8 +355,9 @@ typedef enum {
                                         the partition)                                                                      */
     ESP_PATH_TWO_WORD_ITEMS = 28,    /* the item partition of esp_generate_fem moves 16-byte records (key | cell and vertex)
                                         even where the cell's number fits into the key                                      */
-    ESP_PATH_TAIL_TO_FRONT = 29      /* the entries behind a batch that was flushed by itself are copied to the front of
+    ESP_PATH_TAIL_TO_FRONT = 29,     /* the entries behind a batch that was flushed by itself are copied to the front of
                                         the buffer before their partition (instead of being read where they lie)            */
+    ESP_PATH_NO_GROUP3 = 30          /* never the group-tier kernel with three workgroups per CU (group3_k)                  */
 } esp_debug_path;
 /* last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general) */
 int32_t esp_debug_force_path(esp_handle *h, int32_t path);
@@ -378,7 +379,8 @@ int32_t esp_debug_last_fold_update(const esp_handle *h, int32_t *on);
 /* 1 when the bucket kernel of the last flush was its small variant: segments of at most 3072 entries over at most 256
  * columns, no radix tier, 51 KiB of LDS = three workgroups per CU instead of two (column runs longer than its register
  * tiers take go through a slow tier and send the handle's next flushes to the regular kernel); esp_debug_force_path(18):
- * never */
+ * never.  2 when it was the group tier's kernel with three workgroups per CU (group3_k: long column runs on a fresh matrix,
+ * 4-byte keys; esp_debug_force_path(30): never) */
 int32_t esp_debug_last_local_small(const esp_handle *h, int32_t *small);
 /* which partition the last flush used: 1 = run-based single pass (pre-sorted stream), 2 = 8-bit passes,
  * 4 = none: the producer wrote every entry straight to its bucket (esp_generate_* on an empty buffer: a COUNT launch
