@@ -740,6 +740,15 @@ def test_item_producer_shuffled_fem(esp, orc):
         A.flush()
         assert A.debug_last_partition() == 4 and A.debug_last_key_bytes() == 4, A.debug_last_partition()
         assert_csc_equal(hip_arrays(A), want, "fem %d-D %d" % (dim, npd))
+        # (long column runs on a fresh matrix, 4-byte keys: the group tier's kernel with three workgroups per CU, group3.hpp;
+        # force_path 30: local_k's group-tier kernels)
+        assert A.debug_last_local_small() == 2, (dim, npd, A.debug_last_local_small())
+        G = esp.ExtendableSparseMatrix(nn, nn)
+        G.debug_force_path(30)
+        G.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
+        G.flush()
+        assert G.debug_last_partition() == 4 and G.debug_last_local_small() != 2
+        assert_csc_equal(hip_arrays(G), want, "no group3")
         C = esp.ExtendableSparseMatrix(nn, nn)
         C.debug_force_path(14)
         C.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
