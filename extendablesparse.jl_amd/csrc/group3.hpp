@@ -14,11 +14,14 @@
 
 namespace esplocal {
 
-template <int KEYS>
-__global__ __launch_bounds__(THREADS, 6) void group3_k(Args a) {
+// NI = 6: segments of at most 3072 entries -- 39 KiB of LDS and 54 registers: FOUR workgroups per CU.  (Not instantiated: the
+// headline's stencil segments -- runs of 12, two lanes x 8 keys per column -- take 1.63 ms this way with three workgroups per CU
+// and 1.57 ms with four, against 1.56 ms in the register tiers of local_k's small variant on the same box.)
+template <int KEYS, int NI = ITEMS>
+__global__ __launch_bounds__(THREADS, NI == 6 ? 8 : 6) void group3_k(Args a) {
     static_assert(KEYS == 1 || KEYS == 2, "4-byte keys of one kind");
+    static_assert(NI == ITEMS || NI == 6, "4096 or 3072 entries per segment");
     constexpr bool UPD = KEYS == 2;
-    constexpr int NI = ITEMS;
     constexpr int CAPK = THREADS * NI;
     __shared__ u32 skey[CAPK];
     __shared__ double sval[CAPK];
