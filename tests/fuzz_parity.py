@@ -96,7 +96,52 @@ def generator_case():
     return True
 
 
+def fem_case():
+    """The P1 FEM producer (test/femtools.jl:45-72) on random meshes, natural or shuffled cell order: item partition +
+    expansion, the group tier of the bucket kernel in all its kernels (group3_k with three workgroups per CU on a fresh
+    matrix; local_k's group tier over a stored pattern, with force_path 30, or when a run is too long), further appends
+    behind the batch, re-assembly."""
+    dim = int(rng.choice([2, 2, 3]))
+    npd = int(rng.integers(6, 400)) if dim == 2 else int(rng.integers(4, 42))
+    nn = npd ** dim
+    order = int(rng.choice([0, 1, 1]))
+    force = int(rng.choice([0, 0, 0, 0, 30, 24, 25, 28, 14, 26]))
+    A = esp.ExtendableSparseMatrix(nn, nn)
+    A.debug_force_path(force)
+    O = orc.ExtendableSparseMatrix(nn, nn)
+    for rnd in range(int(rng.integers(1, 4))):
+        seed = int(rng.integers(1, 1 << 30))
+        I, J, V = orc.fem_stream(dim, npd, seed=seed, order_mode=order)
+        A.generate_fem(dim, npd, seed=seed, order_mode=order)
+        O.apply(np.full(len(I), 2, np.uint8), I, J, V)
+        if rng.random() < 0.4:                               # entries behind the batch: a few, or many in a few columns
+            cnt = int(rng.choice([3, 500, 40000]))
+            cols = rng.integers(1, nn + 1, cnt) if rng.random() < 0.6 else rng.choice(rng.integers(1, nn + 1, 3), cnt)
+            Ih, Jh, Vh = rng.integers(1, nn + 1, cnt), np.sort(cols), rng.standard_normal(cnt)
+            kh = rng.integers(0, 3, cnt).astype(np.uint8)
+            A.append(0, Ih, Jh, Vh, kinds=kh)
+            O.apply(kh, Ih, Jh, Vh)
+        try:
+            A.flush()
+        except Exception:
+            print("FLUSH FAILED fem case", dict(dim=dim, npd=npd, order=order, force=force, rnd=rnd, seed=seed))
+            raise
+        O.flush()
+        key = ("fem", A.debug_last_partition(), A.debug_last_key_bytes(), A.debug_last_local_small())
+        paths[key] = paths.get(key, 0) + 1
+        try:
+            assert_csc_equal(A.sparse().arrays(), O.arrays())
+        except AssertionError:
+            print("MISMATCH fem case", dict(dim=dim, npd=npd, order=order, force=force, rnd=rnd, seed=seed))
+            raise
+    return True
+
+
 while time.time() < t_end:
+    if rng.random() < 0.12 and os.environ.get("ESP_FUZZ_FOCUS") != "k32":
+        if fem_case():
+            cases += 1
+        continue
     if rng.random() < 0.35 and os.environ.get("ESP_FUZZ_FOCUS") != "k32":
         if generator_case():
             cases += 1
