@@ -466,6 +466,56 @@ def test_bucket_kernel_tiers(esp, orc, per_col):
         assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
 
 
+def test_append_device_entry_point(esp, orc):
+    """esp_append_device (triplets resident in GPU memory) by itself: on an empty buffer a pre-sorted batch of one kind is
+    partitioned as it is appended (esp_debug_last_partition 4), an unsorted one or one with a kinds array is packed in
+    stream order; op '-' negates; further batches behind the first; an out-of-range entry rejects its whole batch and
+    leaves what was appended before; lengths are checked by the host mirror."""
+    import torch
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()   # noqa: E731
+    rng = np.random.default_rng(321)
+    m, n, cnt = 300000, 200000, 3000000
+    for case in ("sorted_update", "sorted_raw_minus", "unsorted", "kinds_array", "two_batches", "bounds"):
+        A = esp.ExtendableSparseMatrix(m, n)
+        O = orc.ExtendableSparseMatrix(m, n)
+        I = rng.integers(1, m + 1, cnt)
+        J = rng.integers(1, n + 1, cnt)
+        V = rng.standard_normal(cnt)
+        V[rng.random(cnt) < 0.05] = 0.0
+        if case != "unsorted":
+            J = np.sort(J)
+        if case == "sorted_raw_minus":
+            A.append_device(RAW, dev(I), dev(J), dev(V), op="-")
+            O.apply(np.full(cnt, RAW, np.uint8), I, J, -V)
+        elif case == "kinds_array":
+            kinds = rng.integers(0, 3, cnt).astype(np.uint8)
+            A.append_device(0, dev(I), dev(J), dev(V), kinds=dev(kinds))
+            O.apply(kinds, I, J, V)
+        else:
+            A.append_device(UPDATE, dev(I), dev(J), dev(V))
+            O.apply(np.full(cnt, UPDATE, np.uint8), I, J, V)
+        if case == "two_batches":
+            I2, J2, V2 = rng.integers(1, m + 1, 5000), np.sort(rng.integers(1, n + 1, 5000)), rng.standard_normal(5000)
+            A.append_device(orc.KIND_SET, dev(I2), dev(J2), dev(V2))
+            O.apply(np.full(5000, orc.KIND_SET, np.uint8), I2, J2, V2)
+        if case == "bounds":
+            bad = J.copy()
+            bad[7] = n + 1
+            with pytest.raises((esp.BoundsError, IndexError)):
+                A.append_device(UPDATE, dev(I), dev(bad), dev(V))
+            with pytest.raises(ValueError):
+                A.append_device(UPDATE, dev(I[:10]), dev(J), dev(V))
+        A.flush(), O.flush()
+        if case in ("sorted_update", "sorted_raw_minus", "bounds"):
+            assert A.debug_last_partition() == 4, (case, A.debug_last_partition())
+        assert_csc_equal(hip_arrays(A), O.arrays(), case)
+        # ... and once more over the stored pattern (routed), the same entry point
+        A.append_device(UPDATE, dev(I), dev(J), dev(V))
+        O.apply(np.full(cnt, UPDATE, np.uint8), I, J, V)
+        A.flush(), O.flush()
+        assert_csc_equal(hip_arrays(A), O.arrays(), case + " again")
+
+
 def test_tail_partitioned_as_appended(esp, orc):
     """An append of one kind behind a producer's batch over a STORED pattern is partitioned as it comes (partition.hip,
     append_tail_partitioned): kinds UPDATE / SET / RAWUPDATE, op '-', a tail whose columns come in no sorted order (falls
