@@ -29,7 +29,10 @@ if cfg3:
     torch.cuda.synchronize()
 for it in range(3):
     A.reset()
-    if reasm:
+    if reasm and fem:
+        A.generate_fem(fdim, fem, seed=3, order_mode=1)
+        A.flush()
+    elif reasm:
         A.generate_fdrand(n, n, n, rand_mode=1)
         A.flush()
     if fem:
