@@ -438,6 +438,9 @@ def main():
     ap.add_argument("--no-extra", action="store_true", help="skip the extra.configs measurements (configs 3 and 4)")
     ap.add_argument("--sharded", action="store_true",
                     help="use the column-shard exchange path even on one GPU (always used for --gpus > 1)")
+    ap.add_argument("--scrambled", action="store_true",
+                    help="N > 1: the z-planes of the global grid are dealt round-robin to the ranks in blocks of 8 (SURVEY 8d, config 5: "
+                         "(N-1)/N of every rank's entries travel through the all-to-all) instead of one z-slab per rank")
     ap.add_argument("--global-n", type=int, default=int(os.environ.get("ESP_BENCH_GLOBAL_N", "0")),
                     help="STRONG scaling on a fixed global G^3 grid (BASELINE.json configs[4]: --gpus 8 --global-n 512): rank r "
                          "assembles the z-slab of G/N planes it owns; default (0): weak scaling, n x n x (n*N)")
@@ -506,10 +509,19 @@ def main():
         A = SA.local
         Z_total = N + 2 * ((gx - 1) * gy * nzg + gx * (gy - 1) * nzg + gx * gy * (nzg - 1))
 
+        scr_blk = 8 * gx * gy                  # (--scrambled: blocks of 8 z-planes, dealt round-robin)
+        if args.scrambled and (nzg % (8 * world)):
+            raise SystemExit("bench.py: --scrambled deals blocks of 8 z-planes: %d planes do not divide by 8 x %d ranks" % (nzg, world))
+
         def step():
             A.reset()
-            A.generate_fdrand_range(gx, gy, nzg, rank * nodes, (rank + 1) * nodes, seed=0x5EED0002, rand_mode=1,
-                                    kind=esp.ESP_UPDATE)
+            if args.scrambled:
+                for b in range(rank, N // scr_blk, world):
+                    A.generate_fdrand_range(gx, gy, nzg, b * scr_blk, (b + 1) * scr_blk, seed=0x5EED0002, rand_mode=1,
+                                            kind=esp.ESP_UPDATE)
+            else:
+                A.generate_fdrand_range(gx, gy, nzg, rank * nodes, (rank + 1) * nodes, seed=0x5EED0002, rand_mode=1,
+                                        kind=esp.ESP_UPDATE)
             SA.flush()
     # Timed region: HIP events around the bucket kernel only (level 3; every bracketed kernel costs two event records
     # of about 6 us on the stream).  The per-stage breakdown comes from a few extra, untimed steps at level 1
@@ -603,9 +615,10 @@ def main():
                        "n": n, "appended_entries": E, "final_nnz": int(Z),
                        "partition": {1: "run-based single pass in flush!", 2: "8-bit passes in flush!",
                                      4: "producer-side (append = partition)", 7: "shard pieces"}.get(partition_kind, str(partition_kind)),
-                       "parallelism": ("column-range shards x%d, all-to-all-v entry routing (RCCL world size %d), z-slab "
+                       "parallelism": ("column-range shards x%d, all-to-all-v entry routing (RCCL world size %d), %s "
                                        "producers, global grid %dx%dx%d%s, at most %d entries sent off-rank per flush"
-                                       % (world, world, gx, gy, nzg, " (BASELINE.json configs[4])" if args.global_n == 512 else "", sent))
+                                       % (world, world, "scrambled (blocks of 8 z-planes dealt round-robin)" if args.scrambled else "z-slab",
+                                          gx, gy, nzg, " (BASELINE.json configs[4])" if args.global_n == 512 else "", sent))
                                       if sharded else "1 GPU"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
