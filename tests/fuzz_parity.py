@@ -53,7 +53,7 @@ def generator_case():
         seed = int(rng.integers(1, 1 << 30))
         I, J, V = orc.fdrand_stream(nx, ny, nz, rand_mode=mode, seed=seed)
         kk = np.full(len(I), kind, np.uint8)
-        how = rng.choice(["whole", "two_calls", "host_after", "host_before"])
+        how = rng.choice(["whole", "two_calls", "host_after", "host_before", "dev_after"])
         if how == "whole":
             A.generate_fdrand(nx, ny, nz, seed=seed, rand_mode=mode, kind=kind)
             O.apply(kk, I, J, V)
@@ -62,6 +62,20 @@ def generator_case():
             A.generate_fdrand_range(nx, ny, nz, 0, cut_node, seed=seed, rand_mode=mode, kind=kind)
             A.generate_fdrand_range(nx, ny, nz, cut_node, N, seed=seed, rand_mode=mode, kind=kind)
             O.apply(kk, I, J, V)
+        elif how == "dev_after":
+            # triplets resident on the device behind the producer's batch, one kind: over a stored pattern a pre-sorted tail
+            # is partitioned as it is appended (partition.hip, append_tail_partitioned)
+            cnt = int(rng.choice([5000, 200000, 1500000]))
+            Ih, Jh, Vh = rng.integers(1, N + 1, cnt), rng.integers(1, N + 1, cnt), rng.standard_normal(cnt)
+            if rng.random() < 0.8:
+                Jh = np.sort(Jh)
+            kd = int(rng.choice([0, 1, 2]))
+            A.generate_fdrand(nx, ny, nz, seed=seed, rand_mode=mode, kind=kind)
+            O.apply(kk, I, J, V)
+            dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()   # noqa: E731
+            sub = rng.random() < 0.3
+            A.append_device(kd, dev(Ih), dev(Jh), dev(Vh), op="-" if sub else "+")
+            O.apply(np.full(cnt, kd, np.uint8), Ih, Jh, -Vh if (sub and kd != 0) else Vh)
         else:
             cnt = int(rng.choice([1, 7, 5000, 200000]))
             Ih, Jh, Vh = rng.integers(1, N + 1, cnt), rng.integers(1, N + 1, cnt), rng.standard_normal(cnt)
