@@ -1,0 +1,269 @@
+// elements.hip -- libesparse_hip: element-level append (esp_append_elements*, esp_generate_fem_mesh); kernels in elements.hpp
+#include "internal.hpp"
+#include "elements.hpp"
+
+namespace {
+
+template <bool K32>
+void launch_expand(const espelem::Args &a, hipStream_t stream) {
+    const dim3 grid(grid_for(a.nitems, espelem::THREADS)), block(espelem::THREADS);
+    const size_t lds = (size_t)espelem::THREADS * (size_t)a.W * (sizeof(double) + (K32 ? sizeof(u32) : sizeof(u64)));
+    if (a.nloc == 3)
+        hipLaunchKernelGGL((espelem::elem_expand_k<K32, 3>), grid, block, lds, stream, a);
+    else if (a.nloc == 4)
+        hipLaunchKernelGGL((espelem::elem_expand_k<K32, 4>), grid, block, lds, stream, a);
+    else
+        hipLaunchKernelGGL((espelem::elem_expand_k<K32, 0>), grid, block, lds, stream, a);
+}
+
+// The item partition (elements.hpp) on an empty buffer.  *took = false: not applicable (or a cell names a node twice):
+// nothing was appended, the caller writes the updates in stream order.
+int32_t elements_by_items(esp_handle *h, espelem::Args a, i64 E, bool *took) {
+    *took = false;
+    if (h->count != 0 || E <= esplocal::CAP || windowed(h) || h->shard_user) return ESP_OK;
+    // (test hooks that pin another path: 2 general, 5 / 12 / 16 partition flavours, 19 plain pending buffer, 25 the item partition off)
+    if (h->force_path == ESP_PATH_GENERAL || h->force_path == ESP_PATH_NO_RUN_PARTITION || h->force_path == ESP_PATH_RUN_LIST_BY_RADIX ||
+        h->force_path == ESP_PATH_PRODUCER_STREAM_ORDER || h->force_path == ESP_PATH_NO_BATCH_TAIL || h->force_path == ESP_PATH_NO_ITEM_PARTITION)
+        return ESP_OK;
+    const int W = a.W;
+    const i64 NI = a.nitems;
+    if (NI >= 0xFFFFFFF0ll || 2 * NI > E || (i64)esplocal::CAP / W < 64) return ESP_OK;
+    // the records' virtual layout: the item's number below the column bits
+    const int vrb = std::max(h->L.rb, bits_for(NI) - ESP_TAG_BITS);
+    if (vrb + h->L.cb + ESP_TAG_BITS > 64) return ESP_OK;
+    CK(reserve_append(h, E));
+    // two ping-pong arrays of item records inside the flush's scratch array (sized for E updates: E / W items each)
+    CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
+    CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
+    CK(ensure(h, h->misc, 256));
+    unsigned long long *d_err = (unsigned long long *)h->misc.p;
+    u32 *d_dup = (u32 *)((unsigned long long *)h->misc.p + 1);
+    h->pin_scalar[0] = ~0ull;
+    h->pin_scalar[1] = 0ull;
+    HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 16, hipMemcpyHostToDevice, h->stream));
+    a.vrb = vrb;
+    a.err = d_err;
+    a.dup = d_dup;
+    a.ikeys = (u64 *)h->keys2.p;
+    {
+        Span sp(h, ESP_ST_APPEND);
+        hipLaunchKernelGGL(espelem::elem_items_k, dim3(grid_for(NI, espelem::THREADS)), dim3(espelem::THREADS), 0, h->stream, a);
+        sp.add(1);
+    }
+    // the flush's partition over the items: a temporary view of the handle (sort_msd reads count, keys, keys2 and the
+    // key window -- here the records' virtual one)
+    const DevBuf k0 = h->keys, v0 = h->vals, k2 = h->keys2, v2 = h->vals2;
+    const i64 count0 = h->count;
+    const double spread0 = h->seen_spread;
+    const u64 span0 = h->win_span, base0 = h->win_base;
+    h->keys.p = a.ikeys, h->keys.bytes = sizeof(u64) * (size_t)NI;
+    h->keys2.p = a.ikeys + NI, h->keys2.bytes = sizeof(u64) * (size_t)NI;
+    h->vals.bytes = std::max(h->vals.bytes, sizeof(double) * (size_t)NI);  // (keys-only passes never touch the value arrays)
+    h->vals2.bytes = std::max(h->vals2.bytes, sizeof(double) * (size_t)NI);
+    h->count = NI;
+    h->win_base = 0;
+    h->win_span = (u64)std::max<i64>(h->n, 1) << vrb;
+    h->plan_cap = (i64)esplocal::CAP / W;
+    h->item_mode = true;
+    h->item_keys_only = true;
+    Sorted st;
+    const int32_t rc = sort_msd(h, &st);
+    h->keys = k0, h->vals = v0, h->keys2 = k2, h->vals2 = v2;
+    h->count = count0;
+    h->win_base = base0, h->win_span = span0;
+    h->plan_cap = 0;
+    h->item_mode = false;
+    h->item_keys_only = false;
+    if (rc != ESP_OK) return rc;
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    if (h->pin_scalar[0] != ~0ull)
+        FAIL(h, ESP_ERR_BOUNDS, "BoundsError: cell %llu of the batch names a node outside 1..%lld", (unsigned long long)h->pin_scalar[0],
+             (long long)a.lim);
+    const int rem_real = st.rem_bits - (vrb - h->L.rb);
+    if ((u32)h->pin_scalar[1] != 0u || !st.fits || st.S < 2 || st.rem_bits < vrb || rem_real > esplocal::MAX_REM_BITS ||
+        st.maxlen * W > (i64)esplocal::CAP) {
+        h->seen_spread = spread0;
+        return ESP_OK;  // (a cell with a repeated node, or no segment table the bucket kernel takes)
+    }
+    const int K = window_bits(h);
+    const bool k32 = rem_real <= 32 && h->force_path != ESP_PATH_PACKED_KEYS;
+    a.sorted_keys = st.sk;
+    a.rem_bits = rem_real;
+    a.base = h->win_base;
+    a.keys_out = (u64 *)h->keys.p;
+    a.vals_out = (double *)h->vals.p;
+    CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(st.S + 1)));
+    {
+        Span sp(h, ESP_ST_APPEND);
+        if (k32)
+            launch_expand<true>(a, h->stream);
+        else
+            launch_expand<false>(a, h->stream);
+        hipLaunchKernelGGL(espitem::scale_segments_k, dim3(grid_for((i64)st.S + 1, 256)), dim3(256), 0, h->stream, st.seg_start, (i64)st.S + 1,
+                           (i64)W, (i64 *)h->seg[1].p);
+        sp.add(2);
+    }
+    HIPCK(h, hipGetLastError());
+    esp_handle::PrePart &pp = h->pre;
+    pp.K = K;
+    pp.pb = K - rem_real;
+    pp.maxlen = st.maxlen * W;
+    pp.key_bytes = k32 ? 4 : 8;
+    pp.kind = a.kind;
+    pp.E = E;
+    pp.tail = 0;
+    pp.base = h->win_base;
+    pp.span = h->win_span;
+    pp.Ee = plan_entries(E, K, h->win_span);
+    pp.mw_P = 0, pp.mw_me = 0, pp.mw_shift = 0, pp.mw_nb = 0, pp.mw_eps = 0;
+    pp.own32 = false;
+    *took = true;  // (the caller sets pre.valid once the entries are counted in)
+    return ESP_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t esp_append_elements(esp_handle *h, int32_t nloc, int64_t ncells, const int64_t *d_cellnodes, const double *d_elmat,
+                                       const double *d_diag, int32_t kind, int32_t op) {
+    if (!h) return ESP_ERR_INVALID;
+    if (nloc < 1 || nloc > espelem::MAX_NLOC) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_append_elements: %d nodes per cell (1..%d)", nloc, espelem::MAX_NLOC);
+    if (ncells < 0 || (ncells > 0 && (!d_cellnodes || !d_elmat))) FAIL(h, ESP_ERR_INVALID, "esp_append_elements: bad arguments");
+    if (kind < 0 || kind > 3) FAIL(h, ESP_ERR_INVALID, "append: kind %d invalid", kind);
+    if (op != ESP_OP_ADD && op != ESP_OP_SUB) FAIL(h, ESP_ERR_UNSUPPORTED, "append: op %d not supported on the device path", op);
+    if (ncells == 0) return ESP_OK;
+    (void)hipSetDevice(h->device);
+    espelem::Args a;
+    memset(&a, 0, sizeof a);
+    a.nloc = nloc;
+    a.W = nloc + (d_diag ? 1 : 0);
+    a.ncells = ncells;
+    if (ncells > (((i64)1 << 40) / nloc)) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_append_elements: too many cells for one call");
+    a.nitems = ncells * nloc;
+    a.cellnodes = d_cellnodes;
+    a.elmat = d_elmat;
+    a.diag = d_diag;
+    a.lim = std::min(h->m, h->n);
+    a.L = h->L;
+    a.kind = kind;
+    a.negate = (op == ESP_OP_SUB && kind != ESP_SET) ? 1 : 0;
+    const i64 E = a.nitems * a.W;
+    bool took = false;
+    CK(elements_by_items(h, a, E, &took));
+    if (!took) {
+        // stream order: packed keys behind whatever is pending
+        CK(reserve_append(h, E));
+        CK(ensure(h, h->misc, 256));
+        unsigned long long *d_err = (unsigned long long *)h->misc.p;
+        h->pin_scalar[0] = ~0ull;
+        HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 8, hipMemcpyHostToDevice, h->stream));
+        a.err = d_err;
+        a.keys_out = (u64 *)h->keys.p + h->count;
+        a.vals_out = (double *)h->vals.p + h->count;
+        {
+            Span sp(h, ESP_ST_APPEND);
+            const i64 per_cell = (i64)a.nloc * a.W;
+            const i64 cpl = std::max<i64>(1, ((i64)1 << 30) / per_cell);  // (cells per launch: the grid stays below 2^32 threads)
+            for (i64 c0 = 0; c0 < ncells; c0 += cpl) {
+                espelem::Args b = a;
+                const i64 cnt = std::min(cpl, ncells - c0) * per_cell;
+                b.cell_base = c0;
+                b.cellnodes = a.cellnodes + c0 * a.nloc;
+                b.elmat = a.elmat + c0 * a.nloc * a.nloc;
+                b.diag = a.diag ? a.diag + c0 * a.nloc : nullptr;
+                b.keys_out = a.keys_out + c0 * per_cell;
+                b.vals_out = a.vals_out + c0 * per_cell;
+                hipLaunchKernelGGL(espelem::elem_stream_k, dim3(grid_for(cnt, espelem::THREADS)), dim3(espelem::THREADS), 0, h->stream, b, cnt);
+                sp.add(1);
+            }
+        }
+        HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        HIPCK(h, hipGetLastError());
+        if (h->pin_scalar[0] != ~0ull) {
+            h->pre_keep = false;
+            FAIL(h, ESP_ERR_BOUNDS, "BoundsError: cell %llu of the batch names a node outside 1..%lld",
+                 (unsigned long long)h->pin_scalar[0], (long long)a.lim);
+        }
+    }
+    note_kind(h, kind, E);
+    h->count += E;
+    pending_changed(h);
+    if (took) h->pre.valid = true;
+    return ESP_OK;
+}
+
+// host arrays: uploaded as they are (three plain copies), then the device form
+extern "C" int32_t esp_append_elements_host(esp_handle *h, int32_t nloc, int64_t ncells, const int64_t *cellnodes, const double *elmat,
+                                            const double *diag, int32_t kind, int32_t op) {
+    if (!h) return ESP_ERR_INVALID;
+    if (nloc < 1 || nloc > espelem::MAX_NLOC) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_append_elements: %d nodes per cell (1..%d)", nloc, espelem::MAX_NLOC);
+    if (ncells < 0 || (ncells > 0 && (!cellnodes || !elmat))) FAIL(h, ESP_ERR_INVALID, "esp_append_elements: bad arguments");
+    if (ncells == 0) return ESP_OK;
+    (void)hipSetDevice(h->device);
+    DevBuf dn, de, dd;
+    const size_t bn = sizeof(i64) * (size_t)ncells * (size_t)nloc, be = sizeof(double) * (size_t)ncells * (size_t)nloc * (size_t)nloc;
+    int32_t rc = ensure(h, dn, bn);
+    if (rc == ESP_OK) rc = ensure(h, de, be);
+    if (rc == ESP_OK && diag) rc = ensure(h, dd, bn);
+    if (rc == ESP_OK) {
+        Span sp(h, ESP_ST_COPY);
+        hipError_t e = hipMemcpyAsync(dn.p, cellnodes, bn, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(de.p, elmat, be, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess && diag) e = hipMemcpyAsync(dd.p, diag, bn, hipMemcpyHostToDevice, h->stream);
+        sp.add(diag ? 3 : 2);
+        if (e != hipSuccess) {
+            h->err = std::string("esp_append_elements_host: ") + hipGetErrorString(e);
+            rc = ESP_ERR_HIP;
+        }
+    }
+    if (rc == ESP_OK)
+        rc = esp_append_elements(h, nloc, ncells, (const i64 *)dn.p, (const double *)de.p, diag ? (const double *)dd.p : nullptr, kind, op);
+    (void)hipStreamSynchronize(h->stream);  // (the kernels have read the temporaries)
+    release(dn);
+    release(de);
+    release(dd);
+    return rc;
+}
+
+// The element data of the build's Kuhn grid as device arrays (the producer of cellnodes / elmat / diag for tests and bench)
+extern "C" int32_t esp_generate_fem_mesh(esp_handle *h, int32_t dim, int64_t npd, uint64_t seed, int32_t order_mode, int32_t node_mode,
+                                         uint64_t node_seed, int64_t cell_begin, int64_t cell_end, int64_t *d_cellnodes, double *d_elmat,
+                                         double *d_diag) {
+    if (!h) return ESP_ERR_INVALID;
+    if ((dim != 2 && dim != 3) || npd < 2) FAIL(h, ESP_ERR_INVALID, "fem: dim must be 2 or 3 and npd >= 2");
+    const i64 q = npd - 1;
+    const i64 nc = dim == 2 ? 2 * q * q : 6 * q * q * q;
+    const i64 nn = dim == 2 ? npd * npd : npd * npd * npd;
+    if (cell_begin < 0 || cell_end > nc || cell_begin > cell_end || !d_cellnodes || !d_elmat) FAIL(h, ESP_ERR_INVALID, "fem mesh: bad cell range or NULL output");
+    if (cell_begin == cell_end) return ESP_OK;
+    (void)hipSetDevice(h->device);
+    espelem::MeshArgs a;
+    memset(&a, 0, sizeof a);
+    a.fem.dim = dim;
+    a.fem.npd = npd;
+    a.fem.ncells = nc;
+    a.fem.seed = seed;
+    a.fem.order_mode = order_mode;
+    int bits = 2;
+    while (((u64)1 << bits) < (u64)nc) bits += 2;
+    a.fem.bits = bits;
+    espgen::fem_fill_magic(a.fem);
+    a.fem.h = 1.0 / (double)(npd - 1);
+    a.fem.L = h->L;
+    a.nodes = a.fem;
+    a.nodes.ncells = nn;
+    a.nodes.seed = node_seed;
+    a.nodes.order_mode = node_mode ? 1 : 0;
+    bits = 2;
+    while (((u64)1 << bits) < (u64)nn) bits += 2;
+    a.nodes.bits = bits;
+    a.p0 = cell_begin;
+    a.p1 = cell_end;
+    a.cellnodes = d_cellnodes;
+    a.elmat = d_elmat;
+    a.diag = d_diag;
+    hipLaunchKernelGGL(espelem::fem_mesh_k, dim3(grid_for(cell_end - cell_begin, espelem::THREADS)), dim3(espelem::THREADS), 0, h->stream, a);
+    HIPCK(h, hipGetLastError());
+    return ESP_OK;
+}

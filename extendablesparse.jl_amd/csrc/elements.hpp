@@ -1,0 +1,204 @@
+// elements.hpp -- element-level append (esp_append_elements): the inner loops of a finite-element assembly
+// (test/femtools.jl:62-69) for element data the CALLER holds in arrays -- connectivity, element matrices, the optional
+// term on the diagonal -- with the item partition of femitems.hpp as its fast path.
+//
+//   for icell = 1:ncells, il = 1:nloc                      (femtools.jl:61-63)
+//       i = cellnodes[il, icell]
+//       update(A, diag[il, icell], i, i)                   (femtools.jl:64; only when the caller passes diag)
+//       for jl = 1:nloc: update(A, elmat[il, jl, icell], i, cellnodes[jl, icell])    (femtools.jl:65-68)
+//
+// A cell sends its nloc * W updates (W = nloc + 1 with a diagonal term, else nloc) to only nloc columns, W each -- one
+// ITEM per (cell, local column jl) -- and the bucket of an update is a function of its column.  So, on an empty buffer:
+//   elem_items_k   : one 8-byte record per item, in stream order: the column in the key's column bits | the item's number
+//                    p = cell * nloc + jl below them (a VIRTUAL key layout: as many low bits as the item numbers need --
+//                    the partition only ever looks at column bits); reads the connectivity once (8 B per item), checks
+//                    the node numbers (BoundsError) and that no cell names a node twice
+//   partition      : the flush's own stable passes (radix.hpp, keys only) over the records down to the bucket kernel's segments
+//   elem_expand_k  : sorted item g -> its W updates at entries [g W, (g+1) W) of the append buffer: the rows are the
+//                    cell's nodes (nloc * 8 B, gathered), the values column jl of the cell's element matrix (contiguous in
+//                    Julia's layout: nloc * 8 B, gathered) and diag[jl] -- all three addresses follow from the record
+//                    alone, one round trip -- staged through LDS, stored as whole lines, 4-byte keys when they fit
+// The buffer is a stable permutation of the stream whenever the nodes of a cell are distinct (inside a segment: items in
+// stream order, an item's updates in call order; two items of one cell never meet in a (row, column)), the segment table
+// follows from the items' (x W), and esp_flush starts at the bucket kernel (esp_handle::PrePart).  A cell that names a node
+// twice (its two items would interleave in the reference's call order), a non-empty buffer, a column window: the
+// updates go out in stream order as packed keys (elem_stream_k) and the flush partitions them like any other stream.
+#pragma once
+#include "common.hpp"
+#include "generators.hpp"
+
+namespace espelem {
+
+constexpr int THREADS = 256;
+constexpr int MAX_NLOC = 16;
+
+struct Args {
+    int nloc, W;            // nodes per cell; updates per item (nloc + 1 with a diagonal term)
+    i64 ncells, nitems;     // nitems = ncells * nloc
+    i64 cell_base;          // elem_stream_k: cells of the call in front of this launch (error reports)
+    const i64 *cellnodes;   // Int64 nloc x ncells (Julia layout: the nodes of a cell lie together)
+    const double *elmat;    // Float64 nloc x nloc x ncells: elmat[il + nloc * (jl + nloc * cell)]
+    const double *diag;     // Float64 nloc x ncells or nullptr
+    i64 lim;                // every node number must lie in 1 .. lim = min(m, n)
+    KeyLayout L;            // the matrix's key layout
+    int vrb;                // row bits of the VIRTUAL layout of the item records: record = (col0 << (vrb + 2)) | item number
+    int kind, negate;
+    unsigned long long *err;  // atomicMin: first offending cell + 1
+    u32 *dup;                 // set when a cell names a node twice
+    u64 *ikeys;               // item records, stream order
+    const u64 *sorted_keys;   // ... partitioned
+    int rem_bits;             // elem_expand_k, K32: key bits below the segment prefix (real layout)
+    u64 base;                 // key window base
+    u64 *keys_out;            // (K32: u32 keys)
+    double *vals_out;
+};
+
+// item p = cell * nloc + jl: 32-bit arithmetic (the host keeps nitems below 2^32)
+static __global__ __launch_bounds__(THREADS) void elem_items_k(Args a) {
+    const i64 p = (i64)blockIdx.x * THREADS + threadIdx.x;
+    if (p >= a.nitems) return;
+    const u32 nloc = (u32)a.nloc;
+    const u32 cell = (u32)p / nloc, jl = (u32)p - cell * nloc;
+    i64 node = a.cellnodes[p];
+    if (node < 1 || node > a.lim) {
+        atomicMin(a.err, (unsigned long long)cell + 1ull);
+        node = 1;  // (the record stays a valid key; the host stops before anything is expanded)
+    }
+    const i64 *cn = a.cellnodes + (i64)cell * nloc;
+    bool twice = false;
+    for (u32 k = 0; k < jl; k++) twice = twice || cn[k] == node;
+    if (twice) *a.dup = 1u;
+    a.ikeys[p] = ((u64)(node - 1) << (a.vrb + ESP_TAG_BITS)) | (u64)p;
+}
+
+// K32: 4-byte keys (the bits below the segment prefix; every entry has the batch's kind), else packed keys.
+// NLOC > 0: the nodes per cell as a compile-time constant (3, 4: P1 in 2-D / 3-D, rows and values in registers);
+// 0: any 1 .. MAX_NLOC.  Dynamic LDS: THREADS * W values, then THREADS * W keys.
+template <bool K32, int NLOC>
+static __global__ __launch_bounds__(THREADS) void elem_expand_k(Args a) {
+    typedef typename std::conditional<K32, u32, u64>::type KT;
+    extern __shared__ double elem_lds[];
+    const int t = threadIdx.x;
+    const int nloc = NLOC ? NLOC : a.nloc;
+    const int W = a.W;
+    double *lv = elem_lds;
+    KT *lk = reinterpret_cast<KT *>(lv + THREADS * W);
+    const i64 g0 = (i64)blockIdx.x * THREADS, g = g0 + t;
+    if (g < a.nitems) {
+        const u64 rec = a.sorted_keys[g];
+        const int low = a.vrb + ESP_TAG_BITS;
+        const u32 p = (u32)(rec & ((1ull << low) - 1ull));
+        const u64 col0 = rec >> low;
+        const u32 cell = p / (u32)nloc, jl = p - cell * (u32)nloc;
+        const i64 *cn = a.cellnodes + (i64)cell * nloc;
+        const double *em = a.elmat + (i64)p * nloc;  // column jl of the cell's element matrix
+        const u64 lowmask = a.rem_bits >= 64 ? ~0ull : ((1ull << a.rem_bits) - 1ull);
+        const u64 colpart = col0 << a.L.rb;
+        int at = t * W;
+        auto put = [&](i64 row, double v) {
+            if (a.negate) v = -v;
+            if constexpr (K32)
+                lk[at] = (u32)(((colpart | (u64)(row - 1)) - a.base) & lowmask);
+            else
+                lk[at] = ((colpart | (u64)(row - 1)) << ESP_TAG_BITS) | (u64)a.kind;
+            lv[at] = v;
+            at++;
+        };
+        if constexpr (NLOC > 0) {
+            i64 r[NLOC];
+            double v[NLOC];
+#pragma unroll
+            for (int il = 0; il < NLOC; il++) r[il] = cn[il];
+#pragma unroll
+            for (int il = 0; il < NLOC; il++) v[il] = em[il];
+            const double d = a.diag ? a.diag[p] : 0.0;
+#pragma unroll
+            for (int il = 0; il < NLOC; il++) {
+                if (a.diag && (u32)il == jl) put(r[il], d);  // (the diagonal's term comes right before the diagonal: femtools.jl:64)
+                put(r[il], v[il]);
+            }
+        } else {
+            for (int il = 0; il < nloc; il++) {
+                const i64 row = cn[il];
+                if (a.diag && (u32)il == jl) put(row, a.diag[p]);
+                put(row, em[il]);
+            }
+        }
+    }
+    __syncthreads();
+    const int cnt = (int)min((i64)THREADS, a.nitems - g0) * W;
+    // whole lines: g0 * W is a multiple of 256, every array starts 256-byte aligned
+    double *gv = a.vals_out + g0 * W;
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    const int vpair = cnt >> 1;
+    for (int q = t; q < vpair; q += THREADS) reinterpret_cast<dbl2 *>(gv)[q] = dbl2{lv[2 * q], lv[2 * q + 1]};
+    if (t == 0 && (cnt & 1)) gv[cnt - 1] = lv[cnt - 1];
+    if constexpr (K32) {
+        u32 *gk = reinterpret_cast<u32 *>(a.keys_out) + g0 * W;
+        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+        const int kquad = cnt >> 2;
+        for (int q = t; q < kquad; q += THREADS)
+            reinterpret_cast<u32x4 *>(gk)[q] = u32x4{lk[4 * q], lk[4 * q + 1], lk[4 * q + 2], lk[4 * q + 3]};
+        for (int q = 4 * kquad + t; q < cnt; q += THREADS) gk[q] = lk[q];
+    } else {
+        u64 *gk = a.keys_out + g0 * W;
+        typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+        for (int q = t; q < vpair; q += THREADS) reinterpret_cast<ull2 *>(gk)[q] = ull2{lk[2 * q], lk[2 * q + 1]};
+        if (t == 0 && (cnt & 1)) gk[cnt - 1] = lk[cnt - 1];
+    }
+}
+
+// The updates in stream order, as packed keys (any buffer state; what the flush's own partition then takes): entry e of
+// the launch = (cell, il, q), q = 0: the diagonal's term (with diag), then jl = 0 .. nloc-1.
+static __global__ __launch_bounds__(THREADS) void elem_stream_k(Args a, i64 count) {
+    const i64 e = (i64)blockIdx.x * THREADS + threadIdx.x;
+    if (e >= count) return;
+    const i64 per_cell = (i64)a.nloc * a.W;
+    const i64 cell = e / per_cell;
+    const int rem = (int)(e - cell * per_cell);
+    const int il = rem / a.W, q = rem - il * a.W;
+    const i64 *cn = a.cellnodes + cell * a.nloc;
+    const i64 row = cn[il];
+    i64 col;
+    double v;
+    if (a.diag && q == 0) {
+        col = row;
+        v = a.diag[cell * a.nloc + il];
+    } else {
+        const int jl = a.diag ? q - 1 : q;
+        col = cn[jl];
+        v = a.elmat[(cell * a.nloc + jl) * a.nloc + il];
+    }
+    if (row < 1 || row > a.lim || col < 1 || col > a.lim) {
+        atomicMin(a.err, (unsigned long long)(a.cell_base + cell) + 1ull);
+        return;
+    }
+    if (a.negate) v = -v;
+    a.keys_out[e] = esp_pack(a.L, row, col, a.kind);
+    a.vals_out[e] = v;
+}
+
+// ---- the arrays a caller of testassemble! holds, for the build's own Kuhn grid (tests and bench: test/femtools.jl:46-67) ----
+struct MeshArgs {
+    espgen::FemArgs fem;    // cells: dim, npd, ncells, seed, order_mode, bits, mq, h
+    espgen::FemArgs nodes;  // the node renumbering as a second Feistel bijection: ncells = number of nodes, seed, bits; order_mode 0: natural
+    i64 p0, p1;             // stream positions of the cells
+    i64 *cellnodes;
+    double *elmat, *diag;
+};
+static __global__ __launch_bounds__(THREADS) void fem_mesh_k(MeshArgs a) {
+    const i64 q = (i64)blockIdx.x * THREADS + threadIdx.x;
+    if (a.p0 + q >= a.p1) return;
+    const int nloc = a.fem.dim + 1;
+    espgen::fem_cell_updates(a.fem, a.p0 + q, [&](int il, int jl, i64 row, i64 col, double v) {
+        (void)col;
+        if (jl < 0) {
+            a.cellnodes[q * nloc + il] = 1 + (i64)espgen::fem_cell_at(a.nodes, row - 1);
+            if (a.diag) a.diag[q * nloc + il] = v;
+        } else {
+            a.elmat[(q * nloc + jl) * nloc + il] = v;
+        }
+    });
+}
+
+}  // namespace espelem

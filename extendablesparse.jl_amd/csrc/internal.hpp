@@ -267,6 +267,7 @@ struct Sorted {
     const i64 *seg_start;
     int rem_bits;
     bool local_ok;
+    bool fits = false;  // every segment is within seg_cap (local_ok without the limit on the remaining key bits)
     bool all_update = false;  // PIECES: every entry of every piece is an UPDATE (esp_shard_assemble checked)
     int key_bytes = 8;  // 4: sk holds 32-bit keys (the bits below the prefix); every entry has the kind `kind`
     int kind = 0;

@@ -707,6 +707,7 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
     out->seg_start = (const i64 *)h->seg[cur].p;
     out->rem_bits = K - done;
     out->local_ok = ok && (K - done) <= esplocal::MAX_REM_BITS && maxlen <= seg_cap(h);
+    out->fits = ok && maxlen <= seg_cap(h);
     out->maxlen = maxlen;
     h->seen_spread = (done > 0 && Ee > 0.0) ? (double)maxlen * std::ldexp(1.0, done) / Ee : 0.0;
     return ESP_OK;

@@ -187,6 +187,34 @@ class _Handle:
         kp = C.c_void_p(kinds.data_ptr()) if kinds is not None else None
         self.ck(self.lib.esp_append_device(self.h, C.c_void_p(I.data_ptr()), C.c_void_p(J.data_ptr()), C.c_void_p(V.data_ptr()), kp, kind, op, n))
 
+    def append_elements(self, kind, cellnodes, elmat, diag=None, op=ESP_OP_ADD):
+        """esp_append_elements[_host]: the inner loops of test/femtools.jl:61-69 for element data in arrays -- cellnodes
+        (nloc x ncells, int64), elmat (nloc x nloc x ncells, float64), diag (nloc x ncells) or None, all in Julia's
+        (column-major) layout: NumPy arrays in Fortran order (host), or anything with .data_ptr() / .numel() resident on this
+        GPU whose memory is laid out that way (a torch tensor of shape (ncells, nloc[, nloc]) -- its C order IS that layout,
+        elmat[c, jl, il])."""
+        self.commit()
+        if hasattr(cellnodes, "data_ptr"):
+            nloc = int(round(elmat.numel() / max(cellnodes.numel(), 1)))
+            if nloc < 1 or cellnodes.numel() % nloc or elmat.numel() != cellnodes.numel() * nloc or \
+                    (diag is not None and diag.numel() != cellnodes.numel()):
+                raise ValueError("append_elements: array sizes do not fit together")
+            nc = cellnodes.numel() // nloc
+            dp = C.c_void_p(diag.data_ptr()) if diag is not None else None
+            self.ck(self.lib.esp_append_elements(self.h, nloc, nc, C.c_void_p(cellnodes.data_ptr()), C.c_void_p(elmat.data_ptr()), dp, kind, op))
+            return
+        cn = np.asfortranarray(cellnodes, np.int64)
+        nloc, nc = cn.shape
+        em = np.asfortranarray(elmat, np.float64)
+        if em.shape != (nloc, nloc, nc):
+            raise ValueError("append_elements: elmat must be nloc x nloc x ncells")
+        dg = None
+        if diag is not None:
+            dg = np.asfortranarray(diag, np.float64)
+            if dg.shape != (nloc, nc):
+                raise ValueError("append_elements: diag must be nloc x ncells")
+        self.ck(self.lib.esp_append_elements_host(self.h, nloc, nc, _vp(cn), _vp(em), _vp(dg) if dg is not None else None, kind, op))
+
     def pending(self):
         c = C.c_int64()
         self.ck(self.lib.esp_pending(self.h, C.byref(c)))
@@ -373,6 +401,24 @@ class ExtendableSparseMatrix:
         """The bulk form for triplets that already lie in this GPU's memory (torch tensors: int64, int64, float64)."""
         self._touch()
         self._d.append_device(kind, I, J, V, _op(op), kinds)
+
+    def append_elements(self, cellnodes, elmat, diag=None, kind=ESP_RAWUPDATE, op="+"):
+        """The assembly loop of test/femtools.jl:61-69 as one call: for every cell and local row il the optional
+        diag[il, cell] on (i, i), then elmat[il, jl, cell] on (i, cellnodes[jl, cell]) for every jl -- bit-identical to
+        the per-entry rawupdateindex! / updateindex! calls in that order (see _Handle.append_elements for the layouts)."""
+        self._touch()
+        self._d.append_elements(kind, cellnodes, elmat, diag, _op(op))
+
+    def generate_fem_mesh(self, dim, npd, cellnodes, elmat, diag=None, seed=0x5EED0004, order_mode=1, node_mode=0,
+                          node_seed=0x5EED0014, cell_begin=0, cell_end=None):
+        """esp_generate_fem_mesh: fills DEVICE arrays (anything with .data_ptr()) with the element data of generate_fem's
+        grid for the cells at stream positions [cell_begin, cell_end): what a caller of testassemble! would hold."""
+        q = npd - 1
+        nc = 2 * q * q if dim == 2 else 6 * q * q * q
+        cell_end = nc if cell_end is None else cell_end
+        dp = C.c_void_p(diag.data_ptr()) if diag is not None else None
+        self._d.ck(self._d.lib.esp_generate_fem_mesh(self._d.h, dim, npd, seed, order_mode, node_mode, node_seed, cell_begin, cell_end,
+                                                      C.c_void_p(cellnodes.data_ptr()), C.c_void_p(elmat.data_ptr()), dp))
 
     def __getitem__(self, ij):
         """getindex (extendable.jl:226-238).  Pending entries live on the device, so the lookup is

@@ -146,6 +146,31 @@ int32_t esp_generate_fem(esp_handle *h, int32_t dim, int64_t npd, uint64_t seed,
 int32_t esp_generate_fdrand_range(esp_handle *h, int64_t nx, int64_t ny, int64_t nz, uint64_t seed,
                                   int32_t rand_mode, int32_t kind, int64_t node_begin,
                                   int64_t node_end);
+/* Element-level append: the inner loops of a finite-element assembly (test/femtools.jl:61-69) as ONE call, for element data
+ * the caller holds in arrays (Julia layouts, 1-based node numbers):
+ *   for icell = 1:ncells, il = 1:nloc:  i = cellnodes[il,icell]
+ *       diag != NULL:  update(A, diag[il,icell], i, i)                            (femtools.jl:64)
+ *       for jl = 1:nloc:  update(A, elmat[il,jl,icell], i, cellnodes[jl,icell])   (femtools.jl:65-68)
+ * with update = setindex! / updateindex! / rawupdateindex! as `kind` says (op as for esp_commit).  cellnodes: Int64
+ * nloc x ncells (grid[CellNodes], femtools.jl:47), elmat: Float64 nloc x nloc x ncells (vol * S of femtools.jl:67), diag:
+ * Float64 nloc x ncells or NULL; 1 <= nloc <= 16.  Bit-identical to the nloc * (nloc [+ 1]) per-entry calls per cell in
+ * that order.  On an EMPTY buffer the library partitions one 8-byte record per (cell, local column) instead of the updates
+ * and stores every update once, at its bucket position (the flush starts at the bucket kernel: esp_debug_last_partition 4);
+ * a cell that names a node twice, a non-empty buffer or a column window: the updates are appended in stream order.
+ * A node number outside 1..min(m,n): ESP_ERR_BOUNDS, nothing is appended.  The device form reads its arrays on the handle's
+ * stream (they must stay valid until esp_synchronize or the next flush returned). */
+int32_t esp_append_elements(esp_handle *h, int32_t nloc, int64_t ncells, const int64_t *d_cellnodes,
+                            const double *d_elmat, const double *d_diag, int32_t kind, int32_t op);
+int32_t esp_append_elements_host(esp_handle *h, int32_t nloc, int64_t ncells, const int64_t *cellnodes,
+                                 const double *elmat, const double *diag, int32_t kind, int32_t op);
+/* The element data of esp_generate_fem's grid as DEVICE arrays, for the cells at stream positions [cell_begin, cell_end):
+ * what a caller of testassemble! holds (cellnodes) and computes per cell (elmat = vol * S, diag = 0.1 * vol / (dim+1);
+ * femtools.jl:58-67) -- the producer of esp_append_elements' input in tests and bench.  node_mode 1: the nodes carry a
+ * permuted numbering (a bijection of 1..n made from node_seed): nothing downstream can lean on grid arithmetic.
+ * d_diag may be NULL. */
+int32_t esp_generate_fem_mesh(esp_handle *h, int32_t dim, int64_t npd, uint64_t seed, int32_t order_mode,
+                              int32_t node_mode, uint64_t node_seed, int64_t cell_begin, int64_t cell_end,
+                              int64_t *d_cellnodes, double *d_elmat, double *d_diag);
 /* number of appended, not yet flushed entries; >0 iff anything is pending
  * (the flush! gate of genericextendablesparsematrixcsc.jl:32 / nnznew :21) */
 int32_t esp_pending(const esp_handle *h, int64_t *count);

@@ -1159,3 +1159,55 @@ void orc_fem_stream_range(int dim, i64 npd, uint64_t seed, int order_mode, i64 p
 void orc_fem_stream(int dim, i64 npd, uint64_t seed, int order_mode, i64 *I, i64 *J, double *V) {
     orc_fem_stream_range(dim, npd, seed, order_mode, 0, orc_fem_ncells(dim, npd), I, J, V);
 }
+
+/* ---------------------------------------------------------- element-level assembly */
+/* The arrays a caller of testassemble! (test/femtools.jl:45-72) holds for the cells at stream positions [p0, p1) of
+ * the build's Kuhn grid: cellnodes (Int64 nloc x ncells, Julia layout -- grid[CellNodes], femtools.jl:47), and what
+ * the loop body computes per cell before it updates the matrix: elmat[il,jl,c] = vol * S[il,jl] (femtools.jl:67),
+ * diag[il,c] = 0.1 * vol / (dim+1) (femtools.jl:64).  node_mode 1: the nodes carry a permuted numbering (a Feistel
+ * bijection of [0, nnodes) with node_seed), so that nothing downstream can lean on grid arithmetic.              */
+void orc_fem_mesh_range(int dim, i64 npd, uint64_t seed, int order_mode, int node_mode, uint64_t node_seed, i64 p0,
+                        i64 p1, i64 *cellnodes, double *elmat, double *diag) {
+    i64 nc = orc_fem_ncells(dim, npd), nn = orc_fem_nnodes(dim, npd);
+    int nloc = dim + 1;
+    for (i64 p = p0; p < p1; p++) {
+        i64 cell = (i64)orc_fem_cell_at(p, nc, seed, order_mode);
+        i64 nodes[4];
+        double vol, S[4][4];
+        fem_local(dim, npd, cell, nodes, &vol, S);
+        i64 q = p - p0;
+        for (int il = 0; il < nloc; il++) {
+            i64 nd = nodes[il];
+            if (node_mode) nd = 1 + (i64)orc_fem_cell_at(nd - 1, nn, node_seed, 1);
+            cellnodes[q * nloc + il] = nd;
+            if (diag) diag[q * nloc + il] = 0.1 * vol / (double)(dim + 1);
+            for (int jl = 0; jl < nloc; jl++) elmat[(q * nloc + jl) * nloc + il] = vol * S[il][jl];
+        }
+    }
+}
+
+/* The update calls of the assembly loop (test/femtools.jl:62-69) for element data held in arrays:
+ *   for icell: for il: i = cellnodes[il,icell]; [update(A, diag[il,icell], i, i);]
+ *                      for jl: j = cellnodes[jl,icell]; update(A, elmat[il,jl,icell], i, j)
+ * as a triplet stream in call order; returns the number of triplets = ncells * nloc * (nloc + (diag != NULL)).   */
+i64 orc_elements_stream(int nloc, i64 ncells, const i64 *cellnodes, const double *elmat, const double *diag, i64 *I,
+                        i64 *J, double *V) {
+    i64 pos = 0;
+    for (i64 c = 0; c < ncells; c++)
+        for (int il = 0; il < nloc; il++) {
+            i64 i = cellnodes[c * nloc + il];
+            if (diag) {
+                I[pos] = i;
+                J[pos] = i;
+                V[pos] = diag[c * nloc + il];
+                pos++;
+            }
+            for (int jl = 0; jl < nloc; jl++) {
+                I[pos] = i;
+                J[pos] = cellnodes[c * nloc + jl];
+                V[pos] = elmat[(c * nloc + jl) * nloc + il];
+                pos++;
+            }
+        }
+    return pos;
+}

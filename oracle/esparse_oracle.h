@@ -136,6 +136,15 @@ void orc_fem_stream(int dim, i64 npd, uint64_t seed, int order_mode, i64 *I, i64
 void orc_fem_stream_range(int dim, i64 npd, uint64_t seed, int order_mode, i64 p0, i64 p1, i64 *I, i64 *J,
                           double *V);
 
+/* element data of the cells at stream positions [p0, p1) as a caller of testassemble! holds it (femtools.jl:46-67):
+ * cellnodes Int64 nloc x (p1-p0), elmat = vol*S Float64 nloc x nloc x (p1-p0), diag = 0.1*vol/(dim+1) nloc x (p1-p0)
+ * (NULL: not wanted), Julia (column-major) layouts; node_mode 1: permuted node numbering */
+void orc_fem_mesh_range(int dim, i64 npd, uint64_t seed, int order_mode, int node_mode, uint64_t node_seed, i64 p0,
+                        i64 p1, i64 *cellnodes, double *elmat, double *diag);
+/* the update calls of femtools.jl:62-69 for element data in arrays, as triplets in call order; returns their number */
+i64 orc_elements_stream(int nloc, i64 ncells, const i64 *cellnodes, const double *elmat, const double *diag, i64 *I,
+                        i64 *J, double *V);
+
 #ifdef __cplusplus
 }
 #endif

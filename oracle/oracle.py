@@ -159,6 +159,8 @@ def lib():
     sig("orc_fem_cell_nodes", None, C.c_int, i64, i64, p_i64)
     sig("orc_fem_stream", None, C.c_int, i64, C.c_uint64, C.c_int, p_i64, p_i64, p_f64)
     sig("orc_fem_stream_range", None, C.c_int, i64, C.c_uint64, C.c_int, i64, i64, p_i64, p_i64, p_f64)
+    sig("orc_fem_mesh_range", None, C.c_int, i64, C.c_uint64, C.c_int, C.c_int, C.c_uint64, i64, i64, p_i64, p_f64, p_f64)
+    sig("orc_elements_stream", i64, C.c_int, i64, p_i64, p_f64, p_f64, p_i64, p_i64, p_f64)
     _lib = L
     return L
 
@@ -518,4 +520,36 @@ def fem_stream(dim, npd, seed=0x5EED0004, order_mode=1):
     J = np.empty(e, np.int64)
     V = np.empty(e, np.float64)
     lib().orc_fem_stream(dim, npd, seed, order_mode, _pi(I), _pi(J), _pf(V))
+    return I, J, V
+
+
+def fem_mesh(dim, npd, seed=0x5EED0004, order_mode=1, node_mode=0, node_seed=0x5EED0014, p0=0, p1=None, diag=True):
+    """Element data of the cells at stream positions [p0, p1) as a caller of testassemble! holds it: cellnodes
+    (nloc x nc, Fortran order like Julia's grid[CellNodes]), elmat = vol * S (nloc x nloc x nc), diag = 0.1 * vol / (dim+1)."""
+    L = lib()
+    nloc = dim + 1
+    if p1 is None:
+        p1 = L.orc_fem_ncells(dim, npd)
+    nc = p1 - p0
+    cn = np.empty((nloc, nc), np.int64, order="F")
+    em = np.empty((nloc, nloc, nc), np.float64, order="F")
+    dg = np.empty((nloc, nc), np.float64, order="F") if diag else None
+    L.orc_fem_mesh_range(dim, npd, seed, order_mode, node_mode, node_seed, p0, p1, _pi(cn), _pf(em),
+                         _pf(dg) if diag else None)
+    return cn, em, dg
+
+
+def elements_stream(cellnodes, elmat, diag=None):
+    """The update calls of test/femtools.jl:62-69 for element data held in arrays (Julia layouts), as triplets."""
+    nloc, nc = cellnodes.shape
+    cn = np.asfortranarray(cellnodes, np.int64)
+    em = np.asfortranarray(elmat, np.float64)
+    assert em.shape == (nloc, nloc, nc)
+    dg = None if diag is None else np.asfortranarray(diag, np.float64)
+    e = nc * nloc * (nloc + (0 if diag is None else 1))
+    I = np.empty(e, np.int64)
+    J = np.empty(e, np.int64)
+    V = np.empty(e, np.float64)
+    got = lib().orc_elements_stream(nloc, nc, _pi(cn), _pf(em), _pf(dg) if dg is not None else None, _pi(I), _pi(J), _pf(V))
+    assert got == e
     return I, J, V

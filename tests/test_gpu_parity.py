@@ -842,6 +842,140 @@ def test_item_producer_shuffled_fem(esp, orc):
         assert_csc_equal(hip_arrays(A), O.arrays(), "twice")
 
 
+def test_append_elements(esp, orc):
+    """esp_append_elements[_host]: the loops of test/femtools.jl:61-69 for element data held in arrays, against the oracle
+    fed the same calls one by one.  On an empty buffer the library partitions (cell, local column) items and the flush starts
+    at the bucket kernel (esp_debug_last_partition 4); meshes with natural AND permuted node numbering (nothing may lean on
+    grid arithmetic), host and device arrays, without a diagonal term, as updateindex! with zeros, with `-`, a cell that names a
+    node twice (stream-order fall-back), behind other appends, twice in a row, over a stored pattern, BoundsError."""
+    import torch
+    rng = np.random.default_rng(21)
+    for dim, npd in ((2, 300), (3, 31), (3, 18)):
+        nn = npd ** dim
+        nloc = dim + 1
+        for node_mode in (0, 1):
+            cn, em, dg = orc.fem_mesh(dim, npd, seed=0x5EED0004, order_mode=1, node_mode=node_mode)
+            nc = cn.shape[1]
+            I, J, V = orc.elements_stream(cn, em, dg)
+            O = orc.ExtendableSparseMatrix(nn, nn)
+            O.apply(np.full(len(I), RAW, np.uint8), I, J, V)
+            want = O.arrays()
+            if node_mode == 0:   # (natural numbering: the stream IS generate_fem's)
+                I0, J0, V0 = orc.fem_stream(dim, npd, seed=0x5EED0004, order_mode=1)
+                assert np.array_equal(I, I0) and np.array_equal(J, J0) and np.array_equal(bits(V), bits(V0))
+            # host arrays
+            A = esp.ExtendableSparseMatrix(nn, nn)
+            A.append_elements(cn, em, dg)
+            assert A.nnznew() == len(I)
+            A.flush()
+            assert A.debug_last_partition() == 4 and A.debug_last_key_bytes() == 4, (A.debug_last_partition(), A.debug_last_key_bytes())
+            assert_csc_equal(hip_arrays(A), want, "elements host %d-D %d nodes %d" % (dim, npd, node_mode))
+            # device arrays made by esp_generate_fem_mesh: bit for bit the oracle's mesh
+            B = esp.ExtendableSparseMatrix(nn, nn)
+            dcn = torch.empty((nc, nloc), dtype=torch.int64, device="cuda")
+            dem = torch.empty((nc, nloc, nloc), dtype=torch.float64, device="cuda")
+            ddg = torch.empty((nc, nloc), dtype=torch.float64, device="cuda")
+            B.generate_fem_mesh(dim, npd, dcn, dem, ddg, seed=0x5EED0004, order_mode=1, node_mode=node_mode)
+            B.synchronize()
+            assert np.array_equal(dcn.cpu().numpy().T, cn)
+            assert np.array_equal(bits(dem.cpu().numpy().transpose(2, 1, 0)), bits(em))
+            assert np.array_equal(bits(ddg.cpu().numpy().T), bits(dg))
+            B.append_elements(dcn, dem, ddg)
+            B.flush()
+            assert B.debug_last_partition() == 4
+            assert_csc_equal(hip_arrays(B), want, "elements device")
+            # packed keys, the item partition off (stream order through the flush's own passes)
+            for force, parts in ((14, (4,)), (25, (1, 2))):
+                Cc = esp.ExtendableSparseMatrix(nn, nn)
+                Cc.debug_force_path(force)
+                Cc.append_elements(dcn, dem, ddg)
+                Cc.flush()
+                assert Cc.debug_last_partition() in parts, (force, Cc.debug_last_partition())
+                assert_csc_equal(hip_arrays(Cc), want, "force %d" % force)
+            # re-assembly over the stored pattern (all hits), then twice in a row (the second call goes behind the batch)
+            A.append_elements(dcn, dem, ddg)
+            A.flush()
+            O.apply(np.full(len(I), RAW, np.uint8), I, J, V)
+            O.flush()
+            assert_csc_equal(hip_arrays(A), O.arrays(), "re-assembly")
+            A.reset()
+            O.reset()
+            A.append_elements(dcn, dem, ddg)
+            A.append_elements(cn, em, None, op="-")
+            A.flush()
+            I2, J2, V2 = orc.elements_stream(cn, em, None)
+            O.apply(np.full(len(I), RAW, np.uint8), I, J, V)
+            O.apply(np.full(len(I2), RAW, np.uint8), I2, J2, -V2)
+            O.flush()
+            assert_csc_equal(hip_arrays(A), O.arrays(), "twice, the second without diag and with -")
+        # updateindex! with zeros (absent & zero -> no entry), no diagonal term
+        em0 = em.copy(order="F")
+        em0[rng.random(em0.shape) < 0.3] = 0.0
+        I, J, V = orc.elements_stream(cn, em0, None)
+        O = orc.ExtendableSparseMatrix(nn, nn)
+        O.apply(np.full(len(I), UPDATE, np.uint8), I, J, V)
+        A = esp.ExtendableSparseMatrix(nn, nn)
+        A.append_elements(cn, em0, None, kind=UPDATE)
+        A.flush()
+        assert A.debug_last_partition() == 4
+        assert_csc_equal(hip_arrays(A), O.arrays(), "UPDATE with zeros")
+        # behind other appends (non-empty buffer: stream order), and a cell that names a node twice
+        cnt = 3000
+        Ia, Ja, Va = rng.integers(1, nn + 1, cnt), rng.integers(1, nn + 1, cnt), rng.standard_normal(cnt)
+        ka = rng.choice(np.array([0, 1, 2], np.uint8), cnt)
+        cnd = cn.copy(order="F")
+        for c in rng.integers(0, nc, 5):
+            cnd[1, c] = cnd[0, c]
+        I, J, V = orc.elements_stream(cnd, em, dg)
+        for first in (True, False):
+            O = orc.ExtendableSparseMatrix(nn, nn)
+            A = esp.ExtendableSparseMatrix(nn, nn)
+            if first:
+                O.apply(ka, Ia, Ja, Va)
+                A.append(0, Ia, Ja, Va, kinds=ka)
+            O.apply(np.full(len(I), RAW, np.uint8), I, J, V)
+            A.append_elements(cnd, em, dg)
+            A.flush()
+            assert A.debug_last_partition() in (1, 2)
+            assert_csc_equal(hip_arrays(A), O.arrays(), "repeated node, behind appends: %s" % first)
+        # BoundsError: nothing is appended
+        cnb = cn.copy(order="F")
+        cnb[nloc - 1, nc // 2] = nn + 1
+        A = esp.ExtendableSparseMatrix(nn, nn)
+        with pytest.raises(esp.BoundsError):
+            A.append_elements(cnb, em, dg)
+        assert A.nnznew() == 0
+        A.append(RAW, Ia, Ja, Va)
+        with pytest.raises(esp.BoundsError):
+            A.append_elements(cnb, em, dg)
+        assert A.nnznew() == cnt
+
+
+@pytest.mark.parametrize("nloc", [1, 2, 6, 10, 16])
+def test_append_elements_any_nloc(esp, orc, nloc):
+    """Cells of 1 .. 16 nodes (P2 triangles: 6, P2 tetrahedra: 10): random cells of distinct nodes out of a neighbourhood,
+    random element matrices, with and without the diagonal term, rectangular matrices too."""
+    rng = np.random.default_rng(100 + nloc)
+    for (m, n, nc) in ((40000, 40000, 30000), (50000, 30011, 20000)):
+        lim = min(m, n)
+        start = rng.integers(0, lim - 64, nc)
+        cn = np.empty((nloc, nc), np.int64, order="F")
+        for c in range(nc):
+            cn[:, c] = 1 + start[c] + rng.choice(64, nloc, replace=False)
+        em = np.asfortranarray(rng.standard_normal((nloc, nloc, nc)))
+        dg = np.asfortranarray(rng.standard_normal((nloc, nc)))
+        for diag in (dg, None):
+            I, J, V = orc.elements_stream(cn, em, diag)
+            O = orc.ExtendableSparseMatrix(m, n)
+            O.apply(np.full(len(I), RAW, np.uint8), I, J, V)
+            A = esp.ExtendableSparseMatrix(m, n)
+            A.append_elements(cn, em, diag)
+            A.flush()
+            if nloc > 1 or diag is not None:
+                assert A.debug_last_partition() == 4, (nloc, A.debug_last_partition())
+            assert_csc_equal(hip_arrays(A), O.arrays(), "nloc %d %dx%d" % (nloc, m, n))
+
+
 def test_general_path_fdrand_and_plus_mode(esp, orc):
     A = esp.ExtendableSparseMatrix(20 ** 3, 20 ** 3)
     A.debug_force_path(2)

@@ -407,6 +407,46 @@ def test_fem_stream_properties(orc, dim, npd):
         assert len(set(nodes.tolist())) == dim + 1
 
 
+def test_elements_stream_is_the_fem_loop(orc):
+    """orc_elements_stream restates the loops of test/femtools.jl:61-69 over arrays (cellnodes, elmat = vol * S, diag):
+    fed the mesh arrays of the Kuhn grid it must give the very stream orc_fem_stream emits (same calls, same order, same
+    bits); an independent NumPy restatement of the loop nest agrees for arbitrary arrays; a permuted node numbering is a
+    relabelling of rows and columns."""
+    for dim, npd in ((2, 9), (3, 5)):
+        cn, em, dg = orc.fem_mesh(dim, npd, seed=0x5EED0004, order_mode=1)
+        I, J, V = orc.elements_stream(cn, em, dg)
+        I0, J0, V0 = orc.fem_stream(dim, npd, seed=0x5EED0004, order_mode=1)
+        assert np.array_equal(I, I0) and np.array_equal(J, J0) and np.array_equal(V.view(np.uint64), V0.view(np.uint64))
+        # chunks of cells concatenate
+        nc = cn.shape[1]
+        ca, ea, da = orc.fem_mesh(dim, npd, p0=0, p1=nc // 3)
+        cb, eb, db = orc.fem_mesh(dim, npd, p0=nc // 3, p1=nc)
+        assert np.array_equal(np.concatenate([ca, cb], axis=1), cn) and np.array_equal(np.concatenate([ea, eb], axis=2), em)
+        # permuted numbering: a bijection of the nodes applied to the connectivity, element data unchanged
+        cp, ep, dp = orc.fem_mesh(dim, npd, node_mode=1)
+        nn = npd ** dim
+        perm = np.zeros(nn + 1, np.int64)
+        perm[cn.ravel(order="F")] = cp.ravel(order="F")
+        assert sorted(perm[1:].tolist()) == list(range(1, nn + 1)) and not np.array_equal(perm[1:], np.arange(1, nn + 1))
+        assert np.array_equal(perm[cn], cp) and np.array_equal(ep, em) and np.array_equal(dp, dg)
+    rng = np.random.default_rng(3)
+    for nloc, diag in ((1, True), (3, False), (5, True)):
+        nc = 17
+        cn = np.asfortranarray(rng.integers(1, 50, (nloc, nc)))
+        em = np.asfortranarray(rng.standard_normal((nloc, nloc, nc)))
+        dg = np.asfortranarray(rng.standard_normal((nloc, nc))) if diag else None
+        I, J, V = orc.elements_stream(cn, em, dg)
+        ref = []
+        for c in range(nc):               # femtools.jl:61-69
+            for il in range(nloc):
+                i = cn[il, c]
+                if diag:
+                    ref.append((i, i, dg[il, c]))
+                for jl in range(nloc):
+                    ref.append((i, cn[jl, c], em[il, jl, c]))
+        assert [(a, b, v) for a, b, v in zip(I.tolist(), J.tolist(), V.tolist())] == [(int(a), int(b), float(v)) for a, b, v in ref]
+
+
 def test_uniform_is_splitmix64(orc):
     def mix(z):
         M = (1 << 64) - 1
