@@ -479,6 +479,8 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
             # element-level call pays: a shuffled stream, the flush's own passes over 16-byte records)
             ttag = "cfg4_generic_triplets_%dd" % dim
             try:
+                if os.environ.get("ESP_BENCH_SKIP_TRIPLETS"):
+                    raise _Skip()
                 I = cn[:, :, None].expand(nc, nloc, W).reshape(-1).contiguous()
                 J = torch.cat([cn[:, :, None], cn[:, None, :].expand(nc, nloc, nloc)], dim=2).reshape(-1)
                 V = torch.cat([dg[:, :, None], em.transpose(1, 2)], dim=2).reshape(-1)
@@ -505,6 +507,8 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
                              "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS, "partition": A.debug_last_partition(),
                              "stage_ms": stages(tm, 1), "steps": len(dts), "digest_ok": okt}
                 del I, J, V
+            except _Skip:
+                pass
             except Exception as ex:
                 out[ttag] = {"error": repr(ex)}
             del A

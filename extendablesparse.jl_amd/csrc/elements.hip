@@ -8,10 +8,14 @@ template <bool K32>
 void launch_expand(const espelem::Args &a, hipStream_t stream) {
     const dim3 grid(grid_for(a.nitems, espelem::THREADS)), block(espelem::THREADS);
     const size_t lds = (size_t)espelem::THREADS * (size_t)a.W * (sizeof(double) + (K32 ? sizeof(u32) : sizeof(u64)));
-    if (a.nloc == 3)
+    if (a.nloc == 3 && a.cellrec)
         hipLaunchKernelGGL((espelem::elem_expand_k<K32, 3>), grid, block, lds, stream, a);
-    else if (a.nloc == 4)
+    else if (a.nloc == 4 && a.cellrec)
         hipLaunchKernelGGL((espelem::elem_expand_k<K32, 4>), grid, block, lds, stream, a);
+    else if (a.nloc == 3)
+        hipLaunchKernelGGL((espelem::elem_expand_k<K32, 3, false>), grid, block, lds, stream, a);
+    else if (a.nloc == 4)
+        hipLaunchKernelGGL((espelem::elem_expand_k<K32, 4, false>), grid, block, lds, stream, a);
     else
         hipLaunchKernelGGL((espelem::elem_expand_k<K32, 0>), grid, block, lds, stream, a);
 }
@@ -45,9 +49,19 @@ int32_t elements_by_items(esp_handle *h, espelem::Args a, i64 E, bool *took) {
     a.err = d_err;
     a.dup = d_dup;
     a.ikeys = (u64 *)h->keys2.p;
+    // cells of 3 or 4 nodes: a 64-byte record per cell (rows as u32, diag values) in the value half of the scratch pair,
+    // which the keys-only passes never touch (ESP_ELEM_NO_CELLREC: experiments)
+    const bool cellrec = (a.nloc == 3 || a.nloc == 4) && h->m <= ((i64)1 << 32) && (size_t)a.ncells * 64 <= h->vals2.bytes &&
+                         !(getenv("ESP_ELEM_NO_CELLREC") && *getenv("ESP_ELEM_NO_CELLREC"));
+    a.cellrec = cellrec ? (char *)h->vals2.p : nullptr;
     {
         Span sp(h, ESP_ST_APPEND);
-        hipLaunchKernelGGL(espelem::elem_items_k, dim3(grid_for(NI, espelem::THREADS)), dim3(espelem::THREADS), 0, h->stream, a);
+        if (cellrec && a.nloc == 3)
+            hipLaunchKernelGGL(espelem::elem_cells_k<3>, dim3(grid_for(a.ncells, espelem::THREADS)), dim3(espelem::THREADS), 0, h->stream, a);
+        else if (cellrec)
+            hipLaunchKernelGGL(espelem::elem_cells_k<4>, dim3(grid_for(a.ncells, espelem::THREADS)), dim3(espelem::THREADS), 0, h->stream, a);
+        else
+            hipLaunchKernelGGL(espelem::elem_items_k, dim3(grid_for(NI, espelem::THREADS)), dim3(espelem::THREADS), 0, h->stream, a);
         sp.add(1);
     }
     // the flush's partition over the items: a temporary view of the handle (sort_msd reads count, keys, keys2 and the

@@ -15,9 +15,11 @@
 //                    the node numbers (BoundsError) and that no cell names a node twice
 //   partition      : the flush's own stable passes (radix.hpp, keys only) over the records down to the bucket kernel's segments
 //   elem_expand_k  : sorted item g -> its W updates at entries [g W, (g+1) W) of the append buffer: the rows are the
-//                    cell's nodes (nloc * 8 B, gathered), the values column jl of the cell's element matrix (contiguous in
-//                    Julia's layout: nloc * 8 B, gathered) and diag[jl] -- all three addresses follow from the record
-//                    alone, one round trip -- staged through LDS, stored as whole lines, 4-byte keys when they fit
+//                    cell's nodes, the values column jl of the cell's element matrix (contiguous in Julia's layout:
+//                    nloc * 8 B) and diag[jl] -- gathered; every address follows from the record alone, one round trip --
+//                    staged through LDS, stored as whole lines, 4-byte keys when they fit.  The gathers are what the
+//                    kernel is bound by (a 64-byte memory-side request each, at random addresses), so for cells of 3 or 4
+//                    nodes the first kernel (elem_cells_k) leaves rows and diagonal terms of a cell in ONE 64-byte record
 // The buffer is a stable permutation of the stream whenever the nodes of a cell are distinct (inside a segment: items in
 // stream order, an item's updates in call order; two items of one cell never meet in a (row, column)), the segment table
 // follows from the items' (x W), and esp_flush starts at the bucket kernel (esp_handle::PrePart).  A cell that names a node
@@ -51,6 +53,7 @@ struct Args {
     u64 base;                 // key window base
     u64 *keys_out;            // (K32: u32 keys)
     double *vals_out;
+    char *cellrec;            // nloc 3 / 4: one 64-byte record per cell (rows as four u32 | the cell's diag values) -- see elem_cells_k
 };
 
 // item p = cell * nloc + jl: 32-bit arithmetic (the host keeps nitems below 2^32)
@@ -71,12 +74,69 @@ static __global__ __launch_bounds__(THREADS) void elem_items_k(Args a) {
     a.ikeys[p] = ((u64)(node - 1) << (a.vrb + ESP_TAG_BITS)) | (u64)p;
 }
 
+// The same for cells of 3 or 4 nodes (P1 in 2-D / 3-D), one thread per CELL, which also leaves a 64-byte CELL RECORD for
+// the expansion: the cell's rows as four u32 (0-based) | its diag values (four f64).  An item's expansion then fetches
+// its rows and its diagonal term with ONE memory-side request instead of two: the gathers of elem_expand_k are what it is
+// bound by (64-byte requests at random addresses: three per item cost 3.6 ms each at 3-D config-4 size), and the record
+// costs this kernel 32 B more to read and 64 B to write per cell, in stream order.
+template <int NLOC>
+static __global__ __launch_bounds__(THREADS) void elem_cells_k(Args a) {
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+    const i64 c = (i64)blockIdx.x * THREADS + threadIdx.x;
+    if (c >= a.ncells) return;
+    i64 nd[4] = {1, 1, 1, 1};
+    double dg[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < NLOC; k++) nd[k] = a.cellnodes[c * NLOC + k];
+    if (a.diag) {
+#pragma unroll
+        for (int k = 0; k < NLOC; k++) dg[k] = a.diag[c * NLOC + k];
+    }
+    bool bad = false, twice = false;
+#pragma unroll
+    for (int k = 0; k < NLOC; k++) {
+        if (nd[k] < 1 || nd[k] > a.lim) {
+            bad = true;
+            nd[k] = 1;
+        }
+#pragma unroll
+        for (int q = 0; q < k; q++) twice = twice || nd[q] == nd[k];
+    }
+    if (bad) atomicMin(a.err, (unsigned long long)c + 1ull);
+    if (twice && !bad) *a.dup = 1u;
+    const int sh = a.vrb + ESP_TAG_BITS;
+    const u64 p0 = (u64)c * NLOC;
+    u64 rec[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) rec[k] = ((u64)(nd[k] - 1) << sh) | (p0 + (u64)k);
+    if constexpr (NLOC == 4) {
+        ull2 *o = reinterpret_cast<ull2 *>(a.ikeys + p0);  // (32-byte aligned)
+        o[0] = ull2{rec[0], rec[1]};
+        o[1] = ull2{rec[2], rec[3]};
+    } else {
+#pragma unroll
+        for (int k = 0; k < NLOC; k++) a.ikeys[p0 + k] = rec[k];
+    }
+    char *cr = a.cellrec + c * 64;
+    *reinterpret_cast<u32x4 *>(cr) = u32x4{(u32)(nd[0] - 1), (u32)(nd[1] - 1), (u32)(nd[2] - 1), (u32)(nd[3] - 1)};
+    if (a.diag) {
+        *reinterpret_cast<dbl2 *>(cr + 16) = dbl2{dg[0], dg[1]};
+        *reinterpret_cast<dbl2 *>(cr + 32) = dbl2{dg[2], dg[3]};
+    }
+}
+
 // K32: 4-byte keys (the bits below the segment prefix; every entry has the batch's kind), else packed keys.
-// NLOC > 0: the nodes per cell as a compile-time constant (3, 4: P1 in 2-D / 3-D, rows and values in registers);
-// 0: any 1 .. MAX_NLOC.  Dynamic LDS: THREADS * W values, then THREADS * W keys.
-template <bool K32, int NLOC>
+// NLOC > 0: the nodes per cell as a compile-time constant (3, 4), rows and the diagonal term from the cell record
+// (elem_cells_k), the column of the element matrix from the caller's array; 0: any 1 .. MAX_NLOC, everything from the
+// caller's arrays.  Dynamic LDS: THREADS * W values, then THREADS * W keys.
+template <bool K32, int NLOC, bool CR = (NLOC > 0)>
 static __global__ __launch_bounds__(THREADS) void elem_expand_k(Args a) {
     typedef typename std::conditional<K32, u32, u64>::type KT;
+    typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     extern __shared__ double elem_lds[];
     const int t = threadIdx.x;
     const int nloc = NLOC ? NLOC : a.nloc;
@@ -88,23 +148,35 @@ static __global__ __launch_bounds__(THREADS) void elem_expand_k(Args a) {
         const u64 rec = a.sorted_keys[g];
         const int low = a.vrb + ESP_TAG_BITS;
         const u32 p = (u32)(rec & ((1ull << low) - 1ull));
-        const u64 col0 = rec >> low;
+        const u64 colpart = (rec >> low) << a.L.rb;
         const u32 cell = p / (u32)nloc, jl = p - cell * (u32)nloc;
-        const i64 *cn = a.cellnodes + (i64)cell * nloc;
         const double *em = a.elmat + (i64)p * nloc;  // column jl of the cell's element matrix
         const u64 lowmask = a.rem_bits >= 64 ? ~0ull : ((1ull << a.rem_bits) - 1ull);
-        const u64 colpart = col0 << a.L.rb;
         int at = t * W;
-        auto put = [&](i64 row, double v) {
+        auto put = [&](u64 row0, double v) {
             if (a.negate) v = -v;
             if constexpr (K32)
-                lk[at] = (u32)(((colpart | (u64)(row - 1)) - a.base) & lowmask);
+                lk[at] = (u32)(((colpart | row0) - a.base) & lowmask);
             else
-                lk[at] = ((colpart | (u64)(row - 1)) << ESP_TAG_BITS) | (u64)a.kind;
+                lk[at] = ((colpart | row0) << ESP_TAG_BITS) | (u64)a.kind;
             lv[at] = v;
             at++;
         };
-        if constexpr (NLOC > 0) {
+        if constexpr (NLOC > 0 && CR) {
+            const char *cr = a.cellrec + (i64)cell * 64;
+            const u32x4 rr = *reinterpret_cast<const u32x4 *>(cr);
+            const double d = a.diag ? *reinterpret_cast<const double *>(cr + 16 + 8 * jl) : 0.0;
+            const u32 r[4] = {rr.x, rr.y, rr.z, rr.w};
+            double v[NLOC];
+#pragma unroll
+            for (int il = 0; il < NLOC; il++) v[il] = em[il];
+#pragma unroll
+            for (int il = 0; il < NLOC; il++) {
+                if (a.diag && (u32)il == jl) put((u64)r[il], d);  // (the diagonal's term comes right before the diagonal: femtools.jl:64)
+                put((u64)r[il], v[il]);
+            }
+        } else if constexpr (NLOC > 0) {  // (no cell records: more than 2^32 rows, or the test hook)
+            const i64 *cn = a.cellnodes + (i64)cell * NLOC;
             i64 r[NLOC];
             double v[NLOC];
 #pragma unroll
@@ -114,14 +186,15 @@ static __global__ __launch_bounds__(THREADS) void elem_expand_k(Args a) {
             const double d = a.diag ? a.diag[p] : 0.0;
 #pragma unroll
             for (int il = 0; il < NLOC; il++) {
-                if (a.diag && (u32)il == jl) put(r[il], d);  // (the diagonal's term comes right before the diagonal: femtools.jl:64)
-                put(r[il], v[il]);
+                if (a.diag && (u32)il == jl) put((u64)(r[il] - 1), d);
+                put((u64)(r[il] - 1), v[il]);
             }
         } else {
+            const i64 *cn = a.cellnodes + (i64)cell * nloc;
             for (int il = 0; il < nloc; il++) {
-                const i64 row = cn[il];
-                if (a.diag && (u32)il == jl) put(row, a.diag[p]);
-                put(row, em[il]);
+                const u64 row0 = (u64)(cn[il] - 1);
+                if (a.diag && (u32)il == jl) put(row0, a.diag[p]);
+                put(row0, em[il]);
             }
         }
     }
@@ -129,20 +202,17 @@ static __global__ __launch_bounds__(THREADS) void elem_expand_k(Args a) {
     const int cnt = (int)min((i64)THREADS, a.nitems - g0) * W;
     // whole lines: g0 * W is a multiple of 256, every array starts 256-byte aligned
     double *gv = a.vals_out + g0 * W;
-    typedef double dbl2 __attribute__((ext_vector_type(2)));
     const int vpair = cnt >> 1;
     for (int q = t; q < vpair; q += THREADS) reinterpret_cast<dbl2 *>(gv)[q] = dbl2{lv[2 * q], lv[2 * q + 1]};
     if (t == 0 && (cnt & 1)) gv[cnt - 1] = lv[cnt - 1];
     if constexpr (K32) {
         u32 *gk = reinterpret_cast<u32 *>(a.keys_out) + g0 * W;
-        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
         const int kquad = cnt >> 2;
         for (int q = t; q < kquad; q += THREADS)
             reinterpret_cast<u32x4 *>(gk)[q] = u32x4{lk[4 * q], lk[4 * q + 1], lk[4 * q + 2], lk[4 * q + 3]};
         for (int q = 4 * kquad + t; q < cnt; q += THREADS) gk[q] = lk[q];
     } else {
         u64 *gk = a.keys_out + g0 * W;
-        typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
         for (int q = t; q < vpair; q += THREADS) reinterpret_cast<ull2 *>(gk)[q] = ull2{lk[2 * q], lk[2 * q + 1]};
         if (t == 0 && (cnt & 1)) gk[cnt - 1] = lk[cnt - 1];
     }

@@ -842,7 +842,7 @@ def test_item_producer_shuffled_fem(esp, orc):
         assert_csc_equal(hip_arrays(A), O.arrays(), "twice")
 
 
-def test_append_elements(esp, orc):
+def test_append_elements(esp, orc, monkeypatch):
     """esp_append_elements[_host]: the loops of test/femtools.jl:61-69 for element data held in arrays, against the oracle
     fed the same calls one by one.  On an empty buffer the library partitions (cell, local column) items and the flush starts
     at the bucket kernel (esp_debug_last_partition 4); meshes with natural AND permuted node numbering (nothing may lean on
@@ -884,11 +884,16 @@ def test_append_elements(esp, orc):
             B.flush()
             assert B.debug_last_partition() == 4
             assert_csc_equal(hip_arrays(B), want, "elements device")
-            # packed keys, the item partition off (stream order through the flush's own passes)
-            for force, parts in ((14, (4,)), (25, (1, 2))):
+            # packed keys, the item partition off (stream order through the flush's own passes), and without the cell
+            # records (the expansion gathers from the caller's arrays, as it does for other cell sizes)
+            for force, parts in ((14, (4,)), (25, (1, 2)), (-1, (4,))):
                 Cc = esp.ExtendableSparseMatrix(nn, nn)
-                Cc.debug_force_path(force)
+                if force >= 0:
+                    Cc.debug_force_path(force)
+                else:
+                    monkeypatch.setenv("ESP_ELEM_NO_CELLREC", "1")
                 Cc.append_elements(dcn, dem, ddg)
+                monkeypatch.delenv("ESP_ELEM_NO_CELLREC", raising=False)
                 Cc.flush()
                 assert Cc.debug_last_partition() in parts, (force, Cc.debug_last_partition())
                 assert_csc_equal(hip_arrays(Cc), want, "force %d" % force)
