@@ -136,9 +136,11 @@ def baseline_metric():
 
 # ---------------------------------------------------------------------------------------- launcher
 def gpu_count_without_hip():
-    """GPUs of this node from the KFD topology in sysfs (nodes with SIMDs), so that the launcher never brings up a HIP
-    runtime of its own; None when /sys/class/kfd is not there (then torch counts, which may initialise HIP -- harmless
-    here: the launcher only spawns fresh children and never re-executes itself)."""
+    """GPUs of this node as the rank processes will see them: the KFD topology in sysfs (nodes with SIMDs), clamped by
+    the *_VISIBLE_DEVICES lists a child process inherits (HIP_VISIBLE_DEVICES, ROCR_VISIBLE_DEVICES, CUDA_VISIBLE_DEVICES:
+    comma-separated indices or UUIDs -- their length is what counts) -- so that the launcher never brings up a HIP runtime
+    of its own.  None when /sys/class/kfd is not there (then torch counts, which may initialise HIP -- harmless here: the
+    launcher only spawns fresh children and never re-executes itself)."""
     base = "/sys/class/kfd/kfd/topology/nodes"
     try:
         n = 0
@@ -146,9 +148,13 @@ def gpu_count_without_hip():
             with open(os.path.join(base, node, "properties")) as f:
                 props = dict(line.split() for line in f if len(line.split()) == 2)
             n += int(props.get("simd_count", "0")) > 0
-        return n
     except Exception:
         return None
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            n = min(n, len([x for x in v.split(",") if x.strip()]))
+    return n
 
 
 def launch(args, argv):

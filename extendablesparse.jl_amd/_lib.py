@@ -72,6 +72,8 @@ SIGNATURES = {
     "esp_nnz": (i32, [vp, P(i64)]),
     "esp_get_csc": (i32, [vp, vp, vp, vp]),
     "esp_get_nzval": (i32, [vp, vp]),
+    "esp_set_nzval": (i32, [vp, vp]),
+    "esp_flush_sum": (i32, [vp, vp, i32, P(i64), P(i32)]),
     "esp_csc_device": (i32, [vp, P(vp), P(vp), P(vp)]),
     "esp_reset": (i32, [vp]),
     "esp_clear_pending": (i32, [vp]),

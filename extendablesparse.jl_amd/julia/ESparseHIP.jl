@@ -34,10 +34,15 @@ mutable struct SparseMatrixHIPCOO{Tv, Ti <: Integer} <: AbstractSparseMatrixExte
     kinds::Vector{UInt8}
     nstaged::Int
     released::Bool           # consumed by a flush! (plus_consume!): any further use is an error, not a silent empty buffer
+    # the host matrix whose PATTERN the handle's device CSC holds (the colptr / rowval vectors the last download handed out):
+    # while ext.cscmatrix still carries these very vectors only nzval travels (esp_set_nzval / esp_get_nzval)
+    mirror_colptr::Vector{Int64}
+    mirror_rowval::Vector{Int64}
 end
+check_live(x) = x.released && error("SparseMatrixHIPCOO: the buffer was consumed by an earlier flush!")
 
 function wrap_handle(m, n, h::Ptr{Cvoid})
-    x = SparseMatrixHIPCOO{Float64, Int64}(m, n, h, Int64[], Int64[], Float64[], UInt8[], 0, false)
+    x = SparseMatrixHIPCOO{Float64, Int64}(m, n, h, Int64[], Int64[], Float64[], UInt8[], 0, false, Int64[], Int64[])
     finalizer(y -> (y.handle == C_NULL || ccall((:esp_destroy, libesparse), Int32, (Ptr{Cvoid},), y.handle); y.handle = C_NULL), x)
 end
 
@@ -63,6 +68,7 @@ function stage!(x::SparseMatrixHIPCOO)
 end
 
 function commit!(x::SparseMatrixHIPCOO)
+    check_live(x)
     x.nstaged == 0 && return x
     n, x.nstaged = x.nstaged, 0
     esp_check(x.handle, ccall((:esp_commit, libesparse), Int32, (Ptr{Cvoid}, Int64, Int32, Int32), x.handle, n, -1, 0))
@@ -70,6 +76,7 @@ function commit!(x::SparseMatrixHIPCOO)
 end
 
 @inline function push_entry!(x::SparseMatrixHIPCOO, kind, v, i, j)
+    check_live(x)
     (1 <= i <= x.m) & (1 <= j <= x.n) || throw(BoundsError(x, (i, j)))
     isempty(x.rows) && stage!(x)
     k = (x.nstaged += 1)
@@ -88,6 +95,7 @@ end
 
 # nnz(ext) > 0 iff anything is pending: the flush! gate of genericextendablesparsematrixcsc.jl:32
 function SparseArrays.nnz(x::SparseMatrixHIPCOO)
+    check_live(x)
     c = Ref{Int64}(0)
     esp_check(x.handle, ccall((:esp_pending, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}), x.handle, c))
     c[] + x.nstaged
@@ -98,6 +106,21 @@ updateindex!(x::SparseMatrixHIPCOO, ::typeof(+), v, i, j) = push_entry!(x, ESP_U
 updateindex!(x::SparseMatrixHIPCOO, ::typeof(-), v, i, j) = push_entry!(x, ESP_UPDATE, -Float64(v), i, j)
 rawupdateindex!(x::SparseMatrixHIPCOO, ::typeof(+), v, i, j, tid = 1) = push_entry!(x, ESP_RAWUPDATE, Float64(v), i, j)
 rawupdateindex!(x::SparseMatrixHIPCOO, ::typeof(-), v, i, j, tid = 1) = push_entry!(x, ESP_RAWUPDATE, -Float64(v), i, j)
+
+# The assembly loop of test/femtools.jl:61-69 as ONE call: for every cell and local row il the optional diag[il, icell]
+# on (i, i), then elmat[il, jl, icell] on (i, cellnodes[jl, icell]) for every jl -- bit for bit the per-entry
+# rawupdateindex!(A, +, ...) calls in that order.  cellnodes = grid[CellNodes] (nloc x ncells), elmat[:, :, icell] =
+# vol * S of femtools.jl:67, diag[il, icell] = the mass term of femtools.jl:64 (or `nothing`).
+function assemble_elements!(x::SparseMatrixHIPCOO{Float64, Int64}, cellnodes::Matrix{Int64}, elmat::Array{Float64, 3},
+                            diag::Union{Matrix{Float64}, Nothing} = nothing; kind = ESP_RAWUPDATE)
+    commit!(x)
+    nloc, ncells = size(cellnodes)
+    @assert size(elmat) == (nloc, nloc, ncells) && (diag === nothing || size(diag) == (nloc, ncells))
+    esp_check(x.handle, ccall((:esp_append_elements_host, libesparse), Int32,
+                              (Ptr{Cvoid}, Int32, Int64, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Int32, Int32),
+                              x.handle, nloc, ncells, cellnodes, elmat, diag === nothing ? C_NULL : diag, kind, 0))
+    x
+end
 
 # getindex(buffer,i,j) (sparsematrixlnk.jl:151-171; reached from genericextendablesparsematrixcsc.jl:57-66 for
 # positions not yet in the CSC): the ordered fold of the pending calls at (i,j), on the device.  Slow path by design.
@@ -124,51 +147,113 @@ Uploads `csc`, runs the HIP pipeline, downloads into Julia-owned vectors.  Like 
 and `Base.sum` consume their buffers instead (`plus_consume!`).
 """
 function Base.:+(x::SparseMatrixHIPCOO{Float64, Int64}, csc::SparseMatrixCSC{Float64, Int64})
+    check_live(x)
     y = copy(x)                      # esp_clone: the pending entries, device-to-device; x itself is left alone
     out = plus_consume!(y, csc)
     out
 end
 
-# csc + buffer where the buffer is consumed: its pending entries are folded into the result and its device memory is
-# released at once (not at some later GC, which does not see device memory).  What flush! of the Generic wrappers needs:
-# they drop the buffer right after `+` (genericextendablesparsematrixcsc.jl:31-37), see the flush! methods below.
-function plus_consume!(x::SparseMatrixHIPCOO{Float64, Int64}, csc::SparseMatrixCSC{Float64, Int64})
+# The device CSC of handle h := csc.  Values only (8 instead of 24 bytes per entry) when h still holds csc's pattern: the
+# Generic wrappers edit cscmatrix.nzval in place on the host (genericextendablesparsematrixcsc.jl:44-54, and users write
+# nonzeros(A) .= 0: test_parallel.jl:71-92), which nobody can see from outside -- so the values always travel.
+function upload_csc!(x::SparseMatrixHIPCOO, csc::SparseMatrixCSC{Float64, Int64})
+    h = x.handle
+    z = Ref{Int64}(0)
+    esp_check(h, ccall((:esp_nnz, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}), h, z))
+    if csc.colptr === x.mirror_colptr && csc.rowval === x.mirror_rowval && z[] == nnz(csc)
+        esp_check(h, ccall((:esp_set_nzval, libesparse), Int32, (Ptr{Cvoid}, Ptr{Float64}), h, csc.nzval))
+    else
+        esp_check(h, ccall((:esp_set_csc, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int64),
+                           h, csc.colptr, csc.rowval, csc.nzval, nnz(csc)))
+    end
+    x
+end
+# ... and back: a flush that added no position returns csc's own pattern vectors with fresh values (esp_get_nzval)
+function download_csc!(x::SparseMatrixHIPCOO, csc::SparseMatrixCSC{Float64, Int64}, z::Int64, changed::Bool)
+    h = x.handle
+    if !changed && z == nnz(csc)
+        nzval = Vector{Float64}(undef, z)
+        esp_check(h, ccall((:esp_get_nzval, libesparse), Int32, (Ptr{Cvoid}, Ptr{Float64}), h, nzval))
+        out = SparseMatrixCSC{Float64, Int64}(x.m, x.n, csc.colptr, csc.rowval, nzval)
+    else
+        colptr, rowval, nzval = Vector{Int64}(undef, x.n + 1), Vector{Int64}(undef, z), Vector{Float64}(undef, z)
+        esp_check(h, ccall((:esp_get_csc, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}), h, colptr, rowval, nzval))
+        out = SparseMatrixCSC{Float64, Int64}(x.m, x.n, colptr, rowval, nzval)
+    end
+    x.mirror_colptr, x.mirror_rowval = out.colptr, out.rowval
+    out
+end
+
+# csc + buffer where the buffer is consumed: its pending entries are folded into the result.  What flush! of the Generic
+# wrappers needs: they drop the buffer right after `+` (genericextendablesparsematrixcsc.jl:31-37), see the flush! methods
+# below.  keep = true: the handle (device CSC + scratch) lives on in the wrapper's NEXT buffer (adopt!); else its device
+# memory is released at once (not at some later GC, which does not see device memory).
+function plus_consume!(x::SparseMatrixHIPCOO{Float64, Int64}, csc::SparseMatrixCSC{Float64, Int64}; keep = false)
     @assert size(csc) == size(x)
-    x.released && error("SparseMatrixHIPCOO: the buffer was consumed by an earlier flush!")
     commit!(x)
     h = x.handle
-    esp_check(h, ccall((:esp_set_csc, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}, Int64),
-                       h, csc.colptr, csc.rowval, csc.nzval, nnz(csc)))
+    upload_csc!(x, csc)
     z, changed = Ref{Int64}(0), Ref{Int32}(0)
     esp_check(h, ccall((:esp_flush, libesparse), Int32, (Ptr{Cvoid}, Int32, Ptr{Int64}, Ptr{Int32}), h, ESP_FLUSH_PLUS, z, changed))
-    colptr = Vector{Int64}(undef, x.n + 1)
-    rowval = Vector{Int64}(undef, z[])
-    nzval = Vector{Float64}(undef, z[])
-    esp_check(h, ccall((:esp_get_csc, libesparse), Int32, (Ptr{Cvoid}, Ptr{Int64}, Ptr{Int64}, Ptr{Float64}), h, colptr, rowval, nzval))
-    release!(x)                      # pending buffers, scratch, the device copy of the CSC: gone now
-    x.released = true
-    SparseMatrixCSC{Float64, Int64}(x.m, x.n, colptr, rowval, nzval)
+    out = download_csc!(x, csc, z[], changed[] != 0)
+    if !keep
+        release!(x)                  # pending buffers, scratch, the device copy of the CSC: gone now
+        x.released = true
+    end
+    out
+end
+
+# the wrapper's next buffer takes over the handle of the one it drops: the device CSC (and every scratch buffer) stays
+# where it is between flushes; the old struct is left without a handle (its finalizer has nothing to do)
+function adopt!(old::SparseMatrixHIPCOO{Float64, Int64})
+    new = SparseMatrixHIPCOO{Float64, Int64}(old.m, old.n, old.handle, old.rows, old.cols, old.vals, old.kinds, 0, false,
+                                             old.mirror_colptr, old.mirror_rowval)
+    old.handle, old.released = C_NULL, true
+    old.rows, old.cols, old.vals, old.kinds = Int64[], Int64[], Float64[], UInt8[]
+    finalizer(y -> (y.handle == C_NULL || ccall((:esp_destroy, libesparse), Int32, (Ptr{Cvoid},), y.handle); y.handle = C_NULL), new)
 end
 
 # flush! of the Generic wrappers with a HIP buffer: the reference's `ext.cscmatrix = ext.xmatrix + ext.cscmatrix;
-# ext.xmatrix = Tm(m, n)` (genericextendablesparsematrixcsc.jl:31-37) with the buffer consumed instead of copied
+# ext.xmatrix = Tm(m, n)` (genericextendablesparsematrixcsc.jl:31-37) with the buffer consumed instead of copied and the
+# device CSC kept attached: per flush! the values go up, and the values (no new position) or the matrix come back
 function flush!(ext::GenericExtendableSparseMatrixCSC{SparseMatrixHIPCOO{Float64, Int64}, Float64, Int64})
     if nnz(ext.xmatrix) > 0
-        ext.cscmatrix = plus_consume!(ext.xmatrix, ext.cscmatrix)
-        ext.xmatrix = SparseMatrixHIPCOO{Float64, Int64}(size(ext.cscmatrix)...)
+        ext.cscmatrix = plus_consume!(ext.xmatrix, ext.cscmatrix; keep = true)
+        ext.xmatrix = adopt!(ext.xmatrix)
     end
     ext
 end
 Base.:+(csc::SparseMatrixCSC, x::SparseMatrixHIPCOO) = x + csc
 
-# Base.sum(extmatrices, csc) of the plugin contract (abstractsparsematrixextension.jl:11):
-# csc + x1 + x2 + ... left to right, like sparsematrixdilnkc.jl:397-435.  Called by flush! of the MT wrapper
-# (genericmtextendablesparsematrixcsc.jl:45-51), which replaces every buffer right afterwards: the buffers are consumed.
-function Base.sum(xs::Vector{SparseMatrixHIPCOO{Tv, Ti}}, csc::SparseMatrixCSC{Tv, Ti}) where {Tv, Ti}
-    for x in xs
-        nnz(x) > 0 && (csc = plus_consume!(x, csc))
-    end
-    csc
+# Base.sum(extmatrices, csc) of the plugin contract (abstractsparsematrixextension.jl:11): sparse!(I, J, V, m, n, +) over
+# (csc entries, x1's, x2's, ...), i.e. ((csc + x1) + x2) + ... left to right (sparsematrixdilnkc.jl:397-435), as ONE
+# device call: every buffer folds by itself, the folds meet the stored matrix in one flush (esp_flush_sum) -- the CSC
+# travels once whatever np is (test_parallel.jl:41,74: 10, 15, 20).  home: the handle that keeps the CSC; the buffers
+# come back EMPTY (flush! of the MT wrapper replaces them all right afterwards, genericmtextendablesparsematrixcsc.jl:47-49).
+function sum_into!(home::SparseMatrixHIPCOO{Float64, Int64}, xs::Vector{SparseMatrixHIPCOO{Float64, Int64}}, csc::SparseMatrixCSC{Float64, Int64})
+    foreach(commit!, xs)
+    sum(nnz, xs) == 0 && return csc
+    upload_csc!(home, csc)
+    handles = Ptr{Cvoid}[x.handle for x in xs]
+    z, changed = Ref{Int64}(0), Ref{Int32}(0)
+    esp_check(home.handle, ccall((:esp_flush_sum, libesparse), Int32, (Ptr{Cvoid}, Ptr{Ptr{Cvoid}}, Int32, Ptr{Int64}, Ptr{Int32}),
+                                 home.handle, handles, length(xs), z, changed))
+    download_csc!(home, csc, z[], changed[] != 0)
+end
+function Base.sum(xs::Vector{SparseMatrixHIPCOO{Float64, Int64}}, csc::SparseMatrixCSC{Float64, Int64})
+    home = SparseMatrixHIPCOO{Float64, Int64}(size(csc)...)
+    out = sum_into!(home, xs, csc)
+    release!(home)                   # (a one-off destination: its device memory goes now, not at some later GC)
+    home.released = true
+    out
+end
+# flush! of the MT wrapper with HIP buffers (genericmtextendablesparsematrixcsc.jl:45-51): the destination handle lives
+# as long as the wrapper does (one per wrapper, found through its buffer vector's first element ... kept in a WeakKeyDict)
+const HOME_OF = WeakKeyDict{Any, SparseMatrixHIPCOO{Float64, Int64}}()
+function flush!(ext::GenericMTExtendableSparseMatrixCSC{SparseMatrixHIPCOO{Float64, Int64}, Float64, Int64})
+    home = get!(() -> SparseMatrixHIPCOO{Float64, Int64}(size(ext.cscmatrix)...), HOME_OF, ext)
+    ext.cscmatrix = sum_into!(home, ext.xmatrices, ext.cscmatrix)
+    ext                              # (the buffers are empty T_ext(m, n) again: they are kept)
 end
 
 # aliases in the style of src/ExtendableSparse.jl:34-39
@@ -190,6 +275,8 @@ HIPResidentSparseMatrixCSC{Float64, Int64}(m, n; kwargs...) =
 Base.size(A::HIPResidentSparseMatrixCSC) = size(A.buf)
 touch!(A::HIPResidentSparseMatrixCSC) = (A.cscmatrix = nothing; A)
 Base.setindex!(A::HIPResidentSparseMatrixCSC, v, i::Integer, j::Integer) = (setindex!(A.buf, v, i, j); touch!(A))
+assemble_elements!(A::HIPResidentSparseMatrixCSC, cellnodes, elmat, diag = nothing; kwargs...) =
+    (assemble_elements!(A.buf, cellnodes, elmat, diag; kwargs...); touch!(A))
 updateindex!(A::HIPResidentSparseMatrixCSC, op, v, i, j) = (updateindex!(A.buf, op, v, i, j); touch!(A))
 rawupdateindex!(A::HIPResidentSparseMatrixCSC, op, v, i, j, part = 1) = (rawupdateindex!(A.buf, op, v, i, j); touch!(A))
 

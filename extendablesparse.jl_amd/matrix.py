@@ -250,6 +250,29 @@ class _Handle:
         return d
 
 
+def _upload_csc(d, mirror, csc):
+    """Bring the device CSC of handle `d` to `csc`.  `mirror` = the (colptr, rowval) array objects of the host matrix the
+    device CSC equals in pattern (what the last download handed out): when `csc` still carries those very arrays only the
+    values travel (esp_set_nzval: 8 instead of 24 bytes per entry) -- the Generic wrappers edit cscmatrix.nzval in place
+    (genericextendablesparsematrixcsc.jl:44-54), which nobody can see from outside, so the values always do."""
+    if mirror is not None and mirror[0] is csc.colptr and mirror[1] is csc.rowval and d.nnz() == csc.nnz():
+        d.ck(d.lib.esp_set_nzval(d.h, _vp(np.ascontiguousarray(csc.nzval, np.float64))))
+    else:
+        d.set_csc(csc)
+
+
+def _download_csc(d, csc, changed):
+    """The device CSC of `d` as a host SparseMatrixCSC; the pattern arrays of `csc` are shared when the flush kept the
+    pattern (esp_get_nzval: values only).  Returns (matrix, mirror)."""
+    if not changed and d.nnz() == csc.nnz():
+        nz = np.empty(csc.nnz(), np.float64)
+        d.ck(d.lib.esp_get_nzval(d.h, _vp(nz)))
+        out = SparseMatrixCSC(d.m, d.n, csc.colptr, csc.rowval, nz)
+    else:
+        out = d.get_csc()
+    return out, (out.colptr, out.rowval)
+
+
 class SparseMatrixHIPCOO:
     """Device-resident COO append buffer: the `T_ext` of the reference's plugin contract
     (abstractsparsematrixextension.jl:6-14), replacing SparseMatrixLNK (sparsematrixlnk.jl)."""
@@ -257,6 +280,8 @@ class SparseMatrixHIPCOO:
     def __init__(self, m, n, device=0, capacity_hint=0):
         self._d = _Handle(m, n, device, capacity_hint)
         self.m, self.n = int(m), int(n)
+        self._device = device
+        self._mirror = None   # (colptr, rowval) of the host matrix whose pattern the handle's device CSC holds
 
     def size(self):
         return (self.m, self.n)
@@ -300,24 +325,38 @@ class SparseMatrixHIPCOO:
         self._d.append(kind, I, J, V, _op(op), kinds)
 
     def __add__(self, csc):
-        """Base.:+(ext, csc) -> SparseMatrixCSC (sparsematrixlnk.jl:294-383): THE flush."""
+        """Base.:+(ext, csc) -> SparseMatrixCSC (sparsematrixlnk.jl:294-383): THE flush.  The handle keeps the result on
+        the device: the next `+` with the matrix this one returned uploads values only, and a flush that adds no new
+        position downloads values only."""
         if (csc.m, csc.n) != (self.m, self.n):
             raise AssertionError("size mismatch")
-        self._d.set_csc(csc)
-        self._d.flush(ESP_FLUSH_PLUS)
-        return self._d.get_csc()
+        self._d.commit()
+        _upload_csc(self._d, self._mirror, csc)
+        _, changed = self._d.flush(ESP_FLUSH_PLUS)
+        out, self._mirror = _download_csc(self._d, csc, changed)
+        return out
 
     __radd__ = __add__
 
     @staticmethod
-    def sum(xs, csc):
-        """Base.sum(extmatrices, csc) (sparsematrixdilnkc.jl:397-435): csc + x1 + x2 + ... left to right."""
-        if sum(x.nnz() for x in xs) == 0:
-            return csc
-        out = csc
+    def sum(xs, csc, home=None):
+        """Base.sum(extmatrices, csc) (sparsematrixdilnkc.jl:397-435): ((csc + x1) + x2) + ... left to right, as ONE device
+        call (esp_flush_sum): every buffer folds by itself, the folds meet the stored matrix in one flush, the CSC
+        travels once -- values only when `home` (a SparseMatrixHIPCOO kept by the caller between flushes) still holds
+        its pattern.  The buffers come back empty."""
         for x in xs:
-            if x.nnz() > 0:
-                out = x + out
+            x._d.commit()
+        if sum(x._d.pending() for x in xs) == 0:
+            return csc
+        dst = home if home is not None else SparseMatrixHIPCOO(csc.m, csc.n, device=xs[0]._device)
+        d = dst._d
+        _upload_csc(d, dst._mirror, csc)
+        arr = (C.c_void_p * len(xs))(*[x._d.h for x in xs])
+        z, ch = C.c_int64(), C.c_int32()
+        d.ck(d.lib.esp_flush_sum(d.h, arr, len(xs), C.byref(z), C.byref(ch)))
+        out, dst._mirror = _download_csc(d, csc, bool(ch.value))
+        if home is None:
+            d.close()
         return out
 
 
@@ -730,6 +769,7 @@ class GenericMTExtendableSparseMatrixCSC:
         m, n = self.cscmatrix.shape
         p = len(self.xmatrices) if p is None else p
         self.cscmatrix = SparseMatrixCSC(m, n)
+        self._home = None
         self.xmatrices = [self.Tm(m, n, **self._kw) for _ in range(p)]
         self.colparts = np.array([1, 2], np.int64)
         self.partnodes = np.array([1, n + 1], np.int64)
@@ -739,8 +779,15 @@ class GenericMTExtendableSparseMatrixCSC:
         return sum(x.nnz() for x in self.xmatrices)
 
     def flush(self):  # :45-51
-        self.cscmatrix = self.Tm.sum(self.xmatrices, self.cscmatrix)
         m, n = self.cscmatrix.shape
+        if self.Tm is SparseMatrixHIPCOO:
+            # (the device CSC stays attached to a handle of the wrapper's between flushes; esp_flush_sum hands the buffers
+            # back empty -- they ARE fresh T_ext(m,n) again, their device memory serves the next assembly)
+            if getattr(self, "_home", None) is None:
+                self._home = SparseMatrixHIPCOO(m, n, **self._kw)
+            self.cscmatrix = SparseMatrixHIPCOO.sum(self.xmatrices, self.cscmatrix, home=self._home)
+            return self
+        self.cscmatrix = self.Tm.sum(self.xmatrices, self.cscmatrix)
         self.xmatrices = [self.Tm(m, n, **self._kw) for _ in range(len(self.xmatrices))]
         return self
 

@@ -182,12 +182,26 @@ int32_t esp_set_csc(esp_handle *h, const int64_t *colptr, const int64_t *rowval,
 /* THE flush: sort + ordered fold + join, result stays device-resident.
  * pattern_changed = 1 iff the CSC was rebuilt (the reference recomputes phash then). */
 int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int32_t *pattern_changed);
+/* Base.sum(xmatrices, csc) (sparsematrixdilnkc.jl:397-435) = flush! of GenericMTExtendableSparseMatrixCSC
+ * (genericmtextendablesparsematrixcsc.jl:45-51) as ONE call: dst holds the CSC (esp_set_csc, or the result of its last
+ * flush) and no pending entries; xs[0..p) are the partition buffers -- handles of the same size on the same device whose own
+ * matrix is empty.  Result, bit for bit the reference's sparse!(I,J,V,m,n,+) over (csc entries, buffer 1's entries, ...):
+ * at (i,j) ((csc + f_1) + f_2) + ... where f_k is the fold of the calls buffer k received at (i,j), buffers that do not
+ * hold (i,j) skipped, zeros kept.  Every buffer is folded by itself on the device, the folds meet the stored matrix in ONE
+ * routed flush of dst; no CSC travels between host and device whatever p is.  The buffers come back EMPTY (the reference
+ * replaces them all, :47-49).  pattern_changed as for esp_flush. */
+int32_t esp_flush_sum(esp_handle *dst, esp_handle *const *xs, int32_t p, int64_t *new_nnz,
+                      int32_t *pattern_changed);
 /* SparseArrays.nnz of the device CSC (does not flush) */
 int32_t esp_nnz(const esp_handle *h, int64_t *nnz);
 /* D2H into caller arrays: colptr (n+1), rowval (nnz), nzval (nnz); Julia layout */
 int32_t esp_get_csc(esp_handle *h, int64_t *colptr, int64_t *rowval, double *nzval);
 /* D2H of nzval only (pattern unchanged since the caller's last esp_get_csc) */
 int32_t esp_get_nzval(esp_handle *h, double *nzval);
+/* H2D of nzval only: the attached CSC keeps its pattern (the one of the caller's last esp_set_csc / esp_get_csc) and takes
+ * these nnz values -- what a plug-in whose CSC stays on the device between flushes uploads when only nonzeros(A) can have
+ * been edited on the host (the Generic wrappers edit cscmatrix.nzval in place: genericextendablesparsematrixcsc.jl:44-54) */
+int32_t esp_set_nzval(esp_handle *h, const double *nzval);
 /* device pointers of the resident CSC (Int64 1-based values), for device consumers; valid until the next esp_flush /
  * esp_reset / esp_set_csc of the handle (a flush that changes the pattern rotates all three arrays) */
 int32_t esp_csc_device(esp_handle *h, const int64_t **d_colptr, const int64_t **d_rowval,

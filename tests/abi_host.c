@@ -14,6 +14,12 @@
  *      with the device's free memory (hipMemGetInfo, resolved with dlsym: no HIP headers here) returning to its level;
  *   C. the group calls in the order of INTEGRATION.md section 3 (single rank, the library's own RCCL transport):
  *      esp_group_unique_id -> esp_group_create -> appends -> esp_group_flush -> esp_group_nnz -> esp_group_get_csc.
+ *   D. flush! of the MT wrapper as the shim runs it (genericmtextendablesparsematrixcsc.jl:45-51 = Base.sum(xmatrices, csc)):
+ *      p partition buffers filled through their staged chunks, ONE esp_flush_sum into the handle that keeps the CSC,
+ *      esp_get_csc when the pattern changed, else esp_get_nzval; then nonzeros(A) .= 0 on the host (test_parallel.jl:71-92),
+ *      esp_set_nzval (values only) and the same assembly again: every update now meets a stored position;
+ *   E. esp_append_elements_host: the loops of test/femtools.jl:61-69 over cellnodes / elmat / diag arrays, checked against
+ *      the per-entry rawupdateindex! calls in the same order.
  *
  * Exit code 0 and "abi_host: ok" on success; any mismatch prints what differs and exits 1.
  * Built and run by tests/test_abi_host.py (compile-only without a GPU).
@@ -84,6 +90,16 @@ static void dense_plus(dense_t *d, int64_t i, int64_t j, double bufval) {
     } else {
         d->present[at] = 1;
         d->val[at] = bufval;
+    }
+}
+/* rawupdateindex!(A, +, v, i, j): sparsematrixlnk.jl:237-253 (always creates) */
+static void dense_raw(dense_t *d, int64_t i, int64_t j, double v) {
+    size_t at = (size_t)((j - 1) * d->n + (i - 1));
+    if (!d->present[at]) {
+        d->present[at] = 1;
+        d->val[at] = 0.0 + v;
+    } else {
+        d->val[at] = d->val[at] + v;
     }
 }
 static int64_t dense_nnz(const dense_t *d) {
@@ -287,6 +303,69 @@ int main(void) {
         }
     }
 
+    /* ---------------------------------------------------------------- D: Base.sum(xmatrices, csc) as one call */
+    {
+        enum { P = 5 };
+        esp_handle *home = NULL, *xs[P];
+        dense_t B[P];
+        uint64_t rng = 77u;
+        int64_t z = 0, k;
+        int round, t;
+        CHECK(NULL, esp_create(n, n, 0, 0, &home));
+        CHECK(home, esp_set_csc(home, colptr, rowval, nzval, nnz)); /* the wrapper's cscmatrix (state of section B: D must run before C, which reuses rowval / nzval) */
+        for (t = 0; t < P; t++) CHECK(NULL, esp_create(n, n, 0, 0, &xs[t]));
+        for (round = 0; round < 2; round++) {
+            for (t = 0; t < P; t++) B[t] = dense_new(n);
+            for (t = 0; t < P; t++) {
+                stage_open(&st, xs[t]);
+                for (k = 0; k < 400; k++) { /* rawupdateindex!(A, +, v, i, j, tid): positions overlap between the buffers */
+                    int64_t i = 1 + (int64_t)(lcg(&rng) * 40.0) + 13 * t, j = 1 + (int64_t)(lcg(&rng) * 60.0);
+                    double v = lcg(&rng) - 0.5;
+                    stage_push(&st, ESP_RAWUPDATE, v, i, j);
+                    dense_raw(&B[t], i, j, v);
+                }
+                stage_commit(&st);
+            }
+            /* sparse!(I, J, V, m, n, +) over (csc entries, buffer 1, buffer 2, ...): sparsematrixdilnkc.jl:397-435 */
+            for (t = 0; t < P; t++) {
+                int64_t i, j;
+                for (j = 1; j <= n; j++)
+                    for (i = 1; i <= n; i++)
+                        if (B[t].present[(size_t)((j - 1) * n + (i - 1))]) dense_plus(&D, i, j, B[t].val[(size_t)((j - 1) * n + (i - 1))]);
+                dense_free(&B[t]);
+            }
+            CHECK(home, esp_flush_sum(home, xs, P, &z, &changed));
+            for (t = 0; t < P; t++) {
+                int64_t pend = -1, zz = -1;
+                CHECK(xs[t], esp_pending(xs[t], &pend));
+                CHECK(xs[t], esp_nnz(xs[t], &zz));
+                REQUIRE(pend == 0 && zz == 0, "esp_flush_sum hands buffer %d back empty", t);
+            }
+            if (changed) {
+                REQUIRE(round == 0, "the second round repeats the positions of the first");
+                if (z > nnz) {
+                    rowval = (int64_t *)realloc(rowval, sizeof(int64_t) * (size_t)(z + 64));
+                    nzval = (double *)realloc(nzval, sizeof(double) * (size_t)(z + 64));
+                }
+                nnz = z;
+                CHECK(home, esp_get_csc(home, colptr, rowval, nzval));
+            } else {
+                REQUIRE(z == nnz, "an unchanged pattern keeps nnz");
+                CHECK(home, esp_get_nzval(home, nzval)); /* values only */
+            }
+            compare_csc(&D, colptr, rowval, nzval, nnz, round == 0 ? "D: Base.sum, new positions" : "D: Base.sum over the stored pattern");
+            if (round == 0) { /* nonzeros(A) .= 0 on the host copy, then values only travel back */
+                for (k = 0; k < nnz; k++) nzval[k] = 0.0;
+                for (k = 0; k < n * n; k++)
+                    if (D.present[k]) D.val[k] = 0.0;
+                CHECK(home, esp_set_nzval(home, nzval));
+                rng = 77u; /* the same calls again: every position is stored now */
+            }
+        }
+        for (t = 0; t < P; t++) CHECK(xs[t], esp_destroy(xs[t]));
+        CHECK(home, esp_destroy(home));
+    }
+
     /* ---------------------------------------------------------------- C: the group calls of INTEGRATION.md section 3 */
     {
         uint8_t id[128];
@@ -318,6 +397,47 @@ int main(void) {
         CHECK(hs, esp_group_destroy(g));
         CHECK(hs, esp_destroy(hs));
         dense_free(&E);
+    }
+
+    /* ---------------------------------------------------------------- E: element-level append from host arrays */
+    {
+        const int64_t nc = n - q - 1; /* cell c (0-based): the nodes c+1, c+2, c+1+q */
+        int64_t *cn = (int64_t *)malloc(sizeof(int64_t) * 3 * (size_t)nc), c, z = 0;
+        double *em = (double *)malloc(sizeof(double) * 9 * (size_t)nc), *dg = (double *)malloc(sizeof(double) * 3 * (size_t)nc);
+        uint64_t rng = 5u;
+        esp_handle *e = NULL;
+        dense_t E = dense_new(n);
+        int il, jl;
+        REQUIRE(cn && em && dg, "out of memory");
+        for (c = 0; c < nc; c++) {
+            cn[3 * c] = c + 1, cn[3 * c + 1] = c + 2, cn[3 * c + 2] = c + 1 + q;
+            for (il = 0; il < 9; il++) em[9 * c + il] = lcg(&rng) - 0.5;
+            for (il = 0; il < 3; il++) dg[3 * c + il] = lcg(&rng);
+        }
+        for (c = 0; c < nc; c++) /* test/femtools.jl:61-69 */
+            for (il = 0; il < 3; il++) {
+                int64_t i = cn[3 * c + il];
+                dense_raw(&E, i, i, dg[3 * c + il]);
+                for (jl = 0; jl < 3; jl++) dense_raw(&E, i, cn[3 * c + jl], em[9 * c + 3 * jl + il]);
+            }
+        CHECK(NULL, esp_create(n, n, 0, 0, &e));
+        CHECK(e, esp_append_elements_host(e, 3, nc, cn, em, dg, ESP_RAWUPDATE, ESP_OP_ADD));
+        CHECK(e, esp_flush(e, ESP_FLUSH_ROUTED, &z, &changed));
+        if (z > nnz) {
+            rowval = (int64_t *)realloc(rowval, sizeof(int64_t) * (size_t)(z + 64));
+            nzval = (double *)realloc(nzval, sizeof(double) * (size_t)(z + 64));
+        }
+        CHECK(e, esp_get_csc(e, colptr, rowval, nzval));
+        compare_csc(&E, colptr, rowval, nzval, z, "E: esp_append_elements_host");
+        cn[3 * (nc / 2) + 1] = n + 1; /* BoundsError: nothing is appended */
+        REQUIRE(esp_append_elements_host(e, 3, nc, cn, em, dg, ESP_RAWUPDATE, ESP_OP_ADD) == ESP_ERR_BOUNDS, "a node outside the matrix");
+        CHECK(e, esp_pending(e, &z));
+        REQUIRE(z == 0, "a refused batch leaves nothing pending");
+        CHECK(e, esp_destroy(e));
+        dense_free(&E);
+        free(cn);
+        free(em);
+        free(dg);
     }
 
     CHECK(h, esp_destroy(h));

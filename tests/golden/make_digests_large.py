@@ -34,6 +34,20 @@ def fem_chunked(dim, npd, order, chunk_cells=1 << 22):
     return A
 
 
+def elements_chunked(dim, npd, node_mode, chunk_cells=1 << 22):
+    """The same assembly as a caller with a mesh in memory runs it (test/femtools.jl:61-69 over cellnodes / elmat / diag:
+    orc_fem_mesh_range + orc_elements_stream), random cell order, nodes in natural (0) or permuted (1) numbering."""
+    nn, nc, cnt = orc.fem_sizes(dim, npd)
+    A = orc.ExtendableSparseMatrix(nn, nn)
+    for p0 in range(0, nc, chunk_cells):
+        p1 = min(nc, p0 + chunk_cells)
+        cn, em, dg = orc.fem_mesh(dim, npd, seed=0x5EED0004, order_mode=1, node_mode=node_mode, node_seed=0x5EED0014, p0=p0, p1=p1)
+        I, J, V = orc.elements_stream(cn, em, dg)
+        A.apply(np.full(len(I), RAW, np.uint8), I, J, V)
+        del I, J, V, cn, em, dg
+    return A
+
+
 def main():
     only = sys.argv[1:]
     want = lambda tag: not only or any(tag.startswith(p) for p in only)  # noqa: E731
@@ -78,6 +92,16 @@ def main():
             lines.append("%s nnz=%d csc=%s" % (tag, len(rv), digest(cp, rv, nz)))
             print(lines[-1], flush=True)
             del A, cp, rv, nz
+    # ... and from element arrays whose nodes carry a PERMUTED numbering (esp_append_elements: nothing may lean on grid arithmetic)
+    for dim, npd in ((2, 1000), (3, 64), (2, 3163), (3, 216)):
+        tag = "elem%dd_%d_p1" % (dim, npd)
+        if not want(tag):
+            continue
+        A = elements_chunked(dim, npd, 1)
+        cp, rv, nz = A.arrays()
+        lines.append("%s nnz=%d csc=%s" % (tag, len(rv), digest(cp, rv, nz)))
+        print(lines[-1], flush=True)
+        del A, cp, rv, nz
     for ln in lines:
         kept[ln.split()[0]] = ln
     with open(path, "w") as f:

@@ -317,24 +317,138 @@ def test_pending_getindex_and_release(esp, orc):
     assert C1.nnz() == 1 and C1[7, 8] == 4.0
 
 
-def test_mt_wrapper_vs_oracle(esp, orc):
-    """GenericMTExtendableSparseMatrixCSC{SparseMatrixHIPCOO}: test_parallel.jl:18-26 style."""
+@pytest.mark.parametrize("n,p,per_round", [(60, 3, 900), (400, 10, 20000), (1500, 20, 60000)])
+def test_mt_wrapper_vs_oracle(esp, orc, n, p, per_round):
+    """GenericMTExtendableSparseMatrixCSC{SparseMatrixHIPCOO}: test_parallel.jl:18-26 style, np = 3, 10, 20 partitions
+    (test_parallel.jl:41,74).  flush! = Base.sum(xmatrices, csc) as ONE esp_flush_sum: bitwise the oracle's successive
+    csc + buffer merges, over three rounds (new positions, then mostly hits on the host copy + a few new ones)."""
     rng = np.random.default_rng(19)
-    n, p = 60, 3
     M = esp.GenericMTExtendableSparseMatrixCSC(n, n, p)
     O = orc.MTExtendableSparseMatrix(n, n, p)
     with pytest.raises(RuntimeError):
         M[1, 1] = 1.0
-    for rnd in range(2):
-        for _ in range(900):
-            i, j = int(rng.integers(1, n + 1)), int(rng.integers(1, n + 1))
-            tid = int(rng.integers(1, p + 1))
-            v = float(rng.standard_normal())
+    for rnd in range(3):
+        I = rng.integers(1, n + 1, per_round)
+        J = np.minimum(n, np.maximum(1, I + rng.integers(-20, 21, per_round)))
+        T = rng.integers(1, p + 1, per_round)
+        V = rng.standard_normal(per_round)
+        for i, j, tid, v in zip(I.tolist(), J.tolist(), T.tolist(), V.tolist()):
             M.rawupdateindex("+", v, i, j, tid)
             O.rawupdateindex(orc.OP_ADD, v, i, j, tid)
         M.flush()
         O.flush()
         assert_csc_equal(M.arrays(), O.arrays(), "round %d" % rnd)
+        assert M.nnznew() == 0
+
+
+def test_flush_sum_and_values_only_transfers(esp, orc):
+    """esp_flush_sum / esp_set_nzval / esp_get_nzval directly: Base.sum(xs, csc) with a handle that keeps the CSC between
+    flushes.  Buffers with SET / UPDATE / RAWUPDATE calls (each folds by itself: sparsematrixdilnkc.jl:397-435), empty
+    buffers, a round in which no position is new (values only come back, the pattern arrays are shared), nonzeros(A) .= 0 on
+    the host in between (test_parallel.jl:71-92: values only go up), and a csc the handle has never seen (full upload)."""
+    rng = np.random.default_rng(23)
+    m, n, p = 700, 900, 6
+    home = esp.SparseMatrixHIPCOO(m, n)
+    xs = [esp.SparseMatrixHIPCOO(m, n) for _ in range(p)]
+    csc = esp.SparseMatrixCSC(m, n)
+    O = orc.CSC(m, n)
+    pos = (rng.integers(1, m + 1, 5000), rng.integers(1, n + 1, 5000))
+    for rnd in range(5):
+        lnks = []
+        for t, x in enumerate(xs):
+            L = orc.SparseMatrixLNK(m, n)
+            lnks.append(L)
+            if t == 2 or (rnd == 3 and t % 2):
+                continue                                      # an empty buffer
+            cnt = 4000
+            pick = rng.integers(0, 5000, cnt)
+            I, J = pos[0][pick], pos[1][pick]
+            if rnd in (0, 4):                                 # new positions as well
+                I = np.where(rng.random(cnt) < 0.3, rng.integers(1, m + 1, cnt), I)
+            elif rnd >= 1:
+                keep = np.array([csc.findindex(int(i), int(j)) > 0 for i, j in zip(I, J)])
+                I, J = I[keep], J[keep]                       # hits only: the pattern stays
+            V = np.where(rng.random(len(I)) < 0.1, 0.0, rng.standard_normal(len(I)))
+            K = rng.choice(np.array([0, 1, 2], np.uint8), len(I))
+            x.append(0, I, J, V, kinds=K)
+            for k, i, j, v in zip(K.tolist(), I.tolist(), J.tolist(), V.tolist()):
+                if k == 0:
+                    L[i, j] = v
+                elif k == 1:
+                    L.updateindex(orc.OP_ADD, v, i, j)
+                else:
+                    L.rawupdateindex(orc.OP_ADD, v, i, j)
+        before = csc
+        out = esp.SparseMatrixHIPCOO.sum(xs, csc, home=home)
+        for L in lnks:
+            if L.nnz() > 0:
+                O = L + O                                     # (sparse! over csc, x1, x2, ...: successive csc + buffer)
+        assert_csc_equal(out.arrays(), O.arrays(), "round %d" % rnd)
+        assert all(x.nnz() == 0 for x in xs)
+        if rnd in (1, 2, 3):
+            assert out.colptr is before.colptr and out.rowval is before.rowval    # (values only came back)
+        csc = out
+        if rnd == 1:                                          # nonzeros(A) .= 0: only the values travel up
+            csc.nzval[:] = 0.0
+            O = orc.CSC(m, n, *[a.copy() for a in (O.arrays()[0], O.arrays()[1], np.zeros(O.nnz()))])
+        if rnd == 2:                                          # a matrix the handle has never seen
+            csc = esp.SparseMatrixCSC(m, n, csc.colptr.copy(), csc.rowval.copy(), csc.nzval.copy())
+    # x + csc on one buffer keeps its result attached as well
+    x = xs[0]
+    x.updateindex("+", 2.5, int(pos[0][0]), int(pos[1][0]))
+    L = orc.SparseMatrixLNK(m, n)
+    L.updateindex(orc.OP_ADD, 2.5, int(pos[0][0]), int(pos[1][0]))
+    r1 = x + csc
+    O = L + O
+    assert_csc_equal(r1.arrays(), O.arrays(), "x + csc")
+    x.updateindex("+", -1.0, int(pos[0][1]), int(pos[1][1]))
+    L = orc.SparseMatrixLNK(m, n)
+    L.updateindex(orc.OP_ADD, -1.0, int(pos[0][1]), int(pos[1][1]))
+    r2 = x + r1
+    O = L + O
+    assert_csc_equal(r2.arrays(), O.arrays(), "x + (x + csc)")
+    assert r2.colptr is r1.colptr
+
+
+def test_device_consumer_hand_off_and_external_stream(esp, orc):
+    """esp_csc_device (the hand-off to consumers that stay on the GPU), esp_get_nzval and esp_set_stream: an assembly on a
+    caller-made stream, the device CSC read straight from the pointers the library hands out."""
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")          # (the runtime the library itself is linked against)
+    n = 24
+    N = n ** 3
+    A = esp.ExtendableSparseMatrix(N, N)
+    d = A._d
+    stream = C.c_void_p()
+    assert hip.hipStreamCreate(C.byref(stream)) == 0
+    d.ck(d.lib.esp_set_stream(d.h, stream))
+    A.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1)
+    A.flush()
+    want = orc.fdrand(n, n, n, rand_mode=1, seed=0x5EED0002, style=orc.KIND_UPDATE).arrays()
+    Z = A.nnz()
+    assert Z == len(want[1])
+    pc, pr, pv = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    d.ck(d.lib.esp_csc_device(d.h, C.byref(pc), C.byref(pr), C.byref(pv)))
+    A.synchronize()
+    cp, rv, nz = np.empty(N + 1, np.int64), np.empty(Z, np.int64), np.empty(Z, np.float64)
+    for dst, src in ((cp, pc), (rv, pr), (nz, pv)):
+        assert hip.hipMemcpy(C.c_void_p(dst.ctypes.data), src, C.c_size_t(dst.nbytes), 2) == 0     # hipMemcpyDeviceToHost
+    assert_csc_equal((cp, rv, nz), want, "device pointers")
+    nz2 = np.empty(Z, np.float64)
+    d.ck(d.lib.esp_get_nzval(d.h, C.c_void_p(nz2.ctypes.data)))
+    assert np.array_equal(bits(nz2), bits(want[2]))
+    # a re-assembly on the same external stream: the pointers stay valid (no new position), the values double
+    A.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1)
+    A.flush()
+    d.ck(d.lib.esp_get_nzval(d.h, C.c_void_p(nz2.ctypes.data)))
+    O = orc.fdrand(n, n, n, rand_mode=1, seed=0x5EED0002, style=orc.KIND_UPDATE)
+    I, J, V = orc.fdrand_stream(n, n, n, rand_mode=1, seed=0x5EED0002)
+    O.apply(np.full(len(I), UPDATE, np.uint8), I, J, V)
+    O.flush()
+    assert np.array_equal(bits(nz2), bits(O.arrays()[2]))
+    del A
+    d.close()
+    assert hip.hipStreamDestroy(stream) == 0
 
 
 def test_fdrand_stream_and_reassembly(esp, orc):
