@@ -2204,6 +2204,32 @@ def test_fem_digest_bench_size(esp, dim, npd):
     assert gu.digest(*arrs) == d["csc"]
 
 
+@pytest.mark.parametrize("dim,npd", [(2, 1000), (3, 64), (2, 3163), (3, 216)])
+@pytest.mark.parametrize("node_mode", [0, 1])
+def test_elements_digest(esp, dim, npd, node_mode):
+    """esp_append_elements at 10^6 .. 10^7 DoF (the last two: the sizes bench.py times), random cell order, element arrays
+    made on the device (esp_generate_fem_mesh).  Natural node numbering: the stream is generate_fem's, the pin the same;
+    permuted numbering (a mesh that owes nothing to grid arithmetic): pins made by the oracle from its own arrays through
+    the loops of femtools.jl:61-69 (tests/golden/make_digests_large.py: elements_chunked)."""
+    import torch
+    tag = ("fem%dd_%d_o1" if node_mode == 0 else "elem%dd_%d_p1") % (dim, npd)
+    d = gu.digests("digests_large.txt")[tag]
+    nn, nloc = npd ** dim, dim + 1
+    q = npd - 1
+    nc = 2 * q * q if dim == 2 else 6 * q ** 3
+    A = esp.ExtendableSparseMatrix(nn, nn)
+    cn = torch.empty((nc, nloc), dtype=torch.int64, device="cuda")
+    em = torch.empty((nc, nloc, nloc), dtype=torch.float64, device="cuda")
+    dg = torch.empty((nc, nloc), dtype=torch.float64, device="cuda")
+    A.generate_fem_mesh(dim, npd, cn, em, dg, seed=0x5EED0004, order_mode=1, node_mode=node_mode, node_seed=0x5EED0014)
+    A.append_elements(cn, em, dg)
+    A.flush()
+    assert A.debug_last_partition() == 4
+    arrs = hip_arrays(A)
+    assert len(arrs[1]) == int(d["nnz"])
+    assert gu.digest(*arrs) == d["csc"]
+
+
 @pytest.mark.parametrize("dim,npd", [(2, 1000), (3, 64)])
 @pytest.mark.parametrize("order", [0, 1])
 def test_fem_digest(esp, dim, npd, order):
