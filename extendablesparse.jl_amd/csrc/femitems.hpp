@@ -99,11 +99,17 @@ static __global__ __launch_bounds__(THREADS) void fem_expand_k(Args a) {
     __syncthreads();
     const int cnt = (int)min((i64)THREADS, a.nitems - g0) * W;
     if constexpr (K32) {
-        // (4-byte keys: plain coalesced stores; the values as pairs where aligned)
+        // (whole lines, 16 bytes per lane: g0 * W is a multiple of 256 and both arrays start 256-byte aligned)
+        typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+        typedef double dbl2 __attribute__((ext_vector_type(2)));
         u32 *gk = reinterpret_cast<u32 *>(a.keys_out) + g0 * W;
-        for (int q = t; q < cnt; q += THREADS) gk[q] = lk[q];
+        const int kquad = cnt >> 2;
+        for (int q = t; q < kquad; q += THREADS) reinterpret_cast<u32x4 *>(gk)[q] = u32x4{lk[4 * q], lk[4 * q + 1], lk[4 * q + 2], lk[4 * q + 3]};
+        for (int q = 4 * kquad + t; q < cnt; q += THREADS) gk[q] = lk[q];
         double *gv = a.vals_out + g0 * W;
-        for (int q = t; q < cnt; q += THREADS) gv[q] = lv[q];
+        const int vpair = cnt >> 1;
+        for (int q = t; q < vpair; q += THREADS) reinterpret_cast<dbl2 *>(gv)[q] = dbl2{lv[2 * q], lv[2 * q + 1]};
+        if (t == 0 && (cnt & 1)) gv[cnt - 1] = lv[cnt - 1];
     } else {
         espgen::copy_out_staged<THREADS>(lk, lv, cnt, a.keys_out + g0 * W, a.vals_out + g0 * W);
     }

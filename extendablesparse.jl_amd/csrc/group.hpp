@@ -15,6 +15,7 @@
 // front of the bucket kernel, no host synchronisation in between.  A host that brings its own transport (MPI, the
 // in-process harness of the tests) passes a callback table instead (esp_group_create_comm).
 #pragma once
+#include <mutex>
 #include <dlfcn.h>
 #include <rccl/rccl.h>
 
@@ -34,8 +35,10 @@ struct RcclApi {
 };
 static RcclApi g_rccl;
 static std::string g_rccl_err;
+static std::mutex g_rccl_mutex;  // (handles of different host threads may create their groups at the same time)
 
 static bool rccl_load() {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
     if (g_rccl.lib) return true;
     void *lib = nullptr;
     if (const char *e = getenv("ESP_RCCL_LIB")) lib = dlopen(e, RTLD_NOW | RTLD_LOCAL);
@@ -157,6 +160,19 @@ extern "C" int32_t esp_group_unique_id(uint8_t *id128) {
     return ESP_OK;
 }
 
+// what esp_group_create* changes on the caller's handle, put back when the group cannot be made after all
+struct HandleShardState {
+    bool shard_user, win_excl;
+    u64 win_base, win_span;
+    i64 wc0, wc1;
+    explicit HandleShardState(const esp_handle *h) : shard_user(h->shard_user), win_excl(h->win_excl), win_base(h->win_base), win_span(h->win_span), wc0(h->wc0), wc1(h->wc1) {}
+    void restore(esp_handle *h) const {
+        h->shard_user = shard_user, h->win_excl = win_excl;
+        h->win_base = win_base, h->win_span = win_span;
+        h->wc0 = wc0, h->wc1 = wc1;
+    }
+};
+
 static void bind_shard_ops(esp_group *g);
 static int32_t group_common(esp_handle *h, int32_t nranks, int32_t rank, esp_group **out, esp_group **made) {
     if (!h || !out) return ESP_ERR_INVALID;
@@ -169,11 +185,13 @@ static int32_t group_common(esp_handle *h, int32_t nranks, int32_t rank, esp_gro
     g->me = rank;
     g->pol.init(nranks, rank);
     bind_shard_ops(g);
+    const HandleShardState before(h);
     h->shard_user = true;
     const i64 c0 = shard_col0(h->n, nranks, rank), c1 = shard_col0(h->n, nranks, rank + 1);
     if (c1 > c0) {  // after the exchange every pending column is owned: flushes and reset! work on the own range only
         const int32_t st = esp_set_column_window(h, c0 + 1, c1);
         if (st != ESP_OK) {
+            before.restore(h);
             delete g;
             return st;
         }
@@ -186,12 +204,18 @@ extern "C" int32_t esp_group_create(esp_handle *h, int32_t nranks, int32_t rank,
     if (!id128) return ESP_ERR_INVALID;
     if (!rccl_load()) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_group_create: %s", g_rccl_err.c_str());
     esp_group *g = nullptr;
+    const HandleShardState before(h);
     CK(group_common(h, nranks, rank, out, &g));
     (void)hipSetDevice(h->device);
     ncclUniqueId id;
     memcpy(&id, id128, 128);
-    const ncclResult_t r = g_rccl.CommInitRank(&g->nccl, nranks, id, rank);
+    ncclResult_t r = ncclSuccess;
+    if (getenv("ESP_DEBUG_FAIL_COMM_INIT"))  // (test hook: the failure path below without a broken fabric)
+        r = ncclInvalidArgument;
+    else
+        r = g_rccl.CommInitRank(&g->nccl, nranks, id, rank);
     if (r != ncclSuccess) {
+        before.restore(h);  // (the handle is the caller's plain handle again: no shard, no column window)
         delete g;
         FAIL(h, ESP_ERR_HIP, "ncclCommInitRank failed: %s", g_rccl.GetErrorString(r));
     }

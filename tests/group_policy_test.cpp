@@ -1,6 +1,9 @@
 // group_policy_test.cpp -- the exchange policy of esp_group_flush (csrc/group_policy.hpp: the very code the library runs)
 // on the CPU: 2 / 3 / 8 ranks as threads, a host model of a shard behind the ShardOps table, an in-process transport
 // behind esp_comm_t.  Built with -fsanitize=address,undefined by tests/test_group_policy.py.  TEST INFRASTRUCTURE.
+// `--procs P`: the same scenario with every rank a PROCESS of its own (fork) and a transport over Unix socket pairs, every
+// message framed with (operation, sequence number, byte count): ranks that issued their collectives in different orders,
+// or with different sizes, meet a frame they do not expect -- what threads sharing one address space cannot show.
 //
 // Checked after every collective flush, for every rank and column: what the rank flushed for that column is the
 // concatenation, in RANK order, of what every rank appended for it in its own append order (= Base.sum(xmatrices, csc)
@@ -9,6 +12,10 @@
 // rank, nnz offsets -- are the same on all ranks and what the streams call for.
 #include <pthread.h>
 #include <stdint.h>
+#include <sys/socket.h>
+#include <sys/types.h>
+#include <sys/wait.h>
+#include <unistd.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -74,6 +81,75 @@ static int32_t hub_alltoallv(void *ctx, const void *const *send, const int64_t *
         if (theirs > 0) memcpy(recv[q], h->a2a_send[(size_t)q][c->me], (size_t)theirs);
     }
     pthread_barrier_wait(&h->bar);
+    return ESP_OK;
+}
+
+// ---- transport between processes: one Unix socket pair per pair of ranks ----------------------------------------------
+struct SockComm {
+    int P, me;
+    std::vector<int> fd;  // fd[q]: this rank's end of the pair (me, q)
+    uint64_t seq = 0;     // collectives issued so far: must agree between the two ends of every frame
+};
+struct Frame {
+    uint32_t op;  // 1 all-gather, 2 all-to-all-v
+    uint32_t from;
+    uint64_t seq;
+    int64_t bytes;
+};
+static void sock_write(int fd, const void *p, size_t n) {
+    const char *c = static_cast<const char *>(p);
+    while (n > 0) {
+        const ssize_t w = write(fd, c, n);
+        REQUIRE(w > 0, "socket write failed");
+        c += w, n -= (size_t)w;
+    }
+}
+static void sock_read(int fd, void *p, size_t n) {
+    char *c = static_cast<char *>(p);
+    while (n > 0) {
+        const ssize_t r = read(fd, c, n);
+        REQUIRE(r > 0, "socket read failed (the peer is gone?)");
+        c += r, n -= (size_t)r;
+    }
+}
+// pairwise, lower peers first, the lower rank of a pair sends first: no cycle of waiting ranks (messages of any size)
+static void sock_pair_exchange(SockComm *c, int q, uint32_t op, const void *send, int64_t sbytes, void *recv, int64_t rbytes) {
+    const Frame mine{op, (uint32_t)c->me, c->seq, sbytes};
+    Frame theirs{};
+    auto out = [&]() {
+        sock_write(c->fd[(size_t)q], &mine, sizeof mine);
+        if (sbytes > 0) sock_write(c->fd[(size_t)q], send, (size_t)sbytes);
+    };
+    auto in = [&]() {
+        sock_read(c->fd[(size_t)q], &theirs, sizeof theirs);
+        REQUIRE(theirs.op == op && theirs.seq == c->seq && theirs.from == (uint32_t)q,
+                "rank %d expects operation %u number %llu from rank %d, got operation %u number %llu from rank %u: the ranks' collectives are out of step", c->me,
+                op, (unsigned long long)c->seq, q, theirs.op, (unsigned long long)theirs.seq, theirs.from);
+        REQUIRE(theirs.bytes == rbytes, "rank %d expects %lld bytes from rank %d, which sends %lld", c->me, (long long)rbytes, q, (long long)theirs.bytes);
+        if (rbytes > 0) sock_read(c->fd[(size_t)q], recv, (size_t)rbytes);
+    };
+    if (c->me < q) {
+        out();
+        in();
+    } else {
+        in();
+        out();
+    }
+}
+static int32_t sock_allgather(void *ctx, const int64_t *send, int32_t count, int64_t *recv) {
+    SockComm *c = static_cast<SockComm *>(ctx);
+    const int64_t bytes = (int64_t)sizeof(int64_t) * count;
+    memcpy(recv + (size_t)c->me * (size_t)count, send, (size_t)bytes);
+    for (int q = 0; q < c->P; q++)
+        if (q != c->me) sock_pair_exchange(c, q, 1u, send, bytes, recv + (size_t)q * (size_t)count, bytes);
+    c->seq++;
+    return ESP_OK;
+}
+static int32_t sock_alltoallv(void *ctx, const void *const *send, const int64_t *send_bytes, void *const *recv, const int64_t *recv_bytes, void *) {
+    SockComm *c = static_cast<SockComm *>(ctx);
+    for (int q = 0; q < c->P; q++)
+        if (q != c->me) sock_pair_exchange(c, q, 2u, send[q], send_bytes[q], recv[q], recv_bytes[q]);
+    c->seq++;
     return ESP_OK;
 }
 
@@ -264,6 +340,7 @@ struct Round {
 };
 struct Job {
     Hub *hub;
+    SockComm *sock = nullptr;  // --procs: the transport between processes instead of the hub
     int P, me;
     i64 n;
     std::vector<Round> rounds;
@@ -282,6 +359,11 @@ static void *run_rank(void *arg) {
     pol.comm.ctx = &rc;
     pol.comm.allgather_i64 = hub_allgather;
     pol.comm.alltoallv_dev = hub_alltoallv;
+    if (j->sock) {
+        pol.comm.ctx = j->sock;
+        pol.comm.allgather_i64 = sock_allgather;
+        pol.comm.alltoallv_dev = sock_alltoallv;
+    }
     Shard &s = j->shard;
     s.P = j->P, s.me = j->me, s.n = j->n;
     espgroup::ShardOps &o = pol.ops;
@@ -304,7 +386,9 @@ static void *run_rank(void *arg) {
     return nullptr;
 }
 
-static void scenario(int P) {
+// procs: every rank a forked process over socket pairs; each child checks its own shard and reports its per-round decisions to
+// the parent through a pipe, the parent checks what must agree across the ranks
+static void scenario(int P, bool procs = false) {
     const i64 n = 4000 * (i64)P + 37;
     // slab, slab, one rank shuffled (consensus: in place; back-off 1), slab (skipped: in place), slab (partitioned again),
     // one rank empty, two shuffled rounds in a row (back-off 1, then 3)
@@ -334,22 +418,85 @@ static void scenario(int P) {
                 for (size_t i = 0; i < st.size(); i++) st[i].first = (u64)(next() % (u64)n);
             }
         }
-    Hub hub(P);
-    std::vector<Job> jobs((size_t)P);
-    std::vector<pthread_t> th((size_t)P);
-    for (int q = 0; q < P; q++) {
-        jobs[(size_t)q].hub = &hub, jobs[(size_t)q].P = P, jobs[(size_t)q].me = q, jobs[(size_t)q].n = n;
-        jobs[(size_t)q].rounds = rounds, jobs[(size_t)q].streams = &streams;
-    }
-    for (int q = 0; q < P; q++) pthread_create(&th[(size_t)q], nullptr, run_rank, &jobs[(size_t)q]);
-    for (int q = 0; q < P; q++) pthread_join(th[(size_t)q], nullptr);
     // ---- expected: per column, round by round, the ranks' entries in rank order, each rank's in its append order
     std::map<u64, std::vector<double>> want;
     for (size_t r = 0; r < rounds.size(); r++)
         for (int q = 0; q < P; q++)
             for (const auto &e : streams[r * (size_t)P + (size_t)q]) want[e.first].push_back(e.second);
-    size_t seen = 0;
+    Hub hub(P);
+    std::vector<Job> jobs((size_t)P);
     for (int q = 0; q < P; q++) {
+        jobs[(size_t)q].hub = &hub, jobs[(size_t)q].P = P, jobs[(size_t)q].me = q, jobs[(size_t)q].n = n;
+        jobs[(size_t)q].rounds = rounds, jobs[(size_t)q].streams = &streams;
+    }
+    if (procs) {
+        // socket pairs for every pair of ranks, a report pipe per rank; then one process per rank
+        std::vector<std::vector<int>> fds((size_t)P, std::vector<int>((size_t)P, -1));
+        for (int a = 0; a < P; a++)
+            for (int b = a + 1; b < P; b++) {
+                int sv[2];
+                REQUIRE(socketpair(AF_UNIX, SOCK_STREAM, 0, sv) == 0, "socketpair");
+                fds[(size_t)a][(size_t)b] = sv[0], fds[(size_t)b][(size_t)a] = sv[1];
+            }
+        std::vector<int> rep_r((size_t)P), rep_w((size_t)P);
+        std::vector<pid_t> pid((size_t)P);
+        for (int q = 0; q < P; q++) {
+            int pp[2];
+            REQUIRE(pipe(pp) == 0, "pipe");
+            rep_r[(size_t)q] = pp[0], rep_w[(size_t)q] = pp[1];
+        }
+        fflush(stdout);
+        for (int q = 0; q < P; q++) {
+            pid[(size_t)q] = fork();
+            REQUIRE(pid[(size_t)q] >= 0, "fork");
+            if (pid[(size_t)q] == 0) {
+                for (int a = 0; a < P; a++)
+                    for (int b = 0; b < P; b++)
+                        if (a != q && fds[(size_t)a][(size_t)b] >= 0) close(fds[(size_t)a][(size_t)b]);  // (the other ranks' ends)
+                SockComm sc{P, q, fds[(size_t)q]};
+                Job &j = jobs[(size_t)q];
+                j.sock = &sc;
+                run_rank(&j);
+                // this rank's own shard against what every rank appended for its columns
+                size_t mine = 0;
+                for (const auto &kv : want) mine += ref.owner(kv.first) == q;
+                REQUIRE(j.shard.stored.size() == mine, "P = %d rank %d: %zu columns flushed, %zu appended for it", P, q, j.shard.stored.size(), mine);
+                for (const auto &kv : j.shard.stored) {
+                    REQUIRE(ref.owner(kv.first) == q, "column %llu stored on rank %d", (unsigned long long)kv.first, q);
+                    const auto it = want.find(kv.first);
+                    REQUIRE(it != want.end() && it->second == kv.second, "P = %d: column %llu on rank %d: order or content of its %zu updates differs", P,
+                            (unsigned long long)kv.first, q, kv.second.size());
+                }
+                std::vector<i64> rep;
+                for (size_t r = 0; r < rounds.size(); r++) {
+                    rep.push_back(j.kinds[r]), rep.push_back(j.sent[r]), rep.push_back(j.nnz_before[r]), rep.push_back(j.nnz_total[r]);
+                }
+                sock_write(rep_w[(size_t)q], rep.data(), sizeof(i64) * rep.size());
+                _exit(0);
+            }
+        }
+        for (int a = 0; a < P; a++)
+            for (int b = 0; b < P; b++)
+                if (fds[(size_t)a][(size_t)b] >= 0) close(fds[(size_t)a][(size_t)b]);
+        for (int q = 0; q < P; q++) {
+            int st = 0;
+            REQUIRE(waitpid(pid[(size_t)q], &st, 0) == pid[(size_t)q] && WIFEXITED(st) && WEXITSTATUS(st) == 0, "P = %d: the process of rank %d failed (status %d)", P, q,
+                    st);
+            std::vector<i64> rep(4 * rounds.size());
+            sock_read(rep_r[(size_t)q], rep.data(), sizeof(i64) * rep.size());
+            close(rep_r[(size_t)q]), close(rep_w[(size_t)q]);
+            Job &j = jobs[(size_t)q];
+            for (size_t r = 0; r < rounds.size(); r++) {
+                j.kinds.push_back((int)rep[4 * r]), j.sent.push_back(rep[4 * r + 1]), j.nnz_before.push_back(rep[4 * r + 2]), j.nnz_total.push_back(rep[4 * r + 3]);
+            }
+        }
+    } else {
+        std::vector<pthread_t> th((size_t)P);
+        for (int q = 0; q < P; q++) pthread_create(&th[(size_t)q], nullptr, run_rank, &jobs[(size_t)q]);
+        for (int q = 0; q < P; q++) pthread_join(th[(size_t)q], nullptr);
+    }
+    size_t seen = procs ? want.size() : 0;  // (--procs: every child has checked its own shard)
+    for (int q = 0; q < P && !procs; q++) {
         for (const auto &kv : jobs[(size_t)q].shard.stored) {
             REQUIRE(ref.owner(kv.first) == q, "column %llu stored on rank %d", (unsigned long long)kv.first, q);
             const auto it = want.find(kv.first);
@@ -373,10 +520,17 @@ static void scenario(int P) {
         REQUIRE(sent_total == expect_sent, "P = %d round %zu: %lld entries sent off rank, %lld cross the shard boundaries", P, r, (long long)sent_total,
                 (long long)expect_sent);
     }
-    printf("group_policy_test: P = %d ok (%zu rounds, %zu columns)\n", P, rounds.size(), want.size());
+    printf("group_policy_test: P = %d %s ok (%zu rounds, %zu columns)\n", P, procs ? "processes" : "threads", rounds.size(), want.size());
 }
 
-int main() {
+int main(int argc, char **argv) {
+    if (argc >= 3 && strcmp(argv[1], "--procs") == 0) {
+        const int P = atoi(argv[2]);
+        REQUIRE(P >= 1 && P <= 16, "--procs P: 1 .. 16");
+        scenario(P, true);
+        printf("group_policy_test: ok\n");
+        return 0;
+    }
     scenario(1);
     scenario(2);
     scenario(3);

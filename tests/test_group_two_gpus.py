@@ -7,7 +7,6 @@ one stencil, exchange the cross-slab entries through ncclSend / ncclRecv, and th
 what ONE GPU builds from the whole stream (the property the driver's SCALE runs rely on)."""
 import json
 import os
-import subprocess
 import sys
 
 import pytest
@@ -74,16 +73,20 @@ def _gpus():
 @pytest.mark.gpu
 @pytest.mark.skipif(_gpus() < 2, reason="needs two GPUs on one node (RCCL between processes)")
 def test_two_ranks_over_rccl_equal_one_gpu(tmp_path):
+    from procdist import free_port, run_processes
     script = tmp_path / "worker.py"
     script.write_text(WORKER)
-    procs = []
+    port = str(free_port())
+    cmds, envs = [], []
     for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT="29655",
-                   HSA_ENABLE_IPC_MODE_LEGACY="0", ESP_ROOT=ROOT)
-        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
-    outs = [p.communicate(timeout=900) for p in procs]
-    assert all(p.returncode == 0 for p in procs), [o[1][-2000:] for o in outs]
-    d = json.loads([ln for ln in outs[0][0].splitlines() if ln.startswith("{")][-1])
+        envs.append(dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                         HSA_ENABLE_IPC_MODE_LEGACY="0", ESP_ROOT=ROOT))
+        cmds.append([sys.executable, str(script)])
+    # (supervised: a rank that dies at start-up ends the other one instead of leaving it in the rendezvous; nothing stays
+    # behind on the GPUs)
+    outs = run_processes(cmds, envs, timeout=900)
+    assert all(o[0] == 0 for o in outs), [(o[0], o[2][-2000:]) for o in outs]
+    d = json.loads([ln for ln in outs[0][1].splitlines() if ln.startswith("{")][-1])
     assert d["ok"], d
     assert all(k[-1] == "partitioned" for k in d["kinds"]), d      # the slab streams take the partitioned exchange
     assert all(s > 0 for s in d["sent"]), d                       # ... and cross-slab entries really travelled
