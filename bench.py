@@ -520,6 +520,81 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
             del A
         except Exception as ex:
             out[etag] = {"error": repr(ex)}
+    # ---- flush! of the MT wrapper (genericmtextendablesparsematrixcsc.jl:45-51 = Base.sum(xmatrices, csc)): the 2-D mesh
+    # dealt to 16 partition buffers (contiguous chunks of the shuffled cell order), each filled by esp_append_elements, then
+    # ONE esp_flush_sum into the handle that keeps the CSC -- device-resident; `plugin_ms`: the same through
+    # SparseMatrixHIPCOO.sum with a host SparseMatrixCSC on both sides (what the shim's Base.sum pays in PCIe)
+    try:
+        want("cfg_mt_sum")
+        dim, npd, p = 2, fem2d, 16
+        if npd <= 0:
+            raise _Skip()
+        nn, nloc, W = npd ** dim, dim + 1, dim + 2
+        q = npd - 1
+        nc = 2 * q * q
+        E = nc * nloc * W
+        home = esp.SparseMatrixHIPCOO(nn, nn, device=local)
+        xs = [esp.SparseMatrixHIPCOO(nn, nn, device=local) for _ in range(p)]
+        cn = torch.empty((nc, nloc), dtype=torch.int64, device="cuda")
+        em = torch.empty((nc, nloc, nloc), dtype=torch.float64, device="cuda")
+        dg = torch.empty((nc, nloc), dtype=torch.float64, device="cuda")
+        A0 = esp.ExtendableSparseMatrix(nn, nn, device=local)
+        # (the mesh in its natural cell order: a partition = a contiguous chunk of cells = a band of the grid, like the node
+        # partitions of a partitioned grid in test_parallel.jl:57; neighbouring bands share the columns of one grid line)
+        A0.generate_fem_mesh(dim, npd, cn, em, dg, seed=0x5EED0004, order_mode=0)
+        A0.synchronize()
+        cuts = [nc * t // p for t in range(p + 1)]
+        arr = (C.c_void_p * p)(*[x._d.h for x in xs])
+        hd = home._d
+        dts = []
+        Z = 0
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(p)          # (one host thread per partition, like the tasks of testassemble_parallel!)
+
+        def fill(t):
+            xs[t].append_elements(cn[cuts[t]:cuts[t + 1]], em[cuts[t]:cuts[t + 1]], dg[cuts[t]:cuts[t + 1]])
+
+        for it in range(steps + 1):
+            hd.ck(hd.lib.esp_synchronize(hd.h))
+            t0 = time.perf_counter()
+            hd.ck(hd.lib.esp_reset(hd.h))
+            list(pool.map(fill, range(p)))
+            if os.environ.get("ESP_SUM_TRACE"):
+                print("cfg_mt_sum: fills %.3f ms" % ((time.perf_counter() - t0) * 1e3), file=sys.stderr)
+            z, ch = C.c_int64(), C.c_int32()
+            hd.ck(hd.lib.esp_flush_sum(hd.h, arr, p, C.byref(z), C.byref(ch)))
+            hd.ck(hd.lib.esp_synchronize(hd.h))
+            if it > 0:
+                dts.append(time.perf_counter() - t0)
+            Z = z.value
+        dt = sum(dts) / len(dts)
+        # the plug-in form: host matrix in, host matrix out (fresh: the whole CSC comes back; a second flush over the
+        # same pattern moves values only)
+        csc = esp.SparseMatrixCSC(nn, nn)
+        tp = []
+        for it in range(2):
+            list(pool.map(fill, range(p)))
+            t0 = time.perf_counter()
+            csc = esp.SparseMatrixHIPCOO.sum(xs, csc, home=home if it else None)
+            tp.append(time.perf_counter() - t0)
+            if it == 0:
+                home._mirror = None
+                hd.set_csc(csc)
+                home._mirror = (csc.colptr, csc.rowval)
+        algo = 8.0 * nc * nloc * (nloc + 2) + 2 * 16.0 * E + 16.0 * Z + 8.0 * (nn + 1)
+        out["cfg_mt_sum"] = {
+            "workload": "P1 FEM 2-D %d^2 dealt to %d partition buffers (tids: bands of the grid, one host thread each) filled by "
+                        "esp_append_elements, flush! = ONE esp_flush_sum (Base.sum(xmatrices, csc)): every buffer folds by "
+                        "itself, the folds meet in one routed flush" % (npd, p),
+            "ms": dt * 1e3, "nnz_per_s": Z / dt, "final_nnz": Z, "algorithmic_bytes": algo,
+            "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS, "steps": len(dts), "nnz_ok": csc.nnz() == Z,
+            "plugin_fresh_ms": tp[0] * 1e3, "plugin_same_pattern_ms": tp[1] * 1e3}
+        pool.shutdown()
+        del xs, home, cn, em, dg, A0
+    except _Skip:
+        pass
+    except Exception as ex:
+        out["cfg_mt_sum"] = {"error": repr(ex)}
     return out
 
 

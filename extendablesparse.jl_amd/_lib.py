@@ -57,6 +57,7 @@ SIGNATURES = {
     "esp_stage_begin": (i32, [vp, i64, P(vp), P(vp), P(vp), P(vp), P(i64)]),
     "esp_commit": (i32, [vp, i64, i32, i32]),
     "esp_append_host": (i32, [vp, vp, vp, vp, vp, i32, i32, i64]),
+    "esp_append_host_i32": (i32, [vp, vp, vp, vp, vp, i32, i32, i64]),
     "esp_append_device": (i32, [vp, vp, vp, vp, vp, i32, i32, i64]),
     "esp_append_packed": (i32, [vp, vp, vp, i64]),
     "esp_generate_fdrand": (i32, [vp, i64, i64, i64, u64, i32, i32]),

@@ -1,6 +1,11 @@
 // handle.hip -- libesparse_hip: lifetime, buffers, append, CSC in and out, timing, debug getters (see internal.hpp for the map of the translation units)
 #include "internal.hpp"
 
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <mutex>
+
 thread_local std::string g_err;
 
 int32_t ensure(esp_handle *h, DevBuf &b, size_t need, bool keep) {
@@ -424,29 +429,189 @@ extern "C" int32_t esp_commit(esp_handle *h, int64_t count, int32_t kind_all, in
                        kind_all < 0 ? (const uint8_t *)h->stage.d_kinds.p : nullptr, kind_all, op, count);
 }
 
-// host memcpy with a few threads: one core moves ~10 GB/s, PCIe takes ~55 GB/s
+// A small pool of host threads for the copies and conversions of the host boundary (one core moves 10-20 GB/s, PCIe takes
+// ~55 GB/s and the conversions touch 2-3 bytes per byte moved): created on first use, shared by all handles; a call that
+// finds the pool busy (another handle's host thread) runs its parts itself.
+namespace {
+struct HostPool {
+    std::mutex m, busy;
+    std::condition_variable cv_go, cv_done;
+    std::vector<std::thread> th;
+    const std::function<void(int)> *job = nullptr;
+    int nparts = 0, next = 0, pending = 0;
+    unsigned long long epoch = 0;
+    bool stop = false;
+    int size() const { return (int)th.size(); }
+    void start() {
+        const unsigned hw = std::thread::hardware_concurrency();
+        unsigned want = 8u;  // (measured on the 2-socket EPYC of the GPU box: 4 and 8 threads pack at the rate PCIe takes, 16 are slower)
+        if (const char *e = getenv("ESP_HOST_THREADS")) want = (unsigned)std::max(1, atoi(e));  // (experiments)
+        const int n = (int)std::max(1u, std::min(want, hw > 2 ? hw - 1 : 1u)) - 1 > 0 ? (int)std::max(1u, std::min(want, hw > 2 ? hw - 1 : 1u)) - 1 : 1;  // (the caller works too)
+        for (int i = 0; i < n; i++)
+            th.emplace_back([this] {
+                unsigned long long seen = 0;
+                std::unique_lock<std::mutex> lk(m);
+                for (;;) {
+                    cv_go.wait(lk, [&] { return stop || (epoch != seen && next < nparts); });
+                    if (stop) return;
+                    while (next < nparts) {
+                        const int part = next++;
+                        const std::function<void(int)> *f = job;
+                        lk.unlock();
+                        (*f)(part);
+                        lk.lock();
+                        if (--pending == 0) cv_done.notify_all();
+                    }
+                    seen = epoch;
+                }
+            });
+    }
+    ~HostPool() {
+        {
+            std::lock_guard<std::mutex> lk(m);
+            stop = true;
+        }
+        cv_go.notify_all();
+        for (auto &t : th) t.join();
+    }
+    // fn(part) for part = 0 .. parts-1, the caller takes parts too; returns when all are done
+    void run(int parts, const std::function<void(int)> &fn) {
+        if (parts <= 1 || !busy.try_lock()) {
+            for (int p = 0; p < parts; p++) fn(p);
+            return;
+        }
+        {
+            std::lock_guard<std::mutex> lk(m);
+            if (th.empty()) start();
+            job = &fn, nparts = parts, next = 0, pending = parts;
+            epoch++;
+        }
+        cv_go.notify_all();
+        {
+            std::unique_lock<std::mutex> lk(m);
+            while (next < nparts) {
+                const int part = next++;
+                lk.unlock();
+                fn(part);
+                lk.lock();
+                --pending;
+            }
+            cv_done.wait(lk, [&] { return pending == 0; });
+            job = nullptr;
+        }
+        busy.unlock();
+    }
+};
+HostPool &host_pool() {
+    static HostPool p;
+    return p;
+}
+// [0, count) cut into parts of at least min_part elements, at most `cap` parts
+template <typename F>
+void host_parallel(size_t count, size_t min_part, int cap, F body) {
+    static const int env_cap = [] {
+        const char *e = getenv("ESP_HOST_THREADS");
+        return e ? std::max(1, atoi(e)) + 1 : 1 << 20;
+    }();
+    cap = std::min(cap, env_cap);
+    const int parts = (int)std::max<size_t>(1, std::min<size_t>((size_t)cap, count / std::max<size_t>(min_part, 1)));
+    const size_t part = (count + (size_t)parts - 1) / (size_t)parts;
+    const std::function<void(int)> fn = [&](int p) { body(std::min(count, (size_t)p * part), std::min(count, ((size_t)p + 1) * part)); };
+    host_pool().run(parts, fn);
+}
+}  // namespace
+
 void par_memcpy(void *dst, const void *src, size_t bytes) {
-    const size_t min_part = (size_t)4 << 20;
-    int nt = (int)std::min<size_t>(4, bytes / min_part);
-    if (nt <= 1) {
-        memcpy(dst, src, bytes);
-        return;
-    }
-    std::thread th[4];
-    const size_t part = ((bytes / (size_t)nt) + 63) & ~(size_t)63;
-    for (int i = 0; i < nt; i++) {
-        const size_t o = (size_t)i * part;
-        const size_t c = i == nt - 1 ? bytes - o : part;
-        th[i] = std::thread([=] { memcpy((char *)dst + o, (const char *)src + o, c); });
-    }
-    for (int i = 0; i < nt; i++) th[i].join();
+    host_parallel(bytes, (size_t)2 << 20, 8, [=](size_t a, size_t b) {
+        const size_t a64 = a & ~(size_t)63, b64 = b == bytes ? b : (b & ~(size_t)63);  // (parts start on 64-byte boundaries)
+        if (b64 > a64) memcpy((char *)dst + a64, (const char *)src + a64, b64 - a64);
+    });
 }
 
-// Bulk append from host arrays: the batch goes through the pinned staging area in chunks, two halves in
-// flight (the host copy of chunk i+1 overlaps the PCIe transfer and the pack kernel of chunk i); bounds
-// are checked on the device and read back ONCE: the call is one batch, nothing is committed on error.
-extern "C" int32_t esp_append_host(esp_handle *h, const int64_t *rows, const int64_t *cols, const double *vals,
-                                   const uint8_t *kinds, int32_t kind_all, int32_t op, int64_t count) {
+// Packing on the host: (row, col[, kind]) -> the packed key of the handle's layout, values copied (negated for op = SUB
+// unless the kind is SET), with a few threads; *bad = smallest index (relative to index_base) of an entry outside m x n
+// or of a bad kind (BoundsError), else left alone.  The boundary then moves 16 bytes per entry over PCIe instead of 24
+// (25 with kinds), straight into the append buffer: no staging arrays on the device, no pack kernel.
+// (one block of host_pack: branch-free, compiled for AVX-512 / AVX2 as well and picked at load time -- the library itself is
+// built for the baseline x86-64)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define ESP_HOST_SIMD  // (the device pass of hipcc parses host functions too and knows no x86 function multiversioning)
+#else
+#define ESP_HOST_SIMD __attribute__((target_clones("avx512f", "avx2", "default")))
+#endif
+// (function multiversioning does not take templates: one pair of overloads per index type)
+#define ESP_PACK_BLOCKS(TI)                                                                                                                          \
+    ESP_HOST_SIMD static u64 pack_block_one(const TI *rows, const TI *cols, const double *vals, u64 kind, bool neg, i64 cnt, u64 um, u64 un, int rb,  \
+                                            u64 *keys_out, double *vals_out) {                                                                      \
+        u64 anybad = 0;                                                                                                                              \
+        for (i64 i = 0; i < cnt; i++) {                                                                                                              \
+            const u64 r0 = (u64)(i64)rows[i] - 1ull, c0 = (u64)(i64)cols[i] - 1ull;                                                                  \
+            anybad |= (u64)(r0 >= um) | (u64)(c0 >= un);                                                                                             \
+            keys_out[i] = (((c0 << rb) | r0) << ESP_TAG_BITS) | kind;                                                                                \
+        }                                                                                                                                            \
+        if (neg)                                                                                                                                     \
+            for (i64 i = 0; i < cnt; i++) vals_out[i] = -vals[i];                                                                                    \
+        else                                                                                                                                         \
+            memcpy(vals_out, vals, sizeof(double) * (size_t)cnt);                                                                                    \
+        return anybad;                                                                                                                               \
+    }                                                                                                                                                \
+    ESP_HOST_SIMD static u64 pack_block_kinds(const TI *rows, const TI *cols, const double *vals, const uint8_t *kinds, bool negate, i64 cnt, u64 um, \
+                                              u64 un, int rb, u64 *keys_out, double *vals_out) {                                                    \
+        u64 anybad = 0;                                                                                                                              \
+        for (i64 i = 0; i < cnt; i++) {                                                                                                              \
+            const u64 r0 = (u64)(i64)rows[i] - 1ull, c0 = (u64)(i64)cols[i] - 1ull, kind = (u64)kinds[i];                                            \
+            anybad |= (u64)(r0 >= um) | (u64)(c0 >= un) | (u64)(kind > 3ull);                                                                        \
+            keys_out[i] = (((c0 << rb) | r0) << ESP_TAG_BITS) | kind;                                                                                \
+            const double v = vals[i];                                                                                                                \
+            vals_out[i] = (negate && kind != (u64)ESP_SET) ? -v : v;                                                                                 \
+        }                                                                                                                                            \
+        return anybad;                                                                                                                               \
+    }
+ESP_PACK_BLOCKS(int64_t)
+ESP_PACK_BLOCKS(int32_t)
+#undef ESP_PACK_BLOCKS
+
+template <typename TI>
+static void host_pack(const TI *rows, const TI *cols, const double *vals, const uint8_t *kinds, int kind_all, bool negate, i64 count, i64 m, i64 n,
+                      KeyLayout L, u64 *keys_out, double *vals_out, i64 index_base, std::atomic<i64> *bad) {
+    host_parallel((size_t)count, (size_t)1 << 17, 8, [=](size_t sa_, size_t sb_) {
+        const i64 a = (i64)sa_, b = (i64)sb_;
+        i64 first_bad = -1;
+        // blocks of 2048 entries without a branch (the compiler vectorises them): range checks as unsigned compares,
+        // OR-ed into one flag; only a block that raised it is walked again for the first offender
+        const u64 um = (u64)m, un = (u64)n;
+        const int rb = L.rb;
+        for (i64 i0 = a; i0 < b; i0 += 2048) {
+            const i64 i1 = std::min(b, i0 + 2048);
+            const u64 anybad = kinds ? pack_block_kinds(rows + i0, cols + i0, vals + i0, kinds + i0, negate, i1 - i0, um, un, rb, keys_out + i0, vals_out + i0)
+                                     : pack_block_one(rows + i0, cols + i0, vals + i0, (u64)kind_all, negate && kind_all != ESP_SET, i1 - i0, um, un, rb,
+                                                          keys_out + i0, vals_out + i0);
+            if (anybad && first_bad < 0) {
+                for (i64 i = i0; i < i1; i++) {
+                    const i64 r = (i64)rows[i], c = (i64)cols[i];
+                    const int kind = kinds ? (int)kinds[i] : kind_all;
+                    if (!(1 <= r && r <= m && 1 <= c && c <= n) || kind < 0 || kind > 3) {
+                        first_bad = i;
+                        break;
+                    }
+                }
+            }
+        }
+        if (first_bad >= 0) {
+            i64 cur = bad->load();
+            const i64 mine = index_base + first_bad;
+            while ((cur < 0 || mine < cur) && !bad->compare_exchange_weak(cur, mine)) {
+            }
+        }
+    });
+}
+
+// Bulk append from host arrays: the batch is packed on the host (host_pack) into the pinned staging area in chunks, two
+// halves in flight -- the packing of chunk i+1 overlaps the PCIe transfer of chunk i, which lands in the append buffer
+// itself; the call is one batch: nothing is committed when an index lies outside the matrix.
+template <typename TI>
+static int32_t append_host_t(esp_handle *h, const TI *rows, const TI *cols, const double *vals, const uint8_t *kinds, int32_t kind_all, int32_t op,
+                             int64_t count) {
     if (!h || count < 0 || (count > 0 && (!rows || !cols || !vals))) return ESP_ERR_INVALID;
     if (count == 0) return ESP_OK;
     (void)hipSetDevice(h->device);
@@ -454,52 +619,63 @@ extern "C" int32_t esp_append_host(esp_handle *h, const int64_t *rows, const int
     if (op != ESP_OP_ADD && op != ESP_OP_SUB) FAIL(h, ESP_ERR_UNSUPPORTED, "append: op %d not supported on the device path", op);
     const i64 chunk = std::min<i64>((i64)1 << 22, std::max<i64>(count, 1));
     esp_handle::StageArea &sa = h->bulk;
-    CK(ensure_stage(h, sa, 2 * chunk));
+    CK(ensure_stage(h, sa, 2 * chunk));  // (its `rows` half holds packed keys here, `vals` the values; the device mirrors stay unused)
     CK(reserve_append(h, count));
-    CK(ensure(h, h->misc, 256));
-    unsigned long long *d_err = (unsigned long long *)h->misc.p;
-    h->pin_scalar[0] = ~0ull;
-    HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 8, hipMemcpyHostToDevice, h->stream));
     hipEvent_t done[2] = {nullptr, nullptr};
     for (int i = 0; i < 2; i++) HIPCK(h, hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
+    std::atomic<i64> bad(-1);
     int32_t rc = ESP_OK;
     i64 it = 0;
-    for (i64 off = 0; off < count && rc == ESP_OK; off += chunk, it++) {
+    const bool trace = getenv("ESP_HOST_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t_wait = 0.0, t_pack = 0.0;
+    const double t_begin = now();
+    for (i64 off = 0; off < count && rc == ESP_OK && bad.load() < 0; off += chunk, it++) {
         const i64 c = std::min<i64>(chunk, count - off);
         const int half = (int)(it & 1);
-        const i64 so = half ? chunk : 0;  // this half of the staging arrays (host and device)
+        const i64 so = half ? chunk : 0;  // this half of the pinned arrays
+        const double t0 = now();
         if (it >= 2 && hipEventSynchronize(done[half]) != hipSuccess) rc = ESP_ERR_HIP;
-        par_memcpy(sa.rows + so, rows + off, sizeof(i64) * (size_t)c);
-        par_memcpy(sa.cols + so, cols + off, sizeof(i64) * (size_t)c);
-        par_memcpy(sa.vals + so, vals + off, sizeof(double) * (size_t)c);
-        if (kinds) memcpy(sa.kinds + so, kinds + off, (size_t)c);
-        i64 *dr = (i64 *)sa.d_rows.p + so, *dc = (i64 *)sa.d_cols.p + so;
-        double *dv = (double *)sa.d_vals.p + so;
-        uint8_t *dk = (uint8_t *)sa.d_kinds.p + so;
+        const double t1 = now();
+        t_wait += t1 - t0;
+        host_pack<TI>(rows + off, cols + off, vals + off, kinds ? kinds + off : nullptr, kind_all, op == ESP_OP_SUB, c, h->m, h->n, h->L,
+                      (u64 *)sa.rows + so, sa.vals + so, off, &bad);
+        t_pack += now() - t1;
         Span sp(h, ESP_ST_COPY);
-        if (hipMemcpyAsync(dr, sa.rows + so, sizeof(i64) * (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-            hipMemcpyAsync(dc, sa.cols + so, sizeof(i64) * (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-            hipMemcpyAsync(dv, sa.vals + so, sizeof(double) * (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-            (kinds && hipMemcpyAsync(dk, sa.kinds + so, (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess))
+        if (hipMemcpyAsync((u64 *)h->keys.p + h->count + off, (u64 *)sa.rows + so, sizeof(u64) * (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+            hipMemcpyAsync((double *)h->vals.p + h->count + off, sa.vals + so, sizeof(double) * (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess)
             rc = ESP_ERR_HIP;
-        sp.add(kinds ? 4 : 3);
-        hipLaunchKernelGGL(espgen::pack_k, dim3(grid_for(c, espgen::THREADS)), dim3(espgen::THREADS), 0, h->stream, (const i64 *)dr,
-                           (const i64 *)dc, (const double *)dv, kinds ? (const uint8_t *)dk : nullptr, kind_all, op == ESP_OP_SUB ? 1 : 0, c,
-                           h->m, h->n, h->L, (u64 *)h->keys.p + h->count + off, (double *)h->vals.p + h->count + off, d_err, off);
+        sp.add(2);
         (void)hipEventRecord(done[half], h->stream);
     }
-    hipError_t e1 = hipMemcpyAsync(h->pin_scalar, d_err, 8, hipMemcpyDeviceToHost, h->stream);
-    hipError_t e2 = hipStreamSynchronize(h->stream);
+    const hipError_t e2 = hipStreamSynchronize(h->stream);
+    if (trace)
+        fprintf(stderr, "esp_append_host: %lld entries in %lld chunks: %.2f ms (packing %.2f, waiting for transfers %.2f), pool of %d\n", (long long)count,
+                (long long)it, now() - t_begin, t_pack, t_wait, host_pool().size());
     for (int i = 0; i < 2; i++) (void)hipEventDestroy(done[i]);
-    if (rc != ESP_OK || e1 != hipSuccess || e2 != hipSuccess || hipGetLastError() != hipSuccess)
+    if (rc != ESP_OK || e2 != hipSuccess) {
+        h->pre_keep = false;
         FAIL(h, ESP_ERR_HIP, "esp_append_host: transfer failed");
-    if (h->pin_scalar[0] != ~0ull)
-        FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
-             (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
+    }
+    if (bad.load() >= 0) {
+        h->pre_keep = false;
+        FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %lld of the batch has an index outside %lld x %lld (or a bad kind)", (long long)(bad.load() + 1),
+             (long long)h->m, (long long)h->n);
+    }
     if (!kinds) note_kind(h, kind_all, count);
     h->count += count;
     pending_changed(h);
     return ESP_OK;
+}
+
+extern "C" int32_t esp_append_host(esp_handle *h, const int64_t *rows, const int64_t *cols, const double *vals, const uint8_t *kinds,
+                                   int32_t kind_all, int32_t op, int64_t count) {
+    return append_host_t<int64_t>(h, rows, cols, vals, kinds, kind_all, op, count);
+}
+// the same for Int32 index arrays (ExtendableSparseMatrix{Float64, Int32}: extendable.jl:10-25 is generic in Ti)
+extern "C" int32_t esp_append_host_i32(esp_handle *h, const int32_t *rows, const int32_t *cols, const double *vals, const uint8_t *kinds,
+                                       int32_t kind_all, int32_t op, int64_t count) {
+    return append_host_t<int32_t>(h, rows, cols, vals, kinds, kind_all, op, count);
 }
 
 extern "C" int32_t esp_append_device(esp_handle *h, const int64_t *d_rows, const int64_t *d_cols, const double *d_vals,
@@ -603,17 +779,66 @@ int32_t d2h_pipelined(esp_handle *h, void *dst, const void *d_src, size_t bytes)
     return ESP_OK;
 }
 
+// Int64 -> u32 on the device, u32 -> Int64 on the way from the bounce buffers into the caller's array: row indices (and
+// colptr values) of a matrix with fewer than 2^32 rows (entries) cross PCIe as 4 bytes
+static __global__ void narrow_i64_k(const i64 *__restrict__ in, i64 n, u32 *__restrict__ out) {
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) out[g] = (u32)in[g];
+}
+static void par_widen(i64 *dst, const u32 *src, size_t count) {
+    host_parallel(count, (size_t)1 << 18, 8, [=](size_t a, size_t b) {
+        for (size_t i = a; i < b; i++) dst[i] = (i64)src[i];
+    });
+}
+// `count` Int64 values of device array d_src (all below 2^32) into dst: narrowed by a kernel into scratch, moved as u32
+// through the two pinned bounce buffers, widened by the host copy that fills the caller's array anyway
+static int32_t d2h_narrow(esp_handle *h, i64 *dst, const i64 *d_src, i64 count, DevBuf &scratch) {
+    if (count == 0) return ESP_OK;
+    CK(ensure(h, scratch, sizeof(u32) * (size_t)count));
+    hipLaunchKernelGGL(narrow_i64_k, dim3(grid_for(count, 256)), dim3(256), 0, h->stream, d_src, count, (u32 *)scratch.p);
+    HIPCK(h, hipGetLastError());
+    CK(ensure_stage(h, h->bulk, (i64)1 << 22));
+    char *pin[2] = {(char *)h->bulk.rows, (char *)h->bulk.cols};
+    const size_t chunk = (size_t)h->bulk.cap * 8 / sizeof(u32);  // elements per bounce buffer
+    hipEvent_t ev[2] = {nullptr, nullptr};
+    for (int i = 0; i < 2; i++) HIPCK(h, hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    const size_t total = (size_t)count, nchunks = (total + chunk - 1) / chunk;
+    int32_t rc = ESP_OK;
+    for (size_t c = 0; c <= nchunks && rc == ESP_OK; c++) {
+        if (c < nchunks) {
+            const size_t o = c * chunk, len = std::min(chunk, total - o);
+            if (hipMemcpyAsync(pin[c & 1], (const u32 *)scratch.p + o, sizeof(u32) * len, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
+                hipEventRecord(ev[c & 1], h->stream) != hipSuccess)
+                rc = ESP_ERR_HIP;
+        }
+        if (c > 0 && rc == ESP_OK) {
+            const size_t o = (c - 1) * chunk, len = std::min(chunk, total - o);
+            if (hipEventSynchronize(ev[(c - 1) & 1]) != hipSuccess) rc = ESP_ERR_HIP;
+            else par_widen(dst + o, (const u32 *)pin[(c - 1) & 1], len);
+        }
+    }
+    (void)hipStreamSynchronize(h->stream);
+    for (int i = 0; i < 2; i++) (void)hipEventDestroy(ev[i]);
+    if (rc != ESP_OK) FAIL(h, ESP_ERR_HIP, "device-to-host transfer failed");
+    return ESP_OK;
+}
+
 extern "C" int32_t esp_get_csc(esp_handle *h, int64_t *colptr, int64_t *rowval, double *nzval) {
     if (!h || !colptr) return ESP_ERR_INVALID;
     (void)hipSetDevice(h->device);
     CK(fix_tail(h));
     if (h->nnz > 0 && (!rowval || !nzval)) FAIL(h, ESP_ERR_INVALID, "esp_get_csc: rowval/nzval NULL with nnz>0");
     Span sp(h, ESP_ST_COPY);
-    CK(d2h_pipelined(h, colptr, h->colptr.p, sizeof(i64) * (size_t)(h->n + 1)));
-    if (h->nnz > 0) {
-        CK(d2h_pipelined(h, rowval, h->rowval.p, sizeof(i64) * (size_t)h->nnz));
-        CK(d2h_pipelined(h, nzval, h->nzval.p, sizeof(double) * (size_t)h->nnz));
+    // (large matrices whose indices fit 32 bits: colptr and rowval cross PCIe as u32 -- 12 instead of 16 bytes per entry)
+    const bool narrow = h->nnz >= ((i64)1 << 20) && h->m < ((i64)1 << 32) && h->nnz + 1 < ((i64)1 << 32) && !getenv("ESP_NO_NARROW_D2H");
+    if (narrow) {
+        CK(d2h_narrow(h, colptr, (const i64 *)h->colptr.p, h->n + 1, h->heads));
+        CK(d2h_narrow(h, rowval, (const i64 *)h->rowval.p, h->nnz, h->heads));
+    } else {
+        CK(d2h_pipelined(h, colptr, h->colptr.p, sizeof(i64) * (size_t)(h->n + 1)));
+        if (h->nnz > 0) CK(d2h_pipelined(h, rowval, h->rowval.p, sizeof(i64) * (size_t)h->nnz));
     }
+    if (h->nnz > 0) CK(d2h_pipelined(h, nzval, h->nzval.p, sizeof(double) * (size_t)h->nnz));
     sp.add(3);
     return ESP_OK;
 }

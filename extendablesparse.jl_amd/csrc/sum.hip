@@ -2,6 +2,8 @@
 // of a plug-in whose CSC stays attached to its handle between flushes
 #include "internal.hpp"
 
+#include <chrono>
+
 namespace {
 
 // the entries of a device CSC as COO-kind pending entries (column-major = the CSC's own order: a pre-sorted stream)
@@ -46,19 +48,34 @@ extern "C" int32_t esp_flush_sum(esp_handle *dst, esp_handle *const *xs, int32_t
         if (new_nnz) *new_nnz = dst->nnz;
         return ESP_OK;
     }
-    // 1. every buffer's own fold
+    const bool trace = getenv("ESP_SUM_TRACE") != nullptr;
+    auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t_a = now();
+    // 1. every buffer's own fold: the buffers are independent handles with streams of their own, so their flushes -- a
+    // few dozen small launches and three or four host round trips each -- run side by side, one host thread per buffer
+    // (as the reference's partitions are assembled by one task each: test/femtools.jl:88-110)
     i64 folded = 0;
-    for (int k = 0; k < p; k++) {
-        esp_handle *x = xs[k];
-        if (x->count == 0) continue;
-        int64_t z = 0;
-        const int32_t rc = esp_flush(x, ESP_FLUSH_ROUTED, &z, nullptr);
-        if (rc != ESP_OK) {
-            dst->err = x->err;
-            return rc;
+    {
+        std::vector<int32_t> rcs((size_t)p, ESP_OK);
+        std::vector<int64_t> zs((size_t)p, 0);
+        const int WIDTH = 16;  // host threads at a time
+        for (int k0 = 0; k0 < p; k0 += WIDTH) {
+            std::vector<std::thread> th;
+            for (int k = k0; k < std::min(p, k0 + WIDTH); k++) {
+                if (xs[k]->count == 0) continue;
+                th.emplace_back([&, k] { rcs[(size_t)k] = esp_flush(xs[k], ESP_FLUSH_ROUTED, &zs[(size_t)k], nullptr); });
+            }
+            for (auto &t : th) t.join();
         }
-        folded += z;
+        for (int k = 0; k < p; k++) {
+            if (rcs[(size_t)k] != ESP_OK) {
+                dst->err = xs[k]->err;
+                return rcs[(size_t)k];
+            }
+            folded += zs[(size_t)k];
+        }
     }
+    const double t_b = now();
     // 2. their entries behind one another in dst's buffer (dst's stream waits for each buffer's flush: esp_flush returned
     // after its last host round trip, but kernels of the buffer's stream may still run)
     if (folded > 0) {
@@ -81,7 +98,13 @@ extern "C" int32_t esp_flush_sum(esp_handle *dst, esp_handle *const *xs, int32_t
         pending_changed(dst);
     }
     // 3. the one flush that meets the stored matrix
+    const double t_c = now();
     const int32_t rc = esp_flush(dst, ESP_FLUSH_ROUTED, new_nnz, pattern_changed);
+    if (trace) {
+        (void)hipStreamSynchronize(dst->stream);
+        fprintf(stderr, "esp_flush_sum: %d buffers %lld entries -> folds %.3f ms (%lld entries), gather %.3f ms, combine flush %.3f ms\n", p, (long long)total,
+                t_b - t_a, (long long)folded, t_c - t_b, now() - t_c);
+    }
     // (the buffers are consumed whatever happened: genericmtextendablesparsematrixcsc.jl:47-49 replaces them all)
     HIPCK(dst, hipStreamSynchronize(dst->stream));
     for (int k = 0; k < p; k++) (void)esp_reset(xs[k]);

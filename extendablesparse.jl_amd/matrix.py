@@ -168,14 +168,16 @@ class _Handle:
 
     def append(self, kind, I, J, V, op=ESP_OP_ADD, kinds=None):
         self.commit()
-        I = np.ascontiguousarray(I, np.int64)
-        J = np.ascontiguousarray(J, np.int64)
+        i32 = getattr(I, "dtype", None) == np.int32 and getattr(J, "dtype", None) == np.int32   # (Ti = Int32 arrays go as they are)
+        I = np.ascontiguousarray(I, np.int32 if i32 else np.int64)
+        J = np.ascontiguousarray(J, np.int32 if i32 else np.int64)
         V = np.ascontiguousarray(V, np.float64)
         kp = None
         if kinds is not None:
             kinds = np.ascontiguousarray(kinds, np.uint8)
             kp = _vp(kinds)
-        self.ck(self.lib.esp_append_host(self.h, _vp(I), _vp(J), _vp(V), kp, kind, op, len(I)))
+        fn = self.lib.esp_append_host_i32 if i32 else self.lib.esp_append_host
+        self.ck(fn(self.h, _vp(I), _vp(J), _vp(V), kp, kind, op, len(I)))
 
     def append_device(self, kind, I, J, V, op=ESP_OP_ADD, kinds=None):
         """esp_append_device: I, J (int64), V (float64) [, kinds (uint8)] are arrays resident in this GPU's memory --
@@ -323,6 +325,10 @@ class SparseMatrixHIPCOO:
     def append(self, kind, I, J, V, op="+", kinds=None):
         """Bulk form of the three calls above (one C call for the whole batch)."""
         self._d.append(kind, I, J, V, _op(op), kinds)
+
+    def append_elements(self, cellnodes, elmat, diag=None, kind=ESP_RAWUPDATE, op="+"):
+        """The assembly loop of test/femtools.jl:61-69 over element arrays, into this buffer (see _Handle.append_elements)."""
+        self._d.append_elements(kind, cellnodes, elmat, diag, _op(op))
 
     def __add__(self, csc):
         """Base.:+(ext, csc) -> SparseMatrixCSC (sparsematrixlnk.jl:294-383): THE flush.  The handle keeps the result on

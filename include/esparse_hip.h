@@ -122,6 +122,12 @@ int32_t esp_commit(esp_handle *h, int64_t count, int32_t kind_all, int32_t op);
 int32_t esp_append_host(esp_handle *h, const int64_t *rows, const int64_t *cols,
                         const double *vals, const uint8_t *kinds, int32_t kind_all, int32_t op,
                         int64_t count);
+/* the same for Int32 index arrays (ExtendableSparseMatrix{Float64,Int32}: extendable.jl:10-25 is generic in Ti; the CSC
+ * the library hands back is Int64 all the same).  Both pack (row, col, kind) into 8-byte keys on the host: the batch
+ * crosses PCIe as 16 bytes per entry, whatever the index type */
+int32_t esp_append_host_i32(esp_handle *h, const int32_t *rows, const int32_t *cols,
+                            const double *vals, const uint8_t *kinds, int32_t kind_all, int32_t op,
+                            int64_t count);
 /* device-side producers: arrays already in HBM on this handle's device */
 int32_t esp_append_device(esp_handle *h, const int64_t *d_rows, const int64_t *d_cols,
                           const double *d_vals, const uint8_t *d_kinds, int32_t kind_all,

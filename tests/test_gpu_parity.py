@@ -580,6 +580,40 @@ def test_bucket_kernel_tiers(esp, orc, per_col):
         assert_csc_equal(hip_arrays(A), O.arrays(), "round %d" % rnd)
 
 
+def test_host_append_int32_indices_and_kinds(esp, orc):
+    """esp_append_host_i32 (Ti = Int32 callers) and the host-side packing of esp_append_host: per-entry kinds, `-`, a
+    BoundsError in a later chunk of a large batch (nothing is committed), against the oracle."""
+    rng = np.random.default_rng(31)
+    m, n, cnt = 1_000_003, 900_001, 600000       # (short columns: the oracle's list walks stay short)
+    I = rng.integers(1, m + 1, cnt)
+    J = rng.integers(1, n + 1, cnt)
+    V = np.where(rng.random(cnt) < 0.05, 0.0, rng.standard_normal(cnt))
+    K = rng.choice(np.array([0, 1, 2], np.uint8), cnt)
+    O = orc.ExtendableSparseMatrix(m, n)
+    O.apply(K, I, J, V)
+    O.apply(np.full(cnt, UPDATE, np.uint8), I, J, -V)
+    A = esp.ExtendableSparseMatrix(m, n)
+    A.append(0, I.astype(np.int32), J.astype(np.int32), V, kinds=K)          # Int32 arrays go as they are
+    A.append(UPDATE, I, J, V, op="-")
+    assert A.nnznew() == 2 * cnt
+    A.flush()
+    assert_csc_equal(hip_arrays(A), O.arrays(), "int32 + int64 host appends")
+    big = 9_000_000                                                          # three chunks of the staging area
+    Ib = rng.integers(1, m + 1, big).astype(np.int32)
+    Jb = rng.integers(1, n + 1, big).astype(np.int32)
+    Vb = rng.standard_normal(big)
+    Jb[8_500_000] = n + 1
+    with pytest.raises(esp.BoundsError) as ei:
+        A.append(UPDATE, Ib, Jb, Vb)
+    assert "8500001" in str(ei.value) and A.nnznew() == 0
+    Jb[8_500_000] = 1
+    A.append(UPDATE, Ib, Jb, Vb)
+    O.apply(np.full(big, UPDATE, np.uint8), Ib.astype(np.int64), Jb.astype(np.int64), Vb)
+    A.flush()
+    O.flush()
+    assert_csc_equal(hip_arrays(A), O.arrays(), "large int32 batch")
+
+
 def test_append_device_entry_point(esp, orc):
     """esp_append_device (triplets resident in GPU memory) by itself: on an empty buffer a pre-sorted batch of one kind is
     partitioned as it is appended (esp_debug_last_partition 4), an unsorted one or one with a kinds array is packed in

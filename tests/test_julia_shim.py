@@ -96,7 +96,9 @@ def test_shim_binds_what_integration_md_lists():
             "esp_clone", "esp_append_host", "esp_pattern_hash", "esp_mul", "esp_mark_dirichlet", "esp_eliminate_dirichlet",
             "esp_jacobi_setup", "esp_ilu0_setup", "esp_reset", "esp_release_buffers", "esp_last_error",
             "esp_group_unique_id", "esp_group_create", "esp_group_destroy", "esp_group_flush", "esp_group_nnz",
-            "esp_group_column_range", "esp_group_get_csc"}
+            "esp_group_column_range", "esp_group_get_csc",
+            # round 4: one-call Base.sum, values-only transfers of the plug-in that keeps its CSC attached, element-level assembly
+            "esp_flush_sum", "esp_set_nzval", "esp_get_nzval", "esp_append_elements_host"}
     assert need <= called, sorted(need - called)
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     hdr = open(HDR).read()
