@@ -119,6 +119,7 @@ SIGNATURES = {
     "esp_debug_last_fold_update": (i32, [vp, P(i32)]),
     "esp_debug_last_path": (i32, [vp, P(i32)]),
     "esp_debug_last_partition": (i32, [vp, P(i32)]),
+    "esp_debug_last_plan_reused": (i32, [vp, P(i32)]),
 }
 
 # esp_comm_t: the host-supplied transport of esp_group_create_comm

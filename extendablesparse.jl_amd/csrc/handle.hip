@@ -210,6 +210,7 @@ extern "C" int32_t esp_release_buffers(esp_handle *h) {
     h->count = 0;
     h->chunk_cap = 0;
     h->chunk_pb = 0;
+    h->rawplan.valid = false;
     pending_changed(h);
     h->csc_valid = false;
     h->ones_pending = false;
@@ -910,6 +911,11 @@ extern "C" int32_t esp_debug_last_key_bytes(const esp_handle *h, int32_t *bytes)
 extern "C" int32_t esp_debug_last_colptr_direct(const esp_handle *h, int32_t *direct) {
     if (!h || !direct) return ESP_ERR_INVALID;
     *direct = h->last_colptr_direct;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_last_plan_reused(const esp_handle *h, int32_t *reused) {
+    if (!h || !reused) return ESP_ERR_INVALID;
+    *reused = h->last_plan_reused;
     return ESP_OK;
 }
 extern "C" int32_t esp_debug_last_partition(const esp_handle *h, int32_t *kind) {

@@ -94,6 +94,17 @@ struct esp_handle {
         i64 T = 0, maxlen = 0;
         u64 base = 0, span = 0;
     } tailpart;
+    // A caller that repeats its stream (a time-stepping code: the same triplets' positions every step): the run lists,
+    // run offsets and bucket starts of the last append-is-the-partition of caller-supplied triplets (append_partitioned)
+    // serve the next one -- no count pass over the columns; the scatter kernel checks every tile against its run list
+    // and a stream that is not the same falls back to the full path.  Dropped by whatever rewrites the tables.
+    struct RawPlan {
+        bool valid = false;
+        i64 count = 0, chunks = 0, maxlen = 0;
+        int kind = 0, K = 0, pb = 0, key_bytes = 8;
+        u64 base = 0, span = 0;
+        double Ee = 0.0;
+    } rawplan;
     // sort_msd over ITEM records (femitems.hpp): a segment may hold plan_cap records (the bucket kernel's capacity in
     // updates / updates per item), and a shuffled stream need not be tried as a pre-sorted one
     i64 plan_cap = 0;
@@ -155,6 +166,7 @@ struct esp_handle {
     bool part_own_update = false;  // esp_shard_partition: every pending entry was appended as an UPDATE
     bool part_all_update = false;  // esp_shard_assemble: ... and so is every received entry (checked on the device)
     int last_run_order = 0;      // esp_debug_last_run_order
+    int last_plan_reused = 0;    // the last append-is-the-partition of caller triplets used the previous assembly's run lists
     int last_colptr_direct = 0;  // the bucket kernel of the last flush wrote colptr itself
     hipStream_t aux = nullptr;   // second stream + event: small device-to-host reads beside a running kernel
     hipEvent_t aux_ev = nullptr;  // (created on first use, aux_ready)
@@ -349,7 +361,7 @@ int32_t settle_offset(esp_handle *h);
 int32_t item_produce_fem(esp_handle *h, const espgen::FemArgs &fa, i64 E, bool *took);
 int32_t partition_pass(esp_handle *h, espradix::Pass &p, i64 max_tiles);
 int32_t sort_pending_lsd(esp_handle *h, const u64 **sk, const double **sv);
-int32_t chunk_arrays(esp_handle *h, i64 Ccap, int pb, ChunkArrays *out);
+int32_t chunk_arrays(esp_handle *h, i64 Ccap, int pb, ChunkArrays *out, bool keep_plan = false);
 double plan_entries(i64 E, int K, u64 span);
 int plan_run_bits(i64 E, int K, u64 span);
 int plan_prefix_bits(const esp_handle *h, i64 E, int K, double *Ee_out);

@@ -85,7 +85,8 @@ int32_t sort_pending_lsd(esp_handle *h, const u64 **sk, const double **sv) {
 
 
 
-int32_t chunk_arrays(esp_handle *h, i64 Ccap, int pb, ChunkArrays *out) {
+int32_t chunk_arrays(esp_handle *h, i64 Ccap, int pb, ChunkArrays *out, bool keep_plan) {
+    if (!keep_plan) h->rawplan.valid = false;  // (whoever asks for the run tables is about to rewrite them)
     const i64 NB = (i64)1 << pb;
     const i64 RM = Ccap * esprun::RMAX;
     size_t off = 0;
@@ -438,13 +439,74 @@ int32_t append_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_cols, 
     CK(ensure(h, h->tilef[1], sizeof(u64) * (size_t)(NB + 1 + espscan::workspace_elems(NB + 1))));
     CK(ensure(h, h->misc, 256));
     unsigned long long *d_err = (unsigned long long *)h->misc.p;
-    h->pin_scalar[0] = ~0ull;
-    HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 8, hipMemcpyHostToDevice, h->stream));
-    HIPCK(h, hipMemsetAsync((unsigned long long *)h->misc.p + 24, 0, 64, h->stream));  // maxlen .. the four flag words (run_partition)
     const RawSource raw{d_rows, d_cols, kind, (op == ESP_OP_SUB && kind != ESP_SET) ? 1 : 0, d_err};
     bool tr = false, ok = false;
     i64 ml = count;
     int kb = 8;
+    // the run lists of the previous assembly, when this batch looks like a repetition of it (the scatter kernel checks
+    // every tile; force_path 31: never)
+    const esp_handle::RawPlan rp = h->rawplan;
+    bool reused = false;
+    if (rp.valid && rp.count == count && rp.kind == kind && rp.K == K && rp.pb == pb && rp.base == h->win_base && rp.span == h->win_span &&
+        h->force_path != ESP_PATH_NO_PLAN_REUSE) {
+        const i64 C = ceil_div<i64>(count, esprun::TILE);
+        ChunkArrays ca;
+        CK(chunk_arrays(h, C + 64, pb, &ca, /*keep_plan=*/true));
+        if (C == rp.chunks && h->runbuf.p) {
+            // error word | verify flag, then the longest bucket and the four flag words as the ranking kernel left them
+            h->pin_scalar[0] = ~0ull, h->pin_scalar[1] = 0ull;
+            HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 16, hipMemcpyHostToDevice, h->stream));
+            unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
+            hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, (i64 *)d_maxlen, rp.maxlen, (i64)0, (i64)0, (i64)0);
+            hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, (i64 *)d_maxlen + 4, (i64)0, (i64)0, (i64)0, (i64)0);
+            esprun::Args a;
+            memset(&a, 0, sizeof a);
+            a.vals_in = d_vals;
+            a.keys_out = (u64 *)h->keys.p;
+            a.vals_out = (double *)h->vals.p;
+            a.E = count;
+            a.shift = K - pb;
+            a.base = h->win_base, a.span = h->win_span;
+            a.raw_rows = d_rows, a.raw_cols = d_cols;
+            a.raw_m = h->m, a.raw_n = h->n;
+            a.raw_rb = h->L.rb, a.raw_kind = kind, a.raw_negate = raw.negate;
+            a.raw_err = d_err;
+            a.err = (u32 *)h->misc.p + 60;
+            a.runs_d = ca.runs_d, a.runs_c = ca.runs_c, a.nruns = ca.nruns;
+            a.runs_off = (i64 *)h->runbuf.p;
+            a.nruns_raw = 1;
+            a.maxlen = d_maxlen;
+            a.cap = esplocal::CAP;
+            a.verify_err = (u32 *)(d_err + 1);
+            {
+                Span sp(h, ESP_ST_SCATTER);
+                if (rp.key_bytes == 4)
+                    hipLaunchKernelGGL((esprun::run_scatter_k<false, true, true, true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
+                else
+                    hipLaunchKernelGGL((esprun::run_scatter_k<false, false, true, true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a);
+                sp.add(1);
+            }
+            HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 16, hipMemcpyDeviceToHost, h->stream));
+            HIPCK(h, hipStreamSynchronize(h->stream));
+            HIPCK(h, hipGetLastError());
+            if (h->pin_scalar[0] != ~0ull) {
+                h->rawplan.valid = false;
+                FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
+                     (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
+            }
+            if ((u32)h->pin_scalar[1] == 0u) {
+                reused = true;
+                ok = true, ml = rp.maxlen, kb = rp.key_bytes;
+                Ee = rp.Ee;
+            } else {
+                h->rawplan.valid = false;  // (another stream: the full path below, which makes a plan of its own)
+            }
+        }
+    }
+    if (!reused) {
+    h->pin_scalar[0] = ~0ull;
+    HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 8, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemsetAsync((unsigned long long *)h->misc.p + 24, 0, 64, h->stream));  // maxlen .. the four flag words (run_partition)
     CK(run_partition(h, nullptr, d_vals, (u64 *)h->keys.p, (double *)h->vals.p, K, pb, (i64 *)h->seg[1].p, (u64 *)h->tilef[1].p, &tr, &ok, &ml,
                      nullptr, 0, /*allow_k32=*/true, &kb, count, &raw));
     HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 8, hipMemcpyDeviceToHost, h->stream));
@@ -457,6 +519,14 @@ int32_t append_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_cols, 
         h->runs_skip = h->runs_penalty + 1;
         return ESP_OK;
     }
+    // (the tables of this batch serve the next one that looks the same -- only the ranked flavour leaves them complete)
+    esp_handle::RawPlan &np = h->rawplan;
+    np.valid = h->last_run_order == 1;
+    np.count = count, np.chunks = ceil_div<i64>(count, esprun::TILE), np.maxlen = ml;
+    np.kind = kind, np.K = K, np.pb = pb, np.key_bytes = kb;
+    np.base = h->win_base, np.span = h->win_span, np.Ee = Ee;
+    }
+    h->last_plan_reused = reused ? 1 : 0;
     h->runs_penalty = 0;
     esp_handle::PrePart &pp = h->pre;
     pp.K = K;
@@ -539,6 +609,7 @@ int32_t append_tail_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_c
 }
 
 int32_t sort_msd(esp_handle *h, Sorted *out) {
+    h->rawplan.valid = false;  // (the segment tables are rewritten)
     const i64 E = h->count;
     // sort bits of the key window: (key>>2) - win_base lies in [0, win_span)
     int K = 1;

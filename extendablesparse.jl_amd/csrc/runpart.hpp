@@ -74,6 +74,9 @@ struct Args {
     i64 raw_m = 0, raw_n = 0;
     int raw_rb = 0, raw_kind = 0, raw_negate = 0;
     unsigned long long *raw_err = nullptr;  // atomicMin(position + 1) of the first entry outside m x n (BoundsError)
+    // VERIFY kernels (a caller that repeats its stream: the run lists of the previous assembly are used again, no count
+    // pass): a tile whose digits or counts are not what its run list says stores nothing and raises *verify_err
+    u32 *verify_err = nullptr;
 };
 constexpr int MW_MAX = 64;  // windows the MULTI kernels take
 
@@ -439,7 +442,7 @@ static __global__ __launch_bounds__(THREADS) void run_rank_k(const unsigned long
 // item k only look at items >= k.  hd/hj: the tile's map digit -> run index; cnt_w[j] = the wave's entries in run j.
 template <int NI>
 __device__ __forceinline__ void rank_in_runs(u32 (&dig)[NI], const u32 *hd, const u32 *hj, u32 *cnt_w, int lane,
-                                             unsigned short (&rank)[NI], unsigned char (&jrun)[NI]) {
+                                             unsigned short (&rank)[NI], unsigned char (&jrun)[NI], u32 *miss = nullptr) {
     const u64 lt = (1ull << lane) - 1ull;
 #pragma unroll
     for (int k = 0; k < NI; k++) {
@@ -449,14 +452,17 @@ __device__ __forceinline__ void rank_in_runs(u32 (&dig)[NI], const u32 *hd, cons
             const u32 c0 = (u32)__builtin_amdgcn_readlane((int)dig[k], fl);
             int jj = 0;
             {
+                bool found = false;
                 int j = (int)((c0 * 0x9E3779B1u) >> 26) & (RMAX - 1);
                 for (int probe = 0; probe < RMAX; probe++) {
                     if (hd[j] == c0) {
                         jj = (int)hj[j];
+                        found = true;
                         break;
                     }
                     j = (j + 1) & (RMAX - 1);
                 }
+                if (miss && !found && lane == 0) *miss = 1u;  // (VERIFY: a digit the tile's run list does not know)
             }
             u32 running = 0;
 #pragma unroll
@@ -478,8 +484,9 @@ __device__ __forceinline__ void rank_in_runs(u32 (&dig)[NI], const u32 *hd, cons
 
 // (tried for RAW: four workgroups per CU through __launch_bounds__ -- 128 VGPRs instead of the K32 store loop's 152 -- costs
 // 76 bytes of scratch per lane)
-template <bool MULTI, bool K32, bool RAW = false>
+template <bool MULTI, bool K32, bool RAW = false, bool VERIFY = false>
 static __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
+    __shared__ u32 s_bad;
     __shared__ u64 s_mw[MULTI ? MW_MAX : 1];
     __shared__ u32 hd[RMAX];  // open-addressing map digit -> run index of this tile
     __shared__ u32 hj[RMAX];
@@ -499,6 +506,7 @@ static __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
     }
     if (t < WAVES * RMAX) (&cnt[0][0])[t] = 0;
     if (MULTI && t < a.mw_P) s_mw[t] = a.mw_base[t];
+    if (VERIFY && t == 0) s_bad = 0u;
     u64 key[ITEMS];
     double val[ITEMS];
     const i64 wbase = beg + (i64)w * (ESP_WAVE * ITEMS) + lane;
@@ -572,7 +580,7 @@ static __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
     }
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) dig[k] = ((pend >> k) & 1u) ? dig[k] : EMPTY;
-    rank_in_runs<ITEMS>(dig, hd, hj, cnt[w], lane, rank, jrun);
+    rank_in_runs<ITEMS>(dig, hd, hj, cnt[w], lane, rank, jrun, VERIFY ? &s_bad : nullptr);
     __syncthreads();
     // exclusive prefix over the waves, per run
     if (t < RMAX) {
@@ -583,8 +591,17 @@ static __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
             cnt[i][t] = run;
             run += x;
         }
+        if constexpr (VERIFY) {  // (the run list is the previous assembly's: every run must hold what it says)
+            if (t < nr && run != a.runs_c[tile * RMAX + t]) s_bad = 1u;
+        }
     }
     __syncthreads();
+    if constexpr (VERIFY) {
+        if (s_bad) {  // (uniform) not the stream the run lists were made for: nothing of this tile is stored
+            if (t == 0) *a.verify_err = 1u;
+            return;
+        }
+    }
     bool short_keys = false;
     if constexpr (K32) short_keys = *a.maxlen <= (unsigned long long)a.cap;  // (uniform; the host applies the same rule)
     const u32 kmask = a.shift >= 32 ? 0xFFFFFFFFu : ((1u << a.shift) - 1u);

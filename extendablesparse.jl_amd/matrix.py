@@ -643,6 +643,11 @@ class ExtendableSparseMatrix:
         self._d.ck(self._d.lib.esp_debug_last_partition(self._d.h, C.byref(p)))
         return p.value
 
+    def debug_last_plan_reused(self):
+        k = C.c_int32()
+        self._d.ck(self._d.lib.esp_debug_last_plan_reused(self._d.h, C.byref(k)))
+        return k.value
+
     def debug_last_run_order(self):
         """1 = ranking kernel, 2 = radix-ordered run list, 3 = ranking given up, radix-ordered list used"""
         p = C.c_int32()

@@ -402,7 +402,9 @@ typedef enum {
                                         even where the cell's number fits into the key                                      */
     ESP_PATH_TAIL_TO_FRONT = 29,     /* the entries behind a batch that was flushed by itself are copied to the front of
                                         the buffer before their partition (instead of being read where they lie)            */
-    ESP_PATH_NO_GROUP3 = 30          /* never the group-tier kernel with three workgroups per CU (group3_k)                  */
+    ESP_PATH_NO_GROUP3 = 30,         /* never the group-tier kernel with three workgroups per CU (group3_k)                  */
+    ESP_PATH_NO_PLAN_REUSE = 31      /* esp_append_device / esp_commit of one kind on an empty buffer always count their columns
+                                        (never the run lists of the previous, identical-looking batch)                      */
 } esp_debug_path;
 /* last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general) */
 int32_t esp_debug_force_path(esp_handle *h, int32_t path);
@@ -427,6 +429,11 @@ int32_t esp_debug_last_fold_update(const esp_handle *h, int32_t *on);
  * never.  2 when it was the group tier's kernel with three workgroups per CU (group3_k: long column runs on a fresh matrix,
  * 4-byte keys; esp_debug_force_path(30): never) */
 int32_t esp_debug_last_local_small(const esp_handle *h, int32_t *small);
+/* 1 when the last append-is-the-partition of caller-supplied triplets (esp_append_device / esp_commit of one kind on an
+ * empty buffer) used the run lists of the previous assembly instead of counting its columns again: a batch of the same
+ * length and kind is scattered straight away, every tile checked against its run list by the scatter kernel (a stream
+ * that turns out different is partitioned the full way; results never change) */
+int32_t esp_debug_last_plan_reused(const esp_handle *h, int32_t *reused);
 /* which partition the last flush used: 1 = run-based single pass (pre-sorted stream), 2 = 8-bit passes,
  * 4 = none: the producer wrote every entry straight to its bucket (esp_generate_* on an empty buffer: a COUNT launch
  *     of the producer, then its stores go to `bucket start + stable rank`; the flush starts at the bucket kernel),

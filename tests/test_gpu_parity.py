@@ -614,6 +614,69 @@ def test_host_append_int32_indices_and_kinds(esp, orc):
     assert_csc_equal(hip_arrays(A), O.arrays(), "large int32 batch")
 
 
+def test_append_device_reuses_the_previous_run_lists(esp, orc):
+    """A caller that repeats its stream (a time-stepping code): esp_append_device of one kind on an empty buffer uses the run
+    lists of the previous assembly -- no count pass over the columns -- and the scatter kernel checks every tile against its
+    list.  The same stream twice, new values at the same positions, then a changed stream of the same length (falls back,
+    makes a plan of its own, which the next repetition uses), entries swapped inside a tile (same digits and counts: the
+    lists still fit), a BoundsError in a repeated batch, force_path 31 (never); always the oracle's bits."""
+    import torch
+    dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()   # noqa: E731
+    n = 64
+    N = n ** 3
+    I, J, V = orc.fdrand_stream(n, n, n, rand_mode=1, seed=0x5EED0002)
+    E = len(I)
+    rng = np.random.default_rng(41)
+
+    def check(A, Ii, Jj, Vv, expect_reused, what):
+        A.reset()
+        A.append_device(UPDATE, dev(Ii), dev(Jj), dev(Vv))
+        assert A.debug_last_plan_reused() == expect_reused, (what, A.debug_last_plan_reused())
+        A.flush()
+        assert A.debug_last_partition() == 4
+        O = orc.ExtendableSparseMatrix(N, N)
+        O.apply(np.full(len(Ii), UPDATE, np.uint8), Ii, Jj, Vv)
+        assert_csc_equal(hip_arrays(A), O.arrays(), what)
+
+    A = esp.ExtendableSparseMatrix(N, N)
+    check(A, I, J, V, 0, "first assembly")
+    check(A, I, J, V, 1, "the same stream again")
+    check(A, I, J, rng.standard_normal(E), 1, "new values, same positions")
+    # swapped inside a tile: the digits and counts of every tile stay what they were
+    I2, J2, V2 = I.copy(), J.copy(), V.copy()
+    for t0 in range(0, E - 4096, 4096 * 37):
+        a, b = t0 + 5, t0 + 3000
+        for X in (I2, J2, V2):
+            X[a], X[b] = X[b], X[a]
+    check(A, I2, J2, V2, 1, "entries swapped inside their tiles")
+    # a different stream of the same length: two far-apart blocks trade places
+    I3, J3, V3 = I.copy(), J.copy(), V.copy()
+    blk = 50000
+    for X in (I3, J3, V3):
+        tmp = X[:blk].copy()
+        X[:blk] = X[E // 2:E // 2 + blk]
+        X[E // 2:E // 2 + blk] = tmp
+    check(A, I3, J3, V3, 0, "another stream of the same length")
+    check(A, I3, J3, V3, 1, "... repeated")
+    J4 = J3.copy()
+    J4[E - 7] = N + 1
+    A.reset()
+    with pytest.raises(esp.BoundsError):
+        A.append_device(UPDATE, dev(I3), dev(J4), dev(V3))
+    assert A.nnznew() == 0
+    check(A, I3, J3, V3, 0, "after the refused batch")
+    B = esp.ExtendableSparseMatrix(N, N)
+    B.debug_force_path(31)
+    check(B, I, J, V, 0, "never")
+    check(B, I, J, V, 0, "never, again")
+    # a flush that partitions by itself in between rewrites the tables: no reuse right after it
+    check(A, I3, J3, V3, 1, "repeated once more")
+    A.reset()
+    A.append(UPDATE, I[:300000], J[:300000], V[:300000])          # (host append: packed keys, the flush partitions)
+    A.flush()
+    check(A, I3, J3, V3, 0, "after another stream's own partition")
+
+
 def test_append_device_entry_point(esp, orc):
     """esp_append_device (triplets resident in GPU memory) by itself: on an empty buffer a pre-sorted batch of one kind is
     partitioned as it is appended (esp_debug_last_partition 4), an unsorted one or one with a kinds array is packed in
