@@ -2,7 +2,8 @@
 """Randomised parity fuzz (GPU): random shapes (incl. very tall matrices: many row bits), kinds, duplicate
 patterns, stream orders (sorted / clustered / shuffled), multi-flush sequences, both flush modes --
 every result compared bit for bit with the CPU oracle.  usage: tests/fuzz_parity.py [seconds] [seed]   (test infrastructure: it runs the CPU oracle)
-ESP_FUZZ_FOCUS=k32: shapes and batches that reach the 4-byte keys / UPDATE-only fold of the bucket kernel."""
+ESP_FUZZ_FOCUS=k32: shapes and batches that reach the 4-byte keys / UPDATE-only fold of the bucket kernel;
+ESP_FUZZ_FOCUS=elements: only the element-level append (esp_append_elements) and Base.sum (esp_flush_sum) cases."""
 import os
 import sys
 import time
@@ -151,7 +152,117 @@ def fem_case():
     return True
 
 
+def elements_case():
+    """esp_append_elements[_host] on random meshes: cells of 1 .. 16 nodes drawn from a neighbourhood (so that columns get
+    runs of all lengths) under a random node renumbering, random element matrices with zeros, kinds UPDATE / RAWUPDATE / SET,
+    with and without the diagonal term, `-`, now and then a cell that names a node twice (stream-order fall-back), host or
+    device arrays, forced paths, further appends around the batch, re-assembly over the stored pattern; and the same cells
+    dealt to several partition buffers that meet in ONE esp_flush_sum (Base.sum: sparsematrixdilnkc.jl:397-435)."""
+    nloc = int(rng.choice([1, 2, 3, 3, 4, 4, 6, 10, 16]))
+    n = int(rng.choice([500, 20000, 300000, 2000000]))
+    m = n if rng.random() < 0.8 else n + int(rng.integers(1, 1000))
+    lim = min(m, n)
+    nc = int(rng.choice([1, 50, 3000, 60000, 400000]))
+    if nc * nloc * (nloc + 1) > 12000000:
+        nc = 12000000 // (nloc * (nloc + 1))
+    span = int(rng.choice([nloc, 2 * nloc + 3, 64, 500]))
+    span = max(nloc, min(span, lim))
+    start = rng.integers(0, lim - span + 1, nc)
+    local = np.argsort(rng.random((nc, span)), axis=1)[:, :nloc]          # nloc distinct offsets per cell
+    perm = rng.permutation(lim) + 1 if rng.random() < 0.5 else np.arange(1, lim + 1)
+    cn = np.asfortranarray(perm[(start[:, None] + local)].T.astype(np.int64))
+    if rng.random() < 0.15 and nloc > 1 and nc > 0:
+        c = int(rng.integers(0, nc))
+        cn[1, c] = cn[0, c]                                                # a cell that names a node twice
+    em = rng.standard_normal((nloc, nloc, nc))
+    em[rng.random(em.shape) < 0.15] = 0.0
+    em = np.asfortranarray(em)
+    dg = np.asfortranarray(rng.standard_normal((nloc, nc))) if rng.random() < 0.6 else None
+    kind = int(rng.choice([1, 2, 2, 0]))
+    sub = rng.random() < 0.2
+    force = int(rng.choice([0, 0, 0, 0, 14, 25, 30, 24, 2]))
+    I, J, V = orc.elements_stream(cn, em, dg)
+    Vs = -V if (sub and kind != 0) else V
+    if rng.random() < 0.3 and nc >= 4:
+        # ---- Base.sum over p partition buffers
+        p = int(rng.choice([2, 3, 7]))
+        cuts = np.sort(rng.integers(0, nc + 1, p - 1)).tolist()
+        cuts = [0] + cuts + [nc]
+        xs = [esp.SparseMatrixHIPCOO(m, n) for _ in range(p)]
+        home = esp.SparseMatrixHIPCOO(m, n)
+        csc = esp.SparseMatrixCSC(m, n)
+        Oc = orc.CSC(m, n)
+        for rnd in range(2):
+            for t in range(p):
+                a, b = cuts[t], cuts[t + 1]
+                if b > a:
+                    xs[t].append_elements(cn[:, a:b], em[:, :, a:b], None if dg is None else dg[:, a:b], kind=kind, op="-" if sub else "+")
+                L = orc.SparseMatrixLNK(m, n)
+                It, Jt, Vt = orc.elements_stream(cn[:, a:b], em[:, :, a:b], None if dg is None else dg[:, a:b]) if b > a else ([], [], [])
+                for i, j, v in zip(np.asarray(It).tolist(), np.asarray(Jt).tolist(), (np.asarray(Vt) * (-1.0 if (sub and kind != 0) else 1.0)).tolist()):
+                    if kind == 0:
+                        L[i, j] = v
+                    elif kind == 1:
+                        L.updateindex(orc.OP_ADD, v, i, j)
+                    else:
+                        L.rawupdateindex(orc.OP_ADD, v, i, j)
+                if L.nnz() > 0:
+                    Oc = L + Oc
+            csc = esp.SparseMatrixHIPCOO.sum(xs, csc, home=home)
+            try:
+                assert_csc_equal(csc.arrays(), Oc.arrays())
+            except AssertionError:
+                print("MISMATCH elements/sum case", dict(nloc=nloc, m=m, n=n, nc=nc, span=span, kind=kind, p=p, rnd=rnd))
+                raise
+        paths[("elem_sum", p)] = paths.get(("elem_sum", p), 0) + 1
+        return True
+    if len(I) > 3000000 and nloc * nloc > 40:
+        return None                                                       # (the oracle's list walks: keep the case short)
+    A = esp.ExtendableSparseMatrix(m, n)
+    A.debug_force_path(force)
+    O = orc.ExtendableSparseMatrix(m, n)
+    for rnd in range(int(rng.integers(1, 3))):
+        how = rng.choice(["alone", "alone", "host_before", "host_after", "twice"])
+        cnt = int(rng.choice([5, 3000]))
+        Ih, Jh, Vh = rng.integers(1, m + 1, cnt), rng.integers(1, n + 1, cnt), rng.standard_normal(cnt)
+        kh = rng.integers(0, 3, cnt).astype(np.uint8)
+        if how == "host_before":
+            A.append(0, Ih, Jh, Vh, kinds=kh)
+            O.apply(kh, Ih, Jh, Vh)
+        reps = 2 if how == "twice" else 1
+        for _ in range(reps):
+            if rng.random() < 0.5 or nc == 0:
+                A.append_elements(cn, em, dg, kind=kind, op="-" if sub else "+")
+            else:
+                tn = torch.from_numpy(np.ascontiguousarray(cn.T)).cuda()
+                te = torch.from_numpy(np.ascontiguousarray(em.transpose(2, 1, 0))).cuda()
+                td = None if dg is None else torch.from_numpy(np.ascontiguousarray(dg.T)).cuda()
+                A.append_elements(tn, te, td, kind=kind, op="-" if sub else "+")
+            O.apply(np.full(len(I), kind, np.uint8), I, J, Vs)
+        if how == "host_after":
+            A.append(0, Ih, Jh, Vh, kinds=kh)
+            O.apply(kh, Ih, Jh, Vh)
+        try:
+            A.flush()
+        except Exception:
+            print("FLUSH FAILED elements case", dict(nloc=nloc, m=m, n=n, nc=nc, span=span, kind=kind, force=force, rnd=rnd, how=str(how)))
+            raise
+        O.flush()
+        key = ("elem", nloc, A.debug_last_partition(), A.debug_last_key_bytes(), A.debug_last_local_small())
+        paths[key] = paths.get(key, 0) + 1
+        try:
+            assert_csc_equal(A.sparse().arrays(), O.arrays())
+        except AssertionError:
+            print("MISMATCH elements case", dict(nloc=nloc, m=m, n=n, nc=nc, span=span, kind=kind, force=force, rnd=rnd, how=str(how), diag=dg is not None))
+            raise
+    return True
+
+
 while time.time() < t_end:
+    if (rng.random() < 0.12 or os.environ.get("ESP_FUZZ_FOCUS") == "elements") and os.environ.get("ESP_FUZZ_FOCUS") != "k32":
+        if elements_case():
+            cases += 1
+        continue
     if rng.random() < 0.12 and os.environ.get("ESP_FUZZ_FOCUS") != "k32":
         if fem_case():
             cases += 1

@@ -2363,7 +2363,7 @@ def test_producer_partition_odd_grids(esp, orc, dims):
     assert 4 in seen, seen
 
 
-@pytest.mark.parametrize("focus,seed,seconds", [("", 11, 20), ("k32", 12, 12)])
+@pytest.mark.parametrize("focus,seed,seconds", [("", 11, 20), ("k32", 12, 12), ("elements", 13, 15)])
 def test_bounded_fuzz(focus, seed, seconds):
     """tests/fuzz_parity.py (random shapes, kinds, orders, flush sequences, forced paths; every result against the
     oracle bit for bit) with fixed seeds and a bounded budget."""
