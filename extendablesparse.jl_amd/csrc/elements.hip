@@ -42,9 +42,6 @@ int32_t elements_by_items(esp_handle *h, espelem::Args a, i64 E, bool *took) {
     CK(ensure(h, h->misc, 256));
     unsigned long long *d_err = (unsigned long long *)h->misc.p;
     u32 *d_dup = (u32 *)((unsigned long long *)h->misc.p + 1);
-    h->pin_scalar[0] = ~0ull;
-    h->pin_scalar[1] = 0ull;
-    HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 16, hipMemcpyHostToDevice, h->stream));
     a.vrb = vrb;
     a.err = d_err;
     a.dup = d_dup;
@@ -54,75 +51,148 @@ int32_t elements_by_items(esp_handle *h, espelem::Args a, i64 E, bool *took) {
     const bool cellrec = (a.nloc == 3 || a.nloc == 4) && h->m <= ((i64)1 << 32) && (size_t)a.ncells * 64 <= h->vals2.bytes &&
                          !(getenv("ESP_ELEM_NO_CELLREC") && *getenv("ESP_ELEM_NO_CELLREC"));
     a.cellrec = cellrec ? (char *)h->vals2.p : nullptr;
-    {
-        Span sp(h, ESP_ST_APPEND);
-        if (cellrec && a.nloc == 3)
-            hipLaunchKernelGGL(espelem::elem_cells_k<3>, dim3(grid_for(a.ncells, espelem::THREADS)), dim3(espelem::THREADS), 0, h->stream, a);
-        else if (cellrec)
-            hipLaunchKernelGGL(espelem::elem_cells_k<4>, dim3(grid_for(a.ncells, espelem::THREADS)), dim3(espelem::THREADS), 0, h->stream, a);
-        else
-            hipLaunchKernelGGL(espelem::elem_items_k, dim3(grid_for(NI, espelem::THREADS)), dim3(espelem::THREADS), 0, h->stream, a);
-        sp.add(1);
+    const int Kv = bits_for(std::max<i64>(h->n, 1)) + vrb;  // bits of the records' virtual key window (n << vrb keys)
+    const u64 vspan = (u64)std::max<i64>(h->n, 1) << vrb;
+    // with cell records the passes may stop a few bits early: the expansion orders every segment by the last bits itself
+    // (segexpand.hpp); a second attempt with the passes alone when a segment does not fit that
+    int sort_bits = 0;
+    int lbits0 = 0;
+    if (cellrec) {
+        const u64 span0 = h->win_span, base0 = h->win_base;
+        h->win_base = 0, h->win_span = vspan;
+        int Kw = 1;
+        while (Kw < 62 && ((u64)1 << Kw) < vspan) Kw++;
+        lbits0 = plan_local_bits(h, NI, W, Kw, &sort_bits);
+        h->win_base = base0, h->win_span = span0;
     }
-    // the flush's partition over the items: a temporary view of the handle (sort_msd reads count, keys, keys2 and the
-    // key window -- here the records' virtual one)
-    const DevBuf k0 = h->keys, v0 = h->vals, k2 = h->keys2, v2 = h->vals2;
-    const i64 count0 = h->count;
-    const double spread0 = h->seen_spread;
-    const u64 span0 = h->win_span, base0 = h->win_base;
-    h->keys.p = a.ikeys, h->keys.bytes = sizeof(u64) * (size_t)NI;
-    h->keys2.p = a.ikeys + NI, h->keys2.bytes = sizeof(u64) * (size_t)NI;
-    h->vals.bytes = std::max(h->vals.bytes, sizeof(double) * (size_t)NI);  // (keys-only passes never touch the value arrays)
-    h->vals2.bytes = std::max(h->vals2.bytes, sizeof(double) * (size_t)NI);
-    h->count = NI;
-    h->win_base = 0;
-    h->win_span = (u64)std::max<i64>(h->n, 1) << vrb;
-    h->plan_cap = (i64)esplocal::CAP / W;
-    h->item_mode = true;
-    h->item_keys_only = true;
+    (void)Kv;
     Sorted st;
-    const int32_t rc = sort_msd(h, &st);
-    h->keys = k0, h->vals = v0, h->keys2 = k2, h->vals2 = v2;
-    h->count = count0;
-    h->win_base = base0, h->win_span = span0;
-    h->plan_cap = 0;
-    h->item_mode = false;
-    h->item_keys_only = false;
-    if (rc != ESP_OK) return rc;
-    HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 16, hipMemcpyDeviceToHost, h->stream));
-    HIPCK(h, hipStreamSynchronize(h->stream));
-    if (h->pin_scalar[0] != ~0ull)
-        FAIL(h, ESP_ERR_BOUNDS, "BoundsError: cell %llu of the batch names a node outside 1..%lld", (unsigned long long)h->pin_scalar[0],
-             (long long)a.lim);
-    const int rem_real = st.rem_bits - (vrb - h->L.rb);
-    if ((u32)h->pin_scalar[1] != 0u || !st.fits || st.S < 2 || st.rem_bits < vrb || rem_real > esplocal::MAX_REM_BITS ||
-        st.maxlen * W > (i64)esplocal::CAP) {
-        h->seen_spread = spread0;
-        return ESP_OK;  // (a cell with a repeated node, or no segment table the bucket kernel takes)
+    int lbits = 0;
+    i64 maxlen_updates = 0;
+    int rem_real = 0;
+    bool k32 = false, done = false;
+    for (int attempt = lbits0 > 0 ? 0 : 1; attempt < 2 && !done; attempt++) {
+        lbits = attempt == 0 ? lbits0 : 0;
+        h->pin_scalar[0] = ~0ull;
+        h->pin_scalar[1] = 0ull;
+        HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 16, hipMemcpyHostToDevice, h->stream));
+        {
+            Span sp(h, ESP_ST_APPEND);
+            if (cellrec && a.nloc == 3)
+                hipLaunchKernelGGL(espelem::elem_cells_k<3>, dim3(grid_for(a.ncells, espelem::THREADS)), dim3(espelem::THREADS), 0, h->stream, a);
+            else if (cellrec)
+                hipLaunchKernelGGL(espelem::elem_cells_k<4>, dim3(grid_for(a.ncells, espelem::THREADS)), dim3(espelem::THREADS), 0, h->stream, a);
+            else
+                hipLaunchKernelGGL(espelem::elem_items_k, dim3(grid_for(NI, espelem::THREADS)), dim3(espelem::THREADS), 0, h->stream, a);
+            sp.add(1);
+        }
+        // the flush's partition over the items: a temporary view of the handle (sort_msd reads count, keys, keys2 and the
+        // key window -- here the records' virtual one)
+        const DevBuf k0 = h->keys, v0 = h->vals, k2 = h->keys2, v2 = h->vals2;
+        const i64 count0 = h->count;
+        const double spread0 = h->seen_spread;
+        const u64 span0 = h->win_span, base0 = h->win_base;
+        h->keys.p = a.ikeys, h->keys.bytes = sizeof(u64) * (size_t)NI;
+        h->keys2.p = a.ikeys + NI, h->keys2.bytes = sizeof(u64) * (size_t)NI;
+        h->vals.bytes = std::max(h->vals.bytes, sizeof(double) * (size_t)NI);  // (keys-only passes never touch the value arrays)
+        h->vals2.bytes = std::max(h->vals2.bytes, sizeof(double) * (size_t)NI);
+        h->count = NI;
+        h->win_base = 0;
+        h->win_span = vspan;
+        h->plan_cap = lbits ? (i64)espseg::LCAP : (i64)esplocal::CAP / W;
+        h->plan_bits = lbits ? sort_bits : 0;
+        h->item_mode = true;
+        h->item_keys_only = true;
+        st = Sorted();
+        const int32_t rc = sort_msd(h, &st);
+        h->keys = k0, h->vals = v0, h->keys2 = k2, h->vals2 = v2;
+        h->count = count0;
+        h->win_base = base0, h->win_span = span0;
+        h->plan_cap = 0;
+        h->plan_bits = 0;
+        h->item_mode = false;
+        h->item_keys_only = false;
+        if (rc != ESP_OK) return rc;
+        HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 16, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        if (h->pin_scalar[0] != ~0ull)
+            FAIL(h, ESP_ERR_BOUNDS, "BoundsError: cell %llu of the batch names a node outside 1..%lld", (unsigned long long)h->pin_scalar[0],
+                 (long long)a.lim);
+        if ((u32)h->pin_scalar[1] != 0u) {  // a cell with a repeated node: its items would interleave in call order
+            h->seen_spread = spread0;
+            return ESP_OK;
+        }
+        if (lbits) lbits = std::min(lbits, st.rem_bits - vrb);  // (the sub-segments are whole columns)
+        rem_real = st.rem_bits - lbits - (vrb - h->L.rb);
+        const bool usable = st.fits && st.S >= 2 && st.rem_bits - std::max(lbits, 0) >= vrb && rem_real <= esplocal::MAX_REM_BITS &&
+                            (attempt == 0 ? lbits >= 1 : st.maxlen * W <= (i64)esplocal::CAP);
+        if (!usable) {
+            h->seen_spread = spread0;
+            if (attempt == 1) return ESP_OK;  // (no segment table the bucket kernel takes)
+            continue;
+        }
+        k32 = rem_real <= 32 && h->force_path != ESP_PATH_PACKED_KEYS;
+        a.sorted_keys = st.sk;
+        a.rem_bits = rem_real;
+        a.base = h->win_base;
+        a.keys_out = (u64 *)h->keys.p;
+        a.vals_out = (double *)h->vals.p;
+        const i64 S_final = (i64)st.S << lbits;
+        CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(S_final + 1)));
+        if (lbits) {
+            unsigned long long *d_maxsub = (unsigned long long *)h->misc.p + 2;
+            HIPCK(h, hipMemsetAsync(d_maxsub, 0, 8, h->stream));
+            espseg::SegArgs sa;
+            sa.recs = st.sk;
+            sa.seg_start = st.seg_start;
+            sa.S = st.S;
+            sa.W = W;
+            sa.lbits = lbits;
+            sa.lshift = st.rem_bits - lbits;  // (in the records' virtual layout)
+            sa.base = 0;
+            sa.sub_start = (i64 *)h->seg[1].p;
+            sa.maxsub = d_maxsub;
+            sa.total_items = NI;
+            {
+                Span sp(h, ESP_ST_APPEND);
+                const dim3 grid((unsigned)st.S), block(espseg::THREADS);
+                if (a.nloc == 3 && k32)
+                    hipLaunchKernelGGL((espelem::elem_seg_expand_k<true, 3>), grid, block, 0, h->stream, a, sa);
+                else if (a.nloc == 3)
+                    hipLaunchKernelGGL((espelem::elem_seg_expand_k<false, 3>), grid, block, 0, h->stream, a, sa);
+                else if (k32)
+                    hipLaunchKernelGGL((espelem::elem_seg_expand_k<true, 4>), grid, block, 0, h->stream, a, sa);
+                else
+                    hipLaunchKernelGGL((espelem::elem_seg_expand_k<false, 4>), grid, block, 0, h->stream, a, sa);
+                sp.add(1);
+            }
+            HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_maxsub, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCK(h, hipStreamSynchronize(h->stream));
+            maxlen_updates = (i64)h->pin_scalar[0];
+            if (maxlen_updates > (i64)esplocal::CAP) {  // (a sub-segment the bucket kernel does not take: the passes alone)
+                h->seen_spread = spread0;
+                continue;
+            }
+        } else {
+            Span sp(h, ESP_ST_APPEND);
+            if (k32)
+                launch_expand<true>(a, h->stream);
+            else
+                launch_expand<false>(a, h->stream);
+            hipLaunchKernelGGL(espitem::scale_segments_k, dim3(grid_for((i64)st.S + 1, 256)), dim3(256), 0, h->stream, st.seg_start, (i64)st.S + 1,
+                               (i64)W, (i64 *)h->seg[1].p);
+            sp.add(2);
+            maxlen_updates = st.maxlen * W;
+        }
+        done = true;
     }
+    if (!done) return ESP_OK;
     const int K = window_bits(h);
-    const bool k32 = rem_real <= 32 && h->force_path != ESP_PATH_PACKED_KEYS;
-    a.sorted_keys = st.sk;
-    a.rem_bits = rem_real;
-    a.base = h->win_base;
-    a.keys_out = (u64 *)h->keys.p;
-    a.vals_out = (double *)h->vals.p;
-    CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(st.S + 1)));
-    {
-        Span sp(h, ESP_ST_APPEND);
-        if (k32)
-            launch_expand<true>(a, h->stream);
-        else
-            launch_expand<false>(a, h->stream);
-        hipLaunchKernelGGL(espitem::scale_segments_k, dim3(grid_for((i64)st.S + 1, 256)), dim3(256), 0, h->stream, st.seg_start, (i64)st.S + 1,
-                           (i64)W, (i64 *)h->seg[1].p);
-        sp.add(2);
-    }
     HIPCK(h, hipGetLastError());
     esp_handle::PrePart &pp = h->pre;
     pp.K = K;
     pp.pb = K - rem_real;
-    pp.maxlen = st.maxlen * W;
+    pp.maxlen = maxlen_updates;
     pp.key_bytes = k32 ? 4 : 8;
     pp.kind = a.kind;
     pp.E = E;

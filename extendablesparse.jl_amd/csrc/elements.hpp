@@ -28,6 +28,7 @@
 #pragma once
 #include "common.hpp"
 #include "generators.hpp"
+#include "segexpand.hpp"
 
 namespace espelem {
 
@@ -226,6 +227,48 @@ static __global__ __launch_bounds__(THREADS) void elem_expand_k(Args a) {
         for (int q = t; q < vpair; q += THREADS) reinterpret_cast<ull2 *>(gk)[q] = ull2{lk[2 * q], lk[2 * q + 1]};
         if (t == 0 && (cnt & 1)) gk[cnt - 1] = lk[cnt - 1];
     }
+}
+
+// The expansion with the partition's last bits done inside it (segexpand.hpp), cells of 3 / 4 nodes with cell records: one
+// workgroup per segment of up to 4096 item records orders them by the next lbits bits and expands them in that order.
+template <bool K32, int NLOC>
+static __global__ __launch_bounds__(espseg::THREADS) void elem_seg_expand_k(Args a, espseg::SegArgs sa) {
+    typedef typename std::conditional<K32, u32, u64>::type KT;
+    typedef u32 u32x4 __attribute__((ext_vector_type(4)));
+    constexpr int WMAX = NLOC + 1;
+    __shared__ espseg::SegLds L;
+    __shared__ KT lk[espseg::THREADS * WMAX];
+    __shared__ double lv[espseg::THREADS * WMAX];
+    const int low = a.vrb + ESP_TAG_BITS;
+    const u64 lowmask = a.rem_bits >= 64 ? ~0ull : ((1ull << a.rem_bits) - 1ull);
+    espseg::segment_expand<KT>(sa, L, lk, lv, reinterpret_cast<KT *>(a.keys_out), a.vals_out, [&](u64 rec, KT *k, double *v) {
+        const u32 p = (u32)(rec & ((1ull << low) - 1ull));
+        const u64 colpart = (rec >> low) << a.L.rb;
+        const u32 cell = p / (u32)NLOC, jl = p - cell * (u32)NLOC;
+        const double *em = a.elmat + (i64)p * NLOC;
+        const char *cr = a.cellrec + (i64)cell * 64;
+        const u32x4 rr = *reinterpret_cast<const u32x4 *>(cr);
+        const double d = a.diag ? *reinterpret_cast<const double *>(cr + 16 + 8 * jl) : 0.0;
+        const u32 r[4] = {rr.x, rr.y, rr.z, rr.w};
+        double ev[NLOC];
+#pragma unroll
+        for (int il = 0; il < NLOC; il++) ev[il] = em[il];
+        int at = 0;
+        auto put = [&](u64 row0, double val) {
+            if (a.negate) val = -val;
+            if constexpr (K32)
+                k[at] = (u32)(((colpart | row0) - a.base) & lowmask);
+            else
+                k[at] = ((colpart | row0) << ESP_TAG_BITS) | (u64)a.kind;
+            v[at] = val;
+            at++;
+        };
+#pragma unroll
+        for (int il = 0; il < NLOC; il++) {
+            if (a.diag && (u32)il == jl) put((u64)r[il], d);
+            put((u64)r[il], ev[il]);
+        }
+    });
 }
 
 // The updates in stream order, as packed keys (any buffer state; what the flush's own partition then takes): entry e of

@@ -20,6 +20,7 @@
 #pragma once
 #include "common.hpp"
 #include "generators.hpp"
+#include "segexpand.hpp"
 
 namespace espitem {
 
@@ -113,6 +114,30 @@ static __global__ __launch_bounds__(THREADS) void fem_expand_k(Args a) {
     } else {
         espgen::copy_out_staged<THREADS>(lk, lv, cnt, a.keys_out + g0 * W, a.vals_out + g0 * W);
     }
+}
+
+// The expansion with the partition's last bits done inside it (segexpand.hpp): one workgroup per segment of up to 4096
+// single-word item records orders them by the next lbits bits and expands them in that order; writes the sub-segment table.
+template <bool K32>
+static __global__ __launch_bounds__(espseg::THREADS) void fem_seg_expand_k(Args a, espseg::SegArgs sa) {
+    typedef typename std::conditional<K32, u32, u64>::type KT;
+    __shared__ espseg::SegLds L;
+    __shared__ KT lk[espseg::THREADS * MAX_W];
+    __shared__ double lv[espseg::THREADS * MAX_W];
+    const int low = a.fem.L.rb + ESP_TAG_BITS;
+    const u64 lowmask = a.rem_bits >= 64 ? ~0ull : ((1ull << a.rem_bits) - 1ull);
+    espseg::segment_expand<KT>(sa, L, lk, lv, reinterpret_cast<KT *>(a.keys_out), a.vals_out, [&](u64 rec, KT *k, double *v) {
+        const i64 cell = (i64)(rec & ((1ull << low) - 1ull));
+        const i64 icol = (i64)(rec >> low) + 1;
+        espgen::fem_column_of_cell(a.fem, cell, icol, [&](int il, int jl, i64 row, double val) {
+            const int at = jl < 0 ? il : il + (il >= jl ? 1 : 0);
+            if constexpr (K32)
+                k[at] = (u32)(((((u64)(icol - 1) << a.fem.L.rb) | (u64)(row - 1)) - a.base) & lowmask);
+            else
+                k[at] = esp_pack(a.fem.L, row, icol, ESP_RAWUPDATE);
+            v[at] = val;
+        });
+    });
 }
 
 // entries = items * (dim + 2): the segment table of the append buffer from the items'

@@ -108,6 +108,7 @@ struct esp_handle {
     // sort_msd over ITEM records (femitems.hpp): a segment may hold plan_cap records (the bucket kernel's capacity in
     // updates / updates per item), and a shuffled stream need not be tried as a pre-sorted one
     i64 plan_cap = 0;
+    int plan_bits = 0;           // > 0: sort_msd resolves exactly this many prefix bits in its planned passes (item partitions whose expansion does the last bits itself: segexpand.hpp)
     // the pending entries start at this entry of keys/vals (behind a batch that esp_flush flushed by itself); else 0
     i64 pend_off = 0;
     bool item_mode = false;
@@ -365,6 +366,7 @@ int32_t chunk_arrays(esp_handle *h, i64 Ccap, int pb, ChunkArrays *out, bool kee
 double plan_entries(i64 E, int K, u64 span);
 int plan_run_bits(i64 E, int K, u64 span);
 int plan_prefix_bits(const esp_handle *h, i64 E, int K, double *Ee_out);
+int plan_local_bits(esp_handle *h, i64 NI, int W, int K, int *sort_bits);
 int window_bits(const esp_handle *h);
 int32_t aux_ready(esp_handle *h);
 int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u64 *kout, double *vout, int K, int pb,

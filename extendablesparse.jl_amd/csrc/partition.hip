@@ -159,6 +159,30 @@ int plan_prefix_bits(const esp_handle *h, i64 E, int K, double *Ee_out) {
     *Ee_out = Ee;
     return planned;
 }
+// An item partition of NI records (W updates each) whose expansion resolves the last bits itself (segexpand.hpp): the
+// number of those bits (0: not worth it / not possible) and, in *sort_bits, what the passes in front of it resolve.
+// The final prefix is what the classic plan gives for segments of CAP / W items; the passes stop up to three bits
+// earlier when a segment then still fits the expansion's local sort with room to spare.
+int plan_local_bits(esp_handle *h, i64 NI, int W, int K, int *sort_bits) {
+    *sort_bits = 0;
+    // (measured at config 4's sizes, round 4: the pass it saves is worth 1.3 ms at 3-D, the ordering step and the per-segment
+    // rounds cost the expansion 1.6 -- 18.3 against 17.7 ms, elements 24.7 against 23.9, 2-D 5.2 against 4.7: it stays a test
+    // hook, esp_debug_force_path(ESP_PATH_LOCAL_BITS), until a mesh shape shows up where the last pass resolves a single bit)
+    if (h->force_path != ESP_PATH_LOCAL_BITS && !getenv("ESP_LOCAL_BITS")) return 0;
+    const i64 cap0 = h->plan_cap;
+    h->plan_cap = (i64)esplocal::CAP / W;
+    double Ee = 0.0;
+    const int total = plan_prefix_bits(h, NI, K, &Ee);
+    h->plan_cap = cap0;
+    for (int b = espseg::MAXB; b >= 1; b--) {
+        const int sb = total - b;
+        if (sb >= 4 && Ee / (double)((i64)1 << sb) <= 0.8 * (double)espseg::LCAP) {
+            *sort_bits = sb;
+            return b;
+        }
+    }
+    return 0;
+}
 int window_bits(const esp_handle *h) {
     int K = 1;
     while (K < 62 && ((u64)1 << K) < h->win_span) K++;
@@ -623,11 +647,13 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
 
     double Ee = 0.0;
     int planned = plan_prefix_bits(h, E, K, &Ee);
+    const bool fixed_bits = h->plan_bits > 0;
+    if (fixed_bits) planned = std::min(h->plan_bits, K);  // (an item partition that leaves the last bits to its expansion)
     const int planned_run = planned;  // the run-based pass takes up to 20 bits at once: no need to be tight
     // one bit short of a whole number of 8-bit passes: an average fill of up to 95 % is worth
     // trying with one pass less (the longest segment is checked after the planned passes and a
     // further pass is added only if a segment really overflows)
-    if (planned > 8 && planned % 8 == 1 && Ee / (double)((i64)1 << (planned - 1)) <= 0.95 * (double)seg_cap(h)) planned--;
+    if (!fixed_bits && planned > 8 && planned % 8 == 1 && Ee / (double)((i64)1 << (planned - 1)) <= 0.95 * (double)seg_cap(h)) planned--;
     // (digits of 9 bits only where they save a whole pass -- 17 or 18 bits in two passes: a tile then holds 8 entries per
     // digit instead of 16; force_path 23: never)
     const int npass8 = (planned + 7) / 8, npass9 = (planned + espradix::MAX_BITS - 1) / espradix::MAX_BITS;

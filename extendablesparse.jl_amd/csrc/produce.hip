@@ -401,61 +401,113 @@ int32_t item_produce_fem(esp_handle *h, const espgen::FemArgs &fa, i64 E, bool *
     // single-word records when the cell's number fits below the column bits of the key (28: test hook, never)
     a.single = ((u64)fa.ncells <= ((u64)1 << (h->L.rb + ESP_TAG_BITS)) && h->force_path != ESP_PATH_TWO_WORD_ITEMS) ? 1 : 0;
     a.sorted_keys = nullptr;
-    {
-        Span sp(h, ESP_ST_APPEND);
-        hipLaunchKernelGGL(espitem::fem_items_k, dim3(grid_for(fa.ncells, espitem::THREADS)), dim3(espitem::THREADS), 0, h->stream, a);
-        sp.add(1);
-    }
-    // the flush's partition over the items: a temporary view of the handle (sort_msd reads count, keys/vals, keys2/vals2)
-    const DevBuf k0 = h->keys, v0 = h->vals, k2 = h->keys2, v2 = h->vals2;
-    const i64 count0 = h->count;
-    const double spread0 = h->seen_spread;
-    h->keys.p = a.ikeys, h->keys.bytes = sizeof(u64) * (size_t)NI;
-    h->vals.p = a.ivals, h->vals.bytes = sizeof(double) * (size_t)NI;
-    h->keys2.p = a.ikeys + NI, h->keys2.bytes = sizeof(u64) * (size_t)NI;
-    h->vals2.p = a.ivals + NI, h->vals2.bytes = sizeof(double) * (size_t)NI;
-    h->count = NI;
-    h->plan_cap = (i64)esplocal::CAP / W;
-    h->item_mode = true;
-    h->item_keys_only = a.single != 0;
-    Sorted st;
-    const int32_t rc = sort_msd(h, &st);
-    h->keys = k0, h->vals = v0, h->keys2 = k2, h->vals2 = v2;
-    h->count = count0;
-    h->plan_cap = 0;
-    h->item_mode = false;
-    h->item_keys_only = false;
-    if (rc != ESP_OK) return rc;
     const int K = window_bits(h);
-    if (!st.local_ok || st.S < 2 || st.rem_bits < h->L.rb || st.maxlen * W > (i64)esplocal::CAP) {
-        h->seen_spread = spread0;
-        return ESP_OK;  // (no segment table the bucket kernel takes: the plain producer and the flush's own passes)
+    // single-word records: the passes may stop a few bits early, the expansion orders every segment by the last bits itself
+    // (segexpand.hpp); a second attempt with the passes alone when a segment does not fit that
+    int sort_bits = 0;
+    const int lbits0 = a.single ? plan_local_bits(h, NI, W, K, &sort_bits) : 0;
+    Sorted st;
+    int lbits = 0;
+    i64 maxlen_updates = 0;
+    bool done = false;
+    for (int attempt = lbits0 > 0 ? 0 : 1; attempt < 2 && !done; attempt++) {
+        lbits = attempt == 0 ? lbits0 : 0;
+        {
+            Span sp(h, ESP_ST_APPEND);
+            hipLaunchKernelGGL(espitem::fem_items_k, dim3(grid_for(fa.ncells, espitem::THREADS)), dim3(espitem::THREADS), 0, h->stream, a);
+            sp.add(1);
+        }
+        // the flush's partition over the items: a temporary view of the handle (sort_msd reads count, keys/vals, keys2/vals2)
+        const DevBuf k0 = h->keys, v0 = h->vals, k2 = h->keys2, v2 = h->vals2;
+        const i64 count0 = h->count;
+        const double spread0 = h->seen_spread;
+        h->keys.p = a.ikeys, h->keys.bytes = sizeof(u64) * (size_t)NI;
+        h->vals.p = a.ivals, h->vals.bytes = sizeof(double) * (size_t)NI;
+        h->keys2.p = a.ikeys + NI, h->keys2.bytes = sizeof(u64) * (size_t)NI;
+        h->vals2.p = a.ivals + NI, h->vals2.bytes = sizeof(double) * (size_t)NI;
+        h->count = NI;
+        h->plan_cap = lbits ? (i64)espseg::LCAP : (i64)esplocal::CAP / W;
+        h->plan_bits = lbits ? sort_bits : 0;
+        h->item_mode = true;
+        h->item_keys_only = a.single != 0;
+        st = Sorted();
+        const int32_t rc = sort_msd(h, &st);
+        h->keys = k0, h->vals = v0, h->keys2 = k2, h->vals2 = v2;
+        h->count = count0;
+        h->plan_cap = 0;
+        h->plan_bits = 0;
+        h->item_mode = false;
+        h->item_keys_only = false;
+        if (rc != ESP_OK) return rc;
+        if (lbits) lbits = std::min(lbits, st.rem_bits - h->L.rb);  // (the sub-segments are whole columns)
+        const bool usable = st.local_ok && st.S >= 2 && st.rem_bits - std::max(lbits, 0) >= h->L.rb &&
+                            (attempt == 0 ? lbits >= 1 : st.maxlen * W <= (i64)esplocal::CAP);
+        if (!usable) {
+            h->seen_spread = spread0;
+            if (attempt == 1) return ESP_OK;  // (no segment table the bucket kernel takes: the plain producer and the flush's own passes)
+            continue;
+        }
+        const int rem_final = st.rem_bits - lbits;
+        const bool k32 = rem_final <= 32 && h->force_path != ESP_PATH_PACKED_KEYS;
+        a.sorted = st.sv;
+        a.sorted_keys = st.sk;
+        a.rem_bits = rem_final;
+        a.base = h->win_base;
+        a.keys_out = (u64 *)h->keys.p;
+        a.vals_out = (double *)h->vals.p;
+        const i64 S_final = (i64)st.S << lbits;
+        CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(S_final + 1)));
+        if (lbits) {
+            unsigned long long *d_maxsub = (unsigned long long *)h->misc.p + 2;
+            HIPCK(h, hipMemsetAsync(d_maxsub, 0, 8, h->stream));
+            espseg::SegArgs sa;
+            sa.recs = st.sk;
+            sa.seg_start = st.seg_start;
+            sa.S = st.S;
+            sa.W = W;
+            sa.lbits = lbits;
+            sa.lshift = rem_final;
+            sa.base = h->win_base;
+            sa.sub_start = (i64 *)h->seg[1].p;
+            sa.maxsub = d_maxsub;
+            sa.total_items = NI;
+            {
+                Span sp(h, ESP_ST_APPEND);
+                if (k32)
+                    hipLaunchKernelGGL(espitem::fem_seg_expand_k<true>, dim3((unsigned)st.S), dim3(espseg::THREADS), 0, h->stream, a, sa);
+                else
+                    hipLaunchKernelGGL(espitem::fem_seg_expand_k<false>, dim3((unsigned)st.S), dim3(espseg::THREADS), 0, h->stream, a, sa);
+                sp.add(1);
+            }
+            HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_maxsub, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCK(h, hipStreamSynchronize(h->stream));
+            maxlen_updates = (i64)h->pin_scalar[0];
+            if (maxlen_updates > (i64)esplocal::CAP) {  // (a sub-segment the bucket kernel does not take: the passes alone)
+                h->seen_spread = spread0;
+                continue;
+            }
+        } else {
+            Span sp(h, ESP_ST_APPEND);
+            const dim3 grid(grid_for(NI, espitem::THREADS)), block(espitem::THREADS);
+            if (k32)
+                hipLaunchKernelGGL(espitem::fem_expand_k<true>, grid, block, 0, h->stream, a);
+            else
+                hipLaunchKernelGGL(espitem::fem_expand_k<false>, grid, block, 0, h->stream, a);
+            hipLaunchKernelGGL(espitem::scale_segments_k, dim3(grid_for((i64)st.S + 1, 256)), dim3(256), 0, h->stream, st.seg_start, (i64)st.S + 1,
+                               (i64)W, (i64 *)h->seg[1].p);
+            sp.add(2);
+            maxlen_updates = st.maxlen * W;
+        }
+        done = true;
     }
-    const bool k32 = st.rem_bits <= 32 && h->force_path != ESP_PATH_PACKED_KEYS;
-    a.sorted = st.sv;
-    a.sorted_keys = st.sk;
-    a.rem_bits = st.rem_bits;
-    a.base = h->win_base;
-    a.keys_out = (u64 *)h->keys.p;
-    a.vals_out = (double *)h->vals.p;
-    CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(st.S + 1)));
-    {
-        Span sp(h, ESP_ST_APPEND);
-        const dim3 grid(grid_for(NI, espitem::THREADS)), block(espitem::THREADS);
-        if (k32)
-            hipLaunchKernelGGL(espitem::fem_expand_k<true>, grid, block, 0, h->stream, a);
-        else
-            hipLaunchKernelGGL(espitem::fem_expand_k<false>, grid, block, 0, h->stream, a);
-        hipLaunchKernelGGL(espitem::scale_segments_k, dim3(grid_for((i64)st.S + 1, 256)), dim3(256), 0, h->stream, st.seg_start, (i64)st.S + 1,
-                           (i64)W, (i64 *)h->seg[1].p);
-        sp.add(2);
-    }
+    if (!done) return ESP_OK;
+    st.rem_bits -= lbits;
     HIPCK(h, hipGetLastError());
     esp_handle::PrePart &pp = h->pre;
     pp.K = K;
     pp.pb = K - st.rem_bits;
-    pp.maxlen = st.maxlen * W;
-    pp.key_bytes = k32 ? 4 : 8;
+    pp.maxlen = maxlen_updates;
+    pp.key_bytes = (st.rem_bits <= 32 && h->force_path != ESP_PATH_PACKED_KEYS) ? 4 : 8;
     pp.kind = ESP_RAWUPDATE;
     pp.E = E;
     pp.tail = 0;

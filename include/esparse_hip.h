@@ -403,6 +403,10 @@ typedef enum {
     ESP_PATH_TAIL_TO_FRONT = 29,     /* the entries behind a batch that was flushed by itself are copied to the front of
                                         the buffer before their partition (instead of being read where they lie)            */
     ESP_PATH_NO_GROUP3 = 30,         /* never the group-tier kernel with three workgroups per CU (group3_k)                  */
+    ESP_PATH_LOCAL_BITS = 32,        /* item partitions (esp_generate_fem in a shuffled order, esp_append_elements): the passes
+                                        stop up to three bits early and the expansion orders every segment of up to 4096 items
+                                        by the last bits itself (segexpand.hpp) -- one pass less, a slower expansion: measured
+                                        slower at config 4's sizes, so not the default                                      */
     ESP_PATH_NO_PLAN_REUSE = 31      /* esp_append_device / esp_commit of one kind on an empty buffer always count their columns
                                         (never the run lists of the previous, identical-looking batch)                      */
 } esp_debug_path;

@@ -1016,6 +1016,12 @@ def test_item_producer_shuffled_fem(esp, orc):
         C.flush()
         assert C.debug_last_partition() == 4 and C.debug_last_key_bytes() == 8
         assert_csc_equal(hip_arrays(C), want, "packed keys")
+        L3 = esp.ExtendableSparseMatrix(nn, nn)
+        L3.debug_force_path(32)       # the passes stop early, the expansion orders every segment by the last bits (segexpand.hpp)
+        L3.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
+        L3.flush()
+        assert L3.debug_last_partition() == 4
+        assert_csc_equal(hip_arrays(L3), want, "local bits")
         D = esp.ExtendableSparseMatrix(nn, nn)
         D.debug_force_path(28)        # 16-byte item records (the cell's number in a second word)
         D.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
@@ -1097,7 +1103,7 @@ def test_append_elements(esp, orc, monkeypatch):
             assert_csc_equal(hip_arrays(B), want, "elements device")
             # packed keys, the item partition off (stream order through the flush's own passes), and without the cell
             # records (the expansion gathers from the caller's arrays, as it does for other cell sizes)
-            for force, parts in ((14, (4,)), (25, (1, 2)), (-1, (4,))):
+            for force, parts in ((14, (4,)), (25, (1, 2)), (-1, (4,)), (32, (4,))):   # (32: the expansion resolves the last bits)
                 Cc = esp.ExtendableSparseMatrix(nn, nn)
                 if force >= 0:
                     Cc.debug_force_path(force)
