@@ -202,6 +202,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
     h->last_local_small = small_variant ? 1 : 0;
     std::function<int32_t(bool)> launch_all;
     bool used_g3 = false;
+    bool want_wide = h->g3_wide && h->force_path != ESP_PATH_NO_WIDE_GROUP3;
     {
         Span sp(h, ESP_ST_LOCAL);
         a.kind32 = (u32)((st.key_bytes == 4 || st.p32_piece >= 0 || st.all32) ? st.kind : 0);
@@ -285,6 +286,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
             var.g3 = allow_g3 && grp && Z0 == 0 && (keys == 1 || keys == 2) && a.cl_bits >= 0 && a.cl_bits <= esplocal::G3_CL_BITS &&
                      a.cl_bits + a.rb <= 32 && a.rb <= 30 && longest <= 128.0 && !h->g3_off && !a.no_group && !a.stop_after &&
                      h->force_path != ESP_PATH_NO_GROUP3;
+            var.g3wide = var.g3 && want_wide;
             used_g3 = used_g3 || var.g3;
             if (!esplocal::launch(var, grid, h->stream, a)) FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (no bucket kernel for this flush)");
         }
@@ -300,6 +302,32 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         return ESP_OK;
     };
     CK(read_back());
+    auto reset_launch_state = [&]() -> int32_t {
+        HIPCK(h, hipMemsetAsync(status, 0, sizeof(u64) * (size_t)(S + 2 + G), h->stream));
+        if (!direct) {
+            i64 c0, cnt;
+            col_range(h, &c0, &cnt);
+            HIPCK(h, hipMemsetAsync((u64 *)h->colend.p + c0, 0, sizeof(u64) * (size_t)cnt, h->stream));
+        }
+        return ESP_OK;
+    };
+    if (used_g3 && !want_wide && h->force_path != ESP_PATH_NO_WIDE_GROUP3) {
+        const u32 e = (u32)(h->pin_scalar[1] >> 32);
+        if ((e & 8u) && (e & 16u) && !(e & 32u)) {
+            // every segment the kernel refused, it refused for its ROWS alone (spread over more than 2^18: a mesh numbered
+            // without locality): nothing of a fresh-matrix flush has taken effect -- once more with the kernel's wide form
+            // (full rows in LDS, every run sorted twice), which serves this handle from now on
+            want_wide = true;
+            h->g3_wide = true;
+            CK(reset_launch_state());
+            {
+                Span sp(h, ESP_ST_LOCAL);
+                CK(launch_all(true));
+                sp.add(1);
+            }
+            CK(read_back());
+        }
+    }
     if (used_g3 && ((u32)(h->pin_scalar[1] >> 32) & 8u)) {
         // a segment the three-workgroup group kernel does not take (a longer run, rows too far apart): nothing of a
         // fresh-matrix flush has taken effect -- once more with the general kernels, and they serve this handle from now on
@@ -317,7 +345,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         }
         CK(read_back());
     }
-    h->last_group3 = used_g3 ? 1 : 0;
+    h->last_group3 = used_g3 ? (want_wide ? 2 : 1) : 0;
 
     if ((u32)h->pin_scalar[3]) {
         restore_colptr();

@@ -17,14 +17,18 @@ namespace esplocal {
 // NI = 6: segments of at most 3072 entries -- 39 KiB of LDS and 54 registers: FOUR workgroups per CU.  (Not instantiated: the
 // headline's stencil segments -- runs of 12, two lanes x 8 keys per column -- take 1.63 ms this way with three workgroups per CU
 // and 1.57 ms with four, against 1.56 ms in the register tiers of local_k's small variant on the same box.)
-template <int KEYS, int NI = ITEMS>
-__global__ __launch_bounds__(THREADS, NI == 6 ? 8 : 6) void group3_k(Args a) {
+// WIDE: the rows of a segment may lie anywhere (a mesh numbered without locality): every entry's full row in a second
+// LDS array (16 KiB more: two workgroups per CU), the run sorted twice (group_columns<..., WIDE>); rows may span 2^29.
+// A segment the plain kernel refuses for its rows ALONE reports bit 16 beside bit 8: the host then takes this one.
+template <int KEYS, int NI = ITEMS, bool WIDE = false>
+__global__ __launch_bounds__(THREADS, WIDE ? 4 : NI == 6 ? 8 : 6) void group3_k(Args a) {
     static_assert(KEYS == 1 || KEYS == 2, "4-byte keys of one kind");
     static_assert(NI == ITEMS || NI == 6, "4096 or 3072 entries per segment");
     constexpr bool UPD = KEYS == 2;
     constexpr int CAPK = THREADS * NI;
     __shared__ u32 skey[CAPK];
     __shared__ double sval[CAPK];
+    __shared__ u32 srow[WIDE ? CAPK : 1];
     __shared__ u32 ccnt[(1 << G3_CL_BITS) + 4];
     __shared__ unsigned short ctot[1 << G3_CL_BITS];
     __shared__ u32 lw[16];
@@ -135,8 +139,12 @@ __global__ __launch_bounds__(THREADS, NI == 6 ? 8 : 6) void group3_k(Args a) {
     const int gmode = (UPD || a.kind_all == ESP_UPDATE) ? 1 : a.kind_all == ESP_RAWUPDATE ? 2 : 0;
     // the shape: G lanes x 8 keys per column, every column of the segment at once
     const int G = maxrun <= 16 ? 2 : maxrun <= 32 ? 4 : maxrun <= 64 ? 8 : 16;
-    const bool fits = n == 0 || (maxrun <= 128 && ncl * G <= THREADS && s_rmax - rmin < (1u << GROUP_ROW_BITS) && gmode != 0 && a.stop_after == 0);
-    if (!fits && t == 0) atomicOr(a.err, 8u);
+    const bool shape_ok = maxrun <= 128 && ncl * G <= THREADS && gmode != 0 && a.stop_after == 0;
+    const u32 span = s_rmax - rmin;
+    const bool rows_ok = WIDE ? (span >> GROUP_ROW_BITS) < (1u << WIDE_HI_BITS) : span < (1u << GROUP_ROW_BITS);
+    const bool fits = n == 0 || (shape_ok && rows_ok);
+    // (8: the segment is not this kernel's; 16: ... some segment for its rows: the wide kernel may still take the flush)
+    if (!fits && t == 0) atomicOr(a.err, (!WIDE && !rows_ok) ? (8u | 16u) : (8u | 32u));
     LbState lbs;
     lb_init(lbs, 0);
     bool dense = false;
@@ -144,9 +152,12 @@ __global__ __launch_bounds__(THREADS, NI == 6 ? 8 : 6) void group3_k(Args a) {
 #pragma unroll
         for (int i = 0; i < NI; i++) {
             const int p = wbase + i * ESP_WAVE;
-            if (p < n)
+            if (p < n) {
+                const u32 rel = (k[i] & rowmask32) - rmin;
                 skey[ccnt[min(k[i] >> a.rb, (u32)(ncl - 1))] + slot[i]] =
-                    (((k[i] & rowmask32) - rmin) << SUB_SHIFT) | (u32)((p << ESP_TAG_BITS) | (int)a.kind32);
+                    ((WIDE ? (rel & ((1u << GROUP_ROW_BITS) - 1u)) : rel) << SUB_SHIFT) | (u32)((p << ESP_TAG_BITS) | (int)a.kind32);
+                if constexpr (WIDE) srow[p] = rel;
+            }
         }
         __syncthreads();
         unsigned long long *gstamp = nullptr;
@@ -157,12 +168,12 @@ __global__ __launch_bounds__(THREADS, NI == 6 ? 8 : 6) void group3_k(Args a) {
         }
 #endif
         const DenseCtx dcx{&s_early, ctot, &lbs, s};
-#define ESP_G3_GO(GG)                                                                                                      \
-    do {                                                                                                                   \
-        if (gmode == 1)                                                                                                    \
-            group_columns<GG, 8, CAPK, true, 1, true, u32>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp, &dcx);     \
-        else                                                                                                               \
-            group_columns<GG, 8, CAPK, true, 2, true, u32>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp, &dcx);     \
+#define ESP_G3_GO(GG)                                                                                                                \
+    do {                                                                                                                             \
+        if (gmode == 1)                                                                                                              \
+            group_columns<GG, 8, CAPK, true, 1, true, u32, WIDE>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp, &dcx, srow);   \
+        else                                                                                                                         \
+            group_columns<GG, 8, CAPK, true, 2, true, u32, WIDE>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp, &dcx, srow);   \
     } while (0)
         if (G == 2)
             ESP_G3_GO(2);

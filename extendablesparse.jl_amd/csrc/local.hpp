@@ -813,12 +813,20 @@ struct DenseCtx {
 constexpr int DENSE_COLS = 512;
 // KT = u32 (the three-workgroup kernel group3_k, dense form only): the LDS key array holds the 32-bit SORT keys already,
 // and takes the records as (local column << rb) | row.
-template <int G, int R, int CAPK, bool FRESH, int MODE, bool DENSE = false, typename KT = u64>
+// WIDE (group3_k's second instantiation: rows of a segment spread over more than 2^18 -- a mesh whose node numbering has no
+// locality): srow[slot] holds every entry's full row (relative to the segment's smallest), the sort keys its low 18 bits; the
+// run is sorted TWICE with the same network -- by (low bits, slot), then by (high bits, rank of the low-bit group, slot): the
+// keys are unique through their slot, so two unstable sorts compose like a stable two-digit LSD sort -- and a record takes
+// its row from srow.  Rows may span 2^29.
+constexpr int WIDE_GID_BITS = 7;                                   // rank of a low-bit group inside its column run (<= 128 entries)
+constexpr int WIDE_HI_BITS = 32 - SUB_SHIFT - WIDE_GID_BITS;       // 11 high row bits in the second sort key
+template <int G, int R, int CAPK, bool FRESH, int MODE, bool DENSE = false, typename KT = u64, bool WIDE = false>
 __device__ __forceinline__ bool group_columns(const Args &a, KT *skey, double *sval, const u32 *ccnt, int ncl, u32 rmin, u64 hi,
-                                              u64 rowmask, unsigned long long *stamp, const DenseCtx *dc = nullptr) {
+                                              u64 rowmask, unsigned long long *stamp, const DenseCtx *dc = nullptr, const u32 *srow = nullptr) {
     static_assert(!DENSE || (FRESH && MODE != 0), "the dense form is the fresh-matrix addition fold");
     constexpr bool K32L = sizeof(KT) == 4;
     static_assert(!K32L || DENSE, "32-bit LDS keys: dense form only");
+    static_assert(!WIDE || (K32L && R * G <= (1 << WIDE_GID_BITS)), "wide rows: the three-workgroup kernel's shapes only");
     const int t = threadIdx.x, q = t & (G - 1), lane = t & (ESP_WAVE - 1);
     constexpr int CPB = THREADS / G;  // columns the workgroup takes at a time
     constexpr u32 LOWMASK = (1u << SUB_SHIFT) - 1u;
@@ -849,6 +857,46 @@ __device__ __forceinline__ bool group_columns(const Args &a, KT *skey, double *s
             }
         }
         group_sort<G, R>(x, q);
+        if constexpr (WIDE) {
+            // rank of every entry's low-bit group inside the run (the number of group starts up to it, minus one) ...
+            const int nv1 = max(0, min(R, len - q * R));
+            const u32 before1 = (u32)__builtin_amdgcn_update_dpp(0, (int)x[R - 1], 0x111 /* row_shr:1 */, 0xf, 0xf, true);
+            u32 h1 = 0;
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const u32 prev = r == 0 ? before1 : x[r - 1];
+                const bool hh = r < nv1 && ((r == 0 && q == 0) || (prev >> SUB_SHIFT) != (x[r] >> SUB_SHIFT));
+                h1 |= hh ? 1u << r : 0u;
+            }
+            const u32 mine1 = (u32)__popc(h1);
+            u32 inc1 = mine1;
+            if constexpr (G >= 2) {
+                const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)inc1, 0x111, 0xf, 0xf, true);
+                inc1 += q >= 1 ? o : 0u;
+            }
+            if constexpr (G >= 4) {
+                const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)inc1, 0x112, 0xf, 0xf, true);
+                inc1 += q >= 2 ? o : 0u;
+            }
+            if constexpr (G >= 8) {
+                const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)inc1, 0x114, 0xf, 0xf, true);
+                inc1 += q >= 4 ? o : 0u;
+            }
+            if constexpr (G >= 16) {
+                const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)inc1, 0x118, 0xf, 0xf, true);
+                inc1 += q >= 8 ? o : 0u;
+            }
+            const u32 base1 = inc1 - mine1;
+            // ... and the second sort: (high row bits, that rank, slot)
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const u32 gid = base1 + (u32)__popc(h1 & ((2u << r) - 1u)) - 1u;
+                const u32 slot_kind = x[r] & LOWMASK;
+                const u32 rowfull = srow[(x[r] >> ESP_TAG_BITS) & (CAP - 1)];
+                x[r] = r < nv1 ? (((rowfull >> GROUP_ROW_BITS) << (SUB_SHIFT + WIDE_GID_BITS)) | ((gid & ((1u << WIDE_GID_BITS) - 1u)) << SUB_SHIFT) | slot_kind) : ~0u;
+            }
+            group_sort<G, R>(x, q);
+        }
 #ifdef ESP_LOCAL_STAMPS
         if (stamp && t == 0 && c0 == 0) stamp[13] = wall_clock64();
 #endif
@@ -1051,7 +1099,9 @@ __device__ __forceinline__ bool group_columns(const Args &a, KT *skey, double *s
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 if ((emit >> r) & 1u) {
-                    if constexpr (K32L)
+                    if constexpr (WIDE)
+                        skey[d] = (u32)colpart | (srow[(x[r] >> ESP_TAG_BITS) & (CAP - 1)] + rmin);
+                    else if constexpr (K32L)
                         skey[d] = (u32)colpart | ((x[r] >> SUB_SHIFT) + rmin);
                     else
                         skey[d] = hi + (colpart | (u64)((x[r] >> SUB_SHIFT) + rmin));

@@ -85,6 +85,7 @@ struct Variant {
     bool grp = false;  // the group-tier kernel (column runs of more than 16 entries): regular form only
     bool shortg = false;  // ... its form for runs of at most 32 entries (four lanes x 8 keys per column)
     bool g3 = false;      // ... the group tier as a kernel of its own with three workgroups per CU (group3.hpp)
+    bool g3wide = false;  // ... its form for segments whose rows spread over more than 2^18 (two sorts per run, two workgroups per CU)
 };
 // enqueues the kernel; false when the combination has no instantiation
 bool launch(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);

@@ -5,6 +5,15 @@ namespace esplocal {
 
 bool launch_group3(const Variant &v, unsigned grid, hipStream_t stream, const Args &a) {
     if (!v.fresh || v.pieces) return false;
+    if (v.g3wide) {  // (rows of a segment anywhere in the matrix: full rows in LDS, every run sorted twice)
+        if (v.keys == 1)
+            hipLaunchKernelGGL((group3_k<1, ITEMS, true>), dim3(grid), dim3(THREADS), 0, stream, a);
+        else if (v.keys == 2)
+            hipLaunchKernelGGL((group3_k<2, ITEMS, true>), dim3(grid), dim3(THREADS), 0, stream, a);
+        else
+            return false;
+        return true;
+    }
     if (v.keys == 1) {
         hipLaunchKernelGGL((group3_k<1>), dim3(grid), dim3(THREADS), 0, stream, a);
         return true;

@@ -407,6 +407,8 @@ typedef enum {
                                         stop up to three bits early and the expansion orders every segment of up to 4096 items
                                         by the last bits itself (segexpand.hpp) -- one pass less, a slower expansion: measured
                                         slower at config 4's sizes, so not the default                                      */
+    ESP_PATH_NO_WIDE_GROUP3 = 33,    /* never the wide form of group3_k (rows of a segment spread over more than 2^18: full rows
+                                        in LDS, every column run sorted twice); such segments go to local_k's kernels         */
     ESP_PATH_NO_PLAN_REUSE = 31      /* esp_append_device / esp_commit of one kind on an empty buffer always count their columns
                                         (never the run lists of the previous, identical-looking batch)                      */
 } esp_debug_path;
@@ -431,7 +433,8 @@ int32_t esp_debug_last_fold_update(const esp_handle *h, int32_t *on);
  * columns, no radix tier, 51 KiB of LDS = three workgroups per CU instead of two (column runs longer than its register
  * tiers take go through a slow tier and send the handle's next flushes to the regular kernel); esp_debug_force_path(18):
  * never.  2 when it was the group tier's kernel with three workgroups per CU (group3_k: long column runs on a fresh matrix,
- * 4-byte keys; esp_debug_force_path(30): never) */
+ * 4-byte keys; esp_debug_force_path(30): never); 3 when it was that kernel's WIDE form (rows of a segment spread over more than
+ * 2^18 -- a mesh numbered without locality: every run sorted twice; esp_debug_force_path(33): never) */
 int32_t esp_debug_last_local_small(const esp_handle *h, int32_t *small);
 /* 1 when the last append-is-the-partition of caller-supplied triplets (esp_append_device / esp_commit of one kind on an
  * empty buffer) used the run lists of the previous assembly instead of counting its columns again: a batch of the same

@@ -2328,9 +2328,25 @@ def test_elements_digest(esp, dim, npd, node_mode):
     A.append_elements(cn, em, dg)
     A.flush()
     assert A.debug_last_partition() == 4
+    # natural numbering: the group-tier kernel with three workgroups per CU (2); permuted numbering of more than 2^18 nodes:
+    # its wide form (3: full rows in LDS, every column run sorted twice) -- not local_k's radix tier
+    assert A.debug_last_local_small() == (3 if (node_mode == 1 and nn > (1 << 18)) else 2), A.debug_last_local_small()
     arrs = hip_arrays(A)
     assert len(arrs[1]) == int(d["nnz"])
     assert gu.digest(*arrs) == d["csc"]
+    if node_mode == 1 and npd in (1000, 64):
+        # the same without the wide form (force_path 33: local_k's kernels), and a second assembly on the handle that has
+        # learnt (straight to the wide form)
+        B = esp.ExtendableSparseMatrix(nn, nn)
+        B.debug_force_path(33)
+        B.append_elements(cn, em, dg)
+        B.flush()
+        assert B.debug_last_local_small() != 3
+        assert gu.digest(*hip_arrays(B)) == d["csc"]
+        A.reset()
+        A.append_elements(cn, em, dg)
+        A.flush()
+        assert gu.digest(*hip_arrays(A)) == d["csc"]
 
 
 @pytest.mark.parametrize("dim,npd", [(2, 1000), (3, 64)])
