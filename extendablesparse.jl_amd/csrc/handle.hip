@@ -362,9 +362,11 @@ int32_t pack_device(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const d
     }
     HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
-    if (h->pin_scalar[0] != ~0ull)
+    if (h->pin_scalar[0] != ~0ull) {
+        h->pre_keep = false;  // (nothing was appended behind the batch after all)
         FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
              (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
+    }
     if (!d_kinds) note_kind(h, kind_all, count);
     h->count += count;
     pending_changed(h);

@@ -981,6 +981,40 @@ __device__ __forceinline__ bool group_columns(const Args &a, KT *skey, double *s
             double acc = 0.0;
             bool present = false;
             i64 pos = -1;
+            // A re-assembly over the pattern the same mesh built: the k-th (col,row) of a column's sorted run IS the column's
+            // k-th stored entry.  So every first entry of a (col,row) looks there first -- its rank among the run's (col,row)s
+            // from a scan of the lanes' counts, one round trip (the column's start, then row and value side by side with the
+            // neighbouring lanes') -- and searches the column only when that guess does not hold (new couplings, a column the
+            // batch covers in part): the binary search per (col,row), four or five dependent loads each, took 11 of a 3-D FEM
+            // segment's 27 us
+            i64 cstart = 0, cend = 0;
+            u32 gbase = 0;
+            if constexpr (!FRESH) {
+                if (a.csc.nnz > 0 && c < ncl) {
+                    const i64 col = (i64)(colbase >> a.rb);
+                    cstart = a.csc.colptr[col] - 1;
+                    cend = a.csc.colptr[col + 1] - 1;
+                }
+                const u32 mineh = (u32)__popc(heads);
+                u32 inch = mineh;
+                if constexpr (G >= 2) {
+                    const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)inch, 0x111, 0xf, 0xf, true);
+                    inch += q >= 1 ? o : 0u;
+                }
+                if constexpr (G >= 4) {
+                    const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)inch, 0x112, 0xf, 0xf, true);
+                    inch += q >= 2 ? o : 0u;
+                }
+                if constexpr (G >= 8) {
+                    const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)inch, 0x114, 0xf, 0xf, true);
+                    inch += q >= 4 ? o : 0u;
+                }
+                if constexpr (G >= 16) {
+                    const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)inch, 0x118, 0xf, 0xf, true);
+                    inch += q >= 8 ? o : 0u;
+                }
+                gbase = inch - mineh;
+            }
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const bool is_head = (heads >> r) & 1u;
@@ -992,7 +1026,12 @@ __device__ __forceinline__ bool group_columns(const Args &a, KT *skey, double *s
                         acc = 0.0, present = false, pos = -1;
                         if (a.csc.nnz > 0) {
                             const u64 full = colbase + (u64)((x[r] >> SUB_SHIFT) + rmin);
-                            pos = espfold::csc_find(a.csc, (i64)(full >> a.rb), (i64)(full & rowmask));
+                            const i64 row1 = (i64)(full & rowmask) + 1;
+                            const i64 guess = cstart + (i64)gbase + (i64)__popc(heads & ((1u << r) - 1u));
+                            if (guess < cend && a.csc.rowval[guess] == row1)
+                                pos = guess;
+                            else
+                                pos = espfold::csc_find(a.csc, (i64)(full >> a.rb), (i64)(full & rowmask));
                             present = pos >= 0 && a.mode == ESP_FLUSH_ROUTED;
                             acc = present ? a.csc.nzval[pos] : 0.0;
                         }

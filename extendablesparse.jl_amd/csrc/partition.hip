@@ -439,7 +439,8 @@ int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u64 *kou
     return ESP_OK;
 }
 
-// esp_append_device / esp_append_host / esp_commit on an EMPTY buffer, all entries of one kind: the run-based single pass
+// esp_append_device / esp_commit (kind_all >= 0) on an EMPTY buffer, all entries of one kind (NOT esp_append_host, which packs its
+// keys on the host and sends them in stream order: the flush partitions them): the run-based single pass
 // (runpart.hpp) reads the caller's triplets directly -- a count pass over the columns, then one kernel that reads rows,
 // columns and values and stores key and value at their bucket position (4-byte keys when they fit).  What used to be
 // pack (24 B read, 16 B written) + histogram (8 B) + scatter (16 B + 12 B) per entry is 8 B + 24 B read, 12 B written,
@@ -612,9 +613,11 @@ int32_t append_tail_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_c
                      nullptr, 0, /*allow_k32=*/false, &kb, count, &raw));
     HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
-    if (h->pin_scalar[0] != ~0ull)
+    if (h->pin_scalar[0] != ~0ull) {
+        h->pre_keep = false;  // (nothing was appended behind the batch after all)
         FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
              (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
+    }
     if (!ok || kb != 8) {  // no pre-sorted stream: nothing was appended, the caller packs in stream order
         h->runs_penalty = std::min(16, 2 * h->runs_penalty + 1);
         h->runs_skip = h->runs_penalty + 1;

@@ -396,8 +396,8 @@ typedef enum {
                                         group tier (2 .. 16 lanes per column)                                               */
     ESP_PATH_NO_ITEM_PARTITION = 25, /* esp_generate_fem in a shuffled order appends in stream order (no item partition)     */
     ESP_PATH_NO_BIG_VARIANT = 26,    /* never the bucket-kernel variant with the 24-input register tier                      */
-    ESP_PATH_NO_APPEND_PARTITION = 27, /* esp_append_* / esp_commit on an empty buffer pack in stream order (the append is not
-                                        the partition)                                                                      */
+    ESP_PATH_NO_APPEND_PARTITION = 27, /* esp_append_device / esp_commit of one kind on an empty buffer pack in stream order (the
+                                        append is not the partition; esp_append_host always arrives in stream order)       */
     ESP_PATH_TWO_WORD_ITEMS = 28,    /* the item partition of esp_generate_fem moves 16-byte records (key | cell and vertex)
                                         even where the cell's number fits into the key                                      */
     ESP_PATH_TAIL_TO_FRONT = 29,     /* the entries behind a batch that was flushed by itself are copied to the front of
