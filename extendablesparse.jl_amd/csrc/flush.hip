@@ -247,6 +247,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         {
             a.stop_after = stop_env ? atoi(stop_env) : 0;
             a.stamps = nullptr;
+            a.hits_out = nullptr;
             if (getenv("ESP_LOCAL_STAMPS")) {  // diagnostics: per-segment phase stamps, dumped to a file
                 CK(ensure(h, h->heads, sizeof(u64) * (size_t)S * 16));
                 HIPCK(h, hipMemsetAsync(h->heads.p, 0, sizeof(u64) * (size_t)S * 16, h->stream));
@@ -292,8 +293,6 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         }
         return ESP_OK;
         };
-        CK(launch_all(true));
-        sp.add(1);
     }
     auto read_back = [&]() -> int32_t {
         HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (S - 1), 24, hipMemcpyDeviceToHost, h->stream));  // last granule | ticket, err | maxrun
@@ -301,7 +300,6 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         HIPCK(h, hipStreamSynchronize(h->stream));
         return ESP_OK;
     };
-    CK(read_back());
     auto reset_launch_state = [&]() -> int32_t {
         HIPCK(h, hipMemsetAsync(status, 0, sizeof(u64) * (size_t)(S + 2 + G), h->stream));
         if (!direct) {
@@ -311,6 +309,58 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         }
         return ESP_OK;
     };
+    // A re-assembly over the pattern the same mesh built (a ROUTED flush of 4-byte-key additions with long column runs, and
+    // the handle's last flush over the pattern hit): group3_k's re-assembly form -- every (col,row) of a column's sorted run
+    // IS the column's stored entry of the same rank; the sums go to a second value array, swapped in when no column
+    // objected (bit 64) -- else nothing has happened and the general kernels below take the flush.  force_path 34: never.
+    {
+        const bool generic = h->force_path == ESP_PATH_GENERIC_FOLD;
+        const int keys = st.key_bytes != 4 ? 0 : (st.kind == ESP_UPDATE && !generic ? 2 : 1);
+        const double longest = h->seen_maxrun > 0 ? (double)h->seen_maxrun : (double)h->count / (double)std::max<i64>(col_end - col_begin, 1);
+        const bool hits_expected = st.expect_hits >= 0 ? st.expect_hits == 1 : h->seen_hits;
+        bool try_hits = Z0 > 0 && mode == ESP_FLUSH_ROUTED && st.npieces == 0 && (keys == 1 || keys == 2) && (st.kind == ESP_UPDATE || st.kind == ESP_RAWUPDATE) &&
+                        a.kind_all == st.kind && a.cl_bits >= 0 && a.cl_bits <= esplocal::G3_CL_BITS && a.cl_bits + a.rb <= 32 && a.rb <= 30 &&
+                        longest > 16.0 && longest <= 128.0 && hits_expected && !h->hits_off && !a.no_group && !a.stop_after && !small_variant &&
+                        h->force_path != ESP_PATH_NO_GROUP_TIER && h->force_path != ESP_PATH_RADIX_TAIL_ONLY && h->force_path != ESP_PATH_NO_GROUP3 &&
+                        h->force_path != ESP_PATH_NO_HITS_KERNEL && h->force_path != ESP_PATH_MANY_LAUNCHES && (i64)S <= esplocal::MAX_GRID;
+        for (int attempt = 0; attempt < 2 && try_hits; attempt++) {
+            CK(ensure(h, h->nzval2, sizeof(double) * (size_t)Z0));
+            a.hits_out = (double *)h->nzval2.p;
+            a.first = 0;
+            esplocal::Variant var{false, false, false, false, keys};
+            var.grp = var.g3 = var.g3hits = true;
+            var.g3wide = want_wide;
+            {
+                Span sp(h, ESP_ST_LOCAL);
+                if (!esplocal::launch(var, (unsigned)S, h->stream, a)) FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (no re-assembly kernel for this flush)");
+                sp.add(1);
+            }
+            CK(read_back());
+            const u32 e = (u32)(h->pin_scalar[1] >> 32);
+            if ((e & (8u | 64u)) == 0u) {
+                std::swap(h->nzval, h->nzval2);
+                h->last_group3 = want_wide ? 4 : 3;
+                h->seen_maxrun = (int)(u32)(h->pin_scalar[2] & 0xFFFFFFFFull);
+                h->seen_hits = true;
+                *Zn_out = 0;
+                return ESP_OK;
+            }
+            CK(reset_launch_state());
+            if ((e & 8u) && (e & 16u) && !(e & 32u) && !(e & 64u) && !want_wide && h->force_path != ESP_PATH_NO_WIDE_GROUP3) {
+                want_wide = true;  // (refused for its rows alone: once more in the wide form)
+                h->g3_wide = true;
+                continue;
+            }
+            h->hits_off = true;  // (not a re-assembly of the stored pattern, or shapes the kernel does not take: not tried again)
+            try_hits = false;
+        }
+    }
+    {
+        Span sp(h, ESP_ST_LOCAL);
+        CK(launch_all(true));
+        sp.add(1);
+    }
+    CK(read_back());
     if (used_g3 && !want_wide && h->force_path != ESP_PATH_NO_WIDE_GROUP3) {
         const u32 e = (u32)(h->pin_scalar[1] >> 32);
         if ((e & 8u) && (e & 16u) && !(e & 32u)) {

@@ -20,7 +20,9 @@ namespace esplocal {
 // WIDE: the rows of a segment may lie anywhere (a mesh numbered without locality): every entry's full row in a second
 // LDS array (16 KiB more: two workgroups per CU), the run sorted twice (group_columns<..., WIDE>); rows may span 2^29.
 // A segment the plain kernel refuses for its rows ALONE reports bit 16 beside bit 8: the host then takes this one.
-template <int KEYS, int NI = ITEMS, bool WIDE = false>
+// HITS: the re-assembly form (group_columns<..., HITS>): a ROUTED flush of additions over a stored pattern the same mesh built;
+// the new values go to Args::hits_out, all-or-nothing (bit 64 of Args::err: some column is not what the batch covers).
+template <int KEYS, int NI = ITEMS, bool WIDE = false, bool HITS = false>
 __global__ __launch_bounds__(THREADS, WIDE ? 4 : NI == 6 ? 8 : 6) void group3_k(Args a) {
     static_assert(KEYS == 1 || KEYS == 2, "4-byte keys of one kind");
     static_assert(NI == ITEMS || NI == 6, "4096 or 3072 entries per segment");
@@ -145,6 +147,18 @@ __global__ __launch_bounds__(THREADS, WIDE ? 4 : NI == 6 ? 8 : 6) void group3_k(
     const bool fits = n == 0 || (shape_ok && rows_ok);
     // (8: the segment is not this kernel's; 16: ... some segment for its rows: the wide kernel may still take the flush)
     if (!fits && t == 0) atomicOr(a.err, (!WIDE && !rows_ok) ? (8u | 16u) : (8u | 32u));
+    if constexpr (HITS) {
+        if (n == 0 || !fits) {  // (no entries: then none of the segment's columns may hold a stored entry)
+            const i64 c_lo0 = (i64)(hi >> a.rb);
+            bool bad = false;
+            for (int q = t; q < ncl && n == 0; q += THREADS) {
+                const i64 col = c_lo0 + q;
+                bad = bad || (col < a.n_cols && a.csc.colptr[col + 1] != a.csc.colptr[col]);
+            }
+            if (bad) atomicOr(a.err, 64u);
+            return;
+        }
+    }
     LbState lbs;
     lb_init(lbs, 0);
     bool dense = false;
@@ -171,9 +185,9 @@ __global__ __launch_bounds__(THREADS, WIDE ? 4 : NI == 6 ? 8 : 6) void group3_k(
 #define ESP_G3_GO(GG)                                                                                                                \
     do {                                                                                                                             \
         if (gmode == 1)                                                                                                              \
-            group_columns<GG, 8, CAPK, true, 1, true, u32, WIDE>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp, &dcx, srow);   \
+            group_columns<GG, 8, CAPK, true, 1, true, u32, WIDE, HITS>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp, &dcx, srow);   \
         else                                                                                                                         \
-            group_columns<GG, 8, CAPK, true, 2, true, u32, WIDE>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp, &dcx, srow);   \
+            group_columns<GG, 8, CAPK, true, 2, true, u32, WIDE, HITS>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, gstamp, &dcx, srow);   \
     } while (0)
         if (G == 2)
             ESP_G3_GO(2);
@@ -186,6 +200,7 @@ __global__ __launch_bounds__(THREADS, WIDE ? 4 : NI == 6 ? 8 : 6) void group3_k(
 #undef ESP_G3_GO
         dense = true;
     }
+    if constexpr (HITS) return;  // (the sums are in hits_out: nothing to emit)
     __syncthreads();  // the records lie dense in skey / sval; the last wave is at the look-back
 #ifdef ESP_LOCAL_STAMPS
     if (a.stamps && t == 0) a.stamps[(size_t)s * 16 + 4] = wall_clock64();

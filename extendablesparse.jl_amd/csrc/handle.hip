@@ -874,6 +874,7 @@ extern "C" int32_t esp_clear_pending(esp_handle *h) {
 extern "C" int32_t esp_reset(esp_handle *h) {
     if (!h) return ESP_ERR_INVALID;
     (void)hipSetDevice(h->device);
+    h->hits_off = false;  // (a new matrix: its re-assemblies may be what the re-assembly kernel takes)
     h->count = 0;
     pending_changed(h);
     return init_empty_csc(h);

@@ -60,6 +60,7 @@ struct esp_handle {
     int chunk_pb = 0;
     int runs_skip = 0, runs_penalty = 0;  // back-off after a stream turned out not to be pre-sorted
     bool g3_off = false;                  // a segment of this handle's matrix did not fit the three-workgroup group kernel: not tried again
+    bool hits_off = false;                // the re-assembly form of the group kernel met a batch that was no re-assembly of the stored pattern: not tried again (until reset!)
     bool g3_wide = false;                 // ... for its rows alone (spread over more than 2^18): the kernel's wide form serves this handle
     int last_group3 = 0;                  // the last flush's bucket kernel was group3_k (esp_debug_last_local_small reports 2)
     bool seen_hits = true;                // the last flush over a stored pattern mostly hit stored positions (re-assembly)

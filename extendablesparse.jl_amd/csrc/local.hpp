@@ -820,10 +820,17 @@ constexpr int DENSE_COLS = 512;
 // its row from srow.  Rows may span 2^29.
 constexpr int WIDE_GID_BITS = 7;                                   // rank of a low-bit group inside its column run (<= 128 entries)
 constexpr int WIDE_HI_BITS = 32 - SUB_SHIFT - WIDE_GID_BITS;       // 11 high row bits in the second sort key
-template <int G, int R, int CAPK, bool FRESH, int MODE, bool DENSE = false, typename KT = u64, bool WIDE = false>
+// HITS (group3_k's re-assembly form: a ROUTED flush of additions over a stored pattern that the SAME mesh built): the k-th
+// (col,row) of a column's sorted run is the column's k-th stored entry and the run covers them all -- checked, entry by entry
+// and count by count; a column where that does not hold raises bit 64 of Args::err.  The fold is the branch-free fresh-matrix
+// one with the stored value as the start of every (col,row)'s sum; the sums go to a SECOND value array (Args::hits_out) at
+// the stored positions: the host swaps the arrays when no flag came back, else nothing has happened and the flush takes
+// the general kernels.  No records, no look-back, no output stores.
+template <int G, int R, int CAPK, bool FRESH, int MODE, bool DENSE = false, typename KT = u64, bool WIDE = false, bool HITS = false>
 __device__ __forceinline__ bool group_columns(const Args &a, KT *skey, double *sval, const u32 *ccnt, int ncl, u32 rmin, u64 hi,
                                               u64 rowmask, unsigned long long *stamp, const DenseCtx *dc = nullptr, const u32 *srow = nullptr) {
     static_assert(!DENSE || (FRESH && MODE != 0), "the dense form is the fresh-matrix addition fold");
+    static_assert(!HITS || (DENSE && sizeof(KT) == 4), "the re-assembly form: group3_k only");
     constexpr bool K32L = sizeof(KT) == 4;
     static_assert(!K32L || DENSE, "32-bit LDS keys: dense form only");
     static_assert(!WIDE || (K32L && R * G <= (1 << WIDE_GID_BITS)), "wide rows: the three-workgroup kernel's shapes only");
@@ -921,6 +928,55 @@ __device__ __forceinline__ bool group_columns(const Args &a, KT *skey, double *s
         const u64 colbase = hi + ((u64)c << a.rb);
         u32 emit = 0;
         if constexpr (FRESH && MODE != 0) {
+            // HITS: rank of the lane's first (col,row) inside the run, the stored value every (col,row) starts from
+            i64 cstart = 0, cend = 0;
+            u32 gbase = 0;
+            double cst[R];
+            if constexpr (HITS) {
+                const i64 col = (i64)(colbase >> a.rb);
+                if (c < ncl && col < a.n_cols) {
+                    cstart = a.csc.colptr[col] - 1;
+                    cend = a.csc.colptr[col + 1] - 1;
+                }
+                const u32 mineh = (u32)__popc(heads);
+                u32 inch = mineh;
+                if constexpr (G >= 2) {
+                    const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)inch, 0x111, 0xf, 0xf, true);
+                    inch += q >= 1 ? o : 0u;
+                }
+                if constexpr (G >= 4) {
+                    const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)inch, 0x112, 0xf, 0xf, true);
+                    inch += q >= 2 ? o : 0u;
+                }
+                if constexpr (G >= 8) {
+                    const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)inch, 0x114, 0xf, 0xf, true);
+                    inch += q >= 4 ? o : 0u;
+                }
+                if constexpr (G >= 16) {
+                    const u32 o = (u32)__builtin_amdgcn_update_dpp(0, (int)inch, 0x118, 0xf, 0xf, true);
+                    inch += q >= 8 ? o : 0u;
+                }
+                gbase = inch - mineh;
+                bool bad = q == G - 1 && c < ncl && (i64)inch != cend - cstart;  // (the run covers the column's stored entries, all of them)
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    cst[r] = 0.0;
+                    if ((heads >> r) & 1u) {
+                        const i64 pos = cstart + (i64)gbase + (i64)__popc(heads & ((1u << r) - 1u));
+                        u32 rowrel;
+                        if constexpr (WIDE)
+                            rowrel = srow[(x[r] >> ESP_TAG_BITS) & (CAP - 1)];
+                        else
+                            rowrel = x[r] >> SUB_SHIFT;
+                        const i64 row1 = (i64)(((colbase & rowmask) + (u64)rowrel + (u64)rmin)) + 1;
+                        if (pos < cend && a.csc.rowval[pos] == row1)
+                            cst[r] = a.csc.nzval[pos];
+                        else
+                            bad = true;
+                    }
+                }
+                if (bad) atomicOr(a.err, 64u);
+            }
             // ---- pass A, additions on a fresh matrix: running sums, restarted at every first entry of a (col,row); every
             // entry's slot takes the sum up to it -- the slot of a (col,row)'s LAST entry is its record's value slot
             double acc = 0.0;
@@ -928,7 +984,10 @@ __device__ __forceinline__ bool group_columns(const Args &a, KT *skey, double *s
 #pragma unroll
             for (int r = 0; r < R; r++) {
                 const bool is_head = (heads >> r) & 1u;
-                acc = (is_head ? 0.0 : acc) + v[r];
+                if constexpr (HITS)
+                    acc = (is_head ? cst[r] : acc) + v[r];  // (a stored position is present: old + v, whatever v is)
+                else
+                    acc = (is_head ? 0.0 : acc) + v[r];
                 if constexpr (DENSE) {
                     v[r] = r >= f ? acc : v[r];  // (the values in front of the lane's first own (col,row) are pass B's)
                 } else {
@@ -945,10 +1004,10 @@ __device__ __forceinline__ bool group_columns(const Args &a, KT *skey, double *s
             const u32 valid = (1u << nv) - 1u;
             const u32 lastbit = (nv > 0 && !open_end) ? 1u << (nv - 1) : 0u;
             const u32 tails = ((heads >> 1) | lastbit) & valid & ~((1u << f) - 1u);
-            emit = raws ? tails : (tails & pres);
+            emit = (raws || HITS) ? tails : (tails & pres);
             // ---- pass B
             double t_acc = acc;
-            u32 t_present = raws ? 1u : np;
+            u32 t_present = (raws || HITS) ? 1u : np;
             bool final = f < R, need = f > 0;
             while (__ballot(need) != 0ull) {
                 const double in_acc = dpp_shr1_f64(t_acc);
@@ -975,6 +1034,18 @@ __device__ __forceinline__ bool group_columns(const Args &a, KT *skey, double *s
                     }
                     need = false;
                 }
+            }
+            if constexpr (HITS) {
+                // the sums to the second value array, at the stored positions: the (col,row) that ends at entry r has the rank
+                // gbase + (first entries up to r) - 1 -- also the one that came in from the lane before (no first entry up to r)
+#pragma unroll
+                for (int r = 0; r < R; r++) {
+                    if ((emit >> r) & 1u) {
+                        const i64 pos = cstart + (i64)gbase + (i64)__popc(heads & ((2u << r) - 1u)) - 1;
+                        if (pos >= cstart && pos < cend) a.hits_out[pos] = v[r];
+                    }
+                }
+                continue;  // (the next batch of columns, if the segment has more than the workgroup takes at a time: it has not)
             }
         } else {
             // ---- pass A

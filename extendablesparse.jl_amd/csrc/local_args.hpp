@@ -72,6 +72,7 @@ struct Args {
     int no_group;  // test hook: column runs of more than 24 entries go to the radix tier, never to the group tier
     int kind_all;  // >= 0: every pending entry has this kind (the host's bookkeeping), whatever the key format says; else -1
     int expect_hits;  // the host expects most positions to be stored already: a short stored column is fetched with its values
+    double *hits_out; // group3_k's re-assembly form (HITS): the new values of the stored positions (a second nzval array)
 };
 constexpr int MAX_PIECES = 64;
 
@@ -85,6 +86,7 @@ struct Variant {
     bool grp = false;  // the group-tier kernel (column runs of more than 16 entries): regular form only
     bool shortg = false;  // ... its form for runs of at most 32 entries (four lanes x 8 keys per column)
     bool g3 = false;      // ... the group tier as a kernel of its own with three workgroups per CU (group3.hpp)
+    bool g3hits = false;  // ... its re-assembly form: additions over a stored pattern the same mesh built (all-or-nothing, see group_columns)
     bool g3wide = false;  // ... its form for segments whose rows spread over more than 2^18 (two sorts per run, two workgroups per CU)
 };
 // enqueues the kernel; false when the combination has no instantiation

@@ -4,6 +4,18 @@
 namespace esplocal {
 
 bool launch_group3(const Variant &v, unsigned grid, hipStream_t stream, const Args &a) {
+    if (v.g3hits) {  // (additions over a stored pattern the same mesh built: the sums go to a second value array, all-or-nothing)
+        if (v.fresh || v.pieces || (v.keys != 1 && v.keys != 2)) return false;
+        if (v.g3wide && v.keys == 1)
+            hipLaunchKernelGGL((group3_k<1, ITEMS, true, true>), dim3(grid), dim3(THREADS), 0, stream, a);
+        else if (v.g3wide)
+            hipLaunchKernelGGL((group3_k<2, ITEMS, true, true>), dim3(grid), dim3(THREADS), 0, stream, a);
+        else if (v.keys == 1)
+            hipLaunchKernelGGL((group3_k<1, ITEMS, false, true>), dim3(grid), dim3(THREADS), 0, stream, a);
+        else
+            hipLaunchKernelGGL((group3_k<2, ITEMS, false, true>), dim3(grid), dim3(THREADS), 0, stream, a);
+        return true;
+    }
     if (!v.fresh || v.pieces) return false;
     if (v.g3wide) {  // (rows of a segment anywhere in the matrix: full rows in LDS, every run sorted twice)
         if (v.keys == 1)

@@ -409,6 +409,9 @@ typedef enum {
                                         slower at config 4's sizes, so not the default                                      */
     ESP_PATH_NO_WIDE_GROUP3 = 33,    /* never the wide form of group3_k (rows of a segment spread over more than 2^18: full rows
                                         in LDS, every column run sorted twice); such segments go to local_k's kernels         */
+    ESP_PATH_NO_HITS_KERNEL = 34,    /* never group3_k's re-assembly form (additions over a stored pattern the same mesh built:
+                                        every (col,row) of a column run is the stored entry of its rank, sums to a second value
+                                        array, all-or-nothing); such flushes take local_k's group-tier kernels               */
     ESP_PATH_NO_PLAN_REUSE = 31      /* esp_append_device / esp_commit of one kind on an empty buffer always count their columns
                                         (never the run lists of the previous, identical-looking batch)                      */
 } esp_debug_path;
@@ -434,7 +437,8 @@ int32_t esp_debug_last_fold_update(const esp_handle *h, int32_t *on);
  * tiers take go through a slow tier and send the handle's next flushes to the regular kernel); esp_debug_force_path(18):
  * never.  2 when it was the group tier's kernel with three workgroups per CU (group3_k: long column runs on a fresh matrix,
  * 4-byte keys; esp_debug_force_path(30): never); 3 when it was that kernel's WIDE form (rows of a segment spread over more than
- * 2^18 -- a mesh numbered without locality: every run sorted twice; esp_debug_force_path(33): never) */
+ * 2^18 -- a mesh numbered without locality: every run sorted twice; esp_debug_force_path(33): never); 4 / 5 when it was that
+ * kernel's re-assembly form over a stored pattern (plain / wide; esp_debug_force_path(34): never) */
 int32_t esp_debug_last_local_small(const esp_handle *h, int32_t *small);
 /* 1 when the last append-is-the-partition of caller-supplied triplets (esp_append_device / esp_commit of one kind on an
  * empty buffer) used the run lists of the previous assembly instead of counting its columns again: a batch of the same

@@ -1117,9 +1117,38 @@ def test_append_elements(esp, orc, monkeypatch):
             # re-assembly over the stored pattern (all hits), then twice in a row (the second call goes behind the batch)
             A.append_elements(dcn, dem, ddg)
             A.flush()
+            # (additions over the pattern the same mesh built: the group kernel's re-assembly form -- 4, or 5 in its wide form)
+            assert A.debug_last_local_small() in (4, 5), A.debug_last_local_small()
             O.apply(np.full(len(I), RAW, np.uint8), I, J, V)
             O.flush()
             assert_csc_equal(hip_arrays(A), O.arrays(), "re-assembly")
+            # ... a third time with other values, as updateindex! calls; then with the re-assembly kernel off (force_path 34)
+            em3 = (dem * 0.37).contiguous()
+            A.append_elements(dcn, em3, ddg, kind=UPDATE)
+            A.flush()
+            assert A.debug_last_local_small() in (4, 5)
+            I3, J3, V3 = orc.elements_stream(cn, np.asfortranarray(em * 0.37), dg)
+            O.apply(np.full(len(I3), UPDATE, np.uint8), I3, J3, V3)
+            O.flush()
+            assert_csc_equal(hip_arrays(A), O.arrays(), "third assembly")
+            A.debug_force_path(34)
+            A.append_elements(dcn, dem, ddg)
+            A.flush()
+            assert A.debug_last_local_small() not in (4, 5)
+            A.debug_force_path(0)
+            O.apply(np.full(len(I), RAW, np.uint8), I, J, V)
+            O.flush()
+            assert_csc_equal(hip_arrays(A), O.arrays(), "re-assembly without the re-assembly kernel")
+            # a batch that is NOT a re-assembly of the pattern (one cell's column gets a coupling it never had): all-or-nothing
+            cnx = cn.copy(order="F")
+            cnx[0, 0] = cn[0, nc // 2]
+            if len(set(cnx[:, 0].tolist())) == nloc:
+                A.append_elements(cnx, em, dg)
+                A.flush()
+                Ix, Jx, Vx = orc.elements_stream(cnx, em, dg)
+                O.apply(np.full(len(Ix), RAW, np.uint8), Ix, Jx, Vx)
+                O.flush()
+                assert_csc_equal(hip_arrays(A), O.arrays(), "a batch with new couplings over the stored pattern")
             A.reset()
             O.reset()
             A.append_elements(dcn, dem, ddg)
