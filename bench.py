@@ -439,6 +439,30 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
                         "ms": dt * 1e3, "nnz_per_s": Z / dt, "appended_per_s": E / dt, "final_nnz": Z,
                         "algorithmic_bytes": algo, "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS,
                         "partition": A.debug_last_partition(), "stage_ms": stages(tm, 1), "steps": len(dts), "digest_ok": ok4}
+            # ---- a time step's re-assembly over the stored pattern: zero!(A) (sprand.jl:82 style), the stream again, flush! --
+            # every update meets a stored position (the group kernel's re-assembly form); the result is the fresh build's, bit
+            # for bit (0.0 + v1 + v2 ... in call order either way): the same pin
+            rtag = tag + "_reassembly"
+            try:
+                dts = []
+                for it in range(steps + 1):
+                    A.synchronize()
+                    t0 = time.perf_counter()
+                    A.zero_values()
+                    A.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
+                    A.flush()
+                    A.synchronize()
+                    if it > 0:
+                        dts.append(time.perf_counter() - t0)
+                okr = csc_digest_ok(A, "fem%dd_%d_o1" % (dim, npd), pins)
+                dt = sum(dts) / len(dts)
+                algo = 2 * 16.0 * E + 2 * 8.0 * Z + 8.0 * Z + 8.0 * (nn + 1)   # the stream written and read, nzval read and written, rowval + colptr read
+                out[rtag] = {"workload": "re-assembly of the same %d-D mesh over its stored pattern: zero!, %d rawupdateindex! calls, flush! "
+                                         "(every update hits)" % (dim, E),
+                             "ms": dt * 1e3, "appended_per_s": E / dt, "algorithmic_bytes": algo, "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS,
+                             "bucket_kernel": A.debug_last_local_small(), "steps": len(dts), "digest_ok": okr}
+            except Exception as ex:
+                out[rtag] = {"error": repr(ex)}
             del A
         except Exception as ex:
             out[tag] = {"error": repr(ex)}
