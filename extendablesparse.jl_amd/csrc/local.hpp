@@ -1063,8 +1063,10 @@ __device__ __forceinline__ bool group_columns(const Args &a, KT *skey, double *s
             if constexpr (!FRESH) {
                 if (a.csc.nnz > 0 && c < ncl) {
                     const i64 col = (i64)(colbase >> a.rb);
-                    cstart = a.csc.colptr[col] - 1;
-                    cend = a.csc.colptr[col + 1] - 1;
+                    if (col < a.n_cols) {  // (the last segment's column block may reach past the matrix)
+                        cstart = a.csc.colptr[col] - 1;
+                        cend = a.csc.colptr[col + 1] - 1;
+                    }
                 }
                 const u32 mineh = (u32)__popc(heads);
                 u32 inch = mineh;
