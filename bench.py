@@ -505,6 +505,34 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
                          "algorithmic_bytes": algo, "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS,
                          "vs_generator": dt * 1e3 / out[tag]["ms"] if "ms" in out.get(tag, {}) else None,
                          "partition": A.debug_last_partition(), "stage_ms": stages(tm, 1), "steps": len(dts), "digest_ok": oke}
+            # ---- a time step of the same mesh: zero!, the element loop over the KEPT plan (esp_append_elements_again: no pass
+            # over the connectivity, no item partition), flush! over the stored pattern; the result is the fresh build's
+            ptag = etag + "_timestep"
+            try:
+                A.elements_keep_plan()
+                A.reset()
+                A.append_elements(cn, em, dg, kind=esp.ESP_RAWUPDATE)
+                A.flush()
+                dts = []
+                for it in range(steps + 1):
+                    A.synchronize()
+                    t0 = time.perf_counter()
+                    A.zero_values()
+                    A.append_elements_again(em, dg, kind=esp.ESP_RAWUPDATE)
+                    A.flush()
+                    A.synchronize()
+                    if it > 0:
+                        dts.append(time.perf_counter() - t0)
+                okp = csc_digest_ok(A, "fem%dd_%d_o1" % (dim, npd), pins)
+                dt = sum(dts) / len(dts)
+                algo = 8.0 * nc * nloc * (nloc + 1) + 2 * 16.0 * E + 2 * 8.0 * Z + 8.0 * Z + 8.0 * (nn + 1)
+                out[ptag] = {"workload": "a time step of the same mesh: zero!, esp_append_elements_again (kept item order and cell records, new "
+                                         "elmat / diag), flush! over the stored pattern", "ms": dt * 1e3, "appended_per_s": E / dt,
+                             "algorithmic_bytes": algo, "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS,
+                             "bucket_kernel": A.debug_last_local_small(), "steps": len(dts), "digest_ok": okp}
+                A.elements_keep_plan(False)
+            except Exception as ex:
+                out[ptag] = {"error": repr(ex)}
             # ... and as resident Int64 / Int64 / Float64 triplets through esp_append_device (what a caller without the
             # element-level call pays: a shuffled stream, the flush's own passes over 16-byte records)
             ttag = "cfg4_generic_triplets_%dd" % dim

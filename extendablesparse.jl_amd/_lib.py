@@ -64,6 +64,9 @@ SIGNATURES = {
     "esp_generate_fem": (i32, [vp, i32, i64, u64, i32]),
     "esp_append_elements": (i32, [vp, i32, i64, vp, vp, vp, i32, i32]),
     "esp_append_elements_host": (i32, [vp, i32, i64, vp, vp, vp, i32, i32]),
+    "esp_elements_keep_plan": (i32, [vp, i32]),
+    "esp_append_elements_again": (i32, [vp, vp, vp, i32, i32]),
+    "esp_append_elements_again_host": (i32, [vp, vp, vp, i32, i32]),
     "esp_generate_fem_mesh": (i32, [vp, i32, i64, u64, i32, i32, u64, i64, i64, vp, vp, vp]),
     "esp_generate_fdrand_range": (i32, [vp, i64, i64, i64, u64, i32, i32, i64, i64]),
     "esp_set_column_window": (i32, [vp, i64, i64]),

@@ -202,11 +202,121 @@ int32_t elements_by_items(esp_handle *h, espelem::Args a, i64 E, bool *took) {
     pp.Ee = plan_entries(E, K, h->win_span);
     pp.mw_P = 0, pp.mw_me = 0, pp.mw_shift = 0, pp.mw_nb = 0, pp.mw_eps = 0;
     pp.own32 = false;
+    // esp_elements_keep_plan: item order, cell records and segment table into buffers of their own (the flush is about to
+    // take the scratch pair they lie in) for esp_append_elements_again
+    esp_handle::ElemPlan &ep = h->elemplan;
+    ep.valid = false;
+    if (ep.keep && cellrec && lbits == 0) {
+        const i64 S_final = (i64)st.S;
+        CK(ensure(h, ep.sorted, sizeof(u64) * (size_t)NI));
+        CK(ensure(h, ep.cellrec, (size_t)a.ncells * 64));
+        CK(ensure(h, ep.segtab, sizeof(i64) * (size_t)(S_final + 1)));
+        Span sp(h, ESP_ST_COPY);
+        HIPCK(h, hipMemcpyAsync(ep.sorted.p, st.sk, sizeof(u64) * (size_t)NI, hipMemcpyDeviceToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(ep.cellrec.p, a.cellrec, (size_t)a.ncells * 64, hipMemcpyDeviceToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync(ep.segtab.p, h->seg[1].p, sizeof(i64) * (size_t)(S_final + 1), hipMemcpyDeviceToDevice, h->stream));
+        sp.add(3);
+        ep.nloc = a.nloc, ep.W = W, ep.vrb = vrb, ep.rem_real = rem_real, ep.K = K, ep.kind = a.kind;
+        ep.k32 = k32, ep.has_diag = a.diag != nullptr;
+        ep.ncells = a.ncells, ep.S = S_final, ep.maxlen = maxlen_updates;
+        ep.base = h->win_base, ep.span = h->win_span;
+        ep.valid = true;
+    }
     *took = true;  // (the caller sets pre.valid once the entries are counted in)
     return ESP_OK;
 }
 
 }  // namespace
+
+// A handle that keeps the plan of its element-level appends (item order, cell records, segment table: 8 B per item + 64 B
+// per cell of device memory) for esp_append_elements_again.  on = 0: off, the buffers are released.
+extern "C" int32_t esp_elements_keep_plan(esp_handle *h, int32_t on) {
+    if (!h) return ESP_ERR_INVALID;
+    h->elemplan.keep = on != 0;
+    if (!on) {
+        (void)hipSetDevice(h->device);
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        h->elemplan.valid = false;
+        release(h->elemplan.sorted);
+        release(h->elemplan.cellrec);
+        release(h->elemplan.segtab);
+    }
+    return ESP_OK;
+}
+
+// The element loop again over the SAME connectivity as the handle's last planned esp_append_elements (a time step of an
+// instationary / nonlinear code: the mesh stays, the element matrices change): no pass over the connectivity, no item
+// partition -- the diag values of the cell records are refreshed and the expansion runs over the kept item order.  The
+// entries are, bit for bit, what esp_append_elements(h, nloc, ncells, the same cellnodes, d_elmat, d_diag, kind, op) appends.
+extern "C" int32_t esp_append_elements_again(esp_handle *h, const double *d_elmat, const double *d_diag, int32_t kind, int32_t op) {
+    if (!h || !d_elmat) return ESP_ERR_INVALID;
+    if (kind < 0 || kind > 3) FAIL(h, ESP_ERR_INVALID, "append: kind %d invalid", kind);
+    if (op != ESP_OP_ADD && op != ESP_OP_SUB) FAIL(h, ESP_ERR_UNSUPPORTED, "append: op %d not supported on the device path", op);
+    const esp_handle::ElemPlan &ep = h->elemplan;
+    if (!ep.valid) FAIL(h, ESP_ERR_STATE, "esp_append_elements_again: the handle keeps no plan (esp_elements_keep_plan, then esp_append_elements on an empty buffer)");
+    if ((d_diag != nullptr) != ep.has_diag) FAIL(h, ESP_ERR_INVALID, "esp_append_elements_again: the planned call %s a diagonal term", ep.has_diag ? "had" : "had no");
+    if (h->count != 0 || windowed(h) || h->shard_user || ep.base != h->win_base || ep.span != h->win_span)
+        FAIL(h, ESP_ERR_STATE, "esp_append_elements_again: the buffer must be empty (flush first) and the key window the planned call's");
+    (void)hipSetDevice(h->device);
+    espelem::Args a;
+    memset(&a, 0, sizeof a);
+    a.nloc = ep.nloc;
+    a.W = ep.W;
+    a.ncells = ep.ncells;
+    a.nitems = ep.ncells * ep.nloc;
+    a.elmat = d_elmat;
+    a.diag = d_diag;
+    a.lim = std::min(h->m, h->n);
+    a.L = h->L;
+    a.vrb = ep.vrb;
+    a.kind = kind;
+    a.negate = (op == ESP_OP_SUB && kind != ESP_SET) ? 1 : 0;
+    a.cellrec = (char *)ep.cellrec.p;
+    a.sorted_keys = (const u64 *)ep.sorted.p;
+    a.rem_bits = ep.rem_real;
+    a.base = h->win_base;
+    const i64 E = a.nitems * a.W;
+    CK(reserve_append(h, E));
+    a.keys_out = (u64 *)h->keys.p;
+    a.vals_out = (double *)h->vals.p;
+    CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(ep.S + 1)));
+    {
+        Span sp(h, ESP_ST_APPEND);
+        if (d_diag) {
+            const dim3 grid(grid_for(ep.ncells, espelem::THREADS)), block(espelem::THREADS);
+            if (ep.nloc == 3)
+                hipLaunchKernelGGL(espelem::elem_refresh_diag_k<3>, grid, block, 0, h->stream, d_diag, ep.ncells, a.cellrec);
+            else
+                hipLaunchKernelGGL(espelem::elem_refresh_diag_k<4>, grid, block, 0, h->stream, d_diag, ep.ncells, a.cellrec);
+        }
+        if (ep.k32)
+            launch_expand<true>(a, h->stream);
+        else
+            launch_expand<false>(a, h->stream);
+        sp.add(2);
+    }
+    HIPCK(h, hipMemcpyAsync(h->seg[1].p, ep.segtab.p, sizeof(i64) * (size_t)(ep.S + 1), hipMemcpyDeviceToDevice, h->stream));
+    HIPCK(h, hipGetLastError());
+    h->rawplan.valid = false;  // (seg[1] is rewritten)
+    esp_handle::PrePart &pp = h->pre;
+    pp.K = ep.K;
+    pp.pb = ep.K - ep.rem_real;
+    pp.maxlen = ep.maxlen;
+    pp.key_bytes = ep.k32 ? 4 : 8;
+    pp.kind = kind;
+    pp.E = E;
+    pp.tail = 0;
+    pp.base = h->win_base;
+    pp.span = h->win_span;
+    pp.Ee = plan_entries(E, ep.K, h->win_span);
+    pp.mw_P = 0, pp.mw_me = 0, pp.mw_shift = 0, pp.mw_nb = 0, pp.mw_eps = 0;
+    pp.own32 = false;
+    note_kind(h, kind, E);
+    h->count += E;
+    pending_changed(h);
+    h->pre.valid = true;
+    return ESP_OK;
+}
 
 extern "C" int32_t esp_append_elements(esp_handle *h, int32_t nloc, int64_t ncells, const int64_t *d_cellnodes, const double *d_elmat,
                                        const double *d_diag, int32_t kind, int32_t op) {
@@ -305,6 +415,33 @@ extern "C" int32_t esp_append_elements_host(esp_handle *h, int32_t nloc, int64_t
         rc = esp_append_elements(h, nloc, ncells, (const i64 *)dn.p, (const double *)de.p, diag ? (const double *)dd.p : nullptr, kind, op);
     (void)hipStreamSynchronize(h->stream);  // (the kernels have read the temporaries)
     release(dn);
+    release(de);
+    release(dd);
+    return rc;
+}
+
+// host arrays: uploaded as they are, then the device form
+extern "C" int32_t esp_append_elements_again_host(esp_handle *h, const double *elmat, const double *diag, int32_t kind, int32_t op) {
+    if (!h || !elmat) return ESP_ERR_INVALID;
+    const esp_handle::ElemPlan &ep = h->elemplan;
+    if (!ep.valid) FAIL(h, ESP_ERR_STATE, "esp_append_elements_again: the handle keeps no plan (esp_elements_keep_plan, then esp_append_elements on an empty buffer)");
+    (void)hipSetDevice(h->device);
+    DevBuf de, dd;
+    const size_t bn = sizeof(double) * (size_t)ep.ncells * (size_t)ep.nloc, be = bn * (size_t)ep.nloc;
+    int32_t rc = ensure(h, de, be);
+    if (rc == ESP_OK && diag) rc = ensure(h, dd, bn);
+    if (rc == ESP_OK) {
+        Span sp(h, ESP_ST_COPY);
+        hipError_t e = hipMemcpyAsync(de.p, elmat, be, hipMemcpyHostToDevice, h->stream);
+        if (e == hipSuccess && diag) e = hipMemcpyAsync(dd.p, diag, bn, hipMemcpyHostToDevice, h->stream);
+        sp.add(diag ? 2 : 1);
+        if (e != hipSuccess) {
+            h->err = std::string("esp_append_elements_again_host: ") + hipGetErrorString(e);
+            rc = ESP_ERR_HIP;
+        }
+    }
+    if (rc == ESP_OK) rc = esp_append_elements_again(h, (const double *)de.p, diag ? (const double *)dd.p : nullptr, kind, op);
+    (void)hipStreamSynchronize(h->stream);  // (the kernels have read the temporaries)
     release(de);
     release(dd);
     return rc;

@@ -128,6 +128,20 @@ static __global__ __launch_bounds__(THREADS) void elem_cells_k(Args a) {
     }
 }
 
+// the diag values of every cell record again (esp_append_elements_again: the connectivity is the same, the element data new)
+template <int NLOC>
+static __global__ __launch_bounds__(THREADS) void elem_refresh_diag_k(const double *__restrict__ diag, i64 ncells, char *__restrict__ cellrec) {
+    typedef double dbl2 __attribute__((ext_vector_type(2)));
+    const i64 c = (i64)blockIdx.x * THREADS + threadIdx.x;
+    if (c >= ncells) return;
+    double dg[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int k = 0; k < NLOC; k++) dg[k] = diag[c * NLOC + k];
+    char *cr = cellrec + c * 64;
+    *reinterpret_cast<dbl2 *>(cr + 16) = dbl2{dg[0], dg[1]};
+    *reinterpret_cast<dbl2 *>(cr + 32) = dbl2{dg[2], dg[3]};
+}
+
 // K32: 4-byte keys (the bits below the segment prefix; every entry has the batch's kind), else packed keys.
 // NLOC > 0: the nodes per cell as a compile-time constant (3, 4), rows and the diagonal term from the cell record
 // (elem_cells_k), the column of the element matrix from the caller's array; 0: any 1 .. MAX_NLOC, everything from the

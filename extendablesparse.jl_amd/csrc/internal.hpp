@@ -107,6 +107,17 @@ struct esp_handle {
         u64 base = 0, span = 0;
         double Ee = 0.0;
     } rawplan;
+    // esp_elements_keep_plan: the item order, the cell records and the segment table of the last esp_append_elements on an
+    // empty buffer (cells of 3 / 4 nodes) are kept in buffers of their own, so that esp_append_elements_again -- the same
+    // connectivity, new element matrices: a time step of an instationary / nonlinear code -- goes straight to the expansion
+    struct ElemPlan {
+        bool keep = false, valid = false;
+        int nloc = 0, W = 0, vrb = 0, rem_real = 0, K = 0, kind = 0;
+        bool k32 = false, has_diag = false;
+        i64 ncells = 0, S = 0, maxlen = 0;
+        u64 base = 0, span = 0;
+        DevBuf sorted, cellrec, segtab;
+    } elemplan;
     // sort_msd over ITEM records (femitems.hpp): a segment may hold plan_cap records (the bucket kernel's capacity in
     // updates / updates per item), and a shuffled stream need not be tried as a pre-sorted one
     i64 plan_cap = 0;

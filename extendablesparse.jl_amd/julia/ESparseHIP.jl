@@ -122,6 +122,18 @@ function assemble_elements!(x::SparseMatrixHIPCOO{Float64, Int64}, cellnodes::Ma
     x
 end
 
+# A time step of the same mesh (new element matrices over the connectivity of the last assemble_elements!): keep_plan!(x)
+# once, then assemble_elements_again!(x, elmat, diag) per step -- no pass over the connectivity, no item partition
+keep_plan!(x::SparseMatrixHIPCOO, on = true) =
+    (esp_check(x.handle, ccall((:esp_elements_keep_plan, libesparse), Int32, (Ptr{Cvoid}, Int32), x.handle, on ? 1 : 0)); x)
+function assemble_elements_again!(x::SparseMatrixHIPCOO{Float64, Int64}, elmat::Array{Float64, 3}, diag::Union{Matrix{Float64}, Nothing} = nothing;
+                                  kind = ESP_RAWUPDATE)
+    commit!(x)
+    esp_check(x.handle, ccall((:esp_append_elements_again_host, libesparse), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Int32, Int32),
+                              x.handle, elmat, diag === nothing ? C_NULL : diag, kind, 0))
+    x
+end
+
 # getindex(buffer,i,j) (sparsematrixlnk.jl:151-171; reached from genericextendablesparsematrixcsc.jl:57-66 for
 # positions not yet in the CSC): the ordered fold of the pending calls at (i,j), on the device.  Slow path by design.
 function Base.getindex(x::SparseMatrixHIPCOO, i::Integer, j::Integer)
@@ -277,6 +289,9 @@ touch!(A::HIPResidentSparseMatrixCSC) = (A.cscmatrix = nothing; A)
 Base.setindex!(A::HIPResidentSparseMatrixCSC, v, i::Integer, j::Integer) = (setindex!(A.buf, v, i, j); touch!(A))
 assemble_elements!(A::HIPResidentSparseMatrixCSC, cellnodes, elmat, diag = nothing; kwargs...) =
     (assemble_elements!(A.buf, cellnodes, elmat, diag; kwargs...); touch!(A))
+keep_plan!(A::HIPResidentSparseMatrixCSC, on = true) = (keep_plan!(A.buf, on); A)
+assemble_elements_again!(A::HIPResidentSparseMatrixCSC, elmat, diag = nothing; kwargs...) =
+    (assemble_elements_again!(A.buf, elmat, diag; kwargs...); touch!(A))
 updateindex!(A::HIPResidentSparseMatrixCSC, op, v, i, j) = (updateindex!(A.buf, op, v, i, j); touch!(A))
 rawupdateindex!(A::HIPResidentSparseMatrixCSC, op, v, i, j, part = 1) = (rawupdateindex!(A.buf, op, v, i, j); touch!(A))
 

@@ -454,6 +454,24 @@ class ExtendableSparseMatrix:
         self._touch()
         self._d.append_elements(kind, cellnodes, elmat, diag, _op(op))
 
+    def elements_keep_plan(self, on=True):
+        """esp_elements_keep_plan: the next append_elements on the empty buffer keeps its plan (item order, cell records) for
+        append_elements_again -- the same mesh, new element matrices."""
+        self._d.ck(self._d.lib.esp_elements_keep_plan(self._d.h, 1 if on else 0))
+
+    def append_elements_again(self, elmat, diag=None, kind=ESP_RAWUPDATE, op="+"):
+        """esp_append_elements_again[_host]: the element loop over the connectivity of the last planned append_elements; device
+        arrays (anything with .data_ptr()) or NumPy arrays, in append_elements' layouts."""
+        self._touch()
+        self._d.commit()
+        if not hasattr(elmat, "data_ptr"):      # host arrays (Fortran order, like append_elements)
+            em = np.asfortranarray(elmat, np.float64)
+            dg = None if diag is None else np.asfortranarray(diag, np.float64)
+            self._d.ck(self._d.lib.esp_append_elements_again_host(self._d.h, _vp(em), _vp(dg) if dg is not None else None, kind, _op(op)))
+            return
+        dp = C.c_void_p(diag.data_ptr()) if diag is not None else None
+        self._d.ck(self._d.lib.esp_append_elements_again(self._d.h, C.c_void_p(elmat.data_ptr()), dp, kind, _op(op)))
+
     def generate_fem_mesh(self, dim, npd, cellnodes, elmat, diag=None, seed=0x5EED0004, order_mode=1, node_mode=0,
                           node_seed=0x5EED0014, cell_begin=0, cell_end=None):
         """esp_generate_fem_mesh: fills DEVICE arrays (anything with .data_ptr()) with the element data of generate_fem's

@@ -169,6 +169,17 @@ int32_t esp_append_elements(esp_handle *h, int32_t nloc, int64_t ncells, const i
                             const double *d_elmat, const double *d_diag, int32_t kind, int32_t op);
 int32_t esp_append_elements_host(esp_handle *h, int32_t nloc, int64_t ncells, const int64_t *cellnodes,
                                  const double *elmat, const double *diag, int32_t kind, int32_t op);
+/* A time step of an instationary / nonlinear code assembles the SAME mesh again with new element matrices.
+ * esp_elements_keep_plan(h, 1): from now on an esp_append_elements call on an empty buffer (cells of 3 or 4 nodes, the item
+ * partition taken) keeps its plan -- the item order, the cell records, the segment table: 8 B per (cell, local column) + 64 B
+ * per cell of device memory; on = 0 releases it.  esp_append_elements_again(h, d_elmat, d_diag, kind, op): the element loop
+ * over the connectivity of that planned call (diag NULL iff it was then), on an empty buffer: no pass over the connectivity, no
+ * item partition; the entries are bit for bit what esp_append_elements with the same cellnodes would append.  Without a plan:
+ * ESP_ERR_STATE.  Together with the flush over the stored pattern (every update hits) a time step costs less than the
+ * first assembly. */
+int32_t esp_elements_keep_plan(esp_handle *h, int32_t on);
+int32_t esp_append_elements_again(esp_handle *h, const double *d_elmat, const double *d_diag, int32_t kind, int32_t op);
+int32_t esp_append_elements_again_host(esp_handle *h, const double *elmat, const double *diag, int32_t kind, int32_t op);
 /* The element data of esp_generate_fem's grid as DEVICE arrays, for the cells at stream positions [cell_begin, cell_end):
  * what a caller of testassemble! holds (cellnodes) and computes per cell (elmat = vol * S, diag = 0.1 * vol / (dim+1);
  * femtools.jl:58-67) -- the producer of esp_append_elements' input in tests and bench.  node_mode 1: the nodes carry a

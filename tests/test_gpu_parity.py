@@ -1101,6 +1101,38 @@ def test_append_elements(esp, orc, monkeypatch):
             B.flush()
             assert B.debug_last_partition() == 4
             assert_csc_equal(hip_arrays(B), want, "elements device")
+            # the kept plan (esp_elements_keep_plan / esp_append_elements_again): the same connectivity with new element data
+            # -- a time step -- over the stored pattern, then on the matrix after reset!
+            P = esp.ExtendableSparseMatrix(nn, nn)
+            with pytest.raises(esp.EspError):
+                P.append_elements_again(dem, ddg)                 # (no plan yet)
+            P.elements_keep_plan()
+            P.append_elements(dcn, dem, ddg)
+            P.flush()
+            assert_csc_equal(hip_arrays(P), want, "planned first assembly")
+            OP = orc.ExtendableSparseMatrix(nn, nn)
+            OP.apply(np.full(len(I), RAW, np.uint8), I, J, V)
+            for step, (fe, fd) in enumerate(((1.7, 0.3), (-0.25, 2.0))):
+                dem2, ddg2 = (dem * fe).contiguous(), (ddg * fd).contiguous()
+                Is, Js, Vs = orc.elements_stream(cn, np.asfortranarray(em * fe), np.asfortranarray(dg * fd))
+                if step == 1:
+                    P.reset()
+                    OP.reset()
+                if step == 0:
+                    P.append_elements_again(dem2, ddg2)
+                else:                                             # (host arrays)
+                    P.append_elements_again(np.asfortranarray(em * fe), np.asfortranarray(dg * fd))
+                assert P.nnznew() == len(I)
+                P.flush()
+                assert P.debug_last_partition() == 4
+                OP.apply(np.full(len(Is), RAW, np.uint8), Is, Js, Vs)
+                OP.flush()
+                assert_csc_equal(hip_arrays(P), OP.arrays(), "planned step %d" % step)
+            with pytest.raises(esp.EspError):
+                P.append_elements_again(dem, None)                # (the planned call had a diagonal term)
+            P.elements_keep_plan(False)
+            with pytest.raises(esp.EspError):
+                P.append_elements_again(dem, ddg)
             # packed keys, the item partition off (stream order through the flush's own passes), and without the cell
             # records (the expansion gathers from the caller's arrays, as it does for other cell sizes)
             for force, parts in ((14, (4,)), (25, (1, 2)), (-1, (4,)), (32, (4,))):   # (32: the expansion resolves the last bits)
