@@ -137,7 +137,7 @@ static __global__ __launch_bounds__(THREADS) void elem_refresh_diag_k(const doub
     double dg[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int k = 0; k < NLOC; k++) dg[k] = diag[c * NLOC + k];
-    // (the whole 64-byte record goes out again, rows included: full lines instead of half-written ones -- 1.8 -> 1.3 ms at 3-D)
+    // (the whole 64-byte record goes out again, rows included: full lines instead of half-written ones)
     typedef u32 u32x4 __attribute__((ext_vector_type(4)));
     char *cr = cellrec + c * 64;
     const u32x4 rows = *reinterpret_cast<const u32x4 *>(cr);
