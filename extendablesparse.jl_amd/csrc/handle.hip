@@ -48,6 +48,13 @@ void release_all(esp_handle *h) {
         sa->kinds = nullptr;
         sa->cap = 0;
     }
+    for (int i = 0; i < 2; i++) {
+        if (h->cpack.keys[i]) (void)hipHostFree(h->cpack.keys[i]);
+        if (h->cpack.vals[i]) (void)hipHostFree(h->cpack.vals[i]);
+        if (h->cpack.done[i]) (void)hipEventDestroy(h->cpack.done[i]);
+        h->cpack.keys[i] = nullptr, h->cpack.vals[i] = nullptr, h->cpack.done[i] = nullptr, h->cpack.busy[i] = false;
+    }
+    h->cpack.cap = 0;
 }
 
 // ------------------------------------------------------------------------ timing
@@ -416,11 +423,8 @@ extern "C" int32_t esp_stage_begin(esp_handle *h, int64_t want, int64_t **rows, 
     return ESP_OK;
 }
 
-extern "C" int32_t esp_commit(esp_handle *h, int64_t count, int32_t kind_all, int32_t op) {
-    if (!h) return ESP_ERR_INVALID;
-    if (count < 0 || count > h->stage.cap) FAIL(h, ESP_ERR_INVALID, "esp_commit: count %lld exceeds the staged chunk", (long long)count);
-    if (count == 0) return ESP_OK;
-    (void)hipSetDevice(h->device);
+// the staged chunk as device triplets (large chunks of one kind: the append may be the partition, pack_device)
+static int32_t commit_as_triplets(esp_handle *h, int64_t count, int32_t kind_all, int32_t op) {
     {
         Span sp(h, ESP_ST_COPY);
         HIPCK(h, hipMemcpyAsync(h->stage.d_rows.p, h->stage.rows, sizeof(i64) * (size_t)count, hipMemcpyHostToDevice, h->stream));
@@ -734,6 +738,58 @@ extern "C" int32_t esp_append_host(esp_handle *h, const int64_t *rows, const int
 extern "C" int32_t esp_append_host_i32(esp_handle *h, const int32_t *rows, const int32_t *cols, const double *vals, const uint8_t *kinds,
                                        int32_t kind_all, int32_t op, int64_t count) {
     return append_host_t<int32_t>(h, rows, cols, vals, kinds, kind_all, op, count);
+}
+
+// esp_commit: the staged chunk is packed on the host (keys + values, bounds checked there: the answer is immediate) into one
+// of two pinned halves, which leaves for the append buffer ASYNCHRONOUSLY -- the call returns as soon as the chunk may be
+// refilled, i.e. after the packing; the transfer of chunk i overlaps the loop that fills chunk i+1, and no kernel and no
+// stream synchronisation stands between two chunks (round 3: three or four copies, a pack kernel and a round trip for the
+// bounds flag per chunk).  Chunks of more than 2^20 entries of one kind go as device triplets instead (commit_as_triplets:
+// such an append on an empty buffer may be the partition).
+extern "C" int32_t esp_commit(esp_handle *h, int64_t count, int32_t kind_all, int32_t op) {
+    if (!h) return ESP_ERR_INVALID;
+    if (count < 0 || count > h->stage.cap) FAIL(h, ESP_ERR_INVALID, "esp_commit: count %lld exceeds the staged chunk", (long long)count);
+    if (count == 0) return ESP_OK;
+    (void)hipSetDevice(h->device);
+    if (kind_all > 3) FAIL(h, ESP_ERR_INVALID, "append: kind %d invalid", kind_all);
+    if (op != ESP_OP_ADD && op != ESP_OP_SUB) FAIL(h, ESP_ERR_UNSUPPORTED, "append: op %d not supported on the device path", op);
+    if (kind_all >= 0 && count > ((i64)1 << 20)) return commit_as_triplets(h, count, kind_all, op);
+    esp_handle::CommitPack &cp = h->cpack;
+    if (cp.cap < h->stage.cap) {  // (the chunk grew: new halves; transfers out of the old ones have to finish first)
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        for (int i = 0; i < 2; i++) {
+            if (cp.keys[i]) (void)hipHostFree(cp.keys[i]);
+            if (cp.vals[i]) (void)hipHostFree(cp.vals[i]);
+            cp.keys[i] = nullptr, cp.vals[i] = nullptr, cp.busy[i] = false;
+            HIPCK(h, hipHostMalloc((void **)&cp.keys[i], sizeof(u64) * (size_t)h->stage.cap, hipHostMallocDefault));
+            HIPCK(h, hipHostMalloc((void **)&cp.vals[i], sizeof(double) * (size_t)h->stage.cap, hipHostMallocDefault));
+            if (!cp.done[i]) HIPCK(h, hipEventCreateWithFlags(&cp.done[i], hipEventDisableTiming));
+        }
+        cp.cap = h->stage.cap;
+    }
+    const int half = cp.next;
+    if (cp.busy[half]) HIPCK(h, hipEventSynchronize(cp.done[half]));  // (the transfer of two chunks ago)
+    cp.busy[half] = false;
+    std::atomic<i64> bad(-1);
+    host_pack<int64_t>(h->stage.rows, h->stage.cols, h->stage.vals, kind_all < 0 ? h->stage.kinds : nullptr, kind_all, op == ESP_OP_SUB, count, h->m, h->n,
+                       h->L, cp.keys[half], cp.vals[half], 0, &bad);
+    if (bad.load() >= 0)
+        FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %lld of the batch has an index outside %lld x %lld (or a bad kind)", (long long)(bad.load() + 1),
+             (long long)h->m, (long long)h->n);
+    CK(reserve_append(h, count));
+    {
+        Span sp(h, ESP_ST_COPY);
+        HIPCK(h, hipMemcpyAsync((u64 *)h->keys.p + h->count, cp.keys[half], sizeof(u64) * (size_t)count, hipMemcpyHostToDevice, h->stream));
+        HIPCK(h, hipMemcpyAsync((double *)h->vals.p + h->count, cp.vals[half], sizeof(double) * (size_t)count, hipMemcpyHostToDevice, h->stream));
+        sp.add(2);
+    }
+    HIPCK(h, hipEventRecord(cp.done[half], h->stream));
+    cp.busy[half] = true;
+    cp.next = 1 - half;
+    if (kind_all >= 0) note_kind(h, kind_all, count);
+    h->count += count;
+    pending_changed(h);
+    return ESP_OK;
 }
 
 extern "C" int32_t esp_append_device(esp_handle *h, const int64_t *d_rows, const int64_t *d_cols, const double *d_vals,

@@ -162,6 +162,16 @@ struct esp_handle {
         uint8_t *kinds = nullptr;
         DevBuf d_rows, d_cols, d_vals, d_kinds;
     } stage, bulk;
+    // esp_commit of a staged chunk: the chunk is packed on the host (keys + values) into one of two pinned halves and leaves
+    // for the append buffer asynchronously -- the caller refills its chunk while the transfer runs
+    struct CommitPack {
+        i64 cap = 0;  // entries per half
+        u64 *keys[2] = {nullptr, nullptr};
+        double *vals[2] = {nullptr, nullptr};
+        hipEvent_t done[2] = {nullptr, nullptr};
+        bool busy[2] = {false, false};
+        int next = 0;
+    } cpack;
     unsigned long long *pin_scalar = nullptr;  // pinned, 8 slots
     u64 *pin_mw = nullptr;  // pinned source of prepart_begin's asynchronous upload of the window bases (<= MW_MAX)
     hipEvent_t pin_mw_done = nullptr;

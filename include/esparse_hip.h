@@ -114,7 +114,9 @@ int32_t esp_key_layout(const esp_handle *h, int32_t *row_bits, int32_t *col_bits
  * one ccall per chunk, not per entry.  kinds may be left untouched when kind_all>=0.
  * The chunk pointers stay valid until esp_stage_begin is called with a larger `want` (or esp_destroy);
  * no other call moves them (esp_append_host stages through an area of its own).  esp_commit returns
- * when the chunk may be refilled. */
+ * when the chunk may be refilled -- after it has been packed on the host (bounds are checked there: ESP_ERR_BOUNDS is
+ * immediate and nothing of the chunk is appended) into one of two pinned halves; the transfer to the device runs while the
+ * caller fills the chunk again. */
 int32_t esp_stage_begin(esp_handle *h, int64_t want, int64_t **rows, int64_t **cols,
                         double **vals, uint8_t **kinds, int64_t *got);
 int32_t esp_commit(esp_handle *h, int64_t count, int32_t kind_all, int32_t op);
