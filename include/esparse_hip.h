@@ -130,7 +130,9 @@ int32_t esp_append_host(esp_handle *h, const int64_t *rows, const int64_t *cols,
 int32_t esp_append_host_i32(esp_handle *h, const int32_t *rows, const int32_t *cols,
                             const double *vals, const uint8_t *kinds, int32_t kind_all, int32_t op,
                             int64_t count);
-/* device-side producers: arrays already in HBM on this handle's device */
+/* device-side producers: arrays already in HBM on this handle's device.  An index outside the matrix: ESP_ERR_BOUNDS, nothing is
+ * appended; the message names AN offending entry -- the first of the batch when the batch was packed in stream order, the
+ * smallest position among the tiles examined before the kernels gave up when the append was the partition */
 int32_t esp_append_device(esp_handle *h, const int64_t *d_rows, const int64_t *d_cols,
                           const double *d_vals, const uint8_t *d_kinds, int32_t kind_all,
                           int32_t op, int64_t count);
