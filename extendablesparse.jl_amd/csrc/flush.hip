@@ -321,6 +321,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         bool try_hits = Z0 > 0 && mode == ESP_FLUSH_ROUTED && st.npieces == 0 && (keys == 1 || keys == 2) && (st.kind == ESP_UPDATE || st.kind == ESP_RAWUPDATE) &&
                         a.kind_all == st.kind && a.cl_bits >= 0 && a.cl_bits <= esplocal::G3_CL_BITS && a.cl_bits + a.rb <= 32 && a.rb <= 30 &&
                         longest > 16.0 && longest <= 128.0 && hits_expected && !h->hits_off && !a.no_group && !a.stop_after && !small_variant &&
+                        h->wc0 == 0 && h->wc1 == h->n &&  // (the segments cover every column: what they do not write into the second array would be lost)
                         h->force_path != ESP_PATH_NO_GROUP_TIER && h->force_path != ESP_PATH_RADIX_TAIL_ONLY && h->force_path != ESP_PATH_NO_GROUP3 &&
                         h->force_path != ESP_PATH_NO_HITS_KERNEL && h->force_path != ESP_PATH_MANY_LAUNCHES && (i64)S <= esplocal::MAX_GRID;
         for (int attempt = 0; attempt < 2 && try_hits; attempt++) {
