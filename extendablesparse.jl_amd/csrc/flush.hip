@@ -2,6 +2,7 @@
 #include "internal.hpp"
 
 bool esplocal::launch(const Variant &v, unsigned grid, hipStream_t stream, const Args &a) {
+    if (v.wave) return launch_wave(v, grid, stream, a);
     if (v.g3) return launch_group3(v, grid, stream, a);
     if (v.grp) return v.shortg ? launch_group_short(v, grid, stream, a) : launch_group(v, grid, stream, a);
     if (v.pieces) return v.small_variant ? launch_pieces_small(v, grid, stream, a) : v.fresh ? launch_pieces_fresh(v, grid, stream, a) : launch_pieces_stored(v, grid, stream, a);
@@ -147,12 +148,17 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
     // esp_flush normalised the buffers: data in keys/vals, scratch pair = keys2/vals2
     u64 *tk = (u64 *)h->keys2.p;
     double *tv = (double *)h->vals2.p;
-    // look-back granules: one per segment | ticket, error flag | longest run | one per group of 64 segments
-    // (cleared as a multiple of 256 bytes: the runtime splits an odd-sized memset into two launches)
-    const i64 G = ((((i64)S + 63) / 64 + 1 + S + 2 + 31) & ~(i64)31) - (S + 2);
-    CK(ensure(h, h->segout, sizeof(u64) * (size_t)(S + 4 + G)));
+    // look-back granules: one per segment | error flag | longest run | one per group of 256 segments, rounded up to a 4 KiB
+    // page; behind them a page of its own for the ticket counter (every workgroup draws from it while others poll the
+    // granules: on one line with them the draws cost the headline's bucket kernel 0.18 of 1.55 ms) -- one memset clears
+    // everything
+    const i64 n_gs = ((i64)S >> 8) + 2;  // (local.hpp: LB_SHIFT = 8)
+    const i64 G = (((i64)S + 2 + n_gs + 511) & ~(i64)511) - (S + 2);  // (granules behind status[S + 1])
+    const i64 tick_at = S + 2 + G + 256;
+    CK(ensure(h, h->segout, sizeof(u64) * (size_t)(S + 2 + G + 512)));
     u64 *status = (u64 *)h->segout.p;
-    HIPCK(h, hipMemsetAsync(status, 0, sizeof(u64) * (size_t)(S + 2 + G), h->stream));
+    const size_t status_bytes = sizeof(u64) * (size_t)(S + 2 + G + 512);
+    HIPCK(h, hipMemsetAsync(status, 0, status_bytes, h->stream));
     CK(ensure(h, h->colend, sizeof(u64) * (size_t)(N1 + espscan::workspace_elems(N1))));
     esplocal::Args a;
     const char *stop_env = getenv("ESP_LOCAL_STOP");
@@ -200,6 +206,23 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
                         h->force_path != ESP_PATH_NO_SMALL_VARIANT && !stop_env;
     }
     h->last_local_small = small_variant ? 1 : 0;
+    // The wave-per-segment kernel (wavecols.hpp): a fresh matrix, 4-byte keys of one adding kind, segments of at most 64 whole
+    // columns and 1024 entries (the producers' plans cut them so: wave_wanted / plan_wave_bits) that write colptr themselves,
+    // column runs of at most 16 entries.  A segment it refuses makes the flush run again with the kernels below.
+    // Any forced path, ESP_NO_WAVE: never.
+    bool use_wave = false;
+    int wave_ni = 16;
+    {
+        const int clb = st.rem_bits - h->L.rb;
+        const double per_col = (double)h->count / (double)std::max<i64>(col_end - col_begin, 1);
+        const bool runs_fit = h->seen_maxrun > 0 ? h->seen_maxrun <= 16 : per_col <= 16.0;
+        use_wave = direct && Z0 == 0 && st.npieces == 0 && st.seg_start && st.key_bytes == 4 && (st.kind == ESP_UPDATE || st.kind == ESP_RAWUPDATE) &&
+                   clb >= 0 && clb <= esplocal::WAVE_CL_BITS && st.rem_bits <= 32 && st.maxlen <= (i64)esplocal::WAVE_CAP && runs_fit && !h->wave_off &&
+                   h->force_path == ESP_PATH_AUTO && !stop_env && !getenv("ESP_LOCAL_STAMPS") && getenv("ESP_WAVE") && !getenv("ESP_NO_WAVE") &&
+                   ceil_div<i64>(S, esplocal::WAVE_SEGS) <= esplocal::MAX_GRID;
+        wave_ni = st.maxlen <= 768 ? 12 : 16;
+    }
+    h->last_wave = 0;
     std::function<int32_t(bool)> launch_all;
     bool used_g3 = false;
     bool want_wide = h->g3_wide && h->force_path != ESP_PATH_NO_WIDE_GROUP3;
@@ -241,7 +264,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         a.total = total_check;
         a.pstart = st.pstart;
         a.ptab = st.ptab;
-        a.ticket = (u32 *)(status + S);
+        a.ticket = (u32 *)(status + tick_at);
         a.err = (u32 *)(status + S) + 1;
         a.maxrun_seen = (u32 *)(status + S) + 2;  // (zeroed with the granules)
         {
@@ -257,6 +280,15 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         const i64 max_grid = h->force_path == ESP_PATH_MANY_LAUNCHES ? 64 : esplocal::MAX_GRID;  // 4: test hook, many launches
         launch_all = [&, max_grid](bool allow_g3) -> int32_t {
         used_g3 = false;
+        if (use_wave) {  // (one launch: a workgroup per four segments)
+            a.first = 0;
+            esplocal::Variant var{true, false, false, false, st.kind == ESP_UPDATE ? 2 : 1};
+            var.wave = true;
+            var.wave_ni = wave_ni;
+            h->last_fold_update = 1;
+            if (!esplocal::launch(var, (unsigned)ceil_div<i64>(S, esplocal::WAVE_SEGS), h->stream, a)) FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (no wave kernel for this flush)");
+            return ESP_OK;
+        }
         for (i64 first = 0; first < S; first += max_grid) {
             const unsigned grid = (unsigned)std::min<i64>(max_grid, S - first);
             a.first = first;
@@ -295,13 +327,17 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         };
     }
     auto read_back = [&]() -> int32_t {
+        if (use_wave) {  // (its granules are per workgroup: the last one holds the total)
+            HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (ceil_div<i64>(S, esplocal::WAVE_SEGS) - 1), 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCK(h, hipMemcpyAsync(h->pin_scalar + 1, status + S, 16, hipMemcpyDeviceToHost, h->stream));
+        } else
         HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (S - 1), 24, hipMemcpyDeviceToHost, h->stream));  // last granule | ticket, err | maxrun
         HIPCK(h, hipMemcpyAsync(h->pin_scalar + 3, (u32 *)h->misc.p + 60, 4, hipMemcpyDeviceToHost, h->stream));
         HIPCK(h, hipStreamSynchronize(h->stream));
         return ESP_OK;
     };
     auto reset_launch_state = [&]() -> int32_t {
-        HIPCK(h, hipMemsetAsync(status, 0, sizeof(u64) * (size_t)(S + 2 + G), h->stream));
+        HIPCK(h, hipMemsetAsync(status, 0, status_bytes, h->stream));
         if (!direct) {
             i64 c0, cnt;
             col_range(h, &c0, &cnt);
@@ -362,6 +398,24 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         sp.add(1);
     }
     CK(read_back());
+    if (use_wave) {
+        if ((u32)(h->pin_scalar[1] >> 32) & 8u) {
+            // a segment the wave kernel does not take (a column run above 16, rows further apart than 2^22): nothing of a
+            // fresh-matrix flush has taken effect -- once more with the kernels for whole workgroups, which take the finer
+            // segments as well; the handle's next batches are planned for them
+            h->wave_off = true;
+            use_wave = false;
+            CK(reset_launch_state());
+            {
+                Span sp(h, ESP_ST_LOCAL);
+                CK(launch_all(true));
+                sp.add(1);
+            }
+            CK(read_back());
+        } else {
+            h->last_wave = 1;
+        }
+    }
     if (used_g3 && !want_wide && h->force_path != ESP_PATH_NO_WIDE_GROUP3) {
         const u32 e = (u32)(h->pin_scalar[1] >> 32);
         if ((e & 8u) && (e & 16u) && !(e & 32u)) {
@@ -383,7 +437,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         // a segment the three-workgroup group kernel does not take (a longer run, rows too far apart): nothing of a
         // fresh-matrix flush has taken effect -- once more with the general kernels, and they serve this handle from now on
         h->g3_off = true;
-        HIPCK(h, hipMemsetAsync(status, 0, sizeof(u64) * (size_t)(S + 2 + G), h->stream));
+        HIPCK(h, hipMemsetAsync(status, 0, status_bytes, h->stream));
         if (!direct) {
             i64 c0, cnt;
             col_range(h, &c0, &cnt);

@@ -490,7 +490,13 @@ __device__ __forceinline__ void fold_run_lds(const Args &a, u64 *skey, double *s
 // decoupled look-back of round 1 walked back over every segment in flight (seven dependent polls).  Granules: 8 bytes
 // {flag, value}, relaxed agent-scope atomics on both sides (MI355X L2s are per XCD), spins bounded (a timeout surfaces
 // as ESP_ERR_HIP); a segment waits for lower tickets only, and tickets are drawn in start order: no deadlock.
+// The ticket counter lives on a page of its own behind the granules (flush_local): every workgroup draws from it while
+// others poll the granules, and on one line with them the draws cost the headline's bucket kernel 0.18 of 1.55 ms.
+// (Round 4 also tried groups of 64 with unchained group TOTALS under a chain over super-groups of 64 groups -- two 64-wide
+// loads per round, a lane asking only for what it has not seen: no faster for local_k, slower for the persistent wave_k;
+// a poll interval of 8 or 30 instead of 2 x 64 cycles, the group granules on lines of their own, four copies of each: nothing.)
 constexpr int LB_SHIFT = 8;
+
 constexpr int LB_GROUP = 1 << LB_SHIFT;
 struct LbState {
     u64 group_part;  // totals of the own group's segments in front of this one

@@ -853,11 +853,18 @@ __device__ __forceinline__ void copy_out_runs(const PartOut &p, const KT *lk, co
             p.vals_out[dst] = lv[q];
         };
         const int head = (int)(ro & 1);  // the run starts at an odd place: its first entry goes alone
-        if (t == 0 && head) store1(b, ro);
         const int npair = (len - head) >> 1;
+        // A run shorter than one round of the workgroup goes out through ONE wave (runs in turn: wave j mod NWAVES), so that the
+        // short runs of a finely cut tile (segments of 64 columns: a dozen runs of 64 .. 256 pairs) leave side by side instead
+        // of one after the other with three quarters of the threads idle.
+        static_assert((NWAVES & (NWAVES - 1)) == 0, "waves of a producer workgroup: a power of two");
+        const bool wide = npair >= NT;
+        if (!wide && (j & (NWAVES - 1)) != (t >> 6)) continue;
+        const int tq = wide ? t : (t & 63), tstep = wide ? NT : ESP_WAVE;
+        if (tq == 0 && head) store1(b, ro);
         // (4-byte keys of the own window: the pair's key store is 8-byte aligned when its index is even)
         const bool pair32 = run32 && (((ro + head - k4off) & 1) == 0);
-        for (int q = t; q < npair; q += NT) {
+        for (int q = tq; q < npair; q += tstep) {
             const int e = b + head + 2 * q;
             const i64 dst = ro + head + 2 * q;  // even
             if (run32) {
@@ -872,7 +879,7 @@ __device__ __forceinline__ void copy_out_runs(const PartOut &p, const KT *lk, co
             }
             *reinterpret_cast<f64x2 *>(p.vals_out + dst) = f64x2{lv[e], lv[e + 1]};
         }
-        if (t == NT - 1 && ((len - head) & 1)) store1(b + len - 1, ro + len - 1);
+        if (tq == tstep - 1 && ((len - head) & 1)) store1(b + len - 1, ro + len - 1);
     }
 }
 

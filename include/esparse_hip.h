@@ -427,6 +427,9 @@ typedef enum {
     ESP_PATH_NO_HITS_KERNEL = 34,    /* never group3_k's re-assembly form (additions over a stored pattern the same mesh built:
                                         every (col,row) of a column run is the stored entry of its rank, sums to a second value
                                         array, all-or-nothing); such flushes take local_k's group-tier kernels               */
+    ESP_PATH_NO_WAVE_KERNEL = 35,    /* never the bucket kernel with one wave per segment of at most 64 columns (wave_k: short columns on
+                                        a fresh matrix, 4-byte keys), nor the finer plans made for it (every other forced path implies
+                                        this one)                                                                            */
     ESP_PATH_NO_PLAN_REUSE = 31      /* esp_append_device / esp_commit of one kind on an empty buffer always count their columns
                                         (never the run lists of the previous, identical-looking batch)                      */
 } esp_debug_path;
@@ -453,7 +456,8 @@ int32_t esp_debug_last_fold_update(const esp_handle *h, int32_t *on);
  * never.  2 when it was the group tier's kernel with three workgroups per CU (group3_k: long column runs on a fresh matrix,
  * 4-byte keys; esp_debug_force_path(30): never); 3 when it was that kernel's WIDE form (rows of a segment spread over more than
  * 2^18 -- a mesh numbered without locality: every run sorted twice; esp_debug_force_path(33): never); 4 / 5 when it was that
- * kernel's re-assembly form over a stored pattern (plain / wide; esp_debug_force_path(34): never) */
+ * kernel's re-assembly form over a stored pattern (plain / wide; esp_debug_force_path(34): never); 6 when it was the
+ * wave-per-segment kernel (short columns on a fresh matrix, segments of at most 64 columns; esp_debug_force_path(35): never) */
 int32_t esp_debug_last_local_small(const esp_handle *h, int32_t *small);
 /* 1 when the last append-is-the-partition of caller-supplied triplets (esp_append_device / esp_commit of one kind on an
  * empty buffer) used the run lists of the previous assembly instead of counting its columns again: a batch of the same
