@@ -15,6 +15,19 @@
 // colptr themselves, column runs of at most 16 entries, rows of a segment within 2^22 of each other.  A segment outside that
 // reports bit 8 of Args::err (bit 16 beside it: for its rows) and emits nothing; the host then runs the flush again with
 // local_k (a fresh-matrix flush has changed nothing) and the handle remembers.
+//
+// MEASURED (MI355X, 256^3 stencil, same box as local_k's small variant at 1.37 ms; tools/r4_wave.sh, tools/xcc_probe.hip):
+//   one workgroup per ticket (no loop)                       1.41 ms   818 VALU per wave (768 entries) against 8 x 722 per 3072
+//   persistent, tickets and entries requested ahead          1.50 ms   (1.78 with the ticket counter beside the granules)
+//   ... tickets dealt round-robin, no atomic (-DESP_WAVE_STATIC: safe only while every workgroup is resident)   1.14 ms
+//   ... and no look-back polls (wrong results)               1.00 ms
+// i.e. the kernel is bound by what synchronises it, not by its instructions or bytes: a draw from ONE counter costs 12 ns
+// when the whole chip draws (83 M/s: the counter's line travels between the eight L2s; one counter per XCD: 1.9 ns), and draws
+// and polls delay each other.  A pool of tickets per XCD (blocks of 16 claimed from the counter, handed out through a word only
+// that XCD touches) was built and dropped: whoever refills a pool waits for a cross-XCD round trip while it HOLDS a ticket,
+// and every ticket above waits for it in its look-back -- 13 ms.  The finer cut costs the producer 0.17 ms (0.72 against
+// 0.55 ms: a dozen runs per tile instead of four), so the kernel has to reach 1.2 ms to draw level: it stays opt-in
+// (ESP_WAVE=1) as the vehicle for the next round's work on the synchronisation.
 #pragma once
 #include "local.hpp"
 
@@ -247,12 +260,7 @@ __global__ __launch_bounds__(WV_THREADS, NI <= 12 ? 4 : 3) void wave_k(Args a) {
             la.S = nwg;
             LbState lbs;
             lb_publish(la, lbs, wg, wg_total, lane);
-#ifdef ESP_WAVE_NOLB  // (experiment: only the last workgroup of a group resolves its chain; the others store at their INPUT offset -- wrong results)
-            u64 excl = (u64)beg;
-            if (lb_last_of_group(la, wg)) excl = lb_complete(la, lbs, wg, wg_total, lane);
-#else
             const u64 excl = lb_complete(la, lbs, wg, wg_total, lane);
-#endif
             if (lane == 0) s_dst = excl;
         }
         __syncthreads();
