@@ -651,6 +651,35 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
 
 
 # ---------------------------------------------------------------------------------------- one rank
+def bind_near_gpu(torch, local):
+    """Run this process on the CPUs of the NUMA node the GPU hangs off (what `numactl --cpunodebind` does for an HPC job): the
+    host arrays of the PCIe-inclusive lines (cfg2_host, cfg_mt_sum's plug-in form) are then first-touched beside the GPU's
+    root port -- on the two-socket hosts of this pool a process that lands on the other socket moves them at 60 % of the
+    rate.  Returns the node, or None (one node, no sysfs, ESP_BENCH_NO_BIND=1: nothing changed)."""
+    if os.environ.get("ESP_BENCH_NO_BIND"):
+        return None
+    try:
+        pr = torch.cuda.get_device_properties(local)
+        bdf = "%04x:%02x:%02x.0" % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        with open("/sys/bus/pci/devices/%s/numa_node" % bdf) as f:
+            node = int(f.read().strip())
+        if node < 0:
+            return None
+        with open("/sys/devices/system/node/node%d/cpulist" % node) as f:
+            txt = f.read().strip()
+        cpus = set()
+        for part in txt.split(","):
+            a, _, b = part.partition("-")
+            cpus.update(range(int(a), int(b or a) + 1))
+        cpus &= os.sched_getaffinity(0)
+        if len(cpus) < 2:
+            return None
+        os.sched_setaffinity(0, cpus)
+        return node
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -692,6 +721,7 @@ def main():
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local)
+    numa_node = bind_near_gpu(torch, local)
 
     from esparse_loader import load
     esp = load()
@@ -833,6 +863,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "host_numa_node": numa_node,   # the process runs on the CPUs of the GPU's NUMA node (bind_near_gpu); None: unchanged
             "digest_ok": digest_ok,   # sha256 of the device CSC == the CPU oracle's (tests/golden/digests_large.txt); None: no pin for this size
             "config": {"workload": "fdrand %d^3 Float64/Int64 fresh build: device COO append (the producer writes every "
                                    "update to its radix bucket) -> LDS bucket sort + ordered fold -> CSC "

@@ -211,16 +211,18 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
     // column runs of at most 16 entries.  A segment it refuses makes the flush run again with the kernels below.
     // Any forced path, ESP_NO_WAVE: never.
     bool use_wave = false;
-    int wave_ni = 16;
+    int wave_ni = 16, wave_segs = 16;
     {
         const int clb = st.rem_bits - h->L.rb;
         const double per_col = (double)h->count / (double)std::max<i64>(col_end - col_begin, 1);
-        const bool runs_fit = h->seen_maxrun > 0 ? h->seen_maxrun <= 16 : per_col <= 16.0;
+        const bool runs_fit = (getenv("ESP_WAVE") && atoi(getenv("ESP_WAVE")) >= 2) || (h->seen_maxrun > 0 ? h->seen_maxrun <= 16 : per_col <= 16.0);
         use_wave = direct && Z0 == 0 && st.npieces == 0 && st.seg_start && st.key_bytes == 4 && (st.kind == ESP_UPDATE || st.kind == ESP_RAWUPDATE) &&
                    clb >= 0 && clb <= esplocal::WAVE_CL_BITS && st.rem_bits <= 32 && st.maxlen <= (i64)esplocal::WAVE_CAP && runs_fit && !h->wave_off &&
                    h->force_path == ESP_PATH_AUTO && !stop_env && !getenv("ESP_LOCAL_STAMPS") && getenv("ESP_WAVE") && !getenv("ESP_NO_WAVE") &&
-                   ceil_div<i64>(S, esplocal::WAVE_SEGS) <= esplocal::MAX_GRID;
+                   ceil_div<i64>(S, wave_segs) <= esplocal::MAX_GRID;
         wave_ni = st.maxlen <= 768 ? 12 : 16;
+        wave_segs = wave_ni == 12 ? 16 : 12;  // (one workgroup per CU: 160 KiB of LDS at 9.4 / 12.4 KiB per wave)
+        if (const char *e = getenv("ESP_WAVE_SEGS")) wave_segs = atoi(e) == 8 ? 8 : atoi(e) == 4 ? 4 : wave_segs;  // (experiments)
     }
     h->last_wave = 0;
     std::function<int32_t(bool)> launch_all;
@@ -285,8 +287,9 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
             esplocal::Variant var{true, false, false, false, st.kind == ESP_UPDATE ? 2 : 1};
             var.wave = true;
             var.wave_ni = wave_ni;
+            var.wave_segs = wave_segs;
             h->last_fold_update = 1;
-            if (!esplocal::launch(var, (unsigned)ceil_div<i64>(S, esplocal::WAVE_SEGS), h->stream, a)) FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (no wave kernel for this flush)");
+            if (!esplocal::launch(var, (unsigned)ceil_div<i64>(S, wave_segs), h->stream, a)) FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (no wave kernel for this flush)");
             return ESP_OK;
         }
         for (i64 first = 0; first < S; first += max_grid) {
@@ -320,6 +323,12 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
                      a.cl_bits + a.rb <= 32 && a.rb <= 30 && longest <= 128.0 && !h->g3_off && !a.no_group && !a.stop_after &&
                      h->force_path != ESP_PATH_NO_GROUP3;
             var.g3wide = var.g3 && want_wide;
+            if (getenv("ESP_G3_SMALL") && allow_g3 && Z0 == 0 && keys == 2 && st.npieces == 0 && st.maxlen <= 6 * esplocal::THREADS && a.cl_bits >= 0 &&
+                a.cl_bits <= esplocal::G3_CL_BITS && a.cl_bits + a.rb <= 32 && !h->g3_off && !a.stop_after) {  // (experiment)
+                var.g3 = var.grp = var.g3small = true;
+                var.small_variant = false;
+                var.g3wide = false;
+            }
             used_g3 = used_g3 || var.g3;
             if (!esplocal::launch(var, grid, h->stream, a)) FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (no bucket kernel for this flush)");
         }
@@ -328,7 +337,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
     }
     auto read_back = [&]() -> int32_t {
         if (use_wave) {  // (its granules are per workgroup: the last one holds the total)
-            HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (ceil_div<i64>(S, esplocal::WAVE_SEGS) - 1), 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (ceil_div<i64>(S, wave_segs) - 1), 8, hipMemcpyDeviceToHost, h->stream));
             HIPCK(h, hipMemcpyAsync(h->pin_scalar + 1, status + S, 16, hipMemcpyDeviceToHost, h->stream));
         } else
         HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (S - 1), 24, hipMemcpyDeviceToHost, h->stream));  // last granule | ticket, err | maxrun

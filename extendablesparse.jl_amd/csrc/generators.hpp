@@ -267,7 +267,8 @@ static __global__ __launch_bounds__(THREADS) void fdrand_part_k(FdArgs a) {
     u32 slot[4];
     int total;
     // (leaves -- uniformly -- when a flag is set or 4-byte keys do not apply: the host issues the plain producer instead)
-    if (!esprun::tile_slots<4, THREADS / ESP_WAVE>(p, tl, it.dig, it.wt, slot, S, &total, OUT32)) return;
+    esprun::TileRegs tr;
+    if (!esprun::tile_slots<4, THREADS / ESP_WAVE>(p, tl, it.dig, it.wt, slot, S, &total, OUT32, &tr)) return;
     const int rb = a.L.rb;
     for (int lo = 0; lo < total; lo += FD_STAGE) {  // (one round, but for a boundary tile)
         if (lo > 0) __syncthreads();                // (the previous round's copy has read the staging area)
@@ -305,11 +306,11 @@ static __global__ __launch_bounds__(THREADS) void fdrand_part_k(FdArgs a) {
         if constexpr (S32 && !OUT32) {
             if (S.all_own) {  // (a shard's usual tile: the 4-byte-key copy loop of the unsharded producer)
                 esprun::copy_out_runs<KT, true, THREADS, THREADS / ESP_WAVE>(p, lk, lv, total, S, (u32)a.kind, lo, lo + FD_STAGE,
-                                                                           esprun::own_keys32(p.keys_out, S.own_lo));
+                                                                           esprun::own_keys32(p.keys_out, S.own_lo), &tr);
                 continue;
             }
         }
-        esprun::copy_out_runs<KT, OUT32, THREADS, THREADS / ESP_WAVE>(p, lk, lv, total, S, (u32)a.kind, lo, lo + FD_STAGE);
+        esprun::copy_out_runs<KT, OUT32, THREADS, THREADS / ESP_WAVE>(p, lk, lv, total, S, (u32)a.kind, lo, lo + FD_STAGE, nullptr, &tr);
     }
 }
 

@@ -11,26 +11,29 @@ namespace esplocal {
 bool launch_wave(const Variant &v, unsigned grid, hipStream_t stream, const Args &a) {
     if (!v.fresh || v.pieces || (v.keys != 1 && v.keys != 2)) return false;
     // persistent workgroups: as many as the chip holds at once (each draws tickets until none is left)
-    static int per_cu[2] = {0, 0}, ncu = 0;
+    static int ncu = 0;
     if (ncu == 0) {
         int dev = 0;
         hipDeviceProp_t pr;
         if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&pr, dev) != hipSuccess) return false;
-        int b12 = 0, b16 = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b12, wave_k<12>, WV_THREADS, 0) != hipSuccess) b12 = 1;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&b16, wave_k<16>, WV_THREADS, 0) != hipSuccess) b16 = 1;
-        per_cu[0] = b12 > 0 ? b12 : 1;
-        per_cu[1] = b16 > 0 ? b16 : 1;
         ncu = pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 1;
-        if (const char *e = getenv("ESP_WAVE_PER_CU")) per_cu[0] = per_cu[1] = std::max(1, atoi(e));  // (experiments)
-        if (getenv("ESP_WAVE_DEBUG")) fprintf(stderr, "wave_k: %d CUs, %d / %d workgroups per CU (12 / 16 entries per lane)\n", ncu, per_cu[0], per_cu[1]);
     }
     const bool n12 = v.wave_ni <= 12;
-    const unsigned g = (unsigned)std::min<long long>((long long)grid, (long long)ncu * per_cu[n12 ? 0 : 1]);
-    if (n12)
-        hipLaunchKernelGGL((wave_k<12>), dim3(g), dim3(WV_THREADS), 0, stream, a);
-    else
-        hipLaunchKernelGGL((wave_k<16>), dim3(g), dim3(WV_THREADS), 0, stream, a);
+    const int W = v.wave_segs;
+    // (workgroups per CU: 160 KiB of LDS, 9.4 / 12.4 KiB per wave)
+    const int per_cu = std::max(1, (n12 ? 16 : 12) / W);
+    const unsigned g = (unsigned)std::min<long long>((long long)grid, (long long)ncu * per_cu);
+#define ESP_WAVE_GO(NI, WW) hipLaunchKernelGGL((wave_k<NI, WW>), dim3(g), dim3(WW * ESP_WAVE), 0, stream, a)
+    if (W == 4) {
+        if (n12) ESP_WAVE_GO(12, 4); else ESP_WAVE_GO(16, 4);
+    } else if (W == 8) {
+        if (n12) ESP_WAVE_GO(12, 8); else ESP_WAVE_GO(16, 8);
+    } else if (W == 16) {
+        if (n12) ESP_WAVE_GO(12, 16); else ESP_WAVE_GO(16, 12);
+    } else {
+        return false;
+    }
+#undef ESP_WAVE_GO
     return true;
 }
 

@@ -167,6 +167,7 @@ bool wave_wanted(const esp_handle *h, int kind, i64 E) {
     if (h->force_path != ESP_PATH_AUTO || h->wave_off || h->nnz != 0 || windowed(h) || h->shard_user || h->item_mode) return false;
     if (kind != ESP_UPDATE && kind != ESP_RAWUPDATE) return false;
     if (!getenv("ESP_WAVE") || getenv("ESP_NO_WAVE")) return false;  // (opt-in while it does not beat local_k end to end: see wavecols.hpp)
+    if (atoi(getenv("ESP_WAVE")) >= 2) return true;  // (test hook: whatever the columns hold -- a segment with a longer run sends the flush back to local_k)
     const double per_col = (double)E / (double)std::max<i64>(h->n, 1);
     return h->seen_maxrun > 0 ? h->seen_maxrun <= 16 : per_col <= 16.0;
 }

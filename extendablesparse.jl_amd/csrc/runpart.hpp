@@ -715,10 +715,19 @@ __device__ __forceinline__ bool tile_stop(const PartOut &p, const TileLoads &L, 
     return L.stop != 0u || (out32 && L.longest > (unsigned long long)p.cap);
 }
 
+// The run table of a tile as every wave holds it in registers: lane j = run j (what TileLds holds in LDS: the copy-out loop
+// walks the runs one after the other, and a table read from LDS per run -- four dependent round trips -- is a fifth of a
+// finely cut tile's life; a readlane is not)
+struct TileRegs {
+    u32 lst;    // first LDS slot of run `lane` (lane >= nr: the tile's total)
+    i64 roff;   // global offset of run `lane`
+    u64 rbase;  // first key of run `lane`'s bucket
+    u32 rown;   // own32: run `lane` lies in the shard's own window
+};
 // (out32: the launch stores 4-byte keys and leaves when the longest bucket does not fit the bucket kernel)
 template <int NQ, int NWAVES>
 __device__ __forceinline__ bool tile_slots(const PartOut &p, const TileLoads &L, const u32 (&dig)[NQ], const u32 (&wt)[NQ],
-                                           u32 (&slot)[NQ], TileLds<NWAVES> &S, int *total_out, bool out32) {
+                                           u32 (&slot)[NQ], TileLds<NWAVES> &S, int *total_out, bool out32, TileRegs *regs = nullptr) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (L.stop != 0u || (out32 && L.longest > (unsigned long long)p.cap)) return false;
     const int nr = L.nr;
@@ -770,21 +779,22 @@ __device__ __forceinline__ bool tile_slots(const PartOut &p, const TileLoads &L,
     const u32 lst = inc - tot;
     const u32 sb = lst + before;  // first slot of this wave's part of run `lane`
     const int total = __builtin_amdgcn_readlane((int)inc, 63);
+    u64 rb = 0;
+    u32 own = 0;
+    if (lane < nr && (w == 0 || regs)) {
+        if (p.mw_P) {
+            const u32 r = my_run_digit / p.mw_nb;
+            rb = ((int)r == p.mw_me ? p.mw_own_base : p.mw_base[r]) + ((u64)(my_run_digit - r * p.mw_nb) << p.shift);
+            own = (p.own32 && (int)r == p.mw_me) ? 1u : 0u;
+        } else {
+            rb = p.base + ((u64)my_run_digit << p.shift);
+        }
+    }
+    if (regs) *regs = TileRegs{lst, lane < nr ? run_off_raw : 0, rb, own};
     if (w == 0) {
         S.lstart[lane] = lst;
         if (lane == 63) S.lstart[RMAX] = inc;
         S.roff[lane] = lane < nr ? run_off_raw : 0;
-        u64 rb = 0;
-        u32 own = 0;
-        if (lane < nr) {
-            if (p.mw_P) {
-                const u32 r = my_run_digit / p.mw_nb;
-                rb = ((int)r == p.mw_me ? p.mw_own_base : p.mw_base[r]) + ((u64)(my_run_digit - r * p.mw_nb) << p.shift);
-                own = (p.own32 && (int)r == p.mw_me) ? 1u : 0u;
-            } else {
-                rb = p.base + ((u64)my_run_digit << p.shift);
-            }
-        }
         S.rbase[lane] = rb;
         S.rown[lane] = own;
         const u64 foreign = __ballot(lane < nr && !own);
@@ -807,7 +817,7 @@ __device__ __forceinline__ bool tile_slots(const PartOut &p, const TileLoads &L,
 // KT = u64: packed keys staged and stored as they are.
 template <typename KT, bool OUT32, int NT, int NWAVES>
 __device__ __forceinline__ void copy_out_runs(const PartOut &p, const KT *lk, const double *lv, int total, const TileLds<NWAVES> &S,
-                                              u32 kind, int lo = 0, int hi = 0x7FFFFFFF, u32 *k4_all = nullptr) {
+                                              u32 kind, int lo = 0, int hi = 0x7FFFFFFF, u32 *k4_all = nullptr, const TileRegs *R = nullptr) {
     typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
     typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
     typedef double f64x2 __attribute__((ext_vector_type(2)));
@@ -817,21 +827,24 @@ __device__ __forceinline__ void copy_out_runs(const PartOut &p, const KT *lk, co
     for (int j = 0; j < RMAX; j++) {
         // (staging window [lo, hi) of the tile's slots: a tile that does not fit the staging area goes out in rounds;
         // slot q of the window sits at lk[q - lo])
-        const int b0 = (int)S.lstart[j], e0 = (int)S.lstart[j + 1];
+        auto lane_u32 = [&](u32 x, int l) { return (u32)__builtin_amdgcn_readlane((int)x, l); };
+        auto lane_u64 = [&](u64 x, int l) { return ((u64)lane_u32((u32)(x >> 32), l) << 32) | (u64)lane_u32((u32)x, l); };
+        const int b0 = R ? (int)lane_u32(R->lst, j) : (int)S.lstart[j];
+        const int e0 = R ? (j + 1 < ESP_WAVE ? (int)lane_u32(R->lst, j + 1) : total) : (int)S.lstart[j + 1];
         if (b0 >= total || b0 >= hi) break;
         const int bw = max(b0, lo), ew = min(e0, hi);
         const int len = ew - bw;
         if (len <= 0) continue;
         const int b = bw - lo;
-        const i64 ro = S.roff[j] + (i64)(bw - b0);
-        const u64 rb = S.rbase[j];
+        const i64 ro = (R ? (i64)lane_u64((u64)R->roff, j) : S.roff[j]) + (i64)(bw - b0);
+        const u64 rb = R ? lane_u64(R->rbase, j) : S.rbase[j];
         // 4-byte keys for this run: every run (OUT32), or the runs of a shard's own window (own32; KT = u32 then)
         // (k4_all: OUT32 for a tile whose runs all lie in the shard's own window -- the keys go to own_keys32)
         bool run32 = OUT32;
         u32 *k4 = OUT32 && k4_all ? k4_all : reinterpret_cast<u32 *>(p.keys_out);
         const i64 k4off = 0;  // index of the 4-byte key of bucket position q: q - k4off
         if constexpr (sizeof(KT) == 4 && !OUT32) {
-            if (S.rown[j]) {
+            if (R ? lane_u32(R->rown, j) != 0u : S.rown[j] != 0u) {
                 run32 = true;
                 k4 = own_keys32(p.keys_out, S.own_lo);
             }

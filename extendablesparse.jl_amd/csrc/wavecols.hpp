@@ -33,8 +33,6 @@
 
 namespace esplocal {
 
-constexpr int WV_THREADS = 256;
-constexpr int WV_WAVES = WV_THREADS / ESP_WAVE;
 constexpr int WV_CL_BITS = 6;    // at most 64 columns per segment: one lane each
 constexpr int WV_IDX_BITS = 10;  // slot index inside the segment (<= 1024 entries)
 constexpr int WV_ROW_BITS = 32 - WV_IDX_BITS;
@@ -104,18 +102,26 @@ template <int NI>
 __device__ __forceinline__ void wave_fetch(const Args &a, i64 beg, int n, int lane, u32 (&k)[NI], double (&v)[NI]) {
     // (unconditional: an empty segment reads entry 0 and ignores it -- a conditional request would keep the previous
     // ticket's registers alive through the whole iteration)
-    const i64 lbeg = n > 0 ? beg : 0;
-    const u32 *kp = reinterpret_cast<const u32 *>(a.keys_in) + lbeg;
-    const double *vp = a.vals_in + lbeg;
-    const int nlast = n > 0 ? n - 1 : 0;
+    // (uniform base + 32-bit byte offset per lane: one v_min and two shifts per entry instead of 64-bit address arithmetic)
+    // (the segment's start comes out of the loop's carried state, which the register allocator may have moved to vector
+    // registers: back to scalar ones here, so that the loads use a scalar base)
+    const i64 lbeg = esp_uniform_i64(n > 0 ? beg : 0);
+    n = esp_uniform_i32(n);
+    const char *kp = reinterpret_cast<const char *>(reinterpret_cast<const u32 *>(a.keys_in) + lbeg);
+    const char *vp = reinterpret_cast<const char *>(a.vals_in + lbeg);
+    const u32 nlast = n > 0 ? (u32)(n - 1) : 0u;
+    u32 at[NI];
 #pragma unroll
-    for (int i = 0; i < NI; i++) k[i] = kp[min(lane + i * ESP_WAVE, nlast)];
+    for (int i = 0; i < NI; i++) at[i] = min((u32)lane + (u32)(i * ESP_WAVE), nlast);
 #pragma unroll
-    for (int i = 0; i < NI; i++) v[i] = vp[min(lane + i * ESP_WAVE, nlast)];
+    for (int i = 0; i < NI; i++) k[i] = *reinterpret_cast<const u32 *>(kp + (size_t)(at[i] << 2));
+#pragma unroll
+    for (int i = 0; i < NI; i++) v[i] = *reinterpret_cast<const double *>(vp + (size_t)(at[i] << 3));
 }
 
-template <int NI>
-__global__ __launch_bounds__(WV_THREADS, NI <= 12 ? 4 : 3) void wave_k(Args a) {
+// WV_WAVES segments (= waves) per workgroup and ticket: the look-back's granules, polls and ticket draws are per workgroup
+template <int NI, int WV_WAVES>
+__global__ __launch_bounds__(WV_WAVES * ESP_WAVE, NI <= 12 ? 4 : 3) void wave_k(Args a) {
     static_assert(NI * ESP_WAVE <= (1 << WV_IDX_BITS), "slot index bits");
     constexpr int CAPW = NI * ESP_WAVE;
     __shared__ double sval[WV_WAVES][CAPW];
@@ -190,9 +196,9 @@ __global__ __launch_bounds__(WV_THREADS, NI <= 12 ? 4 : 3) void wave_k(Args a) {
                 const bool valid = lane + i * ESP_WAVE < n;
                 const u32 col = valid ? k[i] >> a.rb : (u32)ESP_WAVE;  // (the partition masked the keys: col < 2^cl_bits)
                 slot[i] = atomicAdd(&cc[col], 1u);
-                const u32 row = k[i] & rowmask32;
-                rmin = min(rmin, valid ? row : ~0u);
-                rmax = max(rmax, valid ? row : 0u);
+                const u32 row = k[i] & rowmask32;  // (a slot past the end holds a copy of the last entry: its row changes nothing)
+                rmin = min(rmin, row);
+                rmax = max(rmax, row);
             }
             wave_lds_sync();
             const u32 cnt = cc[lane];
@@ -248,13 +254,11 @@ __global__ __launch_bounds__(WV_THREADS, NI <= 12 ? 4 : 3) void wave_k(Args a) {
         // ---- the next ticket's entries are requested; the workgroup's total is published and the last wave resolves the
         // look-back chain
         wave_fetch<NI>(a, nbeg, min((int)(nend - nbeg), CAPW), lane, k, v);
-        u32 wg_total = 0, before = 0;
-#pragma unroll
-        for (int i = 0; i < WV_WAVES; i++) {
-            const u32 ti = s_tot[i];
-            wg_total += ti;
-            before += i < w ? ti : 0u;
-        }
+        // (the waves' totals scanned by every wave for itself: lane i holds wave i's)
+        const u32 ti = lane < WV_WAVES ? s_tot[lane] : 0u;
+        const u32 tinc = esp_wave_scan_add(ti);
+        const u32 wg_total = (u32)__builtin_amdgcn_readlane((int)tinc, 63);
+        const u32 before = (u32)__builtin_amdgcn_readlane((int)(tinc - ti), w);
         if (w == WV_WAVES - 1) {
             Args la = a;  // (the look-back runs over the workgroups' granules)
             la.S = nwg;
@@ -272,9 +276,13 @@ __global__ __launch_bounds__(WV_THREADS, NI <= 12 ? 4 : 3) void wave_k(Args a) {
         bounds(wgnn, nnbeg, nnend);
         if (t == 0 && wgnn < nwg) tn = ESP_WAVE_TICKET();
         // coalesced stores; the lane's column starts at dst + colbase
-        for (int p = lane; p < (int)tot; p += ESP_WAVE) {
-            a.out_row[dst + p] = (i64)(sk[p] + rmin) + 1;
-            a.out_val[dst + p] = sv[p];
+        {
+            const u64 dstu = esp_uniform_u64(dst);
+            char *orow = reinterpret_cast<char *>(a.out_row + dstu), *oval = reinterpret_cast<char *>(a.out_val + dstu);
+            for (u32 p = (u32)lane; p < tot; p += ESP_WAVE) {
+                *reinterpret_cast<i64 *>(orow + (size_t)(p << 3)) = (i64)(sk[p] + rmin) + 1;
+                *reinterpret_cast<double *>(oval + (size_t)(p << 3)) = sv[p];
+            }
         }
         if (s < a.S) {
             const i64 c = (i64)((((u64)s << a.rem_bits) + a.base) >> a.rb) + lane;

@@ -481,6 +481,48 @@ def test_fdrand_stream_and_reassembly(esp, orc):
     assert A.phash != h0 and A.nnz() == orc.fdrand_nnz(nx, ny, nz) + len(I)
 
 
+def test_wave_kernel_opt_in(esp, orc, monkeypatch):
+    """The wave-per-segment bucket kernel (wavecols.hpp; opt-in: ESP_WAVE=1): the producer cuts segments of at most 64
+    columns, a persistent workgroup of four waves draws tickets and every wave sorts and folds one segment.  Bitwise the
+    oracle's CSC for both adding kinds, grids whose last segment is ragged, and -- ESP_WAVE=2: planned whatever the columns
+    hold -- a matrix whose columns hold 24 entries: its segments are refused (runs above 16) and the flush runs again with
+    local_k's kernels."""
+    monkeypatch.setenv("ESP_WAVE", "1")
+    for (nx, ny, nz, kind) in ((40, 40, 40, UPDATE), (64, 50, 33, RAW), (100, 7, 90, UPDATE)):
+        N = nx * ny * nz
+        A = esp.ExtendableSparseMatrix(N, N)
+        A.generate_fdrand(nx, ny, nz, seed=0x77, rand_mode=1, kind=kind)
+        A.flush()
+        assert A.debug_last_partition() == 4 and A.debug_last_local_small() == 6, (A.debug_last_partition(), A.debug_last_local_small())
+        O = orc.fdrand(nx, ny, nz, rand_mode=1, seed=0x77, style=kind)
+        assert_csc_equal(hip_arrays(A), O.arrays(), "wave kernel %dx%dx%d" % (nx, ny, nz))
+        # a second assembly on the same handle (tickets, pools and granules start from zero again)
+        A.reset()
+        A.generate_fdrand(nx, ny, nz, seed=0x78, rand_mode=1, kind=kind)
+        A.flush()
+        assert A.debug_last_local_small() == 6
+        O = orc.fdrand(nx, ny, nz, rand_mode=1, seed=0x78, style=kind)
+        assert_csc_equal(hip_arrays(A), O.arrays(), "wave kernel, second assembly")
+    monkeypatch.setenv("ESP_WAVE", "2")
+    npd = 300
+    B = esp.ExtendableSparseMatrix(npd * npd, npd * npd)
+    B.generate_fem(2, npd, seed=5, order_mode=0)
+    B.flush()
+    assert B.debug_last_local_small() != 6     # (refused: column runs of 24; the flush ran again)
+    def fem_oracle(seed):
+        I, J, V = orc.fem_stream(2, npd, seed=seed, order_mode=0)
+        O = orc.ExtendableSparseMatrix(npd * npd, npd * npd)
+        O.apply(np.full(len(I), RAW, np.uint8), I, J, V)
+        O.flush()
+        return O.arrays()
+    assert_csc_equal(hip_arrays(B), fem_oracle(5), "wave kernel refused")
+    # ... and the handle does not plan for it again
+    B.reset()
+    B.generate_fem(2, npd, seed=6, order_mode=0)
+    B.flush()
+    assert_csc_equal(hip_arrays(B), fem_oracle(6), "after the refusal")
+
+
 def test_device_generator_stream_is_the_reference_stream(esp, orc):
     """The on-device fdrand stream equals the sequential stream entry for entry (order included):
     feed it through a 1-entry-per-key matrix so every value is observable."""
