@@ -33,8 +33,12 @@ int main() {
     for (int i = 0; i < G; i++) hist[x[i] & 15]++;
     for (int i = 0; i < 16; i++) printf("xcc %d: %d blocks\n", i, hist[i]);
     unsigned long long *ctr, *sink;
-    hipMalloc(&ctr, 4096);
     hipMalloc(&sink, 8);
+    for (int alloc = 0; alloc < 3; alloc++) {
+    // 0: hipMalloc (coarse-grained, cached in the L2s), 1: uncached device memory, 2: fine-grained device memory
+    if (alloc == 0) hipMalloc(&ctr, 4096);
+    else if (hipExtMallocWithFlags((void **)&ctr, 4096, alloc == 1 ? hipDeviceMallocUncached : hipDeviceMallocFinegrained) != hipSuccess) { printf("alloc %d failed\n", alloc); continue; }
+    printf("allocation %d (%s)\n", alloc, alloc == 0 ? "hipMalloc" : alloc == 1 ? "uncached" : "fine-grained");
     for (int mode = 0; mode < 2; mode++) {
         hipMemset(ctr, 0, 4096);
         hipEvent_t a, b;
@@ -49,6 +53,7 @@ int main() {
         float ms = 0;
         hipEventElapsedTime(&ms, a, b);
         printf("mode %d (%s): 1024 workgroups x 64 draws: %.3f ms = %.1f ns per draw\n", mode, mode ? "one counter per XCD" : "one counter", ms, ms * 1e6 / (1024.0 * 64));
+    }
     }
     return 0;
 }
