@@ -235,6 +235,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         a.k32_lo = st.p32_lo;
         h->last_key_bytes = (st.p32_piece >= 0 || st.all32) ? 4 : st.key_bytes;
         a.colptr_out = direct ? (i64 *)h->colptr.p : nullptr;
+        a.late_total = getenv("ESP_LATE_TOTAL") ? 1 : 0;
         a.no_group = h->force_path == ESP_PATH_NO_GROUP_TIER ? 1 : 0;  // 24: test hook, long column runs through the radix tier
         // (every pending entry was noted with one kind; pieces of other ranks carry kinds this handle has not seen)
         a.kind_all = (st.npieces == 0 && h->kind_uniform >= 0 && h->kind_noted == h->count && h->force_path != ESP_PATH_GENERIC_FOLD) ? h->kind_uniform : -1;

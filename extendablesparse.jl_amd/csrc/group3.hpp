@@ -36,7 +36,7 @@ __global__ __launch_bounds__(THREADS, WIDE ? 4 : NI == 6 ? 8 : 6) void group3_k(
     __shared__ u32 lw[16];
     __shared__ u64 s_dst;
     __shared__ int s_seg;
-    __shared__ u32 s_early, s_rmin, s_rmax;
+    __shared__ u32 s_early, s_rmin, s_rmax, s_done;
     __shared__ i64 s_win[66];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -46,6 +46,7 @@ __global__ __launch_bounds__(THREADS, WIDE ? 4 : NI == 6 ? 8 : 6) void group3_k(
     if (t == 0) {
         s_seg = (int)atomicAdd(a.ticket, 1u);
         s_early = 0;
+        s_done = 0;
         s_rmin = ~0u;
         s_rmax = 0u;
     }
@@ -181,7 +182,7 @@ __global__ __launch_bounds__(THREADS, WIDE ? 4 : NI == 6 ? 8 : 6) void group3_k(
             if (t == 0) gstamp[12] = wall_clock64();
         }
 #endif
-        const DenseCtx dcx{&s_early, ctot, &lbs, s};
+        const DenseCtx dcx{&s_early, ctot, &lbs, s, a.late_total ? nullptr : &s_done};
 #define ESP_G3_GO(GG)                                                                                                                \
     do {                                                                                                                             \
         if (gmode == 1)                                                                                                              \

@@ -17,12 +17,22 @@ int32_t ensure(esp_handle *h, DevBuf &b, size_t need, bool keep) {
     if (keep && b.bytes) want = std::max(need, b.bytes + b.bytes / 2);
     want = (want + 255) & ~(size_t)255;
     void *np = nullptr;
-    HIPCK(h, hipMalloc(&np, want));
-    if (keep && b.p && b.bytes) {
-        HIPCK(h, hipMemcpyAsync(np, b.p, b.bytes, hipMemcpyDeviceToDevice, h->stream));
-        HIPCK(h, hipStreamSynchronize(h->stream));
+    if (!(keep && b.p && b.bytes)) {
+        // nothing to carry over: the old allocation goes first (a 256^3 buffer that is replaced never needs old + new at once)
+        release(b);
+        HIPCK(h, hipMalloc(&np, want));
+        b.p = np;
+        b.bytes = want;
+        return ESP_OK;
     }
-    if (b.p) (void)hipFree(b.p);
+    HIPCK(h, hipMalloc(&np, want));
+    hipError_t e = hipMemcpyAsync(np, b.p, b.bytes, hipMemcpyDeviceToDevice, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {  // (the buffer stays as it was; the new allocation does not leak)
+        (void)hipFree(np);
+        FAIL(h, ESP_ERR_HIP, "growing a device buffer failed: %s", hipGetErrorString(e));
+    }
+    (void)hipFree(b.p);
     b.p = np;
     b.bytes = want;
     return ESP_OK;

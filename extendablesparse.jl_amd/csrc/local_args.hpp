@@ -69,6 +69,7 @@ struct Args {
     i64 *colptr_out;
     i64 n_cols;   // columns of the matrix (column-end marks of a failing flush -- keys outside the window -- stay inside colend)
     i64 col_end;  // end of the column range (colptr_out[col_end] = 1 + nnz comes from the last segment)
+    int late_total;  // group3_k: the segment's total is published after the fold even when it is known after the sort (experiments: ESP_LATE_TOTAL)
     int no_group;  // test hook: column runs of more than 24 entries go to the radix tier, never to the group tier
     int kind_all;  // >= 0: every pending entry has this kind (the host's bookkeeping), whatever the key format says; else -1
     int expect_hits;  // the host expects most positions to be stored already: a short stored column is fetched with its values
