@@ -351,6 +351,38 @@ __device__ __forceinline__ void fold_run(const Args &a, u64 *skey, double *sval,
         if (j >= e && j < len) skey[rs + j] = NOREC;
 }
 
+// The same fold on a fresh matrix with the run's values in registers and the records going straight to their DENSE place
+// (`at`: the segment's records in front of this run's -- the emitted counts were scanned before the fold): what the final
+// stores read, no record slots, no NOREC marks, no compaction over the segment's slots afterwards.
+template <int R, bool UPD>
+__device__ __forceinline__ void fold_run_dense(u64 *skey, double *sval, const u64 (&x)[R], const double (&xv)[R], int len, u64 hi, u32 at) {
+    bool present = false;
+    double acc = 0.0;
+    u64 prev = 0;  // first key of the running group
+#pragma unroll
+    for (int j = 0; j <= R; j++) {
+        const bool valid = j < R && j < len;
+        const u64 kj = j < R ? x[j] : NOREC;
+        const bool fresh = j == 0 || !valid || (kj >> SUB_SHIFT) != (prev >> SUB_SHIFT);
+        if (fresh && j > 0 && j <= len && present) {  // close the group
+            skey[at] = hi + (prev >> SUB_SHIFT);
+            sval[at] = acc;
+            at++;
+        }
+        if (fresh) {
+            prev = kj;
+            present = false;
+            acc = 0.0;
+        }
+        if (valid) {
+            if constexpr (UPD)
+                espfold::fold_step_update(present, acc, xv[j < R ? j : 0]);
+            else
+                espfold::fold_step_sel(present, acc, (u32)(kj & ESP_TAG_MASK), xv[j < R ? j : 0]);
+        }
+    }
+}
+
 // Ordered fold of one sorted run over a SHORT stored column (at most CSC_SHORT entries, rows below 2^32): the walk of
 // fold_run is a chain of dependent global loads -- a row, then the value it hits, then the store, for every group of
 // the run (stencil re-assembly: 14 round trips, 8 of a segment's 17 us).  Here the column's rows and values are
@@ -592,9 +624,10 @@ __device__ __forceinline__ bool lb_may_skip(const Args &a, int s) { return !lb_l
 
 // Register tier of the bucket kernel: one lane per column, the whole run (<= R entries) in registers.
 // Returns true when the look-back already ran (early publication of the segment total).
+// *dense (fresh matrix, runs of at most 16): the records lie at their dense places already (fold_run_dense); wtot: WAVES LDS words
 template <int R, bool FRESH, bool UPD, bool SM>
 __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval, const u32 *ccnt, int ncl, int s, u64 hi,
-                                         u64 rowmask, u32 *s_early, LbState &lb) {
+                                         u64 rowmask, u32 *s_early, LbState &lb, bool *dense = nullptr, u32 *wtot = nullptr) {
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     if (FRESH && a.csc.nnz == 0 && ncl <= THREADS - ESP_WAVE) {
         // Nothing can hit the CSC, so the number of entries a run emits is known right after
@@ -610,8 +643,20 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
             load_sorted_run<R>(skey, sval, rs, len, x, xv);
             ec = count_emitted<R, UPD>(x, xv, len);
         }
-        ec = esp_wave_sum(ec);
-        if (lane == 0 && ec) atomicAdd(s_early, ec);
+        // (the lanes' counts scanned: a run's records go straight to their dense place -- see fold_run_dense.  The small variant
+        // has 80 registers: a run of 16 keys and values does not fit them across the barrier)
+#ifdef ESP_NO_DENSE_REG
+        constexpr bool DENSE_R = false;
+#else
+        constexpr bool DENSE_R = SM ? R <= 12 : R <= 16;
+#endif
+        const u32 ecl = ec;
+        const u32 einc = esp_wave_scan_add(ecl);
+        ec = (u32)__builtin_amdgcn_readlane((int)einc, 63);
+        if (lane == 0) {
+            if constexpr (DENSE_R) wtot[w] = ec;
+            if (ec) atomicAdd(s_early, ec);
+        }
 #ifdef ESP_LOCAL_STAMPS
         if (a.stamps && t == 0) a.stamps[(size_t)s * 16 + 8] = wall_clock64();
 #endif
@@ -619,6 +664,20 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
 #ifdef ESP_LOCAL_STAMPS
         if (a.stamps && t == 0) a.stamps[(size_t)s * 16 + 9] = wall_clock64();
 #endif
+        if constexpr (DENSE_R) {
+            // (every lane holds its run's keys and values in registers: the LDS arrays are free for the records)
+            u32 at = einc - ecl;
+#pragma unroll
+            for (int i = 0; i < WAVES; i++) at += i < w ? wtot[i] : 0u;
+            if (w == WAVES - 1) {
+                lb_publish(a, lb, s, *s_early, lane);
+                lb_poll(a, lb, s, lane, 1, false);
+            } else if (t < ncl) {
+                fold_run_dense<R, UPD>(skey, sval, x, xv, len, hi, at);
+            }
+            *dense = true;
+            return true;
+        }
         if (w == WAVES - 1) {
             // publish, then poll the predecessors a bounded number of times: the chain is usually still
             // open when the others are done folding; the wave carries on with it between the following
@@ -1602,10 +1661,11 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
             if (!done && maxrun <= (BIG ? REG_RUN : 16) && a.rem_bits <= REG_MAX_REM) {
                 // one lane per column: the whole run in registers, sorting network + ordered fold; the
                 // network is sized to the longest run of the segment (12 covers a 7-point stencil)
+                // (fresh matrix: the tier leaves the records dense)
                 if (maxrun <= 12)
-                    lb_done = reg_tier<12, FRESH, UPD, SMALL>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
+                    lb_done = reg_tier<12, FRESH, UPD, SMALL>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs, &dense_done, lw);
                 else if (!BIG || maxrun <= 16)
-                    lb_done = reg_tier<16, FRESH, UPD, SMALL>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
+                    lb_done = reg_tier<16, FRESH, UPD, SMALL>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs, &dense_done, lw);
                 else if constexpr (BIG)
                     lb_done = reg_tier<REG_RUN, FRESH, UPD, SMALL>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs);
                 done = true;
