@@ -530,6 +530,9 @@ __device__ __forceinline__ void fold_run_lds(const Args &a, u64 *skey, double *s
 constexpr int LB_SHIFT = 8;
 
 constexpr int LB_GROUP = 1 << LB_SHIFT;
+#ifndef ESP_LB_SLEEP
+#define ESP_LB_SLEEP 2  // (x 64 cycles between two rounds of polls)
+#endif
 struct LbState {
     u64 group_part;  // totals of the own group's segments in front of this one
     u64 prefix;      // gstatus of the previous group
@@ -592,7 +595,7 @@ __device__ __forceinline__ void lb_poll(const Args &a, LbState &st, int s, int l
                 st.finished = true;  // give up (the host reports the error)
                 break;
             }
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(ESP_LB_SLEEP);
         }
     }
 }
@@ -670,8 +673,10 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
 #pragma unroll
             for (int i = 0; i < WAVES; i++) at += i < w ? wtot[i] : 0u;
             if (w == WAVES - 1) {
+                // (no poll here: the wave would reach the barrier behind the fold a round trip late -- HIP's barrier waits for a
+                // wave's outstanding loads -- and the whole workgroup with it: one immediate round of polls cost the headline's
+                // bucket kernel 0.17 of 1.30 ms; the chain is resolved after the fold, lb_complete)
                 lb_publish(a, lb, s, *s_early, lane);
-                lb_poll(a, lb, s, lane, 1, false);
             } else if (t < ncl) {
                 fold_run_dense<R, UPD>(skey, sval, x, xv, len, hi, at);
             }
@@ -685,7 +690,6 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
             // (measured: polling already while the other waves sort costs more in contention than the
             // shorter chain saves -- local 2.52 vs 2.33 ms)
             lb_publish(a, lb, s, *s_early, lane);
-            lb_poll(a, lb, s, lane, 1, false);
         } else if (t < ncl) {
             // (measured: keeping the sorted keys in registers across the barrier and re-reading
             // only the values beats writing the run back to LDS)
@@ -1293,7 +1297,7 @@ __device__ __forceinline__ bool group_columns(const Args &a, KT *skey, double *s
                     lb_init(*dc->lb, dc->s);  // (the total is out already)
                 else
                     lb_publish(a, *dc->lb, dc->s, *dc->s_early, lane);
-                lb_poll(a, *dc->lb, dc->s, lane, 1, false);
+                // (no poll in front of a barrier, see reg_tier)
             }
             if (w == 0) {  // exclusive scan of the columns' record counts (<= 512 columns: eight per lane)
                 u32 pre[DENSE_COLS / ESP_WAVE], run = 0;
