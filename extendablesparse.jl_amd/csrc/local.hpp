@@ -527,6 +527,12 @@ __device__ __forceinline__ void fold_run_lds(const Args &a, u64 *skey, double *s
 // (Round 4 also tried groups of 64 with unchained group TOTALS under a chain over super-groups of 64 groups -- two 64-wide
 // loads per round, a lane asking only for what it has not seen: no faster for local_k, slower for the persistent wave_k;
 // a poll interval of 8 or 30 instead of 2 x 64 cycles, the group granules on lines of their own, four copies of each: nothing.)
+// WHEN the polls happen matters more than how: a round of polls in front of a barrier makes the polling wave -- and the
+// workgroup -- a round trip late (HIP's barrier waits for a wave's outstanding loads): 1.30 -> 1.13 ms for the headline's
+// kernel once the round right after the publication was gone; a round kept in flight ACROSS that barrier (a bare s_barrier for
+// the polling wave), asked for 0.1 / 0.3 us after the publication: 1.27 / 1.21 ms -- polls that come back empty are worse than
+// polls that are not made; the wave that owns the look-back starts polling behind the fold, when it is needed (a pause of
+// 0.2 / 0.6 us in front of that first round: nothing / slower).
 constexpr int LB_SHIFT = 8;
 
 constexpr int LB_GROUP = 1 << LB_SHIFT;
@@ -538,6 +544,7 @@ struct LbState {
     u64 prefix;      // gstatus of the previous group
     bool have_part, have_prefix, finished;
     u32 spins;
+    u64 pend_v[LB_GROUP / 64], pend_gp;  // the answers of a round of polls (lb_issue), looked at by lb_consume
 };
 __device__ __forceinline__ void lb_init(LbState &st, int s) {
     st.group_part = 0;
@@ -548,47 +555,54 @@ __device__ __forceinline__ void lb_init(LbState &st, int s) {
     st.spins = 0;
 }
 __device__ __forceinline__ bool lb_last_of_group(const Args &a, int s) { return (s & (LB_GROUP - 1)) == LB_GROUP - 1 || s == a.S - 1; }
-// at most `iters` polls (block: until resolved)
-__device__ __forceinline__ void lb_poll(const Args &a, LbState &st, int s, int lane, u32 iters, bool block) {
+// one round of polls: all granule loads are in flight together (lanes beyond the segments in front: ready zeros)
+__device__ __forceinline__ void lb_issue(const Args &a, LbState &st, int s, int lane) {
     const int g = s >> LB_SHIFT, gbase = g << LB_SHIFT, need = s - gbase;
-    while (!st.finished && (block || iters-- > 0)) {
-        bool progress = false;
-        u64 v[LB_GROUP / 64];
-        u64 gp = ST_PRE;
-        // all granule loads of a round are in flight together (lanes beyond the segments in front: ready zeros)
+#pragma unroll
+    for (int c = 0; c < LB_GROUP / 64; c++) {
+        st.pend_v[c] = ST_AGG;
+        if (!st.have_part && c * 64 + lane < need)
+            st.pend_v[c] = __hip_atomic_load(&a.status[gbase + c * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    st.pend_gp = ST_PRE;
+    if (!st.have_prefix && lane == 0) st.pend_gp = __hip_atomic_load(&a.gstatus[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// ... and what they brought; true: something new was learnt
+__device__ __forceinline__ bool lb_consume(LbState &st) {
+    bool progress = false;
+    if (!st.have_part) {
+        bool miss = false;
+        u64 sum = 0;
 #pragma unroll
         for (int c = 0; c < LB_GROUP / 64; c++) {
-            v[c] = ST_AGG;
-            if (!st.have_part && c * 64 + lane < need)
-                v[c] = __hip_atomic_load(&a.status[gbase + c * 64 + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            miss = miss || (st.pend_v[c] >> 62) == 0;
+            sum += st.pend_v[c] & ST_VAL;
         }
-        if (!st.have_prefix && lane == 0) gp = __hip_atomic_load(&a.gstatus[g - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (!st.have_part) {
-            bool miss = false;
-            u64 sum = 0;
-#pragma unroll
-            for (int c = 0; c < LB_GROUP / 64; c++) {
-                miss = miss || (v[c] >> 62) == 0;
-                sum += v[c] & ST_VAL;
-            }
-            if (__ballot(miss) == 0ull) {
-                // (totals are < 2^32 each and 256 of them < 2^40: two 32-bit DPP sums of the per-lane sums' halves)
-                const u32 lo = esp_wave_sum((u32)(sum & 0xFFFFFFull));
-                const u32 hi = esp_wave_sum((u32)(sum >> 24));
-                st.group_part = ((u64)hi << 24) + (u64)lo;
-                st.have_part = true;
-                progress = true;
-            }
+        if (__ballot(miss) == 0ull) {
+            // (totals are < 2^32 each and 256 of them < 2^40: two 32-bit DPP sums of the per-lane sums' halves)
+            const u32 lo = esp_wave_sum((u32)(sum & 0xFFFFFFull));
+            const u32 hi = esp_wave_sum((u32)(sum >> 24));
+            st.group_part = ((u64)hi << 24) + (u64)lo;
+            st.have_part = true;
+            progress = true;
         }
-        if (!st.have_prefix) {
-            const u64 g0 = esp_uniform_u64(gp);
-            if ((g0 >> 62) != 0) {
-                st.prefix = g0 & ST_VAL;
-                st.have_prefix = true;
-                progress = true;
-            }
+    }
+    if (!st.have_prefix) {
+        const u64 g0 = esp_uniform_u64(st.pend_gp);
+        if ((g0 >> 62) != 0) {
+            st.prefix = g0 & ST_VAL;
+            st.have_prefix = true;
+            progress = true;
         }
-        st.finished = st.have_part && st.have_prefix;
+    }
+    st.finished = st.have_part && st.have_prefix;
+    return progress;
+}
+// at most `iters` polls (block: until resolved)
+__device__ __forceinline__ void lb_poll(const Args &a, LbState &st, int s, int lane, u32 iters, bool block) {
+    while (!st.finished && (block || iters-- > 0)) {
+        lb_issue(a, st, s, lane);
+        const bool progress = lb_consume(st);
         if (!st.finished && !progress) {
             if (++st.spins > SPIN_LIMIT) {
                 if (lane == 0) atomicOr(a.err, 1u);
@@ -1908,7 +1922,7 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
         for (int i = 0; i < NI; i++) rec[i] = NOREC, rv[i] = 0.0;
     }
     if (dense_done) {
-        if (t == 0) lw[0] = s_early;  // (the records lie dense already; the last wave is at the look-back)
+        // (the records lie dense already, the total is in s_early; the last wave is at the look-back)
     } else if (w == 0) {
 #ifdef ESP_LOCAL_STAMPS
         if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 5] = wall_clock64();
@@ -1937,14 +1951,13 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
             atomicOr(a.err, 4u);  // internal consistency: the early count must equal the folded count
         }
         if (lane == 0) lw[0] = total;
-    } else if (lb_done && w == WAVES - 1) {
-        lb_poll(a, lbs, s, lane, 1, false);
     }
-    __syncthreads();
+    // (no poll of the look-back wave here: it would reach the barrier a round trip late, see reg_tier)
+    if (!dense_done) __syncthreads();
 #ifdef ESP_LOCAL_STAMPS
     if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 6] = wall_clock64();
 #endif
-    const int total = (int)lw[0];
+    const int total = dense_done ? (int)s_early : (int)lw[0];
     // dense prefix in LDS (all records and values are in registers: in-place is safe)
 #pragma unroll
     for (int i = 0; i < NI; i++) {
