@@ -264,6 +264,9 @@ __global__ __launch_bounds__(WV_WAVES * ESP_WAVE, NI <= 12 ? 4 : 3) void wave_k(
             la.S = nwg;
             LbState lbs;
             lb_publish(la, lbs, wg, wg_total, lane);
+#ifdef ESP_WAVE_LB_DELAY
+            if (!lbs.finished) __builtin_amdgcn_s_sleep(ESP_WAVE_LB_DELAY);  // (the neighbours in front publish about now: a round of polls that finds nothing costs more than waiting)
+#endif
             const u64 excl = lb_complete(la, lbs, wg, wg_total, lane);
             if (lane == 0) s_dst = excl;
         }
