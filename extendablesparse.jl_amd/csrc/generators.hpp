@@ -260,7 +260,7 @@ static __global__ __launch_bounds__(THREADS) void fdrand_part_k(FdArgs a) {
     __shared__ esprun::TileLds<THREADS / ESP_WAVE> S;
     const esprun::PartOut &p = a.part;
     const esprun::TileLoads tl = esprun::tile_loads(p, p.chunk_base + blockIdx.x);
-    if (esprun::tile_stop(p, tl, OUT32)) return;
+    // (the flags are looked at by tile_slots: the node's items are formed while the tile's table is on its way)
     const i64 g = a.g_begin + (i64)blockIdx.x * THREADS + threadIdx.x;
     FdItems it;
     fd_items(a, g, it, nullptr);  // (the COUNT launch checked the window)
