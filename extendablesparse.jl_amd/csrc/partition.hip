@@ -807,7 +807,8 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
         done += bits;
         pass_idx++;
         if (pass_idx >= npass_eff) {
-            HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_maxlen, 8, hipMemcpyDeviceToHost, h->stream));
+            // (the longest segment and the window flag lie in one 64-byte block: one copy, one round trip)
+            HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_maxlen, 64, hipMemcpyDeviceToHost, h->stream));
             HIPCK(h, hipStreamSynchronize(h->stream));
             maxlen = (i64)h->pin_scalar[0];
         }
@@ -815,10 +816,8 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
     if (S == 1 && !tiles_ready)  // no pass at all: the buffer is the one segment
         hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, (i64 *)h->seg[0].p, (i64)0, E, (i64)0, (i64)0);
     HIPCK(h, hipGetLastError());
-    if (pass_idx > 0 && !(window_checked && pass_idx == 0)) {  // the partition passes clamp and report keys outside the window
-        HIPCK(h, hipMemcpyAsync(h->pin_scalar + 2, d_werr, 4, hipMemcpyDeviceToHost, h->stream));
-        HIPCK(h, hipStreamSynchronize(h->stream));
-        if ((u32)h->pin_scalar[2]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (partition)");
+    if (pass_idx > 0) {  // the partition passes clamp and report keys outside the window (d_werr: word 12 of the block read above)
+        if ((u32)h->pin_scalar[6]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (partition)");
     }
     if (out->key_bytes == 4 && (pass_idx > 0 || cur != 1))
         FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (4-byte keys met a further partition pass)");
