@@ -16,7 +16,8 @@
 // reports bit 8 of Args::err (bit 16 beside it: for its rows) and emits nothing; the host then runs the flush again with
 // local_k (a fresh-matrix flush has changed nothing) and the handle remembers.
 //
-// MEASURED (MI355X, 256^3 stencil, same box as local_k's small variant at 1.37 ms; tools/r4_wave.sh, tools/xcc_probe.hip):
+// MEASURED (MI355X, 256^3 stencil, same box as local_k's small variant at 1.37 ms -- before local_k's own look-back work,
+// which brought THAT kernel to 1.03-1.15 ms; tools/r4_wave.sh, tools/xcc_probe.hip):
 //   one workgroup per ticket (no loop)                       1.41 ms   818 VALU per wave (768 entries) against 8 x 722 per 3072
 //   persistent, tickets and entries requested ahead          1.50 ms   (1.78 with the ticket counter beside the granules)
 //   ... tickets dealt round-robin, no atomic (-DESP_WAVE_STATIC: safe only while every workgroup is resident)   1.14 ms
@@ -26,8 +27,9 @@
 // and polls delay each other.  A pool of tickets per XCD (blocks of 16 claimed from the counter, handed out through a word only
 // that XCD touches) was built and dropped: whoever refills a pool waits for a cross-XCD round trip while it HOLDS a ticket,
 // and every ticket above waits for it in its look-back -- 13 ms.  The finer cut costs the producer 0.17 ms (0.72 against
-// 0.55 ms: a dozen runs per tile instead of four), so the kernel has to reach 1.2 ms to draw level: it stays opt-in
-// (ESP_WAVE=1) as the vehicle for the next round's work on the synchronisation.
+// 0.55 ms: a dozen runs per tile instead of four).  With 16 segments per ticket (one workgroup of 16 waves per CU) it runs
+// 1.19-1.25 ms: slower than local_k is now, behind a costlier producer -- it stays opt-in (ESP_WAVE=1), the record of how
+// the bucket kernels' real bound was found and a vehicle for further work on the synchronisation.
 #pragma once
 #include "local.hpp"
 
