@@ -627,6 +627,22 @@ void par_memcpy(void *dst, const void *src, size_t bytes) {
             memcpy(vals_out, vals, sizeof(double) * (size_t)cnt);                                                                                    \
         return anybad;                                                                                                                               \
     }                                                                                                                                                \
+    ESP_HOST_SIMD static u64 pack_block_six(const TI *rows, const TI *cols, const double *vals, bool neg, i64 cnt, u64 um, u64 un, int rb,           \
+                                            uint32_t *lo_out, uint16_t *hi_out, double *vals_out) {                                                 \
+        u64 anybad = 0;                                                                                                                              \
+        for (i64 i = 0; i < cnt; i++) {                                                                                                              \
+            const u64 r0 = (u64)(i64)rows[i] - 1ull, c0 = (u64)(i64)cols[i] - 1ull;                                                                  \
+            anybad |= (u64)(r0 >= um) | (u64)(c0 >= un);                                                                                             \
+            const u64 key = (c0 << rb) | r0;                                                                                                         \
+            lo_out[i] = (uint32_t)key;                                                                                                               \
+            hi_out[i] = (uint16_t)(key >> 32);                                                                                                       \
+        }                                                                                                                                            \
+        if (neg)                                                                                                                                     \
+            for (i64 i = 0; i < cnt; i++) vals_out[i] = -vals[i];                                                                                    \
+        else                                                                                                                                         \
+            memcpy(vals_out, vals, sizeof(double) * (size_t)cnt);                                                                                    \
+        return anybad;                                                                                                                               \
+    }                                                                                                                                                \
     ESP_HOST_SIMD static u64 pack_block_kinds(const TI *rows, const TI *cols, const double *vals, const uint8_t *kinds, bool negate, i64 cnt, u64 um, \
                                               u64 un, int rb, u64 *keys_out, double *vals_out) {                                                    \
         u64 anybad = 0;                                                                                                                              \
@@ -643,9 +659,13 @@ ESP_PACK_BLOCKS(int64_t)
 ESP_PACK_BLOCKS(int32_t)
 #undef ESP_PACK_BLOCKS
 
+// lo6 / hi6 != nullptr (one kind for the batch, row + column bits <= 48): the key goes out in SIX bytes -- its low 32 bits and its
+// next 16 in two arrays, no kind bits -- instead of keys_out: 14 instead of 16 bytes per entry over PCIe (unpack6_k puts the
+// packed key together on the device)
 template <typename TI>
 static void host_pack(const TI *rows, const TI *cols, const double *vals, const uint8_t *kinds, int kind_all, bool negate, i64 count, i64 m, i64 n,
-                      KeyLayout L, u64 *keys_out, double *vals_out, i64 index_base, std::atomic<i64> *bad) {
+                      KeyLayout L, u64 *keys_out, double *vals_out, i64 index_base, std::atomic<i64> *bad, uint32_t *lo6 = nullptr,
+                      uint16_t *hi6 = nullptr) {
     host_parallel((size_t)count, (size_t)1 << 17, 8, [=](size_t sa_, size_t sb_) {
         const i64 a = (i64)sa_, b = (i64)sb_;
         i64 first_bad = -1;
@@ -655,7 +675,9 @@ static void host_pack(const TI *rows, const TI *cols, const double *vals, const 
         const int rb = L.rb;
         for (i64 i0 = a; i0 < b; i0 += 2048) {
             const i64 i1 = std::min(b, i0 + 2048);
-            const u64 anybad = kinds ? pack_block_kinds(rows + i0, cols + i0, vals + i0, kinds + i0, negate, i1 - i0, um, un, rb, keys_out + i0, vals_out + i0)
+            const u64 anybad = lo6 ? pack_block_six(rows + i0, cols + i0, vals + i0, negate && kind_all != ESP_SET, i1 - i0, um, un, rb, lo6 + i0, hi6 + i0,
+                                                    vals_out + i0)
+                               : kinds ? pack_block_kinds(rows + i0, cols + i0, vals + i0, kinds + i0, negate, i1 - i0, um, un, rb, keys_out + i0, vals_out + i0)
                                      : pack_block_one(rows + i0, cols + i0, vals + i0, (u64)kind_all, negate && kind_all != ESP_SET, i1 - i0, um, un, rb,
                                                           keys_out + i0, vals_out + i0);
             if (anybad && first_bad < 0) {
@@ -678,6 +700,12 @@ static void host_pack(const TI *rows, const TI *cols, const double *vals, const 
     });
 }
 
+// six-byte keys of one kind (host_pack) -> packed keys of the append buffer
+static __global__ void unpack6_k(const uint32_t *__restrict__ lo, const uint16_t *__restrict__ hi, u32 kind, i64 n, u64 *__restrict__ out) {
+    const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = ((((u64)hi[i] << 32) | (u64)lo[i]) << ESP_TAG_BITS) | (u64)kind;
+}
+
 // Bulk append from host arrays: the batch is packed on the host (host_pack) into the pinned staging area in chunks, two
 // halves in flight -- the packing of chunk i+1 overlaps the PCIe transfer of chunk i, which lands in the append buffer
 // itself; the call is one batch: nothing is committed when an index lies outside the matrix.
@@ -691,7 +719,14 @@ static int32_t append_host_t(esp_handle *h, const TI *rows, const TI *cols, cons
     if (op != ESP_OP_ADD && op != ESP_OP_SUB) FAIL(h, ESP_ERR_UNSUPPORTED, "append: op %d not supported on the device path", op);
     const i64 chunk = std::min<i64>((i64)1 << 22, std::max<i64>(count, 1));
     esp_handle::StageArea &sa = h->bulk;
-    CK(ensure_stage(h, sa, 2 * chunk));  // (its `rows` half holds packed keys here, `vals` the values; the device mirrors stay unused)
+    CK(ensure_stage(h, sa, 2 * chunk));  // (its `rows` half holds packed keys here, `vals` the values)
+    // one kind for the batch and at most 48 key bits: six-byte keys over PCIe (the low 32 bits in the `rows` area, the next 16 in the
+    // `cols` area; two halves of device staging in the area's device mirrors); ESP_HOST_KEYS8: never
+    const bool six = !kinds && h->L.rb + h->L.cb <= 48 && !getenv("ESP_HOST_KEYS8");
+    if (six) {
+        CK(ensure(h, sa.d_rows, sizeof(uint32_t) * (size_t)(2 * chunk)));
+        CK(ensure(h, sa.d_cols, sizeof(uint16_t) * (size_t)(2 * chunk)));
+    }
     CK(reserve_append(h, count));
     hipEvent_t done[2] = {nullptr, nullptr};
     for (int i = 0; i < 2; i++) HIPCK(h, hipEventCreateWithFlags(&done[i], hipEventDisableTiming));
@@ -710,14 +745,28 @@ static int32_t append_host_t(esp_handle *h, const TI *rows, const TI *cols, cons
         if (it >= 2 && hipEventSynchronize(done[half]) != hipSuccess) rc = ESP_ERR_HIP;
         const double t1 = now();
         t_wait += t1 - t0;
+        uint32_t *lo6 = six ? (uint32_t *)sa.rows + so : nullptr;
+        uint16_t *hi6 = six ? (uint16_t *)sa.cols + so : nullptr;
         host_pack<TI>(rows + off, cols + off, vals + off, kinds ? kinds + off : nullptr, kind_all, op == ESP_OP_SUB, c, h->m, h->n, h->L,
-                      (u64 *)sa.rows + so, sa.vals + so, off, &bad);
+                      (u64 *)sa.rows + so, sa.vals + so, off, &bad, lo6, hi6);
         t_pack += now() - t1;
         Span sp(h, ESP_ST_COPY);
+        if (six) {
+            uint32_t *d_lo = (uint32_t *)sa.d_rows.p + so;
+            uint16_t *d_hi = (uint16_t *)sa.d_cols.p + so;
+            if (hipMemcpyAsync(d_lo, lo6, sizeof(uint32_t) * (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+                hipMemcpyAsync(d_hi, hi6, sizeof(uint16_t) * (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
+                hipMemcpyAsync((double *)h->vals.p + h->count + off, sa.vals + so, sizeof(double) * (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess)
+                rc = ESP_ERR_HIP;
+            hipLaunchKernelGGL(unpack6_k, dim3(grid_for(c, 256)), dim3(256), 0, h->stream, (const uint32_t *)d_lo, (const uint16_t *)d_hi, (u32)kind_all, c,
+                               (u64 *)h->keys.p + h->count + off);
+            sp.add(4);
+        } else {
         if (hipMemcpyAsync((u64 *)h->keys.p + h->count + off, (u64 *)sa.rows + so, sizeof(u64) * (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
             hipMemcpyAsync((double *)h->vals.p + h->count + off, sa.vals + so, sizeof(double) * (size_t)c, hipMemcpyHostToDevice, h->stream) != hipSuccess)
             rc = ESP_ERR_HIP;
         sp.add(2);
+        }
         (void)hipEventRecord(done[half], h->stream);
     }
     const hipError_t e2 = hipStreamSynchronize(h->stream);

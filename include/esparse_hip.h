@@ -125,8 +125,10 @@ int32_t esp_append_host(esp_handle *h, const int64_t *rows, const int64_t *cols,
                         const double *vals, const uint8_t *kinds, int32_t kind_all, int32_t op,
                         int64_t count);
 /* the same for Int32 index arrays (ExtendableSparseMatrix{Float64,Int32}: extendable.jl:10-25 is generic in Ti; the CSC
- * the library hands back is Int64 all the same).  Both pack (row, col, kind) into 8-byte keys on the host: the batch
- * crosses PCIe as 16 bytes per entry, whatever the index type */
+ * the library hands back is Int64 all the same).  Both pack (row, col, kind) into keys on the host, whatever the index
+ * type: 8-byte keys (16 bytes per entry over PCIe), or -- one kind for the batch (kinds == NULL) and at most 48 row + column
+ * bits -- six-byte keys without the kind (14 bytes per entry), which a small kernel per chunk turns into packed keys on the
+ * device */
 int32_t esp_append_host_i32(esp_handle *h, const int32_t *rows, const int32_t *cols,
                             const double *vals, const uint8_t *kinds, int32_t kind_all, int32_t op,
                             int64_t count);

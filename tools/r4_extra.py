@@ -14,6 +14,7 @@ torch.cuda.init()
 import bench  # noqa: E402
 from esparse_loader import load  # noqa: E402
 
+bench.bind_near_gpu(torch, 0)   # (as bench.py's main does: the process on the GPU's NUMA node)
 esp = load()
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 3
 out = bench.extra_configs(esp, torch, 0, 256, int(os.environ.get("ESP_CFG4_2D", "3163")), int(os.environ.get("ESP_CFG4_3D", "216")), steps=steps)
