@@ -162,6 +162,44 @@ def test_mixed_kinds_and_zeros(esp, orc):
     assert_csc_equal(hip_arrays(A), O.arrays())
 
 
+@pytest.mark.parametrize("keys8", [False, True])
+def test_host_append_key_formats(esp, orc, monkeypatch, keys8):
+    """esp_append_host of ONE kind crosses PCIe with six-byte keys (low 32 bits + next 16, no kind; unpack6_k on the device) when
+    row + column bits fit 48, else -- or with ESP_HOST_KEYS8 -- with packed eight-byte keys: the same CSC, bit for bit the
+    oracle's, for every kind, op '-' (SET is not negated), Int32 index arrays, several chunks' worth of zeros and duplicates."""
+    if keys8:
+        monkeypatch.setenv("ESP_HOST_KEYS8", "1")
+    rng = np.random.default_rng(2024)
+    m, n = 70001, 65537            # (17 + 17 key bits: the high sixteen of a six-byte key are in use)
+    pool = np.array([0.0, -0.0, 2.5, -2.5, 1e-300])
+    for kind in (SET, UPDATE, RAW):
+        for op in ("+", "-"):
+            A = esp.ExtendableSparseMatrix(m, n)
+            O = orc.ExtendableSparseMatrix(m, n)
+            for splice, i32 in enumerate((False, True, False)):
+                cnt = 60000
+                I = rng.integers(1, m + 1, cnt)
+                J = rng.integers(1, n + 1, cnt)
+                J[: cnt // 3] = rng.integers(1, 40, cnt // 3)          # (duplicates: a few dense columns)
+                I[: cnt // 3] = rng.integers(1, 60, cnt // 3)
+                V = np.where(rng.random(cnt) < 0.3, rng.choice(pool, cnt), rng.standard_normal(cnt))
+                if i32:
+                    A.append(kind, I.astype(np.int32), J.astype(np.int32), V, op=op)
+                else:
+                    A.append(kind, I, J, V, op=op)
+                Vo = -V if (op == "-" and kind != SET) else V
+                O.apply(np.full(cnt, kind, np.uint8), I, J, Vo)
+                if splice == 1:
+                    A.flush()
+                    O.flush()
+            assert_csc_equal(hip_arrays(A), O.arrays(), "kind %d op %s keys8 %s" % (kind, op, keys8))
+    # an index outside the matrix: BoundsError, nothing appended (both formats check on the host)
+    B = esp.ExtendableSparseMatrix(100, 100)
+    with pytest.raises(Exception):
+        B.append(UPDATE, np.array([1, 101]), np.array([1, 1]), np.array([1.0, 2.0]))
+    assert B.nnznew() == 0
+
+
 def test_per_entry_calls_equal_batch(esp, orc):
     rng = np.random.default_rng(11)
     m, n = 40, 50
