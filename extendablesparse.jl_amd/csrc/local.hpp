@@ -735,10 +735,12 @@ __device__ __forceinline__ bool reg_tier(const Args &a, u64 *skey, double *sval,
                 fold_run_short_csc<R, UPD, true>(a, skey, sval, x, rs, len, hi, rowmask, ccur, (int)(cend - ccur));
             else if constexpr (!SM)
                 fold_run_short_csc<R, UPD, false>(a, skey, sval, x, rs, len, hi, rowmask, ccur, (int)(cend - ccur));
-            continue;
-        }
+        } else
 #endif
-        fold_run<R, FRESH, UPD>(a, skey, sval, x, rs, len, hi, rowmask, ccur, cend);  // (a FRESH launch has an empty CSC)
+            fold_run<R, FRESH, UPD>(a, skey, sval, x, rs, len, hi, rowmask, ccur, cend);  // (a FRESH launch has an empty CSC)
+        // (over a stored pattern: did the run leave a record?  A segment whose updates all hit stored positions -- a
+        // re-assembly -- emits nothing, and its workgroup leaves right behind the fold: see local_k)
+        if (!FRESH && len > 0 && skey[rs] != NOREC) *s_early = 1u;
     }
     return false;
 }
@@ -1605,6 +1607,7 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     bool done = n == 0;
     bool refill = false;  // the group tier scattered the keys by column and gave up: the radix tier reads them back
     bool dense_done = false;  // the group tier's dense form wrote the segment's records to their dense LDS positions itself
+    bool reg_ran = false;     // the register tier folded the segment (over a stored pattern it notes in s_early whether a record was left)
     bool lb_done = false;  // the look-back was started by the last wave (early publication, see the register tier)
     LbState lbs;
     lb_init(lbs, 0);
@@ -1680,6 +1683,7 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
                 // one lane per column: the whole run in registers, sorting network + ordered fold; the
                 // network is sized to the longest run of the segment (12 covers a 7-point stencil)
                 // (fresh matrix: the tier leaves the records dense)
+                reg_ran = true;
                 if (maxrun <= 12)
                     lb_done = reg_tier<12, FRESH, UPD, SMALL>(a, skey, sval, ccnt, ncl, s, hi, rowmask, &s_early, lbs, &dense_done, lw);
                 else if (!BIG || maxrun <= 16)
@@ -1806,6 +1810,20 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
             }
         }
         __syncthreads();  // records are in place (or: ccnt storage is free for the radix counters)
+        // Over a stored pattern, every update of the segment hit a stored position (a re-assembly: config 3's batch, a time step):
+        // nothing to compact, no offset to resolve, nothing to store -- the segment publishes its zero total and leaves (the last
+        // segment of a look-back group and of the flush resolve their chain as ever: lb_may_skip).
+        if constexpr (!FRESH && !PIECES) {
+            if (reg_ran && !lb_done && a.stop_after == 0 && s_early == 0u && lb_may_skip(a, s)) {
+#ifdef ESP_LOCAL_STAMPS
+                if (!a.stamps)
+#endif
+                {
+                    if (t == 0) __hip_atomic_store(&a.status[s], ST_AGG, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    return;
+                }
+            }
+        }
     }
 
     if constexpr (!SMALL)
