@@ -530,7 +530,7 @@ __device__ __forceinline__ void fold_run_lds(const Args &a, u64 *skey, double *s
 // WHEN the polls happen matters more than how: a round of polls in front of a barrier makes the polling wave -- and the
 // workgroup -- a round trip late (HIP's barrier waits for a wave's outstanding loads): 1.30 -> 1.13 ms for the headline's
 // kernel once the round right after the publication was gone; a round kept in flight ACROSS that barrier (a bare s_barrier for
-// the polling wave), asked for 0.1 / 0.3 us after the publication: 1.27 / 1.21 ms -- polls that come back empty are worse than
+// the polling wave), asked for 0.1 / 0.3 / 0.8 / 1.3 us after the publication: 1.27 / 1.21 / 1.13 / 1.14 ms -- polls that come back empty are worse than
 // polls that are not made; the wave that owns the look-back starts polling behind the fold, when it is needed (a pause of
 // 0.2 / 0.6 us in front of that first round: nothing / slower).
 constexpr int LB_SHIFT = 8;
