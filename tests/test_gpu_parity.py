@@ -75,6 +75,34 @@ def test_golden_fem(esp, dim, npd):
     assert_csc_equal(hip_arrays(A), (fx[tag + "_colptr"], fx[tag + "_rowval"], fx[tag + "_nzval"]), tag)
 
 
+@pytest.mark.parametrize("late", [False, True])
+def test_group3_total_early_or_late(esp, monkeypatch, late):
+    """group3_k publishes a RAWUPDATE segment's total right after the sort (one record per distinct row; the wave that counts
+    its columns last publishes) -- or, ESP_LATE_TOTAL=1, after the fold as before: the same CSC either way (FEM fixtures)."""
+    if late:
+        monkeypatch.setenv("ESP_LATE_TOTAL", "1")
+    fx = gu.load("fem_small")
+    for dim, npd in ((2, 32), (3, 10)):
+        tag = "fem%dd_%d" % (dim, npd)
+        nn = npd ** dim
+        A = esp.ExtendableSparseMatrix(nn, nn)
+        A.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
+        A.flush()
+        assert_csc_equal(hip_arrays(A), (fx[tag + "_colptr"], fx[tag + "_rowval"], fx[tag + "_nzval"]), tag)
+    # a mesh large enough for many segments and look-back groups: device against device (early against late is the point)
+    npd = 700
+    B = esp.ExtendableSparseMatrix(npd * npd, npd * npd)
+    B.generate_fem(2, npd, seed=11, order_mode=1)
+    B.flush()
+    assert B.debug_last_local_small() == 2
+    d = gu.digest(*hip_arrays(B))
+    monkeypatch.delenv("ESP_LATE_TOTAL", raising=False)
+    C2 = esp.ExtendableSparseMatrix(npd * npd, npd * npd)
+    C2.generate_fem(2, npd, seed=11, order_mode=1)
+    C2.flush()
+    assert gu.digest(*hip_arrays(C2)) == d
+
+
 # ------------------------------------------------------------------ reference test-suite, on the device
 def test_updates_nnz_trace(esp):
     """test/test_updates.jl:10-25."""
