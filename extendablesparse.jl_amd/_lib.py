@@ -76,6 +76,8 @@ SIGNATURES = {
     "esp_nnz": (i32, [vp, P(i64)]),
     "esp_get_csc": (i32, [vp, vp, vp, vp]),
     "esp_get_nzval": (i32, [vp, vp]),
+    "esp_set_csc_i32": (i32, [vp, vp, vp, vp, i64]),
+    "esp_get_csc_i32": (i32, [vp, vp, vp, vp]),
     "esp_set_nzval": (i32, [vp, vp]),
     "esp_flush_sum": (i32, [vp, vp, i32, P(i64), P(i32)]),
     "esp_csc_device": (i32, [vp, P(vp), P(vp), P(vp)]),
@@ -115,6 +117,7 @@ SIGNATURES = {
     "esp_debug_group_loopback": (i32, [vp, i32, P(i64)]),
     "esp_timing_enable": (i32, [vp, i32]),
     "esp_timing": (i32, [vp, P(esp_timing_t), i32]),
+    "esp_debug_plan_cap": (i32, [vp, C.c_double]),
     "esp_debug_force_path": (i32, [vp, i32]),
     "esp_debug_last_run_order": (i32, [vp, P(i32)]),
     "esp_debug_last_colptr_direct": (i32, [vp, P(i32)]),

@@ -46,6 +46,16 @@ __host__ __device__ inline double esp_uniform(u64 seed, u64 counter) {
 #define ESP_GOLDEN 0x9E3779B97F4A7C15ull
 __host__ __device__ inline double esp_uniform_z(u64 z) { return (double)(esp_mix64(z) >> 11) * 0x1.0p-53; }
 
+// Environment switches of the measurement tools (tools/*.sh: ablation stops, phase stamps, traces, plan fill).  They exist in a
+// build with -DESP_EXPERIMENTS only (ESP_EXTRA_FLAGS=-DESP_EXPERIMENTS python extendablesparse.jl_amd/build.py); the product
+// library never reads them: nothing in a caller's environment changes what a flush does.
+#ifdef ESP_EXPERIMENTS
+#include <stdlib.h>
+static inline const char *esp_exp_env(const char *name) { return getenv(name); }
+#else
+static inline const char *esp_exp_env(const char *) { return nullptr; }
+#endif
+
 static inline int bits_for(i64 extent) {  // bits needed for 0..extent-1, at least 1
     int b = 1;
     while (b < 62 && ((i64)1 << b) < extent) b++;

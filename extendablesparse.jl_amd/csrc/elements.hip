@@ -47,9 +47,9 @@ int32_t elements_by_items(esp_handle *h, espelem::Args a, i64 E, bool *took) {
     a.dup = d_dup;
     a.ikeys = (u64 *)h->keys2.p;
     // cells of 3 or 4 nodes: a 64-byte record per cell (rows as u32, diag values) in the value half of the scratch pair,
-    // which the keys-only passes never touch (ESP_ELEM_NO_CELLREC: experiments)
+    // which the keys-only passes never touch (force_path 37: test hook, never -- the expansion gathers from the caller's arrays)
     const bool cellrec = (a.nloc == 3 || a.nloc == 4) && h->m <= ((i64)1 << 32) && (size_t)a.ncells * 64 <= h->vals2.bytes &&
-                         !(getenv("ESP_ELEM_NO_CELLREC") && *getenv("ESP_ELEM_NO_CELLREC"));
+                         h->force_path != ESP_PATH_NO_CELL_RECORDS;
     a.cellrec = cellrec ? (char *)h->vals2.p : nullptr;
     const int Kv = bits_for(std::max<i64>(h->n, 1)) + vrb;  // bits of the records' virtual key window (n << vrb keys)
     const u64 vspan = (u64)std::max<i64>(h->n, 1) << vrb;
@@ -326,6 +326,10 @@ extern "C" int32_t esp_append_elements(esp_handle *h, int32_t nloc, int64_t ncel
     if (kind < 0 || kind > 3) FAIL(h, ESP_ERR_INVALID, "append: kind %d invalid", kind);
     if (op != ESP_OP_ADD && op != ESP_OP_SUB) FAIL(h, ESP_ERR_UNSUPPORTED, "append: op %d not supported on the device path", op);
     if (ncells == 0) return ESP_OK;
+    // any new element-level append supersedes the kept plan: only a call that takes the item partition below makes one again
+    // (a call that leaves early -- non-empty buffer, column window, a repeated node, ESP_ERR_BOUNDS -- must not leave the plan of
+    // an EARLIER mesh behind for esp_append_elements_again)
+    h->elemplan.valid = false;
     (void)hipSetDevice(h->device);
     espelem::Args a;
     memset(&a, 0, sizeof a);

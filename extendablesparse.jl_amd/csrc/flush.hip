@@ -2,7 +2,6 @@
 #include "internal.hpp"
 
 bool esplocal::launch(const Variant &v, unsigned grid, hipStream_t stream, const Args &a) {
-    if (v.wave) return launch_wave(v, grid, stream, a);
     if (v.g3) return launch_group3(v, grid, stream, a);
     if (v.grp) return v.shortg ? launch_group_short(v, grid, stream, a) : launch_group(v, grid, stream, a);
     if (v.pieces) return v.small_variant ? launch_pieces_small(v, grid, stream, a) : v.fresh ? launch_pieces_fresh(v, grid, stream, a) : launch_pieces_stored(v, grid, stream, a);
@@ -161,7 +160,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
     HIPCK(h, hipMemsetAsync(status, 0, status_bytes, h->stream));
     CK(ensure(h, h->colend, sizeof(u64) * (size_t)(N1 + espscan::workspace_elems(N1))));
     esplocal::Args a;
-    const char *stop_env = getenv("ESP_LOCAL_STOP");
+    const char *stop_env = esp_exp_env("ESP_LOCAL_STOP");  // (experiments build only: ablation of the bucket kernel)
     // A fresh matrix whose segments are whole blocks of <= CL_MAX columns that start at the first column of the
     // range this flush can touch (all columns, or the column window of a shard) and cover it: every segment writes
     // the colptr of its own columns (no column-end marks, no memset and no scan over the columns).
@@ -206,25 +205,6 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
                         h->force_path != ESP_PATH_NO_SMALL_VARIANT && !stop_env;
     }
     h->last_local_small = small_variant ? 1 : 0;
-    // The wave-per-segment kernel (wavecols.hpp): a fresh matrix, 4-byte keys of one adding kind, segments of at most 64 whole
-    // columns and 1024 entries (the producers' plans cut them so: wave_wanted / plan_wave_bits) that write colptr themselves,
-    // column runs of at most 16 entries.  A segment it refuses makes the flush run again with the kernels below.
-    // Any forced path, ESP_NO_WAVE: never.
-    bool use_wave = false;
-    int wave_ni = 16, wave_segs = 16;
-    {
-        const int clb = st.rem_bits - h->L.rb;
-        const double per_col = (double)h->count / (double)std::max<i64>(col_end - col_begin, 1);
-        const bool runs_fit = (getenv("ESP_WAVE") && atoi(getenv("ESP_WAVE")) >= 2) || (h->seen_maxrun > 0 ? h->seen_maxrun <= 16 : per_col <= 16.0);
-        use_wave = direct && Z0 == 0 && st.npieces == 0 && st.seg_start && st.key_bytes == 4 && (st.kind == ESP_UPDATE || st.kind == ESP_RAWUPDATE) &&
-                   clb >= 0 && clb <= esplocal::WAVE_CL_BITS && st.rem_bits <= 32 && st.maxlen <= (i64)esplocal::WAVE_CAP && runs_fit && !h->wave_off &&
-                   h->force_path == ESP_PATH_AUTO && !stop_env && !getenv("ESP_LOCAL_STAMPS") && getenv("ESP_WAVE") && !getenv("ESP_NO_WAVE") &&
-                   ceil_div<i64>(S, wave_segs) <= esplocal::MAX_GRID;
-        wave_ni = st.maxlen <= 768 ? 12 : 16;
-        wave_segs = wave_ni == 12 ? 16 : 12;  // (one workgroup per CU: 160 KiB of LDS at 9.4 / 12.4 KiB per wave)
-        if (const char *e = getenv("ESP_WAVE_SEGS")) wave_segs = atoi(e) == 8 ? 8 : atoi(e) == 4 ? 4 : wave_segs;  // (experiments)
-    }
-    h->last_wave = 0;
     std::function<int32_t(bool)> launch_all;
     bool used_g3 = false;
     bool want_wide = h->g3_wide && h->force_path != ESP_PATH_NO_WIDE_GROUP3;
@@ -235,7 +215,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         a.k32_lo = st.p32_lo;
         h->last_key_bytes = (st.p32_piece >= 0 || st.all32) ? 4 : st.key_bytes;
         a.colptr_out = direct ? (i64 *)h->colptr.p : nullptr;
-        a.late_total = getenv("ESP_LATE_TOTAL") ? 1 : 0;
+        a.late_total = h->force_path == ESP_PATH_LATE_TOTAL ? 1 : 0;  // 36: test hook, group3_k publishes a segment's total after the fold
         a.no_group = h->force_path == ESP_PATH_NO_GROUP_TIER ? 1 : 0;  // 24: test hook, long column runs through the radix tier
         // (every pending entry was noted with one kind; pieces of other ranks carry kinds this handle has not seen)
         a.kind_all = (st.npieces == 0 && h->kind_uniform >= 0 && h->kind_noted == h->count && h->force_path != ESP_PATH_GENERIC_FOLD) ? h->kind_uniform : -1;
@@ -274,7 +254,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
             a.stop_after = stop_env ? atoi(stop_env) : 0;
             a.stamps = nullptr;
             a.hits_out = nullptr;
-            if (getenv("ESP_LOCAL_STAMPS")) {  // diagnostics: per-segment phase stamps, dumped to a file
+            if (esp_exp_env("ESP_LOCAL_STAMPS")) {  // diagnostics (experiments build): per-segment phase stamps, dumped to a file
                 CK(ensure(h, h->heads, sizeof(u64) * (size_t)S * 16));
                 HIPCK(h, hipMemsetAsync(h->heads.p, 0, sizeof(u64) * (size_t)S * 16, h->stream));
                 a.stamps = (unsigned long long *)h->heads.p;
@@ -283,16 +263,6 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         const i64 max_grid = h->force_path == ESP_PATH_MANY_LAUNCHES ? 64 : esplocal::MAX_GRID;  // 4: test hook, many launches
         launch_all = [&, max_grid](bool allow_g3) -> int32_t {
         used_g3 = false;
-        if (use_wave) {  // (one launch: a workgroup per four segments)
-            a.first = 0;
-            esplocal::Variant var{true, false, false, false, st.kind == ESP_UPDATE ? 2 : 1};
-            var.wave = true;
-            var.wave_ni = wave_ni;
-            var.wave_segs = wave_segs;
-            h->last_fold_update = 1;
-            if (!esplocal::launch(var, (unsigned)ceil_div<i64>(S, wave_segs), h->stream, a)) FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (no wave kernel for this flush)");
-            return ESP_OK;
-        }
         for (i64 first = 0; first < S; first += max_grid) {
             const unsigned grid = (unsigned)std::min<i64>(max_grid, S - first);
             a.first = first;
@@ -324,12 +294,6 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
                      a.cl_bits + a.rb <= 32 && a.rb <= 30 && longest <= 128.0 && !h->g3_off && !a.no_group && !a.stop_after &&
                      h->force_path != ESP_PATH_NO_GROUP3;
             var.g3wide = var.g3 && want_wide;
-            if (getenv("ESP_G3_SMALL") && allow_g3 && Z0 == 0 && keys == 2 && st.npieces == 0 && st.maxlen <= 6 * esplocal::THREADS && a.cl_bits >= 0 &&
-                a.cl_bits <= esplocal::G3_CL_BITS && a.cl_bits + a.rb <= 32 && !h->g3_off && !a.stop_after) {  // (experiment)
-                var.g3 = var.grp = var.g3small = true;
-                var.small_variant = false;
-                var.g3wide = false;
-            }
             used_g3 = used_g3 || var.g3;
             if (!esplocal::launch(var, grid, h->stream, a)) FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (no bucket kernel for this flush)");
         }
@@ -337,10 +301,6 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         };
     }
     auto read_back = [&]() -> int32_t {
-        if (use_wave) {  // (its granules are per workgroup: the last one holds the total)
-            HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (ceil_div<i64>(S, wave_segs) - 1), 8, hipMemcpyDeviceToHost, h->stream));
-            HIPCK(h, hipMemcpyAsync(h->pin_scalar + 1, status + S, 16, hipMemcpyDeviceToHost, h->stream));
-        } else
         HIPCK(h, hipMemcpyAsync(h->pin_scalar, status + (S - 1), 24, hipMemcpyDeviceToHost, h->stream));  // last granule | ticket, err | maxrun
         HIPCK(h, hipMemcpyAsync(h->pin_scalar + 3, (u32 *)h->misc.p + 60, 4, hipMemcpyDeviceToHost, h->stream));
         HIPCK(h, hipStreamSynchronize(h->stream));
@@ -384,7 +344,9 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
             }
             CK(read_back());
             const u32 e = (u32)(h->pin_scalar[1] >> 32);
-            if ((e & (8u | 64u)) == 0u) {
+            // (accepted only when NOTHING objected: no refused segment (8), no column that is not the stored one (64), no look-back
+            // error (1 / 2 / 4), no entry outside a declared window -- anything else falls through to the general kernels' checks)
+            if ((e & (1u | 2u | 4u | 8u | 64u)) == 0u && (u32)h->pin_scalar[3] == 0u) {
                 std::swap(h->nzval, h->nzval2);
                 h->last_group3 = want_wide ? 4 : 3;
                 h->seen_maxrun = (int)(u32)(h->pin_scalar[2] & 0xFFFFFFFFull);
@@ -408,24 +370,6 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         sp.add(1);
     }
     CK(read_back());
-    if (use_wave) {
-        if ((u32)(h->pin_scalar[1] >> 32) & 8u) {
-            // a segment the wave kernel does not take (a column run above 16, rows further apart than 2^22): nothing of a
-            // fresh-matrix flush has taken effect -- once more with the kernels for whole workgroups, which take the finer
-            // segments as well; the handle's next batches are planned for them
-            h->wave_off = true;
-            use_wave = false;
-            CK(reset_launch_state());
-            {
-                Span sp(h, ESP_ST_LOCAL);
-                CK(launch_all(true));
-                sp.add(1);
-            }
-            CK(read_back());
-        } else {
-            h->last_wave = 1;
-        }
-    }
     if (used_g3 && !want_wide && h->force_path != ESP_PATH_NO_WIDE_GROUP3) {
         const u32 e = (u32)(h->pin_scalar[1] >> 32);
         if ((e & 8u) && (e & 16u) && !(e & 32u)) {
@@ -469,7 +413,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
     if (a.stamps) {
         std::vector<u64> st((size_t)S * 16);
         HIPCK(h, hipMemcpy(st.data(), a.stamps, sizeof(u64) * st.size(), hipMemcpyDeviceToHost));
-        if (FILE *f = fopen(getenv("ESP_LOCAL_STAMPS"), "wb")) {
+        if (FILE *f = fopen(esp_exp_env("ESP_LOCAL_STAMPS"), "wb")) {
             fwrite(st.data(), sizeof(u64), st.size(), f);
             fclose(f);
         }

@@ -499,6 +499,15 @@ bool numa_cpus_of_current_thread(cpu_set_t *out) {
     }
     return found && nodes > 1;
 }
+// ESP_HOST_THREADS = the host threads esp_append_host / esp_get_csc may use beside the caller's (documented in the header: the
+// one environment setting of the product path besides ESP_RCCL_LIB; read once)
+static int host_threads_env() {
+    static const int v = [] {
+        const char *e = getenv("ESP_HOST_THREADS");
+        return e ? std::max(1, atoi(e)) : 0;
+    }();
+    return v;
+}
 struct HostPool {
     std::mutex m, busy;
     std::condition_variable cv_go, cv_done;
@@ -511,7 +520,7 @@ struct HostPool {
     void start() {
         const unsigned hw = std::thread::hardware_concurrency();
         unsigned want = 8u;  // (measured on the 2-socket EPYC of the GPU box: 4 and 8 threads pack at the rate PCIe takes, 16 are slower)
-        if (const char *e = getenv("ESP_HOST_THREADS")) want = (unsigned)std::max(1, atoi(e));  // (experiments)
+        if (host_threads_env() > 0) want = (unsigned)host_threads_env();
         const int n = (int)std::max(1u, std::min(want, hw > 2 ? hw - 1 : 1u)) - 1 > 0 ? (int)std::max(1u, std::min(want, hw > 2 ? hw - 1 : 1u)) - 1 : 1;  // (the caller works too)
         // the pool stays on the NUMA node of the thread that first needs it: the caller's arrays were most likely touched
         // there (first touch), and a two-socket host moves remote pages at a fraction of the local rate (append of the 256^3
@@ -581,10 +590,7 @@ HostPool &host_pool() {
 // [0, count) cut into parts of at least min_part elements, at most `cap` parts
 template <typename F>
 void host_parallel(size_t count, size_t min_part, int cap, F body) {
-    static const int env_cap = [] {
-        const char *e = getenv("ESP_HOST_THREADS");
-        return e ? std::max(1, atoi(e)) + 1 : 1 << 20;
-    }();
+    static const int env_cap = host_threads_env() > 0 ? host_threads_env() + 1 : 1 << 20;
     cap = std::min(cap, env_cap);
     const int parts = (int)std::max<size_t>(1, std::min<size_t>((size_t)cap, count / std::max<size_t>(min_part, 1)));
     const size_t part = (count + (size_t)parts - 1) / (size_t)parts;
@@ -722,7 +728,7 @@ static int32_t append_host_t(esp_handle *h, const TI *rows, const TI *cols, cons
     CK(ensure_stage(h, sa, 2 * chunk));  // (its `rows` half holds packed keys here, `vals` the values)
     // one kind for the batch and at most 48 key bits: six-byte keys over PCIe (the low 32 bits in the `rows` area, the next 16 in the
     // `cols` area; two halves of device staging in the area's device mirrors); ESP_HOST_KEYS8: never
-    const bool six = !kinds && h->L.rb + h->L.cb <= 48 && !getenv("ESP_HOST_KEYS8");
+    const bool six = !kinds && h->L.rb + h->L.cb <= 48 && h->force_path != ESP_PATH_HOST_KEYS8;  // (38: test hook, packed eight-byte keys)
     if (six) {
         CK(ensure(h, sa.d_rows, sizeof(uint32_t) * (size_t)(2 * chunk)));
         CK(ensure(h, sa.d_cols, sizeof(uint16_t) * (size_t)(2 * chunk)));
@@ -733,7 +739,7 @@ static int32_t append_host_t(esp_handle *h, const TI *rows, const TI *cols, cons
     std::atomic<i64> bad(-1);
     int32_t rc = ESP_OK;
     i64 it = 0;
-    const bool trace = getenv("ESP_HOST_TRACE") != nullptr;
+    const bool trace = esp_exp_env("ESP_HOST_TRACE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t_wait = 0.0, t_pack = 0.0;
     const double t_begin = now();
@@ -1003,7 +1009,7 @@ extern "C" int32_t esp_get_csc(esp_handle *h, int64_t *colptr, int64_t *rowval, 
     if (h->nnz > 0 && (!rowval || !nzval)) FAIL(h, ESP_ERR_INVALID, "esp_get_csc: rowval/nzval NULL with nnz>0");
     Span sp(h, ESP_ST_COPY);
     // (large matrices whose indices fit 32 bits: colptr and rowval cross PCIe as u32 -- 12 instead of 16 bytes per entry)
-    const bool narrow = h->nnz >= ((i64)1 << 20) && h->m < ((i64)1 << 32) && h->nnz + 1 < ((i64)1 << 32) && !getenv("ESP_NO_NARROW_D2H");
+    const bool narrow = h->nnz >= ((i64)1 << 20) && h->m < ((i64)1 << 32) && h->nnz + 1 < ((i64)1 << 32);
     if (narrow) {
         CK(d2h_narrow(h, colptr, (const i64 *)h->colptr.p, h->n + 1, h->heads));
         CK(d2h_narrow(h, rowval, (const i64 *)h->rowval.p, h->nnz, h->heads));
@@ -1013,6 +1019,64 @@ extern "C" int32_t esp_get_csc(esp_handle *h, int64_t *colptr, int64_t *rowval, 
     }
     if (h->nnz > 0) CK(d2h_pipelined(h, nzval, h->nzval.p, sizeof(double) * (size_t)h->nnz));
     sp.add(3);
+    return ESP_OK;
+}
+
+// The Int32 forms of the CSC transfers (ExtendableSparseMatrix{Float64,Int32}: extendable.jl:10-25 is generic in Ti).  The device
+// CSC stays Int64; the index arrays are narrowed / widened by a small kernel beside the transfer, so they cross PCIe as 4 bytes.
+static __global__ void widen_i32_k(const int32_t *__restrict__ in, i64 n, i64 *__restrict__ out) {
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < n) out[g] = (i64)in[g];
+}
+extern "C" int32_t esp_get_csc_i32(esp_handle *h, int32_t *colptr, int32_t *rowval, double *nzval) {
+    if (!h || !colptr) return ESP_ERR_INVALID;
+    (void)hipSetDevice(h->device);
+    CK(fix_tail(h));
+    if (h->nnz > 0 && (!rowval || !nzval)) FAIL(h, ESP_ERR_INVALID, "esp_get_csc_i32: rowval/nzval NULL with nnz>0");
+    if (h->m > (i64)INT32_MAX || h->nnz + 1 > (i64)INT32_MAX)
+        FAIL(h, ESP_ERR_UNSUPPORTED, "esp_get_csc_i32: %lld rows / %lld entries do not fit Int32 indices", (long long)h->m, (long long)h->nnz);
+    Span sp(h, ESP_ST_COPY);
+    const i64 counts[2] = {h->n + 1, h->nnz};
+    const i64 *src[2] = {(const i64 *)h->colptr.p, (const i64 *)h->rowval.p};
+    int32_t *dst[2] = {colptr, rowval};
+    for (int a = 0; a < 2; a++) {
+        if (counts[a] == 0) continue;
+        CK(ensure(h, h->heads, sizeof(u32) * (size_t)counts[a]));
+        hipLaunchKernelGGL(narrow_i64_k, dim3(grid_for(counts[a], 256)), dim3(256), 0, h->stream, src[a], counts[a], (u32 *)h->heads.p);
+        HIPCK(h, hipGetLastError());
+        CK(d2h_pipelined(h, dst[a], h->heads.p, sizeof(u32) * (size_t)counts[a]));
+    }
+    if (h->nnz > 0) CK(d2h_pipelined(h, nzval, h->nzval.p, sizeof(double) * (size_t)h->nnz));
+    sp.add(3);
+    return ESP_OK;
+}
+extern "C" int32_t esp_set_csc_i32(esp_handle *h, const int32_t *colptr, const int32_t *rowval, const double *nzval, int64_t nnz) {
+    if (!h || !colptr || nnz < 0 || (nnz > 0 && (!rowval || !nzval))) return ESP_ERR_INVALID;
+    if (colptr[0] != 1 || (i64)colptr[h->n] != nnz + 1) FAIL(h, ESP_ERR_INVALID, "esp_set_csc_i32: colptr[1]=%d colptr[n+1]=%d nnz=%lld violate the CSC invariants", colptr[0], colptr[h->n], (long long)nnz);
+    (void)hipSetDevice(h->device);
+    CK(ensure(h, h->colptr, sizeof(i64) * (size_t)(h->n + 1)));
+    CK(ensure(h, h->rowval, sizeof(i64) * (size_t)std::max<i64>(nnz, 1)));
+    CK(ensure(h, h->nzval, sizeof(double) * (size_t)std::max<i64>(nnz, 1)));
+    CK(ensure(h, h->heads, sizeof(int32_t) * (size_t)std::max<i64>(std::max<i64>(nnz, h->n + 1), 1)));
+    Span sp(h, ESP_ST_COPY);
+    const i64 counts[2] = {h->n + 1, nnz};
+    const int32_t *src[2] = {colptr, rowval};
+    i64 *dst[2] = {(i64 *)h->colptr.p, (i64 *)h->rowval.p};
+    for (int a = 0; a < 2; a++) {
+        if (counts[a] == 0) continue;
+        HIPCK(h, hipMemcpyAsync(h->heads.p, src[a], sizeof(int32_t) * (size_t)counts[a], hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(widen_i32_k, dim3(grid_for(counts[a], 256)), dim3(256), 0, h->stream, (const int32_t *)h->heads.p, counts[a], dst[a]);
+        HIPCK(h, hipGetLastError());
+    }
+    if (nnz > 0) HIPCK(h, hipMemcpyAsync(h->nzval.p, nzval, sizeof(double) * (size_t)nnz, hipMemcpyHostToDevice, h->stream));
+    sp.add(3);
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    h->nnz = nnz;
+    h->pattern_version++, h->values_version++;
+    h->csc_valid = true;
+    h->win_excl = false;
+    h->tail_stale = false;
+    h->ones_pending = false;
     return ESP_OK;
 }
 
@@ -1064,6 +1128,11 @@ extern "C" int32_t esp_zero_values(esp_handle *h) {
 extern "C" int32_t esp_debug_force_path(esp_handle *h, int32_t path) {
     if (!h) return ESP_ERR_INVALID;
     h->force_path = path;
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_plan_cap(esp_handle *h, double cap) {
+    if (!h) return ESP_ERR_INVALID;
+    h->debug_plan_cap = cap > 0.0 ? cap : 0.0;
     return ESP_OK;
 }
 extern "C" int32_t esp_debug_last_run_order(const esp_handle *h, int32_t *kind) {

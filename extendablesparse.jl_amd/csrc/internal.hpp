@@ -62,8 +62,7 @@ struct esp_handle {
     bool g3_off = false;                  // a segment of this handle's matrix did not fit the three-workgroup group kernel: not tried again
     bool hits_off = false;                // the re-assembly form of the group kernel met a batch that was no re-assembly of the stored pattern: not tried again (until reset!)
     bool g3_wide = false;                 // ... for its rows alone (spread over more than 2^18): the kernel's wide form serves this handle
-    bool wave_off = false;                // a segment did not fit the wave-per-segment kernel (wavecols.hpp: a column run above 16, rows too far apart): not planned for again (until reset!)
-    int last_wave = 0;                    // the last flush's bucket kernel was wave_k (esp_debug_last_local_small reports 6)
+    double debug_plan_cap = 0.0;          // esp_debug_plan_cap: plan as if the bucket kernel took segments of this many entries (test hook)
     int last_group3 = 0;                  // the last flush's bucket kernel was group3_k (esp_debug_last_local_small reports 2)
     bool seen_hits = true;                // the last flush over a stored pattern mostly hit stored positions (re-assembly)
     int seen_maxrun = 0;                  // longest column run the bucket kernel met in the last flush
@@ -391,8 +390,6 @@ int32_t chunk_arrays(esp_handle *h, i64 Ccap, int pb, ChunkArrays *out, bool kee
 double plan_entries(i64 E, int K, u64 span);
 int plan_run_bits(i64 E, int K, u64 span);
 int plan_prefix_bits(const esp_handle *h, i64 E, int K, double *Ee_out);
-bool wave_wanted(const esp_handle *h, int kind, i64 E);
-int plan_wave_bits(esp_handle *h, i64 E, int K, double *Ee_out);
 int plan_local_bits(esp_handle *h, i64 NI, int W, int K, int *sort_bits);
 int window_bits(const esp_handle *h);
 int32_t aux_ready(esp_handle *h);
@@ -479,7 +476,7 @@ static inline void col_range(const esp_handle *h, i64 *c0, i64 *cnt) {
 // planned average fill of a segment (fraction of the bucket kernel's capacity); ESP_PLAN_FILL overrides (experiments)
 static double plan_fill() {
     static const double f = [] {
-        const char *e = getenv("ESP_PLAN_FILL");
+        const char *e = esp_exp_env("ESP_PLAN_FILL");
         const double v = e ? atof(e) : 0.9;
         return v > 0.1 && v <= 1.0 ? v : 0.9;
     }();

@@ -89,10 +89,6 @@ struct Variant {
     bool g3 = false;      // ... the group tier as a kernel of its own with three workgroups per CU (group3.hpp)
     bool g3hits = false;  // ... its re-assembly form: additions over a stored pattern the same mesh built (all-or-nothing, see group_columns)
     bool g3wide = false;  // ... its form for segments whose rows spread over more than 2^18 (two sorts per run, two workgroups per CU)
-    bool g3small = false; // (experiment) group3_k for segments of at most 3072 entries: four workgroups per CU
-    bool wave = false;    // one wave per segment of at most 64 columns (wavecols.hpp): short columns on a fresh matrix, 4-byte keys
-    int wave_ni = 16;     // ... entries per lane the instantiation holds (12: segments of at most 768 entries, 16: 1024)
-    int wave_segs = 4;    // ... segments (= waves) per workgroup and ticket
 };
 // enqueues the kernel; false when the combination has no instantiation
 bool launch(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);
@@ -104,10 +100,6 @@ bool launch_pieces_small(const Variant &v, unsigned grid, hipStream_t stream, co
 bool launch_group(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);          // local_f.hip
 bool launch_group_short(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);    // local_g.hip
 bool launch_group3(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);         // local_h.hip
-bool launch_wave(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);           // local_i.hip
-// the wave-per-segment kernel's limits, for the plans that cut segments for it (wavecols.hpp)
-constexpr int WAVE_CL_BITS = 6;     // at most 64 whole columns per segment
-constexpr int WAVE_CAP = 1024;      // ... and 1024 entries
 
 
 }  // namespace esplocal

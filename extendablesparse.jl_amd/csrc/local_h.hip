@@ -26,10 +26,6 @@ bool launch_group3(const Variant &v, unsigned grid, hipStream_t stream, const Ar
             return false;
         return true;
     }
-    if (v.g3small && v.keys == 2) {  // (experiment: 3072-entry segments, four workgroups per CU)
-        hipLaunchKernelGGL((group3_k<2, 6>), dim3(grid), dim3(THREADS), 0, stream, a);
-        return true;
-    }
     if (v.keys == 1) {
         hipLaunchKernelGGL((group3_k<1>), dim3(grid), dim3(THREADS), 0, stream, a);
         return true;

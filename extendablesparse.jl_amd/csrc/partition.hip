@@ -144,7 +144,7 @@ int plan_prefix_bits(const esp_handle *h, i64 E, int K, double *Ee_out) {
         double target = plan_fill() * (double)seg_cap(h);
         // (test hook: plan as if the bucket kernel took segments of this many entries -- many prefix bits, i.e. the 9-bit
         // passes, at sizes a CPU oracle can follow)
-        if (const char *e = getenv("ESP_DEBUG_PLAN_CAP")) target = std::min(target, std::max(8.0, atof(e)));
+        if (h->debug_plan_cap > 0.0) target = std::min(target, std::max(8.0, h->debug_plan_cap));  // (esp_debug_plan_cap)
         while (planned < K && Ee / (double)((i64)1 << planned) > target) planned++;
     }
     if (planned > 0 && h->seen_spread > 0.0 && h->seen_spread < 2.0 &&
@@ -159,29 +159,6 @@ int plan_prefix_bits(const esp_handle *h, i64 E, int K, double *Ee_out) {
     *Ee_out = Ee;
     return planned;
 }
-// The wave-per-segment bucket kernel (wavecols.hpp) serves short columns on a fresh matrix: would a batch of E entries of
-// this kind, appended to the EMPTY buffer now, be flushed by it?  (What is known at append time; the flush checks the rest --
-// 4-byte keys, the longest segment -- and falls back to local_k's variants, which take the finer segments as well.)
-// force_path 35 (and every other forced path): never.
-bool wave_wanted(const esp_handle *h, int kind, i64 E) {
-    if (h->force_path != ESP_PATH_AUTO || h->wave_off || h->nnz != 0 || windowed(h) || h->shard_user || h->item_mode) return false;
-    if (kind != ESP_UPDATE && kind != ESP_RAWUPDATE) return false;
-    if (!getenv("ESP_WAVE") || getenv("ESP_NO_WAVE")) return false;  // (opt-in while it does not beat local_k end to end: see wavecols.hpp)
-    if (atoi(getenv("ESP_WAVE")) >= 2) return true;  // (test hook: whatever the columns hold -- a segment with a longer run sends the flush back to local_k)
-    const double per_col = (double)E / (double)std::max<i64>(h->n, 1);
-    return h->seen_maxrun > 0 ? h->seen_maxrun <= 16 : per_col <= 16.0;
-}
-// ... then the prefix bits of its plan: segments of at most WAVE_CAP entries (planned fill as everywhere) AND at most 64 whole
-// columns; 0: no such plan (the row bits would be cut, or more than 20 bits: the run-based pass resolves no more)
-int plan_wave_bits(esp_handle *h, i64 E, int K, double *Ee_out) {
-    const i64 cap0 = h->plan_cap;
-    h->plan_cap = (i64)esplocal::WAVE_CAP;
-    int pb = plan_prefix_bits(h, E, K, Ee_out);
-    h->plan_cap = cap0;
-    pb = std::max(pb, K - h->L.rb - esplocal::WAVE_CL_BITS);
-    if (pb <= 8 || pb > 20 || K - pb < h->L.rb || K - pb > 32) return 0;
-    return pb;
-}
 // An item partition of NI records (W updates each) whose expansion resolves the last bits itself (segexpand.hpp): the
 // number of those bits (0: not worth it / not possible) and, in *sort_bits, what the passes in front of it resolve.
 // The final prefix is what the classic plan gives for segments of CAP / W items; the passes stop up to three bits
@@ -191,7 +168,7 @@ int plan_local_bits(esp_handle *h, i64 NI, int W, int K, int *sort_bits) {
     // (measured at config 4's sizes, round 4: the pass it saves is worth 1.3 ms at 3-D, the ordering step and the per-segment
     // rounds cost the expansion 1.6 -- 18.3 against 17.7 ms, elements 24.7 against 23.9, 2-D 5.2 against 4.7: it stays a test
     // hook, esp_debug_force_path(ESP_PATH_LOCAL_BITS), until a mesh shape shows up where the last pass resolves a single bit)
-    if (h->force_path != ESP_PATH_LOCAL_BITS && !getenv("ESP_LOCAL_BITS")) return 0;
+    if (h->force_path != ESP_PATH_LOCAL_BITS) return 0;
     const i64 cap0 = h->plan_cap;
     h->plan_cap = (i64)esplocal::CAP / W;
     double Ee = 0.0;

@@ -209,8 +209,7 @@ int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSetup *ps)
         HIPCK(h, hipEventRecord(h->pin_mw_done, h->stream));
     } else {
         K = window_bits(h);
-        pb = wave_wanted(h, kind, E) ? plan_wave_bits(h, E, K, &Ee) : 0;  // (segments of at most 64 columns for the wave-per-segment kernel)
-        if (pb == 0) pb = plan_prefix_bits(h, E, K, &Ee);
+        pb = plan_prefix_bits(h, E, K, &Ee);
         shift = K - pb;
         if (pb <= 8 || pb > 20 || shift < h->L.rb || shift > esplocal::MAX_REM_BITS) return ESP_OK;
         NB = (i64)1 << pb;

@@ -289,7 +289,7 @@ extern "C" int32_t esp_shard_plan(esp_handle *h, int32_t nshards, int32_t self, 
 }
 extern "C" int32_t esp_debug_last_local_small(const esp_handle *h, int32_t *small) {
     if (!h || !small) return ESP_ERR_INVALID;
-    *small = h->last_wave ? 6 : h->last_group3 == 4 ? 5 : h->last_group3 == 3 ? 4 : h->last_group3 == 2 ? 3 : h->last_group3 ? 2 : h->last_local_small;
+    *small = h->last_group3 == 4 ? 5 : h->last_group3 == 3 ? 4 : h->last_group3 == 2 ? 3 : h->last_group3 ? 2 : h->last_local_small;
     return ESP_OK;
 }
 extern "C" int32_t esp_debug_last_shard_source(const esp_handle *h, int32_t *kind) {

@@ -48,65 +48,76 @@ extern "C" int32_t esp_flush_sum(esp_handle *dst, esp_handle *const *xs, int32_t
         if (new_nnz) *new_nnz = dst->nnz;
         return ESP_OK;
     }
-    const bool trace = getenv("ESP_SUM_TRACE") != nullptr;
+    const bool trace = esp_exp_env("ESP_SUM_TRACE") != nullptr;
     auto now = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t_a = now();
-    // 1. every buffer's own fold: the buffers are independent handles with streams of their own, so their flushes -- a
-    // few dozen small launches and three or four host round trips each -- run side by side, one host thread per buffer
-    // (as the reference's partitions are assembled by one task each: test/femtools.jl:88-110)
+    double t_b = t_a, t_c = t_a;
     i64 folded = 0;
-    {
-        std::vector<int32_t> rcs((size_t)p, ESP_OK);
-        std::vector<int64_t> zs((size_t)p, 0);
-        const int WIDTH = 16;  // host threads at a time
-        for (int k0 = 0; k0 < p; k0 += WIDTH) {
-            std::vector<std::thread> th;
-            for (int k = k0; k < std::min(p, k0 + WIDTH); k++) {
-                if (xs[k]->count == 0) continue;
-                th.emplace_back([&, k] { rcs[(size_t)k] = esp_flush(xs[k], ESP_FLUSH_ROUTED, &zs[(size_t)k], nullptr); });
+    // Steps 1 - 3; every exit goes through the cleanup below: the call is all-or-nothing for dst (a failure leaves its stored
+    // matrix as it was and nothing pending) and the buffers come back EMPTY whatever happened.
+    auto run = [&]() -> int32_t {
+        // 1. every buffer's own fold: the buffers are independent handles with streams of their own, so their flushes -- a
+        // few dozen small launches and three or four host round trips each -- run side by side, one host thread per buffer
+        // (as the reference's partitions are assembled by one task each: test/femtools.jl:88-110)
+        {
+            std::vector<int32_t> rcs((size_t)p, ESP_OK);
+            std::vector<int64_t> zs((size_t)p, 0);
+            const int WIDTH = 16;  // host threads at a time
+            for (int k0 = 0; k0 < p; k0 += WIDTH) {
+                std::vector<std::thread> th;
+                for (int k = k0; k < std::min(p, k0 + WIDTH); k++) {
+                    if (xs[k]->count == 0) continue;
+                    th.emplace_back([&, k] { rcs[(size_t)k] = esp_flush(xs[k], ESP_FLUSH_ROUTED, &zs[(size_t)k], nullptr); });
+                }
+                for (auto &t : th) t.join();
             }
-            for (auto &t : th) t.join();
-        }
-        for (int k = 0; k < p; k++) {
-            if (rcs[(size_t)k] != ESP_OK) {
-                dst->err = xs[k]->err;
-                return rcs[(size_t)k];
+            for (int k = 0; k < p; k++) {
+                if (rcs[(size_t)k] != ESP_OK) {
+                    dst->err = xs[k]->err;
+                    return rcs[(size_t)k];
+                }
+                folded += zs[(size_t)k];
             }
-            folded += zs[(size_t)k];
         }
-    }
-    const double t_b = now();
-    // 2. their entries behind one another in dst's buffer (dst's stream waits for each buffer's flush: esp_flush returned
-    // after its last host round trip, but kernels of the buffer's stream may still run)
-    if (folded > 0) {
-        CK(reserve_append(dst, folded));
-        i64 at = dst->count;
-        for (int k = 0; k < p; k++) {
-            esp_handle *x = xs[k];
-            if (x->nnz == 0) continue;
-            CK(fix_tail(x));
-            HIPCK(dst, hipStreamSynchronize(x->stream));
-            Span sp(dst, ESP_ST_APPEND);
-            hipLaunchKernelGGL(csc_as_coo_k, dim3(grid_for(x->n, 256)), dim3(256), 0, dst->stream, (const i64 *)x->colptr.p, (const i64 *)x->rowval.p,
-                               (const double *)x->nzval.p, x->n, dst->L, (u64 *)dst->keys.p + at, (double *)dst->vals.p + at);
-            sp.add(1);
-            at += x->nnz;
+        t_b = now();
+        // 2. their entries behind one another in dst's buffer (dst's stream waits for each buffer's flush: esp_flush returned
+        // after its last host round trip, but kernels of the buffer's stream may still run)
+        if (folded > 0) {
+            CK(reserve_append(dst, folded));
+            i64 at = dst->count;
+            for (int k = 0; k < p; k++) {
+                esp_handle *x = xs[k];
+                if (x->nnz == 0) continue;
+                CK(fix_tail(x));
+                HIPCK(dst, hipStreamSynchronize(x->stream));
+                Span sp(dst, ESP_ST_APPEND);
+                hipLaunchKernelGGL(csc_as_coo_k, dim3(grid_for(x->n, 256)), dim3(256), 0, dst->stream, (const i64 *)x->colptr.p, (const i64 *)x->rowval.p,
+                                   (const double *)x->nzval.p, x->n, dst->L, (u64 *)dst->keys.p + at, (double *)dst->vals.p + at);
+                sp.add(1);
+                at += x->nnz;
+            }
+            HIPCK(dst, hipGetLastError());
+            note_kind(dst, ESP_COO, folded);
+            dst->count += folded;
+            pending_changed(dst);
         }
-        HIPCK(dst, hipGetLastError());
-        note_kind(dst, ESP_COO, folded);
-        dst->count += folded;
-        pending_changed(dst);
-    }
-    // 3. the one flush that meets the stored matrix
-    const double t_c = now();
-    const int32_t rc = esp_flush(dst, ESP_FLUSH_ROUTED, new_nnz, pattern_changed);
+        // 3. the one flush that meets the stored matrix
+        t_c = now();
+        return esp_flush(dst, ESP_FLUSH_ROUTED, new_nnz, pattern_changed);
+    };
+    const int32_t rc = run();
     if (trace) {
         (void)hipStreamSynchronize(dst->stream);
         fprintf(stderr, "esp_flush_sum: %d buffers %lld entries -> folds %.3f ms (%lld entries), gather %.3f ms, combine flush %.3f ms\n", p, (long long)total,
                 t_b - t_a, (long long)folded, t_c - t_b, now() - t_c);
     }
     // (the buffers are consumed whatever happened: genericmtextendablesparsematrixcsc.jl:47-49 replaces them all)
-    HIPCK(dst, hipStreamSynchronize(dst->stream));
+    (void)hipStreamSynchronize(dst->stream);
+    if (rc != ESP_OK && dst->count != 0) {  // (a failure behind the gather: the folded entries must not stay pending in dst)
+        const std::string msg = dst->err;
+        (void)esp_clear_pending(dst);
+        dst->err = msg;
+    }
     for (int k = 0; k < p; k++) (void)esp_reset(xs[k]);
     return rc;
 }

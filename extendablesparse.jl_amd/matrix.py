@@ -252,12 +252,21 @@ class _Handle:
         return d
 
 
+# False: every upload sends the whole matrix (esp_set_csc).  The values-only path recognises "the pattern the device already holds"
+# by the IDENTITY of the colptr / rowval arrays the last download handed out: an in-place edit of those arrays that keeps their
+# length goes unseen (the device would keep the old pattern).  The contract -- as for Julia's SparseMatrixCSC, whose
+# constructor the reference calls with fresh vectors -- is: assign a new matrix, never edit colptr / rowval in place; a caller
+# that cannot promise that sets this switch.
+VALUES_ONLY_UPLOAD = True
+
+
 def _upload_csc(d, mirror, csc):
     """Bring the device CSC of handle `d` to `csc`.  `mirror` = the (colptr, rowval) array objects of the host matrix the
     device CSC equals in pattern (what the last download handed out): when `csc` still carries those very arrays only the
     values travel (esp_set_nzval: 8 instead of 24 bytes per entry) -- the Generic wrappers edit cscmatrix.nzval in place
-    (genericextendablesparsematrixcsc.jl:44-54), which nobody can see from outside, so the values always do."""
-    if mirror is not None and mirror[0] is csc.colptr and mirror[1] is csc.rowval and d.nnz() == csc.nnz():
+    (genericextendablesparsematrixcsc.jl:44-54), which nobody can see from outside, so the values always do.
+    colptr / rowval must never be edited in place (VALUES_ONLY_UPLOAD above)."""
+    if VALUES_ONLY_UPLOAD and mirror is not None and mirror[0] is csc.colptr and mirror[1] is csc.rowval and d.nnz() == csc.nnz():
         d.ck(d.lib.esp_set_nzval(d.h, _vp(np.ascontiguousarray(csc.nzval, np.float64))))
     else:
         d.set_csc(csc)
@@ -372,7 +381,10 @@ class ExtendableSparseMatrix:
     the HIP pipeline in ROUTED mode, which applies updates of entries already in the CSC in call
     order (extendable.jl:164-166) and merges the rest (extendable.jl:248-255)."""
 
-    def __init__(self, m, n=None, device=0, capacity_hint=0):
+    # state of the host copy behind the `cscmatrix` property (ESparseHIP.jl: HOST_CURRENT / HOST_VALUES_STALE / HOST_STALE)
+    HOST_CURRENT, HOST_VALUES_STALE, HOST_STALE = 0, 1, 2
+
+    def __init__(self, m, n=None, device=0, capacity_hint=0, host_edits=True):
         if isinstance(m, SparseMatrixCSC):  # extendable.jl:61-63
             csc = m
             self._d = _Handle(csc.m, csc.n, device, capacity_hint)
@@ -384,6 +396,9 @@ class ExtendableSparseMatrix:
             self.m, self.n = int(m), int(n)
             self._phash = 0  # extendable.jl:40
         self._host = None
+        self._host_state = self.HOST_STALE
+        self._handed_out = False      # read through `cscmatrix` since the last upload: its nzval may carry host edits
+        self.host_edits = host_edits  # False: the caller promises never to edit the host copy (no esp_set_nzval)
 
     @classmethod
     def from_coo(cls, I, J, V, m=None, n=None, combine="+", device=0):
@@ -421,8 +436,44 @@ class ExtendableSparseMatrix:
         self._d.ck(self._d.lib.esp_pattern_hash(self._d.h, C.byref(hsh)))
         return hsh.value
 
-    def _touch(self):
-        self._host = None
+    def _push_edits(self):
+        """nzval of a handed-out host copy back to the device (esp_set_nzval) in front of the next update, flush! or device
+        consumer: the reference's callers edit ext.cscmatrix.nzval in place (nonzeros(A) .= 0: sprand.jl:82,
+        test_parallel.jl:71-92).  Same pattern on both sides: the copy was current when it was handed out."""
+        if self._handed_out:
+            self._handed_out = False
+            if self.host_edits and self._host_state == self.HOST_CURRENT and self._host is not None and self._host.nnz() > 0:
+                self._d.ck(self._d.lib.esp_set_nzval(self._d.h, _vp(np.ascontiguousarray(self._host.nzval, np.float64))))
+
+    def _touch(self, state=1):
+        self._push_edits()
+        self._host_state = max(self._host_state, state)
+
+    @property
+    def cscmatrix(self):
+        """The FIELD ext.cscmatrix of extendable.jl:10-25 as the reference's consumers read it right after flush!
+        (factorizations/ilu0.jl:126-136, umfpack_lu.jl:18-27, jacobi.jl:54-64): flushes, brings the host copy up to date --
+        nothing travels when it is current, nzval only (esp_get_nzval, INTO the array handed out before) when no position was
+        added since the last read, else the whole matrix (esp_get_csc) -- and returns a valid SparseMatrixCSC, never None."""
+        self.flush()
+        if self._host_state != self.HOST_CURRENT or self._host is None:
+            d = self._d
+            if self._host_state == self.HOST_VALUES_STALE and self._host is not None and d.nnz() == self._host.nnz():
+                d.ck(d.lib.esp_get_nzval(d.h, _vp(self._host.nzval)))
+            else:
+                self._host = d.get_csc()
+            self._host_state = self.HOST_CURRENT
+        self._handed_out = True
+        return self._host
+
+    @cscmatrix.setter
+    def cscmatrix(self, csc):
+        """ext.cscmatrix = B (what reset! of the reference does to the field): B becomes the stored matrix (esp_set_csc)."""
+        assert (csc.m, csc.n) == (self.m, self.n)
+        self._d.commit()
+        self._d.set_csc(csc)
+        self._host, self._host_state, self._handed_out = csc, self.HOST_CURRENT, True
+        self._phash = None
 
     def __setitem__(self, ij, v):  # extendable.jl:205-218
         self._touch()
@@ -495,18 +546,17 @@ class ExtendableSparseMatrix:
         return val.value
 
     def flush(self):  # flush!: extendable.jl:248-255
+        self._push_edits()
         if self._d.pending() > 0:
             self._touch()
             _, changed = self._d.flush(ESP_FLUSH_ROUTED)
             if changed:
                 self._phash = None  # extendable.jl:252 (evaluated lazily by the phash property)
+                self._host_state = self.HOST_STALE
         return self
 
-    def sparse(self):  # extendable.jl:258-261: host-visible SparseMatrixCSC
-        self.flush()
-        if self._host is None:
-            self._host = self._d.get_csc()
-        return self._host
+    def sparse(self):  # extendable.jl:258-261: flush!, then the field
+        return self.cscmatrix
 
     def nnz(self):  # abstractextendablesparsematrixcsc.jl:80
         self.flush()
@@ -553,11 +603,12 @@ class ExtendableSparseMatrix:
 
     def copy(self):
         """Base.copy(ext) (extendable.jl:279-285): CSC, pending entries and phash are copied."""
+        self._push_edits()
         c = object.__new__(ExtendableSparseMatrix)
         c._d = self._d.clone()
         c.m, c.n = self.m, self.n
         c._phash = self._phash
-        c._host = None
+        c._host, c._host_state, c._handed_out, c.host_edits = None, self.HOST_STALE, False, self.host_edits
         return c
 
     def mark_dirichlet(self, penalty=1.0e20):
@@ -575,7 +626,7 @@ class ExtendableSparseMatrix:
         if mk.shape != (self.n,):
             raise ValueError("DimensionMismatch")
         self._d.ck(self._d.lib.esp_eliminate_dirichlet(self._d.h, _vp(mk), 0))
-        self._host = None
+        self._touch()
         return self
 
     def jacobi(self):
@@ -597,7 +648,8 @@ class ExtendableSparseMatrix:
         return self.mul(x)
 
     def reset(self):  # reset!: extendable.jl:269-272 (phash kept)
-        self._touch()
+        self._handed_out = False
+        self._host_state = self.HOST_STALE
         self._d._nst = 0
         self._d.ck(self._d.lib.esp_reset(self._d.h))
 
@@ -608,7 +660,7 @@ class ExtendableSparseMatrix:
 
     def dropzeros(self):  # dropzeros!(ext): flush then dropzeros!(csc)
         self.flush()
-        self._touch()
+        self._touch(self.HOST_STALE)
         z = C.c_int64()
         self._d.ck(self._d.lib.esp_dropzeros(self._d.h, C.byref(z)))
         return self
@@ -638,6 +690,10 @@ class ExtendableSparseMatrix:
         """Test hook: 0 automatic, 2 force the general path (global LSD sort + global fold); the other values select
         one implementation where the library has two (include/esparse_hip.h, esp_debug_force_path)."""
         self._d.ck(self._d.lib.esp_debug_force_path(self._d.h, path))
+
+    def debug_plan_cap(self, cap):
+        """Test hook (esp_debug_plan_cap): plan the partition as if the bucket kernel took segments of `cap` entries; 0: off."""
+        self._d.ck(self._d.lib.esp_debug_plan_cap(self._d.h, float(cap)))
 
     def debug_last_path(self):
         p = C.c_int32()

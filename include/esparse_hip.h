@@ -219,6 +219,12 @@ int32_t esp_flush_sum(esp_handle *dst, esp_handle *const *xs, int32_t p, int64_t
 int32_t esp_nnz(const esp_handle *h, int64_t *nnz);
 /* D2H into caller arrays: colptr (n+1), rowval (nnz), nzval (nnz); Julia layout */
 int32_t esp_get_csc(esp_handle *h, int64_t *colptr, int64_t *rowval, double *nzval);
+/* The same transfers for Int32 index arrays (SparseMatrixCSC{Float64,Int32}: extendable.jl:10-25 is generic in Ti).  The
+ * device CSC stays Int64; colptr / rowval are narrowed (widened) on the device, so they cross PCIe as 4 bytes.
+ * esp_get_csc_i32: ESP_ERR_UNSUPPORTED when m or nnz + 1 exceeds 2^31 - 1 (Julia's own Int32 CSC could not hold it). */
+int32_t esp_set_csc_i32(esp_handle *h, const int32_t *colptr, const int32_t *rowval,
+                        const double *nzval, int64_t nnz);
+int32_t esp_get_csc_i32(esp_handle *h, int32_t *colptr, int32_t *rowval, double *nzval);
 /* D2H of nzval only (pattern unchanged since the caller's last esp_get_csc) */
 int32_t esp_get_nzval(esp_handle *h, double *nzval);
 /* H2D of nzval only: the attached CSC keeps its pattern (the one of the caller's last esp_set_csc / esp_get_csc) and takes
@@ -429,14 +435,23 @@ typedef enum {
     ESP_PATH_NO_HITS_KERNEL = 34,    /* never group3_k's re-assembly form (additions over a stored pattern the same mesh built:
                                         every (col,row) of a column run is the stored entry of its rank, sums to a second value
                                         array, all-or-nothing); such flushes take local_k's group-tier kernels               */
-    ESP_PATH_NO_WAVE_KERNEL = 35,    /* never the bucket kernel with one wave per segment of at most 64 columns (wave_k: short columns on
-                                        a fresh matrix, 4-byte keys), nor the finer plans made for it (every other forced path implies
-                                        this one)                                                                            */
+    ESP_PATH_LATE_TOTAL = 36,        /* group3_k publishes a segment's total for the look-back after the fold (instead of right
+                                        after the sort, which a segment of RAWUPDATEs allows)                                */
+    ESP_PATH_NO_CELL_RECORDS = 37,   /* esp_append_elements with cells of 3 / 4 nodes: no 64-byte cell records, the expansion gathers
+                                        rows and diagonal terms from the caller's arrays (as it does for other cell sizes)     */
+    ESP_PATH_HOST_KEYS8 = 38,        /* esp_append_host of one kind: packed eight-byte keys over PCIe (never six-byte keys)      */
     ESP_PATH_NO_PLAN_REUSE = 31      /* esp_append_device / esp_commit of one kind on an empty buffer always count their columns
                                         (never the run lists of the previous, identical-looking batch)                      */
 } esp_debug_path;
-/* last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general) */
+/* last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general).
+ * Environment: the product library reads ESP_HOST_THREADS (host threads esp_append_host / esp_get_csc may use beside the
+ * caller's), ESP_RCCL_LIB (path of the RCCL library esp_group_create loads) and, as test hooks, ESP_DEBUG_FORCE_PATH (the
+ * path every new handle starts with) and ESP_DEBUG_FAIL_COMM_INIT (esp_group_create fails as with a broken fabric) --
+ * nothing else: the switches of the measurement tools exist in a -DESP_EXPERIMENTS build only (csrc/common.hpp). */
 int32_t esp_debug_force_path(esp_handle *h, int32_t path);
+/* test hook: plan the partition as if the bucket kernel took segments of `cap` entries (many prefix bits -- the 9-bit passes,
+ * several rounds -- at sizes a CPU oracle can follow); 0: off */
+int32_t esp_debug_plan_cap(esp_handle *h, double cap);
 int32_t esp_debug_last_path(const esp_handle *h, int32_t *path);
 /* how the last run-based partition turned its run lists into offsets: 1 = one ranking kernel over per-digit run
  * lists, 2 = radix-ordered run list, 3 = ranking kernel given up (a digit with more runs than its list holds),
@@ -458,8 +473,7 @@ int32_t esp_debug_last_fold_update(const esp_handle *h, int32_t *on);
  * never.  2 when it was the group tier's kernel with three workgroups per CU (group3_k: long column runs on a fresh matrix,
  * 4-byte keys; esp_debug_force_path(30): never); 3 when it was that kernel's WIDE form (rows of a segment spread over more than
  * 2^18 -- a mesh numbered without locality: every run sorted twice; esp_debug_force_path(33): never); 4 / 5 when it was that
- * kernel's re-assembly form over a stored pattern (plain / wide; esp_debug_force_path(34): never); 6 when it was the
- * wave-per-segment kernel (short columns on a fresh matrix, segments of at most 64 columns; esp_debug_force_path(35): never) */
+ * kernel's re-assembly form over a stored pattern (plain / wide; esp_debug_force_path(34): never) */
 int32_t esp_debug_last_local_small(const esp_handle *h, int32_t *small);
 /* 1 when the last append-is-the-partition of caller-supplied triplets (esp_append_device / esp_commit of one kind on an
  * empty buffer) used the run lists of the previous assembly instead of counting its columns again: a batch of the same

@@ -20,6 +20,12 @@
  *      esp_set_nzval (values only) and the same assembly again: every update now meets a stored position;
  *   E. esp_append_elements_host: the loops of test/femtools.jl:61-69 over cellnodes / elmat / diag arrays, checked against
  *      the per-entry rawupdateindex! calls in the same order.
+ *   F. the field contract of HIPResidentSparseMatrixCSC (ESparseHIP.jl: host_csc! / push_edits!; the reference's consumers read
+ *      A.cscmatrix right after flush!: factorizations/ilu0.jl:126-136, umfpack_lu.jl:18-27): flush!(ROUTED) -> esp_get_csc ->
+ *      the host edits nzval (nonzeros(A) .= 0.5 on half the entries) -> esp_set_nzval in front of the next update -> updates
+ *      that hit stored positions -> flush! (pattern_changed == 0) -> esp_get_nzval INTO the same vector; then a new position
+ *      -> pattern_changed == 1 -> esp_get_csc again; the same matrix through the Int32 transfers (esp_append_host_i32,
+ *      esp_get_csc_i32, esp_set_csc_i32 on a second handle -> esp_get_csc must return the Int64 arrays).
  *
  * Exit code 0 and "abi_host: ok" on success; any mismatch prints what differs and exits 1.
  * Built and run by tests/test_abi_host.py (compile-only without a GPU).
@@ -438,6 +444,81 @@ int main(void) {
         free(cn);
         free(em);
         free(dg);
+    }
+
+    /* ---------------------------------------------------------------- F: A.cscmatrix after flush!, host edits, Int32 transfers */
+    {
+        esp_handle *f = NULL, *f2 = NULL;
+        dense_t E = dense_new(n);
+        int64_t z = 0, z2 = 0, k, j;
+        int64_t *cp = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1)), *rv, *cp2, *rv2;
+        int32_t *cp32, *rv32, *I32, *J32;
+        double *nz, *nz2, *V;
+        uint64_t rng = 11u;
+        const int64_t T = 5 * n;
+        CHECK(NULL, esp_create(n, n, 0, 0, &f));
+        stage_open(&st, f);
+        stencil_stream(q, 7u, &st, &E);
+        stage_commit(&st);
+        CHECK(f, esp_flush(f, ESP_FLUSH_ROUTED, &z, &changed)); /* flush!(A) */
+        REQUIRE(changed == 1, "F: the first flush! builds the pattern");
+        rv = (int64_t *)malloc(sizeof(int64_t) * (size_t)(z + 8));
+        nz = (double *)malloc(sizeof(double) * (size_t)(z + 8));
+        REQUIRE(cp && rv && nz, "out of memory");
+        CHECK(f, esp_get_csc(f, cp, rv, nz)); /* A.cscmatrix: state STALE -> the whole matrix */
+        compare_csc(&E, cp, rv, nz, z, "F: A.cscmatrix after flush!");
+        for (j = 1; j <= n; j++) /* the host edits values of the matrix it was handed */
+            for (k = cp[j - 1]; k < cp[j]; k++)
+                if (k & 1) nz[k - 1] = 0.5, E.val[(size_t)((j - 1) * n + (rv[k - 1] - 1))] = 0.5;
+        CHECK(f, esp_set_nzval(f, nz)); /* push_edits!: in front of the next update */
+        stage_open(&st, f);
+        stencil_stream(q, 8u, &st, &E); /* every update meets a stored position */
+        stage_commit(&st);
+        CHECK(f, esp_flush(f, ESP_FLUSH_ROUTED, &z2, &changed));
+        REQUIRE(changed == 0 && z2 == z, "F: a re-assembly over the stored pattern changes no position");
+        CHECK(f, esp_get_nzval(f, nz)); /* A.cscmatrix: state VALUES_STALE -> nzval only, into the vector handed out before */
+        compare_csc(&E, cp, rv, nz, z, "F: host edits + hits, values-only download");
+        stage_open(&st, f);
+        stage_push(&st, ESP_RAWUPDATE, 2.25, 1, n), dense_raw(&E, 1, n, 2.25); /* a new position */
+        stage_commit(&st);
+        CHECK(f, esp_flush(f, ESP_FLUSH_ROUTED, &z2, &changed));
+        REQUIRE(changed == 1 && z2 == z + 1, "F: a new position rebuilds the CSC");
+        CHECK(f, esp_get_csc(f, cp, rv, nz));
+        compare_csc(&E, cp, rv, nz, z2, "F: A.cscmatrix after a flush! that added a position");
+        /* Ti = Int32: COO constructor through esp_append_host_i32, A.cscmatrix through esp_get_csc_i32 */
+        dense_free(&E);
+        E = dense_new(n);
+        I32 = (int32_t *)malloc(sizeof(int32_t) * (size_t)T), J32 = (int32_t *)malloc(sizeof(int32_t) * (size_t)T);
+        V = (double *)malloc(sizeof(double) * (size_t)T);
+        REQUIRE(I32 && J32 && V, "out of memory");
+        for (k = 0; k < T; k++) {
+            I32[k] = 1 + (int32_t)(lcg(&rng) * (double)n), J32[k] = 1 + (int32_t)(lcg(&rng) * (double)n), V[k] = lcg(&rng) - 0.5;
+            dense_raw(&E, I32[k], J32[k], V[k]);
+        }
+        CHECK(f, esp_reset(f));
+        CHECK(f, esp_append_host_i32(f, I32, J32, V, NULL, ESP_RAWUPDATE, ESP_OP_ADD, T));
+        CHECK(f, esp_flush(f, ESP_FLUSH_ROUTED, &z, &changed));
+        cp32 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(n + 1)), rv32 = (int32_t *)malloc(sizeof(int32_t) * (size_t)(z + 8));
+        nz2 = (double *)malloc(sizeof(double) * (size_t)(z + 8));
+        cp2 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(n + 1)), rv2 = (int64_t *)malloc(sizeof(int64_t) * (size_t)(z + 8));
+        REQUIRE(cp32 && rv32 && nz2 && cp2 && rv2, "out of memory");
+        CHECK(f, esp_get_csc_i32(f, cp32, rv32, nz2));
+        for (k = 0; k <= n; k++) cp2[k] = cp32[k];
+        for (k = 0; k < z; k++) rv2[k] = rv32[k];
+        compare_csc(&E, cp2, rv2, nz2, z, "F: esp_append_host_i32 + esp_get_csc_i32");
+        CHECK(NULL, esp_create(n, n, 0, 0, &f2)); /* A.cscmatrix = B with an Int32 matrix */
+        CHECK(f2, esp_set_csc_i32(f2, cp32, rv32, nz2, z));
+        memset(cp2, 0, sizeof(int64_t) * (size_t)(n + 1));
+        memset(rv2, 0, sizeof(int64_t) * (size_t)z);
+        memset(nz2, 0, sizeof(double) * (size_t)z);
+        CHECK(f2, esp_nnz(f2, &z2));
+        REQUIRE(z2 == z, "F: esp_set_csc_i32 nnz");
+        CHECK(f2, esp_get_csc(f2, cp2, rv2, nz2));
+        compare_csc(&E, cp2, rv2, nz2, z, "F: esp_set_csc_i32 + esp_get_csc");
+        CHECK(f2, esp_destroy(f2));
+        CHECK(f, esp_destroy(f));
+        dense_free(&E);
+        free(cp), free(rv), free(nz), free(cp32), free(rv32), free(nz2), free(cp2), free(rv2), free(I32), free(J32), free(V);
     }
 
     CHECK(h, esp_destroy(h));

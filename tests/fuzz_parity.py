@@ -272,10 +272,7 @@ while time.time() < t_end:
             cases += 1
         continue
     # (plan hook: many prefix bits at small sizes -- the 9-bit partition passes, three-pass plans)
-    if rng.random() < 0.3:
-        os.environ["ESP_DEBUG_PLAN_CAP"] = str(int(rng.choice([12, 40, 300])))
-    else:
-        os.environ.pop("ESP_DEBUG_PLAN_CAP", None)
+    plan_cap = int(rng.choice([12, 40, 300])) if rng.random() < 0.3 else 0
     n = int(rng.choice([1, 3, 64, 257, 5000, 70000, 400000]))
     m = int(rng.choice([1, 2, 100, 4097, 10 ** 6, 2 ** 31 - 1, 2 ** 33, 2 ** 40]))
     focus = os.environ.get("ESP_FUZZ_FOCUS") == "k32"   # few row bits, many columns: <= 32 key bits below the prefix
@@ -283,6 +280,7 @@ while time.time() < t_end:
         n = int(rng.choice([70000, 400000, 3000000]))
         m = int(rng.choice([3, 100, 4097, 60000]))
     A = esp.ExtendableSparseMatrix(m, n)
+    A.debug_plan_cap(plan_cap)
     O = orc.ExtendableSparseMatrix(m, n)
     force = int(rng.choice([0, 0, 0, 2, 3, 4, 5, 12, 13, 14, 15, 17, 18, 23]))
     if focus:

@@ -78,25 +78,25 @@ def test_golden_fem(esp, dim, npd):
 @pytest.mark.parametrize("late", [False, True])
 def test_group3_total_early_or_late(esp, monkeypatch, late):
     """group3_k publishes a RAWUPDATE segment's total right after the sort (one record per distinct row; the wave that counts
-    its columns last publishes) -- or, ESP_LATE_TOTAL=1, after the fold as before: the same CSC either way (FEM fixtures)."""
-    if late:
-        monkeypatch.setenv("ESP_LATE_TOTAL", "1")
+    its columns last publishes) -- or, esp_debug_force_path(36), after the fold as before: the same CSC either way (FEM fixtures)."""
+    LATE = 36 if late else 0
     fx = gu.load("fem_small")
     for dim, npd in ((2, 32), (3, 10)):
         tag = "fem%dd_%d" % (dim, npd)
         nn = npd ** dim
         A = esp.ExtendableSparseMatrix(nn, nn)
+        A.debug_force_path(LATE)
         A.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
         A.flush()
         assert_csc_equal(hip_arrays(A), (fx[tag + "_colptr"], fx[tag + "_rowval"], fx[tag + "_nzval"]), tag)
     # a mesh large enough for many segments and look-back groups: device against device (early against late is the point)
     npd = 700
     B = esp.ExtendableSparseMatrix(npd * npd, npd * npd)
+    B.debug_force_path(LATE)
     B.generate_fem(2, npd, seed=11, order_mode=1)
     B.flush()
     assert B.debug_last_local_small() == 2
     d = gu.digest(*hip_arrays(B))
-    monkeypatch.delenv("ESP_LATE_TOTAL", raising=False)
     C2 = esp.ExtendableSparseMatrix(npd * npd, npd * npd)
     C2.generate_fem(2, npd, seed=11, order_mode=1)
     C2.flush()
@@ -193,16 +193,16 @@ def test_mixed_kinds_and_zeros(esp, orc):
 @pytest.mark.parametrize("keys8", [False, True])
 def test_host_append_key_formats(esp, orc, monkeypatch, keys8):
     """esp_append_host of ONE kind crosses PCIe with six-byte keys (low 32 bits + next 16, no kind; unpack6_k on the device) when
-    row + column bits fit 48, else -- or with ESP_HOST_KEYS8 -- with packed eight-byte keys: the same CSC, bit for bit the
+    row + column bits fit 48, else -- or with esp_debug_force_path(38) -- with packed eight-byte keys: the same CSC, bit for bit the
     oracle's, for every kind, op '-' (SET is not negated), Int32 index arrays, several chunks' worth of zeros and duplicates."""
-    if keys8:
-        monkeypatch.setenv("ESP_HOST_KEYS8", "1")
     rng = np.random.default_rng(2024)
     m, n = 70001, 65537            # (17 + 17 key bits: the high sixteen of a six-byte key are in use)
     pool = np.array([0.0, -0.0, 2.5, -2.5, 1e-300])
     for kind in (SET, UPDATE, RAW):
         for op in ("+", "-"):
             A = esp.ExtendableSparseMatrix(m, n)
+            if keys8:
+                A.debug_force_path(38)
             O = orc.ExtendableSparseMatrix(m, n)
             for splice, i32 in enumerate((False, True, False)):
                 cnt = 60000
@@ -545,48 +545,6 @@ def test_fdrand_stream_and_reassembly(esp, orc):
     O.flush()
     assert_csc_equal(hip_arrays(A), O.arrays())
     assert A.phash != h0 and A.nnz() == orc.fdrand_nnz(nx, ny, nz) + len(I)
-
-
-def test_wave_kernel_opt_in(esp, orc, monkeypatch):
-    """The wave-per-segment bucket kernel (wavecols.hpp; opt-in: ESP_WAVE=1): the producer cuts segments of at most 64
-    columns, a persistent workgroup of four waves draws tickets and every wave sorts and folds one segment.  Bitwise the
-    oracle's CSC for both adding kinds, grids whose last segment is ragged, and -- ESP_WAVE=2: planned whatever the columns
-    hold -- a matrix whose columns hold 24 entries: its segments are refused (runs above 16) and the flush runs again with
-    local_k's kernels."""
-    monkeypatch.setenv("ESP_WAVE", "1")
-    for (nx, ny, nz, kind) in ((40, 40, 40, UPDATE), (64, 50, 33, RAW), (100, 7, 90, UPDATE)):
-        N = nx * ny * nz
-        A = esp.ExtendableSparseMatrix(N, N)
-        A.generate_fdrand(nx, ny, nz, seed=0x77, rand_mode=1, kind=kind)
-        A.flush()
-        assert A.debug_last_partition() == 4 and A.debug_last_local_small() == 6, (A.debug_last_partition(), A.debug_last_local_small())
-        O = orc.fdrand(nx, ny, nz, rand_mode=1, seed=0x77, style=kind)
-        assert_csc_equal(hip_arrays(A), O.arrays(), "wave kernel %dx%dx%d" % (nx, ny, nz))
-        # a second assembly on the same handle (tickets, pools and granules start from zero again)
-        A.reset()
-        A.generate_fdrand(nx, ny, nz, seed=0x78, rand_mode=1, kind=kind)
-        A.flush()
-        assert A.debug_last_local_small() == 6
-        O = orc.fdrand(nx, ny, nz, rand_mode=1, seed=0x78, style=kind)
-        assert_csc_equal(hip_arrays(A), O.arrays(), "wave kernel, second assembly")
-    monkeypatch.setenv("ESP_WAVE", "2")
-    npd = 300
-    B = esp.ExtendableSparseMatrix(npd * npd, npd * npd)
-    B.generate_fem(2, npd, seed=5, order_mode=0)
-    B.flush()
-    assert B.debug_last_local_small() != 6     # (refused: column runs of 24; the flush ran again)
-    def fem_oracle(seed):
-        I, J, V = orc.fem_stream(2, npd, seed=seed, order_mode=0)
-        O = orc.ExtendableSparseMatrix(npd * npd, npd * npd)
-        O.apply(np.full(len(I), RAW, np.uint8), I, J, V)
-        O.flush()
-        return O.arrays()
-    assert_csc_equal(hip_arrays(B), fem_oracle(5), "wave kernel refused")
-    # ... and the handle does not plan for it again
-    B.reset()
-    B.generate_fem(2, npd, seed=6, order_mode=0)
-    B.flush()
-    assert_csc_equal(hip_arrays(B), fem_oracle(6), "after the refusal")
 
 
 def test_device_generator_stream_is_the_reference_stream(esp, orc):
@@ -1243,14 +1201,10 @@ def test_append_elements(esp, orc, monkeypatch):
                 P.append_elements_again(dem, ddg)
             # packed keys, the item partition off (stream order through the flush's own passes), and without the cell
             # records (the expansion gathers from the caller's arrays, as it does for other cell sizes)
-            for force, parts in ((14, (4,)), (25, (1, 2)), (-1, (4,)), (32, (4,))):   # (32: the expansion resolves the last bits)
+            for force, parts in ((14, (4,)), (25, (1, 2)), (37, (4,)), (32, (4,))):   # (37: no cell records; 32: the expansion resolves the last bits)
                 Cc = esp.ExtendableSparseMatrix(nn, nn)
-                if force >= 0:
-                    Cc.debug_force_path(force)
-                else:
-                    monkeypatch.setenv("ESP_ELEM_NO_CELLREC", "1")
+                Cc.debug_force_path(force)
                 Cc.append_elements(dcn, dem, ddg)
-                monkeypatch.delenv("ESP_ELEM_NO_CELLREC", raising=False)
                 Cc.flush()
                 assert Cc.debug_last_partition() in parts, (force, Cc.debug_last_partition())
                 assert_csc_equal(hip_arrays(Cc), want, "force %d" % force)
@@ -1684,7 +1638,7 @@ def test_csc_plus_buffer_with_batch_and_tail(esp, orc):
 
 def test_nine_bit_partition_passes(esp, orc, monkeypatch):
     """Shuffled streams whose plan needs 17 or 18 prefix bits take TWO passes of 9-bit digits instead of three of at most
-    8 (espradix::scatter_k<true>: two digits per thread).  The test hook ESP_DEBUG_PLAN_CAP makes the plan ask for that
+    8 (espradix::scatter_k<true>: two digits per thread).  The test hook esp_debug_plan_cap makes the plan ask for that
     many bits at a size the oracle can follow; force_path 23 = 8-bit passes only; both must equal the oracle."""
     rng = np.random.default_rng(123)
     m, n, cnt = 3000, 200003, 2500000
@@ -1695,14 +1649,13 @@ def test_nine_bit_partition_passes(esp, orc, monkeypatch):
     O.flush()
     want = O.arrays()
     for cap, force in ((24, 0), (12, 0), (24, 23)):
-        monkeypatch.setenv("ESP_DEBUG_PLAN_CAP", str(cap))
         A = esp.ExtendableSparseMatrix(m, n)
+        A.debug_plan_cap(cap)
         A.debug_force_path(force)
         A.append(0, I, J, V, kinds=kinds)
         A.flush()
         assert A.debug_last_partition() == 2 and A.debug_last_path() == 1
         assert_csc_equal(hip_arrays(A), want, "cap %d force %d" % (cap, force))
-    monkeypatch.delenv("ESP_DEBUG_PLAN_CAP")
 
 
 def test_producer_batch_with_a_tail(esp, orc):
@@ -2884,3 +2837,174 @@ def test_no_append_between_shard_assemble_and_flush(esp, orc):
     assert A.debug_last_partition() == 7
     O = orc.fdrand(n, n, n, rand_mode=1, seed=9, style=orc.KIND_UPDATE)
     assert_csc_equal(hip_arrays(A), O.arrays())
+
+
+# ------------------------------------------------------------------ round 5: the field contract of the north-star type
+def test_cscmatrix_field_contract_and_host_edits(esp, orc):
+    """`A.cscmatrix` right after `flush!` (how the reference's consumers read it: factorizations/ilu0.jl:126-136,
+    umfpack_lu.jl:18-27, jacobi.jl:54-64) is a valid host CSC: nothing travels when it is current, nzval only -- INTO the array
+    handed out before -- when no position was added, the whole matrix otherwise; host edits of nonzeros (sprand.jl:82,
+    test_parallel.jl:71-92) go back to the device in front of the next update.  The Python class mirrors
+    HIPResidentSparseMatrixCSC of ESparseHIP.jl (host_csc!, push_edits!, touch!) call for call."""
+    rng = np.random.default_rng(55)
+    N = 400
+    A = esp.ExtendableSparseMatrix(N, N)
+    O = orc.ExtendableSparseMatrix(N, N)
+
+    def batch(cnt, lo=1, hi=N):
+        I, J, V = rng.integers(lo, hi + 1, cnt), rng.integers(lo, hi + 1, cnt), rng.standard_normal(cnt)
+        return I, J, V
+
+    def both(I, J, V, kind=UPDATE):
+        A.append(kind, I, J, V)
+        O.apply(np.full(len(I), kind, np.uint8), I, J, V)
+
+    I1, J1, V1 = batch(5000, 1, N // 2)
+    both(I1, J1, V1)
+    A.flush(), O.flush()
+    ph0 = A.phash
+    c = A.cscmatrix                                   # STALE -> esp_get_csc
+    check_julia_invariants(N, N, *c.arrays())
+    assert_csc_equal(c.arrays(), O.arrays(), "field after flush!")
+    assert A.cscmatrix is c and A.sparse() is c       # CURRENT: the same object, nothing travels
+    nz_id = c.nzval
+    c.nzval[:] = 0.0                                  # nonzeros(A) .= 0 on the host ...
+    O.zero_values()
+    both(I1, J1, 2.0 * V1)                            # ... then a re-assembly: every update hits a stored position
+    A.flush(), O.flush()
+    assert A.phash == ph0                             # no position added: phash kept (extendable.jl:249-252)
+    c2 = A.cscmatrix                                  # VALUES_STALE -> esp_get_nzval into the array handed out before
+    assert c2 is c and c2.nzval is nz_id
+    assert_csc_equal(c2.arrays(), O.arrays(), "host edit + hits")
+    c.nzval[::3] = 1.25                               # an edit with NO update behind it still reaches the device consumers
+    cp_, rv_, nz_ = O.arrays()
+    dense = np.zeros(N)
+    x = rng.standard_normal(N)
+    nzo = nz_.copy()
+    nzo[::3] = 1.25
+    for j in range(N):
+        for k in range(cp_[j] - 1, cp_[j + 1] - 1):
+            dense[rv_[k] - 1] += nzo[k] * x[j]
+    r = A.mul(x)
+    assert np.allclose(r, dense, rtol=1e-13, atol=1e-13)
+    I2, J2, V2 = batch(3000)                          # new positions: the CSC is rebuilt
+    O2 = orc.ExtendableSparseMatrix(N, N)             # (the oracle has no host-edit call: replay its matrix with the edited values)
+    cols = np.repeat(np.arange(1, N + 1), np.diff(cp_))
+    O2.apply(np.full(len(rv_), RAW, np.uint8), rv_, cols, nzo)
+    O2.flush()
+    A.append(UPDATE, I2, J2, V2)
+    O2.apply(np.full(len(I2), UPDATE, np.uint8), I2, J2, V2)
+    A.flush(), O2.flush()
+    assert A.phash != ph0
+    c3 = A.cscmatrix
+    assert c3 is not c and c3.colptr is not c.colptr
+    assert_csc_equal(c3.arrays(), O2.arrays(), "field after a flush! that added positions")
+    # A.cscmatrix = B attaches B (reset! of the reference assigns the field)
+    B = esp.ExtendableSparseMatrix(N, N, host_edits=False)
+    B.cscmatrix = esp.SparseMatrixCSC(N, N, c3.colptr.copy(), c3.rowval.copy(), c3.nzval.copy())
+    assert B.nnz() == c3.nnz()
+    b = B.cscmatrix
+    b.nzval[:] = 7.0                                  # host_edits = False: the caller promised not to, nothing goes up
+    B.rawupdateindex("+", 0.5, int(I2[0]), int(J2[0]))
+    A.rawupdateindex("+", 0.5, int(I2[0]), int(J2[0]))
+    assert_csc_equal(B.cscmatrix.arrays(), A.cscmatrix.arrays(), "host_edits = False")
+
+
+def test_int32_csc_transfers(esp, orc):
+    """esp_get_csc_i32 / esp_set_csc_i32 (ExtendableSparseMatrix{Float64,Int32}: extendable.jl:10-25 is generic in Ti): the same
+    matrix as the Int64 transfers, index arrays narrowed / widened on the device."""
+    import ctypes as C
+    n = 17
+    A = esp.fdrand(n, n, n, rand_mode=1, seed=0x5EED0002)
+    cp, rv, nz = A.sparse().arrays()
+    d = A._d
+    cp32, rv32, nz2 = np.full(len(cp), -1, np.int32), np.full(len(rv), -1, np.int32), np.zeros(len(nz))
+    d.ck(d.lib.esp_get_csc_i32(d.h, C.c_void_p(cp32.ctypes.data), C.c_void_p(rv32.ctypes.data), C.c_void_p(nz2.ctypes.data)))
+    assert np.array_equal(cp32, cp) and np.array_equal(rv32, rv) and np.array_equal(bits(nz2), bits(nz))
+    B = esp.ExtendableSparseMatrix(n ** 3, n ** 3)
+    b = B._d
+    b.ck(b.lib.esp_set_csc_i32(b.h, C.c_void_p(cp32.ctypes.data), C.c_void_p(rv32.ctypes.data), C.c_void_p(nz2.ctypes.data), len(rv)))
+    B._phash = None
+    assert_csc_equal(B._d.get_csc().arrays(), (cp, rv, nz))
+    rng = np.random.default_rng(1)
+    I, J, V = rng.integers(1, n ** 3 + 1, 4000), rng.integers(1, n ** 3 + 1, 4000), rng.standard_normal(4000)
+    O = orc.fdrand(n, n, n, rand_mode=1, seed=0x5EED0002, style=orc.KIND_UPDATE)
+    B.append(UPDATE, I.astype(np.int32), J.astype(np.int32), V)        # esp_append_host_i32
+    O.apply(np.full(4000, UPDATE, np.uint8), I, J, V)
+    assert_csc_equal(B.sparse().arrays(), O.arrays())
+    empty = esp.ExtendableSparseMatrix(5, 5)
+    e = empty._d
+    cpe = np.zeros(6, np.int32)
+    e.ck(e.lib.esp_get_csc_i32(e.h, C.c_void_p(cpe.ctypes.data), None, None))
+    assert np.array_equal(cpe, np.ones(6, np.int32))
+
+
+def test_elements_plan_is_superseded_by_any_later_element_append(esp, orc):
+    """a kept plan is that of the LAST esp_append_elements.  A later element-level append that does not
+    take the item partition (here: a non-empty buffer; also a repeated node, a BoundsError) must not leave the plan of the
+    earlier mesh behind: esp_append_elements_again then returns ESP_ERR_STATE instead of assembling mesh A's connectivity
+    with mesh B's element matrices."""
+    import torch
+    dim, npd = 2, 120
+    nn, nloc = npd ** dim, dim + 1
+    cnA, emA, dgA = orc.fem_mesh(dim, npd, seed=0x5EED0004, order_mode=1, node_mode=0)
+    cnB, emB, dgB = orc.fem_mesh(dim, npd, seed=0x5EED0104, order_mode=1, node_mode=1)
+    P = esp.ExtendableSparseMatrix(nn, nn)
+    P.elements_keep_plan()
+    P.append_elements(cnA, emA, dgA)
+    P.flush()
+    P.append_elements_again(np.asfortranarray(emA * 2.0), np.asfortranarray(dgA))       # the plan of mesh A works
+    P.flush()
+    P.rawupdateindex("+", 1.0, 1, 1)
+    P.append_elements(cnB, emB, dgB)                  # non-empty buffer: stream order, no plan is made ...
+    P.flush()
+    with pytest.raises(esp.EspError) as ei:
+        P.append_elements_again(np.asfortranarray(emB), np.asfortranarray(dgB))          # ... and mesh A's must be gone
+    assert ei.value.code == esp._lib.ESP_ERR_STATE
+    assert P.nnznew() == 0
+    bad = cnA.copy()
+    bad[1, 7] = nn + 1
+    P.reset()
+    P.append_elements(cnA, emA, dgA)                  # a planned call again ...
+    P.flush()
+    with pytest.raises(esp.BoundsError):
+        P.append_elements(bad, emA, dgA)              # ... superseded by a call that fails
+    with pytest.raises(esp.EspError):
+        P.append_elements_again(np.asfortranarray(emA), np.asfortranarray(dgA))
+
+
+def test_flush_sum_failure_leaves_everything_clean(esp, orc):
+    """esp_flush_sum is all-or-nothing.  A buffer whose own flush fails (here: a declared column window with an entry
+    outside it -> ESP_ERR_STATE) makes the call fail; every buffer still comes back EMPTY (nothing pending, no matrix of its
+    own), the destination keeps its stored matrix and has nothing pending, and the next esp_flush_sum works."""
+    import ctypes as C
+    m = n = 600
+    rng = np.random.default_rng(9)
+    home = esp.SparseMatrixHIPCOO(m, n)
+    xs = [esp.SparseMatrixHIPCOO(m, n) for _ in range(3)]
+    I, J, V = rng.integers(1, m + 1, 3000), rng.integers(1, n + 1, 3000), rng.standard_normal(3000)
+    csc = esp.SparseMatrixCSC(m, n)
+    xs[0].append(UPDATE, I, J, V)
+    first = esp.SparseMatrixHIPCOO.sum(xs, csc, home=home)
+    O = orc.ExtendableSparseMatrix(m, n)
+    O.apply(np.full(3000, UPDATE, np.uint8), I, J, V)
+    assert_csc_equal(first.arrays(), O.arrays())
+    # round 2: buffer 1 promises columns 1..100 and breaks the promise
+    xs[0].append(UPDATE, I, J, V)
+    d1 = xs[1]._d
+    d1.ck(d1.lib.esp_set_column_window(d1.h, 1, 100))
+    xs[1].append(UPDATE, np.array([5, 6]), np.array([7, 450]), np.array([1.0, 2.0]))
+    xs[2].append(UPDATE, I[:10], J[:10], V[:10])
+    with pytest.raises(esp.EspError):
+        esp.SparseMatrixHIPCOO.sum(xs, first, home=home)
+    for x in xs:
+        assert x.nnz() == 0 and x._d.nnz() == 0
+    assert home._d.pending() == 0 and home._d.nnz() == first.nnz()
+    assert_csc_equal(home._d.get_csc().arrays(), O.arrays(), "the destination after a failed sum")
+    d1.ck(d1.lib.esp_set_column_window(d1.h, 1, n))
+    xs[1].append(UPDATE, I, J, V)
+    out = esp.SparseMatrixHIPCOO.sum(xs, first, home=home)
+    L = orc.SparseMatrixLNK(m, n)
+    for i, j, v in zip(I.tolist(), J.tolist(), V.tolist()):
+        L.updateindex(orc.OP_ADD, v, i, j)
+    assert_csc_equal(out.arrays(), (L + orc.CSC(m, n, *O.arrays())).arrays(), "the sum after the failed one")
