@@ -680,6 +680,34 @@ def bind_near_gpu(torch, local):
         return None
 
 
+def summary_of(out):
+    """A compact copy of what a reader of the record needs, as the LAST key of the JSON line (the driver keeps the last 2 000
+    characters of it): the headline, its roofline and CPU baseline, and for every extra config [ms, fraction of the HBM
+    roofline on SURVEY 8d's bytes, digest_ok] -- cfg2_host (PCIe-inclusive): [ms, nnz/s]."""
+    r3 = lambda x: None if x is None else round(float(x), 3)
+    s = {"ms_per_step": r3(out.get("ms_per_step")), "value": float("%.4g" % out["value"]) if out.get("value") else None,
+         "digest_ok": out.get("digest_ok")}
+    rf = out.get("roofline") or {}
+    s["roofline"] = [rf.get("kernel"), r3(rf.get("avg_launch_ms")), r3(rf.get("frac")),
+                     None if rf.get("traffic") is None else float("%.4g" % rf["traffic"])]
+    s["pipeline_frac"] = r3((out.get("pipeline") or {}).get("frac_of_hbm_peak"))
+    cb = out.get("cpu_baseline") or {}
+    if cb:
+        s["cpu"] = [float("%.4g" % cb["value"]) if cb.get("value") else None, cb.get("cores"), cb.get("kind")]
+    cfgs = {}
+    for name, c in ((out.get("extra") or {}).get("configs") or {}).items():
+        if "error" in c:
+            cfgs[name] = "error"
+        elif "frac_of_hbm_peak" in c:
+            cfgs[name] = [r3(c.get("ms")), r3(c.get("frac_of_hbm_peak")), c.get("digest_ok", c.get("nnz_ok"))]
+        else:
+            cfgs[name] = [r3(c.get("ms")), float("%.4g" % c["nnz_per_s"]) if c.get("nnz_per_s") else None]
+    if cfgs:
+        s["cfg"] = cfgs
+        s["cfg_cols"] = "ms, frac_of_hbm_peak (SURVEY 8d bytes), digest_ok; cfg2_host: ms, nnz_per_s"
+    return s
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -896,6 +924,8 @@ def main():
                                                  int(os.environ.get("ESP_CFG4_3D", "216")))}
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, args.cpu_mt_n)
+    if rank == 0:
+        out["summary"] = summary_of(out)   # LAST key: the driver's record keeps the tail of the line
     if dist is not None:
         dist.destroy_process_group()
     if rank == 0:

@@ -22,6 +22,7 @@
 #include "fold.hpp"
 #include "generators.hpp"
 #include "femitems.hpp"
+#include "elements.hpp"
 #include "local_args.hpp"
 #include "merge.hpp"
 #include "radix.hpp"
@@ -87,6 +88,21 @@ struct esp_handle {
         bool own32 = false;      // ... and the shard's OWN range holds 4-byte keys of kind `kind` (the sent ranges: packed)
     } pre;
     bool pre_keep = false;       // reserve_append: the append that follows goes behind the bucket-ordered batch
+    // A batch of an item partition whose EXPANSION has not run (group3_items.hpp): `pre` describes it as if its updates lay
+    // bucket by bucket in keys / vals -- they do not yet: the sorted item records lie in the keys array (the two ping-pong
+    // halves of the item passes), the cell records of an element-level append in the vals array, and the flush's bucket
+    // kernel forms the updates itself (fresh matrix, nothing appended behind the batch).  Everybody else -- an append behind
+    // the batch, a clone, getindex, a shard call, a flush over a stored pattern, a segment the fused kernel refuses -- calls
+    // lazy_expand() first (pending_materialize and reserve_append do), which runs the expansion kernel into the scratch pair,
+    // swaps the pairs and leaves the handle as a producer-side partition always left it.  on implies pre.valid.
+    struct LazyItems {
+        bool on = false;
+        int src = 0;             // 1: the built-in generator's items (espitem), 2: an element-level append's (espelem)
+        bool k32 = true;         // the expansion writes 4-byte keys (pre.key_bytes == 4)
+        espitem::Args it;        // the expansion's argument block (sorted_keys set; keys_out / vals_out filled in by lazy_expand)
+        espelem::Args el;
+    } lazy;
+    int last_lazy_items = 0;     // the last flush's bucket kernel formed its updates from item records (esp_debug_last_lazy_items)
     // The entries appended behind a batch over a STORED pattern were partitioned as they came (append_tail_partitioned):
     // pre.tail packed keys in bucket order of a plan of their own -- still a pending stream like any other (a stable
     // partition keeps every column's order), so whoever does not know about it loses nothing; esp_flush's split
@@ -236,7 +252,7 @@ static inline void pending_changed(esp_handle *h) {
     if (h->pre.valid && h->pre_keep && h->count >= h->pre.E)
         h->pre.tail = h->count - h->pre.E;
     else
-        h->pre.valid = false;
+        h->pre.valid = false, h->lazy.on = false;
     h->pre_keep = false;
     h->tailpart.valid = false;  // (append_tail_partitioned sets it after this call)
 }
@@ -317,6 +333,7 @@ struct Sorted {
     int npieces = 0;
     const i64 *pstart = nullptr;
     const void *const *ptab = nullptr;
+    const esp_handle::LazyItems *lazy = nullptr;  // sk holds sorted ITEM records, seg_start counts their updates: the fused bucket kernel or nothing
     bool has_base = false;  // the segments' key base, if it is not the handle's window / shard range
     int expect_hits = -1;   // 1 / 0: the caller knows what the entries will mostly do over the stored pattern; -1: the handle's history
     u64 base = 0;
@@ -382,6 +399,9 @@ int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSetup *ps)
 int32_t prepart_rank(esp_handle *h, PartSetup *ps);
 int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took);
 int32_t pending_materialize(esp_handle *h);
+int32_t lazy_expand(esp_handle *h);   // produce.hip: the expansion of a batch held as sorted items (esp_handle::LazyItems)
+// may an item partition on this handle leave its batch unexpanded?  (kind: what its updates are; produce.hip)
+bool lazy_items_wanted(const esp_handle *h, int kind);
 int32_t settle_offset(esp_handle *h);
 int32_t item_produce_fem(esp_handle *h, const espgen::FemArgs &fa, i64 E, bool *took);
 int32_t partition_pass(esp_handle *h, espradix::Pass &p, i64 max_tiles);

@@ -334,6 +334,7 @@ int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took) {
 // packed keys again: every call that reads or extends the pending entries other than the flush they were written for
 int32_t pending_materialize(esp_handle *h) {
     if (!h->pre.valid) return ESP_OK;
+    CK(lazy_expand(h));  // (a batch still held as sorted items: its updates first)
     h->pre.valid = false;
     h->part_own32 = false;
     if (h->pre.mw_P > 0 && h->pre.own32 && h->count > 0) {
@@ -378,6 +379,57 @@ int32_t pending_materialize(esp_handle *h) {
 }
 
 
+// ---- batches held as sorted items (esp_handle::LazyItems, group3_items.hpp) -----------------------------------------
+// The fused bucket kernel serves a FRESH matrix whose flush would take group3_k in its plain form: additions of one kind
+// (UPDATE / RAWUPDATE), cells of 3 or 4 nodes, rows below 2^30.  Whether the matrix is still fresh at flush time nobody knows
+// here; a handle that already holds a matrix assembles over it (re-assembly kernels read expanded entries), so its batches
+// are expanded at once.  force_path 39 (ESP_PATH_NO_LAZY_ITEMS): never; any other forced path but 36: never either.
+bool lazy_items_wanted(const esp_handle *h, int kind) {
+    if (h->force_path != ESP_PATH_AUTO && h->force_path != ESP_PATH_LATE_TOTAL) return false;
+    if (kind != ESP_UPDATE && kind != ESP_RAWUPDATE) return false;
+    if (h->nnz != 0 || h->count != 0 || windowed(h) || h->shard_user) return false;
+    if (h->g3_off || h->g3_wide) return false;  // (the handle's segments are not group3_k's plain form's)
+    if (h->L.rb > 30) return false;
+    return true;
+}
+// The expansion that was put off: sorted items (in the keys array) -> updates, bucket by bucket, into the scratch pair; then
+// the pairs trade places.  Afterwards the handle is what item_produce_fem / elements_by_items used to leave.
+int32_t lazy_expand(esp_handle *h) {
+    if (!h->lazy.on) return ESP_OK;
+    h->lazy.on = false;
+    if (!h->pre.valid) return ESP_OK;
+    const i64 E = h->pre.E;
+    CK(ensure(h, h->keys2, std::max(h->keys.bytes, sizeof(u64) * (size_t)E)));
+    CK(ensure(h, h->vals2, std::max(h->vals.bytes, sizeof(double) * (size_t)E)));
+    {
+        Span sp(h, ESP_ST_APPEND);
+        if (h->lazy.src == 1) {
+            espitem::Args a = h->lazy.it;
+            a.keys_out = (u64 *)h->keys2.p;
+            a.vals_out = (double *)h->vals2.p;
+            const dim3 grid(grid_for(a.nitems, espitem::THREADS)), block(espitem::THREADS);
+            if (h->lazy.k32)
+                hipLaunchKernelGGL(espitem::fem_expand_k<true>, grid, block, 0, h->stream, a);
+            else
+                hipLaunchKernelGGL(espitem::fem_expand_k<false>, grid, block, 0, h->stream, a);
+        } else {
+            espelem::Args a = h->lazy.el;
+            a.keys_out = (u64 *)h->keys2.p;
+            a.vals_out = (double *)h->vals2.p;
+            if (h->lazy.k32)
+                espelem::launch_expand<true>(a, h->stream);
+            else
+                espelem::launch_expand<false>(a, h->stream);
+        }
+        sp.add(1);
+    }
+    HIPCK(h, hipGetLastError());
+    std::swap(h->keys, h->keys2);
+    std::swap(h->vals, h->vals2);
+    h->cap = (i64)std::min(h->keys.bytes / sizeof(u64), h->vals.bytes / sizeof(double));
+    return ESP_OK;
+}
+
 // Shuffled FEM stream on an empty buffer (femitems.hpp): item records -> the flush's own partition passes over them ->
 // every update stored once at its bucket position; the handle is left as after a producer-side partition (h->pre).
 // *took = false: not applicable, the caller appends in stream order.
@@ -401,11 +453,16 @@ int32_t item_produce_fem(esp_handle *h, const espgen::FemArgs &fa, i64 E, bool *
     // single-word records when the cell's number fits below the column bits of the key (28: test hook, never)
     a.single = ((u64)fa.ncells <= ((u64)1 << (h->L.rb + ESP_TAG_BITS)) && h->force_path != ESP_PATH_TWO_WORD_ITEMS) ? 1 : 0;
     a.sorted_keys = nullptr;
+    // the batch stays a list of sorted items and the flush's bucket kernel forms the updates (group3_items.hpp): the item
+    // records then ping-pong inside the KEYS array (the pending buffer the updates would fill), the scratch pair stays free
+    // for the flush's output
+    const bool lazy = a.single && lazy_items_wanted(h, ESP_RAWUPDATE) && h->keys.bytes >= 2 * sizeof(u64) * (size_t)NI;
+    if (lazy) a.ikeys = (u64 *)h->keys.p;
     const int K = window_bits(h);
     // single-word records: the passes may stop a few bits early, the expansion orders every segment by the last bits itself
     // (segexpand.hpp); a second attempt with the passes alone when a segment does not fit that
     int sort_bits = 0;
-    const int lbits0 = a.single ? plan_local_bits(h, NI, W, K, &sort_bits) : 0;
+    const int lbits0 = (a.single && !lazy) ? plan_local_bits(h, NI, W, K, &sort_bits) : 0;
     Sorted st;
     int lbits = 0;
     i64 maxlen_updates = 0;
@@ -489,7 +546,11 @@ int32_t item_produce_fem(esp_handle *h, const espgen::FemArgs &fa, i64 E, bool *
         } else {
             Span sp(h, ESP_ST_APPEND);
             const dim3 grid(grid_for(NI, espitem::THREADS)), block(espitem::THREADS);
-            if (k32)
+            if (lazy) {  // (the expansion is the flush's business now -- or lazy_expand's)
+                h->lazy.src = 1;
+                h->lazy.k32 = k32;
+                h->lazy.it = a;
+            } else if (k32)
                 hipLaunchKernelGGL(espitem::fem_expand_k<true>, grid, block, 0, h->stream, a);
             else
                 hipLaunchKernelGGL(espitem::fem_expand_k<false>, grid, block, 0, h->stream, a);
@@ -501,6 +562,7 @@ int32_t item_produce_fem(esp_handle *h, const espgen::FemArgs &fa, i64 E, bool *
         done = true;
     }
     if (!done) return ESP_OK;
+    h->lazy.on = lazy;  // (pre.valid follows once the caller has counted the entries in)
     st.rem_bits -= lbits;
     HIPCK(h, hipGetLastError());
     esp_handle::PrePart &pp = h->pre;
