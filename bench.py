@@ -542,6 +542,7 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
                 I = cn[:, :, None].expand(nc, nloc, W).reshape(-1).contiguous()
                 J = torch.cat([cn[:, :, None], cn[:, None, :].expand(nc, nloc, nloc)], dim=2).reshape(-1)
                 V = torch.cat([dg[:, :, None], em.transpose(1, 2)], dim=2).reshape(-1)
+                torch.cuda.synchronize()      # (torch made the triplets on ITS stream; the library reads them on the handle's own)
                 del cn, em, dg
                 dts, tm = [], None
                 for it in range(steps + 2):

@@ -4,22 +4,6 @@
 
 namespace {
 
-template <bool K32>
-void launch_expand(const espelem::Args &a, hipStream_t stream) {
-    const dim3 grid(grid_for(a.nitems, espelem::THREADS)), block(espelem::THREADS);
-    const size_t lds = (size_t)espelem::THREADS * (size_t)a.W * (sizeof(double) + (K32 ? sizeof(u32) : sizeof(u64)));
-    if (a.nloc == 3 && a.cellrec)
-        hipLaunchKernelGGL((espelem::elem_expand_k<K32, 3>), grid, block, lds, stream, a);
-    else if (a.nloc == 4 && a.cellrec)
-        hipLaunchKernelGGL((espelem::elem_expand_k<K32, 4>), grid, block, lds, stream, a);
-    else if (a.nloc == 3)
-        hipLaunchKernelGGL((espelem::elem_expand_k<K32, 3, false>), grid, block, lds, stream, a);
-    else if (a.nloc == 4)
-        hipLaunchKernelGGL((espelem::elem_expand_k<K32, 4, false>), grid, block, lds, stream, a);
-    else
-        hipLaunchKernelGGL((espelem::elem_expand_k<K32, 0>), grid, block, lds, stream, a);
-}
-
 // The item partition (elements.hpp) on an empty buffer.  *took = false: not applicable (or a cell names a node twice):
 // nothing was appended, the caller writes the updates in stream order.
 int32_t elements_by_items(esp_handle *h, espelem::Args a, i64 E, bool *took) {
@@ -51,13 +35,22 @@ int32_t elements_by_items(esp_handle *h, espelem::Args a, i64 E, bool *took) {
     const bool cellrec = (a.nloc == 3 || a.nloc == 4) && h->m <= ((i64)1 << 32) && (size_t)a.ncells * 64 <= h->vals2.bytes &&
                          h->force_path != ESP_PATH_NO_CELL_RECORDS;
     a.cellrec = cellrec ? (char *)h->vals2.p : nullptr;
+    // the batch stays a list of sorted items and the flush's bucket kernel forms the updates (group3_items.hpp): item records
+    // and cell records then live in the pending buffer's own arrays (which the updates would fill), the scratch pair stays
+    // free for the flush's output
+    const bool lazy = cellrec && lazy_items_wanted(h, a.kind) && h->keys.bytes >= 2 * sizeof(u64) * (size_t)NI &&
+                      h->vals.bytes >= (size_t)a.ncells * 64;
+    if (lazy) {
+        a.ikeys = (u64 *)h->keys.p;
+        a.cellrec = (char *)h->vals.p;
+    }
     const int Kv = bits_for(std::max<i64>(h->n, 1)) + vrb;  // bits of the records' virtual key window (n << vrb keys)
     const u64 vspan = (u64)std::max<i64>(h->n, 1) << vrb;
     // with cell records the passes may stop a few bits early: the expansion orders every segment by the last bits itself
     // (segexpand.hpp); a second attempt with the passes alone when a segment does not fit that
     int sort_bits = 0;
     int lbits0 = 0;
-    if (cellrec) {
+    if (cellrec && !lazy) {
         const u64 span0 = h->win_span, base0 = h->win_base;
         h->win_base = 0, h->win_span = vspan;
         int Kw = 1;
@@ -175,10 +168,14 @@ int32_t elements_by_items(esp_handle *h, espelem::Args a, i64 E, bool *took) {
             }
         } else {
             Span sp(h, ESP_ST_APPEND);
-            if (k32)
-                launch_expand<true>(a, h->stream);
+            if (lazy) {  // (the expansion is the flush's business now -- or lazy_expand's)
+                h->lazy.src = 2;
+                h->lazy.k32 = k32;
+                h->lazy.el = a;
+            } else if (k32)
+                espelem::launch_expand<true>(a, h->stream);
             else
-                launch_expand<false>(a, h->stream);
+                espelem::launch_expand<false>(a, h->stream);
             hipLaunchKernelGGL(espitem::scale_segments_k, dim3(grid_for((i64)st.S + 1, 256)), dim3(256), 0, h->stream, st.seg_start, (i64)st.S + 1,
                                (i64)W, (i64 *)h->seg[1].p);
             sp.add(2);
@@ -222,6 +219,7 @@ int32_t elements_by_items(esp_handle *h, espelem::Args a, i64 E, bool *took) {
         ep.base = h->win_base, ep.span = h->win_span;
         ep.valid = true;
     }
+    h->lazy.armed = lazy;  // (-> lazy.on beside pre.valid, once the caller has counted the entries in)
     *took = true;  // (the caller sets pre.valid once the entries are counted in)
     return ESP_OK;
 }
@@ -290,9 +288,9 @@ extern "C" int32_t esp_append_elements_again(esp_handle *h, const double *d_elma
                 hipLaunchKernelGGL(espelem::elem_refresh_diag_k<4>, grid, block, 0, h->stream, d_diag, ep.ncells, a.cellrec);
         }
         if (ep.k32)
-            launch_expand<true>(a, h->stream);
+            espelem::launch_expand<true>(a, h->stream);
         else
-            launch_expand<false>(a, h->stream);
+            espelem::launch_expand<false>(a, h->stream);
         sp.add(2);
     }
     HIPCK(h, hipMemcpyAsync(h->seg[1].p, ep.segtab.p, sizeof(i64) * (size_t)(ep.S + 1), hipMemcpyDeviceToDevice, h->stream));
@@ -387,7 +385,8 @@ extern "C" int32_t esp_append_elements(esp_handle *h, int32_t nloc, int64_t ncel
     note_kind(h, kind, E);
     h->count += E;
     pending_changed(h);
-    if (took) h->pre.valid = true;
+    if (took) h->pre.valid = true, h->lazy.on = h->lazy.armed;
+    h->lazy.armed = false;
     return ESP_OK;
 }
 
@@ -399,6 +398,11 @@ extern "C" int32_t esp_append_elements_host(esp_handle *h, int32_t nloc, int64_t
     if (ncells < 0 || (ncells > 0 && (!cellnodes || !elmat))) FAIL(h, ESP_ERR_INVALID, "esp_append_elements: bad arguments");
     if (ncells == 0) return ESP_OK;
     (void)hipSetDevice(h->device);
+    if (h->lazy_hold.p) {  // (the matrices of an earlier batch: whatever still gathers from them runs now -- an append behind a batch of items expands it)
+        CK(lazy_expand(h));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        release(h->lazy_hold);
+    }
     DevBuf dn, de, dd;
     const size_t bn = sizeof(i64) * (size_t)ncells * (size_t)nloc, be = sizeof(double) * (size_t)ncells * (size_t)nloc * (size_t)nloc;
     int32_t rc = ensure(h, dn, bn);
@@ -419,6 +423,12 @@ extern "C" int32_t esp_append_elements_host(esp_handle *h, int32_t nloc, int64_t
         rc = esp_append_elements(h, nloc, ncells, (const i64 *)dn.p, (const double *)de.p, diag ? (const double *)dd.p : nullptr, kind, op);
     (void)hipStreamSynchronize(h->stream);  // (the kernels have read the temporaries)
     release(dn);
+    if (rc == ESP_OK && h->lazy.on) {
+        // the batch stayed a list of items: the fused bucket kernel (or lazy_expand) gathers the values from the uploaded
+        // element matrices at flush time -- they live on in the handle (rows and diagonal terms are in the cell records)
+        h->lazy_hold = de;
+        de = DevBuf();
+    }
     release(de);
     release(dd);
     return rc;

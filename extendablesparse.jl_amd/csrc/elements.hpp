@@ -248,6 +248,24 @@ static __global__ __launch_bounds__(THREADS) void elem_expand_k(Args a) {
     }
 }
 
+// host side: the expansion's launch (elements.hip, and lazy_expand in produce.hip)
+template <bool K32>
+static inline void launch_expand(const Args &a, hipStream_t stream) {
+    const dim3 grid((unsigned)((a.nitems + THREADS - 1) / THREADS)), block(THREADS);
+    const size_t lds = (size_t)THREADS * (size_t)a.W * (sizeof(double) + (K32 ? sizeof(u32) : sizeof(u64)));
+    if (a.nloc == 3 && a.cellrec)
+        hipLaunchKernelGGL((elem_expand_k<K32, 3>), grid, block, lds, stream, a);
+    else if (a.nloc == 4 && a.cellrec)
+        hipLaunchKernelGGL((elem_expand_k<K32, 4>), grid, block, lds, stream, a);
+    else if (a.nloc == 3)
+        hipLaunchKernelGGL((elem_expand_k<K32, 3, false>), grid, block, lds, stream, a);
+    else if (a.nloc == 4)
+        hipLaunchKernelGGL((elem_expand_k<K32, 4, false>), grid, block, lds, stream, a);
+    else
+        hipLaunchKernelGGL((elem_expand_k<K32, 0>), grid, block, lds, stream, a);
+}
+
+
 // The expansion with the partition's last bits done inside it (segexpand.hpp), cells of 3 / 4 nodes with cell records: one
 // workgroup per segment of up to 4096 item records orders them by the next lbits bits and expands them in that order.
 template <bool K32, int NLOC>

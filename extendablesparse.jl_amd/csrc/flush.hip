@@ -295,6 +295,10 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
                      h->force_path != ESP_PATH_NO_GROUP3;
             var.g3wide = var.g3 && want_wide;
             used_g3 = used_g3 || var.g3;
+            if (st.lazy) {  // sorted ITEM records: group3_k's fused form (group3_items.hpp) or nothing
+                if (!var.g3 || var.g3wide || !esplocal::launch_group3_items(*st.lazy, grid, h->stream, a)) return ESP_RETRY_EXPANDED;
+                continue;
+            }
             if (!esplocal::launch(var, grid, h->stream, a)) FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (no bucket kernel for this flush)");
         }
         return ESP_OK;
@@ -370,6 +374,13 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         sp.add(1);
     }
     CK(read_back());
+    h->last_lazy_items = 0;
+    if (st.lazy) {
+        // a segment the fused kernel refuses (a column run above 128, rows spread over more than 2^18): nothing of a
+        // fresh-matrix flush has taken effect -- the caller expands the items and comes back with the entries
+        if ((u32)(h->pin_scalar[1] >> 32) & 8u) return ESP_RETRY_EXPANDED;
+        h->last_lazy_items = 1;
+    }
     if (used_g3 && !want_wide && h->force_path != ESP_PATH_NO_WIDE_GROUP3) {
         const u32 e = (u32)(h->pin_scalar[1] >> 32);
         if ((e & 8u) && (e & 16u) && !(e & 32u)) {
@@ -681,6 +692,8 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
                             pp.span == h->win_span && pp.maxlen <= (i64)esplocal::CAP && pp.K - pp.pb <= esplocal::MAX_REM_BITS;
         if (!usable) CK(pending_materialize(h));
     }
+    // a batch still held as sorted items goes to the fused bucket kernel only on a fresh matrix with nothing behind it
+    if (h->pre.valid && h->lazy.on && (h->nnz != 0 || h->pre.tail != 0 || !use_local)) CK(lazy_expand(h));
     bool served = false, split = false, tail_direct = false;
     i64 Zsplit = 0;  // new entries of the batch's own flush
     if (h->pre.valid && h->pre.tail > 0 && h->nnz > 0 && mode == ESP_FLUSH_ROUTED && h->force_path != ESP_PATH_BATCH_TAIL_ONE_FLUSH) {
@@ -770,7 +783,26 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         st.maxlen = pp.maxlen;
         CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
         CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
-        CK(flush_local(h, st, mode, &Zn));
+        int32_t rc_local;
+        if (h->lazy.on) {
+            st.sk = h->lazy.src == 1 ? h->lazy.it.sorted_keys : h->lazy.el.sorted_keys;
+            st.sv = nullptr;
+            st.lazy = &h->lazy;
+            rc_local = flush_local(h, st, mode, &Zn);
+            if (rc_local == ESP_RETRY_EXPANDED) {  // (not the fused kernel's flush after all: the entries, then the usual way)
+                CK(lazy_expand(h));
+                st.sk = (const u64 *)h->keys.p;
+                st.sv = (const double *)h->vals.p;
+                st.lazy = nullptr;
+                CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
+                CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
+                rc_local = flush_local(h, st, mode, &Zn);
+            }
+            // (a failed flush leaves the batch pending as it was: still items, or expanded by the retry)
+        } else {
+            rc_local = flush_local(h, st, mode, &Zn);
+        }
+        CK(rc_local);
         h->last_partition = 4;
         h->runs_penalty = 0;
         h->seen_spread = pp.Ee > 0.0 ? (double)pp.maxlen * std::ldexp(1.0, pp.pb) / pp.Ee : 0.0;
@@ -847,6 +879,10 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
     h->count = 0;
     h->pend_off = 0;
     pending_changed(h);
+    if (h->lazy_hold.p) {  // (the uploaded element matrices of esp_append_elements_host: their batch is flushed)
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        release(h->lazy_hold);
+    }
     if (h->timing && fa) {
         hipEvent_t fb = ev_get(h);
         (void)hipEventRecord(fb, h->stream);

@@ -46,7 +46,7 @@ void release(DevBuf &b) {
 void release_all(esp_handle *h) {
     for (DevBuf *b : {&h->keys, &h->vals, &h->keys2, &h->vals2, &h->hist, &h->segs, &h->colend, &h->newkey,
                       &h->newval, &h->heads, &h->misc, &h->colptr, &h->colptr2, &h->rowval, &h->nzval, &h->rowval2,
-                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->tseg, &h->ttile, &h->runbuf, &h->chunkbuf, &h->parttab, &h->piecetab, &h->csr_rowptr, &h->csr_perm, &h->csr_col, &h->csr_tmp, &h->csr_val, &h->mul_x, &h->mul_r, &h->elemplan.sorted, &h->elemplan.cellrec, &h->elemplan.segtab, &h->stage.d_rows, &h->stage.d_cols, &h->stage.d_vals, &h->stage.d_kinds, &h->bulk.d_rows, &h->bulk.d_cols, &h->bulk.d_vals, &h->bulk.d_kinds})
+                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->tseg, &h->ttile, &h->runbuf, &h->chunkbuf, &h->parttab, &h->piecetab, &h->csr_rowptr, &h->csr_perm, &h->csr_col, &h->csr_tmp, &h->csr_val, &h->mul_x, &h->mul_r, &h->lazy_hold, &h->elemplan.sorted, &h->elemplan.cellrec, &h->elemplan.segtab, &h->stage.d_rows, &h->stage.d_cols, &h->stage.d_vals, &h->stage.d_kinds, &h->bulk.d_rows, &h->bulk.d_cols, &h->bulk.d_vals, &h->bulk.d_kinds})
         release(*b);
     for (esp_handle::StageArea *sa : {&h->stage, &h->bulk}) {
         if (sa->rows) (void)hipHostFree(sa->rows);
@@ -333,6 +333,7 @@ int32_t reserve_append(esp_handle *h, i64 add) {
     // An append behind a bucket-ordered batch: the batch stays as it is (its 4-byte keys fill the front half of their
     // slots), the new entries follow it as packed keys, and the flush partitions only them (flush_pre_tail).  A shard's
     // batch, or force_path 19: back to packed keys first.
+    CK(lazy_expand(h));  // (a batch still held as sorted items: whatever comes behind it needs its updates where they belong)
     h->pre_keep = h->pre.valid && h->pre.mw_P == 0 && h->force_path != ESP_PATH_NO_BATCH_TAIL && h->count == h->pre.E + h->pre.tail;
     if (!h->pre_keep) CK(pending_materialize(h));
     const i64 need = h->count + add;
@@ -1111,6 +1112,7 @@ extern "C" int32_t esp_reset(esp_handle *h) {
     h->hits_off = false;  // (a new matrix: its re-assemblies may be what the re-assembly kernel takes)
     h->count = 0;
     pending_changed(h);
+    if (h->lazy_hold.p) release(h->lazy_hold);  // (hipFree waits for whatever still reads it)
     return init_empty_csc(h);
 }
 

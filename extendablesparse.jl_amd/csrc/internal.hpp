@@ -97,11 +97,14 @@ struct esp_handle {
     // swaps the pairs and leaves the handle as a producer-side partition always left it.  on implies pre.valid.
     struct LazyItems {
         bool on = false;
+        bool armed = false;      // set by the item partition; the producer turns it into `on` beside pre.valid = true (after pending_changed)
         int src = 0;             // 1: the built-in generator's items (espitem), 2: an element-level append's (espelem)
         bool k32 = true;         // the expansion writes 4-byte keys (pre.key_bytes == 4)
         espitem::Args it;        // the expansion's argument block (sorted_keys set; keys_out / vals_out filled in by lazy_expand)
         espelem::Args el;
     } lazy;
+    DevBuf lazy_hold;            // esp_append_elements_host: the uploaded element matrices of a batch that stayed a list of items (the fused
+                                 // bucket kernel or lazy_expand gathers from them); released by the next flush / reset / upload
     int last_lazy_items = 0;     // the last flush's bucket kernel formed its updates from item records (esp_debug_last_lazy_items)
     // The entries appended behind a batch over a STORED pattern were partitioned as they came (append_tail_partitioned):
     // pre.tail packed keys in bucket order of a plan of their own -- still a pending stream like any other (a stable
@@ -399,6 +402,10 @@ int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSetup *ps)
 int32_t prepart_rank(esp_handle *h, PartSetup *ps);
 int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took);
 int32_t pending_materialize(esp_handle *h);
+namespace esplocal {
+bool launch_group3_items(const esp_handle::LazyItems &lz, unsigned grid, hipStream_t stream, const Args &a);  // local_j.hip
+}
+constexpr int32_t ESP_RETRY_EXPANDED = 1000;  // flush_local to esp_flush: expand the items (lazy_expand) and call again -- never leaves the library
 int32_t lazy_expand(esp_handle *h);   // produce.hip: the expansion of a batch held as sorted items (esp_handle::LazyItems)
 // may an item partition on this handle leave its batch unexpanded?  (kind: what its updates are; produce.hip)
 bool lazy_items_wanted(const esp_handle *h, int kind);

@@ -164,7 +164,8 @@ extern "C" int32_t esp_generate_fem(esp_handle *h, int32_t dim, int64_t npd, uin
     note_kind(h, ESP_RAWUPDATE, E);
     h->count += E;
     pending_changed(h);
-    if (took) h->pre.valid = true;  // (else: whatever pending_changed left -- an earlier batch with this call as its tail)
+    if (took) h->pre.valid = true, h->lazy.on = h->lazy.armed;  // (else: whatever pending_changed left -- an earlier batch with this call as its tail)
+    h->lazy.armed = false;
     return ESP_OK;
 }
 
@@ -562,7 +563,7 @@ int32_t item_produce_fem(esp_handle *h, const espgen::FemArgs &fa, i64 E, bool *
         done = true;
     }
     if (!done) return ESP_OK;
-    h->lazy.on = lazy;  // (pre.valid follows once the caller has counted the entries in)
+    h->lazy.armed = lazy;  // (-> lazy.on beside pre.valid, once the caller has counted the entries in)
     st.rem_bits -= lbits;
     HIPCK(h, hipGetLastError());
     esp_handle::PrePart &pp = h->pre;

@@ -706,6 +706,12 @@ class ExtendableSparseMatrix:
         self._d.ck(self._d.lib.esp_debug_last_local_small(self._d.h, C.byref(p)))
         return p.value
 
+    def debug_last_lazy_items(self):
+        """1: the last flush's bucket kernel formed its updates from sorted item records (the expansion never ran)"""
+        p = C.c_int32()
+        self._d.ck(self._d.lib.esp_debug_last_lazy_items(self._d.h, C.byref(p)))
+        return p.value
+
     def debug_last_shard_source(self):
         """1: the last esp_shard_partition moved the entries itself, 2: the producer had partitioned them"""
         p = C.c_int32()

@@ -440,6 +440,9 @@ typedef enum {
     ESP_PATH_NO_CELL_RECORDS = 37,   /* esp_append_elements with cells of 3 / 4 nodes: no 64-byte cell records, the expansion gathers
                                         rows and diagonal terms from the caller's arrays (as it does for other cell sizes)     */
     ESP_PATH_HOST_KEYS8 = 38,        /* esp_append_host of one kind: packed eight-byte keys over PCIe (never six-byte keys)      */
+    ESP_PATH_NO_LAZY_ITEMS = 39,     /* item partitions (esp_generate_fem in a shuffled order, esp_append_elements) always run their
+                                        expansion at append time: the updates are stored bucket by bucket and the flush's bucket
+                                        kernel reads them -- never the fused form that forms them from the sorted item records  */
     ESP_PATH_NO_PLAN_REUSE = 31      /* esp_append_device / esp_commit of one kind on an empty buffer always count their columns
                                         (never the run lists of the previous, identical-looking batch)                      */
 } esp_debug_path;
@@ -475,6 +478,11 @@ int32_t esp_debug_last_fold_update(const esp_handle *h, int32_t *on);
  * 2^18 -- a mesh numbered without locality: every run sorted twice; esp_debug_force_path(33): never); 4 / 5 when it was that
  * kernel's re-assembly form over a stored pattern (plain / wide; esp_debug_force_path(34): never) */
 int32_t esp_debug_last_local_small(const esp_handle *h, int32_t *small);
+/* 1 when the bucket kernel of the last flush formed its updates from the sorted ITEM records of an item partition
+ * (esp_generate_fem in a shuffled order, esp_append_elements on an empty buffer of a fresh matrix): the expansion -- every
+ * update stored once at its bucket position, read again by the bucket kernel -- never ran (csrc/group3_items.hpp);
+ * esp_debug_force_path(39): never */
+int32_t esp_debug_last_lazy_items(const esp_handle *h, int32_t *on);
 /* 1 when the last append-is-the-partition of caller-supplied triplets (esp_append_device / esp_commit of one kind on an
  * empty buffer) used the run lists of the previous assembly instead of counting its columns again: a batch of the same
  * length and kind is scattered straight away, every tile checked against its run list by the scatter kernel (a stream

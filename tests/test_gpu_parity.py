@@ -2423,7 +2423,7 @@ def test_fem_digest_bench_size(esp, dim, npd):
     A = esp.ExtendableSparseMatrix(nn, nn)
     A.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
     A.flush()
-    assert A.debug_last_partition() == 4
+    assert A.debug_last_partition() == 4 and A.debug_last_lazy_items() == 1
     arrs = hip_arrays(A)
     assert len(arrs[1]) == int(d["nnz"])
     assert gu.digest(*arrs) == d["csc"]
@@ -2453,6 +2453,9 @@ def test_elements_digest(esp, dim, npd, node_mode):
     # natural numbering: the group-tier kernel with three workgroups per CU (2); permuted numbering of more than 2^18 nodes:
     # its wide form (3: full rows in LDS, every column run sorted twice) -- not local_k's radix tier
     assert A.debug_last_local_small() == (3 if (node_mode == 1 and nn > (1 << 18)) else 2), A.debug_last_local_small()
+    # (the fused bucket kernel formed the updates from the item records -- unless it refused the segments for their rows:
+    # then the items were expanded and the wide form took the entries)
+    assert A.debug_last_lazy_items() == (0 if (node_mode == 1 and nn > (1 << 18)) else 1)
     arrs = hip_arrays(A)
     assert len(arrs[1]) == int(d["nnz"])
     assert gu.digest(*arrs) == d["csc"]
@@ -2485,6 +2488,20 @@ def test_fem_digest(esp, dim, npd, order):
     arrs = hip_arrays(A)
     assert len(arrs[1]) == int(d["nnz"])
     assert gu.digest(*arrs) == d["csc"]
+    # random order: the batch stayed a list of sorted items and the bucket kernel formed the updates itself (group3_items.hpp);
+    # force_path 39: the expansion at append time, as before -- the same CSC
+    # (single-word item records only: the cell's number must fit below the column bits of a key -- 3-D, 64^3 nodes: it does not)
+    q = npd - 1
+    ncells = 2 * q * q if dim == 2 else 6 * q ** 3
+    single = ncells <= 1 << (max(1, (nn - 1).bit_length()) + 2)
+    assert A.debug_last_lazy_items() == (1 if (order == 1 and single) else 0)
+    if order == 1:
+        B = esp.ExtendableSparseMatrix(nn, nn)
+        B.debug_force_path(39)
+        B.generate_fem(dim, npd, seed=0x5EED0004, order_mode=order)
+        B.flush()
+        assert B.debug_last_partition() == 4 and B.debug_last_lazy_items() == 0
+        assert gu.digest(*hip_arrays(B)) == d["csc"]
 
 
 @pytest.mark.parametrize("dims", [(4096, 300, 1), (300, 4096, 1), (2000001, 1, 1), (37, 41, 1013), (1021, 3, 509), (2, 2, 400000),
@@ -3008,3 +3025,92 @@ def test_flush_sum_failure_leaves_everything_clean(esp, orc):
     for i, j, v in zip(I.tolist(), J.tolist(), V.tolist()):
         L.updateindex(orc.OP_ADD, v, i, j)
     assert_csc_equal(out.arrays(), (L + orc.CSC(m, n, *O.arrays())).arrays(), "the sum after the failed one")
+
+
+def test_lazy_item_batches_and_everything_that_expands_them(esp, orc):
+    """A batch of an item partition stays a list of sorted items until its flush (group3_items.hpp: the bucket kernel forms the
+    updates itself).  Whatever else touches the pending entries first must find them as entries: an append behind the batch, a
+    clone, getindex on the buffer, nnznew, a flush over a stored pattern (the second assembly), reset!, a second batch right
+    behind the first, esp_flush_sum.  Every result against the oracle fed the same calls one by one; op '-', updateindex! with
+    zeros, meshes without a diagonal term; 2-D and 3-D."""
+    import torch
+    rng = np.random.default_rng(77)
+    for dim, npd in ((2, 220), (3, 26)):
+        nn, nloc = npd ** dim, dim + 1
+        cn, em, dg = orc.fem_mesh(dim, npd, seed=0x5EED0004, order_mode=1, node_mode=0)
+        em[:, :, ::7] = 0.0                                 # (zeros: updateindex! creates nothing for them)
+        I, J, V = orc.elements_stream(cn, em, dg)
+        In, Jn, Vn = orc.elements_stream(cn, em, None)
+
+        def oracle(calls):
+            O = orc.ExtendableSparseMatrix(nn, nn)
+            for kind, (i, j, v) in calls:
+                O.apply(np.full(len(i), kind, np.uint8), i, j, v)
+            O.flush()
+            return O.arrays()
+
+        # plain: the fused kernel, every kind / op it takes, with and without the diagonal term
+        for kind, op, diag in ((RAW, "+", True), (UPDATE, "+", True), (RAW, "-", True), (UPDATE, "-", False), (RAW, "+", False)):
+            A = esp.ExtendableSparseMatrix(nn, nn)
+            A.append_elements(cn, em, dg if diag else None, kind=kind, op=op)
+            A.flush()
+            assert A.debug_last_lazy_items() == 1 and A.debug_last_partition() == 4, (kind, op, diag)
+            i, j, v = (I, J, V) if diag else (In, Jn, Vn)
+            assert_csc_equal(hip_arrays(A), oracle([(kind, (i, j, v if op == "+" else -v))]), "plain %d %s %s" % (kind, op, diag))
+        # SET is not the fused kernel's: expanded at append time
+        A = esp.ExtendableSparseMatrix(nn, nn)
+        A.append_elements(cn, em, dg, kind=SET)
+        A.flush()
+        assert A.debug_last_lazy_items() == 0
+        assert_csc_equal(hip_arrays(A), oracle([(SET, (I, J, V))]), "SET")
+        # an append behind the batch (then the batch + tail flush), a second batch behind the first
+        I2, J2, V2 = rng.integers(1, nn + 1, 5000), rng.integers(1, nn + 1, 5000), rng.standard_normal(5000)
+        A = esp.ExtendableSparseMatrix(nn, nn)
+        A.append_elements(cn, em, dg)
+        A.append(UPDATE, I2, J2, V2)
+        A.flush()
+        assert A.debug_last_lazy_items() == 0
+        assert_csc_equal(hip_arrays(A), oracle([(RAW, (I, J, V)), (UPDATE, (I2, J2, V2))]), "tail")
+        A.reset()
+        A.append_elements(cn, em, dg)
+        A.append_elements(cn, em, dg)
+        assert A.nnznew() == 2 * len(I)
+        A.flush()
+        assert_csc_equal(hip_arrays(A), oracle([(RAW, (I, J, V)), (RAW, (I, J, V))]), "twice")
+        # the second assembly runs over the stored pattern (every update hits): expanded, the re-assembly kernels
+        A.append_elements(cn, em, dg)
+        A.flush()
+        assert A.debug_last_lazy_items() == 0
+        assert_csc_equal(hip_arrays(A), oracle([(RAW, (I, J, V))] * 3), "over the stored pattern")
+        # clone of a handle with a lazy batch: both flush to the same matrix; getindex on the pending buffer
+        A = esp.ExtendableSparseMatrix(nn, nn)
+        A.append_elements(cn, em, dg)
+        B = A.copy()
+        want = oracle([(RAW, (I, J, V))])
+        assert_csc_equal(hip_arrays(B), want, "clone")
+        assert_csc_equal(hip_arrays(A), want, "the cloned handle")
+        X = esp.SparseMatrixHIPCOO(nn, nn)
+        X.append_elements(cn, em, dg)
+        i0, j0 = int(I[5]), int(J[5])
+        ref = orc.SparseMatrixLNK(nn, nn)
+        for i, j, v in zip(I.tolist(), J.tolist(), V.tolist()):
+            if j == j0 and i == i0:
+                ref.rawupdateindex(orc.OP_ADD, v, i, j)
+        assert bits(np.array([X[i0, j0]])) == bits(np.array([ref[i0, j0]]))
+        csc = X + esp.SparseMatrixCSC(nn, nn)
+        assert_csc_equal(csc.arrays(), want, "buffer + csc after getindex")
+        # the generator's items the same way: tail behind the batch, reset with a batch pending, then a clean assembly
+        G = esp.ExtendableSparseMatrix(nn, nn)
+        G.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
+        G.append(UPDATE, I2, J2, V2)
+        G.flush()
+        Ig, Jg, Vg = orc.fem_stream(dim, npd, seed=0x5EED0004, order_mode=1)
+        assert_csc_equal(hip_arrays(G), oracle([(RAW, (Ig, Jg, Vg)), (UPDATE, (I2, J2, V2))]), "generator + tail")
+        G.reset()
+        G.generate_fem(dim, npd, seed=0x5EED0004, order_mode=1)
+        G.reset()
+        G.generate_fem(dim, npd, seed=0x5EED0009, order_mode=1)
+        G.flush()
+        assert G.debug_last_lazy_items() == 1
+        Ig, Jg, Vg = orc.fem_stream(dim, npd, seed=0x5EED0009, order_mode=1)
+        assert_csc_equal(hip_arrays(G), oracle([(RAW, (Ig, Jg, Vg))]), "generator after reset")
