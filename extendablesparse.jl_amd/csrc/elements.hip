@@ -296,6 +296,7 @@ extern "C" int32_t esp_append_elements_again(esp_handle *h, const double *d_elma
     HIPCK(h, hipMemcpyAsync(h->seg[1].p, ep.segtab.p, sizeof(i64) * (size_t)(ep.S + 1), hipMemcpyDeviceToDevice, h->stream));
     HIPCK(h, hipGetLastError());
     h->rawplan.valid = false;  // (seg[1] is rewritten)
+    h->genplan.valid = false;
     esp_handle::PrePart &pp = h->pre;
     pp.K = ep.K;
     pp.pb = ep.K - ep.rem_real;

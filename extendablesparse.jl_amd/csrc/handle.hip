@@ -231,6 +231,7 @@ extern "C" int32_t esp_release_buffers(esp_handle *h) {
     h->chunk_cap = 0;
     h->chunk_pb = 0;
     h->rawplan.valid = false;
+    h->genplan.valid = false;
     h->elemplan.valid = false;
     pending_changed(h);
     h->csc_valid = false;

@@ -127,6 +127,19 @@ struct esp_handle {
         u64 base = 0, span = 0;
         double Ee = 0.0;
     } rawplan;
+    // The same for the stencil generator (esp_generate_fdrand*): its run lists, run offsets and bucket starts are a function of
+    // the grid, the node range and the plan alone -- not of seed, values or kind -- so an assembly that repeats the previous
+    // one (a time loop: reset!, fdrand!, flush!) goes straight to the PART launch: no COUNT launch, no ranking launches, no
+    // host round trip for their flags.  Dropped by whatever rewrites the tables (chunk_arrays, sort_msd, release_buffers).
+    struct GenPlan {
+        bool valid = false;
+        i64 nx = 0, ny = 0, nz = 0, g0 = 0, g1 = 0, E = 0;
+        int kind = 0;
+        u64 base = 0, span = 0;
+        const void *keys_at = nullptr;  // (the arrays the stored PartOut wrote to: a reallocation drops the plan)
+        esprun::PartOut out;
+        PrePart pre;
+    } genplan;
     // esp_elements_keep_plan: the item order, the cell records and the segment table of the last esp_append_elements on an
     // empty buffer (cells of 3 / 4 nodes) are kept in buffers of their own, so that esp_append_elements_again -- the same
     // connectivity, new element matrices: a time step of an instationary / nonlinear code -- goes straight to the expansion

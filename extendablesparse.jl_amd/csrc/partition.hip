@@ -87,6 +87,7 @@ int32_t sort_pending_lsd(esp_handle *h, const u64 **sk, const double **sv) {
 
 int32_t chunk_arrays(esp_handle *h, i64 Ccap, int pb, ChunkArrays *out, bool keep_plan) {
     if (!keep_plan) h->rawplan.valid = false;  // (whoever asks for the run tables is about to rewrite them)
+    h->genplan.valid = false;
     const i64 NB = (i64)1 << pb;
     const i64 RM = Ccap * esprun::RMAX;
     size_t off = 0;
@@ -637,6 +638,7 @@ int32_t append_tail_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_c
 
 int32_t sort_msd(esp_handle *h, Sorted *out) {
     h->rawplan.valid = false;  // (the segment tables are rewritten)
+    h->genplan.valid = false;
     const i64 E = h->count;
     // sort bits of the key window: (key>>2) - win_base lies in [0, win_span)
     int K = 1;

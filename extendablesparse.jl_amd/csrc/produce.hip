@@ -60,10 +60,39 @@ extern "C" int32_t esp_generate_fdrand_range(esp_handle *h, int64_t nx, int64_t 
     const dim3 grid(grid_for(node_end - node_begin, espgen::THREADS)), block(espgen::THREADS);
     // the append is the partition when the buffer is empty and the stream is one an assembly loop emits: COUNT launch
     // (ALU only), two tiny ranking launches, then every update goes straight to its bucket
+    // ... and when the call repeats the handle's last one (same grid, node range and kind on the same empty buffer: a time
+    // loop) the tables of that call still stand: straight to the PART launch (esp_handle::GenPlan; force_path 31: never)
     PartSetup ps;
-    CK(prepart_begin(h, E, (i64)grid.x, kind, &ps));
-    a.part = ps.out;
     bool took = false;
+    const esp_handle::GenPlan &gp = h->genplan;
+    const bool reuse = gp.valid && gp.nx == nx && gp.ny == ny && gp.nz == nz && gp.g0 == node_begin && gp.g1 == node_end && gp.kind == kind &&
+                       gp.E == E && h->count == 0 && h->force_path == ESP_PATH_AUTO && !h->part_assembled &&
+                       gp.base == h->win_base && gp.span == h->win_span && gp.keys_at == h->keys.p && h->runs_skip == 0 &&
+                       // (a shard: the plan was made for the exchange the caller announced -- esp_shard_plan -- and that one only)
+                       (h->shard_user ? (h->shard_plan.valid && gp.pre.mw_P == h->shard_plan.P && gp.pre.mw_me == h->shard_plan.me &&
+                                         gp.pre.mw_eps == h->shard_plan.eps)
+                                      : gp.pre.mw_P == 0);
+    h->last_plan_reused = reuse ? 1 : 0;
+    if (reuse) {
+        a.part = gp.out;
+        a.part.keys_out = (u64 *)h->keys.p;
+        a.part.vals_out = (double *)h->vals.p;
+        HIPCK(h, hipMemsetAsync((u32 *)h->misc.p + 60, 0, 16, h->stream));  // (the flag words the PART launch looks at: a failed flush may have left one)
+        Span sp(h, ESP_ST_APPEND);
+        if (gp.out.k32)
+            hipLaunchKernelGGL((espgen::fdrand_part_k<true, true>), grid, block, 0, h->stream, a);
+        else if (gp.out.s32)
+            hipLaunchKernelGGL((espgen::fdrand_part_k<true, false>), grid, block, 0, h->stream, a);
+        else
+            hipLaunchKernelGGL((espgen::fdrand_part_k<false, false>), grid, block, 0, h->stream, a);
+        sp.add(1);
+        h->pre = gp.pre;
+        h->pre.valid = false;  // (set below, once the entries are counted in)
+        took = true;
+    } else {
+        CK(prepart_begin(h, E, (i64)grid.x, kind, &ps));
+        a.part = ps.out;
+    }
     if (ps.on) {
         {
             Span sp(h, ESP_ST_HIST);
@@ -82,6 +111,15 @@ extern "C" int32_t esp_generate_fdrand_range(esp_handle *h, int64_t nx, int64_t 
             sp.add(1);
         }
         CK(prepart_finish(h, &ps, &took));
+        if (took) {  // the tables stand until somebody rewrites them: the next identical call starts at the PART launch
+            esp_handle::GenPlan &np = h->genplan;
+            np.nx = nx, np.ny = ny, np.nz = nz, np.g0 = node_begin, np.g1 = node_end, np.E = E, np.kind = kind;
+            np.base = h->win_base, np.span = h->win_span;
+            np.keys_at = h->keys.p;
+            np.out = ps.out;
+            np.pre = h->pre;
+            np.valid = true;
+        }
     }
     if (!took) {  // stream order (the PART launch left without a store when the stream turned out not to be pre-sorted)
         Span sp(h, ESP_ST_APPEND);

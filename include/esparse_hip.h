@@ -487,6 +487,9 @@ int32_t esp_debug_last_lazy_items(const esp_handle *h, int32_t *on);
  * empty buffer) used the run lists of the previous assembly instead of counting its columns again: a batch of the same
  * length and kind is scattered straight away, every tile checked against its run list by the scatter kernel (a stream
  * that turns out different is partitioned the full way; results never change) */
+/* ... likewise 1 when the last esp_generate_fdrand[_range] repeated the handle's previous call (same grid, node range and kind on
+ * the same empty buffer: a time loop of reset! / fdrand! / flush!) and went straight to its PART launch: the run lists, run
+ * offsets and bucket starts are a function of the grid and the plan, not of seed or values (esp_debug_force_path(31): never) */
 int32_t esp_debug_last_plan_reused(const esp_handle *h, int32_t *reused);
 /* which partition the last flush used: 1 = run-based single pass (pre-sorted stream), 2 = 8-bit passes,
  * 4 = none: the producer wrote every entry straight to its bucket (esp_generate_* on an empty buffer: a COUNT launch

@@ -3114,3 +3114,57 @@ def test_lazy_item_batches_and_everything_that_expands_them(esp, orc):
         assert G.debug_last_lazy_items() == 1
         Ig, Jg, Vg = orc.fem_stream(dim, npd, seed=0x5EED0009, order_mode=1)
         assert_csc_equal(hip_arrays(G), oracle([(RAW, (Ig, Jg, Vg))]), "generator after reset")
+
+
+def test_generator_repeats_its_plan(esp, orc):
+    """esp_generate_fdrand on the same grid again (a time loop: reset!, fdrand!, flush!): the second call finds the run lists
+    and bucket starts of the first -- a function of the grid and the plan, not of seed, values or kind of randomness -- and goes
+    straight to its PART launch (esp_debug_last_plan_reused).  Another grid, another kind, an append in between, a partition
+    of another stream in between, force_path 31: the full path.  Always the oracle's bits."""
+    import torch
+    for (nx, ny, nz) in ((48, 48, 48), (300, 201, 5)):
+        N = nx * ny * nz
+        A = esp.ExtendableSparseMatrix(N, N)
+
+        def run(seed, kind, expect, what, mode=1):
+            A.reset()
+            A.generate_fdrand(nx, ny, nz, seed=seed, rand_mode=mode, kind=kind)
+            assert A.debug_last_plan_reused() == expect, (what, A.debug_last_plan_reused())
+            A.flush()
+            assert A.debug_last_partition() == 4
+            O = orc.fdrand(nx, ny, nz, rand_mode=mode, seed=seed, style=kind)
+            assert_csc_equal(hip_arrays(A), O.arrays(), what)
+
+        run(1, UPDATE, 0, "first")
+        run(2, UPDATE, 1, "same grid, new values")
+        run(3, UPDATE, 1, "again", mode=2)
+        run(4, RAW, 0, "another kind")
+        run(5, RAW, 1, "that kind again")
+        # an append of another stream in between rewrites the tables: the full path, then reuse again
+        A.reset()
+        I, J, V = orc.fdrand_stream(nx, ny, nz, rand_mode=1, seed=9)
+        dev = lambda x: torch.from_numpy(np.ascontiguousarray(x)).cuda()   # noqa: E731
+        A.append_device(UPDATE, dev(I[::2]), dev(J[::2]), dev(V[::2]))
+        A.flush()
+        run(6, RAW, 0, "after a partition of another stream")
+        run(7, RAW, 1, "and again")
+        # behind pending entries the generator does not partition at all; afterwards the plan still stands
+        A.reset()
+        A.rawupdateindex("+", 1.0, 1, 1)
+        A.generate_fdrand(nx, ny, nz, seed=8, rand_mode=1, kind=RAW)
+        assert A.debug_last_plan_reused() == 0
+        A.flush()
+        O = orc.ExtendableSparseMatrix(N, N)
+        O.rawupdateindex(orc.OP_ADD, 1.0, 1, 1)
+        I, J, V = orc.fdrand_stream(nx, ny, nz, rand_mode=1, seed=8)
+        O.apply(np.full(len(I), RAW, np.uint8), I, J, V)
+        O.flush()
+        assert_csc_equal(hip_arrays(A), O.arrays(), "behind a pending entry")
+        B = esp.ExtendableSparseMatrix(N, N)
+        B.debug_force_path(31)
+        for seed in (1, 2):
+            B.reset()
+            B.generate_fdrand(nx, ny, nz, seed=seed, rand_mode=1, kind=UPDATE)
+            assert B.debug_last_plan_reused() == 0
+            B.flush()
+        assert_csc_equal(hip_arrays(B), orc.fdrand(nx, ny, nz, rand_mode=1, seed=2, style=orc.KIND_UPDATE).arrays(), "force 31")
