@@ -278,6 +278,7 @@ extern "C" int32_t esp_append_elements_again(esp_handle *h, const double *d_elma
     a.keys_out = (u64 *)h->keys.p;
     a.vals_out = (double *)h->vals.p;
     CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(ep.S + 1)));
+    bool lazy = false;
     {
         Span sp(h, ESP_ST_APPEND);
         if (d_diag) {
@@ -287,7 +288,14 @@ extern "C" int32_t esp_append_elements_again(esp_handle *h, const double *d_elma
             else
                 hipLaunchKernelGGL(espelem::elem_refresh_diag_k<4>, grid, block, 0, h->stream, d_diag, ep.ncells, a.cellrec);
         }
-        if (ep.k32)
+        // (the batch may stay a list of items -- the kept order IS the sorted item list: the fused bucket kernel's re-assembly
+        // form forms the updates at flush time, lazy_expand for everybody else)
+        lazy = lazy_items_wanted(h, kind);
+        if (lazy) {
+            h->lazy.src = 2;
+            h->lazy.k32 = ep.k32;
+            h->lazy.el = a;
+        } else if (ep.k32)
             espelem::launch_expand<true>(a, h->stream);
         else
             espelem::launch_expand<false>(a, h->stream);
@@ -314,6 +322,7 @@ extern "C" int32_t esp_append_elements_again(esp_handle *h, const double *d_elma
     h->count += E;
     pending_changed(h);
     h->pre.valid = true;
+    h->lazy.on = lazy;
     return ESP_OK;
 }
 
@@ -441,6 +450,11 @@ extern "C" int32_t esp_append_elements_again_host(esp_handle *h, const double *e
     const esp_handle::ElemPlan &ep = h->elemplan;
     if (!ep.valid) FAIL(h, ESP_ERR_STATE, "esp_append_elements_again: the handle keeps no plan (esp_elements_keep_plan, then esp_append_elements on an empty buffer)");
     (void)hipSetDevice(h->device);
+    if (h->lazy_hold.p) {  // (the matrices of an earlier batch: see esp_append_elements_host)
+        CK(lazy_expand(h));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        release(h->lazy_hold);
+    }
     DevBuf de, dd;
     const size_t bn = sizeof(double) * (size_t)ep.ncells * (size_t)ep.nloc, be = bn * (size_t)ep.nloc;
     int32_t rc = ensure(h, de, be);
@@ -457,6 +471,10 @@ extern "C" int32_t esp_append_elements_again_host(esp_handle *h, const double *e
     }
     if (rc == ESP_OK) rc = esp_append_elements_again(h, (const double *)de.p, diag ? (const double *)dd.p : nullptr, kind, op);
     (void)hipStreamSynchronize(h->stream);  // (the kernels have read the temporaries)
+    if (rc == ESP_OK && h->lazy.on) {  // (the batch stayed a list of items: the element matrices live on until its flush)
+        h->lazy_hold = de;
+        de = DevBuf();
+    }
     release(de);
     release(dd);
     return rc;

@@ -343,7 +343,10 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
             var.g3wide = want_wide;
             {
                 Span sp(h, ESP_ST_LOCAL);
-                if (!esplocal::launch(var, (unsigned)S, h->stream, a)) FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (no re-assembly kernel for this flush)");
+                if (st.lazy) {  // (sorted item records: the fused form -- plain rows only -- or the caller expands them)
+                    if (want_wide || !esplocal::launch_group3_items(*st.lazy, (unsigned)S, h->stream, a, true)) return ESP_RETRY_EXPANDED;
+                } else if (!esplocal::launch(var, (unsigned)S, h->stream, a))
+                    FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (no re-assembly kernel for this flush)");
                 sp.add(1);
             }
             CK(read_back());
@@ -355,10 +358,12 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
                 h->last_group3 = want_wide ? 4 : 3;
                 h->seen_maxrun = (int)(u32)(h->pin_scalar[2] & 0xFFFFFFFFull);
                 h->seen_hits = true;
+                h->last_lazy_items = st.lazy ? 1 : 0;
                 *Zn_out = 0;
                 return ESP_OK;
             }
             CK(reset_launch_state());
+            if (st.lazy) return ESP_RETRY_EXPANDED;  // (nothing has happened: the entries, then whatever form takes them)
             if ((e & 8u) && (e & 16u) && !(e & 32u) && !(e & 64u) && !want_wide && h->force_path != ESP_PATH_NO_WIDE_GROUP3) {
                 want_wide = true;  // (refused for its rows alone: once more in the wide form)
                 h->g3_wide = true;
@@ -667,6 +672,133 @@ int32_t flush_pre_tail(esp_handle *h, int mode, i64 *Zn, bool *served) {
     return ESP_OK;
 }
 
+// ---- a routed flush that REBUILDS the matrix: the stored CSC as the first piece of every segment ------------------------
+// A flush over a stored pattern whose entries mostly open NEW positions (the entries behind a re-assembly's batch: a mesh
+// that gained couplings) used to run the bucket kernel against the stored columns (look-ups that miss), emit the new
+// entries and join them with the stored matrix in a pass of its own (colmerge_k): the stored rows read twice, the new
+// entries written and read again.  But a stored entry is, to the ordered fold, nothing but an entry that came FIRST and
+// always creates -- the COO kind (fold.hpp: the first value as it is, whatever follows added or set in call order).  So the
+// flush runs as a FRESH one whose segments are two pieces (the PIECES variants the shard exchange uses): the stored
+// entries of the segment's columns -- contiguous in the CSC, their keys formed once (csc_keys_k), their values read where
+// they lie -- then the pending entries of the segment.  The bucket kernel writes the new rowval / nzval / colptr itself: no
+// look-ups, no join.  Config 3's tail (33 M entries behind 117 M stored): tail kernel 0.75 + join 1.23 + scan 0.09 ms -> one
+// kernel over 150 M entries.  Taken for short columns only (the PIECES variants have no group tier), whole-column segments,
+// ROUTED mode (csc + buffer folds the buffer by itself first); a merged segment above the kernel's capacity: not served,
+// the caller takes the look-up + join path.  force_path 40: never.
+// keys of the stored entries, entry-parallel (coalesced reads and stores): a workgroup takes 256 columns, their colptr slice in
+// LDS, every entry finds its column by a binary search there.  K32: the 32 key bits below the segment prefix (rem_bits <= 32:
+// (col << rb | row) mod 2^rem_bits -- what the bucket kernel's P32 piece format reads), else packed keys of kind COO.
+template <bool K32>
+__global__ __launch_bounds__(256) void csc_keys_k(const i64 *__restrict__ colptr, const i64 *__restrict__ rowval, i64 n, KeyLayout L, int rem_bits,
+                                                  void *__restrict__ keys_out) {
+    __shared__ i64 cp[257];
+    const int t = threadIdx.x;
+    const i64 c0 = (i64)blockIdx.x * 256;
+    for (int q = t; q <= 256; q += 256) cp[q] = colptr[min(c0 + q, n)] - 1;
+    __syncthreads();
+    const i64 e0 = cp[0], e1 = cp[256];
+    const u64 lowmask = rem_bits >= 64 ? ~0ull : ((1ull << rem_bits) - 1ull);
+    for (i64 e = e0 + t; e < e1; e += 256) {
+        int lo = 0, hi = 256;  // invariant cp[lo] <= e < cp[hi]
+#pragma unroll
+        for (int step = 0; step < 8; step++) {
+            const int mid = (lo + hi) >> 1;
+            if (cp[mid] <= e)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const u64 kk = ((u64)(c0 + lo) << L.rb) | (u64)(rowval[e] - 1);
+        if constexpr (K32)
+            static_cast<u32 *>(keys_out)[e] = (u32)(kk & lowmask);
+        else
+            static_cast<u64 *>(keys_out)[e] = (kk << ESP_TAG_BITS) | (u64)ESP_COO;
+    }
+}
+// start of segment s in the stored CSC: the first entry of column s << clb (columns behind the last: nnz)
+__global__ void csc_piece_starts_k(const i64 *__restrict__ colptr, i64 n, int clb, i64 S, i64 *__restrict__ pstart) {
+    const i64 s = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > S) return;
+    const i64 c = (s << clb) < n ? (s << clb) : n;
+    pstart[s] = colptr[c] - 1;
+}
+int32_t flush_rebuild(esp_handle *h, const Sorted &st, int mode, i64 *Znew, bool *served) {
+    *served = false;
+    const i64 Z0 = h->nnz, T = st.total;
+    if (mode != ESP_FLUSH_ROUTED || Z0 == 0 || T <= 0 || st.npieces != 0 || !st.seg_start || st.key_bytes != 8 || st.has_base) return ESP_OK;
+    if (windowed(h) || h->shard_user || h->win_base != 0 || h->force_path != ESP_PATH_AUTO) return ESP_OK;
+    const int clb = st.rem_bits - h->L.rb;
+    if (clb < 0 || clb > esplocal::CL_MAX_BITS || st.S < 2 || ((i64)st.S << clb) < h->n) return ESP_OK;
+    if (Z0 + T >= 0xFFFFFFF0ll) return ESP_OK;
+    // (short columns only: the register tiers of the PIECES variants; longer runs would go through their radix tier)
+    if ((double)Z0 > 10.0 * (double)h->n || (double)(Z0 + T) > 14.0 * (double)h->n) return ESP_OK;
+    CK(fix_tail(h));
+    const i64 S = st.S;
+    CK(ensure(h, h->newkey, sizeof(u64) * (size_t)Z0));
+    const size_t o_ps = 256 * 8;
+    CK(ensure(h, h->piecetab, o_ps + sizeof(i64) * 2 * (size_t)(S + 1)));
+    CK(ensure(h, h->misc, 256));
+    char *TB = (char *)h->piecetab.p;
+    i64 *pstart = (i64 *)(TB + o_ps);
+    unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
+    const void *tab[4] = {h->newkey.p, st.sk, h->nzval.p, st.sv};
+    const bool k32 = st.rem_bits <= 32;  // (the stored piece as 4-byte keys of kind COO: the bucket kernel's P32 piece format)
+    {
+        Span sp(h, ESP_ST_MERGE);
+        if (k32)
+            hipLaunchKernelGGL(csc_keys_k<true>, dim3(grid_for(h->n, 256)), dim3(256), 0, h->stream, (const i64 *)h->colptr.p, (const i64 *)h->rowval.p,
+                               h->n, h->L, st.rem_bits, h->newkey.p);
+        else
+            hipLaunchKernelGGL(csc_keys_k<false>, dim3(grid_for(h->n, 256)), dim3(256), 0, h->stream, (const i64 *)h->colptr.p, (const i64 *)h->rowval.p,
+                               h->n, h->L, st.rem_bits, h->newkey.p);
+        hipLaunchKernelGGL(csc_piece_starts_k, dim3(grid_for(S + 1, 256)), dim3(256), 0, h->stream, (const i64 *)h->colptr.p, h->n, clb, S, pstart);
+        sp.add(2);
+    }
+    HIPCK(h, hipMemcpyAsync(TB, tab, sizeof(tab), hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemcpyAsync(pstart + (S + 1), st.seg_start, sizeof(i64) * (size_t)(S + 1), hipMemcpyDeviceToDevice, h->stream));
+    HIPCK(h, hipMemsetAsync(d_maxlen, 0, 16, h->stream));
+    hipLaunchKernelGGL(piece_totals_k, dim3(grid_for(S, 256)), dim3(256), 0, h->stream, (const i64 *)pstart, 2, S, d_maxlen, d_maxlen + 1);
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_maxlen, 16, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));  // (tab is read by the copy above)
+    const i64 merged = (i64)h->pin_scalar[0];
+    if (merged > (i64)esplocal::CAP || h->pin_scalar[1] != 0) return ESP_OK;  // (the caller's look-up + join path takes any segment)
+    HIPCK(h, hipMemsetAsync((u32 *)h->misc.p + 60, 0, 4, h->stream));
+    Sorted sp2 = st;
+    sp2.seg_start = nullptr;
+    sp2.npieces = 2;
+    sp2.all_update = false;
+    sp2.ptab = (const void *const *)TB;
+    sp2.pstart = pstart;
+    sp2.maxlen = merged;
+    sp2.total = -1;
+    sp2.has_base = true;
+    sp2.base = h->win_base;
+    sp2.expect_hits = -1;
+    if (k32) {
+        sp2.p32_piece = 0;
+        sp2.p32_lo = 0;
+        sp2.kind = ESP_COO;
+    }
+    CK(ensure(h, h->keys2, sizeof(u64) * (size_t)(Z0 + T)));
+    CK(ensure(h, h->vals2, sizeof(double) * (size_t)(Z0 + T)));
+    // the bucket kernel writes colptr itself: into the second array (a failed flush leaves the stored matrix as it was)
+    CK(ensure(h, h->colptr2, sizeof(i64) * (size_t)(h->n + 1)));
+    std::swap(h->colptr, h->colptr2);
+    h->nnz = 0;  // (a fresh matrix to everything below: the stored entries are pending entries of piece 0 now)
+    i64 Ztot = 0;
+    const int32_t rc = flush_local(h, sp2, mode, &Ztot);
+    if (rc != ESP_OK) {
+        std::swap(h->colptr, h->colptr2);
+        h->nnz = Z0;
+        h->tail_stale = false;
+        h->ones_pending = false;
+        return rc;
+    }
+    *Znew = Ztot - Z0;
+    *served = true;
+    return ESP_OK;
+}
+
 extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int32_t *pattern_changed) {
     if (!h) return ESP_ERR_INVALID;
     if (mode != ESP_FLUSH_ROUTED && mode != ESP_FLUSH_PLUS) FAIL(h, ESP_ERR_INVALID, "esp_flush: mode");
@@ -684,6 +816,7 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         (void)hipEventRecord(fa, h->stream);
     }
     i64 Zn = 0;
+    h->last_rebuild = 0;
     bool use_local = h->force_path != ESP_PATH_GENERAL;
     if (h->ones_pending && windowed(h)) CK(fix_tail(h));  // (cannot happen: a window is declared through fix_tail)
     if (h->pre.valid) {  // the producer's partition serves this flush if nothing changed since (appends BEHIND it may have)
@@ -693,7 +826,10 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         if (!usable) CK(pending_materialize(h));
     }
     // a batch still held as sorted items goes to the fused bucket kernel only on a fresh matrix with nothing behind it
-    if (h->pre.valid && h->lazy.on && (h->nnz != 0 || h->pre.tail != 0 || !use_local)) CK(lazy_expand(h));
+    // (... or over the pattern the same mesh built, when the handle's last flush over it hit: the re-assembly form)
+    if (h->pre.valid && h->lazy.on &&
+        (h->pre.tail != 0 || !use_local || (h->nnz != 0 && !(h->seen_hits && !h->hits_off && mode == ESP_FLUSH_ROUTED))))
+        CK(lazy_expand(h));
     bool served = false, split = false, tail_direct = false;
     i64 Zsplit = 0;  // new entries of the batch's own flush
     if (h->pre.valid && h->pre.tail > 0 && h->nnz > 0 && mode == ESP_FLUSH_ROUTED && h->force_path != ESP_PATH_BATCH_TAIL_ONE_FLUSH) {
@@ -749,7 +885,11 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
             st2.local_ok = true;
             st2.maxlen = tp.maxlen;
             st2.expect_hits = 0;
-            const int32_t rc = flush_local(h, st2, mode, &Zn);
+            // (the tail opens new positions: the rebuild -- stored entries as the first piece of a fresh flush -- where it applies)
+            bool rebuilt = false;
+            int32_t rc = flush_rebuild(h, st2, mode, &Zn, &rebuilt);
+            h->last_rebuild = rebuilt ? 1 : 0;
+            if (rc == ESP_OK && !rebuilt) rc = flush_local(h, st2, mode, &Zn);
             if (rc != ESP_OK) {
                 (void)settle_offset(h);
                 return rc;

@@ -34,7 +34,10 @@ struct ItemArgs {
 };
 
 // NLOC = nodes per cell (3 / 4), DIAG: an item carries the diagonal's term (W = NLOC + 1)
-template <int SRC, int NLOC, bool DIAG>
+// HITS: group3_k's re-assembly form (a ROUTED flush of additions over the pattern the same mesh built: the sums go to
+// Args::hits_out, all-or-nothing -- bit 64 of Args::err) fed the same way: a time step of an instationary code never
+// writes its updates anywhere
+template <int SRC, int NLOC, bool DIAG, bool HITS = false>
 __global__ __launch_bounds__(THREADS, 6) void group3_items_k(Args a, ItemArgs ia) {
     constexpr int W = NLOC + (DIAG ? 1 : 0);
     constexpr int NI = ITEMS;
@@ -204,6 +207,17 @@ __global__ __launch_bounds__(THREADS, 6) void group3_items_k(Args a, ItemArgs ia
     const bool fits = n == 0 || (shape_ok && rows_ok);
     // (8: the segment is not this kernel's -- the host expands the items and runs the flush again with the other kernels)
     if (!fits && t == 0) atomicOr(a.err, !rows_ok ? (8u | 16u) : (8u | 32u));
+    if constexpr (HITS) {
+        if (n == 0 || !fits) {  // (no entries: then none of the segment's columns may hold a stored entry)
+            bool bad = false;
+            for (int q = t; q < ncl && n == 0; q += THREADS) {
+                const i64 col = c_lo + q;
+                bad = bad || (col < a.n_cols && a.csc.colptr[col + 1] != a.csc.colptr[col]);
+            }
+            if (bad) atomicOr(a.err, 64u);
+            return;
+        }
+    }
     LbState lbs;
     lb_init(lbs, 0);
     bool dense = false;
@@ -225,9 +239,9 @@ __global__ __launch_bounds__(THREADS, 6) void group3_items_k(Args a, ItemArgs ia
 #define ESP_G3I_GO(GG)                                                                                                               \
     do {                                                                                                                             \
         if (gmode == 1)                                                                                                              \
-            group_columns<GG, 8, CAPK, true, 1, true, u32, false, false>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, nullptr, &dcx, nullptr); \
+            group_columns<GG, 8, CAPK, true, 1, true, u32, false, HITS>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, nullptr, &dcx, nullptr); \
         else                                                                                                                         \
-            group_columns<GG, 8, CAPK, true, 2, true, u32, false, false>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, nullptr, &dcx, nullptr); \
+            group_columns<GG, 8, CAPK, true, 2, true, u32, false, HITS>(a, skey, sval, ccnt, ncl, rmin, hi, rowmask, nullptr, &dcx, nullptr); \
     } while (0)
         if (G == 2)
             ESP_G3I_GO(2);
@@ -240,6 +254,7 @@ __global__ __launch_bounds__(THREADS, 6) void group3_items_k(Args a, ItemArgs ia
 #undef ESP_G3I_GO
         dense = true;
     }
+    if constexpr (HITS) return;  // (the sums are in hits_out: nothing to emit)
     __syncthreads();  // the records lie dense in skey / sval; the last wave is at the look-back
     if (!dense) {  // nothing to emit (an empty segment, or one the host will run again): the chain must still go on
         if (w == 0) {

@@ -105,6 +105,7 @@ struct esp_handle {
     } lazy;
     DevBuf lazy_hold;            // esp_append_elements_host: the uploaded element matrices of a batch that stayed a list of items (the fused
                                  // bucket kernel or lazy_expand gathers from them); released by the next flush / reset / upload
+    int last_rebuild = 0;        // the last flush's tail rebuilt the matrix (flush_rebuild: the stored CSC as the first piece of a fresh flush)
     int last_lazy_items = 0;     // the last flush's bucket kernel formed its updates from item records (esp_debug_last_lazy_items)
     // The entries appended behind a batch over a STORED pattern were partitioned as they came (append_tail_partitioned):
     // pre.tail packed keys in bucket order of a plan of their own -- still a pending stream like any other (a stable
@@ -416,7 +417,7 @@ int32_t prepart_rank(esp_handle *h, PartSetup *ps);
 int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took);
 int32_t pending_materialize(esp_handle *h);
 namespace esplocal {
-bool launch_group3_items(const esp_handle::LazyItems &lz, unsigned grid, hipStream_t stream, const Args &a);  // local_j.hip
+bool launch_group3_items(const esp_handle::LazyItems &lz, unsigned grid, hipStream_t stream, const Args &a, bool hits = false);  // local_j.hip
 }
 constexpr int32_t ESP_RETRY_EXPANDED = 1000;  // flush_local to esp_flush: expand the items (lazy_expand) and call again -- never leaves the library
 int32_t lazy_expand(esp_handle *h);   // produce.hip: the expansion of a batch held as sorted items (esp_handle::LazyItems)

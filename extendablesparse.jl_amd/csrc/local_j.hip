@@ -5,7 +5,7 @@
 namespace esplocal {
 
 // false: no instantiation for this batch (the caller expands the items and takes the ordinary kernels)
-bool launch_group3_items(const esp_handle::LazyItems &lz, unsigned grid, hipStream_t stream, const Args &a) {
+bool launch_group3_items(const esp_handle::LazyItems &lz, unsigned grid, hipStream_t stream, const Args &a, bool hits) {
     ItemArgs ia;
     memset(&ia, 0, sizeof ia);
     ia.src = lz.src;
@@ -15,8 +15,12 @@ bool launch_group3_items(const esp_handle::LazyItems &lz, unsigned grid, hipStre
         ia.sorted = it.sorted_keys;
         ia.low = it.fem.L.rb + ESP_TAG_BITS;
         ia.fem = it.fem;
-        if (it.fem.dim == 2)
+        if (it.fem.dim == 2 && hits)
+            hipLaunchKernelGGL((group3_items_k<1, 3, true, true>), dim3(grid), dim3(THREADS), 0, stream, a, ia);
+        else if (it.fem.dim == 2)
             hipLaunchKernelGGL((group3_items_k<1, 3, true>), dim3(grid), dim3(THREADS), 0, stream, a, ia);
+        else if (hits)
+            hipLaunchKernelGGL((group3_items_k<1, 4, true, true>), dim3(grid), dim3(THREADS), 0, stream, a, ia);
         else
             hipLaunchKernelGGL((group3_items_k<1, 4, true>), dim3(grid), dim3(THREADS), 0, stream, a, ia);
         return true;
@@ -30,6 +34,17 @@ bool launch_group3_items(const esp_handle::LazyItems &lz, unsigned grid, hipStre
         ia.cellrec = el.cellrec;
         ia.negate = el.negate;
         const bool dg = el.diag != nullptr;
+        if (hits) {
+            if (el.nloc == 3 && dg)
+                hipLaunchKernelGGL((group3_items_k<2, 3, true, true>), dim3(grid), dim3(THREADS), 0, stream, a, ia);
+            else if (el.nloc == 3)
+                hipLaunchKernelGGL((group3_items_k<2, 3, false, true>), dim3(grid), dim3(THREADS), 0, stream, a, ia);
+            else if (dg)
+                hipLaunchKernelGGL((group3_items_k<2, 4, true, true>), dim3(grid), dim3(THREADS), 0, stream, a, ia);
+            else
+                hipLaunchKernelGGL((group3_items_k<2, 4, false, true>), dim3(grid), dim3(THREADS), 0, stream, a, ia);
+            return true;
+        }
         if (el.nloc == 3 && dg)
             hipLaunchKernelGGL((group3_items_k<2, 3, true>), dim3(grid), dim3(THREADS), 0, stream, a, ia);
         else if (el.nloc == 3)

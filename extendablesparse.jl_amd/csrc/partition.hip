@@ -592,7 +592,14 @@ int32_t append_tail_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_c
         return ESP_OK;
     const int K = window_bits(h);
     double Ee = 0.0;
-    const int pb = plan_prefix_bits(h, count, K, &Ee);
+    // (short stored columns: the tail's flush rebuilds the matrix with the stored entries as the first piece of every segment
+    // -- flush_rebuild --, so a segment must hold its columns' stored entries too, and suit the small variant of the bucket kernel)
+    const bool rebuild = h->force_path == ESP_PATH_AUTO && (double)h->nnz <= 10.0 * (double)h->n && (double)(h->nnz + count) <= 14.0 * (double)h->n;
+    const i64 cap0 = h->plan_cap;
+    if (rebuild) h->plan_cap = 6 * esplocal::THREADS;
+    int pb = plan_prefix_bits(h, rebuild ? count + h->nnz : count, K, &Ee);
+    h->plan_cap = cap0;
+    if (rebuild && (pb > 20 || K - pb < h->L.rb)) pb = plan_prefix_bits(h, count, K, &Ee);  // (no such plan: the tail by itself)
     const int shift = K - pb;
     if (pb <= 8 || pb > 20 || shift < h->L.rb || shift > esplocal::MAX_REM_BITS) return ESP_OK;
     CK(reserve_append(h, count));

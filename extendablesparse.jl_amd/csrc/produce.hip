@@ -426,7 +426,9 @@ int32_t pending_materialize(esp_handle *h) {
 bool lazy_items_wanted(const esp_handle *h, int kind) {
     if (h->force_path != ESP_PATH_AUTO && h->force_path != ESP_PATH_LATE_TOTAL) return false;
     if (kind != ESP_UPDATE && kind != ESP_RAWUPDATE) return false;
-    if (h->nnz != 0 || h->count != 0 || windowed(h) || h->shard_user) return false;
+    if (h->count != 0 || windowed(h) || h->shard_user) return false;
+    // (over a stored pattern: only when the handle's last flush over it hit -- the re-assembly form of the fused kernel)
+    if (h->nnz != 0 && !(h->seen_hits && !h->hits_off)) return false;
     if (h->g3_off || h->g3_wide) return false;  // (the handle's segments are not group3_k's plain form's)
     if (h->L.rb > 30) return false;
     return true;

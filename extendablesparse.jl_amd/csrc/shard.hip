@@ -287,6 +287,11 @@ extern "C" int32_t esp_shard_plan(esp_handle *h, int32_t nshards, int32_t self, 
     h->shard_plan.eps = entries_per_shard;
     return ESP_OK;
 }
+extern "C" int32_t esp_debug_last_rebuild(const esp_handle *h, int32_t *on) {
+    if (!h || !on) return ESP_ERR_INVALID;
+    *on = h->last_rebuild;
+    return ESP_OK;
+}
 extern "C" int32_t esp_debug_last_lazy_items(const esp_handle *h, int32_t *on) {
     if (!h || !on) return ESP_ERR_INVALID;
     *on = h->last_lazy_items;

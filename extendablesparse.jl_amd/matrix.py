@@ -712,6 +712,12 @@ class ExtendableSparseMatrix:
         self._d.ck(self._d.lib.esp_debug_last_lazy_items(self._d.h, C.byref(p)))
         return p.value
 
+    def debug_last_rebuild(self):
+        """1: the last flush rebuilt the matrix for the entries behind a re-assembly's batch (stored entries as a first piece)"""
+        p = C.c_int32()
+        self._d.ck(self._d.lib.esp_debug_last_rebuild(self._d.h, C.byref(p)))
+        return p.value
+
     def debug_last_shard_source(self):
         """1: the last esp_shard_partition moved the entries itself, 2: the producer had partitioned them"""
         p = C.c_int32()

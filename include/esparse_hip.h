@@ -440,6 +440,9 @@ typedef enum {
     ESP_PATH_NO_CELL_RECORDS = 37,   /* esp_append_elements with cells of 3 / 4 nodes: no 64-byte cell records, the expansion gathers
                                         rows and diagonal terms from the caller's arrays (as it does for other cell sizes)     */
     ESP_PATH_HOST_KEYS8 = 38,        /* esp_append_host of one kind: packed eight-byte keys over PCIe (never six-byte keys)      */
+    ESP_PATH_NO_REBUILD = 40,        /* the entries behind a re-assembly's batch never REBUILD the matrix (a fresh flush whose segments start with
+                                        the stored entries of their columns as a first piece: no look-ups, no join): always the bucket kernel
+                                        against the stored columns + the column-tiled join                                      */
     ESP_PATH_NO_LAZY_ITEMS = 39,     /* item partitions (esp_generate_fem in a shuffled order, esp_append_elements) always run their
                                         expansion at append time: the updates are stored bucket by bucket and the flush's bucket
                                         kernel reads them -- never the fused form that forms them from the sorted item records  */
@@ -483,6 +486,9 @@ int32_t esp_debug_last_local_small(const esp_handle *h, int32_t *small);
  * update stored once at its bucket position, read again by the bucket kernel -- never ran (csrc/group3_items.hpp);
  * esp_debug_force_path(39): never */
 int32_t esp_debug_last_lazy_items(const esp_handle *h, int32_t *on);
+/* 1 when the last flush REBUILT the matrix for the entries behind a re-assembly's batch (a fresh flush whose segments start
+ * with the stored entries of their columns: no look-ups against the stored columns, no join); esp_debug_force_path(40): never */
+int32_t esp_debug_last_rebuild(const esp_handle *h, int32_t *on);
 /* 1 when the last append-is-the-partition of caller-supplied triplets (esp_append_device / esp_commit of one kind on an
  * empty buffer) used the run lists of the previous assembly instead of counting its columns again: a batch of the same
  * length and kind is scattered straight away, every tile checked against its run list by the scatter kernel (a stream

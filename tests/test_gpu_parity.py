@@ -2368,10 +2368,12 @@ def test_config3_digest_128(esp):
     N = n ** 3
     d = gu.digests("digests_large.txt")["cfg3_%d" % n]
     I2, J2, V2 = gu.cfg3_new_positions(n)
-    for order in ("append_first", "generate_first", "generate_first_19", "generate_first_29"):
+    for order in ("append_first", "generate_first", "generate_first_19", "generate_first_29", "generate_first_40"):
         A = esp.ExtendableSparseMatrix(N, N)
         A.generate_fdrand(n, n, n, seed=0x5EED0002, rand_mode=1)
         A.flush()
+        if order.endswith("_40"):
+            A.debug_force_path(40)                   # (never the rebuild: the bucket kernel against the stored columns + the join)
         if order.endswith("_19"):
             A.debug_force_path(19)                   # (no batch + tail flush: packed keys, the ordinary partition)
         if order.endswith("_29"):
@@ -2389,7 +2391,9 @@ def test_config3_digest_128(esp):
         # (the bench's order: the producer's batch is flushed as it is, the new couplings as a flush of their own)
         # (8: the new couplings were partitioned as they were appended; 29 reads them as a packed tail)
         assert A.debug_last_partition() == {"generate_first": 8, "generate_first_29": 6}.get(order, A.debug_last_partition()), order
-        assert (A.debug_last_partition() in (6, 8)) == (order in ("generate_first", "generate_first_29")), (order, A.debug_last_partition())
+        assert (A.debug_last_partition() in (6, 8)) == (order in ("generate_first", "generate_first_29", "generate_first_40")), (order, A.debug_last_partition())
+        # (the couplings behind the batch REBUILD the matrix -- the stored entries as the first piece of a fresh flush: flush_rebuild)
+        assert A.debug_last_rebuild() == (1 if order == "generate_first" else 0), (order, A.debug_last_rebuild())
         arrs = hip_arrays(A)
         assert len(arrs[1]) == int(d["nnz"])
         assert gu.digest(*arrs) == d["csc"], order
@@ -2409,9 +2413,16 @@ def test_config3_digest_bench_size(esp):
     A.append(UPDATE, I2, J2, V2)
     A.flush()
     assert A.debug_last_partition() in (6, 8)   # (8: the host append arrived as one chunk and was partitioned as it came)
+    assert A.debug_last_rebuild() == (1 if A.debug_last_partition() == 8 else 0)
     arrs = hip_arrays(A)
     assert len(arrs[1]) == int(d["nnz"])
     assert gu.digest(*arrs) == d["csc"]
+    # ... and a third assembly over the rebuilt matrix: every update hits now (the in-place kernels again)
+    A.generate_fdrand(n, n, n, seed=0x5EED0012, rand_mode=1)
+    A.append(UPDATE, I2, J2, V2)
+    A.flush()
+    assert A.debug_last_rebuild() == 0 or A.nnz() == int(d["nnz"])
+    assert A.nnz() == int(d["nnz"])
 
 
 @pytest.mark.parametrize("dim,npd", [(2, 3163), (3, 216)])
@@ -3077,11 +3088,41 @@ def test_lazy_item_batches_and_everything_that_expands_them(esp, orc):
         assert A.nnznew() == 2 * len(I)
         A.flush()
         assert_csc_equal(hip_arrays(A), oracle([(RAW, (I, J, V)), (RAW, (I, J, V))]), "twice")
-        # the second assembly runs over the stored pattern (every update hits): expanded, the re-assembly kernels
+        # (a handle that met column runs above 128 -- "twice" in 3-D -- has learnt that group3_k is not for it: no items any more)
         A.append_elements(cn, em, dg)
         A.flush()
-        assert A.debug_last_lazy_items() == 0
-        assert_csc_equal(hip_arrays(A), oracle([(RAW, (I, J, V))] * 3), "over the stored pattern")
+        assert_csc_equal(hip_arrays(A), oracle([(RAW, (I, J, V))] * 3), "over the stored pattern, after twice")
+        # the second assembly runs over the stored pattern (every update hits): items again, the fused kernel's re-assembly form
+        A = esp.ExtendableSparseMatrix(nn, nn)
+        A.append_elements(cn, em, dg)
+        A.flush()
+        A.append_elements(cn, em, dg)
+        A.flush()
+        assert A.debug_last_lazy_items() == 1 and A.debug_last_local_small() == 4, (A.debug_last_lazy_items(), A.debug_last_local_small())
+        assert_csc_equal(hip_arrays(A), oracle([(RAW, (I, J, V))] * 2), "over the stored pattern")
+        # ... a third one, then one that brings NEW positions (the re-assembly form refuses: expanded, the general kernels)
+        A.append_elements(cn, em, dg)
+        A.flush()
+        assert A.debug_last_lazy_items() == 1 and A.debug_last_local_small() == 4, (A.debug_last_lazy_items(), A.debug_last_local_small())
+        assert_csc_equal(hip_arrays(A), oracle([(RAW, (I, J, V))] * 3), "re-assembly, fused")
+        # (the same mesh with shifted node numbers: mostly positions the pattern lacks)
+        A.append_elements(np.asfortranarray((cn + 7 - 1) % nn + 1), em, dg)
+        A.flush()
+        Is, Js, Vs = orc.elements_stream(np.asfortranarray((cn + 7 - 1) % nn + 1), em, dg)
+        assert_csc_equal(hip_arrays(A), oracle([(RAW, (I, J, V))] * 3 + [(RAW, (Is, Js, Vs))]), "new positions over the pattern")
+        # a time step through the kept plan (esp_append_elements_again): the same
+        P = esp.ExtendableSparseMatrix(nn, nn)
+        P.elements_keep_plan()
+        P.append_elements(cn, em, dg)
+        P.flush()
+        calls = [(RAW, (I, J, V))]
+        for step in range(3):
+            em2, dg2 = np.asfortranarray(em * (1.5 + step)), np.asfortranarray(dg * 0.5)
+            P.append_elements_again(em2, dg2)
+            P.flush()
+            calls.append((RAW, orc.elements_stream(cn, em2, dg2)))
+            assert P.debug_last_lazy_items() == 1, (step, P.debug_last_lazy_items())
+            assert_csc_equal(hip_arrays(P), oracle(calls), "time step %d" % step)
         # clone of a handle with a lazy batch: both flush to the same matrix; getindex on the pending buffer
         A = esp.ExtendableSparseMatrix(nn, nn)
         A.append_elements(cn, em, dg)
