@@ -293,6 +293,15 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
             var.g3 = allow_g3 && grp && Z0 == 0 && (keys == 1 || keys == 2) && a.cl_bits >= 0 && a.cl_bits <= esplocal::G3_CL_BITS &&
                      a.cl_bits + a.rb <= 32 && a.rb <= 30 && longest <= 128.0 && !h->g3_off && !a.no_group && !a.stop_after &&
                      h->force_path != ESP_PATH_NO_GROUP3;
+            // (packed keys of ONE known adding kind whose bits below the prefix fit 32 -- a shuffled stream of triplets after the
+            // flush's own passes: the same kernel, the keys narrowed as they are loaded; not its wide form)
+            const bool k64_ok = keys == 0 && st.key_bytes == 8 && st.npieces == 0 && st.rem_bits <= 32 && !want_wide &&
+                                (a.kind_all == ESP_UPDATE || a.kind_all == ESP_RAWUPDATE) && h->force_path == ESP_PATH_AUTO;
+            if (!var.g3 && k64_ok && allow_g3 && grp && Z0 == 0 && a.cl_bits >= 0 && a.cl_bits <= esplocal::G3_CL_BITS && a.cl_bits + a.rb <= 32 &&
+                a.rb <= 30 && longest <= 128.0 && !h->g3_off && !a.no_group && !a.stop_after) {
+                var.g3 = var.g3k64 = true;
+                a.kind32 = (u32)a.kind_all;
+            }
             var.g3wide = var.g3 && want_wide;
             used_g3 = used_g3 || var.g3;
             if (st.lazy) {  // sorted ITEM records: group3_k's fused form (group3_items.hpp) or nothing

@@ -22,7 +22,9 @@ namespace esplocal {
 // A segment the plain kernel refuses for its rows ALONE reports bit 16 beside bit 8: the host then takes this one.
 // HITS: the re-assembly form (group_columns<..., HITS>): a ROUTED flush of additions over a stored pattern the same mesh built;
 // the new values go to Args::hits_out, all-or-nothing (bit 64 of Args::err: some column is not what the batch covers).
-template <int KEYS, int NI = ITEMS, bool WIDE = false, bool HITS = false>
+// K64: the segment's keys are PACKED 8-byte keys of one known kind (Args::kind32) whose bits below the prefix fit 32 -- what the
+// flush's own radix passes leave of a shuffled stream of caller-supplied triplets: the load turns them into the 32-bit form
+template <int KEYS, int NI = ITEMS, bool WIDE = false, bool HITS = false, bool K64 = false>
 __global__ __launch_bounds__(THREADS, WIDE ? 4 : NI == 6 ? 8 : 6) void group3_k(Args a) {
     static_assert(KEYS == 1 || KEYS == 2, "4-byte keys of one kind");
     static_assert(NI == ITEMS || NI == 6, "4096 or 3072 entries per segment");
@@ -73,8 +75,13 @@ __global__ __launch_bounds__(THREADS, WIDE ? 4 : NI == 6 ? 8 : 6) void group3_k(
     {
         const u32 *k32 = reinterpret_cast<const u32 *>(a.keys_in);
         double vraw[NI];
+        if constexpr (K64) {
 #pragma unroll
-        for (int i = 0; i < NI; i++) k[i] = k32[lbeg + min(wbase + i * ESP_WAVE, nlast)];
+            for (int i = 0; i < NI; i++) k[i] = (u32)((a.keys_in[lbeg + min(wbase + i * ESP_WAVE, nlast)] >> ESP_TAG_BITS) - hi);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NI; i++) k[i] = k32[lbeg + min(wbase + i * ESP_WAVE, nlast)];
+        }
 #pragma unroll
         for (int i = 0; i < NI; i++) vraw[i] = a.vals_in[lbeg + min(wbase + i * ESP_WAVE, nlast)];
         u32 rmin = ~0u, rmax = 0u;

@@ -89,6 +89,7 @@ struct Variant {
     bool g3 = false;      // ... the group tier as a kernel of its own with three workgroups per CU (group3.hpp)
     bool g3hits = false;  // ... its re-assembly form: additions over a stored pattern the same mesh built (all-or-nothing, see group_columns)
     bool g3wide = false;  // ... its form for segments whose rows spread over more than 2^18 (two sorts per run, two workgroups per CU)
+    bool g3k64 = false;   // ... fed packed 8-byte keys of one known kind whose bits below the prefix fit 32 (the radix passes' output)
 };
 // enqueues the kernel; false when the combination has no instantiation
 bool launch(const Variant &v, unsigned grid, hipStream_t stream, const Args &a);

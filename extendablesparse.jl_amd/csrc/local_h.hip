@@ -26,6 +26,13 @@ bool launch_group3(const Variant &v, unsigned grid, hipStream_t stream, const Ar
             return false;
         return true;
     }
+    if (v.g3k64) {  // (packed keys of one kind: Args::kind32 says which)
+        if (a.kind32 == (u32)ESP_UPDATE)
+            hipLaunchKernelGGL((group3_k<2, ITEMS, false, false, true>), dim3(grid), dim3(THREADS), 0, stream, a);
+        else
+            hipLaunchKernelGGL((group3_k<1, ITEMS, false, false, true>), dim3(grid), dim3(THREADS), 0, stream, a);
+        return true;
+    }
     if (v.keys == 1) {
         hipLaunchKernelGGL((group3_k<1>), dim3(grid), dim3(THREADS), 0, stream, a);
         return true;
