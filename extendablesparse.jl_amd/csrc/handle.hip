@@ -370,6 +370,8 @@ int32_t pack_device(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const d
         if (took) return ESP_OK;
         CK(append_tail_partitioned(h, d_rows, d_cols, d_vals, kind_all, op, count, &took));  // (behind a batch over a stored pattern)
         if (took) return ESP_OK;
+        CK(append_first_pass(h, d_rows, d_cols, d_vals, kind_all, op, count, &took));  // (a shuffled stream: the first radix pass of its flush, from the caller's arrays)
+        if (took) return ESP_OK;
     }
     CK(reserve_append(h, count));
     h->pin_scalar[0] = ~0ull;

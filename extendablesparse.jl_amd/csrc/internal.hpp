@@ -132,6 +132,18 @@ struct esp_handle {
     // the grid, the node range and the plan alone -- not of seed, values or kind -- so an assembly that repeats the previous
     // one (a time loop: reset!, fdrand!, flush!) goes straight to the PART launch: no COUNT launch, no ranking launches, no
     // host round trip for their flags.  Dropped by whatever rewrites the tables (chunk_arrays, sort_msd, release_buffers).
+    // A caller's triplets of one kind on an empty buffer that are NOT a pre-sorted stream (a shuffled assembly): the first radix
+    // pass of their flush ran while they were appended (append_first_pass: keys formed from rows / cols on the fly, values read
+    // where the caller holds them -- no packed copy in stream order is written and read again).  The buffer holds packed keys in
+    // the order of that pass -- a stable permutation of the stream: to everybody who does not know, an ordinary pending buffer --
+    // and sort_msd resumes behind it (segment / tile tables in seg[cur] / tilef[cur]).  Dropped by pending_changed.
+    struct PrePass {
+        bool valid = false;
+        i64 count = 0, maxlen = 0;
+        int K = 0, planned = 0, npass = 0, bits0 = 0, cur = 0, S = 0;
+        u64 base = 0, span = 0;
+        double Ee = 0.0;
+    } prepass;
     struct GenPlan {
         bool valid = false;
         i64 nx = 0, ny = 0, nz = 0, g0 = 0, g1 = 0, E = 0;
@@ -270,6 +282,7 @@ static inline void pending_changed(esp_handle *h) {
         h->pre.tail = h->count - h->pre.E;
     else
         h->pre.valid = false, h->lazy.on = false;
+    h->prepass.valid = false;
     h->pre_keep = false;
     h->tailpart.valid = false;  // (append_tail_partitioned sets it after this call)
 }
@@ -438,6 +451,7 @@ int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u64 *kou
                              i64 *seg_out, u64 *tile_first_out, bool *tiles_ready, bool *ok, i64 *maxlen_out,
                              const MultiWin *mw = nullptr, int mw_shift = 0, bool allow_k32 = false, int *key_bytes_out = nullptr,
                              i64 E_in = -1, const RawSource *raw = nullptr);
+int32_t append_first_pass(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const double *d_vals, int kind, int op, i64 count, bool *took);  // partition.hip
 int32_t append_tail_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const double *d_vals, int kind, int op, i64 count,
                                  bool *took);
 int32_t append_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const double *d_vals, int kind, int op, i64 count,

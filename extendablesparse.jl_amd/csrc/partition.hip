@@ -13,7 +13,10 @@ int32_t partition_pass(esp_handle *h, espradix::Pass &p, i64 max_tiles) {
     HIPCK(h, hipMemsetAsync(p.hist, 0, sizeof(u64) * (size_t)hn, h->stream));
     {
         Span sp(h, ESP_ST_HIST);
-        hipLaunchKernelGGL(espradix::tile_hist_k, dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
+        if (p.raw_cols)
+            hipLaunchKernelGGL(espradix::tile_hist_raw_k, dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
+        else
+            hipLaunchKernelGGL(espradix::tile_hist_k, dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
         sp.add(1);
     }
     {
@@ -22,7 +25,11 @@ int32_t partition_pass(esp_handle *h, espradix::Pass &p, i64 max_tiles) {
     }
     {
         Span sp(h, ESP_ST_SCATTER);
-        if (p.keys_only && p.bits > 8)
+        if (p.raw_cols && p.bits > 8)
+            hipLaunchKernelGGL((espradix::scatter_k<true, false, true>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
+        else if (p.raw_cols)
+            hipLaunchKernelGGL((espradix::scatter_k<false, false, true>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
+        else if (p.keys_only && p.bits > 8)
             hipLaunchKernelGGL((espradix::scatter_k<true, true>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
         else if (p.keys_only)
             hipLaunchKernelGGL((espradix::scatter_k<false, true>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
@@ -643,9 +650,115 @@ int32_t append_tail_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_c
     return ESP_OK;
 }
 
+// the planned passes of sort_msd over E entries: prefix bits and number of passes
+static void plan_passes(const esp_handle *h, i64 E, int K, int *planned_out, int *npass_out, double *Ee_out) {
+    int planned = plan_prefix_bits(h, E, K, Ee_out);
+    const bool fixed_bits = h->plan_bits > 0;
+    if (fixed_bits) planned = std::min(h->plan_bits, K);  // (an item partition that leaves the last bits to its expansion)
+    // one bit short of a whole number of 8-bit passes: an average fill of up to 95 % is worth
+    // trying with one pass less (the longest segment is checked after the planned passes and a
+    // further pass is added only if a segment really overflows)
+    if (!fixed_bits && planned > 8 && planned % 8 == 1 && *Ee_out / (double)((i64)1 << (planned - 1)) <= 0.95 * (double)seg_cap(h)) planned--;
+    // (digits of 9 bits only where they save a whole pass -- 17 or 18 bits in two passes: a tile then holds 8 entries per
+    // digit instead of 16; force_path 23: never)
+    const int npass8 = (planned + 7) / 8, npass9 = (planned + espradix::MAX_BITS - 1) / espradix::MAX_BITS;
+    *npass_out = (npass9 < npass8 && h->force_path != ESP_PATH_EIGHT_BIT_PASSES) ? npass9 : npass8;
+    *planned_out = planned;
+}
+
+// esp_append_device / esp_commit of ONE kind on an EMPTY buffer whose stream is no pre-sorted one (append_partitioned gave up: a
+// shuffled assembly handed over as triplets): the FIRST radix pass of the flush runs now, straight from the caller's arrays --
+// a histogram over the columns, then a scatter that forms key and value and stores them in the order of that pass.  What used to
+// be pack (24 B read, 16 B written) + histogram (8 B) + scatter (16 B + 16 B) per entry is 8 B + 24 B read, 16 B written; the
+// buffer holds packed keys -- a stable permutation of the stream: an ordinary pending buffer to whoever does not know -- and
+// sort_msd resumes behind the pass (esp_handle::PrePass).  *took = false: not applicable, the caller packs in stream order.
+int32_t append_first_pass(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const double *d_vals, int kind, int op, i64 count, bool *took) {
+    *took = false;
+    if (h->count != 0 || count < ((i64)1 << 18) || count >= 0xFFFFFFF0ll || h->shard_user || windowed(h) || h->force_path != ESP_PATH_AUTO) return ESP_OK;
+    const int K = window_bits(h);
+    int planned = 0, npass = 0;
+    double Ee = 0.0;
+    plan_passes(h, count, K, &planned, &npass, &Ee);
+    if (planned < 8 || npass < 1) return ESP_OK;
+    const int bits0 = (planned + npass - 1) / npass;
+    if (K - bits0 < h->L.rb) return ESP_OK;  // (the digit must follow from the column alone)
+    CK(reserve_append(h, count));
+    h->rawplan.valid = false;
+    h->genplan.valid = false;
+    CK(ensure(h, h->misc, 256));
+    unsigned long long *d_err = (unsigned long long *)h->misc.p;
+    unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
+    u32 *d_werr = (u32 *)h->misc.p + 60;
+    h->pin_scalar[0] = ~0ull;
+    HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 8, hipMemcpyHostToDevice, h->stream));
+    HIPCK(h, hipMemsetAsync(d_maxlen, 0, 64, h->stream));
+    const i64 T = ceil_div<i64>(count, espradix::TILE);
+    CK(ensure(h, h->seg[0], sizeof(i64) * 4));
+    CK(ensure(h, h->tilef[0], sizeof(u64) * (size_t)(4 + espscan::workspace_elems(4))));
+    {
+        Span sp(h, ESP_ST_SCAN);
+        hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, (i64 *)h->seg[0].p, (i64)0, count, (i64)0, (i64)0);
+        hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, (i64 *)h->tilef[0].p, (i64)0, T, (i64)0, (i64)0);
+        sp.add(2);
+    }
+    espradix::Pass p;
+    p.keys_in = nullptr;
+    p.vals_in = d_vals;
+    p.keys_out = (u64 *)h->keys.p;
+    p.vals_out = (double *)h->vals.p;
+    p.seg_start = (const i64 *)h->seg[0].p;
+    p.tile_first = (const i64 *)h->tilef[0].p;
+    p.S = 1;
+    p.owner_P = 0;
+    p.owner_n = 1;
+    p.colshift = 0;
+    p.base = h->win_base;
+    p.span = h->win_span;
+    p.err = d_werr;
+    p.bits = bits0;
+    p.shift = K - bits0;
+    p.keys_only = 0;
+    p.raw_rows = d_rows, p.raw_cols = d_cols;
+    p.raw_m = h->m, p.raw_n = h->n;
+    p.raw_rb = h->L.rb, p.raw_kind = kind, p.raw_negate = (op == ESP_OP_SUB && kind != ESP_SET) ? 1 : 0;
+    p.raw_err = d_err;
+    CK(partition_pass(h, p, T));
+    const int S2 = 1 << bits0;
+    CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(S2 + 1)));
+    CK(ensure(h, h->tilef[1], sizeof(u64) * (size_t)(S2 + 1 + espscan::workspace_elems(S2 + 1))));
+    {
+        Span sp(h, ESP_ST_SCAN);
+        hipLaunchKernelGGL(espradix::new_segments_k, dim3(grid_for(S2 + 1, 256)), dim3(256), 0, h->stream, (const u64 *)h->hist.p,
+                           (const i64 *)h->seg[0].p, (const i64 *)h->tilef[0].p, 1, bits0, (i64 *)h->seg[1].p, count);
+        u64 *tf = (u64 *)h->tilef[1].p;
+        hipLaunchKernelGGL(espradix::seg_tiles_k, dim3(grid_for(S2 + 1, 256)), dim3(256), 0, h->stream, (const i64 *)h->seg[1].p, (i64)S2,
+                           (i64)espradix::TILE, tf, d_maxlen);
+        sp.add(2 + espscan::exclusive<u64, false>(h->stream, tf, tf, S2 + 1, tf + S2 + 1));
+    }
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipMemcpyAsync(h->pin_scalar + 1, d_maxlen, 8, hipMemcpyDeviceToHost, h->stream));
+    HIPCK(h, hipStreamSynchronize(h->stream));
+    HIPCK(h, hipGetLastError());
+    if (h->pin_scalar[0] != ~0ull)
+        FAIL(h, ESP_ERR_BOUNDS, "BoundsError: entry %llu of the batch has an index outside %lld x %lld (or a bad kind)",
+             (unsigned long long)h->pin_scalar[0], (long long)h->m, (long long)h->n);
+    note_kind(h, kind, count);
+    h->count += count;
+    pending_changed(h);
+    esp_handle::PrePass &pp = h->prepass;
+    pp.count = count, pp.maxlen = (i64)h->pin_scalar[1];
+    pp.K = K, pp.planned = planned, pp.npass = npass, pp.bits0 = bits0, pp.cur = 1, pp.S = S2;
+    pp.base = h->win_base, pp.span = h->win_span, pp.Ee = Ee;
+    pp.valid = true;
+    *took = true;
+    return ESP_OK;
+}
+
 int32_t sort_msd(esp_handle *h, Sorted *out) {
     h->rawplan.valid = false;  // (the segment tables are rewritten)
     h->genplan.valid = false;
+    const esp_handle::PrePass pre0 = h->prepass;
+    h->prepass.valid = false;
     const i64 E = h->count;
     // sort bits of the key window: (key>>2) - win_base lies in [0, win_span)
     int K = 1;
@@ -658,18 +771,15 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
     HIPCK(h, hipMemsetAsync(d_maxlen, 0, 64, h->stream));  // maxlen .. the four flag words (run_partition)
 
     double Ee = 0.0;
-    int planned = plan_prefix_bits(h, E, K, &Ee);
     const bool fixed_bits = h->plan_bits > 0;
-    if (fixed_bits) planned = std::min(h->plan_bits, K);  // (an item partition that leaves the last bits to its expansion)
-    const int planned_run = planned;  // the run-based pass takes up to 20 bits at once: no need to be tight
-    // one bit short of a whole number of 8-bit passes: an average fill of up to 95 % is worth
-    // trying with one pass less (the longest segment is checked after the planned passes and a
-    // further pass is added only if a segment really overflows)
-    if (!fixed_bits && planned > 8 && planned % 8 == 1 && Ee / (double)((i64)1 << (planned - 1)) <= 0.95 * (double)seg_cap(h)) planned--;
-    // (digits of 9 bits only where they save a whole pass -- 17 or 18 bits in two passes: a tile then holds 8 entries per
-    // digit instead of 16; force_path 23: never)
-    const int npass8 = (planned + 7) / 8, npass9 = (planned + espradix::MAX_BITS - 1) / espradix::MAX_BITS;
-    const int npass = (npass9 < npass8 && h->force_path != ESP_PATH_EIGHT_BIT_PASSES) ? npass9 : npass8;
+    int planned_run = plan_prefix_bits(h, E, K, &Ee);  // the run-based pass takes up to 20 bits at once: no need to be tight
+    if (fixed_bits) planned_run = std::min(h->plan_bits, K);
+    int planned = 0, npass = 0;
+    plan_passes(h, E, K, &planned, &npass, &Ee);
+    // the first pass ran while the entries were appended (append_first_pass): its tables stand, the loop resumes behind it
+    const bool resume = pre0.valid && pre0.count == E && h->pend_off == 0 && pre0.K == K && pre0.base == h->win_base && pre0.span == h->win_span &&
+                        !h->item_mode && !fixed_bits && h->force_path == ESP_PATH_AUTO && !h->shard_user;
+    if (resume) planned = pre0.planned, npass = pre0.npass, Ee = pre0.Ee;
 
     int cur = 0, S = 1, done = 0;
     CK(ensure(h, h->seg[0], sizeof(i64) * 4));
@@ -686,7 +796,14 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
     bool window_checked = false;
     h->last_partition = 2;
     // pre-sorted streams: the first (up to) 16 bits in ONE pass (runpart.hpp)
-    if (planned_run > 8 && h->force_path != ESP_PATH_NO_RUN_PARTITION && !h->item_mode) {
+    int passes_here = 0;
+    if (resume) {
+        cur = pre0.cur, S = pre0.S, done = pre0.bits0, pass_idx = 1;
+        tiles_ready = true;
+        maxlen = pre0.maxlen;
+        if (h->runs_skip > 0) h->runs_skip--;  // (the back-off of the run-based attempt counts flushes)
+    }
+    if (planned_run > 8 && h->force_path != ESP_PATH_NO_RUN_PARTITION && !h->item_mode && !resume) {
         if (h->runs_skip > 0) {
             h->runs_skip--;
         } else {
@@ -792,6 +909,7 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
         S = S2;
         done += bits;
         pass_idx++;
+        passes_here++;
         if (pass_idx >= npass_eff) {
             // (the longest segment and the window flag lie in one 64-byte block: one copy, one round trip)
             HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_maxlen, 64, hipMemcpyDeviceToHost, h->stream));
@@ -802,7 +920,7 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
     if (S == 1 && !tiles_ready)  // no pass at all: the buffer is the one segment
         hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, (i64 *)h->seg[0].p, (i64)0, E, (i64)0, (i64)0);
     HIPCK(h, hipGetLastError());
-    if (pass_idx > 0) {  // the partition passes clamp and report keys outside the window (d_werr: word 12 of the block read above)
+    if (passes_here > 0) {  // the partition passes clamp and report keys outside the window (d_werr: word 12 of the block read above)
         if ((u32)h->pin_scalar[6]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (partition)");
     }
     if (out->key_bytes == 4 && (pass_idx > 0 || cur != 1))

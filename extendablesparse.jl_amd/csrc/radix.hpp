@@ -53,6 +53,12 @@ struct Pass {
     int colshift;
     u64 *hist;  // [tile_first[s]*R + d*ntiles_s + tile_in_seg]; scanned in place
     int keys_only = 0;  // the records are their keys (single-word item records, femitems.hpp): no value array is read or written
+    // RAW: the FIRST pass over a caller's triplets, run while they are appended (append_first_pass, partition.hip): the keys are
+    // formed from rows / cols on the fly -- no packed stream is written in stream order and read again; vals_in = the caller's values
+    const i64 *raw_rows = nullptr, *raw_cols = nullptr;
+    i64 raw_m = 0, raw_n = 0;
+    int raw_rb = 0, raw_kind = 0, raw_negate = 0;
+    unsigned long long *raw_err = nullptr;  // atomicMin: first entry (1-based) with an index outside the matrix
 };
 
 // CHECK: report keys outside the window (the histogram kernel sees every key of a pass with the
@@ -78,6 +84,45 @@ __device__ __forceinline__ int find_segment(const i64 *__restrict__ tile_first, 
             hi = mid;
     }
     return lo;
+}
+
+// RAW first pass (one segment: the whole batch): the digit of an entry follows from its column alone (the pass's shift does not
+// reach into the row bits); columns outside the matrix are reported and counted under digit 0 (the host stops before anything
+// is appended)
+static __global__ __launch_bounds__(THREADS) void tile_hist_raw_k(Pass p) {
+    __shared__ u32 cnt[RADIX];
+    const int t = threadIdx.x;
+    const i64 tile = xcd_tile();
+    if (tile >= p.tile_first[1]) return;
+    const i64 nts = p.tile_first[1];
+    const i64 beg = tile * TILE;
+    const i64 end = min(p.seg_start[1], beg + (i64)TILE);
+    cnt[t] = 0;
+    cnt[t + THREADS] = 0;
+    __syncthreads();
+    const u32 mask = (1u << p.bits) - 1u;
+    i64 c[ITEMS];
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const i64 idx = beg + (i64)k * THREADS + t;
+        c[k] = idx < end ? p.raw_cols[idx] : 1;
+    }
+#pragma unroll
+    for (int k = 0; k < ITEMS; k++) {
+        const i64 idx = beg + (i64)k * THREADS + t;
+        if (idx < end) {
+            i64 col = c[k];
+            if (col < 1 || col > p.raw_n) {
+                atomicMin(p.raw_err, (unsigned long long)idx + 1ull);
+                col = 1;
+            }
+            atomicAdd(&cnt[digit_of<true>(p, ((u64)(col - 1) << p.raw_rb) << ESP_TAG_BITS, mask)], 1u);
+        }
+    }
+    __syncthreads();
+    const int R = 1 << p.bits;
+    if (t < R && cnt[t] != 0) p.hist[(i64)t * nts + tile] = cnt[t];
+    if (t + THREADS < R && cnt[t + THREADS] != 0) p.hist[(i64)(t + THREADS) * nts + tile] = cnt[t + THREADS];
 }
 
 static __global__ __launch_bounds__(THREADS) void tile_hist_k(Pass p) {
@@ -146,8 +191,10 @@ static __global__ __launch_bounds__(THREADS) void tile_hist_k(Pass p) {
 // NINE: digits of 9 bits (two per thread, the digit of an output slot recomputed from its key); else at most 8 bits (one
 // digit per thread, the slot's digit kept in an LDS byte): the 8-bit passes of 3-D FEM lost 5 % in the general form.
 // NOVAL: the records are 8-byte keys by themselves (Pass::keys_only): half the traffic of a pass
-template <bool NINE, bool NOVAL = false>
+// RAW: keys and values from the caller's triplets (Pass::raw_*), see tile_hist_raw_k
+template <bool NINE, bool NOVAL = false, bool RAW = false>
 static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
+    static_assert(!RAW || !NOVAL, "a raw pass moves values");
     constexpr int RDX = NINE ? RADIX : 256;
     __shared__ u64 lbuf[TILE];
     __shared__ u32 cnt[WAVES][RDX];
@@ -181,16 +228,39 @@ static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
     u64 key[ITEMS];
     double val[ITEMS];
     const i64 wbase = beg + (i64)w * (ESP_WAVE * ITEMS) + lane;
+    if constexpr (RAW) {
+        i64 rr[ITEMS], cc[ITEMS];
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        const i64 idx = wbase + k * ESP_WAVE;
-        key[k] = idx < end ? p.keys_in[idx] : ~0ull;
+        for (int k = 0; k < ITEMS; k++) {
+            const i64 idx = wbase + k * ESP_WAVE;
+            rr[k] = idx < end ? p.raw_rows[idx] : 1;
+            cc[k] = idx < end ? p.raw_cols[idx] : 1;
+        }
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const i64 idx = wbase + k * ESP_WAVE;
+            i64 r = rr[k], c = cc[k];
+            if (idx < end && (r < 1 || r > p.raw_m || c < 1 || c > p.raw_n)) {
+                atomicMin(p.raw_err, (unsigned long long)idx + 1ull);
+                r = 1, c = 1;  // (a valid key: the host stops before the batch is counted in)
+            }
+            key[k] = idx < end ? (((((u64)(c - 1) << p.raw_rb) | (u64)(r - 1)) << ESP_TAG_BITS) | (u64)p.raw_kind) : ~0ull;
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const i64 idx = wbase + k * ESP_WAVE;
+            key[k] = idx < end ? p.keys_in[idx] : ~0ull;
+        }
     }
     if constexpr (!NOVAL) {
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
             const i64 idx = wbase + k * ESP_WAVE;
             val[k] = idx < end ? p.vals_in[idx] : 0.0;
+            if constexpr (RAW) {
+                if (p.raw_negate) val[k] = -val[k];
+            }
         }
     } else {
 #pragma unroll
