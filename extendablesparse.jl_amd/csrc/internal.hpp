@@ -7,7 +7,8 @@
 //   flush.hip      esp_flush: bucket kernel launch, join with a stored CSC, batch + tail, general path
 //   shard.hip      column shards (esp_shard_*) and the group API (group.hpp: exchange policy + RCCL transport)
 //   consumers.hip  what reads or edits the assembled CSC: getindex, dropzeros, pattern hash, mul!, Dirichlet, Jacobi / ILU0
-//   local_*.hip    the instantiations of the bucket kernel (local.hpp; local_h.hip: group3.hpp, the group tier with three workgroups per CU)
+//   local_*.hip    the instantiations of the bucket kernel (local.hpp; local_h.hip: group3.hpp, the group tier with three workgroups per CU;
+//                  local_j.hip: group3_items.hpp, the same fed with the item records of an element-level batch)
 #pragma once
 #include <stdio.h>
 #include <stdlib.h>

@@ -169,8 +169,11 @@ int32_t esp_generate_fdrand_range(esp_handle *h, int64_t nx, int64_t ny, int64_t
  * that order.  On an EMPTY buffer the library partitions one 8-byte record per (cell, local column) instead of the updates
  * and stores every update once, at its bucket position (the flush starts at the bucket kernel: esp_debug_last_partition 4);
  * a cell that names a node twice, a non-empty buffer or a column window: the updates are appended in stream order.
- * A node number outside 1..min(m,n): ESP_ERR_BOUNDS, nothing is appended.  The device form reads its arrays on the handle's
- * stream (they must stay valid until esp_synchronize or the next flush returned). */
+ * A node number outside 1..min(m,n): ESP_ERR_BOUNDS, nothing is appended.  The device form reads d_elmat (and, without cell
+ * records, d_cellnodes / d_diag) AT FLUSH TIME: on a fresh matrix -- and over the pattern the same mesh built -- the batch stays a
+ * list of sorted (cell, local column) items and the flush's bucket kernel forms the updates itself (csrc/group3_items.hpp: the
+ * updates are never written to the append buffer).  The arrays must stay valid and unchanged until the handle's next esp_flush
+ * (or esp_reset / esp_clear_pending / esp_destroy) has returned; the host form keeps its own device copy that long. */
 int32_t esp_append_elements(esp_handle *h, int32_t nloc, int64_t ncells, const int64_t *d_cellnodes,
                             const double *d_elmat, const double *d_diag, int32_t kind, int32_t op);
 int32_t esp_append_elements_host(esp_handle *h, int32_t nloc, int64_t ncells, const int64_t *cellnodes,
@@ -184,6 +187,7 @@ int32_t esp_append_elements_host(esp_handle *h, int32_t nloc, int64_t ncells, co
  * ESP_ERR_STATE.  Together with the flush over the stored pattern (every update hits) a time step costs less than the
  * first assembly. */
 int32_t esp_elements_keep_plan(esp_handle *h, int32_t on);
+/* (d_elmat as for esp_append_elements: read at flush time, valid until the next esp_flush has returned) */
 int32_t esp_append_elements_again(esp_handle *h, const double *d_elmat, const double *d_diag, int32_t kind, int32_t op);
 int32_t esp_append_elements_again_host(esp_handle *h, const double *elmat, const double *diag, int32_t kind, int32_t op);
 /* The element data of esp_generate_fem's grid as DEVICE arrays, for the cells at stream positions [cell_begin, cell_end):
