@@ -837,7 +837,8 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
     // a batch still held as sorted items goes to the fused bucket kernel only on a fresh matrix with nothing behind it
     // (... or over the pattern the same mesh built, when the handle's last flush over it hit: the re-assembly form)
     if (h->pre.valid && h->lazy.on &&
-        (h->pre.tail != 0 || !use_local || (h->nnz != 0 && !(h->seen_hits && !h->hits_off && mode == ESP_FLUSH_ROUTED))))
+        (h->pre.tail != 0 || !use_local || windowed(h) || h->shard_user || h->part_assembled ||
+         (h->nnz != 0 && !(h->seen_hits && !h->hits_off && mode == ESP_FLUSH_ROUTED))))
         CK(lazy_expand(h));
     bool served = false, split = false, tail_direct = false;
     i64 Zsplit = 0;  // new entries of the batch's own flush

@@ -412,6 +412,37 @@ template <typename F>
 __device__ __forceinline__ void fem_cell_updates(const FemArgs &a, i64 p, F emit) {
     fem_updates_of_cell(a, (i64)fem_cell_at(a, p), emit);
 }
+// n / d for several numerators over ONE denominator, bit for bit the IEEE quotient: the compiler's f64 division is
+// div_scale x 2, rcp, four fma refining the reciprocal, a product, a remainder fma, div_fmas, div_fixup -- of which the
+// reciprocal and its refinement depend on d alone whenever div_scale does not scale (both operands well inside the normal
+// range: what a cell of a mesh gives).  SharedDiv keeps them; quot() is the product, the exact remainder and the final fma --
+// the very operations div_fmas / div_fixup perform on unscaled, finite operands.  Operands outside [2^-400, 2^400] (or a zero
+// / non-finite denominator): the plain division.  The nine gradient components of a tetrahedron share their determinant.
+struct SharedDiv {
+    double d, r;
+    bool fast;
+    __device__ __forceinline__ static bool mid(double x) {
+        const double ax = fabs(x);
+        return ax > 0x1.0p-400 && ax < 0x1.0p400;
+    }
+    __device__ __forceinline__ explicit SharedDiv(double den) : d(den) {
+        fast = mid(den);
+        const double r0 = __builtin_amdgcn_rcp(den);
+        const double e0 = fma(-den, r0, 1.0);
+        const double r1 = fma(r0, e0, r0);
+        const double e1 = fma(-den, r1, 1.0);
+        r = fma(r1, e1, r1);
+    }
+    __device__ __forceinline__ double quot(double n) const {
+        if (fast && (n == 0.0 || mid(n))) {
+            const double q0 = n * r;
+            const double rem = fma(-d, q0, n);
+            return fma(rem, r, q0);
+        }
+        return n / d;
+    }
+};
+
 // vertices' node numbers, gradients of the P1 basis functions and the volume of one cell
 __device__ __forceinline__ void fem_cell_geometry(const FemArgs &a, i64 cell, i64 (&nodes)[4], double (&G)[4][3], double *vol_out) {
     const int dim = a.dim;
@@ -434,10 +465,11 @@ __device__ __forceinline__ void fem_cell_geometry(const FemArgs &a, i64 cell, i6
         const double aa = X[1][0] - X[0][0], bb = X[2][0] - X[0][0];
         const double cc = X[1][1] - X[0][1], dd = X[2][1] - X[0][1];
         det = aa * dd - bb * cc;
-        G[1][0] = dd / det;
-        G[1][1] = -bb / det;
-        G[2][0] = -cc / det;
-        G[2][1] = aa / det;
+        const SharedDiv by(det);
+        G[1][0] = by.quot(dd);
+        G[1][1] = by.quot(-bb);
+        G[2][0] = by.quot(-cc);
+        G[2][1] = by.quot(aa);
         G[0][0] = -(G[1][0] + G[2][0]);
         G[0][1] = -(G[1][1] + G[2][1]);
     } else {
@@ -450,15 +482,16 @@ __device__ __forceinline__ void fem_cell_geometry(const FemArgs &a, i64 cell, i6
         const double c01 = J[1][0] * J[2][2] - J[1][2] * J[2][0];
         const double c02 = J[1][0] * J[2][1] - J[1][1] * J[2][0];
         det = J[0][0] * c00 - J[0][1] * c01 + J[0][2] * c02;
-        G[1][0] = c00 / det;
-        G[1][1] = -(J[0][1] * J[2][2] - J[0][2] * J[2][1]) / det;
-        G[1][2] = (J[0][1] * J[1][2] - J[0][2] * J[1][1]) / det;
-        G[2][0] = -c01 / det;
-        G[2][1] = (J[0][0] * J[2][2] - J[0][2] * J[2][0]) / det;
-        G[2][2] = -(J[0][0] * J[1][2] - J[0][2] * J[1][0]) / det;
-        G[3][0] = c02 / det;
-        G[3][1] = -(J[0][0] * J[2][1] - J[0][1] * J[2][0]) / det;
-        G[3][2] = (J[0][0] * J[1][1] - J[0][1] * J[1][0]) / det;
+        const SharedDiv by(det);
+        G[1][0] = by.quot(c00);
+        G[1][1] = by.quot(-(J[0][1] * J[2][2] - J[0][2] * J[2][1]));
+        G[1][2] = by.quot(J[0][1] * J[1][2] - J[0][2] * J[1][1]);
+        G[2][0] = by.quot(-c01);
+        G[2][1] = by.quot(J[0][0] * J[2][2] - J[0][2] * J[2][0]);
+        G[2][2] = by.quot(-(J[0][0] * J[1][2] - J[0][2] * J[1][0]));
+        G[3][0] = by.quot(c02);
+        G[3][1] = by.quot(-(J[0][0] * J[2][1] - J[0][1] * J[2][0]));
+        G[3][2] = by.quot(J[0][0] * J[1][1] - J[0][1] * J[1][0]);
 #pragma unroll
         for (int d = 0; d < 3; d++) G[0][d] = -((G[1][d] + G[2][d]) + G[3][d]);
     }

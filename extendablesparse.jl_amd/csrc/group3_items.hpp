@@ -31,14 +31,23 @@ struct ItemArgs {
     const double *elmat;    // src 2: Float64 nloc x nloc x ncells
     const char *cellrec;    // src 2: 64-byte cell records (rows as four u32 | the cell's diag values)
     int negate;             // src 2: op = '-'
+    // MULTI (src 2): the launch's tickets are the non-empty (buffer, segment) pairs of several buffers
+    const u32 *vlist;       // pair of ticket v: buffer << MULTI_SEG_BITS | segment
+    const MultiBuf *mbuf;   // per buffer: sorted items, segment table, element matrices, cell records
+    i64 *counts;            // records the pair emitted: counts[buffer * (S_real + 1) + segment]
+    int S_real;             // segments per buffer
 };
 
 // NLOC = nodes per cell (3 / 4), DIAG: an item carries the diagonal's term (W = NLOC + 1)
 // HITS: group3_k's re-assembly form (a ROUTED flush of additions over the pattern the same mesh built: the sums go to
 // Args::hits_out, all-or-nothing -- bit 64 of Args::err) fed the same way: a time step of an instationary code never
 // writes its updates anywhere
-template <int SRC, int NLOC, bool DIAG, bool HITS = false>
+// MULTI: Base.sum over several buffers (esp_flush_sum): ticket v is the pair vlist[v] = (buffer, segment); the folded records of
+// the pair go out as PACKED keys of kind COO + values at the look-back offset -- pair after pair, buffer-major: the pieces of the
+// combine flush, which reads segment s as the concatenation of every buffer's records for it (no CSC per buffer, no partition)
+template <int SRC, int NLOC, bool DIAG, bool HITS = false, bool MULTI = false>
 __global__ __launch_bounds__(THREADS, 6) void group3_items_k(Args a, ItemArgs ia) {
+    static_assert(!MULTI || (SRC == 2 && !HITS), "several buffers: element arrays, fresh folds");
     constexpr int W = NLOC + (DIAG ? 1 : 0);
     constexpr int NI = ITEMS;
     constexpr int CAPK = THREADS * NI;
@@ -60,7 +69,9 @@ __global__ __launch_bounds__(THREADS, 6) void group3_items_k(Args a, ItemArgs ia
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     constexpr int WIN = 64;
     const i64 w0 = max((i64)0, a.first + (i64)blockIdx.x - WIN / 2);
-    if (t <= WIN + 1 && w0 + t <= (i64)a.S) s_win[t] = a.seg_start[w0 + t];
+    if constexpr (!MULTI) {
+        if (t <= WIN + 1 && w0 + t <= (i64)a.S) s_win[t] = a.seg_start[w0 + t];
+    }
     if (t == 0) {
         s_seg = (int)atomicAdd(a.ticket, 1u);
         s_early = 0;
@@ -71,13 +82,27 @@ __global__ __launch_bounds__(THREADS, 6) void group3_items_k(Args a, ItemArgs ia
     const int ncl = 1 << a.cl_bits;
     for (int q = t; q <= ncl; q += THREADS) ccnt[q] = 0;
     __syncthreads();
-    const int s = esp_uniform_i32(s_seg);
-    if (s >= a.S) return;
+    const int vs = esp_uniform_i32(s_seg);  // the ticket: the segment's place in the look-back chain
+    if (vs >= a.S) return;
+    int s = vs, kb = 0;
+    const u64 *sorted = ia.sorted;
+    const double *elmat = ia.elmat;
+    const char *cellrec = ia.cellrec;
+    int negate = ia.negate, low = ia.low;
+    const i64 *segtab = a.seg_start;
+    if constexpr (MULTI) {
+        const u32 v = (u32)esp_uniform_i32((int)ia.vlist[vs]);
+        kb = (int)(v >> MULTI_SEG_BITS);
+        s = (int)(v & ((1u << MULTI_SEG_BITS) - 1u));
+        const MultiBuf &mb = ia.mbuf[kb];
+        sorted = mb.sorted, elmat = mb.elmat, cellrec = mb.cellrec, negate = mb.negate, segtab = mb.seg;
+        low = mb.low;
+    }
     const u32 rowmask32 = a.rb >= 32 ? ~0u : ((1u << a.rb) - 1u);
     const u64 rowmask = (1ull << a.rb) - 1ull;
-    const bool inwin = s >= w0 && (i64)s + 1 <= w0 + WIN + 1;
-    const i64 beg = esp_uniform_i64(inwin ? s_win[s - w0] : a.seg_start[s]);
-    const i64 seg_end = esp_uniform_i64(inwin ? s_win[s - w0 + 1] : a.seg_start[s + 1]);
+    const bool inwin = !MULTI && s >= w0 && (i64)s + 1 <= w0 + WIN + 1;
+    const i64 beg = esp_uniform_i64(inwin ? s_win[s - w0] : segtab[s]);
+    const i64 seg_end = esp_uniform_i64(inwin ? s_win[s - w0 + 1] : segtab[s + 1]);
     const int n = min((int)(seg_end - beg), MAXIT * W);
     const int nit = n / W;                     // (a segment holds whole items)
     const i64 ibeg = beg / W;
@@ -98,12 +123,12 @@ __global__ __launch_bounds__(THREADS, 6) void group3_items_k(Args a, ItemArgs ia
 #pragma unroll
             for (int e = 0; e < W; e++) rows[i][e] = 0;
             if (j < nit) {
-                const u64 rec = ia.sorted[ibeg + j];
-                const i64 col0 = (i64)(rec >> ia.low);
+                const u64 rec = sorted[ibeg + j];
+                const i64 col0 = (i64)(rec >> low);
                 lcol[i] = (u32)min(max(col0 - c_lo, (i64)0), (i64)(ncl - 1));
                 double *vout = sval + j * W;
                 if constexpr (SRC == 1) {
-                    const i64 cell = (i64)(rec & ((1ull << ia.low) - 1ull));
+                    const i64 cell = (i64)(rec & ((1ull << low) - 1ull));
                     espgen::fem_column_of_cell(ia.fem, cell, col0 + 1, [&](int il, int jl, i64 row, double v) {
                         const int at = jl < 0 ? il : il + (il >= jl ? 1 : 0);
 #pragma unroll
@@ -112,10 +137,10 @@ __global__ __launch_bounds__(THREADS, 6) void group3_items_k(Args a, ItemArgs ia
                         vout[at] = v;
                     });
                 } else {
-                    const u32 p = (u32)(rec & ((1ull << ia.low) - 1ull));
+                    const u32 p = (u32)(rec & ((1ull << low) - 1ull));
                     const u32 cell = p / (u32)NLOC, jl = p - cell * (u32)NLOC;
-                    const double *em = ia.elmat + (i64)p * NLOC;  // column jl of the cell's element matrix
-                    const char *cr = ia.cellrec + (i64)cell * 64;
+                    const double *em = elmat + (i64)p * NLOC;  // column jl of the cell's element matrix
+                    const char *cr = cellrec + (i64)cell * 64;
                     const u32x4 rr = *reinterpret_cast<const u32x4 *>(cr);
                     double d = 0.0;
                     if constexpr (DIAG) d = *reinterpret_cast<const double *>(cr + 16 + 8 * jl);
@@ -123,7 +148,7 @@ __global__ __launch_bounds__(THREADS, 6) void group3_items_k(Args a, ItemArgs ia
 #pragma unroll
                     for (int il = 0; il < NLOC; il++) v[il] = em[il];
                     const u32 r[4] = {rr.x, rr.y, rr.z, rr.w};
-                    if (ia.negate) {
+                    if (negate) {
                         d = -d;
 #pragma unroll
                         for (int il = 0; il < NLOC; il++) v[il] = -v[il];
@@ -235,7 +260,7 @@ __global__ __launch_bounds__(THREADS, 6) void group3_items_k(Args a, ItemArgs ia
             }
         }
         __syncthreads();
-        const DenseCtx dcx{&s_early, ctot, &lbs, s, a.late_total ? nullptr : &s_done};
+        const DenseCtx dcx{&s_early, ctot, &lbs, vs, a.late_total ? nullptr : &s_done};
 #define ESP_G3I_GO(GG)                                                                                                               \
     do {                                                                                                                             \
         if (gmode == 1)                                                                                                              \
@@ -258,16 +283,26 @@ __global__ __launch_bounds__(THREADS, 6) void group3_items_k(Args a, ItemArgs ia
     __syncthreads();  // the records lie dense in skey / sval; the last wave is at the look-back
     if (!dense) {  // nothing to emit (an empty segment, or one the host will run again): the chain must still go on
         if (w == 0) {
-            const u64 excl = lookback_wave(a, s, 0u, lane);
+            const u64 excl = lookback_wave(a, vs, 0u, lane);
             if (lane == 0) s_dst = excl;
         }
     } else if (w == WAVES - 1) {
-        const u64 excl = lb_complete(a, lbs, s, s_early, lane);
+        const u64 excl = lb_complete(a, lbs, vs, s_early, lane);
         if (lane == 0) s_dst = excl;
     }
     __syncthreads();
     const int total = dense ? (int)s_early : 0;
     const u64 dst = esp_uniform_u64(s_dst);
+    if constexpr (MULTI) {  // the pair's records as packed COO keys + values; how many: for the combine flush's piece table
+        for (int p = t; p < total; p += THREADS) {
+            const u32 key = skey[p];
+            const u64 col0 = (u64)c_lo + (u64)(key >> a.rb);
+            a.out_key[dst + p] = (((col0 << a.rb) | (u64)(key & rowmask32)) << ESP_TAG_BITS) | (u64)ESP_COO;
+            a.out_val[dst + p] = sval[p];
+        }
+        if (t == 0) ia.counts[(size_t)kb * (size_t)(ia.S_real + 1) + (size_t)s] = (i64)total;
+        return;
+    }
     // ---- coalesced stores + column-end marks (or colptr itself); a dense key is (local column << rb) | row
     const bool direct = a.colptr_out != nullptr;
     const i64 c_hi = direct ? min(c_lo + ((i64)1 << a.cl_bits), a.col_end) : c_lo;

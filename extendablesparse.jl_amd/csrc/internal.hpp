@@ -432,6 +432,8 @@ int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took);
 int32_t pending_materialize(esp_handle *h);
 namespace esplocal {
 bool launch_group3_items(const esp_handle::LazyItems &lz, unsigned grid, hipStream_t stream, const Args &a, bool hits = false);  // local_j.hip
+bool launch_group3_items_multi(int nloc, bool diag, const u32 *vlist, const MultiBuf *mbuf, i64 *counts, int S_real, unsigned grid,
+                               hipStream_t stream, const Args &a);  // local_j.hip
 }
 constexpr int32_t ESP_RETRY_EXPANDED = 1000;  // flush_local to esp_flush: expand the items (lazy_expand) and call again -- never leaves the library
 int32_t lazy_expand(esp_handle *h);   // produce.hip: the expansion of a batch held as sorted items (esp_handle::LazyItems)

@@ -77,6 +77,18 @@ struct Args {
 };
 constexpr int MAX_PIECES = 64;
 
+// Base.sum over several buffers that all hold element batches as sorted items (sum.hip: flush_sum_items): ONE launch of the fused
+// bucket kernel (group3_items.hpp, MULTI) folds every non-empty (buffer, segment) pair; per buffer it needs
+struct MultiBuf {
+    const u64 *sorted;     // the buffer's sorted item records
+    const i64 *seg;        // its segment table (S + 1 entries, in UPDATES)
+    const double *elmat;   // its element matrices
+    const char *cellrec;   // its 64-byte cell records
+    int negate;
+    int low;               // its item records' bits below the column (virtual row bits + 2)
+};
+constexpr int MULTI_SEG_BITS = 20;  // a (buffer, segment) pair as buffer << 20 | segment
+
 // which instantiation of local_k serves a flush (see the kernel's template parameters in local.hpp)
 struct Variant {
     bool fresh;   // the matrix holds no entries: rowval/nzval of the new CSC are written directly

@@ -58,4 +58,27 @@ bool launch_group3_items(const esp_handle::LazyItems &lz, unsigned grid, hipStre
     return false;
 }
 
+// Base.sum over several buffers: ONE launch over the non-empty (buffer, segment) pairs (group3_items_k<2, ., ., false, MULTI>)
+bool launch_group3_items_multi(int nloc, bool diag, const u32 *vlist, const MultiBuf *mbuf, i64 *counts, int S_real, unsigned grid,
+                               hipStream_t stream, const Args &a) {
+    ItemArgs ia;
+    memset(&ia, 0, sizeof ia);
+    ia.src = 2;
+    ia.vlist = vlist;
+    ia.mbuf = mbuf;
+    ia.counts = counts;
+    ia.S_real = S_real;
+    if (nloc == 3 && diag)
+        hipLaunchKernelGGL((group3_items_k<2, 3, true, false, true>), dim3(grid), dim3(THREADS), 0, stream, a, ia);
+    else if (nloc == 3)
+        hipLaunchKernelGGL((group3_items_k<2, 3, false, false, true>), dim3(grid), dim3(THREADS), 0, stream, a, ia);
+    else if (nloc == 4 && diag)
+        hipLaunchKernelGGL((group3_items_k<2, 4, true, false, true>), dim3(grid), dim3(THREADS), 0, stream, a, ia);
+    else if (nloc == 4)
+        hipLaunchKernelGGL((group3_items_k<2, 4, false, false, true>), dim3(grid), dim3(THREADS), 0, stream, a, ia);
+    else
+        return false;
+    return true;
+}
+
 }  // namespace esplocal

@@ -18,7 +18,182 @@ __global__ __launch_bounds__(256) void csc_as_coo_k(const i64 *__restrict__ colp
     }
 }
 
+// ---- the buffers' folds as ONE launch (every buffer holds an element batch as sorted items: esp_handle::LazyItems) ----------
+// flags[k S + s] = 1 when segment s of buffer k holds items
+__global__ __launch_bounds__(256) void pair_flags_k(const esplocal::MultiBuf *__restrict__ mb, int P, i64 S, u64 *__restrict__ flags) {
+    const i64 g = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (g > (i64)P * S) return;
+    u64 f = 0;
+    if (g < (i64)P * S) {
+        const int k = (int)(g / S);
+        const i64 s = g - (i64)k * S;
+        const i64 *seg = mb[k].seg;
+        f = (seg && seg[s + 1] > seg[s]) ? 1ull : 0ull;
+    }
+    flags[g] = f;
+}
+// the non-empty pairs in (buffer, segment) order: pos = exclusive scan of the flags
+__global__ __launch_bounds__(256) void pair_list_k(const esplocal::MultiBuf *__restrict__ mb, int P, i64 S, const u64 *__restrict__ pos,
+                                                  u32 *__restrict__ vlist) {
+    const i64 g = (i64)blockIdx.x * 256 + threadIdx.x;
+    if (g >= (i64)P * S) return;
+    const int k = (int)(g / S);
+    const i64 s = g - (i64)k * S;
+    const i64 *seg = mb[k].seg;
+    if (seg && seg[s + 1] > seg[s]) vlist[pos[g]] = ((u32)k << esplocal::MULTI_SEG_BITS) | (u32)s;
+}
+
 }  // namespace
+
+__global__ void piece_totals_k(const i64 *__restrict__ pstart, int P, i64 nb, unsigned long long *__restrict__ maxlen,
+                               unsigned long long *__restrict__ negative);  // shard.hip
+
+// Base.sum when every non-empty buffer holds ONE element-level batch that stayed a list of sorted items, all with the same plan
+// (key window, prefix bits, cell size, kind): the p folds are ONE launch of the fused bucket kernel over the non-empty
+// (buffer, segment) pairs -- buffer-major, so the records of pair (k, s) lie behind those of every earlier pair -- which emits
+// packed COO keys + values straight into dst's buffer and the number of records per pair; a scan of those numbers is the
+// piece table of the combine flush, whose bucket kernel reads segment s as the concatenation of every buffer's records for
+// it (the PIECES variants of the shard exchange: no CSC per buffer, no copy, no partition).  *served = false: not
+// applicable or refused (nothing has happened: the general path below takes the buffers as they are).
+static int32_t flush_sum_items(esp_handle *dst, esp_handle *const *xs, int p, int64_t *new_nnz, int32_t *pattern_changed, bool *served) {
+    *served = false;
+    if (p < 2 || p > esplocal::MAX_PIECES || dst->count != 0 || windowed(dst) || dst->shard_user || dst->force_path != ESP_PATH_AUTO) return ESP_OK;
+    const esp_handle *ref = nullptr;
+    i64 total_in = 0;
+    for (int k = 0; k < p; k++) {
+        const esp_handle *x = xs[k];
+        if (x->count == 0) continue;
+        const espelem::Args &el = x->lazy.el;
+        if (!x->pre.valid || !x->lazy.on || x->lazy.src != 2 || x->pre.tail != 0 || x->pre.E != x->count || x->pre.key_bytes != 4 ||
+            x->pre.mw_P != 0 || windowed(x) || x->shard_user || x->force_path != ESP_PATH_AUTO || !el.cellrec || (el.nloc != 3 && el.nloc != 4))
+            return ESP_OK;
+        if (x->kind_uniform != el.kind || x->kind_noted != x->count || (el.kind != ESP_UPDATE && el.kind != ESP_RAWUPDATE)) return ESP_OK;
+        if (!ref) ref = x;
+        const espelem::Args &e0 = ref->lazy.el;
+        if (x->pre.K != ref->pre.K || x->pre.pb != ref->pre.pb || x->pre.base != ref->pre.base || x->pre.span != ref->pre.span ||
+            el.nloc != e0.nloc || (el.diag != nullptr) != (e0.diag != nullptr) || el.kind != e0.kind || x->L.rb != dst->L.rb)
+            return ESP_OK;
+        total_in += x->count;
+    }
+    if (!ref || ref->pre.base != dst->win_base || ref->pre.span != dst->win_span) return ESP_OK;
+    const int K = ref->pre.K, pb = ref->pre.pb, rem = K - pb, clb = rem - dst->L.rb;
+    if (pb > esplocal::MULTI_SEG_BITS || clb < 0 || clb > esplocal::G3_CL_BITS || clb + dst->L.rb > 32 || dst->L.rb > 30 || rem > 32) return ESP_OK;
+    const i64 S = (i64)1 << pb, PS = (i64)p * S;
+    if (PS > ((i64)1 << 24) || total_in >= 0xFFFFFFF0ll) return ESP_OK;
+    const espelem::Args &e0 = ref->lazy.el;
+    // ---- tables: per-buffer arguments | the pair list; flags / positions
+    std::vector<esplocal::MultiBuf> mb((size_t)p);
+    for (int k = 0; k < p; k++) {
+        const esp_handle *x = xs[k];
+        esplocal::MultiBuf &b = mb[(size_t)k];
+        memset(&b, 0, sizeof b);
+        if (x->count == 0) continue;
+        const espelem::Args &el = x->lazy.el;
+        b.sorted = el.sorted_keys, b.seg = (const i64 *)x->seg[1].p, b.elmat = el.elmat, b.cellrec = el.cellrec;
+        b.negate = el.negate, b.low = el.vrb + ESP_TAG_BITS;
+        HIPCK(dst, hipStreamSynchronize(x->stream));  // (the buffer's item partition has run on ITS stream)
+    }
+    const size_t o_list = 4096;
+    CK(ensure(dst, dst->heads, o_list + sizeof(u32) * (size_t)PS));
+    CK(ensure(dst, dst->hist, sizeof(u64) * (size_t)(PS + 1 + espscan::workspace_elems(PS + 1))));
+    CK(ensure(dst, dst->misc, 256));
+    esplocal::MultiBuf *d_mb = (esplocal::MultiBuf *)dst->heads.p;
+    u32 *d_list = (u32 *)((char *)dst->heads.p + o_list);
+    u64 *d_pos = (u64 *)dst->hist.p;
+    HIPCK(dst, hipMemcpyAsync(d_mb, mb.data(), sizeof(esplocal::MultiBuf) * (size_t)p, hipMemcpyHostToDevice, dst->stream));
+    {
+        Span sp(dst, ESP_ST_SCAN);
+        hipLaunchKernelGGL(pair_flags_k, dim3(grid_for(PS + 1, 256)), dim3(256), 0, dst->stream, d_mb, p, S, d_pos);
+        int l = 1 + espscan::exclusive<u64, false>(dst->stream, d_pos, d_pos, PS + 1, d_pos + PS + 1);
+        hipLaunchKernelGGL(pair_list_k, dim3(grid_for(PS, 256)), dim3(256), 0, dst->stream, d_mb, p, S, (const u64 *)d_pos, d_list);
+        sp.add(l + 1);
+    }
+    HIPCK(dst, hipMemcpyAsync(dst->pin_scalar, d_pos + PS, 8, hipMemcpyDeviceToHost, dst->stream));
+    HIPCK(dst, hipStreamSynchronize(dst->stream));  // (mb is read by the copy above)
+    const i64 SV = (i64)dst->pin_scalar[0];
+    if (SV <= 0 || SV > esplocal::MAX_GRID) return ESP_OK;
+    // ---- the folds: one launch; records to dst's buffer, counts to the piece table
+    CK(reserve_append(dst, total_in));
+    const size_t o_ps = 256 * 8;
+    CK(ensure(dst, dst->piecetab, o_ps + sizeof(i64) * (size_t)(p * (S + 1) + espscan::workspace_elems(p * (S + 1)))));
+    char *TB = (char *)dst->piecetab.p;
+    i64 *pstart = (i64 *)(TB + o_ps);
+    HIPCK(dst, hipMemsetAsync(pstart, 0, sizeof(i64) * (size_t)(p * (S + 1)), dst->stream));
+    const i64 n_gs = (SV >> 8) + 2;
+    const i64 G = ((SV + 2 + n_gs + 511) & ~(i64)511) - (SV + 2);
+    const i64 tick_at = SV + 2 + G + 256;
+    CK(ensure(dst, dst->segout, sizeof(u64) * (size_t)(SV + 2 + G + 512)));
+    u64 *status = (u64 *)dst->segout.p;
+    HIPCK(dst, hipMemsetAsync(status, 0, sizeof(u64) * (size_t)(SV + 2 + G + 512), dst->stream));
+    esplocal::Args a;
+    memset(&a, 0, sizeof a);
+    a.S = (int)SV;
+    a.rem_bits = rem;
+    a.base = dst->win_base;
+    a.rb = dst->L.rb;
+    a.cl_bits = clb;
+    a.col_aligned = 1;
+    a.mode = ESP_FLUSH_ROUTED;
+    a.out_key = (u64 *)dst->keys.p;
+    a.out_val = (double *)dst->vals.p;
+    a.status = status;
+    a.gstatus = status + SV + 2;
+    a.ticket = (u32 *)(status + tick_at);
+    a.err = (u32 *)(status + SV) + 1;
+    a.maxrun_seen = (u32 *)(status + SV) + 2;
+    a.total = -1;
+    a.kind32 = (u32)e0.kind;
+    a.k32_piece = -1;
+    a.n_cols = dst->n;
+    a.col_end = dst->n;
+    a.kind_all = e0.kind;
+    {
+        Span sp(dst, ESP_ST_LOCAL);
+        if (!esplocal::launch_group3_items_multi(e0.nloc, e0.diag != nullptr, d_list, d_mb, pstart, (int)S, (unsigned)SV, dst->stream, a)) return ESP_OK;
+        sp.add(1);
+    }
+    HIPCK(dst, hipMemcpyAsync(dst->pin_scalar, status + (SV - 1), 24, hipMemcpyDeviceToHost, dst->stream));
+    HIPCK(dst, hipStreamSynchronize(dst->stream));
+    HIPCK(dst, hipGetLastError());
+    const u32 err = (u32)(dst->pin_scalar[1] >> 32);
+    if (err & 1u) FAIL(dst, ESP_ERR_HIP, "esp_flush_sum: look-back chain timed out inside the bucket kernel");
+    if (err & (2u | 4u | 8u)) return ESP_OK;  // (a segment the fused kernel does not take: nothing has happened to the buffers)
+    const i64 folded = (i64)(dst->pin_scalar[0] & esplocal::ST_VAL);
+    if (folded == 0) return ESP_OK;
+    // ---- the combine: piece starts = exclusive scan of the pairs' record counts (buffer-major = the order they were written in)
+    unsigned long long *d_maxlen = (unsigned long long *)dst->misc.p + 24;
+    HIPCK(dst, hipMemsetAsync(d_maxlen, 0, 16, dst->stream));
+    {
+        Span sp(dst, ESP_ST_SCAN);
+        const i64 np = (i64)p * (S + 1);
+        int l = espscan::exclusive<u64, false>(dst->stream, (const u64 *)pstart, (u64 *)pstart, np, (u64 *)pstart + np);
+        hipLaunchKernelGGL(piece_totals_k, dim3(grid_for(S, 256)), dim3(256), 0, dst->stream, (const i64 *)pstart, p, S, d_maxlen, d_maxlen + 1);
+        sp.add(l + 1);
+    }
+    std::vector<const void *> tab(192, nullptr);
+    for (int k = 0; k < p; k++) tab[(size_t)k] = dst->keys.p, tab[(size_t)(p + k)] = dst->vals.p;
+    HIPCK(dst, hipMemcpyAsync(TB, tab.data(), sizeof(void *) * 192, hipMemcpyHostToDevice, dst->stream));
+    HIPCK(dst, hipMemcpyAsync(dst->pin_scalar, d_maxlen, 16, hipMemcpyDeviceToHost, dst->stream));
+    HIPCK(dst, hipStreamSynchronize(dst->stream));
+    const i64 merged = (i64)dst->pin_scalar[0];
+    if (merged > (i64)esplocal::CAP || dst->pin_scalar[1] != 0) return ESP_OK;
+    note_kind(dst, ESP_COO, folded);
+    dst->count = folded;
+    pending_changed(dst);
+    dst->part_assembled = true;
+    dst->part_valid = false;
+    dst->part_P = p, dst->part_me = 0, dst->part_shift = rem;
+    dst->part_nb = (u32)S;
+    dst->part_base = dst->win_base;
+    dst->part_total = folded, dst->part_maxlen = merged, dst->part_own_lo = 0;
+    dst->part_all_update = false;
+    dst->part_own32 = false;
+    const int32_t rc = esp_flush(dst, ESP_FLUSH_ROUTED, new_nnz, pattern_changed);
+    if (rc != ESP_OK) return rc;
+    dst->last_lazy_items = 2;  // (esp_debug_last_lazy_items: 2 = the folds of a Base.sum ran as one launch over item records)
+    *served = true;
+    return ESP_OK;
+}
 
 // Base.sum(xmatrices, csc) (sparsematrixdilnkc.jl:397-435; flush! of GenericMTExtendableSparseMatrixCSC,
 // genericmtextendablesparsematrixcsc.jl:45-51).  The reference lists the CSC's entries, then every buffer's -- each buffer
@@ -55,7 +230,12 @@ extern "C" int32_t esp_flush_sum(esp_handle *dst, esp_handle *const *xs, int32_t
     i64 folded = 0;
     // Steps 1 - 3; every exit goes through the cleanup below: the call is all-or-nothing for dst (a failure leaves its stored
     // matrix as it was and nothing pending) and the buffers come back EMPTY whatever happened.
+    bool by_items = false;
     auto run = [&]() -> int32_t {
+        // 0. every buffer holds an element batch as sorted items with one common plan: the folds as ONE launch, the combine
+        // flush over their records as pieces (flush_sum_items)
+        CK(flush_sum_items(dst, xs, p, new_nnz, pattern_changed, &by_items));
+        if (by_items) return ESP_OK;
         // 1. every buffer's own fold: the buffers are independent handles with streams of their own, so their flushes -- a
         // few dozen small launches and three or four host round trips each -- run side by side, one host thread per buffer
         // (as the reference's partitions are assembled by one task each: test/femtools.jl:88-110)

@@ -488,7 +488,8 @@ int32_t esp_debug_last_local_small(const esp_handle *h, int32_t *small);
 /* 1 when the bucket kernel of the last flush formed its updates from the sorted ITEM records of an item partition
  * (esp_generate_fem in a shuffled order, esp_append_elements on an empty buffer of a fresh matrix): the expansion -- every
  * update stored once at its bucket position, read again by the bucket kernel -- never ran (csrc/group3_items.hpp);
- * esp_debug_force_path(39): never */
+ * esp_debug_force_path(39): never.  2 (on the destination of esp_flush_sum): the folds of all buffers ran as ONE launch over their
+ * item records and the combine flush read the folded records as pieces (every buffer held an element batch with the same plan) */
 int32_t esp_debug_last_lazy_items(const esp_handle *h, int32_t *on);
 /* 1 when the last flush REBUILT the matrix for the entries behind a re-assembly's batch (a fresh flush whose segments start
  * with the stored entries of their columns: no look-ups against the stored columns, no join); esp_debug_force_path(40): never */

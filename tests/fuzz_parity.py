@@ -43,7 +43,7 @@ def generator_case():
     N = nx * ny * nz
     if N > 3000000:
         return None
-    force = int(rng.choice([0, 0, 0, 14, 15, 16, 18, 13, 4, 19]))
+    force = int(rng.choice([0, 0, 0, 0, 14, 15, 16, 18, 13, 4, 19, 31, 40]))
     kind = int(rng.choice([1, 1, 2]))
     mode = int(rng.choice([0, 1, 2]))
     A = esp.ExtendableSparseMatrix(N, N)
@@ -120,7 +120,7 @@ def fem_case():
     npd = int(rng.integers(6, 400)) if dim == 2 else int(rng.integers(4, 42))
     nn = npd ** dim
     order = int(rng.choice([0, 1, 1]))
-    force = int(rng.choice([0, 0, 0, 0, 30, 24, 25, 28, 14, 26, 32]))
+    force = int(rng.choice([0, 0, 0, 0, 0, 30, 24, 25, 28, 14, 26, 32, 39, 36]))
     A = esp.ExtendableSparseMatrix(nn, nn)
     A.debug_force_path(force)
     O = orc.ExtendableSparseMatrix(nn, nn)
@@ -180,7 +180,7 @@ def elements_case():
     dg = np.asfortranarray(rng.standard_normal((nloc, nc))) if rng.random() < 0.6 else None
     kind = int(rng.choice([1, 2, 2, 0]))
     sub = rng.random() < 0.2
-    force = int(rng.choice([0, 0, 0, 0, 14, 25, 30, 24, 2, 32, 32]))
+    force = int(rng.choice([0, 0, 0, 0, 0, 14, 25, 30, 24, 2, 32, 39, 37]))
     I, J, V = orc.elements_stream(cn, em, dg)
     Vs = -V if (sub and kind != 0) else V
     if rng.random() < 0.3 and nc >= 4:

@@ -16,7 +16,7 @@ for f in glob.glob('gpurun_out/trcf/**/*memory_copy_trace.csv', recursive=True):
 rows.sort()
 hits = [i for i, r in enumerate(rows) if 'fem_items_k' in r[2] or 'fem_count_k' in r[2]]
 # the last assembly starts at the last fem_count_k (its PART launch leaves at once on a shuffled stream) or fem_items_k
-starts = [i for i, r in enumerate(rows) if 'fem_count_k' in r[2]] or hits
+starts = [i for i, r in enumerate(rows) if 'fem_items_k' in r[2]] or hits
 first = starts[-1]
 out = open('gpurun_out/fem_trace.txt', 'w')
 t0 = rows[first][0]

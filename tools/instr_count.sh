@@ -11,7 +11,7 @@ for f in glob.glob("gpurun_out/ic/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         acc[r["Kernel_Name"].replace("void ", "").split("(")[0]][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, v in acc.items():
-    if not any(x in k for x in ("local_k", "wave_k", "group3_k", "run_hist_k", "run_scatter_k", "fdrand_k", "fdrand_part_k", "fd_count_k", "fem_", "merge_k", "tile_hist_k", "scatter_k")):
+    if not any(x in k for x in ("local_k", "wave_k", "group3_k", "group3_items_k", "elem_", "run_hist_k", "run_scatter_k", "fdrand_k", "fdrand_part_k", "fd_count_k", "fem_", "merge_k", "tile_hist_k", "scatter_k")):
         continue
     m = {c: sum(x) / len(x) for c, x in v.items()}
     w = m["SQ_WAVES"]
