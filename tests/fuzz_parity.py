@@ -212,7 +212,10 @@ def elements_case():
             try:
                 assert_csc_equal(csc.arrays(), Oc.arrays())
             except AssertionError:
-                print("MISMATCH elements/sum case", dict(nloc=nloc, m=m, n=n, nc=nc, span=span, kind=kind, p=p, rnd=rnd))
+                lz = __import__("ctypes").c_int32()
+                home._d.lib.esp_debug_last_lazy_items(home._d.h, __import__("ctypes").byref(lz))
+                print("MISMATCH elements/sum case", dict(nloc=nloc, m=m, n=n, nc=nc, span=span, kind=kind, p=p, rnd=rnd, sub=sub, diag=dg is not None,
+                                                         lazy=lz.value, case=cases))
                 raise
         paths[("elem_sum", p)] = paths.get(("elem_sum", p), 0) + 1
         return True
@@ -253,7 +256,9 @@ def elements_case():
         try:
             assert_csc_equal(A.sparse().arrays(), O.arrays())
         except AssertionError:
-            print("MISMATCH elements case", dict(nloc=nloc, m=m, n=n, nc=nc, span=span, kind=kind, force=force, rnd=rnd, how=str(how), diag=dg is not None))
+            print("MISMATCH elements case", dict(nloc=nloc, m=m, n=n, nc=nc, span=span, kind=kind, force=force, rnd=rnd, how=str(how), diag=dg is not None,
+                                                 sub=sub, lazy=A.debug_last_lazy_items(), small=A.debug_last_local_small(), part=A.debug_last_partition(),
+                                                 rebuild=A.debug_last_rebuild(), case=cases))
             raise
     return True
 
