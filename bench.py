@@ -607,6 +607,12 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
         def fill(t):
             xs[t].append_elements(cn[cuts[t]:cuts[t + 1]], em[cuts[t]:cuts[t + 1]], dg[cuts[t]:cuts[t + 1]])
 
+        # (the first fill of every buffer -- all its device allocations -- runs on ONE thread: concurrent first use of fresh handles
+        # from several host threads gave rare memory faults on this stack, NOTES/round5.md section 8; the timed fills are
+        # concurrent, one host thread per partition, on warm handles)
+        for t in range(p):
+            fill(t)
+        hd.ck(hd.lib.esp_flush_sum(hd.h, arr, p, C.byref(C.c_int64()), C.byref(C.c_int32())))
         for it in range(steps + 1):
             hd.ck(hd.lib.esp_synchronize(hd.h))
             t0 = time.perf_counter()

@@ -236,28 +236,19 @@ extern "C" int32_t esp_flush_sum(esp_handle *dst, esp_handle *const *xs, int32_t
         // flush over their records as pieces (flush_sum_items)
         CK(flush_sum_items(dst, xs, p, new_nnz, pattern_changed, &by_items));
         if (by_items) return ESP_OK;
-        // 1. every buffer's own fold: the buffers are independent handles with streams of their own, so their flushes -- a
-        // few dozen small launches and three or four host round trips each -- run side by side, one host thread per buffer
-        // (as the reference's partitions are assembled by one task each: test/femtools.jl:88-110)
-        {
-            std::vector<int32_t> rcs((size_t)p, ESP_OK);
-            std::vector<int64_t> zs((size_t)p, 0);
-            const int WIDTH = 16;  // host threads at a time
-            for (int k0 = 0; k0 < p; k0 += WIDTH) {
-                std::vector<std::thread> th;
-                for (int k = k0; k < std::min(p, k0 + WIDTH); k++) {
-                    if (xs[k]->count == 0) continue;
-                    th.emplace_back([&, k] { rcs[(size_t)k] = esp_flush(xs[k], ESP_FLUSH_ROUTED, &zs[(size_t)k], nullptr); });
-                }
-                for (auto &t : th) t.join();
+        // 1. every buffer's own fold, one after the other on the calling thread.  (Round 4 ran them side by side, one host thread
+        // per buffer: concurrent esp_flush calls on different handles -- each with hipFree / hipMalloc of its scratch and its own
+        // non-blocking stream -- produced rare memory faults and wrong results on this stack (found by the parity fuzz in round
+        // 5: 4 of 8 runs of one case; 0 of 8 serial), and 16 small pipelines did not overlap well anyway.)
+        for (int k = 0; k < p; k++) {
+            if (xs[k]->count == 0) continue;
+            int64_t z = 0;
+            const int32_t rc1 = esp_flush(xs[k], ESP_FLUSH_ROUTED, &z, nullptr);
+            if (rc1 != ESP_OK) {
+                dst->err = xs[k]->err;
+                return rc1;
             }
-            for (int k = 0; k < p; k++) {
-                if (rcs[(size_t)k] != ESP_OK) {
-                    dst->err = xs[k]->err;
-                    return rcs[(size_t)k];
-                }
-                folded += zs[(size_t)k];
-            }
+            folded += z;
         }
         t_b = now();
         // 2. their entries behind one another in dst's buffer (dst's stream waits for each buffer's flush: esp_flush returned

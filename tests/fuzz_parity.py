@@ -263,7 +263,8 @@ def elements_case():
     return True
 
 
-while time.time() < t_end:
+max_cases = int(os.environ.get("ESP_FUZZ_MAXCASES", "0"))
+while time.time() < t_end and (max_cases == 0 or cases < max_cases):
     if (rng.random() < 0.12 or os.environ.get("ESP_FUZZ_FOCUS") == "elements") and os.environ.get("ESP_FUZZ_FOCUS") != "k32":
         if elements_case():
             cases += 1
