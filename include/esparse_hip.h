@@ -23,9 +23,10 @@
  *   - one handle = one device + one HIP stream; a handle is not thread-safe
  *     (like one reference buffer per `tid`); distinct handles are independent and may be
  *     driven from different host threads -- with one caveat found by the parity fuzz
- *     (NOTES/round5.md section 8): a handle's FIRST appends / flush (its device
- *     allocations) should not run concurrently with other handles' calls; the library
- *     itself starts no threads on the flush path;
+ *     (NOTES/round5.md section 8): concurrent esp_flush calls on different handles that
+ *     allocate or free device memory (first use, growth) showed rare faults on this
+ *     stack; warm a handle on one thread first.  The library itself starts no threads on
+ *     the flush path;
  *   - element types: Float64 values, Int64 indices (the reference's default
  *     ExtendableSparseMatrix{Float64,Int64}); other Tv/Ti stay on the CPU path.
  */
