@@ -564,7 +564,7 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
                 out[ttag] = {"workload": "the same stream as resident Int64/Int64/Float64 triplets (%d): esp_append_device + flush!" % E,
                              "ms": dt * 1e3, "nnz_per_s": Z / dt, "appended_per_s": E / dt, "algorithmic_bytes": algo,
                              "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS, "partition": A.debug_last_partition(),
-                             "stage_ms": stages(tm, 1), "steps": len(dts), "digest_ok": okt}
+                             "key_bytes": A.debug_last_key_bytes(), "stage_ms": stages(tm, 1), "steps": len(dts), "digest_ok": okt}
                 del I, J, V
             except _Skip:
                 pass

@@ -120,6 +120,7 @@ SIGNATURES = {
     "esp_timing_enable": (i32, [vp, i32]),
     "esp_timing": (i32, [vp, P(esp_timing_t), i32]),
     "esp_debug_plan_cap": (i32, [vp, C.c_double]),
+    "esp_debug_fail_next_bucket_stage": (i32, [vp]),
     "esp_debug_force_path": (i32, [vp, i32]),
     "esp_debug_last_run_order": (i32, [vp, P(i32)]),
     "esp_debug_last_colptr_direct": (i32, [vp, P(i32)]),

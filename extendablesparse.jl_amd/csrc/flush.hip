@@ -1002,7 +1002,21 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         }
         if (st.local_ok) {
             if (split) st.expect_hits = 0;
-            const int32_t rc = flush_local(h, st, mode, &Zn);
+            int32_t rc;
+            if (h->debug_fail_bucket) {  // (esp_debug_fail_next_bucket_stage)
+                h->debug_fail_bucket = false;
+                rc = [&]() -> int32_t { FAIL(h, ESP_ERR_STATE, "esp_flush: the bucket stage was told to fail (esp_debug_fail_next_bucket_stage)"); }();
+            } else {
+                rc = flush_local(h, st, mode, &Zn);
+            }
+            if (rc != ESP_OK && st.key_bytes == 4 && st.k32_passes >= 2) {
+                // (two or more passes moved 4-byte keys: the scratch pair holds the input of the last one, 4-byte keys as well --
+                // the packed keys are rebuilt there from the partitioned ones)
+                hipLaunchKernelGGL(esprun::expand_keys_k, dim3((unsigned)st.S), dim3(esprun::THREADS), 0, h->stream, (const u32 *)st.sk,
+                                   st.seg_start, st.rem_bits, h->win_base, (u32)st.kind, (u64 *)h->keys2.p);
+                (void)hipMemcpyAsync(h->vals2.p, st.sv, sizeof(double) * (size_t)st.total, hipMemcpyDeviceToDevice, h->stream);
+                (void)hipStreamSynchronize(h->stream);
+            }
             if (rc != ESP_OK && st.key_bytes == 4) {
                 // the batch stays pending: its packed keys are intact in the scratch pair (the partition wrote the 4-byte
                 // keys into the other one)

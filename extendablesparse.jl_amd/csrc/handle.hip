@@ -1140,6 +1140,11 @@ extern "C" int32_t esp_debug_plan_cap(esp_handle *h, double cap) {
     h->debug_plan_cap = cap > 0.0 ? cap : 0.0;
     return ESP_OK;
 }
+extern "C" int32_t esp_debug_fail_next_bucket_stage(esp_handle *h) {
+    if (!h) return ESP_ERR_INVALID;
+    h->debug_fail_bucket = true;
+    return ESP_OK;
+}
 extern "C" int32_t esp_debug_last_run_order(const esp_handle *h, int32_t *kind) {
     if (!h || !kind) return ESP_ERR_INVALID;
     *kind = h->last_run_order;

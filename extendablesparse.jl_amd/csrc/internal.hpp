@@ -64,6 +64,7 @@ struct esp_handle {
     bool g3_off = false;                  // a segment of this handle's matrix did not fit the three-workgroup group kernel: not tried again
     bool hits_off = false;                // the re-assembly form of the group kernel met a batch that was no re-assembly of the stored pattern: not tried again (until reset!)
     bool g3_wide = false;                 // ... for its rows alone (spread over more than 2^18): the kernel's wide form serves this handle
+    bool debug_fail_bucket = false;       // esp_debug_fail_next_bucket_stage (test hook, one shot)
     double debug_plan_cap = 0.0;          // esp_debug_plan_cap: plan as if the bucket kernel took segments of this many entries (test hook)
     int last_group3 = 0;                  // the last flush's bucket kernel was group3_k (esp_debug_last_local_small reports 2)
     bool seen_hits = true;                // the last flush over a stored pattern mostly hit stored positions (re-assembly)
@@ -354,6 +355,7 @@ struct Sorted {
     bool fits = false;  // every segment is within seg_cap (local_ok without the limit on the remaining key bits)
     bool all_update = false;  // PIECES: every entry of every piece is an UPDATE (esp_shard_assemble checked)
     int key_bytes = 8;  // 4: sk holds 32-bit keys (the bits below the prefix); every entry has the kind `kind`
+    int k32_passes = 0;  // the 8-bit passes that wrote 4-byte keys (sort_msd): > 0 = the other pair holds no packed copy of the entries
     int kind = 0;
     i64 maxlen = esplocal::CAP;  // longest segment
     i64 total = -1;              // entries of all segments, if the caller knows (lets flush_local drop the segments behind the last column)

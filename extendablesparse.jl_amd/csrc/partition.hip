@@ -15,6 +15,8 @@ int32_t partition_pass(esp_handle *h, espradix::Pass &p, i64 max_tiles) {
         Span sp(h, ESP_ST_HIST);
         if (p.raw_cols)
             hipLaunchKernelGGL(espradix::tile_hist_raw_k, dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
+        else if (p.k32_in)
+            hipLaunchKernelGGL(espradix::tile_hist32_k, dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
         else
             hipLaunchKernelGGL(espradix::tile_hist_k, dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
         sp.add(1);
@@ -797,6 +799,7 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
     h->last_partition = 2;
     // pre-sorted streams: the first (up to) 16 bits in ONE pass (runpart.hpp)
     int passes_here = 0;
+    bool k32_written = false;  // the buffer the last pass wrote holds 4-byte keys
     if (resume) {
         cur = pre0.cur, S = pre0.S, done = pre0.bits0, pass_idx = 1;
         tiles_ready = true;
@@ -840,6 +843,20 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
             }
         }
     }
+    // (the passes ended in 4-byte keys and the bucket kernel cannot take the result: packed keys again, into the other pair, whose
+    // entries the last pass has consumed)
+    auto unpack32 = [&]() -> int32_t {
+        Span sp(h, ESP_ST_COPY);
+        hipLaunchKernelGGL(esprun::expand_keys_k, dim3((unsigned)S), dim3(esprun::THREADS), 0, h->stream, (const u32 *)kin,
+                           (const i64 *)h->seg[cur].p, K - done, h->win_base, (u32)h->kind_uniform, kout);
+        HIPCK(h, hipMemcpyAsync(vout, vin, sizeof(double) * (size_t)E, hipMemcpyDeviceToDevice, h->stream));
+        sp.add(2);
+        std::swap(kin, kout);
+        std::swap(vin, vout);
+        out->key_bytes = 8;
+        k32_written = false;
+        return ESP_OK;
+    };
     for (;;) {
         int bits;
         if (pass_idx < npass_eff) {
@@ -888,8 +905,24 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
         p.bits = bits;
         p.shift = K - done - bits;
         p.keys_only = h->item_mode && h->item_keys_only ? 1 : 0;
+        // a stream of ONE known kind: from the first pass that leaves at most 32 key bits below its prefix on, 4-byte keys (those
+        // bits) out of a pass, into the next and into the bucket kernel (12 bytes per entry instead of 16; the bucket kernel takes
+        // its 4-byte-key forms).  Any force_path: packed keys throughout
+        const int rem_out = K - done - bits;
+        const bool k32_now = k32_written || (!h->item_mode && !fixed_bits && h->force_path == ESP_PATH_AUTO && h->pend_off == 0 &&
+                                             h->kind_uniform >= 0 && h->kind_noted == h->count && !windowed(h) && !h->shard_user &&
+                                             rem_out <= 32 && rem_out <= esplocal::MAX_REM_BITS && out->key_bytes != 4);
+        p.k32_in = k32_written ? 1 : 0;
+        p.k32_out = k32_now ? 1 : 0;
+        p.k32_rem = rem_out;
         const i64 max_tiles = S == 1 ? T : T + S;
         CK(partition_pass(h, p, max_tiles));
+        if (k32_now) {
+            out->key_bytes = 4;
+            out->kind = h->kind_uniform;
+            out->k32_passes += 1;
+            k32_written = true;
+        }
         const int S2 = S << bits;
         CK(ensure(h, h->seg[1 - cur], sizeof(i64) * (size_t)(S2 + 1)));
         CK(ensure(h, h->tilef[1 - cur], sizeof(u64) * (size_t)(S2 + 1 + espscan::workspace_elems(S2 + 1))));
@@ -917,13 +950,14 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
             maxlen = (i64)h->pin_scalar[0];
         }
     }
+    if (k32_written && !(ok && maxlen <= seg_cap(h))) CK(unpack32());  // (the general path sorts packed keys)
     if (S == 1 && !tiles_ready)  // no pass at all: the buffer is the one segment
         hipLaunchKernelGGL(set_i64_k, dim3(1), dim3(1), 0, h->stream, (i64 *)h->seg[0].p, (i64)0, E, (i64)0, (i64)0);
     HIPCK(h, hipGetLastError());
     if (passes_here > 0) {  // the partition passes clamp and report keys outside the window (d_werr: word 12 of the block read above)
         if ((u32)h->pin_scalar[6]) FAIL(h, ESP_ERR_STATE, "esp_flush: a pending entry lies outside the declared column window (partition)");
     }
-    if (out->key_bytes == 4 && (pass_idx > 0 || cur != 1))
+    if (out->key_bytes == 4 && !k32_written && (passes_here > 0 || cur != 1))
         FAIL(h, ESP_ERR_STATE, "esp_flush: internal error (4-byte keys met a further partition pass)");
     out->sk = kin;
     out->sv = vin;

@@ -59,12 +59,28 @@ struct Pass {
     i64 raw_m = 0, raw_n = 0;
     int raw_rb = 0, raw_kind = 0, raw_negate = 0;
     unsigned long long *raw_err = nullptr;  // atomicMin: first entry (1-based) with an index outside the matrix
+    // entries of ONE known kind: from the first pass that leaves at most 32 key bits below its prefix, the passes write those bits
+    // as 4-byte keys (k32_out: keys_out is a u32 array) and read them as such (k32_in: keys_in is one; digit = key32 >> shift) --
+    // 12 instead of 16 bytes per entry out of a pass, into the next one and into the bucket kernel
+    int k32_out = 0;
+    int k32_in = 0;
+    int k32_rem = 0;  // key bits below the prefix after this pass
 };
+
+// the 4-byte key a pass writes for the entry whose key (packed, or 4-byte from the pass before) it holds as kk
+__device__ __forceinline__ u32 narrow_key(const Pass &p, u64 kk) {
+    const u64 low = p.k32_rem >= 32 ? 0xffffffffull : ((1ull << p.k32_rem) - 1ull);
+    if (p.k32_in) return (u32)(kk & low);
+    u64 kn = (kk >> ESP_TAG_BITS) - p.base;
+    kn = kn < p.span ? kn : p.span - 1;  // (as digit_of: the histogram kernel has reported it)
+    return (u32)(kn & low);
+}
 
 // CHECK: report keys outside the window (the histogram kernel sees every key of a pass with the
 // same parameters, so the scatter kernel only clamps)
 template <bool CHECK>
 __device__ __forceinline__ u32 digit_of(const Pass &p, u64 key, u32 mask) {
+    if (p.k32_in) return (u32)(key >> p.shift) & mask;  // (a 4-byte key: the bits below the prefix, checked by an earlier pass)
     if (p.owner_P) return (u32)(((key >> p.colshift) * (u64)p.owner_P) / (u64)p.owner_n);
     u64 kn = (key >> ESP_TAG_BITS) - p.base;
     if (CHECK && kn >= p.span) *p.err = 1u;
@@ -184,6 +200,61 @@ static __global__ __launch_bounds__(THREADS) void tile_hist_k(Pass p) {
     if (t + THREADS < R && cnt[t + THREADS] != 0) p.hist[tf * R + (i64)(t + THREADS) * nts + tin] = cnt[t + THREADS];
 }
 
+// the same over 4-byte keys (Pass::k32_in): 8-byte loads of two keys
+static __global__ __launch_bounds__(THREADS) void tile_hist32_k(Pass p) {
+    __shared__ u32 cnt[RADIX];
+    const int t = threadIdx.x;
+    const i64 tile = xcd_tile();
+    const int s = p.S == 1 ? (tile < p.tile_first[1] ? 0 : -1) : find_segment(p.tile_first, p.S, tile);
+    if (s < 0) return;
+    const i64 tf = p.tile_first[s];
+    const i64 nts = p.tile_first[s + 1] - tf;
+    const i64 tin = tile - tf;
+    const i64 beg = p.seg_start[s] + tin * TILE;
+    const i64 end = min(p.seg_start[s + 1], beg + (i64)TILE);
+    cnt[t] = 0;
+    cnt[t + THREADS] = 0;
+    __syncthreads();
+    const u32 mask = (1u << p.bits) - 1u;
+    const u32 *k32 = reinterpret_cast<const u32 *>(p.keys_in);
+    const i64 a0 = (beg + 1) & ~(i64)1;  // first 8-byte aligned key of the tile
+    const i64 a1 = end & ~(i64)1;
+    const i64 npair = a1 > a0 ? (a1 - a0) >> 1 : 0;
+    const uint2 *pk = reinterpret_cast<const uint2 *>(k32 + a0);
+    uint2 kk[ITEMS / 2];
+#pragma unroll
+    for (int k = 0; k < ITEMS / 2; k++) {
+        const i64 q = (i64)k * THREADS + t;
+        kk[k] = q < npair ? pk[q] : uint2{0u, 0u};
+    }
+    const int lane = t & 63;
+#pragma unroll
+    for (int k = 0; k < ITEMS / 2; k++) {
+        const bool valid = ((i64)k * THREADS + t) < npair;
+        const u32 dA = valid ? (kk[k].x >> p.shift) & mask : 0u, dB = valid ? (kk[k].y >> p.shift) & mask : 0u;
+        const u64 vm = __ballot(valid);
+        if (vm) {
+            const int fl = __builtin_ctzll(vm);
+            const u32 d0 = (u32)__shfl((int)dA, fl, ESP_WAVE);
+            const u64 same = __ballot(valid && dA == d0 && dB == d0);
+            if (same == vm) {
+                if (lane == fl) atomicAdd(&cnt[d0], 2u * (u32)__popcll(vm));
+            } else if (valid) {
+                atomicAdd(&cnt[dA], 1u);
+                atomicAdd(&cnt[dB], 1u);
+            }
+        }
+    }
+    if (t == 0) {  // unaligned head / tail keys
+        if (a0 > beg && beg < end) atomicAdd(&cnt[(k32[beg] >> p.shift) & mask], 1u);
+        if (a1 < end && a1 >= a0) atomicAdd(&cnt[(k32[a1] >> p.shift) & mask], 1u);
+    }
+    __syncthreads();
+    const int R = 1 << p.bits;
+    if (t < R && cnt[t] != 0) p.hist[tf * R + (i64)t * nts + tin] = cnt[t];
+    if (t + THREADS < R && cnt[t + THREADS] != 0) p.hist[tf * R + (i64)(t + THREADS) * nts + tin] = cnt[t + THREADS];
+}
+
 // The tile is reordered through ONE 32 KiB LDS buffer, keys first, values second: 43 KiB of LDS and 144 VGPRs = three
 // workgroups per CU (keys and values staged side by side: 73 KiB = two).  Worth 5 % on the shuffled FEM streams (2.6 ->
 // 2.5 ms per pass over 2.4 10^8 entries): the pass is bound by its 128-byte write runs -- a tile of 4096 shuffled
@@ -250,7 +321,7 @@ static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
             const i64 idx = wbase + k * ESP_WAVE;
-            key[k] = idx < end ? p.keys_in[idx] : ~0ull;
+            key[k] = idx < end ? (p.k32_in ? (u64) reinterpret_cast<const u32 *>(p.keys_in)[idx] : p.keys_in[idx]) : ~0ull;
         }
     }
     if constexpr (!NOVAL) {
@@ -361,7 +432,10 @@ static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
                 const u64 kk = lbuf[slot];
                 const u32 d = digit_of<false>(p, kk, mask);
                 sdig[j] = (unsigned short)d;
-                p.keys_out[goff[d] + slot] = kk;
+                if (p.k32_out)
+                    reinterpret_cast<u32 *>(p.keys_out)[goff[d] + slot] = narrow_key(p, kk);
+                else
+                    p.keys_out[goff[d] + slot] = kk;
             }
         }
         if constexpr (NOVAL) return;
@@ -379,7 +453,12 @@ static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
 #pragma unroll 4
         for (int j = 0; j < ITEMS; j++) {
             const int slot = t + j * THREADS;
-            if (slot < ntile) p.keys_out[goff[ldig[slot]] + slot] = lbuf[slot];
+            if (slot < ntile) {
+                if (p.k32_out)
+                    reinterpret_cast<u32 *>(p.keys_out)[goff[ldig[slot]] + slot] = narrow_key(p, lbuf[slot]);
+                else
+                    p.keys_out[goff[ldig[slot]] + slot] = lbuf[slot];
+            }
         }
         if constexpr (NOVAL) return;
         __syncthreads();  // (every key has been read)

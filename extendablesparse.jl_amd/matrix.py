@@ -695,6 +695,10 @@ class ExtendableSparseMatrix:
         """Test hook (esp_debug_plan_cap): plan the partition as if the bucket kernel took segments of `cap` entries; 0: off."""
         self._d.ck(self._d.lib.esp_debug_plan_cap(self._d.h, float(cap)))
 
+    def debug_fail_next_bucket_stage(self):
+        """Test hook (esp_debug_fail_next_bucket_stage): the next flush fails at its bucket stage, once; the batch stays pending."""
+        self._d.ck(self._d.lib.esp_debug_fail_next_bucket_stage(self._d.h))
+
     def debug_last_path(self):
         p = C.c_int32()
         self._d.ck(self._d.lib.esp_debug_last_path(self._d.h, C.byref(p)))

@@ -467,6 +467,9 @@ int32_t esp_debug_force_path(esp_handle *h, int32_t path);
 /* test hook: plan the partition as if the bucket kernel took segments of `cap` entries (many prefix bits -- the 9-bit passes,
  * several rounds -- at sizes a CPU oracle can follow); 0: off */
 int32_t esp_debug_plan_cap(esp_handle *h, double cap);
+/* test hook: the NEXT flush that reaches its bucket stage reports ESP_ERR_STATE there instead of running it (once) -- the batch
+ * must stay pending, whatever the partition left in the buffers (4-byte keys in both pairs ...), and the next flush must finish it */
+int32_t esp_debug_fail_next_bucket_stage(esp_handle *h);
 int32_t esp_debug_last_path(const esp_handle *h, int32_t *path);
 /* how the last run-based partition turned its run lists into offsets: 1 = one ranking kernel over per-digit run
  * lists, 2 = radix-ordered run list, 3 = ranking kernel given up (a digit with more runs than its list holds),

@@ -1658,6 +1658,65 @@ def test_nine_bit_partition_passes(esp, orc, monkeypatch):
         assert_csc_equal(hip_arrays(A), want, "cap %d force %d" % (cap, force))
 
 
+def test_last_partition_pass_writes_short_keys(esp, orc):
+    """A shuffled stream of ONE kind: from the first radix pass that leaves at most 32 key bits below its prefix on, the passes
+    write and read 4-byte keys (12 instead of 16 bytes per entry out of a pass, into the next and into the bucket kernel:
+    last_key_bytes 4) -- from host arrays (packed on the device) and from device arrays (the first pass at append time, the
+    flush resumes), with two passes (here K = 30 bits: both move 4-byte keys) or three (plan_cap 24).  Mixed kinds keep
+    packed keys.  A skewed stream -- a third of the entries in 64 columns -- overfills a segment behind the planned passes: a
+    further pass over the 4-byte keys.  Onto a stored matrix (hits + new entries) and with SET (last wins) as well, and
+    after a flush whose bucket stage failed: all bit-equal to the oracle."""
+    import torch
+    rng = np.random.default_rng(321)
+    m, n, cnt = 3000, 200003, 2500000
+    I, J, V = rng.integers(1, m + 1, cnt), rng.integers(1, n + 1, cnt), rng.standard_normal(cnt)
+    Js = J.copy()
+    skew = rng.random(cnt) < 0.33
+    Js[skew] = 1000 + rng.integers(0, 64, int(skew.sum()))
+    mixed = rng.choice(np.array([0, 1, 1, 2], np.uint8), cnt)
+    for name, kind, cols, kinds, device, cap, want_bytes in (
+            ("update host", UPDATE, J, None, False, 0, 4), ("update device", UPDATE, J, None, True, 0, 4),
+            ("set host", 0, J, None, False, 0, 4), ("raw device cap 24", 2, J, None, True, 24, 4),
+            ("mixed", 0, J, mixed, False, 0, 8), ("skew host", UPDATE, Js, None, False, 0, 4),
+            ("skew device", UPDATE, Js, None, True, 0, 4)):
+        kk = np.full(cnt, kind, np.uint8) if kinds is None else kinds
+        O = orc.ExtendableSparseMatrix(m, n)
+        O.apply(kk, I, cols, V)
+        O.flush()
+        A = esp.ExtendableSparseMatrix(m, n)
+        if cap:
+            A.debug_plan_cap(cap)
+        if device:
+            dI, dJ, dV = (torch.as_tensor(x, device="cuda") for x in (I, cols, V))
+            torch.cuda.synchronize()
+            A.append_device(kind, dI, dJ, dV)
+        else:
+            A.append(kind, I, cols, V, kinds=kinds)
+        if name.startswith(("update", "raw", "skew")):
+            # the bucket stage fails once (test hook): the batch stays pending as packed keys -- rebuilt from the partitioned 4-byte
+            # keys where two passes moved those -- and the next flush finishes it
+            A.debug_fail_next_bucket_stage()
+            with pytest.raises(esp.EspError):
+                A.flush()
+        A.flush()
+        assert A.debug_last_partition() == 2 and A.debug_last_path() == 1, name
+        assert A.debug_last_key_bytes() == want_bytes, (name, A.debug_last_key_bytes())
+        assert_csc_equal(hip_arrays(A), O.arrays(), name)
+        if name in ("update host", "update device"):
+            # a second shuffled batch onto the stored matrix: hits and new entries
+            I2, J2, V2 = rng.integers(1, m + 1, cnt), rng.integers(1, n + 1, cnt), rng.standard_normal(cnt)
+            O.apply(np.full(cnt, UPDATE, np.uint8), I2, J2, V2)
+            O.flush()
+            if device:
+                dI, dJ, dV = (torch.as_tensor(x, device="cuda") for x in (I2, J2, V2))
+                torch.cuda.synchronize()
+                A.append_device(UPDATE, dI, dJ, dV)
+            else:
+                A.append(UPDATE, I2, J2, V2)
+            A.flush()
+            assert_csc_equal(hip_arrays(A), O.arrays(), name + " second batch")
+
+
 def test_producer_batch_with_a_tail(esp, orc):
     """Entries appended BEHIND a producer's bucket-ordered batch leave it as it is: the flush partitions the tail alone
     and the bucket kernel reads every segment as two pieces (last_partition 5).  Kinds of the tail are free (the batch's
