@@ -35,6 +35,14 @@ int32_t partition_pass(esp_handle *h, espradix::Pass &p, i64 max_tiles) {
             hipLaunchKernelGGL((espradix::scatter_k<true, true>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
         else if (p.keys_only)
             hipLaunchKernelGGL((espradix::scatter_k<false, true>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
+        else if (p.k32_out && p.bits > 8 && p.k32_in)
+            hipLaunchKernelGGL((espradix::scatter_k<true, false, false, 2>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
+        else if (p.k32_out && p.bits > 8)
+            hipLaunchKernelGGL((espradix::scatter_k<true, false, false, 1>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
+        else if (p.k32_out && p.k32_in)
+            hipLaunchKernelGGL((espradix::scatter_k<false, false, false, 2>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
+        else if (p.k32_out)
+            hipLaunchKernelGGL((espradix::scatter_k<false, false, false, 1>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
         else if (p.bits > 8)
             hipLaunchKernelGGL((espradix::scatter_k<true>), dim3(espradix::scatter_grid(max_tiles)), dim3(espradix::THREADS), 0, h->stream, p);
         else

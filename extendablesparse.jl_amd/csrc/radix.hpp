@@ -68,9 +68,10 @@ struct Pass {
 };
 
 // the 4-byte key a pass writes for the entry whose key (packed, or 4-byte from the pass before) it holds as kk
+template <bool K32IN>
 __device__ __forceinline__ u32 narrow_key(const Pass &p, u64 kk) {
     const u64 low = p.k32_rem >= 32 ? 0xffffffffull : ((1ull << p.k32_rem) - 1ull);
-    if (p.k32_in) return (u32)(kk & low);
+    if constexpr (K32IN) return (u32)(kk & low);
     u64 kn = (kk >> ESP_TAG_BITS) - p.base;
     kn = kn < p.span ? kn : p.span - 1;  // (as digit_of: the histogram kernel has reported it)
     return (u32)(kn & low);
@@ -78,9 +79,9 @@ __device__ __forceinline__ u32 narrow_key(const Pass &p, u64 kk) {
 
 // CHECK: report keys outside the window (the histogram kernel sees every key of a pass with the
 // same parameters, so the scatter kernel only clamps)
-template <bool CHECK>
+template <bool CHECK, bool K32IN = false>
 __device__ __forceinline__ u32 digit_of(const Pass &p, u64 key, u32 mask) {
-    if (p.k32_in) return (u32)(key >> p.shift) & mask;  // (a 4-byte key: the bits below the prefix, checked by an earlier pass)
+    if constexpr (K32IN) return (u32)(key >> p.shift) & mask;  // (a 4-byte key: the bits below the prefix, checked by an earlier pass)
     if (p.owner_P) return (u32)(((key >> p.colshift) * (u64)p.owner_P) / (u64)p.owner_n);
     u64 kn = (key >> ESP_TAG_BITS) - p.base;
     if (CHECK && kn >= p.span) *p.err = 1u;
@@ -263,9 +264,12 @@ static __global__ __launch_bounds__(THREADS) void tile_hist32_k(Pass p) {
 // digit per thread, the slot's digit kept in an LDS byte): the 8-bit passes of 3-D FEM lost 5 % in the general form.
 // NOVAL: the records are 8-byte keys by themselves (Pass::keys_only): half the traffic of a pass
 // RAW: keys and values from the caller's triplets (Pass::raw_*), see tile_hist_raw_k
-template <bool NINE, bool NOVAL = false, bool RAW = false>
+// K32: 0 packed keys in and out; 1 packed keys in, 4-byte keys out (Pass::k32_out); 2 4-byte keys in and out (Pass::k32_in) --
+// compile-time: the same choice at run time cost the keys-only passes 60 % (3-D FEM 3.2 -> 5.4 ms)
+template <bool NINE, bool NOVAL = false, bool RAW = false, int K32 = 0>
 static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
     static_assert(!RAW || !NOVAL, "a raw pass moves values");
+    static_assert(K32 == 0 || (!RAW && !NOVAL), "4-byte keys: the flush's own passes over packed entries");
     constexpr int RDX = NINE ? RADIX : 256;
     __shared__ u64 lbuf[TILE];
     __shared__ u32 cnt[WAVES][RDX];
@@ -321,7 +325,10 @@ static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
             const i64 idx = wbase + k * ESP_WAVE;
-            key[k] = idx < end ? (p.k32_in ? (u64) reinterpret_cast<const u32 *>(p.keys_in)[idx] : p.keys_in[idx]) : ~0ull;
+            if constexpr (K32 == 2)
+                key[k] = idx < end ? (u64) reinterpret_cast<const u32 *>(p.keys_in)[idx] : ~0ull;
+            else
+                key[k] = idx < end ? p.keys_in[idx] : ~0ull;
         }
     }
     if constexpr (!NOVAL) {
@@ -346,7 +353,7 @@ static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
         const bool valid = (wbase + k * ESP_WAVE) < end;
-        const u32 d = valid ? digit_of<false>(p, key[k], mask) : 0u;
+        const u32 d = valid ? digit_of<false, K32 == 2>(p, key[k], mask) : 0u;
         dig[k] = (unsigned short)d;
         const u64 vm = __ballot(valid);
         u64 m = vm;
@@ -430,10 +437,10 @@ static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
             sdig[j] = 0;
             if (slot < ntile) {
                 const u64 kk = lbuf[slot];
-                const u32 d = digit_of<false>(p, kk, mask);
+                const u32 d = digit_of<false, K32 == 2>(p, kk, mask);
                 sdig[j] = (unsigned short)d;
-                if (p.k32_out)
-                    reinterpret_cast<u32 *>(p.keys_out)[goff[d] + slot] = narrow_key(p, kk);
+                if constexpr (K32 != 0)
+                    reinterpret_cast<u32 *>(p.keys_out)[goff[d] + slot] = narrow_key<K32 == 2>(p, kk);
                 else
                     p.keys_out[goff[d] + slot] = kk;
             }
@@ -454,8 +461,8 @@ static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
         for (int j = 0; j < ITEMS; j++) {
             const int slot = t + j * THREADS;
             if (slot < ntile) {
-                if (p.k32_out)
-                    reinterpret_cast<u32 *>(p.keys_out)[goff[ldig[slot]] + slot] = narrow_key(p, lbuf[slot]);
+                if constexpr (K32 != 0)
+                    reinterpret_cast<u32 *>(p.keys_out)[goff[ldig[slot]] + slot] = narrow_key<K32 == 2>(p, lbuf[slot]);
                 else
                     p.keys_out[goff[ldig[slot]] + slot] = lbuf[slot];
             }
