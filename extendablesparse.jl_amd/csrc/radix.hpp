@@ -267,8 +267,11 @@ static __global__ __launch_bounds__(THREADS) void tile_hist32_k(Pass p) {
 // K32: 0 packed keys in and out; 1 packed keys in, 4-byte keys out (Pass::k32_out); 2 4-byte keys in and out (Pass::k32_in) --
 // compile-time: the same choice at run time cost the keys-only passes 60 % (3-D FEM 3.2 -> 5.4 ms)
 template <bool NINE, bool NOVAL = false, bool RAW = false, int K32 = 0>
-static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
+static __global__ __launch_bounds__(THREADS, (NOVAL && !NINE) ? 4 : 3) void scatter_k(Pass p) {
     static_assert(!RAW || !NOVAL, "a raw pass moves values");
+    // SLOTDIG: the digit of an output slot is recomputed from its key (NINE; NOVAL: without the byte per slot the kernel's LDS is
+    // 39 KiB and FOUR workgroups share a CU); else it is kept in an LDS byte
+    constexpr bool SLOTDIG = NINE || NOVAL;
     static_assert(K32 == 0 || (!RAW && !NOVAL), "4-byte keys: the flush's own passes over packed entries");
     constexpr int RDX = NINE ? RADIX : 256;
     __shared__ u64 lbuf[TILE];
@@ -276,7 +279,7 @@ static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
     __shared__ u32 dstart[RDX];
     __shared__ i64 goff[RDX];
     __shared__ u32 lw[WAVES];
-    __shared__ unsigned char ldig[NINE ? 1 : TILE];
+    __shared__ unsigned char ldig[SLOTDIG ? 1 : TILE];
 
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const i64 tile = xcd_tile();
@@ -423,12 +426,12 @@ static __global__ __launch_bounds__(THREADS, 3) void scatter_k(Pass p) {
             const u32 slot = dstart[d] + cnt[w][d] + rank[k];
             rank[k] = (unsigned short)slot;  // (kept for the values)
             lbuf[slot] = key[k];
-            if constexpr (!NINE) ldig[slot] = (unsigned char)d;
+            if constexpr (!SLOTDIG) ldig[slot] = (unsigned char)d;
         }
     }
     __syncthreads();
     double *lvals = reinterpret_cast<double *>(lbuf);
-    if constexpr (NINE) {
+    if constexpr (SLOTDIG) {
         // (the digit of an output slot: from its key once, kept in a register for the values)
         unsigned short sdig[ITEMS];
 #pragma unroll
