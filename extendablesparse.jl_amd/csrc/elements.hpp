@@ -89,11 +89,24 @@ static __global__ __launch_bounds__(THREADS) void elem_cells_k(Args a) {
     if (c >= a.ncells) return;
     i64 nd[4] = {1, 1, 1, 1};
     double dg[4] = {0.0, 0.0, 0.0, 0.0};
+    // (32 bytes per cell: two 16-byte loads where the caller's arrays are 16-byte aligned -- a view into a larger array need not be)
+    const bool vec = NLOC == 4 && ((reinterpret_cast<unsigned long long>(a.cellnodes) | reinterpret_cast<unsigned long long>(a.diag)) & 15ull) == 0;
+    if (vec) {
+        const ull2 *cn = reinterpret_cast<const ull2 *>(a.cellnodes + c * 4);
+        const ull2 n01 = cn[0], n23 = cn[1];
+        nd[0] = (i64)n01.x, nd[1] = (i64)n01.y, nd[2] = (i64)n23.x, nd[3] = (i64)n23.y;
+        if (a.diag) {
+            const dbl2 *dp = reinterpret_cast<const dbl2 *>(a.diag + c * 4);
+            const dbl2 d01 = dp[0], d23 = dp[1];
+            dg[0] = d01.x, dg[1] = d01.y, dg[2] = d23.x, dg[3] = d23.y;
+        }
+    } else {
 #pragma unroll
-    for (int k = 0; k < NLOC; k++) nd[k] = a.cellnodes[c * NLOC + k];
-    if (a.diag) {
+        for (int k = 0; k < NLOC; k++) nd[k] = a.cellnodes[c * NLOC + k];
+        if (a.diag) {
 #pragma unroll
-        for (int k = 0; k < NLOC; k++) dg[k] = a.diag[c * NLOC + k];
+            for (int k = 0; k < NLOC; k++) dg[k] = a.diag[c * NLOC + k];
+        }
     }
     bool bad = false, twice = false;
 #pragma unroll
@@ -122,10 +135,10 @@ static __global__ __launch_bounds__(THREADS) void elem_cells_k(Args a) {
     }
     char *cr = a.cellrec + c * 64;
     *reinterpret_cast<u32x4 *>(cr) = u32x4{(u32)(nd[0] - 1), (u32)(nd[1] - 1), (u32)(nd[2] - 1), (u32)(nd[3] - 1)};
-    if (a.diag) {
-        *reinterpret_cast<dbl2 *>(cr + 16) = dbl2{dg[0], dg[1]};
-        *reinterpret_cast<dbl2 *>(cr + 32) = dbl2{dg[2], dg[3]};
-    }
+    // (the whole 64-byte record, its unused tail included: full lines instead of masked ones)
+    *reinterpret_cast<dbl2 *>(cr + 16) = dbl2{dg[0], dg[1]};
+    *reinterpret_cast<dbl2 *>(cr + 32) = dbl2{dg[2], dg[3]};
+    *reinterpret_cast<dbl2 *>(cr + 48) = dbl2{0.0, 0.0};
 }
 
 // the diag values of every cell record again (esp_append_elements_again: the connectivity is the same, the element data new)
