@@ -3097,6 +3097,33 @@ def test_flush_sum_failure_leaves_everything_clean(esp, orc):
     assert_csc_equal(out.arrays(), (L + orc.CSC(m, n, *O.arrays())).arrays(), "the sum after the failed one")
 
 
+def test_elements_from_arrays_at_odd_offsets(esp, orc):
+    """Device arrays that are 8- but not 16-byte aligned (views that start one element into a larger array): the cells kernel
+    takes its 8-byte loads instead of the 16-byte ones; aligned arrays of the same mesh.  3-D (4 nodes per cell) and 2-D."""
+    import torch
+    for dim, npd in ((3, 22), (2, 150)):
+        nn = npd ** dim
+        cn, em, dg = orc.fem_mesh(dim, npd, seed=0x5EED0004, order_mode=1, node_mode=0)
+        I, J, V = orc.elements_stream(cn, em, dg)
+        O = orc.ExtendableSparseMatrix(nn, nn)
+        O.apply(np.full(len(I), RAW, np.uint8), I, J, V)
+        O.flush()
+        flat = lambda x: np.ascontiguousarray(np.asfortranarray(x).ravel(order="F"))   # noqa: E731  (Julia's layout, flat)
+        for off in (1, 0):
+            dev = []
+            for x in (flat(cn), flat(em), flat(dg)):
+                buf = torch.zeros(len(x) + 2, dtype=torch.from_numpy(x).dtype, device="cuda")
+                buf[off:off + len(x)] = torch.from_numpy(x).cuda()
+                dev.append(buf[off:off + len(x)])
+            torch.cuda.synchronize()
+            assert all(t.data_ptr() % 16 == 8 * off for t in dev)
+            A = esp.ExtendableSparseMatrix(nn, nn)
+            A.append_elements(dev[0], dev[1], dev[2])
+            A.flush()
+            assert A.debug_last_lazy_items() == 1
+            assert_csc_equal(hip_arrays(A), O.arrays(), "dim %d offset %d" % (dim, off))
+
+
 def test_lazy_item_batches_and_everything_that_expands_them(esp, orc):
     """A batch of an item partition stays a list of sorted items until its flush (group3_items.hpp: the bucket kernel forms the
     updates itself).  Whatever else touches the pending entries first must find them as entries: an append behind the batch, a
