@@ -1012,8 +1012,8 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
             if (rc != ESP_OK && st.key_bytes == 4 && st.k32_passes >= 2) {
                 // (two or more passes moved 4-byte keys: the scratch pair holds the input of the last one, 4-byte keys as well --
                 // the packed keys are rebuilt there from the partitioned ones)
-                hipLaunchKernelGGL(esprun::expand_keys_k, dim3((unsigned)st.S), dim3(esprun::THREADS), 0, h->stream, (const u32 *)st.sk,
-                                   st.seg_start, st.rem_bits, h->win_base, (u32)st.kind, (u64 *)h->keys2.p);
+                hipLaunchKernelGGL(esprun::expand_keys_k, dim3(esprun::expand_keys_grid(st.S)), dim3(esprun::THREADS), 0, h->stream, (const u32 *)st.sk,
+                                   st.seg_start, st.rem_bits, h->win_base, (u32)st.kind, (u64 *)h->keys2.p, (i64)st.S);
                 (void)hipMemcpyAsync(h->vals2.p, st.sv, sizeof(double) * (size_t)st.total, hipMemcpyDeviceToDevice, h->stream);
                 (void)hipStreamSynchronize(h->stream);
             }

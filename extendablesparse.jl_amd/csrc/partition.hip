@@ -855,8 +855,8 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
     // entries the last pass has consumed)
     auto unpack32 = [&]() -> int32_t {
         Span sp(h, ESP_ST_COPY);
-        hipLaunchKernelGGL(esprun::expand_keys_k, dim3((unsigned)S), dim3(esprun::THREADS), 0, h->stream, (const u32 *)kin,
-                           (const i64 *)h->seg[cur].p, K - done, h->win_base, (u32)h->kind_uniform, kout);
+        hipLaunchKernelGGL(esprun::expand_keys_k, dim3(esprun::expand_keys_grid(S)), dim3(esprun::THREADS), 0, h->stream, (const u32 *)kin,
+                           (const i64 *)h->seg[cur].p, K - done, h->win_base, (u32)h->kind_uniform, kout, (i64)S);
         HIPCK(h, hipMemcpyAsync(vout, vin, sizeof(double) * (size_t)E, hipMemcpyDeviceToDevice, h->stream));
         sp.add(2);
         std::swap(kin, kout);

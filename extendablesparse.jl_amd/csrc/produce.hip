@@ -403,8 +403,8 @@ int32_t pending_materialize(esp_handle *h) {
     const esp_handle::PrePart &pp = h->pre;
     CK(ensure(h, h->keys2, std::max(h->keys.bytes, sizeof(u64) * (size_t)h->count)));
     Span sp(h, ESP_ST_COPY);
-    hipLaunchKernelGGL(esprun::expand_keys_k, dim3((unsigned)((i64)1 << pp.pb)), dim3(esprun::THREADS), 0, h->stream, (const u32 *)h->keys.p,
-                       (const i64 *)h->seg[1].p, pp.K - pp.pb, pp.base, (u32)pp.kind, (u64 *)h->keys2.p);
+    hipLaunchKernelGGL(esprun::expand_keys_k, dim3(esprun::expand_keys_grid((i64)1 << pp.pb)), dim3(esprun::THREADS), 0, h->stream, (const u32 *)h->keys.p,
+                       (const i64 *)h->seg[1].p, pp.K - pp.pb, pp.base, (u32)pp.kind, (u64 *)h->keys2.p, (i64)1 << pp.pb);
     sp.add(1);
     if (h->count > pp.E) {  // (the packed entries behind the batch)
         HIPCK(h, hipMemcpyAsync((u64 *)h->keys2.p + pp.E, (const u64 *)h->keys.p + pp.E, sizeof(u64) * (size_t)(h->count - pp.E),

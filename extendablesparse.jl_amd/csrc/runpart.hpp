@@ -929,13 +929,17 @@ __device__ __forceinline__ u32 column_digit(const PartOut &p, i64 col0, int rb, 
 
 // 4-byte keys of a bucket-ordered pending buffer back to packed keys (any call that reads or extends the pending
 // entries other than the flush they were written for): one workgroup per bucket
+// (buckets in a grid-stride loop: the flush's own passes may leave 2^24 segments, more than a launch has workgroups of this size --
+// expand_keys_grid)
 static __global__ __launch_bounds__(THREADS) void expand_keys_k(const u32 *__restrict__ k32, const i64 *__restrict__ seg_start, int shift,
-                                                         u64 base, u32 kind, u64 *__restrict__ out) {
-    const i64 s = blockIdx.x;
-    const i64 b = seg_start[s], e = seg_start[s + 1];
-    const u64 hi = ((u64)s << shift) + base;
-    for (i64 i = b + threadIdx.x; i < e; i += THREADS) out[i] = ((hi + (u64)k32[i]) << ESP_TAG_BITS) | (u64)kind;
+                                                         u64 base, u32 kind, u64 *__restrict__ out, i64 nseg) {
+    for (i64 s = blockIdx.x; s < nseg; s += gridDim.x) {
+        const i64 b = seg_start[s], e = seg_start[s + 1];
+        const u64 hi = ((u64)s << shift) + base;
+        for (i64 i = b + threadIdx.x; i < e; i += THREADS) out[i] = ((hi + (u64)k32[i]) << ESP_TAG_BITS) | (u64)kind;
+    }
 }
+static inline unsigned expand_keys_grid(i64 nseg) { return (unsigned)(nseg < ((i64)1 << 20) ? nseg : ((i64)1 << 20)); }
 
 // the same for a shard's own window (digits [d0, d0 + nb) of the multi-window partition): 4-byte keys at
 // own_keys32(keys, own_lo)[p] -> packed keys at out[p]

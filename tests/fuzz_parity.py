@@ -329,7 +329,12 @@ while time.time() < t_end and (max_cases == 0 or cases < max_cases):
                 if hi_ > lo_:
                     A.append(kd, I[lo_:hi_], J[lo_:hi_], V[lo_:hi_])
                     O.apply(np.full(hi_ - lo_, kd, np.uint8), I[lo_:hi_], J[lo_:hi_], V[lo_:hi_])
-        A.flush()
+        try:
+            A.flush()
+        except Exception:
+            print("FLUSH FAILED seed", seed, "case", cases, dict(m=m, n=n, force=force, plan_cap=plan_cap, flush=f, cnt=cnt, per_col=per_col, order=str(order),
+                                                                style=str(style), nnz=A._d.nnz()))
+            raise
         O.flush()
         key = (A.debug_last_path(), A.debug_last_partition(), A.debug_last_key_bytes(), int(A.debug_last_fold_update()),
                A.debug_last_local_small())

@@ -1717,6 +1717,25 @@ def test_last_partition_pass_writes_short_keys(esp, orc):
             assert_csc_equal(hip_arrays(A), O.arrays(), name + " second batch")
 
 
+def test_short_keys_are_unpacked_for_the_general_path(esp, orc):
+    """64 columns, 2^40 rows, 1.28 million updates of one kind on 3 distinct rows (6 667 per position: no prefix brings a
+    segment under the bucket kernel's capacity).  The passes go on into the row bits, switch to 4-byte keys once 32 bits are
+    left, give up at 2^24 and more segments -- and the general path must find packed keys again (expand_keys_k in a grid-stride
+    loop: one workgroup per segment was an invalid launch; found by the parity fuzz, seed 911)."""
+    rng = np.random.default_rng(911)
+    m, n, cnt = 2 ** 40, 64, 1280000
+    rowpool = rng.integers(1, m + 1, 3)
+    I, J, V = rowpool[rng.integers(0, 3, cnt)], rng.integers(1, n + 1, cnt), rng.standard_normal(cnt)
+    O = orc.ExtendableSparseMatrix(m, n)
+    O.apply(np.full(cnt, UPDATE, np.uint8), I, J, V)
+    O.flush()
+    A = esp.ExtendableSparseMatrix(m, n)
+    A.append(UPDATE, I, J, V)
+    A.flush()
+    assert A.debug_last_path() == 2, A.debug_last_path()
+    assert_csc_equal(hip_arrays(A), O.arrays())
+
+
 def test_producer_batch_with_a_tail(esp, orc):
     """Entries appended BEHIND a producer's bucket-ordered batch leave it as it is: the flush partitions the tail alone
     and the bucket kernel reads every segment as two pieces (last_partition 5).  Kinds of the tail are free (the batch's
