@@ -64,6 +64,76 @@ static __global__ __launch_bounds__(THREADS) void fem_items_k(Args a) {
         }
 }
 
+// The same for a cell order whose walk is long (the host picks: 2^bits > 1.5 ncells).
+// The cell of a stream position is a Feistel permutation of [0, 2^bits) walked until it lands below ncells (fem_cell_at).  The
+// 2-D mesh of config 4 -- 2.0 10^7 cells in a domain of 2^26 -- walks 3.4 steps on average, and a wave that walks lane by lane
+// waits for its slowest lane: 12 steps, 0.75 ms for the kernel.  So a wave walks ITEM_CELLS x 64 positions TOGETHER: after the
+// first step the positions still outside wait in a queue (LDS, the wave's own: no workgroup barrier), which the wave takes 64 at a
+// time, round after round, survivors packed to the queue's front -- the work follows the average, not the maximum.
+constexpr int ITEM_CELLS = 8;                          // stream positions per lane
+constexpr int ITEM_WAVE_CELLS = ITEM_CELLS * ESP_WAVE;  // ... per wave
+static __global__ __launch_bounds__(THREADS) void fem_items_walk_k(Args a) {
+    constexpr int WAVES = THREADS / ESP_WAVE;
+    __shared__ u64 queue[WAVES][ITEM_WAVE_CELLS];  // x | owner << 48 (a cell number has at most 40 bits, its domain 42)
+    __shared__ u64 cellof[WAVES][ITEM_WAVE_CELLS];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const u64 lt = (1ull << lane) - 1ull;
+    const i64 wbase = ((i64)blockIdx.x * WAVES + w) * ITEM_WAVE_CELLS;
+    const u64 nc = (u64)a.fem.ncells;
+    const bool walk = a.fem.order_mode != 0 && a.fem.ncells >= 2;
+    int cnt = 0;
+#pragma unroll
+    for (int i = 0; i < ITEM_CELLS; i++) {
+        const i64 pos = wbase + i * ESP_WAVE + lane;
+        const bool go = walk && pos < a.fem.ncells;
+        const u64 y = go ? espgen::fem_feistel(a.fem, (u64)pos) : (u64)pos;
+        const bool out = go && y >= nc;
+        if (!out) cellof[w][i * ESP_WAVE + lane] = y;
+        const u64 bal = __ballot(out);
+        if (out) queue[w][cnt + (int)__popcll(bal & lt)] = y | ((u64)(i * ESP_WAVE + lane) << 48);
+        cnt += (int)__popcll(bal);
+    }
+    while (cnt > 0) {  // (wave-uniform)
+        int kept = 0;
+        for (int g = 0; g * ESP_WAVE < cnt; g++) {
+            const int idx = g * ESP_WAVE + lane;
+            const bool has = idx < cnt;
+            __builtin_amdgcn_wave_barrier();
+            const u64 e = has ? queue[w][idx] : 0ull;  // (read before this round's survivors are packed in front of it: kept <= g 64)
+            __builtin_amdgcn_wave_barrier();
+            const u64 own = e >> 48;
+            const u64 y = has ? espgen::fem_feistel(a.fem, e & ((1ull << 48) - 1ull)) : 0ull;
+            const bool out = has && y >= nc;
+            if (has && !out) cellof[w][own] = y;
+            const u64 bal = __ballot(out);
+            if (out) queue[w][kept + (int)__popcll(bal & lt)] = y | (own << 48);
+            kept += (int)__popcll(bal);
+        }
+        cnt = kept;
+    }
+    __builtin_amdgcn_wave_barrier();
+    const int ni = a.fem.dim + 1;
+#pragma unroll 1
+    for (int i = 0; i < ITEM_CELLS; i++) {
+        const i64 pos = wbase + i * ESP_WAVE + lane;
+        if (pos >= a.fem.ncells) continue;
+        i64 vx[4][3];
+        i64 nodes[4];
+        const i64 cell = (i64)cellof[w][i * ESP_WAVE + lane];
+        espgen::fem_vertices(a.fem, cell, vx, nodes);
+#pragma unroll
+        for (int k = 0; k < 4; k++)
+            if (k < ni) {
+                if (a.single) {
+                    a.ikeys[pos * ni + k] = esp_pack(a.fem.L, 1, nodes[k], 0) | (u64)cell;
+                } else {
+                    a.ikeys[pos * ni + k] = esp_pack(a.fem.L, 1, nodes[k], 0);
+                    a.ivals[pos * ni + k] = __longlong_as_double((long long)(((u64)cell << 2) | (u64)k));  // (the cell, not its stream position: the expansion need not walk the permutation again)
+                }
+            }
+    }
+}
+
 // K32: 4-byte keys (the bits below the segment prefix; every entry is a RAWUPDATE), else packed keys
 template <bool K32>
 static __global__ __launch_bounds__(THREADS) void fem_expand_k(Args a) {

@@ -329,22 +329,26 @@ struct FemArgs {
     double *vals;
 };
 
-__device__ __forceinline__ u64 fem_cell_at(const FemArgs &a, i64 pos) {
-    if (a.order_mode == 0 || a.ncells < 2) return (u64)pos;
+// one application of the 4-round Feistel permutation of [0, 2^bits)
+__device__ __forceinline__ u64 fem_feistel(const FemArgs &a, u64 x) {
     const int half = a.bits / 2;
     const u64 mask = (1ull << half) - 1ull;
-    u64 x = (u64)pos;
-    do {
-        u64 Lh = x >> half, R = x & mask;
+    u64 Lh = x >> half, R = x & mask;
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-            const u64 f = esp_mix64(R + a.seed + (u64)(r + 1) * 0x9E3779B97F4A7C15ull) & mask;
-            const u64 tt = Lh ^ f;
-            Lh = R;
-            R = tt;
-        }
-        x = (Lh << half) | R;
-    } while (x >= (u64)a.ncells);
+    for (int r = 0; r < 4; r++) {
+        const u64 f = esp_mix64(R + a.seed + (u64)(r + 1) * 0x9E3779B97F4A7C15ull) & mask;
+        const u64 tt = Lh ^ f;
+        Lh = R;
+        R = tt;
+    }
+    return (Lh << half) | R;
+}
+// the cell at stream position pos: the permutation, walked until it lands inside [0, ncells) (cycle walking)
+__device__ __forceinline__ u64 fem_cell_at(const FemArgs &a, i64 pos) {
+    if (a.order_mode == 0 || a.ncells < 2) return (u64)pos;
+    u64 x = (u64)pos;
+    do x = fem_feistel(a, x);
+    while (x >= (u64)a.ncells);
     return x;
 }
 

@@ -512,7 +512,11 @@ int32_t item_produce_fem(esp_handle *h, const espgen::FemArgs &fa, i64 E, bool *
         lbits = attempt == 0 ? lbits0 : 0;
         {
             Span sp(h, ESP_ST_APPEND);
-            hipLaunchKernelGGL(espitem::fem_items_k, dim3(grid_for(fa.ncells, espitem::THREADS)), dim3(espitem::THREADS), 0, h->stream, a);
+            // (a shuffled order whose permutation domain is much larger than the mesh: the waves walk it together)
+            if (fa.order_mode != 0 && fa.ncells >= 2 && ((u64)1 << fa.bits) > (u64)fa.ncells + (u64)fa.ncells / 2)
+                hipLaunchKernelGGL(espitem::fem_items_walk_k, dim3(grid_for(fa.ncells, espitem::THREADS * espitem::ITEM_CELLS)), dim3(espitem::THREADS), 0, h->stream, a);
+            else
+                hipLaunchKernelGGL(espitem::fem_items_k, dim3(grid_for(fa.ncells, espitem::THREADS)), dim3(espitem::THREADS), 0, h->stream, a);
             sp.add(1);
         }
         // the flush's partition over the items: a temporary view of the handle (sort_msd reads count, keys/vals, keys2/vals2)
