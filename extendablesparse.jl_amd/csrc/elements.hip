@@ -419,15 +419,11 @@ extern "C" int32_t esp_append_elements_host(esp_handle *h, int32_t nloc, int64_t
     if (rc == ESP_OK) rc = ensure(h, de, be);
     if (rc == ESP_OK && diag) rc = ensure(h, dd, bn);
     if (rc == ESP_OK) {
-        Span sp(h, ESP_ST_COPY);
-        hipError_t e = hipMemcpyAsync(dn.p, cellnodes, bn, hipMemcpyHostToDevice, h->stream);
-        if (e == hipSuccess) e = hipMemcpyAsync(de.p, elmat, be, hipMemcpyHostToDevice, h->stream);
-        if (e == hipSuccess && diag) e = hipMemcpyAsync(dd.p, diag, bn, hipMemcpyHostToDevice, h->stream);
+        Span sp(h, ESP_ST_COPY);  // (pageable arrays: through the pinned bounce buffers, handle.hip)
+        rc = h2d_pipelined(h, dn.p, cellnodes, bn);
+        if (rc == ESP_OK) rc = h2d_pipelined(h, de.p, elmat, be);
+        if (rc == ESP_OK && diag) rc = h2d_pipelined(h, dd.p, diag, bn);
         sp.add(diag ? 3 : 2);
-        if (e != hipSuccess) {
-            h->err = std::string("esp_append_elements_host: ") + hipGetErrorString(e);
-            rc = ESP_ERR_HIP;
-        }
     }
     if (rc == ESP_OK)
         rc = esp_append_elements(h, nloc, ncells, (const i64 *)dn.p, (const double *)de.p, diag ? (const double *)dd.p : nullptr, kind, op);
@@ -461,13 +457,9 @@ extern "C" int32_t esp_append_elements_again_host(esp_handle *h, const double *e
     if (rc == ESP_OK && diag) rc = ensure(h, dd, bn);
     if (rc == ESP_OK) {
         Span sp(h, ESP_ST_COPY);
-        hipError_t e = hipMemcpyAsync(de.p, elmat, be, hipMemcpyHostToDevice, h->stream);
-        if (e == hipSuccess && diag) e = hipMemcpyAsync(dd.p, diag, bn, hipMemcpyHostToDevice, h->stream);
+        rc = h2d_pipelined(h, de.p, elmat, be);
+        if (rc == ESP_OK && diag) rc = h2d_pipelined(h, dd.p, diag, bn);
         sp.add(diag ? 2 : 1);
-        if (e != hipSuccess) {
-            h->err = std::string("esp_append_elements_again_host: ") + hipGetErrorString(e);
-            rc = ESP_ERR_HIP;
-        }
     }
     if (rc == ESP_OK) rc = esp_append_elements_again(h, (const double *)de.p, diag ? (const double *)dd.p : nullptr, kind, op);
     (void)hipStreamSynchronize(h->stream);  // (the kernels have read the temporaries)

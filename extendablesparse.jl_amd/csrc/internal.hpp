@@ -427,6 +427,9 @@ int32_t pack_device(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const d
 int32_t ensure_stage(esp_handle *h, esp_handle::StageArea &sa, i64 want);
 void par_memcpy(void *dst, const void *src, size_t bytes);
 int32_t d2h_pipelined(esp_handle *h, void *dst, const void *d_src, size_t bytes);
+// pageable host memory -> device through the same two pinned bounce buffers (the host copy of chunk i+1 overlaps the transfer
+// of chunk i); returns when the device holds the data
+int32_t h2d_pipelined(esp_handle *h, void *d_dst, const void *src, size_t bytes);
 i64 fd_offset_host(i64 nx, i64 ny, i64 nz, i64 g);
 int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSetup *ps);
 int32_t prepart_rank(esp_handle *h, PartSetup *ps);

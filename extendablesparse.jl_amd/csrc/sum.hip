@@ -302,8 +302,7 @@ extern "C" int32_t esp_set_nzval(esp_handle *h, const double *nzval) {
     if (!nzval) return ESP_ERR_INVALID;
     (void)hipSetDevice(h->device);
     Span sp(h, ESP_ST_COPY);
-    HIPCK(h, hipMemcpyAsync(h->nzval.p, nzval, sizeof(double) * (size_t)h->nnz, hipMemcpyHostToDevice, h->stream));
-    HIPCK(h, hipStreamSynchronize(h->stream));
+    CK(h2d_pipelined(h, h->nzval.p, nzval, sizeof(double) * (size_t)h->nnz));
     sp.add(1);
     h->values_version++;
     return ESP_OK;
