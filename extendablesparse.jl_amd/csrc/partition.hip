@@ -803,7 +803,6 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
     bool ok = true;
     int pass_idx = 0;
     int npass_eff = npass;
-    bool window_checked = false;
     h->last_partition = 2;
     // pre-sorted streams: the first (up to) 16 bits in ONE pass (runpart.hpp)
     int passes_here = 0;
@@ -844,7 +843,6 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
                 h->last_partition = 1;
                 h->runs_penalty = 0;
                 maxlen = ml;
-                window_checked = true;
             } else {
                 h->runs_penalty = std::min(16, 2 * h->runs_penalty + 1);
                 h->runs_skip = h->runs_penalty;
