@@ -389,6 +389,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
     }
     CK(read_back());
     h->last_lazy_items = 0;
+    h->last_sum_join = 0;
     if (st.lazy) {
         // a segment the fused kernel refuses (a column run above 128, rows spread over more than 2^18): nothing of a
         // fresh-matrix flush has taken effect -- the caller expands the items and comes back with the entries

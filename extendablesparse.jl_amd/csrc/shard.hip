@@ -297,6 +297,11 @@ extern "C" int32_t esp_debug_last_lazy_items(const esp_handle *h, int32_t *on) {
     *on = h->last_lazy_items;
     return ESP_OK;
 }
+extern "C" int32_t esp_debug_last_sum_join(const esp_handle *h, int32_t *segments) {
+    if (!h || !segments) return ESP_ERR_INVALID;
+    *segments = h->last_sum_join;
+    return ESP_OK;
+}
 extern "C" int32_t esp_debug_last_local_small(const esp_handle *h, int32_t *small) {
     if (!h || !small) return ESP_ERR_INVALID;
     *small = h->last_group3 == 4 ? 5 : h->last_group3 == 3 ? 4 : h->last_group3 == 2 ? 3 : h->last_group3 ? 2 : h->last_local_small;

@@ -43,6 +43,41 @@ __global__ __launch_bounds__(256) void pair_list_k(const esplocal::MultiBuf *__r
     if (seg && seg[s + 1] > seg[s]) vlist[pos[g]] = ((u32)k << esplocal::MULTI_SEG_BITS) | (u32)s;
 }
 
+// the longest segment the combine flush would meet with 2 / 4 / 8 neighbouring segments of the folds' plan joined into one
+// (one thread per group of 8; out[0..2])
+__global__ void coarse_max_k(const i64 *__restrict__ pstart, int P, i64 S, unsigned long long *__restrict__ out) {
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    i64 m2 = 0, m4 = 0, m8 = 0;
+    if (g * 8 < S) {
+        i64 t[8];
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const i64 s = g * 8 + j;
+            t[j] = 0;
+            if (s < S)
+                for (int q = 0; q < P; q++) t[j] += pstart[(size_t)q * (size_t)(S + 1) + s + 1] - pstart[(size_t)q * (size_t)(S + 1) + s];
+        }
+#pragma unroll
+        for (int j = 0; j < 8; j += 2) m2 = max(m2, t[j] + t[j + 1]);
+        m4 = max(t[0] + t[1] + t[2] + t[3], t[4] + t[5] + t[6] + t[7]);
+        m8 = t[0] + t[1] + t[2] + t[3] + t[4] + t[5] + t[6] + t[7];
+    }
+    m2 = (i64)esp_wave_max((u32)m2), m4 = (i64)esp_wave_max((u32)m4), m8 = (i64)esp_wave_max((u32)m8);  // (totals below 2^32: checked by the host)
+    if ((threadIdx.x & 63) == 0) {
+        atomicMax(out + 0, (unsigned long long)m2);
+        atomicMax(out + 1, (unsigned long long)m4);
+        atomicMax(out + 2, (unsigned long long)m8);
+    }
+}
+// piece starts of the joined segments: every f-th entry of each piece's row (and its last)
+__global__ void coarsen_pieces_k(const i64 *__restrict__ pstart, int P, i64 S, int f, i64 *__restrict__ out) {
+    const i64 S2 = S / f;
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= (i64)P * (S2 + 1)) return;
+    const i64 q = g / (S2 + 1), s2 = g - q * (S2 + 1);
+    out[g] = pstart[(size_t)q * (size_t)(S + 1) + (size_t)(s2 * f)];
+}
+
 }  // namespace
 
 __global__ void piece_totals_k(const i64 *__restrict__ pstart, int P, i64 nb, unsigned long long *__restrict__ maxlen,
@@ -175,15 +210,44 @@ static int32_t flush_sum_items(esp_handle *dst, esp_handle *const *xs, int p, in
     HIPCK(dst, hipMemcpyAsync(TB, tab.data(), sizeof(void *) * 192, hipMemcpyHostToDevice, dst->stream));
     HIPCK(dst, hipMemcpyAsync(dst->pin_scalar, d_maxlen, 16, hipMemcpyDeviceToHost, dst->stream));
     HIPCK(dst, hipStreamSynchronize(dst->stream));
-    const i64 merged = (i64)dst->pin_scalar[0];
+    i64 merged = (i64)dst->pin_scalar[0];
     if (merged > (i64)esplocal::CAP || dst->pin_scalar[1] != 0) return ESP_OK;
+    // The folds' plan cuts the columns for ONE buffer's items; what p bands of a mesh leave per segment is a fraction of the
+    // bucket kernel's capacity, and its time follows the number of segments: 2 / 4 / 8 neighbours are joined while the longest
+    // joined segment still fits (the pairs' records lie buffer-major, a buffer's segments one behind the other: a joined piece
+    // is contiguous) and the kernel still counts the segment's columns in LDS.
+    int coarse = 1, rem_c = rem;
+    if (S >= 64 && merged * 2 <= (i64)esplocal::CAP) {
+        unsigned long long *d_cm = (unsigned long long *)dst->misc.p + 26;
+        HIPCK(dst, hipMemsetAsync(d_cm, 0, 24, dst->stream));
+        hipLaunchKernelGGL(coarse_max_k, dim3(grid_for((S + 7) / 8, 256)), dim3(256), 0, dst->stream, (const i64 *)pstart, p, S, d_cm);
+        HIPCK(dst, hipMemcpyAsync(dst->pin_scalar, d_cm, 24, hipMemcpyDeviceToHost, dst->stream));
+        HIPCK(dst, hipStreamSynchronize(dst->stream));
+        for (int lf = 3; lf >= 1; lf--)
+            if ((i64)dst->pin_scalar[lf - 1] <= (i64)esplocal::CAP && clb + lf <= esplocal::CL_MAX_BITS && rem + lf <= esplocal::MAX_REM_BITS) {
+                coarse = 1 << lf;
+                rem_c = rem + lf;
+                merged = (i64)dst->pin_scalar[lf - 1];
+                break;
+            }
+    }
+    i64 S_c = S;
+    if (coarse > 1) {
+        S_c = S / coarse;
+        const i64 np2 = (i64)p * (S_c + 1);
+        CK(ensure(dst, dst->hist, sizeof(i64) * (size_t)np2));
+        Span sp(dst, ESP_ST_SCAN);
+        hipLaunchKernelGGL(coarsen_pieces_k, dim3(grid_for(np2, 256)), dim3(256), 0, dst->stream, (const i64 *)pstart, p, S, coarse, (i64 *)dst->hist.p);
+        HIPCK(dst, hipMemcpyAsync(pstart, dst->hist.p, sizeof(i64) * (size_t)np2, hipMemcpyDeviceToDevice, dst->stream));
+        sp.add(2);
+    }
     note_kind(dst, ESP_COO, folded);
     dst->count = folded;
     pending_changed(dst);
     dst->part_assembled = true;
     dst->part_valid = false;
-    dst->part_P = p, dst->part_me = 0, dst->part_shift = rem;
-    dst->part_nb = (u32)S;
+    dst->part_P = p, dst->part_me = 0, dst->part_shift = rem_c;
+    dst->part_nb = (u32)S_c;
     dst->part_base = dst->win_base;
     dst->part_total = folded, dst->part_maxlen = merged, dst->part_own_lo = 0;
     dst->part_all_update = false;
@@ -191,6 +255,7 @@ static int32_t flush_sum_items(esp_handle *dst, esp_handle *const *xs, int p, in
     const int32_t rc = esp_flush(dst, ESP_FLUSH_ROUTED, new_nnz, pattern_changed);
     if (rc != ESP_OK) return rc;
     dst->last_lazy_items = 2;  // (esp_debug_last_lazy_items: 2 = the folds of a Base.sum ran as one launch over item records)
+    dst->last_sum_join = coarse;
     *served = true;
     return ESP_OK;
 }

@@ -499,6 +499,9 @@ int32_t esp_debug_last_local_small(const esp_handle *h, int32_t *small);
  * esp_debug_force_path(39): never.  2 (on the destination of esp_flush_sum): the folds of all buffers ran as ONE launch over their
  * item records and the combine flush read the folded records as pieces (every buffer held an element batch with the same plan) */
 int32_t esp_debug_last_lazy_items(const esp_handle *h, int32_t *on);
+/* how many neighbouring segments of the folds' plan the combine flush of the last esp_flush_sum of that kind (last_lazy_items 2)
+ * joined into one (1, 2, 4 or 8: as many as keep the longest joined segment within the bucket kernel's capacity); 0 otherwise */
+int32_t esp_debug_last_sum_join(const esp_handle *h, int32_t *segments);
 /* 1 when the last flush REBUILT the matrix for the entries behind a re-assembly's batch (a fresh flush whose segments start
  * with the stored entries of their columns: no look-ups against the stored columns, no join); esp_debug_force_path(40): never */
 int32_t esp_debug_last_rebuild(const esp_handle *h, int32_t *on);

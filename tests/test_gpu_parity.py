@@ -3329,6 +3329,11 @@ def test_flush_sum_over_element_batches(esp, orc):
         home._d.ck(home._d.lib.esp_debug_last_lazy_items(home._d.h, C.byref(v)))
         return v.value
 
+    def join_state(home):
+        v = C.c_int32()
+        home._d.ck(home._d.lib.esp_debug_last_sum_join(home._d.h, C.byref(v)))
+        return v.value
+
     def deal(cn, em, dg, p, how):
         nc = cn.shape[1]
         if how == "bands":
@@ -3361,6 +3366,7 @@ def test_flush_sum_over_element_batches(esp, orc):
             O = L + O                          # (successive csc + buffer: each buffer folded by itself, sparsematrixdilnkc.jl:397-435)
         assert_csc_equal(csc.arrays(), O.arrays(), "round %d" % rnd)
     # larger: device against device (the per-buffer folds: force_path 39 keeps every batch expanded)
+    joins = []     # (segments of the folds' plan the combine flush joined: bands of a mesh leave a fraction of a segment each)
     for dim, npd, p, how, diag, neg in ((2, 400, 16, "bands", True, -1), (2, 300, 5, "round_robin", False, 2), (3, 30, 8, "bands", True, 0)):
         nn = npd ** dim
         cn, em, dg = orc.fem_mesh(dim, npd, seed=0x5EED0004, order_mode=0, node_mode=0)
@@ -3380,6 +3386,7 @@ def test_flush_sum_over_element_batches(esp, orc):
                 csc = esp.SparseMatrixHIPCOO.sum(xs, csc, home=home)
                 if force == 0 and how == "bands":
                     assert lazy_state(home) == 2, (dim, npd, p, how, rnd, lazy_state(home))
+                    joins.append(join_state(home))
                 elif force == 0:
                     # (cells dealt round-robin: every buffer covers every column, a segment's records of all buffers together exceed
                     # the combine kernel's capacity -- the joint path declines after its folds and the general path takes the buffers
@@ -3392,3 +3399,4 @@ def test_flush_sum_over_element_batches(esp, orc):
             a = [r[2] for r in results if r[0] == 0 and r[1] == rnd][0]
             b = [r[2] for r in results if r[0] == 39 and r[1] == rnd][0]
             assert_csc_equal(a, b, "%d-D %d buffers %s round %d" % (dim, p, how, rnd))
+    assert max(joins) > 1 and all(j in (1, 2, 4, 8) for j in joins), joins
