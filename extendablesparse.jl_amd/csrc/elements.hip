@@ -131,6 +131,14 @@ int32_t elements_by_items(esp_handle *h, espelem::Args a, i64 E, bool *took) {
         a.keys_out = (u64 *)h->keys.p;
         a.vals_out = (double *)h->vals.p;
         const i64 S_final = (i64)st.S << lbits;
+        if (lbits && st.seg_start == (const i64 *)h->seg[1].p) {
+            // (the passes left their table in the array the sub-segment table goes to -- which grows, and is written while the
+            // coarse entries are still read: the coarse table moves aside first.  Found with released buffers poisoned.)
+            CK(ensure(h, h->segout, sizeof(i64) * (size_t)(st.S + 1)));
+            HIPCK(h, hipMemcpyAsync(h->segout.p, st.seg_start, sizeof(i64) * (size_t)(st.S + 1), hipMemcpyDeviceToDevice, h->stream));
+            HIPCK(h, hipStreamSynchronize(h->stream));
+            st.seg_start = (const i64 *)h->segout.p;
+        }
         CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(S_final + 1)));
         if (lbits) {
             unsigned long long *d_maxsub = (unsigned long long *)h->misc.p + 2;

@@ -32,12 +32,77 @@ int32_t ensure(esp_handle *h, DevBuf &b, size_t need, bool keep) {
         (void)hipFree(np);
         FAIL(h, ESP_ERR_HIP, "growing a device buffer failed: %s", hipGetErrorString(e));
     }
-    (void)hipFree(b.p);
+    {
+        DevBuf old = b;  // (through release: the experiments build may keep it poisoned)
+        release(old);
+    }
     b.p = np;
     b.bytes = want;
     return ESP_OK;
 }
+#ifdef ESP_EXPERIMENTS
+// ESP_POISON_FREE (experiments build): a released buffer is not freed but filled with 0xA5 and kept -- whoever still READS it
+// meets garbage at once (the parity fuzz then fails deterministically, single-threaded), and esp_exp_check_graveyard (called by
+// esp_destroy) finds whoever WROTE to it afterwards.  The hunt for use-after-release, GPU AddressSanitizer not being available.
+namespace {
+struct Grave { void *p; size_t bytes; };
+std::vector<Grave> g_graves;
+size_t g_grave_bytes = 0;  // (above 64 GB the oldest are checked one last time and really freed)
+std::mutex g_graves_m;
+__global__ void grave_check_k(const unsigned long long *p, size_t words, unsigned long long *bad) {
+    size_t n = 0;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < words; i += (size_t)gridDim.x * blockDim.x)
+        n += p[i] != 0xA5A5A5A5A5A5A5A5ull;
+    if (n) atomicAdd(bad, (unsigned long long)n);
+}
+bool poison_release(DevBuf &b) {
+    if (!esp_exp_env("ESP_POISON_FREE")) return false;
+    (void)hipDeviceSynchronize();
+    (void)hipMemset(b.p, 0xA5, b.bytes);
+    (void)hipDeviceSynchronize();
+    std::lock_guard<std::mutex> lk(g_graves_m);
+    g_graves.push_back({b.p, b.bytes});
+    g_grave_bytes += b.bytes;
+    return true;
+}
+}  // namespace
+void esp_exp_check_graveyard() {
+    if (!esp_exp_env("ESP_POISON_FREE")) return;
+    std::lock_guard<std::mutex> lk(g_graves_m);
+    (void)hipDeviceSynchronize();
+    unsigned long long *d_bad = nullptr;
+    if (hipMalloc((void **)&d_bad, 8) != hipSuccess) return;
+    size_t total = 0;
+    for (const Grave &g : g_graves) {
+        (void)hipMemset(d_bad, 0, 8);
+        hipLaunchKernelGGL(grave_check_k, dim3(1024), dim3(256), 0, 0, (const unsigned long long *)g.p, g.bytes / 8, d_bad);
+        unsigned long long bad = 0;
+        (void)hipMemcpy(&bad, d_bad, 8, hipMemcpyDeviceToHost);
+        if (bad) {
+            fprintf(stderr, "POISON: %llu words of a released buffer (%p, %zu bytes) were written after its release\n", bad, g.p, g.bytes);
+            (void)hipMemset(g.p, 0xA5, g.bytes);
+        }
+        total += g.bytes;
+    }
+    (void)hipFree(d_bad);
+    size_t drop = 0;
+    while (g_grave_bytes > ((size_t)64 << 30) && drop < g_graves.size()) {
+        (void)hipFree(g_graves[drop].p);
+        g_grave_bytes -= g_graves[drop].bytes;
+        drop++;
+    }
+    g_graves.erase(g_graves.begin(), g_graves.begin() + (long)drop);
+    if (esp_exp_env("ESP_POISON_VERBOSE")) fprintf(stderr, "POISON: %zu released buffers, %.1f MB checked\n", g_graves.size(), (double)total / 1e6);
+}
+#endif
 void release(DevBuf &b) {
+#ifdef ESP_EXPERIMENTS
+    if (b.p && poison_release(b)) {
+        b.p = nullptr;
+        b.bytes = 0;
+        return;
+    }
+#endif
     if (b.p) (void)hipFree(b.p);
     b.p = nullptr;
     b.bytes = 0;
@@ -200,6 +265,9 @@ extern "C" int32_t esp_destroy(esp_handle *h) {
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
     release_all(h);
+#ifdef ESP_EXPERIMENTS
+    esp_exp_check_graveyard();
+#endif
     if (h->pin_scalar) (void)hipHostFree(h->pin_scalar);
     if (h->pin_mw) (void)hipHostFree(h->pin_mw);
     if (h->pin_mw_done) (void)hipEventDestroy(h->pin_mw_done);

@@ -1,6 +1,7 @@
 // sum.hip -- libesparse_hip: Base.sum(buffers, csc) as ONE call (esp_flush_sum), and the values-only upload (esp_set_nzval)
 // of a plug-in whose CSC stays attached to its handle between flushes
 #include "internal.hpp"
+#include <thread>
 
 #include <chrono>
 
@@ -305,6 +306,27 @@ extern "C" int32_t esp_flush_sum(esp_handle *dst, esp_handle *const *xs, int32_t
         // per buffer: concurrent esp_flush calls on different handles -- each with hipFree / hipMalloc of its scratch and its own
         // non-blocking stream -- produced rare memory faults and wrong results on this stack (found by the parity fuzz in round
         // 5: 4 of 8 runs of one case; 0 of 8 serial), and 16 small pipelines did not overlap well anyway.)
+#ifdef ESP_EXPERIMENTS
+        if (esp_exp_env("ESP_SUM_THREADS")) {  // (round 4's form, for the hunt of NOTES/round5.md section 8: one host thread per buffer)
+            std::vector<std::thread> th;
+            std::vector<int32_t> rcs((size_t)p, ESP_OK);
+            std::vector<int64_t> zs((size_t)p, 0);
+            for (int k = 0; k < p; k++)
+                if (xs[k]->count != 0)
+                    th.emplace_back([&, k] {
+                        (void)hipSetDevice(xs[k]->device);
+                        rcs[(size_t)k] = esp_flush(xs[k], ESP_FLUSH_ROUTED, &zs[(size_t)k], nullptr);
+                    });
+            for (auto &t : th) t.join();
+            for (int k = 0; k < p; k++) {
+                if (rcs[(size_t)k] != ESP_OK) {
+                    dst->err = xs[k]->err;
+                    return rcs[(size_t)k];
+                }
+                folded += zs[(size_t)k];
+            }
+        } else
+#endif
         for (int k = 0; k < p; k++) {
             if (xs[k]->count == 0) continue;
             int64_t z = 0;
