@@ -459,8 +459,9 @@ typedef enum {
                                         (never the run lists of the previous, identical-looking batch)                      */
 } esp_debug_path;
 /* last_path reports which pipeline the last flush took (1 = LDS bucket path, 2 = general).
- * Environment: the product library reads ESP_HOST_THREADS (host threads esp_append_host / esp_get_csc may use beside the
- * caller's), ESP_RCCL_LIB (path of the RCCL library esp_group_create loads) and, as test hooks, ESP_DEBUG_FORCE_PATH (the
+ * Environment: the product library reads ESP_HOST_THREADS (host threads the transfers from / to pageable host arrays --
+ * esp_append_host, esp_set_csc / esp_set_nzval, esp_get_csc / esp_get_nzval, esp_append_elements_host -- may use beside the
+ * caller's: they go through two pinned bounce buffers, the host copy of one chunk overlapping the PCIe transfer of the other), ESP_RCCL_LIB (path of the RCCL library esp_group_create loads) and, as test hooks, ESP_DEBUG_FORCE_PATH (the
  * path every new handle starts with) and ESP_DEBUG_FAIL_COMM_INIT (esp_group_create fails as with a broken fabric) --
  * nothing else: the switches of the measurement tools exist in a -DESP_EXPERIMENTS build only (csrc/common.hpp). */
 int32_t esp_debug_force_path(esp_handle *h, int32_t path);
