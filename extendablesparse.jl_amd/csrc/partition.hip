@@ -736,14 +736,12 @@ int32_t append_first_pass(esp_handle *h, const i64 *d_rows, const i64 *d_cols, c
     const int S2 = 1 << bits0;
     CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(S2 + 1)));
     CK(ensure(h, h->tilef[1], sizeof(u64) * (size_t)(S2 + 1 + espscan::workspace_elems(S2 + 1))));
-    {
+    {  // (at most 512 segments: one launch for the table, its tile counts and the longest segment)
         Span sp(h, ESP_ST_SCAN);
-        hipLaunchKernelGGL(espradix::new_segments_k, dim3(grid_for(S2 + 1, 256)), dim3(256), 0, h->stream, (const u64 *)h->hist.p,
-                           (const i64 *)h->seg[0].p, (const i64 *)h->tilef[0].p, 1, bits0, (i64 *)h->seg[1].p, count);
-        u64 *tf = (u64 *)h->tilef[1].p;
-        hipLaunchKernelGGL(espradix::seg_tiles_k, dim3(grid_for(S2 + 1, 256)), dim3(256), 0, h->stream, (const i64 *)h->seg[1].p, (i64)S2,
-                           (i64)espradix::TILE, tf, d_maxlen);
-        sp.add(2 + espscan::exclusive<u64, false>(h->stream, tf, tf, S2 + 1, tf + S2 + 1));
+        static_assert((1 << espradix::MAX_BITS) < espradix::SMALL_TABLE, "the first pass's table is a small one");
+        hipLaunchKernelGGL(espradix::small_table_k, dim3(1), dim3(256), 0, h->stream, (const u64 *)h->hist.p, (const i64 *)h->seg[0].p,
+                           (const i64 *)h->tilef[0].p, 1, bits0, (i64 *)h->seg[1].p, count, (i64)espradix::TILE, (u64 *)h->tilef[1].p, d_maxlen);
+        sp.add(1);
     }
     HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_err, 8, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipMemcpyAsync(h->pin_scalar + 1, d_maxlen, 8, hipMemcpyDeviceToHost, h->stream));
@@ -932,7 +930,13 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
         const int S2 = S << bits;
         CK(ensure(h, h->seg[1 - cur], sizeof(i64) * (size_t)(S2 + 1)));
         CK(ensure(h, h->tilef[1 - cur], sizeof(u64) * (size_t)(S2 + 1 + espscan::workspace_elems(S2 + 1))));
-        {
+        if (S2 < espradix::SMALL_TABLE) {  // (a small table: segments, tile counts, their scan and the longest segment in one launch)
+            Span sp(h, ESP_ST_SCAN);
+            hipLaunchKernelGGL(espradix::small_table_k, dim3(1), dim3(256), 0, h->stream, (const u64 *)h->hist.p, (const i64 *)h->seg[cur].p,
+                               (const i64 *)h->tilef[cur].p, S, bits, (i64 *)h->seg[1 - cur].p, E, (i64)espradix::TILE, (u64 *)h->tilef[1 - cur].p,
+                               d_maxlen);
+            sp.add(1);
+        } else {
             Span sp(h, ESP_ST_SCAN);
             hipLaunchKernelGGL(espradix::new_segments_k, dim3(grid_for(S2 + 1, 256)), dim3(256), 0, h->stream, (const u64 *)h->hist.p,
                                (const i64 *)h->seg[cur].p, (const i64 *)h->tilef[cur].p, S, bits, (i64 *)h->seg[1 - cur].p, E);

@@ -524,4 +524,64 @@ static __global__ void seg_tiles_k(const i64 *__restrict__ seg_start, i64 S, i64
     }
 }
 
+// new_segments_k + seg_tiles_k + the scan of the tile counts in ONE launch, for a table of at most 2047 segments (the first pass
+// of a flush: 128 .. 512 segments) -- four launches and a memset less; *maxlen is written, not maximised (nobody else writes
+// it in this launch)
+constexpr int SMALL_TABLE = 2048;
+static __global__ __launch_bounds__(256) void small_table_k(const u64 *__restrict__ hist, const i64 *__restrict__ seg_start,
+                                                        const i64 *__restrict__ tile_first, int S, int bits,
+                                                        i64 *__restrict__ new_seg_start, i64 total, i64 tile,
+                                                        u64 *__restrict__ new_tile_first, unsigned long long *__restrict__ maxlen) {
+    __shared__ i64 st[SMALL_TABLE + 1];
+    __shared__ u64 lw[4];
+    __shared__ u64 wmax[4];
+    const int t = threadIdx.x;
+    const int R = 1 << bits;
+    const int NS = S * R;  // (< SMALL_TABLE)
+    for (int g = t; g <= NS; g += 256) {
+        i64 v = total;
+        if (g < NS) {
+            const int s = g >> bits, d = g & (R - 1);
+            const i64 nts = tile_first[s + 1] - tile_first[s];
+            v = nts == 0 ? seg_start[s] : (i64)hist[tile_first[s] * R + (i64)d * nts];
+        }
+        st[g] = v;
+        new_seg_start[g] = v;
+    }
+    __syncthreads();
+    // tile counts of 8 consecutive segments per thread, exclusive scan over the block
+    u64 cnt[8], run = 0, mx = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int g = t * 8 + k;
+        u64 c = 0;
+        if (g < NS) {
+            const u64 len = (u64)(st[g + 1] - st[g]);
+            mx = len > mx ? len : mx;
+            c = (len + (u64)tile - 1) / (u64)tile;
+        }
+        cnt[k] = run;
+        run += c;
+    }
+    u64 tot;
+    const u64 pre = espscan::block_exclusive<u64, false>(run, lw, &tot);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        const int g = t * 8 + k;
+        if (g <= NS) new_tile_first[g] = pre + cnt[k];
+    }
+    // the longest segment
+    for (int o = 32; o; o >>= 1) {
+        const u64 x = __shfl_xor(mx, o, 64);
+        mx = x > mx ? x : mx;
+    }
+    if ((t & 63) == 0) wmax[t >> 6] = mx;
+    __syncthreads();
+    if (t == 0) {
+        u64 m = wmax[0];
+        for (int i = 1; i < 4; i++) m = wmax[i] > m ? wmax[i] : m;
+        *maxlen = m;
+    }
+}
+
 }  // namespace espradix
