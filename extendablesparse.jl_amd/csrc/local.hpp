@@ -1415,6 +1415,12 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     __shared__ u32 s_early;
     __shared__ u32 s_rmin, s_rmax;  // group tier: smallest / largest row of the segment
     __shared__ i64 s_win[66];
+    // scratch of the radix tier, NOT inside s_win: between a wave's reads of s_win (its segment's bounds) and another wave's
+    // first scratch store there is no workgroup barrier when the column tiers are skipped (cl_bits < 0) -- the radix tier used to
+    // keep its two words per wave in s_win[0 .. 16) and a wave that was late met the other waves' AND / OR masks instead of its
+    // segment's bounds whenever its ticket lay 17 .. 32 below its workgroup index (NOTES/round6.md: what corrupted a handle whose
+    // flush ran beside another handle's)
+    __shared__ u64 s_rtail[SMALL ? 1 : 2 * WAVES];
     u32(*cnt)[256] = reinterpret_cast<u32(*)[256]>(cntraw);
     u32 *ccnt = cntraw;
 
@@ -1837,7 +1843,7 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
             __syncthreads();
         }
         const int npass = radix_tail(k, skey, cnt, lw, refill ? a.rem_bits + IDX_BITS : a.rem_bits, t, lane, w, wbase, n,
-                                     reinterpret_cast<u64 *>(s_win), refill ? ESP_TAG_BITS : SUB_SHIFT);
+                                     s_rtail, refill ? ESP_TAG_BITS : SUB_SHIFT);
         if (npass == 0) {
 #pragma unroll
             for (int i = 0; i < ITEMS; i++) skey[wbase + i * ESP_WAVE] = k[i];

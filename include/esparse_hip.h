@@ -22,11 +22,11 @@
  *   - output arrays are caller-allocated (Julia Vectors) after a size query;
  *   - one handle = one device + one HIP stream; a handle is not thread-safe
  *     (like one reference buffer per `tid`); distinct handles are independent and may be
- *     driven from different host threads -- with one caveat found by the parity fuzz
- *     (NOTES/round5.md section 8): concurrent esp_flush calls on different handles that
- *     allocate or free device memory (first use, growth) showed rare faults on this
- *     stack; warm a handle on one thread first.  The library itself starts no threads on
- *     the flush path;
+ *     driven from different host threads concurrently -- fills, flushes, transfers, first
+ *     use included (genericmtextendablesparsematrixcsc.jl:87-99: one buffer per task;
+ *     tests/test_concurrent_handles.py; the corruption rounds 4 and 5 saw here was a
+ *     missing barrier inside the bucket kernel, NOTES/round6.md section 1).  The library
+ *     itself starts no threads on the flush path;
  *   - element types: Float64 values, Int64 indices (the reference's default
  *     ExtendableSparseMatrix{Float64,Int64}); other Tv/Ti stay on the CPU path.
  */
