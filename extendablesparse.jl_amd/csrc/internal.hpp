@@ -110,6 +110,7 @@ struct esp_handle {
     int last_rebuild = 0;        // the last flush's tail rebuilt the matrix (flush_rebuild: the stored CSC as the first piece of a fresh flush)
     int last_lazy_items = 0;     // the last flush's bucket kernel formed its updates from item records (esp_debug_last_lazy_items)
     int last_sum_join = 0;     // esp_debug_last_sum_join
+    double last_sum_ms[2] = {0.0, 0.0};  // esp_debug_last_sum_ms: host wall-clock of the last esp_flush_sum's folds / gather + combine flush
     // The entries appended behind a batch over a STORED pattern were partitioned as they came (append_tail_partitioned):
     // pre.tail packed keys in bucket order of a plan of their own -- still a pending stream like any other (a stable
     // partition keeps every column's order), so whoever does not know about it loses nothing; esp_flush's split

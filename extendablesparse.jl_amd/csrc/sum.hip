@@ -93,9 +93,11 @@ __global__ void piece_totals_k(const i64 *__restrict__ pstart, int P, i64 nb, un
 // applicable or refused (nothing has happened: the general path below takes the buffers as they are).
 static int32_t flush_sum_items(esp_handle *dst, esp_handle *const *xs, int p, int64_t *new_nnz, int32_t *pattern_changed, bool *served) {
     *served = false;
+    const auto t_in = std::chrono::steady_clock::now();
     if (p < 2 || p > esplocal::MAX_PIECES || dst->count != 0 || windowed(dst) || dst->shard_user || dst->force_path != ESP_PATH_AUTO) return ESP_OK;
     const esp_handle *ref = nullptr;
     i64 total_in = 0;
+    int pb_min = 1 << 20, pb_max = 0;
     for (int k = 0; k < p; k++) {
         const esp_handle *x = xs[k];
         if (x->count == 0) continue;
@@ -106,19 +108,26 @@ static int32_t flush_sum_items(esp_handle *dst, esp_handle *const *xs, int p, in
         if (x->kind_uniform != el.kind || x->kind_noted != x->count || (el.kind != ESP_UPDATE && el.kind != ESP_RAWUPDATE)) return ESP_OK;
         if (!ref) ref = x;
         const espelem::Args &e0 = ref->lazy.el;
-        if (x->pre.K != ref->pre.K || x->pre.pb != ref->pre.pb || x->pre.base != ref->pre.base || x->pre.span != ref->pre.span ||
+        if (x->pre.K != ref->pre.K || x->pre.base != ref->pre.base || x->pre.span != ref->pre.span ||
             el.nloc != e0.nloc || (el.diag != nullptr) != (e0.diag != nullptr) || el.kind != e0.kind || x->L.rb != dst->L.rb)
             return ESP_OK;
+        pb_min = std::min(pb_min, x->pre.pb), pb_max = std::max(pb_max, x->pre.pb);
         total_in += x->count;
     }
     if (!ref || ref->pre.base != dst->win_base || ref->pre.span != dst->win_span) return ESP_OK;
-    const int K = ref->pre.K, pb = ref->pre.pb, rem = K - pb, clb = rem - dst->L.rb;
+    // The buffers' COMMON plan is the coarsest of their own: every handle plans its item partition from its own history
+    // (plan_prefix_bits: seen_spread), so two bands of one mesh may come with prefixes that differ by a bit -- the segments of the finer
+    // plan are halves of the coarser one's, its items lie in the same order, and every 2^d-th entry of its segment table IS the
+    // table of the coarser plan (a joined segment that outgrows the fused kernel is refused by it like any other: general path)
+    if (pb_max - pb_min > 3) return ESP_OK;
+    const int K = ref->pre.K, pb = pb_min, rem = K - pb, clb = rem - dst->L.rb;
     if (pb > esplocal::MULTI_SEG_BITS || clb < 0 || clb > esplocal::G3_CL_BITS || clb + dst->L.rb > 32 || dst->L.rb > 30 || rem > 32) return ESP_OK;
     const i64 S = (i64)1 << pb, PS = (i64)p * S;
     if (PS > ((i64)1 << 24) || total_in >= 0xFFFFFFF0ll) return ESP_OK;
     const espelem::Args &e0 = ref->lazy.el;
     // ---- tables: per-buffer arguments | the pair list; flags / positions
     std::vector<esplocal::MultiBuf> mb((size_t)p);
+    if (pb_max > pb_min) CK(ensure(dst, dst->tseg, sizeof(i64) * (size_t)p * (size_t)(S + 1)));  // (dst has nothing pending: its tail table is free)
     for (int k = 0; k < p; k++) {
         const esp_handle *x = xs[k];
         esplocal::MultiBuf &b = mb[(size_t)k];
@@ -128,6 +137,12 @@ static int32_t flush_sum_items(esp_handle *dst, esp_handle *const *xs, int p, in
         b.sorted = el.sorted_keys, b.seg = (const i64 *)x->seg[1].p, b.elmat = el.elmat, b.cellrec = el.cellrec;
         b.negate = el.negate, b.low = el.vrb + ESP_TAG_BITS;
         HIPCK(dst, hipStreamSynchronize(x->stream));  // (the buffer's item partition has run on ITS stream)
+        if (x->pre.pb > pb) {  // a finer plan: its table at the common prefix
+            i64 *coarse_tab = (i64 *)dst->tseg.p + (size_t)k * (size_t)(S + 1);
+            hipLaunchKernelGGL(coarsen_pieces_k, dim3(grid_for(S + 1, 256)), dim3(256), 0, dst->stream, (const i64 *)x->seg[1].p, 1, (i64)1 << x->pre.pb,
+                               1 << (x->pre.pb - pb), coarse_tab);
+            b.seg = coarse_tab;
+        }
     }
     const size_t o_list = 4096;
     CK(ensure(dst, dst->heads, o_list + sizeof(u32) * (size_t)PS));
@@ -196,6 +211,7 @@ static int32_t flush_sum_items(esp_handle *dst, esp_handle *const *xs, int p, in
     if (err & (2u | 4u | 8u)) return ESP_OK;  // (a segment the fused kernel does not take: nothing has happened to the buffers)
     const i64 folded = (i64)(dst->pin_scalar[0] & esplocal::ST_VAL);
     if (folded == 0) return ESP_OK;
+    const auto t_folded = std::chrono::steady_clock::now();
     // ---- the combine: piece starts = exclusive scan of the pairs' record counts (buffer-major = the order they were written in)
     unsigned long long *d_maxlen = (unsigned long long *)dst->misc.p + 24;
     HIPCK(dst, hipMemsetAsync(d_maxlen, 0, 16, dst->stream));
@@ -257,6 +273,9 @@ static int32_t flush_sum_items(esp_handle *dst, esp_handle *const *xs, int p, in
     if (rc != ESP_OK) return rc;
     dst->last_lazy_items = 2;  // (esp_debug_last_lazy_items: 2 = the folds of a Base.sum ran as one launch over item records)
     dst->last_sum_join = coarse;
+    (void)hipStreamSynchronize(dst->stream);
+    dst->last_sum_ms[0] = std::chrono::duration<double, std::milli>(t_folded - t_in).count();
+    dst->last_sum_ms[1] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_folded).count();
     *served = true;
     return ESP_OK;
 }
@@ -364,6 +383,11 @@ extern "C" int32_t esp_flush_sum(esp_handle *dst, esp_handle *const *xs, int32_t
         return esp_flush(dst, ESP_FLUSH_ROUTED, new_nnz, pattern_changed);
     };
     const int32_t rc = run();
+    if (!by_items) {
+        (void)hipStreamSynchronize(dst->stream);
+        dst->last_sum_ms[0] = t_b - t_a;
+        dst->last_sum_ms[1] = now() - t_b;
+    }
     if (trace) {
         (void)hipStreamSynchronize(dst->stream);
         fprintf(stderr, "esp_flush_sum: %d buffers %lld entries -> folds %.3f ms (%lld entries), gather %.3f ms, combine flush %.3f ms\n", p, (long long)total,
@@ -383,6 +407,13 @@ extern "C" int32_t esp_flush_sum(esp_handle *dst, esp_handle *const *xs, int32_t
 // nzval of the attached CSC := the caller's values (H2D of the values only: the pattern -- colptr, rowval -- is the one
 // the handle holds since the caller's last esp_get_csc / esp_set_csc).  What a plug-in whose CSC stays on the device
 // between flushes uploads instead of the whole matrix when only nonzeros(A) can have been edited on the host.
+extern "C" int32_t esp_debug_last_sum_ms(const esp_handle *h, double *folds_ms, double *combine_ms) {
+    if (!h || !folds_ms || !combine_ms) return ESP_ERR_INVALID;
+    *folds_ms = h->last_sum_ms[0];
+    *combine_ms = h->last_sum_ms[1];
+    return ESP_OK;
+}
+
 extern "C" int32_t esp_set_nzval(esp_handle *h, const double *nzval) {
     if (!h) return ESP_ERR_INVALID;
     if (h->nnz == 0) return ESP_OK;

@@ -226,7 +226,9 @@ int32_t esp_flush_sum(esp_handle *dst, esp_handle *const *xs, int32_t p, int64_t
                       int32_t *pattern_changed);
 /* SparseArrays.nnz of the device CSC (does not flush) */
 int32_t esp_nnz(const esp_handle *h, int64_t *nnz);
-/* D2H into caller arrays: colptr (n+1), rowval (nnz), nzval (nnz); Julia layout */
+/* D2H into caller arrays: colptr (n+1), rowval (nnz), nzval (nnz); Julia layout.  Large destinations (> 8 MiB) get
+ * madvise(MADV_HUGEPAGE) on their 2 MiB-aligned interior before the first byte lands -- a hint that changes no contents: a
+ * vector the caller has just allocated is untouched memory, and its first touch otherwise costs ten times the copy */
 int32_t esp_get_csc(esp_handle *h, int64_t *colptr, int64_t *rowval, double *nzval);
 /* The same transfers for Int32 index arrays (SparseMatrixCSC{Float64,Int32}: extendable.jl:10-25 is generic in Ti).  The
  * device CSC stays Int64; colptr / rowval are narrowed (widened) on the device, so they cross PCIe as 4 bytes.
@@ -503,6 +505,10 @@ int32_t esp_debug_last_lazy_items(const esp_handle *h, int32_t *on);
 /* how many neighbouring segments of the folds' plan the combine flush of the last esp_flush_sum of that kind (last_lazy_items 2)
  * joined into one (1, 2, 4 or 8: as many as keep the longest joined segment within the bucket kernel's capacity); 0 otherwise */
 int32_t esp_debug_last_sum_join(const esp_handle *h, int32_t *segments);
+/* host wall-clock split of the destination's last esp_flush_sum, in ms: the buffers' folds (one launch over their item records, or
+ * every buffer's own flush) | everything behind them (gather, combine flush, its completion) -- what a bench line reports beside
+ * esp_debug_last_lazy_items / _sum_join so that a slow run can be told from a run that took the other path */
+int32_t esp_debug_last_sum_ms(const esp_handle *h, double *folds_ms, double *combine_ms);
 /* 1 when the last flush REBUILT the matrix for the entries behind a re-assembly's batch (a fresh flush whose segments start
  * with the stored entries of their columns: no look-ups against the stored columns, no join); esp_debug_force_path(40): never */
 int32_t esp_debug_last_rebuild(const esp_handle *h, int32_t *on);

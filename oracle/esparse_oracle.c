@@ -637,6 +637,21 @@ int orc_mt_updateindex(orc_mt *t, int op, double v, i64 i, i64 j, i64 tid) { /* 
         orc_lnk_updateindex(t->x[tid - 1], op, v, i, j);
     return 0;
 }
+/* a batch of (raw)updateindex! calls with one tid: the loop a task of test/femtools.jl:88-107 runs over its partition */
+int orc_mt_apply(orc_mt *t, i64 count, const uint8_t *kinds, const i64 *I, const i64 *J, const double *V, i64 tid) {
+    for (i64 e = 0; e < count; e++) {
+        const int k = kinds ? kinds[e] : ORC_KIND_RAWUPDATE;
+        int rc;
+        if (k == ORC_KIND_UPDATE)
+            rc = orc_mt_updateindex(t, ORC_OP_ADD, V[e], I[e], J[e], tid);
+        else if (k == ORC_KIND_RAWUPDATE)
+            rc = orc_mt_rawupdateindex(t, ORC_OP_ADD, V[e], I[e], J[e], tid);
+        else
+            rc = orc_mt_setindex(t, V[e], I[e], J[e]);
+        if (rc) return rc;
+    }
+    return 0;
+}
 /* flush!: :45-51 + Base.sum: sparsematrixdilnkc.jl:397-435 */
 int orc_mt_flush(orc_mt *t) {
     i64 lnew = orc_mt_nnznew(t);

@@ -105,6 +105,7 @@ void orc_mt_free(orc_mt *);
 int orc_mt_setindex(orc_mt *, double v, i64 i, i64 j);
 int orc_mt_updateindex(orc_mt *, int op, double v, i64 i, i64 j, i64 tid);
 int orc_mt_rawupdateindex(orc_mt *, int op, double v, i64 i, i64 j, i64 tid);
+int orc_mt_apply(orc_mt *, i64 count, const uint8_t *kinds, const i64 *I, const i64 *J, const double *V, i64 tid);
 int orc_mt_getindex(const orc_mt *, i64 i, i64 j, double *out);
 i64 orc_mt_nnznew(const orc_mt *);
 int orc_mt_flush(orc_mt *);

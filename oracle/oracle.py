@@ -140,6 +140,7 @@ def lib():
     sig("orc_mt_setindex", C.c_int, vp, C.c_double, i64, i64)
     sig("orc_mt_updateindex", C.c_int, vp, C.c_int, C.c_double, i64, i64, i64)
     sig("orc_mt_rawupdateindex", C.c_int, vp, C.c_int, C.c_double, i64, i64, i64)
+    sig("orc_mt_apply", C.c_int, vp, i64, p_u8, p_i64, p_i64, p_f64, i64)
     sig("orc_mt_getindex", C.c_int, vp, i64, i64, p_f64)
     sig("orc_mt_nnznew", i64, vp)
     sig("orc_mt_flush", C.c_int, vp)
@@ -419,6 +420,18 @@ class MTExtendableSparseMatrix:
 
     def rawupdateindex(self, op, v, i, j, tid=1):
         _check(lib().orc_mt_rawupdateindex(self._h, op, float(v), i, j, tid))
+
+    def apply(self, kinds, I, J, V, tid=1):
+        """a batch of per-entry calls with one tid, in order (kinds None: rawupdateindex!)"""
+        I = np.ascontiguousarray(I, np.int64)
+        J = np.ascontiguousarray(J, np.int64)
+        V = np.ascontiguousarray(V, np.float64)
+        kk = None if kinds is None else np.ascontiguousarray(kinds, np.uint8)
+        kp = None if kk is None else kk.ctypes.data_as(C.POINTER(C.c_uint8))
+        rc = lib().orc_mt_apply(self._h, len(I), kp, _pi(I), _pi(J), _pf(V), tid)
+        if rc == -2:
+            raise RuntimeError("use rawupdateindex! for new entries")
+        _check(rc)
 
     def nnznew(self):
         return lib().orc_mt_nnznew(self._h)

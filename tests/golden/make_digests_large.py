@@ -102,6 +102,28 @@ def main():
         lines.append("%s nnz=%d csc=%s" % (tag, len(rv), digest(cp, rv, nz)))
         print(lines[-1], flush=True)
         del A, cp, rv, nz
+    # flush! of the MT wrapper (genericmtextendablesparsematrixcsc.jl:45-51 = Base.sum(xmatrices, csc)): the 2-D mesh in its natural
+    # cell order dealt to 16 partition buffers (tid t = the cells [nc t / 16, nc (t + 1) / 16): a band of the grid), every task's
+    # loop of test/femtools.jl:88-107 with rawupdateindex!, then ONE flush! -- bench.py's cfg_mt_sum and the test of the same name
+    for npd, p in ((1000, 16), (3163, 16)):
+        tag = "mt2d_%d_p%d" % (npd, p)
+        if not want(tag):
+            continue
+        nn, nc, cnt = orc.fem_sizes(2, npd)
+        M = orc.MTExtendableSparseMatrix(nn, nn, p)
+        for t in range(p):
+            a, b = nc * t // p, nc * (t + 1) // p
+            for p0 in range(a, b, 1 << 22):
+                p1 = min(b, p0 + (1 << 22))
+                cn, em, dg = orc.fem_mesh(2, npd, seed=0x5EED0004, order_mode=0, node_mode=0, p0=p0, p1=p1)
+                I, J, V = orc.elements_stream(cn, em, dg)
+                M.apply(None, I, J, V, tid=t + 1)
+                del I, J, V, cn, em, dg
+        M.flush()
+        cp, rv, nz = M.arrays()
+        lines.append("%s nnz=%d csc=%s" % (tag, len(rv), digest(cp, rv, nz)))
+        print(lines[-1], flush=True)
+        del M, cp, rv, nz
     for ln in lines:
         kept[ln.split()[0]] = ln
     with open(path, "w") as f:

@@ -3400,3 +3400,24 @@ def test_flush_sum_over_element_batches(esp, orc):
             b = [r[2] for r in results if r[0] == 39 and r[1] == rnd][0]
             assert_csc_equal(a, b, "%d-D %d buffers %s round %d" % (dim, p, how, rnd))
     assert max(joins) > 1 and all(j in (1, 2, 4, 8) for j in joins), joins
+    # buffers whose own plans differ (every handle plans its item partition from its own history; here: the plan hook on two of
+    # them, one / two prefix bits more): the joint path takes the coarsest plan and reads the finer buffers' tables at it
+    dim, npd, p = 2, 400, 8
+    nn = npd ** dim
+    cn, em, dg = orc.fem_mesh(dim, npd, seed=0x5EED0004, order_mode=0, node_mode=0)
+    parts = deal(cn, em, dg, p, "bands")
+    results = []
+    for caps in ((0, 0, 0, 0, 0, 0, 0, 0), (0, 0, 0, 40.0, 0, 0, 20.0, 0)):
+        xs = [esp.SparseMatrixHIPCOO(nn, nn) for _ in range(p)]
+        for x, cap in zip(xs, caps):
+            x._d.ck(x._d.lib.esp_debug_plan_cap(x._d.h, C.c_double(cap)))
+        home = esp.SparseMatrixHIPCOO(nn, nn)
+        csc = esp.SparseMatrixCSC(nn, nn)
+        for rnd in range(2):
+            for t, (c, e, d) in enumerate(parts):
+                xs[t].append_elements(c, e, d)
+            csc = esp.SparseMatrixHIPCOO.sum(xs, csc, home=home)
+            assert lazy_state(home) == 2, (caps, rnd, lazy_state(home))
+            results.append(csc.arrays())
+    assert_csc_equal(results[0], results[2], "plans that differ, fresh")
+    assert_csc_equal(results[1], results[3], "plans that differ, stored pattern")
