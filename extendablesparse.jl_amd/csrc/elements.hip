@@ -241,6 +241,11 @@ extern "C" int32_t esp_elements_keep_plan(esp_handle *h, int32_t on) {
     h->elemplan.keep = on != 0;
     if (!on) {
         (void)hipSetDevice(h->device);
+        // (a pending batch of esp_append_elements_again that stayed a list of items reads the plan's item order and cell records
+        // at flush time: its updates are formed now, before the plan's buffers go)
+        if (h->lazy.on && h->lazy.src == 2 &&
+            (h->lazy.el.sorted_keys == (const u64 *)h->elemplan.sorted.p || h->lazy.el.cellrec == (char *)h->elemplan.cellrec.p))
+            CK(lazy_expand(h));
         HIPCK(h, hipStreamSynchronize(h->stream));
         h->elemplan.valid = false;
         release(h->elemplan.sorted);

@@ -125,6 +125,12 @@ void release_all(esp_handle *h) {
         sa->cap = 0;
     }
     for (int i = 0; i < 2; i++) {
+        if (h->bounce.pin[i]) (void)hipHostFree(h->bounce.pin[i]);
+        if (h->bounce.ev[i]) (void)hipEventDestroy(h->bounce.ev[i]);
+        h->bounce.pin[i] = nullptr, h->bounce.ev[i] = nullptr;
+    }
+    h->bounce.bytes = 0;
+    for (int i = 0; i < 2; i++) {
         if (h->cpack.keys[i]) (void)hipHostFree(h->cpack.keys[i]);
         if (h->cpack.vals[i]) (void)hipHostFree(h->cpack.vals[i]);
         if (h->cpack.done[i]) (void)hipEventDestroy(h->cpack.done[i]);
@@ -996,6 +1002,23 @@ extern "C" int32_t esp_set_csc(esp_handle *h, const int64_t *colptr, const int64
 // Device -> pageable host memory (a Julia Vector, a NumPy array) through two pinned bounce buffers: the
 // PCIe transfer of chunk i+1 overlaps the (multi-threaded) host copy of chunk i.  A plain hipMemcpy into
 // pageable memory runs at ~10 GB/s here, this at ~45 GB/s.
+int32_t ensure_bounce(esp_handle *h) {
+    esp_handle::Bounce &b = h->bounce;
+    const size_t want = (size_t)32 << 20;
+    for (int i = 0; i < 2; i++) {
+        if (!b.pin[i]) {
+            const hipError_t e = hipHostMalloc((void **)&b.pin[i], want, hipHostMallocDefault);
+            if (e != hipSuccess) {
+                b.pin[i] = nullptr;
+                FAIL(h, ESP_ERR_NOMEM, "pinned bounce buffer: %s", hipGetErrorString(e));
+            }
+        }
+        if (!b.ev[i]) HIPCK(h, hipEventCreateWithFlags(&b.ev[i], hipEventDisableTiming));
+    }
+    b.bytes = want;
+    return ESP_OK;
+}
+
 // A large destination the caller has just allocated (the vectors of a fresh SparseMatrixCSC: Base.sum and `lnk + csc` return new
 // arrays) is untouched memory: the host copy below pays one page fault per 4 KiB -- 560 MB: 48 ms with eight threads on the hosts
 // of this pool, against 4.5 ms for the copy itself (tools/r6_prefault.c).  With transparent huge pages in `madvise` mode a hint on
@@ -1016,29 +1039,29 @@ int32_t d2h_pipelined(esp_handle *h, void *dst, const void *d_src, size_t bytes)
         return ESP_OK;
     }
     hint_huge_pages(dst, bytes);
-    CK(ensure_stage(h, h->bulk, (i64)1 << 22));  // rows / cols of the bulk area: 2 x 32 MiB pinned
-    char *pin[2] = {(char *)h->bulk.rows, (char *)h->bulk.cols};
-    const size_t chunk = (size_t)h->bulk.cap * 8;
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    for (int i = 0; i < 2; i++) HIPCK(h, hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    CK(ensure_bounce(h));
+    HIPCK(h, hipStreamSynchronize(h->stream));  // (an earlier transfer through the halves is over)
+    char *const *pin = h->bounce.pin;
+    const size_t chunk = h->bounce.bytes;
+    hipEvent_t *ev = h->bounce.ev;
     const size_t nchunks = (bytes + chunk - 1) / chunk;
     int32_t rc = ESP_OK;
+    hipError_t he = hipSuccess;
     for (size_t c = 0; c <= nchunks && rc == ESP_OK; c++) {
         if (c < nchunks) {  // issue the transfer of chunk c
             const size_t o = c * chunk, len = std::min(chunk, bytes - o);
-            if (hipMemcpyAsync(pin[c & 1], (const char *)d_src + o, len, hipMemcpyDeviceToHost, h->stream) != hipSuccess ||
-                hipEventRecord(ev[c & 1], h->stream) != hipSuccess)
+            if ((he = hipMemcpyAsync(pin[c & 1], (const char *)d_src + o, len, hipMemcpyDeviceToHost, h->stream)) != hipSuccess ||
+                (he = hipEventRecord(ev[c & 1], h->stream)) != hipSuccess)
                 rc = ESP_ERR_HIP;
         }
         if (c > 0 && rc == ESP_OK) {  // ... while chunk c-1 moves from its bounce buffer to the caller
             const size_t o = (c - 1) * chunk, len = std::min(chunk, bytes - o);
-            if (hipEventSynchronize(ev[(c - 1) & 1]) != hipSuccess) rc = ESP_ERR_HIP;
+            if ((he = hipEventSynchronize(ev[(c - 1) & 1])) != hipSuccess) rc = ESP_ERR_HIP;
             else par_memcpy((char *)dst + o, pin[(c - 1) & 1], len);
         }
     }
     (void)hipStreamSynchronize(h->stream);
-    for (int i = 0; i < 2; i++) (void)hipEventDestroy(ev[i]);
-    if (rc != ESP_OK) FAIL(h, ESP_ERR_HIP, "device-to-host transfer failed");
+    if (rc != ESP_OK) FAIL(h, ESP_ERR_HIP, "device-to-host transfer failed: %s", hipGetErrorString(he));
     return ESP_OK;
 }
 
@@ -1053,28 +1076,27 @@ int32_t h2d_pipelined(esp_handle *h, void *d_dst, const void *src, size_t bytes)
         HIPCK(h, hipStreamSynchronize(h->stream));
         return ESP_OK;
     }
-    CK(ensure_stage(h, h->bulk, (i64)1 << 22));
+    CK(ensure_bounce(h));
     HIPCK(h, hipStreamSynchronize(h->stream));  // (an earlier transfer out of / into the halves is over)
-    char *pin[2] = {(char *)h->bulk.rows, (char *)h->bulk.cols};
-    const size_t chunk = (size_t)h->bulk.cap * 8;
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    for (int i = 0; i < 2; i++) HIPCK(h, hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    char *const *pin = h->bounce.pin;
+    const size_t chunk = h->bounce.bytes;
+    hipEvent_t *ev = h->bounce.ev;
     const size_t nchunks = (bytes + chunk - 1) / chunk;
     int32_t rc = ESP_OK;
+    hipError_t he = hipSuccess;
     for (size_t c = 0; c < nchunks && rc == ESP_OK; c++) {
         const size_t o = c * chunk, len = std::min(chunk, bytes - o);
         const int half = (int)(c & 1);
-        if (c >= 2 && hipEventSynchronize(ev[half]) != hipSuccess) rc = ESP_ERR_HIP;  // (chunk c-2 has left this half)
+        if (c >= 2 && (he = hipEventSynchronize(ev[half])) != hipSuccess) rc = ESP_ERR_HIP;  // (chunk c-2 has left this half)
         if (rc == ESP_OK) {
             par_memcpy(pin[half], (const char *)src + o, len);
-            if (hipMemcpyAsync((char *)d_dst + o, pin[half], len, hipMemcpyHostToDevice, h->stream) != hipSuccess ||
-                hipEventRecord(ev[half], h->stream) != hipSuccess)
+            if ((he = hipMemcpyAsync((char *)d_dst + o, pin[half], len, hipMemcpyHostToDevice, h->stream)) != hipSuccess ||
+                (he = hipEventRecord(ev[half], h->stream)) != hipSuccess)
                 rc = ESP_ERR_HIP;
         }
     }
     (void)hipStreamSynchronize(h->stream);
-    for (int i = 0; i < 2; i++) (void)hipEventDestroy(ev[i]);
-    if (rc != ESP_OK) FAIL(h, ESP_ERR_HIP, "host-to-device transfer failed");
+    if (rc != ESP_OK) FAIL(h, ESP_ERR_HIP, "host-to-device transfer failed: %s", hipGetErrorString(he));
     return ESP_OK;
 }
 
@@ -1096,12 +1118,11 @@ static int32_t d2h_narrow(esp_handle *h, i64 *dst, const i64 *d_src, i64 count, 
     CK(ensure(h, scratch, sizeof(u32) * (size_t)count));
     hipLaunchKernelGGL(narrow_i64_k, dim3(grid_for(count, 256)), dim3(256), 0, h->stream, d_src, count, (u32 *)scratch.p);
     HIPCK(h, hipGetLastError());
-    CK(ensure_stage(h, h->bulk, (i64)1 << 22));
+    CK(ensure_bounce(h));
     if ((size_t)count * sizeof(i64) > ((size_t)8 << 20)) hint_huge_pages(dst, (size_t)count * sizeof(i64));
-    char *pin[2] = {(char *)h->bulk.rows, (char *)h->bulk.cols};
-    const size_t chunk = (size_t)h->bulk.cap * 8 / sizeof(u32);  // elements per bounce buffer
-    hipEvent_t ev[2] = {nullptr, nullptr};
-    for (int i = 0; i < 2; i++) HIPCK(h, hipEventCreateWithFlags(&ev[i], hipEventDisableTiming));
+    char *const *pin = h->bounce.pin;
+    const size_t chunk = h->bounce.bytes / sizeof(u32);  // elements per bounce buffer
+    hipEvent_t *ev = h->bounce.ev;
     const size_t total = (size_t)count, nchunks = (total + chunk - 1) / chunk;
     int32_t rc = ESP_OK;
     for (size_t c = 0; c <= nchunks && rc == ESP_OK; c++) {
@@ -1118,7 +1139,6 @@ static int32_t d2h_narrow(esp_handle *h, i64 *dst, const i64 *d_src, i64 count, 
         }
     }
     (void)hipStreamSynchronize(h->stream);
-    for (int i = 0; i < 2; i++) (void)hipEventDestroy(ev[i]);
     if (rc != ESP_OK) FAIL(h, ESP_ERR_HIP, "device-to-host transfer failed");
     return ESP_OK;
 }

@@ -222,6 +222,13 @@ struct esp_handle {
         bool busy[2] = {false, false};
         int next = 0;
     } cpack;
+    // two pinned bounce buffers + their events for transfers between PAGEABLE host memory and the device (d2h_pipelined,
+    // h2d_pipelined, the narrowed downloads): made on first use, nothing on the device side
+    struct Bounce {
+        char *pin[2] = {nullptr, nullptr};
+        size_t bytes = 0;  // each
+        hipEvent_t ev[2] = {nullptr, nullptr};
+    } bounce;
     unsigned long long *pin_scalar = nullptr;  // pinned, 8 slots
     u64 *pin_mw = nullptr;  // pinned source of prepart_begin's asynchronous upload of the window bases (<= MW_MAX)
     hipEvent_t pin_mw_done = nullptr;
@@ -427,6 +434,7 @@ int32_t reserve_append(esp_handle *h, i64 add);
 int32_t pack_device(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const double *d_vals,
                            const uint8_t *d_kinds, int kind_all, int op, i64 count);
 int32_t ensure_stage(esp_handle *h, esp_handle::StageArea &sa, i64 want);
+int32_t ensure_bounce(esp_handle *h);
 void par_memcpy(void *dst, const void *src, size_t bytes);
 int32_t d2h_pipelined(esp_handle *h, void *dst, const void *d_src, size_t bytes);
 // pageable host memory -> device through the same two pinned bounce buffers (the host copy of chunk i+1 overlaps the transfer

@@ -77,7 +77,10 @@ extern "C" int32_t esp_generate_fdrand_range(esp_handle *h, int64_t nx, int64_t 
         a.part = gp.out;
         a.part.keys_out = (u64 *)h->keys.p;
         a.part.vals_out = (double *)h->vals.p;
-        HIPCK(h, hipMemsetAsync((u32 *)h->misc.p + 60, 0, 16, h->stream));  // (the flag words the PART launch looks at: a failed flush may have left one)
+        // (the 64-byte block the PART launch looks at -- longest bucket, which it only compares with the bucket kernel's capacity, and
+        // the flag words: flush_pre_tail, flush_rebuild, a shard's assemble and a failed flush all write there; the plan's own
+        // longest bucket fitted, or the plan would not have been kept)
+        HIPCK(h, hipMemsetAsync((unsigned long long *)h->misc.p + 24, 0, 64, h->stream));
         Span sp(h, ESP_ST_APPEND);
         if (gp.out.k32)
             hipLaunchKernelGGL((espgen::fdrand_part_k<true, true>), grid, block, 0, h->stream, a);

@@ -10,6 +10,7 @@ int32_t shard_prepare(esp_handle *h, int P, espradix::Pass *out) {
     h->shard_user = true;
     CK(pending_materialize(h));
     h->part_valid = h->part_assembled = false;  // (its tables share scratch arrays with this path)
+    h->genplan.valid = h->rawplan.valid = false;  // (seg[1] and the histogram arrays are rewritten: a kept producer plan would read them)
     if ((double)h->n * (double)P >= 9.0e18) FAIL(h, ESP_ERR_UNSUPPORTED, "shards: n*nshards overflows");
     const i64 E = h->count;
     int bits = 1;

@@ -112,6 +112,7 @@ class _Handle:
         self.h = h
         self._st = None
         self._nst = 0
+        self._held = []   # device arrays the library reads at FLUSH time (esp_append_elements[_again]): kept alive until then
 
     def clone(self):
         """A second handle with the same CSC and pending entries (device-to-device): Base.copy."""
@@ -120,13 +121,24 @@ class _Handle:
         c.lib, c.m, c.n = self.lib, self.m, self.n
         h = C.c_void_p()
         self.ck(self.lib.esp_clone(self.h, C.byref(h)))
-        c.h, c._st, c._nst = h, None, 0
+        c.h, c._st, c._nst, c._held = h, None, 0, list(self._held)
         return c
 
     def close(self):
         if getattr(self, "h", None):
             self.lib.esp_destroy(self.h)
             self.h = None
+            self._held = []
+
+    def hold(self, *objs):
+        """The device form of an element-level append reads elmat / diag (and, without cell records, cellnodes) when the batch is
+        FLUSHED (include/esparse_hip.h: valid and unchanged until the handle's next esp_flush / esp_reset / esp_clear_pending has
+        returned): the handle keeps the caller's array objects alive that long -- a temporary tensor must not go back to its
+        allocator in between.  (Keeping them UNCHANGED stays the caller's part.)"""
+        self._held.extend(o for o in objs if o is not None)
+
+    def drop_held(self):
+        self._held = []
 
     def __del__(self):
         try:
@@ -194,7 +206,7 @@ class _Handle:
         (nloc x ncells, int64), elmat (nloc x nloc x ncells, float64), diag (nloc x ncells) or None, all in Julia's
         (column-major) layout: NumPy arrays in Fortran order (host), or anything with .data_ptr() / .numel() resident on this
         GPU whose memory is laid out that way (a torch tensor of shape (ncells, nloc[, nloc]) -- its C order IS that layout,
-        elmat[c, jl, il])."""
+        elmat[c, jl, il]).  Device arrays are read at FLUSH time and must stay unchanged until then (the handle keeps them alive: hold)."""
         self.commit()
         if hasattr(cellnodes, "data_ptr"):
             nloc = int(round(elmat.numel() / max(cellnodes.numel(), 1)))
@@ -203,6 +215,7 @@ class _Handle:
                 raise ValueError("append_elements: array sizes do not fit together")
             nc = cellnodes.numel() // nloc
             dp = C.c_void_p(diag.data_ptr()) if diag is not None else None
+            self.hold(cellnodes, elmat, diag)
             self.ck(self.lib.esp_append_elements(self.h, nloc, nc, C.c_void_p(cellnodes.data_ptr()), C.c_void_p(elmat.data_ptr()), dp, kind, op))
             return
         cn = np.asfortranarray(cellnodes, np.int64)
@@ -234,6 +247,7 @@ class _Handle:
         self.commit()
         z, ch = C.c_int64(), C.c_int32()
         self.ck(self.lib.esp_flush(self.h, mode, C.byref(z), C.byref(ch)))
+        self.drop_held()
         return z.value, bool(ch.value)
 
     def get_csc(self):
@@ -322,6 +336,7 @@ class SparseMatrixHIPCOO:
         wrapper drops after flush!: the garbage collector does not see device memory)."""
         self._d._st, self._d._nst = None, 0
         self._d.ck(self._d.lib.esp_release_buffers(self._d.h))
+        self._d.drop_held()
 
     def updateindex(self, op, v, i, j):  # updateindex!: sparsematrixlnk.jl:210-228
         v = float(v)
@@ -369,6 +384,8 @@ class SparseMatrixHIPCOO:
         arr = (C.c_void_p * len(xs))(*[x._d.h for x in xs])
         z, ch = C.c_int64(), C.c_int32()
         d.ck(d.lib.esp_flush_sum(d.h, arr, len(xs), C.byref(z), C.byref(ch)))
+        for x in xs:
+            x._d.drop_held()          # (the buffers come back empty)
         out, dst._mirror = _download_csc(d, csc, bool(ch.value))
         if home is None:
             d.close()
@@ -521,6 +538,7 @@ class ExtendableSparseMatrix:
             self._d.ck(self._d.lib.esp_append_elements_again_host(self._d.h, _vp(em), _vp(dg) if dg is not None else None, kind, _op(op)))
             return
         dp = C.c_void_p(diag.data_ptr()) if diag is not None else None
+        self._d.hold(elmat, diag)     # (read at flush time, like append_elements' device arrays)
         self._d.ck(self._d.lib.esp_append_elements_again(self._d.h, C.c_void_p(elmat.data_ptr()), dp, kind, _op(op)))
 
     def generate_fem_mesh(self, dim, npd, cellnodes, elmat, diag=None, seed=0x5EED0004, order_mode=1, node_mode=0,
@@ -652,6 +670,7 @@ class ExtendableSparseMatrix:
         self._host_state = self.HOST_STALE
         self._d._nst = 0
         self._d.ck(self._d.lib.esp_reset(self._d.h))
+        self._d.drop_held()
 
     def zero_values(self):  # fdrand!'s zero!: sprand.jl:82
         self.flush()

@@ -1196,7 +1196,18 @@ def test_append_elements(esp, orc, monkeypatch):
                 assert_csc_equal(hip_arrays(P), OP.arrays(), "planned step %d" % step)
             with pytest.raises(esp.EspError):
                 P.append_elements_again(dem, None)                # (the planned call had a diagonal term)
+            # the plan is released while a batch of append_elements_again is still PENDING as a list of items (it reads the plan's
+            # item order and cell records at flush time: esp_elements_keep_plan(0) forms its updates first); the tensors the batch
+            # was made from are temporaries that go out of scope before the flush (the handle keeps them alive: _Handle.hold)
+            P.append_elements_again((dem * 3.0).contiguous(), (ddg * 0.5).contiguous())
             P.elements_keep_plan(False)
+            filler = torch.full((dem.numel() + ddg.numel(),), float("nan"), dtype=torch.float64, device="cuda")   # (what a freed tensor's memory would be reused for)
+            P.flush()
+            del filler
+            Is, Js, Vs = orc.elements_stream(cn, np.asfortranarray(em * 3.0), np.asfortranarray(dg * 0.5))
+            OP.apply(np.full(len(Is), RAW, np.uint8), Is, Js, Vs)
+            OP.flush()
+            assert_csc_equal(hip_arrays(P), OP.arrays(), "plan released under a pending batch")
             with pytest.raises(esp.EspError):
                 P.append_elements_again(dem, ddg)
             # packed keys, the item partition off (stream order through the flush's own passes), and without the cell
