@@ -710,6 +710,42 @@ def bind_near_gpu(torch, local):
         return None
 
 
+def consumer_lines(esp, torch, A, N, Z, reps=5):
+    """mul! / Dirichlet helpers / Jacobi and ILU0 set-up on the resident CSC (device vectors, nothing crosses PCIe): ms per call and,
+    for mul!, the fraction of the HBM roofline on its algorithmic bytes (values + row indices once, x and r once: 16 Z + 16 N)."""
+    import ctypes as C
+    d = A._d
+    x = torch.rand(N, dtype=torch.float64, device="cuda")
+    r = torch.empty(N, dtype=torch.float64, device="cuda")
+    inv = torch.empty(N, dtype=torch.float64, device="cuda")
+    idg = torch.empty(N, dtype=torch.int64, device="cuda")
+    mk = torch.zeros(N, dtype=torch.uint8, device="cuda")
+    torch.cuda.synchronize()
+    vp = lambda t: C.c_void_p(t.data_ptr())   # noqa: E731
+
+    def timed(fn, n=reps):
+        fn()                                  # (first call: the row-wise index of mul!, scratch allocations)
+        d.ck(d.lib.esp_synchronize(d.h))
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        d.ck(d.lib.esp_synchronize(d.h))
+        return (time.perf_counter() - t0) / n * 1e3
+
+    out = {}
+    ms = timed(lambda: d.ck(d.lib.esp_mul(d.h, vp(x), vp(r), 1)))
+    algo = 16.0 * Z + 16.0 * N
+    out["mul"] = {"ms": ms, "algorithmic_bytes": algo, "frac_of_hbm_peak": algo / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS}
+    out["jacobi_setup"] = {"ms": timed(lambda: d.ck(d.lib.esp_jacobi_setup(d.h, vp(inv), 1)))}
+    out["ilu0_setup"] = {"ms": timed(lambda: d.ck(d.lib.esp_ilu0_setup(d.h, vp(inv), vp(idg), 1)))}
+    out["mark_dirichlet"] = {"ms": timed(lambda: d.ck(d.lib.esp_mark_dirichlet(d.h, C.c_double(1.0e20), vp(mk), 1)))}
+    mk[::97] = 1
+    torch.cuda.synchronize()
+    out["eliminate_dirichlet"] = {"ms": timed(lambda: d.ck(d.lib.esp_eliminate_dirichlet(d.h, vp(mk), 1)), 2), "marked": int(mk.sum().item())}
+    del x, r, inv, idg, mk
+    return out
+
+
 def summary_of(out):
     """A compact copy of what a reader of the record needs, as the LAST key of the JSON line (the driver keeps the last 2 000
     characters of it): the headline, its roofline and CPU baseline, and for every extra config [ms, fraction of the HBM
@@ -734,6 +770,11 @@ def summary_of(out):
                 cfgs[name] += [c.get("lazy_items"), c.get("sum_join"), r3(c.get("fills_ms")), r3(c.get("folds_ms")), r3(c.get("combine_ms"))]
         else:
             cfgs[name] = [r3(c.get("ms")), float("%.4g" % c["nnz_per_s"]) if c.get("nnz_per_s") else None]
+    s["plan_reused"], s["first_call_ms"] = out.get("plan_reused"), r3(out.get("first_call_ms"))
+    cons = (out.get("extra") or {}).get("consumers") or {}
+    if cons and "error" not in cons:
+        s["consumers_ms"] = {k: r3(v.get("ms")) for k, v in cons.items()}
+        s["mul_frac"] = r3((cons.get("mul") or {}).get("frac_of_hbm_peak"))
     if cfgs:
         s["cfg"] = cfgs
         s["cfg_cols"] = "ms, frac_of_hbm_peak (SURVEY 8d bytes), digest_ok; cfg2_host: ms, nnz_per_s; cfg_mt_sum: + lazy_items, sum_join, fills_ms, folds_ms, combine_ms"
@@ -886,6 +927,28 @@ def main():
         barrier()
         tm_all = A.timing(clear=True)
     A.timing_enable(0)
+    # what the timed steps do NOT pay: they repeat the previous assembly, so the producer reuses its count / ranking tables
+    # (esp_handle::GenPlan).  `first_call_ms`: the same step with that reuse switched off (esp_debug_force_path(31): COUNT launch,
+    # ranking launches and the host round trip for their flags in every step) -- what the first assembly of a grid costs
+    plan_reused = A.debug_last_plan_reused()
+    first_call_ms = None
+    if not os.environ.get("ESP_BENCH_FORCE_PATH"):
+        A.debug_force_path(31)
+        step()
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(5):
+            step()
+        barrier()
+        first_call_ms = (time.perf_counter() - t1) / 5 * 1e3
+        A.debug_force_path(0)
+    # the consumers of the flushed CSC that stay on the device, on the matrix the timed loop built
+    consumers = None
+    if rank == 0 and not sharded and not args.no_extra:
+        try:
+            consumers = consumer_lines(esp, torch, A, N, int(Z_total))
+        except Exception as ex:
+            consumers = {"error": repr(ex)}
     Z = Z_total / world   # per-rank share of the final nnz (value below multiplies by world)
 
     out = None
@@ -924,6 +987,8 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "host_numa_node": numa_node,   # the process runs on the CPUs of the GPU's NUMA node (bind_near_gpu); None: unchanged
+            # the timed steps repeat the previous assembly: the producer reused its plan (1) -- first_call_ms is the step without that
+            "plan_reused": plan_reused, "first_call_ms": first_call_ms,
             "digest_ok": digest_ok,   # sha256 of the device CSC == the CPU oracle's (tests/golden/digests_large.txt); None: no pin for this size
             "config": {"workload": "fdrand %d^3 Float64/Int64 fresh build: device COO append (the producer writes every "
                                    "update to its radix bucket) -> LDS bucket sort + ordered fold -> CSC "
@@ -954,6 +1019,8 @@ def main():
         del A
         out["extra"] = {"configs": extra_configs(esp, torch, local, n, int(os.environ.get("ESP_CFG4_2D", "3163")),
                                                  int(os.environ.get("ESP_CFG4_3D", "216")))}
+    if rank == 0 and consumers is not None:
+        out.setdefault("extra", {})["consumers"] = consumers
     if rank == 0 and not args.no_cpu_baseline and world == 1:
         out["cpu_baseline"] = cpu_baseline(args.cpu_sample_n, args.cpu_mt_n)
     if rank == 0:
