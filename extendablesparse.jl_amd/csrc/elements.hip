@@ -207,6 +207,7 @@ int32_t elements_by_items(esp_handle *h, espelem::Args a, i64 E, bool *took) {
     pp.Ee = plan_entries(E, K, h->win_span);
     pp.mw_P = 0, pp.mw_me = 0, pp.mw_shift = 0, pp.mw_nb = 0, pp.mw_eps = 0;
     pp.own32 = false;
+    pp.fb = 0, pp.maxlen_c = 0;
     // esp_elements_keep_plan: item order, cell records and segment table into buffers of their own (the flush is about to
     // take the scratch pair they lie in) for esp_append_elements_again
     esp_handle::ElemPlan &ep = h->elemplan;
@@ -331,6 +332,7 @@ extern "C" int32_t esp_append_elements_again(esp_handle *h, const double *d_elma
     pp.Ee = plan_entries(E, ep.K, h->win_span);
     pp.mw_P = 0, pp.mw_me = 0, pp.mw_shift = 0, pp.mw_nb = 0, pp.mw_eps = 0;
     pp.own32 = false;
+    pp.fb = 0, pp.maxlen_c = 0;
     note_kind(h, kind, E);
     h->count += E;
     pending_changed(h);

@@ -214,6 +214,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         a.k32_piece = st.p32_piece;
         a.k32_lo = st.p32_lo;
         h->last_key_bytes = (st.p32_piece >= 0 || st.all32) ? 4 : st.key_bytes;
+        a.fb = st.npieces == 0 && st.key_bytes == 4 ? st.fb : 0;
         a.colptr_out = direct ? (i64 *)h->colptr.p : nullptr;
         a.late_total = h->force_path == ESP_PATH_LATE_TOTAL ? 1 : 0;  // 36: test hook, group3_k publishes a segment's total after the fold
         a.no_group = h->force_path == ESP_PATH_NO_GROUP_TIER ? 1 : 0;  // 24: test hook, long column runs through the radix tier
@@ -290,7 +291,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
             // (the group tier with three workgroups per CU -- group3.hpp: a fresh matrix, 4-byte keys of one kind, segments of at
             // most 256 whole columns whose (local column, row) fits 32 bits, runs of at most 128 entries; a segment it does not
             // take makes the flush run again with the kernels above; 30: test hook, never)
-            var.g3 = allow_g3 && grp && Z0 == 0 && (keys == 1 || keys == 2) && a.cl_bits >= 0 && a.cl_bits <= esplocal::G3_CL_BITS &&
+            var.g3 = allow_g3 && grp && st.fb == 0 && Z0 == 0 && (keys == 1 || keys == 2) && a.cl_bits >= 0 && a.cl_bits <= esplocal::G3_CL_BITS &&
                      a.cl_bits + a.rb <= 32 && a.rb <= 30 && longest <= 128.0 && !h->g3_off && !a.no_group && !a.stop_after &&
                      h->force_path != ESP_PATH_NO_GROUP3;
             // (packed keys of ONE known adding kind whose bits below the prefix fit 32 -- a shuffled stream of triplets after the
@@ -337,7 +338,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         const int keys = st.key_bytes != 4 ? 0 : (st.kind == ESP_UPDATE && !generic ? 2 : 1);
         const double longest = h->seen_maxrun > 0 ? (double)h->seen_maxrun : (double)h->count / (double)std::max<i64>(col_end - col_begin, 1);
         const bool hits_expected = st.expect_hits >= 0 ? st.expect_hits == 1 : h->seen_hits;
-        bool try_hits = Z0 > 0 && mode == ESP_FLUSH_ROUTED && st.npieces == 0 && (keys == 1 || keys == 2) && (st.kind == ESP_UPDATE || st.kind == ESP_RAWUPDATE) &&
+        bool try_hits = Z0 > 0 && st.fb == 0 && mode == ESP_FLUSH_ROUTED && st.npieces == 0 && (keys == 1 || keys == 2) && (st.kind == ESP_UPDATE || st.kind == ESP_RAWUPDATE) &&
                         a.kind_all == st.kind && a.cl_bits >= 0 && a.cl_bits <= esplocal::G3_CL_BITS && a.cl_bits + a.rb <= 32 && a.rb <= 30 &&
                         longest > 16.0 && longest <= 128.0 && hits_expected && !h->hits_off && !a.no_group && !a.stop_after && !small_variant &&
                         h->wc0 == 0 && h->wc1 == h->n &&  // (the segments cover every column: what they do not write into the second array would be lost)
@@ -932,6 +933,13 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
         st.key_bytes = pp.key_bytes;
         st.kind = pp.kind;
         st.maxlen = pp.maxlen;
+        if (pp.fb > 0 && pp.key_bytes == 4 && !h->lazy.on) {
+            // a FINE partition: the bucket kernel takes 2^fb neighbouring buckets as one segment (PrePart::fb)
+            st.fb = pp.fb;
+            st.S = 1 << (pp.pb - pp.fb);
+            st.rem_bits = pp.K - pp.pb + pp.fb;
+            st.maxlen = pp.maxlen_c;
+        }
         CK(ensure(h, h->keys2, sizeof(u64) * (size_t)E));
         CK(ensure(h, h->vals2, sizeof(double) * (size_t)E));
         int32_t rc_local;

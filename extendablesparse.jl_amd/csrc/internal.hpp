@@ -79,6 +79,12 @@ struct esp_handle {
         int key_bytes = 8;       // 4: `keys` holds u32 keys (the bits below the prefix); every entry has the kind `kind`
         int kind = 0;
         i64 E = 0, maxlen = 0;   // entries, longest bucket
+        // FINE partition (round 6): the plan has `fb` more prefix bits than the bucket kernel needs, so that the bits below the
+        // prefix fit 4-byte keys (322^3: 33 bits below the planned prefix; 400^3: 34); the flush's bucket kernel takes 2^fb
+        // neighbouring buckets as ONE segment (maxlen_c: the longest of those) and tells an entry's bucket by its position.
+        // To everybody else the batch is what its fine plan says: 2^pb buckets of 4-byte keys.
+        int fb = 0;
+        i64 maxlen_c = 0;
         i64 tail = 0;            // packed entries appended BEHIND the E bucket-ordered ones (count = E + tail)
         u64 base = 0, span = 0;  // the key window it was made for
         double Ee = 0.0;         // (plan_entries of the batch: spread bookkeeping)
@@ -127,8 +133,8 @@ struct esp_handle {
     // and a stream that is not the same falls back to the full path.  Dropped by whatever rewrites the tables.
     struct RawPlan {
         bool valid = false;
-        i64 count = 0, chunks = 0, maxlen = 0;
-        int kind = 0, K = 0, pb = 0, key_bytes = 8;
+        i64 count = 0, chunks = 0, maxlen = 0, maxlen_c = 0;
+        int kind = 0, K = 0, pb = 0, key_bytes = 8, fb = 0;
         u64 base = 0, span = 0;
         double Ee = 0.0;
     } rawplan;
@@ -305,6 +311,7 @@ struct PartSetup {
     esprun::RunSink sink;  // for its COUNT kernel
     u32 *err = nullptr;    // window flag of the COUNT kernel
     int K = 0, pb = 0, kind = -1;
+    int fb = 0;            // fine partition: pb holds fb bits more than the bucket kernel's segments need
     i64 E = 0, chunks = 0;
     double Ee = 0.0;
     i64 NB = 0;            // buckets (1 << pb, or shards * digits per shard)
@@ -364,6 +371,7 @@ struct Sorted {
     bool fits = false;  // every segment is within seg_cap (local_ok without the limit on the remaining key bits)
     bool all_update = false;  // PIECES: every entry of every piece is an UPDATE (esp_shard_assemble checked)
     int key_bytes = 8;  // 4: sk holds 32-bit keys (the bits below the prefix); every entry has the kind `kind`
+    int fb = 0;         // 4-byte keys of a FINE partition: seg_start has (S << fb) + 1 entries, segment s = its buckets [s << fb, (s + 1) << fb)
     int k32_passes = 0;  // the 8-bit passes that wrote 4-byte keys (sort_msd): > 0 = the other pair holds no packed copy of the entries
     int kind = 0;
     i64 maxlen = esplocal::CAP;  // longest segment
@@ -529,6 +537,14 @@ static __global__ void fill_i64_k(i64 *p, i64 n, i64 v) {
 // the chip -- to read it, only the event recorded behind this launch.
 static __global__ void publish_block_k(const unsigned long long *__restrict__ src, unsigned long long *__restrict__ host_dst) {
     if (threadIdx.x < 8) __hip_atomic_store(&host_dst[threadIdx.x], src[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// the longest run of 2^fb neighbouring buckets (one segment of a fine partition's flush: esp_handle::PrePart::fb)
+static __global__ void coarse_seg_max_k(const i64 *__restrict__ seg, i64 S_coarse, int fb, unsigned long long *__restrict__ out) {
+    const i64 g = (i64)blockIdx.x * blockDim.x + threadIdx.x;
+    const u32 len = g < S_coarse ? (u32)min((i64)0xFFFFFFFFll, seg[(g + 1) << fb] - seg[g << fb]) : 0u;
+    const u32 m = esp_wave_max(len);
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(out, (unsigned long long)m);
 }
 
 static inline unsigned grid_for(i64 n, int threads) { return (unsigned)std::max<i64>(1, ceil_div<i64>(n, threads)); }

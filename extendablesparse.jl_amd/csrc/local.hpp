@@ -1414,7 +1414,8 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     __shared__ int s_seg;
     __shared__ u32 s_early;
     __shared__ u32 s_rmin, s_rmax;  // group tier: smallest / largest row of the segment
-    __shared__ i64 s_win[66];
+    __shared__ i64 s_win[96];
+    __shared__ u32 s_fine[16];  // fine partition: where bucket j of the segment starts (relative to the segment)
     // scratch of the radix tier, NOT inside s_win: between a wave's reads of s_win (its segment's bounds) and another wave's
     // first scratch store there is no workgroup barrier when the column tiers are skipped (cl_bits < 0) -- the radix tier used to
     // keep its two words per wave in s_win[0 .. 16) and a wave that was late met the other waves' AND / OR masks instead of its
@@ -1431,9 +1432,11 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     // The segment starts around the expected ticket (launch offset + blockIdx) are fetched while the
     // ticket atomic is in flight: two dependent round trips become one (speed only -- a ticket
     // outside the window simply reloads).
-    constexpr int WIN = 64;
+    // (a FINE partition's table -- 4-byte keys only -- holds 2^fb entries per segment: the window covers fewer segments)
+    const int fb = K32 ? a.fb : 0;
+    const int WIN = 64 >> fb;
     const i64 w0 = max((i64)0, a.first + (i64)blockIdx.x - WIN / 2);
-    if (!PIECES && t <= WIN + 1 && w0 + t <= (i64)a.S) s_win[t] = a.seg_start[w0 + t];
+    if (!PIECES && t <= ((WIN + 1) << fb) && (w0 << fb) + t <= ((i64)a.S << fb)) s_win[t] = a.seg_start[(w0 << fb) + t];
     if (t == 0) {
         s_seg = (int)atomicAdd(a.ticket, 1u);
         s_early = 0;
@@ -1452,8 +1455,9 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     int n;
     if constexpr (!PIECES) {
         const bool inwin = s >= w0 && (i64)s + 1 <= w0 + WIN + 1;
-        const i64 beg = esp_uniform_i64(inwin ? s_win[s - w0] : a.seg_start[s]);
-        const i64 seg_end = esp_uniform_i64(inwin ? s_win[s - w0 + 1] : a.seg_start[s + 1]);
+        const i64 beg = esp_uniform_i64(inwin ? s_win[(s - w0) << fb] : a.seg_start[(i64)s << fb]);
+        const i64 seg_end = esp_uniform_i64(inwin ? s_win[(s - w0 + 1) << fb] : a.seg_start[((i64)s + 1) << fb]);
+        if (fb > 0 && t < (1 << fb)) s_fine[t] = (u32)((inwin ? s_win[((s - w0) << fb) + t] : a.seg_start[((i64)s << fb) + t]) - beg);
 #ifdef ESP_LOCAL_STAMPS
         if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)s * 16 + 0] = wall_clock64();
 #endif
@@ -1579,6 +1583,20 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     // (LDS work that does not depend on the loads goes first: it runs while they are in flight)
     if (a.cl_bits >= 0)
         for (int q = t; q <= (1 << a.cl_bits); q += THREADS) ccnt[q] = 0;
+    if constexpr (K32 && !PIECES) {
+        if (fb > 0) {
+            // the bucket's number inside the segment = the key bits [32, 32 + fb): an entry's position tells it (the entries lie
+            // bucket by bucket)
+            __syncthreads();  // (s_fine)
+#pragma unroll
+            for (int i = 0; i < NI; i++) {
+                const u32 p = (u32)(wbase + i * ESP_WAVE);
+                u32 sub = 0;
+                for (int j = 1; j < (1 << fb); j++) sub += p >= s_fine[j] ? 1u : 0u;
+                k[i] |= (u64)sub << 32;
+            }
+        }
+    }
     // branch-free: slots past the end hold a copy of the last entry (clamped loads) and become NOREC
     u64 bad = 0;
     const u64 relmask = (((u64)1 << (a.rem_bits + ESP_TAG_BITS - 1)) << 1) - 1ull;  // (rem_bits + 2 may be 64)

@@ -73,6 +73,8 @@ struct Args {
     int no_group;  // test hook: column runs of more than 24 entries go to the radix tier, never to the group tier
     int kind_all;  // >= 0: every pending entry has this kind (the host's bookkeeping), whatever the key format says; else -1
     int expect_hits;  // the host expects most positions to be stored already: a short stored column is fetched with its values
+    int fb;           // K32 kernels: the segment table is 2^fb times finer than the segments (esp_handle::PrePart::fb): segment s =
+                      // table entries [s << fb, (s + 1) << fb], and the 4-byte key of an entry lacks the bucket's number inside the segment
     double *hits_out; // group3_k's re-assembly form (HITS): the new values of the stored positions (a second nzval array)
 };
 constexpr int MAX_PIECES = 64;

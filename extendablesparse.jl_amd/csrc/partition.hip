@@ -473,9 +473,19 @@ int32_t append_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_cols, 
         return ESP_OK;
     const int K = window_bits(h);
     double Ee = 0.0;
-    const int pb = plan_prefix_bits(h, count, K, &Ee);
-    const int shift = K - pb;
+    int pb = plan_prefix_bits(h, count, K, &Ee);
+    int shift = K - pb;
     if (pb <= 8 || pb > 20 || shift < h->L.rb || shift > esplocal::MAX_REM_BITS) return ESP_OK;
+    // (FINE partition, as for the device-side producers -- prepart_begin: up to four more prefix bits bring the rest into
+    // 4-byte keys, the flush's bucket kernel takes 2^fb buckets as one segment)
+    int fb = 0;
+    i64 maxlen_c = 0;
+    if (shift > 32 && shift - 32 <= 4 && pb + (shift - 32) <= esprun::MAX_PB && h->L.rb <= 32 && h->force_path != ESP_PATH_NO_FINE_PARTITION &&
+        h->force_path != ESP_PATH_PACKED_KEYS) {
+        fb = shift - 32;
+        pb += fb;
+        shift = 32;
+    }
     CK(reserve_append(h, count));
     const i64 NB = (i64)1 << pb;
     CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(NB + 1)));
@@ -541,6 +551,7 @@ int32_t append_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_cols, 
                 reused = true;
                 ok = true, ml = rp.maxlen, kb = rp.key_bytes;
                 Ee = rp.Ee;
+                fb = rp.fb, maxlen_c = rp.maxlen_c;
             } else {
                 h->rawplan.valid = false;  // (another stream: the full path below, which makes a plan of its own)
             }
@@ -562,11 +573,23 @@ int32_t append_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_cols, 
         h->runs_skip = h->runs_penalty + 1;
         return ESP_OK;
     }
+    if (fb > 0 && kb == 4) {  // the longest SEGMENT the flush will meet (2^fb buckets); one that outgrows the bucket kernel: bucket by bucket
+        unsigned long long *d_cm = (unsigned long long *)h->misc.p + 25;
+        HIPCK(h, hipMemsetAsync(d_cm, 0, 8, h->stream));
+        hipLaunchKernelGGL(coarse_seg_max_k, dim3(grid_for(NB >> fb, 256)), dim3(256), 0, h->stream, (const i64 *)h->seg[1].p, NB >> fb, fb, d_cm);
+        HIPCK(h, hipMemcpyAsync(h->pin_scalar, d_cm, 8, hipMemcpyDeviceToHost, h->stream));
+        HIPCK(h, hipStreamSynchronize(h->stream));
+        maxlen_c = (i64)h->pin_scalar[0];
+        if (maxlen_c > (i64)esplocal::CAP) fb = 0;
+    } else {
+        fb = 0;
+    }
     // (the tables of this batch serve the next one that looks the same -- only the ranked flavour leaves them complete)
     esp_handle::RawPlan &np = h->rawplan;
     np.valid = h->last_run_order == 1;
     np.count = count, np.chunks = ceil_div<i64>(count, esprun::TILE), np.maxlen = ml;
     np.kind = kind, np.K = K, np.pb = pb, np.key_bytes = kb;
+    np.fb = fb, np.maxlen_c = maxlen_c;
     np.base = h->win_base, np.span = h->win_span, np.Ee = Ee;
     }
     h->last_plan_reused = reused ? 1 : 0;
@@ -584,6 +607,7 @@ int32_t append_partitioned(esp_handle *h, const i64 *d_rows, const i64 *d_cols, 
     pp.Ee = Ee;
     pp.mw_P = 0, pp.mw_me = 0, pp.mw_shift = 0, pp.mw_nb = 0, pp.mw_eps = 0;
     pp.own32 = false;
+    pp.fb = (kb == 4) ? fb : 0, pp.maxlen_c = maxlen_c;
     note_kind(h, kind, count);
     h->count += count;
     pending_changed(h);

@@ -219,6 +219,7 @@ extern "C" int32_t esp_generate_fem(esp_handle *h, int32_t dim, int64_t npd, uin
 // force_path 16: never.
 int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSetup *ps) {
     ps->on = false;
+    ps->fb = 0;
     memset(&ps->out, 0, sizeof ps->out);
     if (h->count != 0 || E <= esplocal::CAP || chunks >= ((i64)1 << 38)) return ESP_OK;
     if (h->force_path == ESP_PATH_GENERAL || h->force_path == ESP_PATH_NO_RUN_PARTITION || h->force_path == ESP_PATH_RUN_LIST_BY_RADIX || h->force_path == ESP_PATH_PRODUCER_STREAM_ORDER) return ESP_OK;
@@ -254,6 +255,15 @@ int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSetup *ps)
         pb = plan_prefix_bits(h, E, K, &Ee);
         shift = K - pb;
         if (pb <= 8 || pb > 20 || shift < h->L.rb || shift > esplocal::MAX_REM_BITS) return ESP_OK;
+        // FINE partition: 33 .. 36 key bits below the planned prefix (a stencil above 256^3) and one known kind -- up to four
+        // more prefix bits make the rest fit 4-byte keys; the flush's bucket kernel still takes the PLANNED segments (2^fb
+        // buckets each: its time follows the number of segments, NOTES/round5.md section 9).  force_path 41 / 14: never.
+        if (kind >= 0 && shift > 32 && shift - 32 <= 4 && pb + (shift - 32) <= esprun::MAX_PB && shift - (shift - 32) >= h->L.rb &&
+            h->force_path != ESP_PATH_NO_FINE_PARTITION && h->force_path != ESP_PATH_PACKED_KEYS) {
+            ps->fb = shift - 32;
+            pb += ps->fb;
+            shift = 32;
+        }
         NB = (i64)1 << pb;
     }
     ChunkArrays ca;
@@ -330,6 +340,11 @@ int32_t prepart_rank(esp_handle *h, PartSetup *ps) {
         hipLaunchKernelGGL(esprun::run_rank_k, dim3(g), dim3(esprun::THREADS), 0, h->stream, ps->bucket_count, (const u64 *)ps->coarse,
                            ps->dcount, ps->dlist, NB, ps->seg_out, ps->runs_off, d_maxlen, flags + 3);
         sp.add(2);
+        if (ps->fb > 0) {  // (word 1 of the block: the longest SEGMENT of the flush, 2^fb buckets)
+            const i64 Sc = NB >> ps->fb;
+            hipLaunchKernelGGL(coarse_seg_max_k, dim3(grid_for(Sc, 256)), dim3(256), 0, h->stream, (const i64 *)ps->seg_out, Sc, ps->fb, d_maxlen + 1);
+            sp.add(1);
+        }
     }
     // (the host reads the flags while the PART launch runs)
     hipLaunchKernelGGL(publish_block_k, dim3(1), dim3(64), 0, h->stream, (const unsigned long long *)d_maxlen, h->pin_scalar);
@@ -357,6 +372,9 @@ int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took) {
     pp.pb = ps->pb;
     pp.maxlen = (i64)h->pin_scalar[0];
     pp.key_bytes = ps->out.k32 ? 4 : 8;
+    // (a fine partition whose joined segments outgrow the bucket kernel is flushed bucket by bucket, like any other batch)
+    pp.maxlen_c = ps->fb > 0 ? (i64)h->pin_scalar[1] : 0;
+    pp.fb = (ps->fb > 0 && ps->out.k32 && pp.maxlen_c <= (i64)esplocal::CAP) ? ps->fb : 0;
     pp.kind = ps->kind;
     pp.E = ps->E;
     pp.tail = 0;
@@ -634,6 +652,7 @@ int32_t item_produce_fem(esp_handle *h, const espgen::FemArgs &fa, i64 E, bool *
     pp.Ee = plan_entries(E, K, h->win_span);
     pp.mw_P = 0, pp.mw_me = 0, pp.mw_shift = 0, pp.mw_nb = 0, pp.mw_eps = 0;
     pp.own32 = false;
+    pp.fb = 0, pp.maxlen_c = 0;
     *took = true;  // (the caller sets pre.valid once the entries are counted in)
     return ESP_OK;
 }

@@ -30,6 +30,7 @@ constexpr int WAVES = THREADS / ESP_WAVE;
 constexpr int ITEMS = 16;
 constexpr int TILE = THREADS * ITEMS;  // same tiles as espradix
 constexpr int RMAX = 64;               // distinct digits a tile may hold on this path
+constexpr int MAX_PB = 20;             // prefix bits of the run-based single pass / a producer-side partition (2^20 buckets: the run lists' arrays)
 constexpr u32 EMPTY = 0xFFFFFFFFu;
 constexpr int DCAP = 32;               // runs one digit may collect in its own list (ranked path)
 

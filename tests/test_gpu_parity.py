@@ -2421,24 +2421,53 @@ def test_fdrand_full_size_digest(esp, n):
 
 
 def test_more_than_32_key_bits_below_the_prefix(esp):
-    """A 256^3 stencil leaves exactly 32 key bits below its 16-bit prefix (4-byte keys everywhere); a larger problem --
-    322^3: 33 bits; the 8-GPU weak-scaling run: 36 -- takes the packed-key forms of the producer-side partition
-    (fdrand_part_k<false,false>), alone and with the multi-window digits of a column shard.  No CPU oracle at this size:
-    three device results -- plain producer + the flush's own partition, producer-side partition, shard producer through
-    the group API -- must agree bit for bit."""
+    """A 256^3 stencil leaves exactly 32 key bits below its 16-bit prefix (4-byte keys everywhere); a larger problem -- 322^3: 33
+    bits -- takes the FINE partition (round 6): one more prefix bit, so that the rest fits 4-byte keys, while the bucket kernel
+    still takes the planned segments (two buckets each, an entry's bucket told by its position).  No CPU oracle at this size:
+    device results that must agree bit for bit -- the plain producer + the flush's own partition (packed keys), the producer-side
+    partition with the fine plan (4-byte keys) and with the hook that forbids it (41: packed keys), the same stream as resident
+    triplets through esp_append_device (fine plan, then its repetition over the kept run lists), and the shard producer through the
+    group API (packed keys: a shard's ranges travel)."""
+    import ctypes as C
+    torch = pytest.importorskip("torch")
     n = 322
     N = n ** 3
     E = 12 * n * n * (n - 1) + 6 * n * n
     seen = {}
-    for name, force in (("flush_partition", 16), ("producer_partition", 0)):
+    for name, force, kb, part in (("flush_partition", 16, 8, 1), ("producer_fine", 0, 4, 4), ("producer_packed", 41, 8, 4)):
         A = esp.ExtendableSparseMatrix(N, N, capacity_hint=E)
         A.debug_force_path(force)
-        A.generate_fdrand(n, n, n, seed=7, rand_mode=1)
-        A.flush()
-        assert A.debug_last_key_bytes() == 8
-        assert A.debug_last_partition() == (4 if force == 0 else 1)
+        for it in range(2 if force == 0 else 1):        # (the second assembly reuses the generator's plan, fine bits included)
+            A.reset()
+            A.generate_fdrand(n, n, n, seed=7, rand_mode=1)
+            A.flush()
+            assert A.debug_last_key_bytes() == kb, (name, A.debug_last_key_bytes())
+            assert A.debug_last_partition() == part
         seen[name] = gu.digest(*hip_arrays(A))
         del A
+    # the stream as a caller's resident triplets (stream order: the plain producer's packed keys, unpacked)
+    keys = torch.empty(E, dtype=torch.int64, device="cuda")
+    vals = torch.empty(E, dtype=torch.float64, device="cuda")
+    G = esp.ExtendableSparseMatrix(N, N, capacity_hint=E)
+    G.debug_force_path(16)
+    G.generate_fdrand(n, n, n, seed=7, rand_mode=1)
+    offs = (C.c_int64 * 2)()
+    rbits, cbits = C.c_int32(), C.c_int32()
+    G._d.ck(G._d.lib.esp_key_layout(G._d.h, C.byref(rbits), C.byref(cbits)))
+    G._d.ck(G._d.lib.esp_shard_export(G._d.h, 1, C.c_void_p(keys.data_ptr()), C.c_void_p(vals.data_ptr()), offs))
+    rb = rbits.value
+    rows = ((keys >> 2) & ((1 << rb) - 1)) + 1
+    cols = (keys >> (2 + rb)) + 1
+    del keys, G
+    T = esp.ExtendableSparseMatrix(N, N, capacity_hint=E)
+    for it in range(2):
+        T.reset()
+        T.append_device(esp.ESP_UPDATE, rows, cols, vals)
+        T.flush()
+        assert T.debug_last_key_bytes() == 4 and T.debug_last_partition() == 4, (it, T.debug_last_key_bytes(), T.debug_last_partition())
+        assert T.debug_last_plan_reused() == it
+        seen["triplets_%d" % it] = gu.digest(*hip_arrays(T))
+    del T, rows, cols, vals
     SA = esp.GroupShardedMatrix(N, N, nranks=1, rank=0, capacity_hint=E)
     A = SA.local
     for it in range(2):                 # (the second assembly finds the plan of the first flush: the producer partitions)
