@@ -118,22 +118,45 @@ static __global__ __launch_bounds__(THREADS) void tile_hist_raw_k(Pass p) {
     cnt[t + THREADS] = 0;
     __syncthreads();
     const u32 mask = (1u << p.bits) - 1u;
-    i64 c[ITEMS];
+    // 16-byte loads (two columns per lane: counting does not care about order; a tile starts at a multiple of TILE entries, so
+    // only the caller's base pointer decides the alignment), all of a thread's loads in flight before the first count
+    auto count_one = [&](i64 col, i64 idx) {
+        if (col < 1 || col > p.raw_n) {
+            atomicMin(p.raw_err, (unsigned long long)idx + 1ull);
+            col = 1;
+        }
+        atomicAdd(&cnt[digit_of<true>(p, ((u64)(col - 1) << p.raw_rb) << ESP_TAG_BITS, mask)], 1u);
+    };
+    if ((reinterpret_cast<uintptr_t>(p.raw_cols) & 15) == 0) {
+        typedef long long ll2 __attribute__((ext_vector_type(2)));
+        const ll2 *pc = reinterpret_cast<const ll2 *>(p.raw_cols + beg);
+        const i64 npair = (end - beg) >> 1;
+        ll2 c2[ITEMS / 2];
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        const i64 idx = beg + (i64)k * THREADS + t;
-        c[k] = idx < end ? p.raw_cols[idx] : 1;
-    }
+        for (int k = 0; k < ITEMS / 2; k++) {
+            const i64 q = (i64)k * THREADS + t;
+            c2[k] = q < npair ? pc[q] : ll2{1, 1};
+        }
 #pragma unroll
-    for (int k = 0; k < ITEMS; k++) {
-        const i64 idx = beg + (i64)k * THREADS + t;
-        if (idx < end) {
-            i64 col = c[k];
-            if (col < 1 || col > p.raw_n) {
-                atomicMin(p.raw_err, (unsigned long long)idx + 1ull);
-                col = 1;
+        for (int k = 0; k < ITEMS / 2; k++) {
+            const i64 q = (i64)k * THREADS + t;
+            if (q < npair) {
+                count_one(c2[k].x, beg + 2 * q);
+                count_one(c2[k].y, beg + 2 * q + 1);
             }
-            atomicAdd(&cnt[digit_of<true>(p, ((u64)(col - 1) << p.raw_rb) << ESP_TAG_BITS, mask)], 1u);
+        }
+        if (t == 0 && ((end - beg) & 1)) count_one(p.raw_cols[end - 1], end - 1);
+    } else {
+        i64 c[ITEMS];
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const i64 idx = beg + (i64)k * THREADS + t;
+            c[k] = idx < end ? p.raw_cols[idx] : 1;
+        }
+#pragma unroll
+        for (int k = 0; k < ITEMS; k++) {
+            const i64 idx = beg + (i64)k * THREADS + t;
+            if (idx < end) count_one(c[k], idx);
         }
     }
     __syncthreads();
