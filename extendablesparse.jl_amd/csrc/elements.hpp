@@ -55,6 +55,8 @@ struct Args {
     u64 *keys_out;            // (K32: u32 keys)
     double *vals_out;
     char *cellrec;            // nloc 3 / 4: one 64-byte record per cell (rows as four u32 | the cell's diag values) -- see elem_cells_k
+    u32 *colrange;            // {smallest, largest} 0-based node of the batch (atomicMin / atomicMax; matrices below 2^32 columns), or nullptr:
+                              // the item partition plans for the columns the batch really touches (a band of a mesh: one partition's cells)
 };
 
 // item p = cell * nloc + jl: 32-bit arithmetic (the host keeps nitems below 2^32)
@@ -86,7 +88,10 @@ static __global__ __launch_bounds__(THREADS) void elem_cells_k(Args a) {
     typedef double dbl2 __attribute__((ext_vector_type(2)));
     typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
     const i64 c = (i64)blockIdx.x * THREADS + threadIdx.x;
-    if (c >= a.ncells) return;
+    __shared__ u32 s_lo, s_hi;
+    if (threadIdx.x == 0) s_lo = ~0u, s_hi = 0u;
+    __syncthreads();
+    if (c < a.ncells) {
     i64 nd[4] = {1, 1, 1, 1};
     double dg[4] = {0.0, 0.0, 0.0, 0.0};
     // (32 bytes per cell: two 16-byte loads where the caller's arrays are 16-byte aligned -- a view into a larger array need not be)
@@ -139,6 +144,19 @@ static __global__ __launch_bounds__(THREADS) void elem_cells_k(Args a) {
     *reinterpret_cast<dbl2 *>(cr + 16) = dbl2{dg[0], dg[1]};
     *reinterpret_cast<dbl2 *>(cr + 32) = dbl2{dg[2], dg[3]};
     *reinterpret_cast<dbl2 *>(cr + 48) = dbl2{0.0, 0.0};
+    if (a.colrange) {
+        u32 lo = (u32)(nd[0] - 1), hi = lo;
+#pragma unroll
+        for (int k = 1; k < NLOC; k++) lo = min(lo, (u32)(nd[k] - 1)), hi = max(hi, (u32)(nd[k] - 1));
+        atomicMin(&s_lo, lo);
+        atomicMax(&s_hi, hi);
+    }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && a.colrange && s_lo <= s_hi) {
+        atomicMin(a.colrange, s_lo);
+        atomicMax(a.colrange + 1, s_hi);
+    }
 }
 
 // the diag values of every cell record again (esp_append_elements_again: the connectivity is the same, the element data new)

@@ -116,6 +116,7 @@ struct esp_handle {
     int last_rebuild = 0;        // the last flush's tail rebuilt the matrix (flush_rebuild: the stored CSC as the first piece of a fresh flush)
     int last_lazy_items = 0;     // the last flush's bucket kernel formed its updates from item records (esp_debug_last_lazy_items)
     int last_sum_join = 0;     // esp_debug_last_sum_join
+    int last_sum_plan_bits[2] = {0, 0};  // esp_debug_last_sum_plan_bits: smallest / largest prefix the buffers of the last joint esp_flush_sum had planned
     double last_sum_ms[2] = {0.0, 0.0};  // esp_debug_last_sum_ms: host wall-clock of the last esp_flush_sum's folds / gather + combine flush
     // The entries appended behind a batch over a STORED pattern were partitioned as they came (append_tail_partitioned):
     // pre.tail packed keys in bucket order of a plan of their own -- still a pending stream like any other (a stable
@@ -177,6 +178,7 @@ struct esp_handle {
     // sort_msd over ITEM records (femitems.hpp): a segment may hold plan_cap records (the bucket kernel's capacity in
     // updates / updates per item), and a shuffled stream need not be tried as a pre-sorted one
     i64 plan_cap = 0;
+    u64 plan_occ_span = 0;       // > 0: the records to partition occupy only this many keys of the window (the columns one band of a mesh touches): the plan counts them as that dense
     int plan_bits = 0;           // > 0: sort_msd resolves exactly this many prefix bits in its planned passes (item partitions whose expansion does the last bits itself: segexpand.hpp)
     // the pending entries start at this entry of keys/vals (behind a batch that esp_flush flushed by itself); else 0
     i64 pend_off = 0;

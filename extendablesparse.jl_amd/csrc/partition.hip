@@ -157,7 +157,9 @@ int plan_run_bits(i64 E, int K, u64 span) {
 // corrected by what the handle's last flush saw (seen_spread)
 int plan_prefix_bits(const esp_handle *h, i64 E, int K, double *Ee_out) {
     int planned = 0;
-    const double Ee = plan_entries(E, K, h->win_span);  // (see plan_entries: the window fills only part of its 2^K keys)
+    // (see plan_entries: the window fills only part of its 2^K keys -- and a batch that touches only part of the window's columns,
+    // plan_occ_span, is as dense as if the rest of the window held the same)
+    const double Ee = plan_entries(E, K, h->plan_occ_span > 0 && h->plan_occ_span < h->win_span ? h->plan_occ_span : h->win_span);
     if (E > seg_cap(h)) {
         double target = plan_fill() * (double)seg_cap(h);
         // (test hook: plan as if the bucket kernel took segments of this many entries -- many prefix bits, i.e. the 9-bit
@@ -835,7 +837,10 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
         maxlen = pre0.maxlen;
         if (h->runs_skip > 0) h->runs_skip--;  // (the back-off of the run-based attempt counts flushes)
     }
-    if (planned_run > 8 && h->force_path != ESP_PATH_NO_RUN_PARTITION && !h->item_mode && !resume) {
+    // (item records that are single words -- an element batch in a mesh's natural cell order is as pre-sorted as any assembly loop's
+    // stream -- take it too, keys only; records with a value word stay with the radix passes)
+    const bool items_1w = h->item_mode && h->item_keys_only;
+    if (planned_run > 8 && h->force_path != ESP_PATH_NO_RUN_PARTITION && (!h->item_mode || items_1w) && !resume) {
         if (h->runs_skip > 0) {
             h->runs_skip--;
         } else {
@@ -847,8 +852,8 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
             i64 ml = E;
             bool tr = false;
             int kb = 8;
-            CK(run_partition(h, kin, vin, kout, vout, K, pb, (i64 *)h->seg[1].p, (u64 *)h->tilef[1].p, &tr, &took, &ml, nullptr, 0,
-                             /*allow_k32=*/pb >= planned_run, &kb));
+            CK(run_partition(h, kin, items_1w ? nullptr : vin, kout, items_1w ? nullptr : vout, K, pb, (i64 *)h->seg[1].p, (u64 *)h->tilef[1].p, &tr,
+                             &took, &ml, nullptr, 0, /*allow_k32=*/pb >= planned_run && !h->item_mode, &kb));
             if (took) {
                 tiles_ready = tr;
                 out->key_bytes = kb;

@@ -545,10 +545,14 @@ static __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
             const i64 idx = wbase + k * ESP_WAVE;
             key[k] = idx < end ? a.keys_in[idx] : 0ull;
         }
+        // (vals_in == nullptr: the records are single words -- the item records of an element batch, femitems.hpp / elements.hpp --
+        // no value array is read or written)
+        if (a.vals_in) {
 #pragma unroll
-        for (int k = 0; k < ITEMS; k++) {
-            const i64 idx = wbase + k * ESP_WAVE;
-            val[k] = idx < end ? a.vals_in[idx] : 0.0;
+            for (int k = 0; k < ITEMS; k++) {
+                const i64 idx = wbase + k * ESP_WAVE;
+                val[k] = idx < end ? a.vals_in[idx] : 0.0;
+            }
         }
     }
     __syncthreads();
@@ -617,7 +621,7 @@ static __global__ __launch_bounds__(THREADS) void run_scatter_k(Args a) {
                 reinterpret_cast<u32 *>(a.keys_out)[dst] = (u32)((key[k] - base4) >> ESP_TAG_BITS) & kmask;
             else
                 a.keys_out[dst] = key[k];
-            a.vals_out[dst] = val[k];
+            if (RAW || a.vals_in) a.vals_out[dst] = val[k];
         }
     }
 }

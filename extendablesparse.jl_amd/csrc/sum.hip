@@ -120,6 +120,7 @@ static int32_t flush_sum_items(esp_handle *dst, esp_handle *const *xs, int p, in
     // plan are halves of the coarser one's, its items lie in the same order, and every 2^d-th entry of its segment table IS the
     // table of the coarser plan (a joined segment that outgrows the fused kernel is refused by it like any other: general path)
     if (pb_max - pb_min > 3) return ESP_OK;
+    dst->last_sum_plan_bits[0] = pb_min, dst->last_sum_plan_bits[1] = pb_max;
     const int K = ref->pre.K, pb = pb_min, rem = K - pb, clb = rem - dst->L.rb;
     if (pb > esplocal::MULTI_SEG_BITS || clb < 0 || clb > esplocal::G3_CL_BITS || clb + dst->L.rb > 32 || dst->L.rb > 30 || rem > 32) return ESP_OK;
     const i64 S = (i64)1 << pb, PS = (i64)p * S;
@@ -407,6 +408,12 @@ extern "C" int32_t esp_flush_sum(esp_handle *dst, esp_handle *const *xs, int32_t
 // nzval of the attached CSC := the caller's values (H2D of the values only: the pattern -- colptr, rowval -- is the one
 // the handle holds since the caller's last esp_get_csc / esp_set_csc).  What a plug-in whose CSC stays on the device
 // between flushes uploads instead of the whole matrix when only nonzeros(A) can have been edited on the host.
+extern "C" int32_t esp_debug_last_sum_plan_bits(const esp_handle *h, int32_t *pb_min, int32_t *pb_max) {
+    if (!h || !pb_min || !pb_max) return ESP_ERR_INVALID;
+    *pb_min = h->last_sum_plan_bits[0];
+    *pb_max = h->last_sum_plan_bits[1];
+    return ESP_OK;
+}
 extern "C" int32_t esp_debug_last_sum_ms(const esp_handle *h, double *folds_ms, double *combine_ms) {
     if (!h || !folds_ms || !combine_ms) return ESP_ERR_INVALID;
     *folds_ms = h->last_sum_ms[0];

@@ -512,6 +512,9 @@ int32_t esp_debug_last_sum_join(const esp_handle *h, int32_t *segments);
  * every buffer's own flush) | everything behind them (gather, combine flush, its completion) -- what a bench line reports beside
  * esp_debug_last_lazy_items / _sum_join so that a slow run can be told from a run that took the other path */
 int32_t esp_debug_last_sum_ms(const esp_handle *h, double *folds_ms, double *combine_ms);
+/* the smallest / largest number of prefix bits the buffers of the destination's last joint esp_flush_sum (last_lazy_items 2) had planned
+ * for their item partitions: every handle plans from its own history, the joint path takes the coarsest plan (test hook) */
+int32_t esp_debug_last_sum_plan_bits(const esp_handle *h, int32_t *pb_min, int32_t *pb_max);
 /* 1 when the last flush REBUILT the matrix for the entries behind a re-assembly's batch (a fresh flush whose segments start
  * with the stored entries of their columns: no look-ups against the stored columns, no join); esp_debug_force_path(40): never */
 int32_t esp_debug_last_rebuild(const esp_handle *h, int32_t *on);

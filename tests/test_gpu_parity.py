@@ -3447,7 +3447,7 @@ def test_flush_sum_over_element_batches(esp, orc):
     cn, em, dg = orc.fem_mesh(dim, npd, seed=0x5EED0004, order_mode=0, node_mode=0)
     parts = deal(cn, em, dg, p, "bands")
     results = []
-    for caps in ((0, 0, 0, 0, 0, 0, 0, 0), (0, 0, 0, 40.0, 0, 0, 20.0, 0)):
+    for caps in ((0, 0, 0, 0, 0, 0, 0, 0), (0, 0, 0, 400.0, 0, 0, 200.0, 0)):
         xs = [esp.SparseMatrixHIPCOO(nn, nn) for _ in range(p)]
         for x, cap in zip(xs, caps):
             x._d.ck(x._d.lib.esp_debug_plan_cap(x._d.h, C.c_double(cap)))
@@ -3458,6 +3458,9 @@ def test_flush_sum_over_element_batches(esp, orc):
                 xs[t].append_elements(c, e, d)
             csc = esp.SparseMatrixHIPCOO.sum(xs, csc, home=home)
             assert lazy_state(home) == 2, (caps, rnd, lazy_state(home))
+            lo, hi = C.c_int32(), C.c_int32()
+            home._d.ck(home._d.lib.esp_debug_last_sum_plan_bits(home._d.h, C.byref(lo), C.byref(hi)))
+            assert (hi.value > lo.value) == any(caps), (caps, lo.value, hi.value)     # (the plans really differ)
             results.append(csc.arrays())
     assert_csc_equal(results[0], results[2], "plans that differ, fresh")
     assert_csc_equal(results[1], results[3], "plans that differ, stored pattern")
