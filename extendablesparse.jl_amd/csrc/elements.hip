@@ -70,7 +70,8 @@ int32_t elements_by_items(esp_handle *h, espelem::Args a, i64 E, bool *took) {
         h->pin_scalar[1] = 0ull;
         h->pin_scalar[2] = 0ull, h->pin_scalar[3] = 0ull;
         h->pin_scalar[4] = 0x00000000FFFFFFFFull;  // (colrange: smallest node in the low word, largest in the high one)
-        HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 40, hipMemcpyHostToDevice, h->stream));
+        h->pin_scalar[5] = 0ull;                   // (... and the count of wide waves)
+        HIPCK(h, hipMemcpyAsync(d_err, h->pin_scalar, 48, hipMemcpyHostToDevice, h->stream));
         a.colrange = (cellrec && h->n < ((i64)1 << 32)) ? (u32 *)((unsigned long long *)h->misc.p + 4) : nullptr;
         {
             Span sp(h, ESP_ST_APPEND);
@@ -98,13 +99,18 @@ int32_t elements_by_items(esp_handle *h, espelem::Args a, i64 E, bool *took) {
         h->plan_cap = lbits ? (i64)espseg::LCAP : (i64)esplocal::CAP / W;
         h->plan_bits = lbits ? sort_bits : 0;
         h->plan_occ_span = 0;
+        h->plan_try_runs = false;
         if (a.colrange && !lbits) {
             // the columns the batch touches (one round trip: it saves the pass -- a dozen launches -- a plan made for the whole window
             // needs when the batch is a band of the mesh: one partition's cells, 1 / p of the columns at p times the density)
-            HIPCK(h, hipMemcpyAsync(h->pin_scalar, (unsigned long long *)h->misc.p + 4, 8, hipMemcpyDeviceToHost, h->stream));
+            HIPCK(h, hipMemcpyAsync(h->pin_scalar, (unsigned long long *)h->misc.p + 4, 16, hipMemcpyDeviceToHost, h->stream));
             HIPCK(h, hipStreamSynchronize(h->stream));
             const u64 lo = h->pin_scalar[0] & 0xFFFFFFFFull, hi = h->pin_scalar[0] >> 32;
             if (lo <= hi) h->plan_occ_span = (hi - lo + 1) << vrb;
+            // (the run-based single pass only for a cell order that looks like a mesh's own: fewer than an eighth of the waves wide)
+            const u64 blocks = (u64)grid_for(a.ncells, espelem::THREADS);
+            const u64 wide = h->pin_scalar[1] & 0xFFFFFFFFull, sampled = (blocks + 63) / 64 + 1;  // (elem_cells_k: one wave of every 64th workgroup + the last)
+            h->plan_try_runs = wide * 8 <= sampled;
         }
         h->item_mode = true;
         h->item_keys_only = true;
@@ -116,6 +122,7 @@ int32_t elements_by_items(esp_handle *h, espelem::Args a, i64 E, bool *took) {
         h->plan_cap = 0;
         h->plan_bits = 0;
         h->plan_occ_span = 0;
+        h->plan_try_runs = false;
         h->item_mode = false;
         h->item_keys_only = false;
         if (rc != ESP_OK) return rc;

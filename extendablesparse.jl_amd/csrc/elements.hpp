@@ -88,9 +88,7 @@ static __global__ __launch_bounds__(THREADS) void elem_cells_k(Args a) {
     typedef double dbl2 __attribute__((ext_vector_type(2)));
     typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
     const i64 c = (i64)blockIdx.x * THREADS + threadIdx.x;
-    __shared__ u32 s_lo, s_hi;
-    if (threadIdx.x == 0) s_lo = ~0u, s_hi = 0u;
-    __syncthreads();
+    u32 lo = ~0u, hi = 0u;  // smallest / largest 0-based node of this thread's cell (neutral for a thread without one)
     if (c < a.ncells) {
     i64 nd[4] = {1, 1, 1, 1};
     double dg[4] = {0.0, 0.0, 0.0, 0.0};
@@ -144,18 +142,24 @@ static __global__ __launch_bounds__(THREADS) void elem_cells_k(Args a) {
     *reinterpret_cast<dbl2 *>(cr + 16) = dbl2{dg[0], dg[1]};
     *reinterpret_cast<dbl2 *>(cr + 32) = dbl2{dg[2], dg[3]};
     *reinterpret_cast<dbl2 *>(cr + 48) = dbl2{0.0, 0.0};
-    if (a.colrange) {
-        u32 lo = (u32)(nd[0] - 1), hi = lo;
+    lo = (u32)(nd[0] - 1), hi = lo;
 #pragma unroll
-        for (int k = 1; k < NLOC; k++) lo = min(lo, (u32)(nd[k] - 1)), hi = max(hi, (u32)(nd[k] - 1));
-        atomicMin(&s_lo, lo);
-        atomicMax(&s_hi, hi);
+    for (int k = 1; k < NLOC; k++) lo = min(lo, (u32)(nd[k] - 1)), hi = max(hi, (u32)(nd[k] - 1));
     }
-    }
-    __syncthreads();
-    if (threadIdx.x == 0 && a.colrange && s_lo <= s_hi) {
-        atomicMin(a.colrange, s_lo);
-        atomicMax(a.colrange + 1, s_hi);
+    // (every lane of the wave is here: the DPP reductions need them all)
+    // A SAMPLE of the batch -- the first wave of every 64th workgroup and of the last one -- tells the host what the cell order looks
+    // like (atomics on one address cost the chip ~12 ns each: one per wave of a 2 10^7-cell batch would be 4 ms): the nodes of the
+    // wave's 64 consecutive cells go into the batch's range (colrange[0 .. 1]: the item partition plans for the columns the batch
+    // touches -- a hint: a sample's range misses at most a few thousand cells at either end), and colrange[2] counts the sampled waves
+    // whose cells lie more than lim / 16 apart -- a shuffled cell order or a mesh numbered without locality: nearly all of them; a mesh in
+    // its own order: none (the host's cue for the run-based pass).
+    if (a.colrange && threadIdx.x < ESP_WAVE && ((blockIdx.x & 63u) == 0u || blockIdx.x == gridDim.x - 1)) {
+        const u32 wlo = ~esp_wave_max(~lo), whi = esp_wave_max(hi);
+        if ((threadIdx.x & 63) == 0 && wlo <= whi) {
+            atomicMin(a.colrange, wlo);
+            atomicMax(a.colrange + 1, whi);
+            if ((i64)(whi - wlo) > (a.lim >> 4)) atomicAdd(a.colrange + 2, 1u);
+        }
     }
 }
 

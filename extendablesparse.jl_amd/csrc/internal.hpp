@@ -178,6 +178,7 @@ struct esp_handle {
     // sort_msd over ITEM records (femitems.hpp): a segment may hold plan_cap records (the bucket kernel's capacity in
     // updates / updates per item), and a shuffled stream need not be tried as a pre-sorted one
     i64 plan_cap = 0;
+    bool plan_try_runs = false;  // item records of an element batch whose cell order looked pre-sorted to elem_cells_k: sort_msd tries the run-based pass
     u64 plan_occ_span = 0;       // > 0: the records to partition occupy only this many keys of the window (the columns one band of a mesh touches): the plan counts them as that dense
     int plan_bits = 0;           // > 0: sort_msd resolves exactly this many prefix bits in its planned passes (item partitions whose expansion does the last bits itself: segexpand.hpp)
     // the pending entries start at this entry of keys/vals (behind a batch that esp_flush flushed by itself); else 0

@@ -839,7 +839,7 @@ int32_t sort_msd(esp_handle *h, Sorted *out) {
     }
     // (item records that are single words -- an element batch in a mesh's natural cell order is as pre-sorted as any assembly loop's
     // stream -- take it too, keys only; records with a value word stay with the radix passes)
-    const bool items_1w = h->item_mode && h->item_keys_only;
+    const bool items_1w = h->item_mode && h->item_keys_only && h->plan_try_runs;
     if (planned_run > 8 && h->force_path != ESP_PATH_NO_RUN_PARTITION && (!h->item_mode || items_1w) && !resume) {
         if (h->runs_skip > 0) {
             h->runs_skip--;
