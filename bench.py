@@ -573,6 +573,39 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
             del A
         except Exception as ex:
             out[etag] = {"error": repr(ex)}
+    # ---- the path every rank of a multi-GPU run takes (BASELINE config 5's per-rank work), on this one GPU: a single-rank group --
+    # column-shard plan, producer partitions by (owner, digit), exchange policy with nothing to send, PIECES bucket kernel.  Not a
+    # multi-GPU measurement (there has never been a node to make one): the overhead of the sharded path over the headline's.
+    try:
+        want("cfg5")
+        n = n_cfg3
+        N = n ** 3
+        E, Z = fd_counts(n)
+        SA = esp.GroupShardedMatrix(N, N, nranks=1, rank=0, device=local, capacity_hint=E + 8 * n * n, unique_id=esp.GroupShardedMatrix.unique_id())
+        A = SA.local
+        dts = []
+        for it in range(steps + 3):
+            A.synchronize()
+            t0 = time.perf_counter()
+            A.reset()
+            A.generate_fdrand_range(n, n, n, 0, N, seed=0x5EED0002, rand_mode=1, kind=esp.ESP_UPDATE)
+            SA.flush()
+            A.synchronize()
+            if it > 2:
+                dts.append(time.perf_counter() - t0)
+        ok5 = csc_digest_ok(A, "fd_%d_m1" % n, pins)
+        dt = sum(dts) / len(dts)
+        algo = 2 * 16.0 * E + 16.0 * Z + 8.0 * (N + 1)
+        out["cfg5_one_rank_shard"] = {
+            "workload": "fdrand %d^3 through the column-shard path with ONE rank (esp_group_flush: shard plan, producer partition by (owner, digit), "
+                        "PIECES bucket kernel; nothing travels): what each rank of config 5 does locally -- NOT a multi-GPU measurement" % n,
+            "ms": dt * 1e3, "nnz_per_s": Z / dt, "algorithmic_bytes": algo, "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS,
+            "key_bytes": A.debug_last_key_bytes(), "shard_source": A.debug_last_shard_source(), "steps": len(dts), "digest_ok": ok5}
+        del SA, A
+    except _Skip:
+        pass
+    except Exception as ex:
+        out["cfg5_one_rank_shard"] = {"error": repr(ex)}
     # ---- flush! of the MT wrapper (genericmtextendablesparsematrixcsc.jl:45-51 = Base.sum(xmatrices, csc)): the 2-D mesh
     # dealt to 16 partition buffers (contiguous chunks of the shuffled cell order), each filled by esp_append_elements, then
     # ONE esp_flush_sum into the handle that keeps the CSC -- device-resident; `plugin_ms`: the same through
