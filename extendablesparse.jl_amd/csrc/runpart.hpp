@@ -300,12 +300,36 @@ static __global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_c
     }
     if (t == 0) over = 0;
     u64 key[ITEMS];
+    // (RAW, the caller's columns 16-byte aligned: two columns per load -- counting does not care which lane holds which entry;
+    // item k of a lane is then entry 2 ((k >> 1) THREADS + t) + (k & 1) of the chunk)
+    bool vec = false;
+    if constexpr (RAW) vec = (reinterpret_cast<uintptr_t>(a.raw_cols) & 15) == 0;
+    auto idx_of = [&](int k) -> i64 { return vec ? beg + 2 * ((i64)(k >> 1) * THREADS + t) + (k & 1) : beg + (i64)k * THREADS + t; };
     if constexpr (RAW) {  // (the digit is a function of the column: row 0 stands in; a column outside the matrix is reported)
+        i64 cc[ITEMS];
+        if (vec) {
+            typedef long long ll2 __attribute__((ext_vector_type(2)));
+            const ll2 *pc = reinterpret_cast<const ll2 *>(a.raw_cols + beg);  // (beg is a multiple of TILE)
+#pragma unroll
+            for (int k = 0; k < ITEMS; k += 2) {
+                const i64 i0 = idx_of(k);
+                ll2 v{1, 1};
+                if (i0 + 1 < end) v = pc[(i64)(k >> 1) * THREADS + t];
+                else if (i0 < end) v.x = a.raw_cols[i0];
+                cc[k] = v.x, cc[k + 1] = v.y;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < ITEMS; k++) {
+                const i64 idx = idx_of(k);
+                cc[k] = idx < end ? a.raw_cols[idx] : 1;
+            }
+        }
 #pragma unroll
         for (int k = 0; k < ITEMS; k++) {
-            const i64 idx = beg + k * THREADS + t;
-            i64 c = idx < end ? a.raw_cols[idx] : 1;
-            if (!(1 <= c && c <= a.raw_n)) {
+            const i64 idx = idx_of(k);
+            i64 c = cc[k];
+            if (idx < end && !(1 <= c && c <= a.raw_n)) {
                 atomicMin(a.raw_err, (unsigned long long)(idx + 1));
                 c = 1;
             }
@@ -326,7 +350,7 @@ static __global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_c
     if constexpr (MULTI) ww = wave_window(a, s_mw, key[0]);
 #pragma unroll
     for (int k = 0; k < ITEMS; k++) {
-        const bool valid = (beg + k * THREADS + t) < end;
+        const bool valid = idx_of(k) < end;
         dig[k] = valid ? digit_mw<MULTI>(a, s_mw, ww, key[k], true) : 0u;
         pend |= valid ? (1u << k) : 0u;
     }
