@@ -304,13 +304,21 @@ int32_t run_partition(esp_handle *h, const u64 *kin, const double *vin, u64 *kou
             HIPCK(h, hipMemsetAsync(bstart, 0, sizeof(u64) * (size_t)(NB + 1), h->stream));
         }
         Span sp(h, ESP_ST_HIST);
-        if (raw)
-            hipLaunchKernelGGL((esprun::run_hist_k<false, true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a, (i64)0);
-        else if (mw)
-            hipLaunchKernelGGL((esprun::run_hist_k<true>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a, (i64)0);
-        else
-            hipLaunchKernelGGL((esprun::run_hist_k<false>), dim3((unsigned)C), dim3(esprun::THREADS), 0, h->stream, a, (i64)0);
-        sp.add(1);
+        // Two launches: a PROBE over the first chunks, then the rest -- whose workgroups look at the overflow flag BEFORE they
+        // request their keys (run_hist_k: first_chunk > 0).  A stream that is not pre-sorted is recognised by the probe, and what
+        // used to cost a full pass over the keys (2.2 ms for 1.2 10^9 shuffled triplets, every time the back-off lets the handle try
+        // again) costs the probe.
+        const i64 C0 = C > 2 * esprun::PROBE_CHUNKS ? (i64)esprun::PROBE_CHUNKS : C;
+        for (i64 c0 = 0; c0 < C; c0 = c0 == 0 ? C0 : C) {
+            const unsigned g = (unsigned)(c0 == 0 ? C0 : C - C0);
+            if (raw)
+                hipLaunchKernelGGL((esprun::run_hist_k<false, true>), dim3(g), dim3(esprun::THREADS), 0, h->stream, a, c0);
+            else if (mw)
+                hipLaunchKernelGGL((esprun::run_hist_k<true>), dim3(g), dim3(esprun::THREADS), 0, h->stream, a, c0);
+            else
+                hipLaunchKernelGGL((esprun::run_hist_k<false>), dim3(g), dim3(esprun::THREADS), 0, h->stream, a, c0);
+            sp.add(1);
+        }
     }
     if (ranked) {
         {

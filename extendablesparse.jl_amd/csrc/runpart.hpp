@@ -30,6 +30,7 @@ constexpr int WAVES = THREADS / ESP_WAVE;
 constexpr int ITEMS = 16;
 constexpr int TILE = THREADS * ITEMS;  // same tiles as espradix
 constexpr int RMAX = 64;               // distinct digits a tile may hold on this path
+constexpr int PROBE_CHUNKS = 512;       // run_hist_k's first launch (2 M entries): a stream that is not pre-sorted shows there
 constexpr int MAX_PB = 20;             // prefix bits of the run-based single pass / a producer-side partition (2^20 buckets: the run lists' arrays)
 constexpr u32 EMPTY = 0xFFFFFFFFu;
 constexpr int DCAP = 32;               // runs one digit may collect in its own list (ranked path)
@@ -294,6 +295,8 @@ static __global__ __launch_bounds__(THREADS) void run_hist_k(Args a, i64 first_c
     // a stream that is not pre-sorted is recognised by the first workgroups: the rest leave at once
     // (the flag is read while the keys are in flight)
     const u32 give_up = __hip_atomic_load(a.overflow, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (the launch behind the probe -- partition.hip -- waits for the flag: its workgroups request nothing when the probe gave up)
+    if (first_chunk > 0 && give_up != 0u) return;
     if (t < RMAX) {
         rd[t] = EMPTY;
         rc[t] = 0;
