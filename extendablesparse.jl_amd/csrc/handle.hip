@@ -678,6 +678,10 @@ void host_parallel(size_t count, size_t min_part, int cap, F body) {
 }
 }  // namespace
 
+// fn(part) for part = 0 .. parts-1 on the host pool's threads and the caller's; returns when all are done (one job at a time: a
+// second caller runs its parts itself)
+void host_run_parts(int parts, const std::function<void(int)> &fn) { host_pool().run(parts, fn); }
+
 void par_memcpy(void *dst, const void *src, size_t bytes) {
     host_parallel(bytes, (size_t)2 << 20, 8, [=](size_t a, size_t b) {
         const size_t a64 = a & ~(size_t)63, b64 = b == bytes ? b : (b & ~(size_t)63);  // (parts start on 64-byte boundaries)

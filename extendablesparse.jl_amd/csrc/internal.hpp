@@ -447,6 +447,7 @@ int32_t pack_device(esp_handle *h, const i64 *d_rows, const i64 *d_cols, const d
 int32_t ensure_stage(esp_handle *h, esp_handle::StageArea &sa, i64 want);
 int32_t ensure_bounce(esp_handle *h);
 void par_memcpy(void *dst, const void *src, size_t bytes);
+void host_run_parts(int parts, const std::function<void(int)> &fn);
 int32_t d2h_pipelined(esp_handle *h, void *dst, const void *d_src, size_t bytes);
 // pageable host memory -> device through the same two pinned bounce buffers (the host copy of chunk i+1 overlaps the transfer
 // of chunk i); returns when the device holds the data

@@ -322,40 +322,29 @@ extern "C" int32_t esp_flush_sum(esp_handle *dst, esp_handle *const *xs, int32_t
         // flush over their records as pieces (flush_sum_items)
         CK(flush_sum_items(dst, xs, p, new_nnz, pattern_changed, &by_items));
         if (by_items) return ESP_OK;
-        // 1. every buffer's own fold, one after the other on the calling thread.  (Round 4 ran them side by side, one host thread
-        // per buffer: concurrent esp_flush calls on different handles -- each with hipFree / hipMalloc of its scratch and its own
-        // non-blocking stream -- produced rare memory faults and wrong results on this stack (found by the parity fuzz in round
-        // 5: 4 of 8 runs of one case; 0 of 8 serial), and 16 small pipelines did not overlap well anyway.)
-#ifdef ESP_EXPERIMENTS
-        if (esp_exp_env("ESP_SUM_THREADS")) {  // (round 4's form, for the hunt of NOTES/round5.md section 8: one host thread per buffer)
-            std::vector<std::thread> th;
-            std::vector<int32_t> rcs((size_t)p, ESP_OK);
-            std::vector<int64_t> zs((size_t)p, 0);
+        // 1. every buffer's own fold -- side by side on the host pool's threads (handle.hip: the threads of the bulk host copies; up to
+        // eight with the caller's): distinct handles are independent (NOTES/round6.md section 1), and 16 pipelines of a dozen small
+        // launches and two or three host round trips each overlap well: 16 buffers of 2 10^6 entries 8.8 -> 6.6 ms, of 2 10^5
+        // entries 3.8 -> 1.7 ms (tools/r6_sum_threads.py).  (Rounds 4 / 5 had taken the threads away: what looked like a hazard of
+        // concurrent flushes was the bucket kernel's missing barrier.)
+        {
+            std::vector<int> idx;
             for (int k = 0; k < p; k++)
-                if (xs[k]->count != 0)
-                    th.emplace_back([&, k] {
-                        (void)hipSetDevice(xs[k]->device);
-                        rcs[(size_t)k] = esp_flush(xs[k], ESP_FLUSH_ROUTED, &zs[(size_t)k], nullptr);
-                    });
-            for (auto &t : th) t.join();
-            for (int k = 0; k < p; k++) {
-                if (rcs[(size_t)k] != ESP_OK) {
-                    dst->err = xs[k]->err;
-                    return rcs[(size_t)k];
+                if (xs[k]->count != 0) idx.push_back(k);
+            std::vector<int32_t> rcs(idx.size(), ESP_OK);
+            std::vector<int64_t> zs(idx.size(), 0);
+            host_run_parts((int)idx.size(), [&](int j) {
+                esp_handle *x = xs[(size_t)idx[(size_t)j]];
+                (void)hipSetDevice(x->device);
+                rcs[(size_t)j] = esp_flush(x, ESP_FLUSH_ROUTED, &zs[(size_t)j], nullptr);
+            });
+            for (size_t j = 0; j < idx.size(); j++) {
+                if (rcs[j] != ESP_OK) {
+                    dst->err = xs[(size_t)idx[j]]->err;
+                    return rcs[j];
                 }
-                folded += zs[(size_t)k];
+                folded += zs[j];
             }
-        } else
-#endif
-        for (int k = 0; k < p; k++) {
-            if (xs[k]->count == 0) continue;
-            int64_t z = 0;
-            const int32_t rc1 = esp_flush(xs[k], ESP_FLUSH_ROUTED, &z, nullptr);
-            if (rc1 != ESP_OK) {
-                dst->err = xs[k]->err;
-                return rc1;
-            }
-            folded += z;
         }
         t_b = now();
         // 2. their entries behind one another in dst's buffer (dst's stream waits for each buffer's flush: esp_flush returned

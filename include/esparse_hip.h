@@ -26,7 +26,9 @@
  *     use included (genericmtextendablesparsematrixcsc.jl:87-99: one buffer per task;
  *     tests/test_concurrent_handles.py; the corruption rounds 4 and 5 saw here was a
  *     missing barrier inside the bucket kernel, NOTES/round6.md section 1).  The library
- *     itself starts no threads on the flush path;
+ *     starts no threads of its own on the flush path, with one exception: esp_flush_sum folds
+ *     buffers that are not element batches side by side on its host-copy pool (at most eight
+ *     threads with the caller's; ESP_HOST_THREADS caps it);
  *   - element types: Float64 values, Int64 indices (the reference's default
  *     ExtendableSparseMatrix{Float64,Int64}); other Tv/Ti stay on the CPU path.
  */
