@@ -83,6 +83,19 @@ def cfg3_new_positions(n, seed=0x5EED0003):
     return np.concatenate([l, l + 2]), np.concatenate([l + 2, l]), np.concatenate([v, v])
 
 
+def mt_per_entry_streams(n=4000000, p=16, cnt=2000000, seed=1):
+    """The per-entry form of the reference's multi-threaded assembly (same generator as tests/golden_util.mt_per_entry_streams, which
+    made the pin mtgen_4M_p16): task t sends cnt updateindex! / rawupdateindex! calls to the columns of its band."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    out = []
+    for t in range(p):
+        J = np.sort(rng.integers(t * n // p + 1, (t + 1) * n // p + 1, cnt))
+        I = np.clip(J + rng.integers(-30, 31, cnt), 1, n)
+        out.append((I, J, rng.standard_normal(cnt), rng.integers(1, 3, cnt).astype(np.uint8)))
+    return out
+
+
 def fd_counts(n):
     E = 12 * n * n * (n - 1) + 6 * n * n
     Z = n ** 3 + 6 * n * n * (n - 1)
@@ -710,6 +723,55 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
         pass
     except Exception as ex:
         out["cfg_mt_sum"] = {"error": repr(ex)}
+    # ---- ... and its per-entry form (test/femtools.jl:88-107: every task calls updateindex! / rawupdateindex! with its tid): 16 buffers
+    # of 2 10^6 calls each, mixed kinds -- not element batches: esp_flush_sum's general path, every buffer's own fold (side by side on
+    # the library's host pool since round 6), their entries gathered, one routed flush.  Timed: the flush! alone (the per-entry
+    # appends are the host loop's).
+    try:
+        want("cfg_mt_sum")
+        import hashlib
+        n5, p5 = 4000000, 16
+        streams = mt_per_entry_streams(n5, p5)
+        xs = [esp.SparseMatrixHIPCOO(n5, n5, device=local) for _ in range(p5)]
+        home = esp.SparseMatrixHIPCOO(n5, n5, device=local)
+        hd = home._d
+        arr = (C.c_void_p * p5)(*[x._d.h for x in xs])
+        dts, Z = [], 0
+        for it in range(steps + 2):
+            hd.ck(hd.lib.esp_reset(hd.h))
+            for t, (I, J, V, K) in enumerate(streams):
+                xs[t].append(0, I, J, V, kinds=K)
+            for x in xs:
+                x._d.ck(x._d.lib.esp_synchronize(x._d.h))
+            z, ch = C.c_int64(), C.c_int32()
+            t0 = time.perf_counter()
+            hd.ck(hd.lib.esp_flush_sum(hd.h, arr, p5, C.byref(z), C.byref(ch)))
+            hd.ck(hd.lib.esp_synchronize(hd.h))
+            if it > 1:
+                dts.append(time.perf_counter() - t0)
+            Z = z.value
+        okp = None
+        if "mtgen_4M_p16" in pins:
+            cpd, rvd, nzd = hd.get_csc().arrays()
+            hh = hashlib.sha256()
+            for a_ in (cpd, rvd, nzd):
+                hh.update(memoryview(a_).cast("B"))
+            okp = len(rvd) == int(pins["mtgen_4M_p16"]["nnz"]) and hh.hexdigest() == pins["mtgen_4M_p16"]["csc"]
+            del cpd, rvd, nzd
+        dt = sum(dts) / len(dts)
+        Ein = sum(len(sx[0]) for sx in streams)
+        algo = 16.0 * Ein + 2 * 16.0 * Z + 16.0 * Z + 8.0 * (n5 + 1)   # (pending entries read, the folds written and read, the CSC written)
+        out["cfg_mt_sum_per_entry"] = {
+            "workload": "%d partition buffers of %d per-entry updateindex! / rawupdateindex! calls each (mixed kinds, a band of columns per tid), "
+                        "flush! = ONE esp_flush_sum: general path (every buffer's own fold, side by side on the host pool; gather; one routed "
+                        "flush) -- the flush! alone is timed" % (p5, len(streams[0][0])),
+            "ms": dt * 1e3, "nnz_per_s": Z / dt, "final_nnz": Z, "algorithmic_bytes": algo, "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS,
+            "steps": len(dts), "digest_ok": okp}
+        del xs, home, streams
+    except _Skip:
+        pass
+    except Exception as ex:
+        out["cfg_mt_sum_per_entry"] = {"error": repr(ex)}
     return out
 
 

@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(HERE))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle import oracle as orc  # noqa: E402
-from golden_util import digest, cfg3_new_positions  # noqa: E402
+from golden_util import digest, cfg3_new_positions, mt_per_entry_streams  # noqa: E402
 
 UPDATE, RAW = 1, 2
 
@@ -122,6 +122,18 @@ def main():
         M.flush()
         cp, rv, nz = M.arrays()
         lines.append("%s nnz=%d csc=%s" % (tag, len(rv), digest(cp, rv, nz)))
+        print(lines[-1], flush=True)
+        del M, cp, rv, nz
+    # ... and its per-entry form: 16 tasks x 2 10^6 updateindex! / rawupdateindex! calls with their tid, ONE flush! (bench.py's
+    # cfg_mt_sum_per_entry: esp_flush_sum's general path, the buffers' folds side by side)
+    if want("mtgen_4M_p16"):
+        n, p = 4000000, 16
+        M = orc.MTExtendableSparseMatrix(n, n, p)
+        for t, (I, J, V, K) in enumerate(mt_per_entry_streams(n, p)):
+            M.apply(K, I, J, V, tid=t + 1)
+        M.flush()
+        cp, rv, nz = M.arrays()
+        lines.append("mtgen_4M_p16 nnz=%d csc=%s" % (len(rv), digest(cp, rv, nz)))
         print(lines[-1], flush=True)
         del M, cp, rv, nz
     for ln in lines:

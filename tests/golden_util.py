@@ -27,6 +27,19 @@ def cfg3_new_positions(n, seed=0x5EED0003):
     return np.concatenate([l, l + 2]), np.concatenate([l + 2, l]), np.concatenate([v, v])
 
 
+def mt_per_entry_streams(n=4000000, p=16, cnt=2000000, seed=1):
+    """The per-entry form of the reference's multi-threaded assembly (test/femtools.jl:88-107: every task calls updateindex! /
+    rawupdateindex! with its tid): task t sends cnt calls to the columns of its band (columns ascending, rows within 30 of the
+    column, kinds UPDATE / RAWUPDATE mixed).  Returns [(I, J, V, K)] per task; bench.py's cfg_mt_sum_per_entry and its pin."""
+    rng = np.random.default_rng(seed)
+    out = []
+    for t in range(p):
+        J = np.sort(rng.integers(t * n // p + 1, (t + 1) * n // p + 1, cnt))
+        I = np.clip(J + rng.integers(-30, 31, cnt), 1, n)
+        out.append((I, J, rng.standard_normal(cnt), rng.integers(1, 3, cnt).astype(np.uint8)))
+    return out
+
+
 def digests(name="digests.txt"):
     out = {}
     with open(os.path.join(GOLDEN, name)) as f:

@@ -2479,6 +2479,27 @@ def test_more_than_32_key_bits_below_the_prefix(esp):
     assert len(set(seen.values())) == 1, seen
 
 
+def test_mt_per_entry_digest(esp):
+    """The per-entry form of the reference's multi-threaded assembly at bench size (test/femtools.jl:88-107: 16 tasks x 2 10^6
+    updateindex! / rawupdateindex! calls with their tid, ONE flush! = Base.sum(xmatrices, csc)): esp_flush_sum's general path --
+    every buffer's own fold, side by side on the library's host pool -- against the oracle's MT wrapper (tests/golden: mtgen_4M_p16)."""
+    import ctypes as C
+    d = gu.digests("digests_large.txt")["mtgen_4M_p16"]
+    n, p = 4000000, 16
+    xs = [esp.SparseMatrixHIPCOO(n, n) for _ in range(p)]
+    home = esp.SparseMatrixHIPCOO(n, n)
+    streams = gu.mt_per_entry_streams(n, p)
+    for rnd in range(2):                                 # (fresh handles, then warm ones)
+        home._d.ck(home._d.lib.esp_reset(home._d.h))
+        for t, (I, J, V, K) in enumerate(streams):
+            xs[t].append(0, I, J, V, kinds=K)
+        arr = (C.c_void_p * p)(*[x._d.h for x in xs])
+        z, ch = C.c_int64(), C.c_int32()
+        home._d.ck(home._d.lib.esp_flush_sum(home._d.h, arr, p, C.byref(z), C.byref(ch)))
+        assert z.value == int(d["nnz"])
+        assert gu.digest(*home._d.get_csc().arrays()) == d["csc"], rnd
+
+
 def test_config3_digest_128(esp):
     """BASELINE config 3 at 128^3: stored stencil CSC + new second-neighbour positions + the full stream again, one
     flush through the routed fold and the merge-path join; digest of the oracle's result."""
