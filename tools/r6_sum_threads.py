@@ -32,4 +32,7 @@ for it in range(6):
     hd.ck(hd.lib.esp_flush_sum(hd.h, arr, p, C.byref(z), C.byref(ch)))
     hd.ck(hd.lib.esp_synchronize(hd.h))
     ts.append(time.perf_counter() - t0)
+f_ms, c_ms = C.c_double(), C.c_double()
+hd.ck(hd.lib.esp_debug_last_sum_ms(hd.h, C.byref(f_ms), C.byref(c_ms)))
+print("last call: folds %.2f ms, gather + combine flush %.2f ms" % (f_ms.value, c_ms.value))
 print("threads" if os.environ.get("ESP_SUM_THREADS") else "serial ", "p %d x %d entries: esp_flush_sum %.2f ms (min of %s)" % (p, cnt, min(ts[1:]) * 1e3, [round(x * 1e3, 2) for x in ts]), "nnz", z.value)
