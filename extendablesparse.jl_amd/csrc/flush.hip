@@ -160,6 +160,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
     HIPCK(h, hipMemsetAsync(status, 0, status_bytes, h->stream));
     CK(ensure(h, h->colend, sizeof(u64) * (size_t)(N1 + espscan::workspace_elems(N1))));
     esplocal::Args a;
+    memset(&a, 0, sizeof a);
     const char *stop_env = esp_exp_env("ESP_LOCAL_STOP");  // (experiments build only: ablation of the bucket kernel)
     // A fresh matrix whose segments are whole blocks of <= CL_MAX columns that start at the first column of the
     // range this flush can touch (all columns, or the column window of a shard) and cover it: every segment writes
@@ -245,6 +246,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         a.status = status;
         a.gstatus = status + S + 2;
         a.npieces = st.npieces;
+        a.pieces_dense = st.pieces_dense ? 1 : 0;
         a.total = total_check;
         a.pstart = st.pstart;
         a.ptab = st.ptab;
@@ -665,6 +667,7 @@ int32_t flush_pre_tail(esp_handle *h, int mode, i64 *Zn, bool *served) {
     st.all_update = h->kind_uniform == ESP_UPDATE && h->kind_noted == h->count;
     st.ptab = (const void *const *)TB;
     st.pstart = pstart;
+    st.pieces_dense = true;
     st.maxlen = merged;
     st.has_base = true;
     st.base = h->win_base;
@@ -780,6 +783,7 @@ int32_t flush_rebuild(esp_handle *h, const Sorted &st, int mode, i64 *Znew, bool
     sp2.all_update = false;
     sp2.ptab = (const void *const *)TB;
     sp2.pstart = pstart;
+    sp2.pieces_dense = true;
     sp2.maxlen = merged;
     sp2.total = -1;
     sp2.has_base = true;

@@ -112,7 +112,7 @@ void release(DevBuf &b) {
 void release_all(esp_handle *h) {
     for (DevBuf *b : {&h->keys, &h->vals, &h->keys2, &h->vals2, &h->hist, &h->segs, &h->colend, &h->newkey,
                       &h->newval, &h->heads, &h->misc, &h->colptr, &h->colptr2, &h->rowval, &h->nzval, &h->rowval2,
-                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->tseg, &h->ttile, &h->runbuf, &h->chunkbuf, &h->parttab, &h->piecetab, &h->csr_rowptr, &h->csr_perm, &h->csr_col, &h->csr_tmp, &h->csr_val, &h->mul_x, &h->mul_r, &h->lazy_hold, &h->elemplan.sorted, &h->elemplan.cellrec, &h->elemplan.segtab, &h->stage.d_rows, &h->stage.d_cols, &h->stage.d_vals, &h->stage.d_kinds, &h->bulk.d_rows, &h->bulk.d_cols, &h->bulk.d_vals, &h->bulk.d_kinds})
+                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->tseg, &h->ttile, &h->runbuf, &h->chunkbuf, &h->parttab, &h->piecetab, &h->asmwork, &h->csr_rowptr, &h->csr_perm, &h->csr_col, &h->csr_tmp, &h->csr_val, &h->mul_x, &h->mul_r, &h->lazy_hold, &h->elemplan.sorted, &h->elemplan.cellrec, &h->elemplan.segtab, &h->stage.d_rows, &h->stage.d_cols, &h->stage.d_vals, &h->stage.d_kinds, &h->bulk.d_rows, &h->bulk.d_cols, &h->bulk.d_vals, &h->bulk.d_kinds})
         release(*b);
     for (esp_handle::StageArea *sa : {&h->stage, &h->bulk}) {
         if (sa->rows) (void)hipHostFree(sa->rows);
@@ -277,6 +277,7 @@ extern "C" int32_t esp_destroy(esp_handle *h) {
 #endif
     if (h->pin_scalar) (void)hipHostFree(h->pin_scalar);
     if (h->pin_mw) (void)hipHostFree(h->pin_mw);
+    if (h->pin_asm) (void)hipHostFree(h->pin_asm);
     if (h->pin_mw_done) (void)hipEventDestroy(h->pin_mw_done);
     for (auto &s : h->spans) {
         (void)hipEventDestroy(s.a);

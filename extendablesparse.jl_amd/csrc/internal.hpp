@@ -271,6 +271,9 @@ struct esp_handle {
     u64 part_base = 0, part_span = 0;
     i64 part_total = 0, part_maxlen = 0, part_own_lo = 0;
     DevBuf parttab, piecetab;
+    DevBuf asmwork;                        // esp_shard_assemble's kernel: ticket | summary | per-workgroup partial results (zeroed once)
+    unsigned long long *pin_asm = nullptr;  // ... and the pinned block its last workgroup writes the results to
+    unsigned long long asm_seq = 0;
     // row-wise view of the device CSC for mul! (built on first use after a pattern change)
     unsigned long long pattern_version = 1, csr_version = 0;
     unsigned long long values_version = 1, csr_val_version = 0;  // nzval changed / row-wise copy of the values
@@ -384,6 +387,7 @@ struct Sorted {
     i64 p32_lo = 0;
     // PIECES (partitioned shard exchange): segments are concatenations of per-source pieces
     int npieces = 0;
+    bool pieces_dense = false;   // PIECES: most segments hold entries of several pieces (a batch and its tail, a stored slice and new entries)
     const i64 *pstart = nullptr;
     const void *const *ptab = nullptr;
     const esp_handle::LazyItems *lazy = nullptr;  // sk holds sorted ITEM records, seg_start counts their updates: the fused bucket kernel or nothing

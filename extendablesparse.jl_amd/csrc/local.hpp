@@ -1375,7 +1375,9 @@ __device__ __forceinline__ bool group_columns(const Args &a, KT *skey, double *s
 // prefix -- and every entry has the kind a.kind32 (the run-based partition writes them when all pending entries
 // share one kind); 2 = the same and that kind is UPDATE (an assembly loop of updateindex! calls): the register
 // tiers fold without decoding a kind; 3 = packed keys whose kinds are all UPDATE (the pieces of a shard whose
-// received blocks were checked): the same fold; 4 / 5 = pieces of which one holds 4-byte keys (5: all UPDATE); 6 / 7 = pieces
+// received blocks were checked): the same fold; 4 / 5 = pieces of which one holds 4-byte keys (5: all UPDATE -- the others' packed keys are narrowed to
+// 4-byte ones as they are loaded and the kernel is the 4-byte-key one: it is bound by the instructions it issues, and decoding
+// packed keys was a tenth of them); 6 / 7 = pieces
 // that ALL hold 4-byte keys of the kind a.kind32 (a producer's batch and the tail behind it; 7: UPDATE)
 // SMALL: segments of at most 3072 entries (6 per thread) over at most 256 columns, no radix tier: 51 KiB of LDS instead
 // of 74, i.e. THREE workgroups per CU (measured at 256^3: one workgroup per CU 2.70 ms, two 1.70 ms, three 1.48 ms).
@@ -1395,8 +1397,11 @@ template <bool FRESH, bool PIECES, bool BIG, int KEYS, bool SMALL = false, bool 
 __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     static_assert(!GRP || (!PIECES && !BIG && !SMALL), "the group-tier kernel exists for the plain regular form only");
     static_assert(!SHORTG || GRP, "SHORTG is a form of the group-tier kernel");
-    constexpr bool K32 = KEYS == 1 || KEYS == 2 || KEYS == 6 || KEYS == 7, UPD = KEYS == 2 || KEYS == 3 || KEYS == 5 || KEYS == 7,
-                   P32 = KEYS == 4 || KEYS == 5;
+    // (MIX = KEYS 5: every entry is an UPDATE, so the packed keys of the other pieces are narrowed to the 4-byte form as they are
+    // loaded -- the bits below the segment's prefix, checked against the segment there -- and the kernel is the 4-byte-key one)
+    constexpr bool MIX = KEYS == 5;
+    constexpr bool K32 = KEYS == 1 || KEYS == 2 || KEYS == 6 || KEYS == 7 || MIX, UPD = KEYS == 2 || KEYS == 3 || KEYS == 5 || KEYS == 7,
+                   P32 = KEYS == 4;
     static_assert(PIECES == (KEYS >= 3) || KEYS == 0, "KEYS 3 .. 7 are piece formats, 1 / 2 are not");
     constexpr int NI = SMALL ? 6 : ITEMS;
     constexpr int CAPK = THREADS * NI;
@@ -1437,6 +1442,23 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     const int WIN = 64 >> fb;
     const i64 w0 = max((i64)0, a.first + (i64)blockIdx.x - WIN / 2);
     if (!PIECES && t <= ((WIN + 1) << fb) && (w0 << fb) + t <= ((i64)a.S << fb)) s_win[t] = a.seg_start[(w0 << fb) + t];
+    // (pieces: the same window over every source's row of piece starts -- WINP + 1 bounds per source in the 96 words -- and the
+    // sources' array addresses, which do not depend on the ticket at all)
+    const int WINP = PIECES ? min(64, 96 / max(a.npieces, 1) - 1) : 0;
+    const i64 wp0 = max((i64)0, a.first + (i64)blockIdx.x - WINP / 2);
+    __shared__ const u64 *p_k[PIECES ? MAX_PIECES : 1];
+    __shared__ const double *p_v[PIECES ? MAX_PIECES : 1];
+    if constexpr (PIECES) {
+        if (WINP >= 4 && t < a.npieces * (WINP + 1)) {
+            const int q = t / (WINP + 1), j = t - q * (WINP + 1);
+            if (wp0 + j <= (i64)a.S) s_win[t] = a.pstart[(size_t)q * (size_t)(a.S + 1) + (size_t)(wp0 + j)];
+        }
+        if (t >= THREADS - 2 * MAX_PIECES) {  // (the last two waves: the first ones fetch the window)
+            const int q = t - (THREADS - 2 * MAX_PIECES);
+            if (q < a.npieces) p_k[q] = static_cast<const u64 *>(a.ptab[q]);
+            if (q >= MAX_PIECES && q - MAX_PIECES < a.npieces) p_v[q - MAX_PIECES] = static_cast<const double *>(a.ptab[a.npieces + q - MAX_PIECES]);
+        }
+    }
     if (t == 0) {
         s_seg = (int)atomicAdd(a.ticket, 1u);
         s_early = 0;
@@ -1452,6 +1474,7 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
     u64 k[NI];
     double vraw[NI];
     u64 hi;
+    u64 bad = 0;
     int n;
     if constexpr (!PIECES) {
         const bool inwin = s >= w0 && (i64)s + 1 <= w0 + WIN + 1;
@@ -1490,35 +1513,40 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
         // the segment's pieces, one per source rank (most segments of a slab-wise assembly have one)
         __shared__ i64 p_beg[MAX_PIECES];
         __shared__ int p_pre[MAX_PIECES + 1];
-        __shared__ const u64 *p_k[MAX_PIECES];
-        __shared__ const double *p_v[MAX_PIECES];
-        __shared__ int p_single;
-        if (w == 0) {
-            int len = 0;
-            if (lane < a.npieces) {
-                const i64 b = a.pstart[(size_t)lane * (size_t)(a.S + 1) + (size_t)s];
-                len = (int)(a.pstart[(size_t)lane * (size_t)(a.S + 1) + (size_t)s + 1] - b);
-                p_beg[lane] = b;
-                p_k[lane] = static_cast<const u64 *>(a.ptab[lane]);
-                p_v[lane] = static_cast<const double *>(a.ptab[a.npieces + lane]);
-            }
-            int inc = len;
-#pragma unroll
-            for (int dlt = 1; dlt < ESP_WAVE; dlt <<= 1) {
-                const int o = __shfl_up(inc, dlt, ESP_WAVE);
-                if (lane >= dlt) inc += o;
-            }
-            if (lane < a.npieces) p_pre[lane] = inc - len;
-            if (lane == 63) p_pre[a.npieces] = inc;
-            const u64 nonempty = __ballot(len > 0);
-            if (lane == 0) p_single = __popcll(nonempty) == 1 ? __builtin_ctzll(nonempty) : -1;
+        // (every wave looks at the piece bounds itself: a segment with ONE non-empty piece -- all of them but those along a range
+        // boundary -- needs no table in LDS, no scan and no second barrier; the test is the same in every wave)
+        int len = 0;
+        i64 pb0 = 0;
+        if ((w == 0 || !a.pieces_dense) && lane < a.npieces) {
+            const bool inwin = WINP >= 4 && s >= wp0 && (i64)s + 1 <= wp0 + WINP;
+            const int at = lane * (WINP + 1) + (int)(s - wp0);
+            pb0 = inwin ? s_win[at] : a.pstart[(size_t)lane * (size_t)(a.S + 1) + (size_t)s];
+            len = (int)((inwin ? s_win[at + 1] : a.pstart[(size_t)lane * (size_t)(a.S + 1) + (size_t)s + 1]) - pb0);
         }
-        __syncthreads();
-        n = p_pre[a.npieces];
+        const u64 nonempty = a.pieces_dense ? 0ull : __ballot(len > 0);
+        const int single = __popcll(nonempty) == 1 ? (int)__builtin_ctzll(nonempty) : -1;
+        i64 beg1 = 0;
+        if (single >= 0) {
+            n = esp_uniform_i32(__shfl(len, single, ESP_WAVE));
+            beg1 = esp_uniform_i64(__shfl(pb0, single, ESP_WAVE));
+        } else {
+            if (w == 0) {
+                if (lane < a.npieces) p_beg[lane] = pb0;
+                int inc = len;
+#pragma unroll
+                for (int dlt = 1; dlt < ESP_WAVE; dlt <<= 1) {
+                    const int o = __shfl_up(inc, dlt, ESP_WAVE);
+                    if (lane >= dlt) inc += o;
+                }
+                if (lane < a.npieces) p_pre[lane] = inc - len;
+                if (lane == 63) p_pre[a.npieces] = inc;
+            }
+            __syncthreads();
+            n = p_pre[a.npieces];
+        }
         n = min(n, CAPK);  // (the host checked the merged length; never index past the LDS arrays)
         hi = ((u64)s << a.rem_bits) + a.base;
         const int nlast = n > 0 ? n - 1 : 0;
-        const int single = p_single;
         // P32: piece a.k32_piece holds 4-byte keys -- the bits below the segment's prefix, kind a.kind32 (a shard's own
         // range, written by its producer) -- which become packed keys as they are loaded; the others are packed
         // (pointers read from a table are generic to the compiler: say that they are global memory, or every load of
@@ -1529,8 +1557,18 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
         if (single >= 0) {
             const g_u64 pk = (g_u64)p_k[single];
             const g_f64 pv = (g_f64)p_v[single];
-            const i64 beg = p_beg[single];
-            if constexpr (K32) {
+            const i64 beg = beg1;
+            const bool narrow = MIX && single != a.k32_piece;  // (packed keys that become 4-byte ones below)
+            if constexpr (MIX) {
+                if (narrow) {
+#pragma unroll
+                    for (int i = 0; i < NI; i++) k[i] = pk[beg + min(wbase + i * ESP_WAVE, nlast)];
+                } else {
+                    const g_u32 pk4 = (g_u32)(pk + a.k32_lo) + (a.k32_lo & 1) - a.k32_lo;  // (esprun::own_keys32)
+#pragma unroll
+                    for (int i = 0; i < NI; i++) k[i] = (u64)pk4[beg + min(wbase + i * ESP_WAVE, nlast)];
+                }
+            } else if constexpr (K32) {
                 const g_u32 pk4 = (g_u32)pk;
 #pragma unroll
                 for (int i = 0; i < NI; i++) k[i] = (u64)pk4[beg + min(wbase + i * ESP_WAVE, nlast)];
@@ -1546,6 +1584,16 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
             }
 #pragma unroll
             for (int i = 0; i < NI; i++) vraw[i] = pv[beg + min(wbase + i * ESP_WAVE, nlast)];
+            if constexpr (MIX) {
+                if (narrow && n > 0) {
+#pragma unroll
+                    for (int i = 0; i < NI; i++) {
+                        const u64 rel = (k[i] >> ESP_TAG_BITS) - hi;
+                        bad |= rel >> a.rem_bits;
+                        k[i] = rel & 0xFFFFFFFFull;
+                    }
+                }
+            }
         } else {
             g_u64 ak[NI];
             g_f64 av[NI];
@@ -1556,9 +1604,9 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
                 int q = 0;
                 while (q + 1 < a.npieces && p >= p_pre[q + 1]) q++;
                 const i64 at = p_beg[q] + (i64)(p - p_pre[q]);
-                k4[i] = P32 && q == a.k32_piece;
+                k4[i] = (P32 || MIX) && q == a.k32_piece;
                 const g_u64 base_k = (g_u64)p_k[q];
-                if constexpr (K32)
+                if constexpr (K32 && !MIX)
                     ak[i] = (g_u64)((g_u32)base_k + at);
                 else
                     ak[i] = k4[i] ? (g_u64)((g_u32)(base_k + a.k32_lo) + ((a.k32_lo & 1) + at - a.k32_lo)) : base_k + at;
@@ -1568,15 +1616,25 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
             for (int i = 0; i < NI; i++) {
                 if (n <= 0)
                     k[i] = 0ull;
-                else if constexpr (K32)
+                else if constexpr (K32 && !MIX)
                     k[i] = (u64) * (g_u32)ak[i];
                 else if (k4[i])
-                    k[i] = ((hi + (u64) * (g_u32)ak[i]) << ESP_TAG_BITS) | (u64)a.kind32;
+                    k[i] = MIX ? (u64) * (g_u32)ak[i] : ((hi + (u64) * (g_u32)ak[i]) << ESP_TAG_BITS) | (u64)a.kind32;
                 else
                     k[i] = *ak[i];
             }
 #pragma unroll
             for (int i = 0; i < NI; i++) vraw[i] = n > 0 ? *av[i] : 0.0;
+            if constexpr (MIX) {
+                if (n > 0) {
+#pragma unroll
+                    for (int i = 0; i < NI; i++) {
+                        const u64 rel = (k[i] >> ESP_TAG_BITS) - hi;
+                        bad |= k4[i] ? 0ull : rel >> a.rem_bits;
+                        k[i] = k4[i] ? k[i] : rel & 0xFFFFFFFFull;
+                    }
+                }
+            }
         }
     }
     const u64 hi4 = hi << ESP_TAG_BITS;  // the segment's prefix as it sits in a packed key
@@ -1598,7 +1656,6 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
         }
     }
     // branch-free: slots past the end hold a copy of the last entry (clamped loads) and become NOREC
-    u64 bad = 0;
     const u64 relmask = (((u64)1 << (a.rem_bits + ESP_TAG_BITS - 1)) << 1) - 1ull;  // (rem_bits + 2 may be 64)
 #pragma unroll
     for (int i = 0; i < NI; i++) {

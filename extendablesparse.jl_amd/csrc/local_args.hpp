@@ -60,6 +60,8 @@ struct Args {
     int npieces;
     const i64 *pstart;
     const void *const *ptab;
+    int pieces_dense;  // most segments hold entries of several pieces: their table goes through LDS at once (else every wave first looks
+                       // whether the segment has ONE non-empty piece -- a shard's usual segment -- and then needs neither table nor barrier)
     u32 *maxrun_seen;  // longest column run any segment of this flush met (atomicMax)
     // FRESH kernels on whole-column segments that cover the flush's column range: the segment writes colptr (1-based)
     // for its own columns itself -- no column-end marks, no scan over the columns afterwards (nullptr: marks in colend)

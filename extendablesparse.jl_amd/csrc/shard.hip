@@ -205,49 +205,147 @@ __global__ void diff_counts_k(const i64 *__restrict__ bstart, i64 NB, i64 *__res
     if (i < NB) cnt[i] = bstart[i + 1] - bstart[i];
 }
 
-// one workgroup per source q: pstart[q][0..nb] = exclusive scan of that source's per-digit counts
-// (q == me: the bucket starts of the own range -- absolute positions in the partitioned buffer -- which the host
-// copies into the row with a device-to-device copy; the workgroup only writes the summary)
+// esp_shard_assemble's ONE launch.  Workgroups [0, P): source q's row of piece starts, pstart[q][0 .. nb] = exclusive scan of
+// its per-digit counts; workgroups [P, P + G): the merged length of 1024 segments each (straight from the counts: no scan
+// needed), their longest one and whether a length is negative -- and their part of row `me`, a copy of the bucket starts of
+// the own range (absolute positions in the partitioned buffer).  Workgroup 0 also stores the pointer table the bucket kernel reads.  The
+// workgroup that finishes last (a ticket that it sets back to zero) gathers the partial results and writes them to PINNED
+// host memory: the host reads them behind the launch, without a copy.  (Round 5 ran this as a pointer-table upload, two
+// memsets, a device-to-device copy, two kernels and two downloads.)
+struct AsmArgs {
+    const void *tab[192];    // keys | values (from P) | counts (from 128) of every source
+    const void **T;          // device copy of tab
+    const i64 *own_bstart;   // own range of the bucket starts (nb + 1)
+    i64 *pstart;             // P rows of nb + 1
+    unsigned long long *work;  // [0] ticket | [8, 8 + P + 1) summary | [80, 80 + G) longest segment of a workgroup | [80 + G, 80 + 2 G) negative lengths
+    const unsigned long long *other;  // kinds_check_k's flag (nullptr: no received block was looked at)
+    unsigned long long *host;  // pinned: [0] seq | [1] longest merged segment | [2] negative lengths | [3] other kinds | [4, 4 + P + 1) summary
+    unsigned long long seq;
+    i64 nb;
+    int P, me, G;
+};
+constexpr int ASM_WORK_WORDS = 80 + 2 * 1024;  // (G <= 1024: at most 2^20 digits per shard)
 // summary[q] = entries of source q (q == me: of the own range), summary[P] = start of the own range
-__global__ __launch_bounds__(1024) void piece_scan_k(const i64 *const *__restrict__ counts, const i64 *__restrict__ own_bstart, int me,
-                                                     i64 nb, i64 *__restrict__ pstart, i64 *__restrict__ summary) {
+__global__ __launch_bounds__(1024) void assemble_k(AsmArgs a) {
     __shared__ i64 lw[2][16];
-    const int q = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
-    i64 *out = pstart + (size_t)q * (size_t)(nb + 1);
-    if (q == me) {
+    __shared__ u32 s_last;
+    const int b = blockIdx.x, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const i64 nb = a.nb;
+    unsigned long long *summary = a.work + 8;
+    auto put = [](unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    auto get = [](const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); };
+    if (b == 0 && t < 192) a.T[t] = a.tab[t];
+    if (b < a.P) {
+        const int q = b;
+        i64 *out = a.pstart + (size_t)q * (size_t)(nb + 1);
+        if (q == a.me) {  // (the row itself is copied by the workgroups below, 1024 digits each: one workgroup would take 50 us for 2^16)
+            if (t == 0) {
+                put(&summary[q], (unsigned long long)(a.own_bstart[nb] - a.own_bstart[0]));
+                put(&summary[a.P], (unsigned long long)a.own_bstart[0]);
+            }
+        } else {
+            const i64 *c = static_cast<const i64 *>(a.tab[128 + q]);
+            i64 carry = 0;  // (the same in every thread: all of them add up the 16 wave totals of a round)
+            int buf = 0;
+            for (i64 b0 = 0; b0 < nb; b0 += 1024, buf ^= 1) {
+                const i64 d = b0 + t;
+                const i64 x = d < nb ? c[d] : 0;
+                i64 inc = x;
+#pragma unroll
+                for (int dlt = 1; dlt < 64; dlt <<= 1) {
+                    const i64 o = __shfl_up(inc, dlt, 64);
+                    if (lane >= dlt) inc += o;
+                }
+                if (lane == 63) lw[buf][w] = inc;
+                __syncthreads();  // (one barrier per round: the wave totals alternate between two buffers)
+                i64 pre = carry, tot = 0;
+#pragma unroll
+                for (int i = 0; i < 16; i++) {
+                    const i64 v = lw[buf][i];
+                    pre += i < w ? v : 0;
+                    tot += v;
+                }
+                if (d < nb) out[d] = pre + inc - x;
+                carry += tot;
+            }
+            if (t == 0) {
+                out[nb] = carry;
+                put(&summary[q], (unsigned long long)carry);
+            }
+        }
+    } else {
+        const i64 d = (i64)(b - a.P) * 1024 + t;
+        i64 tot = 0;
+        bool neg = false;
+        if (d < nb) {
+            const i64 o0 = a.own_bstart[d], o1 = a.own_bstart[d + 1];
+            i64 *own_row = a.pstart + (size_t)a.me * (size_t)(nb + 1);
+            own_row[d] = o0;
+            if (d == nb - 1) own_row[nb] = o1;
+            for (int q = 0; q < a.P; q++) {
+                const i64 len = q == a.me ? o1 - o0 : static_cast<const i64 *>(a.tab[128 + q])[d];
+                neg |= len < 0;
+                tot += len;
+            }
+        }
+#pragma unroll
+        for (int o = 32; o; o >>= 1) {
+            const i64 x = __shfl_xor(tot, o, 64);
+            tot = x > tot ? x : tot;
+        }
+        const u64 negs = __ballot(neg);
+        if (lane == 0) {
+            lw[0][w] = tot;
+            lw[1][w] = (i64)__popcll(negs);
+        }
+        __syncthreads();
         if (t == 0) {
-            summary[q] = own_bstart[nb] - own_bstart[0];
-            summary[gridDim.x] = own_bstart[0];
+            i64 mx = 0, ng = 0;
+            for (int i = 0; i < 16; i++) {
+                mx = lw[0][i] > mx ? lw[0][i] : mx;
+                ng += lw[1][i];
+            }
+            put(&a.work[80 + (b - a.P)], (unsigned long long)mx);
+            put(&a.work[80 + a.G + (b - a.P)], (unsigned long long)ng);
         }
-        return;
     }
-    const i64 *c = counts[q];
-    i64 carry = 0;  // (the same in every thread: all of them add up the 16 wave totals of a round)
-    int buf = 0;
-    for (i64 b0 = 0; b0 < nb; b0 += 1024, buf ^= 1) {
-        const i64 d = b0 + t;
-        const i64 x = d < nb ? c[d] : 0;
-        i64 inc = x;
-#pragma unroll
-        for (int dlt = 1; dlt < 64; dlt <<= 1) {
-            const i64 o = __shfl_up(inc, dlt, 64);
-            if (lane >= dlt) inc += o;
-        }
-        if (lane == 63) lw[buf][w] = inc;
-        __syncthreads();  // (one barrier per round: the wave totals alternate between two buffers)
-        i64 pre = carry, tot = 0;
-#pragma unroll
-        for (int i = 0; i < 16; i++) {
-            const i64 v = lw[buf][i];
-            pre += i < w ? v : 0;
-            tot += v;
-        }
-        if (d < nb) out[d] = pre + inc - x;
-        carry += tot;
+    // ---- the workgroup that finishes last publishes
+    __threadfence();
+    __syncthreads();
+    if (t == 0) s_last = atomicAdd(a.work, 1ull) == (unsigned long long)(gridDim.x - 1) ? 1u : 0u;
+    __syncthreads();
+    if (!s_last) return;
+    __threadfence();
+    i64 mx = 0, ng = 0;
+    for (int i = t; i < a.G; i += 1024) {
+        const i64 v = (i64)get(&a.work[80 + i]);
+        mx = v > mx ? v : mx;
+        ng += (i64)get(&a.work[80 + a.G + i]);
     }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const i64 x = __shfl_xor(mx, o, 64);
+        mx = x > mx ? x : mx;
+        ng += __shfl_xor(ng, o, 64);
+    }
+    if (lane == 0) {
+        lw[0][w] = mx;
+        lw[1][w] = ng;
+    }
+    __syncthreads();
+    auto host_put = [](unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); };
+    if (t <= a.P) host_put(&a.host[4 + t], get(&summary[t]));
     if (t == 0) {
-        out[nb] = carry;
-        summary[q] = carry;
+        mx = 0, ng = 0;
+        for (int i = 0; i < 16; i++) {
+            mx = lw[0][i] > mx ? lw[0][i] : mx;
+            ng += lw[1][i];
+        }
+        host_put(&a.host[1], (unsigned long long)mx);
+        host_put(&a.host[2], (unsigned long long)ng);
+        host_put(&a.host[3], a.other ? *a.other : 0ull);
+        host_put(&a.host[0], a.seq);  // (the host reads behind the launch: a block that still holds another launch's number is an error)
+        put(a.work, 0ull);  // (the ticket, for the next launch)
     }
 }
 
@@ -258,7 +356,7 @@ __global__ void kinds_check_k(const u64 *__restrict__ keys, i64 count, unsigned 
     if (__ballot(bad) != 0ull && (threadIdx.x & 63) == 0) atomicOr(other, 1ull);
 }
 
-// merged length of every segment; longest one
+// merged length of every segment; longest one (a batch and its tail, a stored slice and its new entries, Base.sum: flush.hip, sum.hip)
 __global__ void piece_totals_k(const i64 *__restrict__ pstart, int P, i64 nb, unsigned long long *__restrict__ maxlen,
                                unsigned long long *__restrict__ negative) {
     const i64 d = (i64)blockIdx.x * blockDim.x + threadIdx.x;
@@ -420,51 +518,70 @@ extern "C" int32_t esp_shard_assemble(esp_handle *h, const uint64_t *const *d_re
     const int P = h->part_P, me = h->part_me;
     const i64 nb = (i64)h->part_nb;
     const i64 *bstart = (const i64 *)h->seg[1].p + (size_t)me * (size_t)nb;  // own range of the bucket starts
-    // pointer table (keys | values | counts of every source) | summary | piece starts
-    const size_t o_sum = 192 * 8, o_ps = 256 * 8;
+    // pointer table (keys | values | counts of every source) | piece starts
+    const size_t o_ps = 256 * 8;
     CK(ensure(h, h->piecetab, o_ps + sizeof(i64) * (size_t)P * (size_t)(nb + 1)));
     char *T = (char *)h->piecetab.p;
-    std::vector<const void *> tab(192, nullptr);
+    AsmArgs aa;
+    memset(&aa, 0, sizeof aa);
     i64 total_recv = 0;
+    bool look = false;
     for (int q = 0; q < P; q++) {
         if (q == me) {
-            tab[(size_t)q] = h->keys.p;
-            tab[(size_t)P + q] = h->vals.p;
+            aa.tab[(size_t)q] = h->keys.p;
+            aa.tab[(size_t)P + q] = h->vals.p;
         } else {
             if (recv_entries[q] < 0 || (recv_entries[q] > 0 && (!d_recv_keys[q] || !d_recv_vals[q])) || !d_recv_counts[q])
                 FAIL(h, ESP_ERR_INVALID, "esp_shard_assemble: received block %d", q);
-            tab[(size_t)q] = d_recv_keys[q];
-            tab[(size_t)P + q] = d_recv_vals[q];
-            tab[128 + (size_t)q] = d_recv_counts[q];
+            aa.tab[(size_t)q] = d_recv_keys[q];
+            aa.tab[(size_t)P + q] = d_recv_vals[q];
+            aa.tab[128 + (size_t)q] = d_recv_counts[q];
             total_recv += recv_entries[q];
+            look |= h->part_own_update && recv_entries[q] > 0;
         }
     }
-    HIPCK(h, hipMemcpyAsync(T, tab.data(), 192 * 8, hipMemcpyHostToDevice, h->stream));
     i64 *pstart = (i64 *)(T + o_ps);
-    i64 *d_sum = (i64 *)(T + o_sum);
     CK(ensure(h, h->misc, 256));
-    unsigned long long *d_maxlen = (unsigned long long *)h->misc.p + 24;
-    HIPCK(h, hipMemsetAsync(d_maxlen, 0, 24, h->stream));
+    unsigned long long *d_other = (unsigned long long *)h->misc.p + 26;
+    if (!h->pin_asm) HIPCK(h, hipHostMalloc((void **)&h->pin_asm, sizeof(unsigned long long) * 80, hipHostMallocDefault));
+    if (h->asmwork.bytes == 0) {  // (the ticket starts at zero and every launch leaves it there)
+        CK(ensure(h, h->asmwork, sizeof(unsigned long long) * (size_t)ASM_WORK_WORDS));
+        HIPCK(h, hipMemsetAsync(h->asmwork.p, 0, sizeof(unsigned long long) * (size_t)ASM_WORK_WORDS, h->stream));
+    }
+    const int G = (int)grid_for(nb, 1024);
+    if (G > 1024) FAIL(h, ESP_ERR_UNSUPPORTED, "esp_shard_assemble: %lld digits per shard", (long long)nb);
     {
         Span sp(h, ESP_ST_SCAN);
-        if (h->part_own_update)  // (the received blocks are the cross-shard pairs only: a few launches over little data)
+        if (look) {  // (the received blocks are the cross-shard pairs only: a few launches over little data)
+            HIPCK(h, hipMemsetAsync(d_other, 0, 8, h->stream));
             for (int q = 0; q < P; q++)
                 if (q != me && recv_entries[q] > 0) {
                     hipLaunchKernelGGL(kinds_check_k, dim3(grid_for(recv_entries[q], 256)), dim3(256), 0, h->stream, (const u64 *)d_recv_keys[q],
-                                       (i64)recv_entries[q], d_maxlen + 2);
+                                       (i64)recv_entries[q], d_other);
                     sp.add(1);
                 }
-        HIPCK(h, hipMemcpyAsync(pstart + (size_t)me * (size_t)(nb + 1), bstart, sizeof(i64) * (size_t)(nb + 1), hipMemcpyDeviceToDevice, h->stream));
-        hipLaunchKernelGGL(piece_scan_k, dim3((unsigned)P), dim3(1024), 0, h->stream, (const i64 *const *)(T + 128 * 8), bstart, me, nb, pstart, d_sum);
-        hipLaunchKernelGGL(piece_totals_k, dim3(grid_for(nb, 256)), dim3(256), 0, h->stream, (const i64 *)pstart, P, nb, d_maxlen, d_maxlen + 1);
-        sp.add(2);
+        }
+        aa.T = (const void **)T;
+        aa.own_bstart = bstart;
+        aa.pstart = pstart;
+        aa.work = (unsigned long long *)h->asmwork.p;
+        aa.other = look ? d_other : nullptr;
+        aa.host = h->pin_asm;
+        aa.seq = ++h->asm_seq;
+        aa.nb = nb;
+        aa.P = P, aa.me = me, aa.G = G;
+        hipLaunchKernelGGL(assemble_k, dim3((unsigned)(P + G)), dim3(1024), 0, h->stream, aa);
+        sp.add(1);
     }
-    std::vector<i64> last((size_t)P + 1);
-    HIPCK(h, hipMemcpyAsync(last.data(), d_sum, sizeof(i64) * (size_t)(P + 1), hipMemcpyDeviceToHost, h->stream));
-    unsigned long long mx[3];
-    HIPCK(h, hipMemcpyAsync(mx, d_maxlen, 24, hipMemcpyDeviceToHost, h->stream));
     HIPCK(h, hipStreamSynchronize(h->stream));
     HIPCK(h, hipGetLastError());
+    if (h->pin_asm[0] != aa.seq) {
+        (void)hipMemsetAsync(h->asmwork.p, 0, 8, h->stream);
+        FAIL(h, ESP_ERR_STATE, "esp_shard_assemble: internal error (the table kernel did not publish its results)");
+    }
+    const unsigned long long mx[3] = {h->pin_asm[1], h->pin_asm[2], h->pin_asm[3]};
+    std::vector<i64> last((size_t)P + 1);
+    for (int q = 0; q <= P; q++) last[(size_t)q] = (i64)h->pin_asm[4 + q];
     for (int q = 0; q < P; q++)
         if (q != me && last[(size_t)q] != recv_entries[q])
             FAIL(h, ESP_ERR_STATE, "esp_shard_assemble: block from shard %d holds %lld entries, its digit counts sum to %lld", q,

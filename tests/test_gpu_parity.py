@@ -2743,6 +2743,10 @@ def _group_ranks_run(esp, orc, world, deal, n=44, rounds=3):
                 # from the second assembly on the generator partitions by (owner, digit) itself (esp_shard_plan, set by
                 # the previous esp_group_flush): esp_shard_partition has nothing left to move
                 assert A.local.debug_last_shard_source() == (1 if rnd == 0 else 2), (rnd, A.local.debug_last_shard_source())
+                # ... its own range with 4-byte keys; the neighbours' packed keys are narrowed as the bucket kernel loads them
+                # (every entry is an UPDATE: the 4-byte-key kernel with the UPDATE-only fold, local.hpp KEYS 5)
+                if rnd > 0:
+                    assert A.local.debug_last_key_bytes() == 4 and A.local.debug_last_fold_update(), (rnd, A.local.debug_last_key_bytes())
         total = A.nnz()
         piece = A.local_slice()
         lo, hi = A.column_range()

@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B of library builds (ab/lib_X.so) on bench.py's extra configs: ESP_EXTRA_ONLY=cfg2|cfg3|cfg4 tools/ab_cfg.sh X Y
+# A/B of library builds (ab/lib_X.so) on bench.py's extra configs: [ESP_AB_STEPS=n] ESP_EXTRA_ONLY=cfg2|cfg3|cfg4 tools/ab_cfg.sh X Y
 for rep in 1 2; do
   for v in "$@"; do
     cp ab/lib_$v.so extendablesparse.jl_amd/libesparse_hip.so
-    ESP_BENCH_SKIP_TRIPLETS=1 ESP_BENCH_SKIP_HOST=1 timeout 900 python tools/r4_extra.py 2>/dev/null | python -c "
+    ESP_BENCH_SKIP_TRIPLETS=1 ESP_BENCH_SKIP_HOST=1 timeout 900 python tools/r4_extra.py ${ESP_AB_STEPS:-3} 2>/dev/null | python -c "
 import sys,json
 for l in sys.stdin:
     l=l.strip()
