@@ -94,7 +94,19 @@ struct esp_handle {
         u32 mw_nb = 0;
         i64 mw_eps = 0;
         bool own32 = false;      // ... and the shard's OWN range holds 4-byte keys of kind `kind` (the sent ranges: packed)
+        u64 plan_id = 0;         // ... the table build it came from (prepart_finish numbers them; a reused plan keeps its number)
     } pre;
+    u64 plan_counter = 0;
+    // esp_shard_partition over a producer's batch whose plan was REUSED: the owner ranges and per-digit counts are those of the
+    // call that built the tables -- kept, so that nothing runs beside the PART launch (a second queue with three tiny operations
+    // cost that launch 90 us of 500: NOTES/round6.md section 7)
+    struct ShardOffsets {
+        u64 plan_id = 0;
+        int P = 0, me = 0;
+        i64 eps = 0, NB = 0, E = 0;
+        const void *cnt_at = nullptr;
+        std::vector<i64> off;
+    } shard_offsets;
     bool pre_keep = false;       // reserve_append: the append that follows goes behind the bucket-ordered batch
     // A batch of an item partition whose EXPANSION has not run (group3_items.hpp): `pre` describes it as if its updates lay
     // bucket by bucket in keys / vals -- they do not yet: the sorted item records lie in the keys array (the two ping-pong

@@ -387,6 +387,7 @@ int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took) {
     pp.mw_nb = ps->mw_nb;
     pp.mw_eps = ps->mw_eps;
     pp.own32 = ps->out.own32 != 0;
+    pp.plan_id = ++h->plan_counter;
     *took = true;  // (the caller sets pre.valid once the entries are counted in)
     return ESP_OK;
 }

@@ -485,14 +485,28 @@ extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t s
     // returns while the entries are still being moved -- the caller's consensus round runs beside the scatter
     // kernel; esp_synchronize() before the key/value arrays are read.
     // (a producer's batch: the bucket starts were final behind ITS ranking kernel, the PART launch may still run)
-    hipStream_t qs = (E > 0 && (h->last_run_order == 1 || from_producer) && h->aux && h->aux_ev) ? h->aux : h->stream;
-    if (qs == h->aux) HIPCK(h, hipStreamWaitEvent(h->aux, h->aux_ev, 0));  // (recorded right behind the ranking kernel)
-    hipLaunchKernelGGL(diff_counts_k, dim3(grid_for(NB, 256)), dim3(256), 0, qs, (const i64 *)bstart, NB, cnt);
-    // owner ranges = bucket starts at every multiple of nb
-    i64 *d_off = (i64 *)(T + 64 * 8);
-    hipLaunchKernelGGL(gather_stride_k, dim3(1), dim3(128), 0, qs, (const i64 *)bstart, (i64)nb64, P + 1, d_off);
-    HIPCK(h, hipMemcpyAsync(off.data(), d_off, sizeof(i64) * (size_t)(P + 1), hipMemcpyDeviceToHost, qs));
-    HIPCK(h, hipStreamSynchronize(qs));
+    // (a producer's batch over a REUSED plan: the tables are those of the call that built them, and so are the counts and
+    // the owner ranges this call derived from them then -- nothing to launch, nothing to wait for)
+    esp_handle::ShardOffsets &so = h->shard_offsets;
+    const bool kept = from_producer && h->pre.plan_id != 0 && so.plan_id == h->pre.plan_id && so.P == P && so.me == self &&
+                      so.eps == entries_per_shard && so.NB == NB && so.E == E && so.cnt_at == (const void *)cnt &&
+                      (int)so.off.size() == P + 1 && h->force_path == ESP_PATH_AUTO;
+    if (kept) {
+        off = so.off;
+    } else {
+        hipStream_t qs = (E > 0 && (h->last_run_order == 1 || from_producer) && h->aux && h->aux_ev) ? h->aux : h->stream;
+        if (qs == h->aux) HIPCK(h, hipStreamWaitEvent(h->aux, h->aux_ev, 0));  // (recorded right behind the ranking kernel)
+        hipLaunchKernelGGL(diff_counts_k, dim3(grid_for(NB, 256)), dim3(256), 0, qs, (const i64 *)bstart, NB, cnt);
+        // owner ranges = bucket starts at every multiple of nb
+        i64 *d_off = (i64 *)(T + 64 * 8);
+        hipLaunchKernelGGL(gather_stride_k, dim3(1), dim3(128), 0, qs, (const i64 *)bstart, (i64)nb64, P + 1, d_off);
+        HIPCK(h, hipMemcpyAsync(off.data(), d_off, sizeof(i64) * (size_t)(P + 1), hipMemcpyDeviceToHost, qs));
+        HIPCK(h, hipStreamSynchronize(qs));
+        so.plan_id = from_producer ? h->pre.plan_id : 0;  // (0: the tables of this call are nobody's plan)
+        so.P = P, so.me = self, so.eps = entries_per_shard, so.NB = NB, so.E = E;
+        so.cnt_at = cnt;
+        so.off = off;
+    }
     for (int r = 0; r <= P; r++) entry_offsets[r] = off[(size_t)r];
     *digits_per_shard = (int64_t)nb64;
     *d_keys = (uint64_t *)h->keys.p;
