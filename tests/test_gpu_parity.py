@@ -3010,6 +3010,52 @@ def test_no_append_between_shard_assemble_and_flush(esp, orc):
     assert_csc_equal(hip_arrays(A), O.arrays())
 
 
+@pytest.mark.parametrize("self_rank", [0, 63])
+def test_shard_assemble_with_64_shards(esp, orc, self_rank):
+    """The most shards the partitioned exchange takes (64): one handle plays shard `self_rank`, nothing arrives from the
+    others (their ranges are sent and dropped here), the local flush must give the oracle's columns of that shard bit for bit.
+    (Round 6: the table kernel's summary -- entries per source, start of the own range -- has P + 1 words; with 64 shards the
+    last one used to be the same word as the first piece start.)"""
+    import ctypes as C
+    import torch
+    n = 128          # (64 columns per digit: a chunk of the stencil's stream stays within the run limit of the run-based partition)
+    N = n ** 3
+    P = 64
+    A = esp.ExtendableSparseMatrix(N, N)
+    d = A._d
+    I, J, V = orc.fdrand_stream(n, n, n, rand_mode=1, seed=21)
+    A.append(UPDATE, I, J, V)
+    E = len(I)
+    c0, c1 = esp.owner_ranges(N, P)[self_rank]
+    d.ck(d.lib.esp_set_column_window(d.h, c0 + 1, c1))
+    ok = C.c_int32()
+    pk, pv, pc = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    eoff = np.zeros(P + 1, np.int64)
+    nb = C.c_int64()
+    # (entries_per_shard is the planning hint every rank passes alike: 10^6 makes the plan 512 digits per shard at a size the
+    # oracle follows -- the partitioned exchange declines problems below 2^8 segments per shard)
+    d.ck(d.lib.esp_shard_partition(d.h, P, self_rank, 1000000, C.byref(ok), C.byref(pk), C.byref(pv), C.byref(pc),
+                                   eoff.ctypes.data_as(C.c_void_p), C.byref(nb)))
+    assert ok.value == 1, "the plan declined: the case does not reach esp_shard_assemble"
+    own = (J > c0) & (J <= c1)
+    assert eoff[self_rank + 1] - eoff[self_rank] == np.count_nonzero(own) and eoff[P] == E
+    if self_rank > 0:
+        assert eoff[self_rank] > 0        # (the start of the own range is not zero: the word that was shared)
+    zeros = torch.zeros(int(nb.value), dtype=torch.int64, device="cuda")
+    keys = (C.c_void_p * P)()
+    vals = (C.c_void_p * P)()
+    cnts = (C.c_void_p * P)(*[zeros.data_ptr()] * P)
+    ne = np.zeros(P, np.int64)
+    d.ck(d.lib.esp_shard_assemble(d.h, keys, vals, cnts, ne.ctypes.data_as(C.c_void_p), C.byref(ok)))
+    assert ok.value == 1
+    A.flush()
+    assert A.debug_last_partition() == 7
+    O = orc.ExtendableSparseMatrix(N, N)
+    O.apply(np.full(np.count_nonzero(own), UPDATE, np.uint8), I[own], J[own], V[own])
+    O.flush()
+    assert_csc_equal(hip_arrays(A), O.arrays())
+
+
 # ------------------------------------------------------------------ round 5: the field contract of the north-star type
 def test_cscmatrix_field_contract_and_host_edits(esp, orc):
     """`A.cscmatrix` right after `flush!` (how the reference's consumers read it: factorizations/ilu0.jl:126-136,
