@@ -215,7 +215,8 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
         a.k32_piece = st.p32_piece;
         a.k32_lo = st.p32_lo;
         h->last_key_bytes = (st.p32_piece >= 0 || st.all32) ? 4 : st.key_bytes;
-        a.fb = st.npieces == 0 && st.key_bytes == 4 ? st.fb : 0;
+        a.fb = ((st.npieces == 0 && st.key_bytes == 4) || (st.npieces > 0 && st.p32_piece >= 0 && st.own_fine)) ? st.fb : 0;
+        a.own_fine = a.fb > 0 ? st.own_fine : nullptr;
         a.colptr_out = direct ? (i64 *)h->colptr.p : nullptr;
         a.late_total = h->force_path == ESP_PATH_LATE_TOTAL ? 1 : 0;  // 36: test hook, group3_k publishes a segment's total after the fold
         a.no_group = h->force_path == ESP_PATH_NO_GROUP_TIER ? 1 : 0;  // 24: test hook, long column runs through the radix tier
@@ -991,6 +992,10 @@ extern "C" int32_t esp_flush(esp_handle *h, int32_t mode, int64_t *new_nnz, int3
             st.p32_piece = h->part_me;
             st.p32_lo = h->part_own_lo;
             st.kind = h->part_kind32;
+            if (h->part_fb > 0) {  // (the own range lies bucket by bucket of the producer's FINE partition)
+                st.fb = h->part_fb;
+                st.own_fine = (const i64 *)h->seg[1].p + (size_t)h->part_me * ((size_t)h->part_nb << h->part_fb);
+            }
         }
         CK(ensure(h, h->keys2, sizeof(u64) * (size_t)std::max<i64>(h->part_total, 1)));
         CK(ensure(h, h->vals2, sizeof(double) * (size_t)std::max<i64>(h->part_total, 1)));

@@ -282,6 +282,7 @@ struct esp_handle {
     u32 part_nb = 0;
     u64 part_base = 0, part_span = 0;
     i64 part_total = 0, part_maxlen = 0, part_own_lo = 0;
+    int part_fb = 0;              // the own range came from a producer's FINE partition: 2^part_fb buckets of seg[1] per digit
     DevBuf parttab, piecetab;
     DevBuf asmwork;                        // esp_shard_assemble's kernel: ticket | summary | per-workgroup partial results (zeroed once)
     unsigned long long *pin_asm = nullptr;  // ... and the pinned block its last workgroup writes the results to
@@ -399,6 +400,7 @@ struct Sorted {
     i64 p32_lo = 0;
     // PIECES (partitioned shard exchange): segments are concatenations of per-source pieces
     int npieces = 0;
+    const i64 *own_fine = nullptr;  // PIECES, fb > 0: the fine table of the piece p32_piece (local_args.hpp, Args::own_fine)
     bool pieces_dense = false;   // PIECES: most segments hold entries of several pieces (a batch and its tail, a stored slice and new entries)
     const i64 *pstart = nullptr;
     const void *const *ptab = nullptr;
@@ -438,6 +440,10 @@ struct MwPlan {
     int K = 0, shift = 0, pb = 0;
     u64 nb64 = 0;
     i64 NB = 0;
+    // FINE partition of a producer's batch (33 .. 36 key bits below the plan's prefix -- the shards of 512^3 over 8 GPUs: 35): the
+    // producer may cut every digit into 2^fb buckets (tables of NB << fb buckets, digit width 2^(shift - fb) = 2^32), so that its
+    // OWN range holds 4-byte keys; the exchange, the piece tables and the bucket kernel's segments stay the plan's digits
+    int fb = 0;
     std::vector<u64> base;
 };
 
@@ -618,6 +624,7 @@ static MwPlan shard_mw_plan(const esp_handle *h, int P, i64 entries_per_shard) {
     if (m.NB > ((i64)1 << 24)) return m;
     m.pb = 1;
     while (((i64)1 << m.pb) < m.NB) m.pb++;
+    if (m.shift > 32 && m.shift - 32 <= 4 && h->L.rb <= 32 && (m.NB << (m.shift - 32)) <= ((i64)1 << 24)) m.fb = m.shift - 32;
     m.ok = true;
     return m;
 }

@@ -1547,6 +1547,22 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
         n = min(n, CAPK);  // (the host checked the merged length; never index past the LDS arrays)
         hi = ((u64)s << a.rem_bits) + a.base;
         const int nlast = n > 0 ? n - 1 : 0;
+        // FINE partition of a shard's producer: the own piece lies bucket by bucket, 2^fb buckets per segment, and its 4-byte keys
+        // lack the bucket's number inside the segment (Args::fb, Args::own_fine) -- an entry's position in the piece tells it.
+        // Lane j of every wave: where bucket j starts, relative to the piece (requested here, used behind the loads).
+        const int pfb = (P32 || MIX) ? a.fb : 0;
+        u32 fine_rel = 0;
+        if (pfb > 0 && lane < (1 << pfb)) fine_rel = (u32)(a.own_fine[((i64)s << pfb) + lane] - a.own_fine[(i64)s << pfb]);
+        auto sub_bucket = [&](u32 prel) -> u64 {
+            u32 sub = 0;
+#pragma unroll
+            for (int j = 1; j < 16; j++) {
+                const u32 f = (u32)__builtin_amdgcn_readlane((int)fine_rel, j);
+                sub += (j < (1 << pfb) && prel >= f) ? 1u : 0u;
+            }
+            return (u64)sub;
+        };
+        const u64 lowmask = (((u64)1 << (a.rem_bits - 1)) << 1) - 1ull;
         // P32: piece a.k32_piece holds 4-byte keys -- the bits below the segment's prefix, kind a.kind32 (a shard's own
         // range, written by its producer) -- which become packed keys as they are loaded; the others are packed
         // (pointers read from a table are generic to the compiler: say that they are global memory, or every load of
@@ -1590,7 +1606,16 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
                     for (int i = 0; i < NI; i++) {
                         const u64 rel = (k[i] >> ESP_TAG_BITS) - hi;
                         bad |= rel >> a.rem_bits;
-                        k[i] = rel & 0xFFFFFFFFull;
+                        k[i] = rel & lowmask;
+                    }
+                }
+            }
+            if constexpr (P32 || MIX) {
+                if (pfb > 0 && single == a.k32_piece) {
+#pragma unroll
+                    for (int i = 0; i < NI; i++) {
+                        const u64 sub = sub_bucket((u32)min(wbase + i * ESP_WAVE, nlast));
+                        k[i] += MIX ? sub << 32 : sub << (32 + ESP_TAG_BITS);
                     }
                 }
             }
@@ -1598,12 +1623,14 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
             g_u64 ak[NI];
             g_f64 av[NI];
             bool k4[NI];
+            u32 prel4[NI];  // (position inside the piece: what tells an entry of the own piece its bucket)
 #pragma unroll
             for (int i = 0; i < NI; i++) {
                 const int p = min(wbase + i * ESP_WAVE, nlast);
                 int q = 0;
                 while (q + 1 < a.npieces && p >= p_pre[q + 1]) q++;
                 const i64 at = p_beg[q] + (i64)(p - p_pre[q]);
+                prel4[i] = (u32)(p - p_pre[q]);
                 k4[i] = (P32 || MIX) && q == a.k32_piece;
                 const g_u64 base_k = (g_u64)p_k[q];
                 if constexpr (K32 && !MIX)
@@ -1631,7 +1658,16 @@ __global__ __launch_bounds__(THREADS, SMALL ? 6 : 4) void local_k(Args a) {
                     for (int i = 0; i < NI; i++) {
                         const u64 rel = (k[i] >> ESP_TAG_BITS) - hi;
                         bad |= k4[i] ? 0ull : rel >> a.rem_bits;
-                        k[i] = k4[i] ? k[i] : rel & 0xFFFFFFFFull;
+                        k[i] = k4[i] ? k[i] : rel & lowmask;
+                    }
+                }
+            }
+            if constexpr (P32 || MIX) {
+                if (pfb > 0 && n > 0) {
+#pragma unroll
+                    for (int i = 0; i < NI; i++) {
+                        const u64 sub = k4[i] ? sub_bucket(prel4[i]) : 0ull;
+                        k[i] += MIX ? sub << 32 : sub << (32 + ESP_TAG_BITS);
                     }
                 }
             }

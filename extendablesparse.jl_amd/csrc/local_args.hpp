@@ -77,6 +77,8 @@ struct Args {
     int expect_hits;  // the host expects most positions to be stored already: a short stored column is fetched with its values
     int fb;           // K32 kernels: the segment table is 2^fb times finer than the segments (esp_handle::PrePart::fb): segment s =
                       // table entries [s << fb, (s + 1) << fb], and the 4-byte key of an entry lacks the bucket's number inside the segment
+                      // PIECES with a 4-byte-key piece (a shard's own range, KEYS 4 / 5): the same for THAT piece, whose fine table is
+    const i64 *own_fine;  // ... this one: 2^fb entries per segment (+ 1), absolute positions like the piece's row of pstart
     double *hits_out; // group3_k's re-assembly form (HITS): the new values of the stored positions (a second nzval array)
 };
 constexpr int MAX_PIECES = 64;

@@ -237,6 +237,11 @@ int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSetup *ps)
         mw = shard_mw_plan(h, P, h->shard_plan.eps);
         if (!mw.ok || mw.shift < h->L.rb) return ESP_OK;
         K = mw.K, pb = mw.pb, shift = mw.shift, NB = mw.NB;
+        // (FINE partition: 2^fb buckets per digit of the plan -- 4-byte keys for the own range; force_path 41 / 14: never)
+        if (mw.fb > 0 && kind >= 0 && h->force_path != ESP_PATH_NO_FINE_PARTITION && h->force_path != ESP_PATH_PACKED_KEYS) {
+            ps->fb = mw.fb;
+            pb += mw.fb, shift -= mw.fb, NB <<= mw.fb;
+        }
         const size_t o_cnt = 256 * 8;  // (the table layout of esp_shard_partition: window bases | owner offsets | counts)
         CK(ensure(h, h->parttab, o_cnt + sizeof(i64) * (size_t)(NB + 1)));
         // (the copy is asynchronous: its source lives in the handle, not in this function's frame -- and a flush that
@@ -288,8 +293,8 @@ int32_t prepart_begin(esp_handle *h, i64 E, i64 chunks, int kind, PartSetup *ps)
     if (mw.ok) {
         ps->mw_P = h->shard_plan.P;
         ps->mw_me = h->shard_plan.me;
-        ps->mw_shift = mw.shift;
-        ps->mw_nb = (u32)mw.nb64;
+        ps->mw_shift = shift;                        // (the tables' digits: the plan's, or 2^fb times finer)
+        ps->mw_nb = (u32)(mw.nb64 << ps->fb);
         ps->mw_eps = h->shard_plan.eps;
     }
     ps->seg_out = (i64 *)h->seg[1].p;
@@ -375,6 +380,7 @@ int32_t prepart_finish(esp_handle *h, PartSetup *ps, bool *took) {
     // (a fine partition whose joined segments outgrow the bucket kernel is flushed bucket by bucket, like any other batch)
     pp.maxlen_c = ps->fb > 0 ? (i64)h->pin_scalar[1] : 0;
     pp.fb = (ps->fb > 0 && ps->out.k32 && pp.maxlen_c <= (i64)esplocal::CAP) ? ps->fb : 0;
+    if (ps->mw_P > 0) pp.fb = ps->fb;  // (a shard: the plan's digits are what the exchange speaks, whatever their longest one is)
     pp.kind = ps->kind;
     pp.E = ps->E;
     pp.tail = 0;

@@ -200,9 +200,10 @@ __global__ void gather_stride_k(const i64 *__restrict__ src, i64 stride, int cou
     if (i < count) dst[i] = src[(size_t)i * (size_t)stride];
 }
 
-__global__ void diff_counts_k(const i64 *__restrict__ bstart, i64 NB, i64 *__restrict__ cnt) {
+// (fb: the table is 2^fb times finer than the digits -- a producer's FINE partition)
+__global__ void diff_counts_k(const i64 *__restrict__ bstart, i64 NB, int fb, i64 *__restrict__ cnt) {
     const i64 i = (i64)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < NB) cnt[i] = bstart[i + 1] - bstart[i];
+    if (i < NB) cnt[i] = bstart[(i + 1) << fb] - bstart[i << fb];
 }
 
 // esp_shard_assemble's ONE launch.  Workgroups [0, P): source q's row of piece starts, pstart[q][0 .. nb] = exclusive scan of
@@ -222,6 +223,7 @@ struct AsmArgs {
     unsigned long long *host;  // pinned: [0] seq | [1] longest merged segment | [2] negative lengths | [3] other kinds | [4, 4 + P + 1) summary
     unsigned long long seq;
     i64 nb;
+    int fb;  // own_bstart holds 2^fb entries per digit (a producer's FINE partition)
     int P, me, G;
 };
 constexpr int ASM_WORK_WORDS = 80 + 2 * 1024;  // (G <= 1024: at most 2^20 digits per shard)
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(1024) void assemble_k(AsmArgs a) {
         i64 *out = a.pstart + (size_t)q * (size_t)(nb + 1);
         if (q == a.me) {  // (the row itself is copied by the workgroups below, 1024 digits each: one workgroup would take 50 us for 2^16)
             if (t == 0) {
-                put(&summary[q], (unsigned long long)(a.own_bstart[nb] - a.own_bstart[0]));
+                put(&summary[q], (unsigned long long)(a.own_bstart[nb << a.fb] - a.own_bstart[0]));
                 put(&summary[a.P], (unsigned long long)a.own_bstart[0]);
             }
         } else {
@@ -278,7 +280,7 @@ __global__ __launch_bounds__(1024) void assemble_k(AsmArgs a) {
         i64 tot = 0;
         bool neg = false;
         if (d < nb) {
-            const i64 o0 = a.own_bstart[d], o1 = a.own_bstart[d + 1];
+            const i64 o0 = a.own_bstart[d << a.fb], o1 = a.own_bstart[(d + 1) << a.fb];
             i64 *own_row = a.pstart + (size_t)a.me * (size_t)(nb + 1);
             own_row[d] = o0;
             if (d == nb - 1) own_row[nb] = o1;
@@ -444,16 +446,19 @@ extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t s
     const int K = plan.K, shift = plan.shift, pb = plan.pb;
     const u64 nb64 = plan.nb64;
     const i64 NB = plan.NB;
-    if (from_producer && (h->pre.mw_shift != shift || h->pre.mw_nb != (u32)nb64))
+    // (a producer's FINE partition: its tables are 2^fb times finer than the plan's digits; counts, owner ranges and everything
+    // behind this call speak the plan's digits)
+    const int fbp = from_producer ? h->pre.fb : 0;
+    if (from_producer && (fbp > plan.fb || (fbp > 0 && fbp != plan.fb) || h->pre.mw_shift != shift - fbp || h->pre.mw_nb != (u32)(nb64 << fbp)))
         FAIL(h, ESP_ERR_STATE, "esp_shard_partition: internal error (the producer's plan differs)");
     // tables: bases (<= 64 u64) | owner offsets (<= 65 i64) | counts (NB i64)
     const size_t o_cnt = 256 * 8;
-    CK(ensure(h, h->parttab, o_cnt + sizeof(i64) * (size_t)(NB + 1)));
+    CK(ensure(h, h->parttab, o_cnt + sizeof(i64) * (size_t)((NB << fbp) + 1)));
     char *T = (char *)h->parttab.p;
     // (a producer's batch: prepart_begin wrote the window bases; the copy would queue behind the PART launch)
     if (!from_producer) HIPCK(h, hipMemcpyAsync(T, base.data(), sizeof(u64) * (size_t)P, hipMemcpyHostToDevice, h->stream));
     i64 *cnt = (i64 *)(T + o_cnt);
-    CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)(NB + 1)));
+    CK(ensure(h, h->seg[1], sizeof(i64) * (size_t)((NB << fbp) + 1)));
     CK(ensure(h, h->tilef[1], sizeof(u64) * (size_t)(NB + 1 + espscan::workspace_elems(NB + 1))));
     i64 *bstart = (i64 *)h->seg[1].p;
     std::vector<i64> off((size_t)P + 1, 0);
@@ -496,10 +501,10 @@ extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t s
     } else {
         hipStream_t qs = (E > 0 && (h->last_run_order == 1 || from_producer) && h->aux && h->aux_ev) ? h->aux : h->stream;
         if (qs == h->aux) HIPCK(h, hipStreamWaitEvent(h->aux, h->aux_ev, 0));  // (recorded right behind the ranking kernel)
-        hipLaunchKernelGGL(diff_counts_k, dim3(grid_for(NB, 256)), dim3(256), 0, qs, (const i64 *)bstart, NB, cnt);
+        hipLaunchKernelGGL(diff_counts_k, dim3(grid_for(NB, 256)), dim3(256), 0, qs, (const i64 *)bstart, NB, fbp, cnt);
         // owner ranges = bucket starts at every multiple of nb
         i64 *d_off = (i64 *)(T + 64 * 8);
-        hipLaunchKernelGGL(gather_stride_k, dim3(1), dim3(128), 0, qs, (const i64 *)bstart, (i64)nb64, P + 1, d_off);
+        hipLaunchKernelGGL(gather_stride_k, dim3(1), dim3(128), 0, qs, (const i64 *)bstart, (i64)(nb64 << fbp), P + 1, d_off);
         HIPCK(h, hipMemcpyAsync(off.data(), d_off, sizeof(i64) * (size_t)(P + 1), hipMemcpyDeviceToHost, qs));
         HIPCK(h, hipStreamSynchronize(qs));
         so.plan_id = from_producer ? h->pre.plan_id : 0;  // (0: the tables of this call are nobody's plan)
@@ -517,6 +522,7 @@ extern "C" int32_t esp_shard_partition(esp_handle *h, int32_t nshards, int32_t s
     h->part_me = self;
     h->part_shift = shift;
     h->part_nb = (u32)nb64;
+    h->part_fb = fbp;
     h->part_base = base[(size_t)self];
     h->part_span = (u64)(shard_col0(h->n, P, self + 1) - shard_col0(h->n, P, self)) << h->L.rb;
     *ok = 1;
@@ -531,7 +537,8 @@ extern "C" int32_t esp_shard_assemble(esp_handle *h, const uint64_t *const *d_re
     (void)hipSetDevice(h->device);
     const int P = h->part_P, me = h->part_me;
     const i64 nb = (i64)h->part_nb;
-    const i64 *bstart = (const i64 *)h->seg[1].p + (size_t)me * (size_t)nb;  // own range of the bucket starts
+    const int fb = h->part_fb;  // (a producer's FINE partition: 2^fb table entries per digit)
+    const i64 *bstart = (const i64 *)h->seg[1].p + (size_t)me * ((size_t)nb << fb);  // own range of the bucket starts
     // pointer table (keys | values | counts of every source) | piece starts
     const size_t o_ps = 256 * 8;
     CK(ensure(h, h->piecetab, o_ps + sizeof(i64) * (size_t)P * (size_t)(nb + 1)));
@@ -583,6 +590,7 @@ extern "C" int32_t esp_shard_assemble(esp_handle *h, const uint64_t *const *d_re
         aa.host = h->pin_asm;
         aa.seq = ++h->asm_seq;
         aa.nb = nb;
+        aa.fb = fb;
         aa.P = P, aa.me = me, aa.G = G;
         hipLaunchKernelGGL(assemble_k, dim3((unsigned)(P + G)), dim3(1024), 0, h->stream, aa);
         sp.add(1);

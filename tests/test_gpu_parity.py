@@ -2427,7 +2427,7 @@ def test_more_than_32_key_bits_below_the_prefix(esp):
     device results that must agree bit for bit -- the plain producer + the flush's own partition (packed keys), the producer-side
     partition with the fine plan (4-byte keys) and with the hook that forbids it (41: packed keys), the same stream as resident
     triplets through esp_append_device (fine plan, then its repetition over the kept run lists), and the shard producer through the
-    group API (packed keys: a shard's ranges travel)."""
+    group API (its own range as 4-byte keys of a fine partition; with hook 41 packed keys)."""
     import ctypes as C
     torch = pytest.importorskip("torch")
     n = 322
@@ -2468,14 +2468,20 @@ def test_more_than_32_key_bits_below_the_prefix(esp):
         assert T.debug_last_plan_reused() == it
         seen["triplets_%d" % it] = gu.digest(*hip_arrays(T))
     del T, rows, cols, vals
-    SA = esp.GroupShardedMatrix(N, N, nranks=1, rank=0, capacity_hint=E)
-    A = SA.local
-    for it in range(2):                 # (the second assembly finds the plan of the first flush: the producer partitions)
-        A.reset()
-        A.generate_fdrand(n, n, n, seed=7, rand_mode=1)
-        SA.flush()
-    assert A.debug_last_shard_source() == 2 and A.debug_last_key_bytes() == 8
-    seen["shard_producer"] = gu.digest(*hip_arrays(A))
+    # the shard producer: its tables 2^fb times finer than the exchange's digits, the own range 4-byte keys (third assembly: over
+    # the kept plan and the kept owner ranges); with hook 41: packed keys
+    for name, force, kb in (("shard_producer", 0, 4), ("shard_producer_packed", 41, 8)):
+        SA = esp.GroupShardedMatrix(N, N, nranks=1, rank=0, capacity_hint=E)
+        A = SA.local
+        A.debug_force_path(force)
+        for it in range(3 if force == 0 else 2):   # (the second assembly finds the plan of the first flush: the producer partitions)
+            A.reset()
+            A.generate_fdrand(n, n, n, seed=7, rand_mode=1)
+            SA.flush()
+            if it > 0:
+                assert A.debug_last_shard_source() == 2 and A.debug_last_key_bytes() == kb, (name, it, A.debug_last_key_bytes())
+        seen[name] = gu.digest(*hip_arrays(A))
+        del SA, A
     assert len(set(seen.values())) == 1, seen
 
 
@@ -2773,6 +2779,49 @@ def test_group_api_partitioned_exchange(esp, orc, world, deal):
     hist = _group_ranks_run(esp, orc, world, deal)
     for h in hist:
         assert h == [("partitioned", 7)] * 3, h
+
+
+@pytest.mark.parametrize("force", [0, 41])
+def test_group_api_fine_partition_two_ranks(esp, force):
+    """Two ranks (threads, one GPU) whose shards leave more than 32 key bits below the plan's prefix (322 x 322 x 162 nodes): from the
+    second assembly on the producers cut every digit of the plan in two or four buckets, their own ranges hold 4-byte keys, the neighbour's packed
+    keys are narrowed by the bucket kernel (boundary segments: two pieces) -- what an 8-GPU run of 512^3 does with 35 bits.  No
+    CPU oracle at this size: the stitched CSC must be the unsharded handle's, bit for bit; hook 41 (no fine partition): packed keys."""
+    from threaddist import ThreadComm, run_ranks
+    world, nx, ny, n = 2, 322, 322, 81      # (a shard just above 2^23 columns, 25 row bits: 33 or 34 bits below the plan's prefix)
+    nzg = n * world
+    N = nx * ny * nzg
+    nodes = nx * ny * n
+    R = esp.ExtendableSparseMatrix(N, N)
+    for seed in (77, 78, 79):            # (three assemblies onto the same matrix, like the ranks below)
+        R.generate_fdrand(nx, ny, nzg, seed=seed, rand_mode=1)
+        R.flush()
+    want = gu.digest(*hip_arrays(R))
+    want_nnz = R.nnz()
+    del R
+    comm = ThreadComm(world, esp._lib)
+
+    def body(rank, dist):
+        holder = {}
+        table = comm.table(rank, lambda: holder["A"].local._d.h)
+        A = esp.GroupShardedMatrix(N, N, nranks=world, rank=rank, comm=table)
+        holder["A"] = A
+        A.local.debug_force_path(force)
+        for rnd, seed in enumerate((77, 78, 79)):
+            A.local.generate_fdrand_range(nx, ny, nzg, rank * nodes, (rank + 1) * nodes, seed=seed, rand_mode=1)
+            A.flush()
+            assert A.last_exchange == "partitioned" and A.local.debug_last_partition() == 7
+            if rnd > 0:
+                assert A.local.debug_last_shard_source() == 2
+                assert A.local.debug_last_key_bytes() == (4 if force == 0 else 8), (rnd, A.local.debug_last_key_bytes())
+        return A.local_slice(), A.nnz()
+
+    outs = run_ranks(world, body)
+    if comm.errors:
+        raise comm.errors[0]
+    assert outs[0][1] == want_nnz
+    G = esp.GroupShardedMatrix.stitch(N, N, [o[0] for o in outs], outs[0][1])
+    assert gu.digest(*G.arrays()) == want
 
 
 def test_group_api_falls_back_by_consensus(esp, orc):
