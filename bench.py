@@ -619,6 +619,42 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
         pass
     except Exception as ex:
         out["cfg5_one_rank_shard"] = {"error": repr(ex)}
+    # ---- above 32 key bits below the planned prefix: 322^3 (33 bits) takes the FINE partition -- 4-byte keys as at 256^3 -- unsharded and
+    # as the one-rank shard (round 6); pinned by the oracle's digest at this size
+    try:
+        want("cfg5")
+        n = 322
+        N = n ** 3
+        E, Z = fd_counts(n)
+        algo = 2 * 16.0 * E + 16.0 * Z + 8.0 * (N + 1)
+        for tag, sharded in (("cfg_large_322", False), ("cfg_large_322_one_rank_shard", True)):
+            if sharded:
+                SA = esp.GroupShardedMatrix(N, N, nranks=1, rank=0, device=local, capacity_hint=E + 8 * n * n, unique_id=esp.GroupShardedMatrix.unique_id())
+                A = SA.local
+            else:
+                SA = None
+                A = esp.ExtendableSparseMatrix(N, N, device=local, capacity_hint=E + 8 * n * n)
+            dts = []
+            for it in range(min(steps, 10) + 3):
+                A.synchronize()
+                t0 = time.perf_counter()
+                A.reset()
+                A.generate_fdrand_range(n, n, n, 0, N, seed=0x5EED0002, rand_mode=1, kind=esp.ESP_UPDATE)
+                (SA if sharded else A).flush()
+                A.synchronize()
+                if it > 2:
+                    dts.append(time.perf_counter() - t0)
+            okl = csc_digest_ok(A, "fd_%d_m1" % n, pins)
+            dt = sum(dts) / len(dts)
+            out[tag] = {"workload": "fdrand %d^3 fresh assemble + flush (%s): 33 key bits below the planned prefix, 4-byte keys through the FINE partition"
+                                    % (n, "column-shard path with ONE rank" if sharded else "unsharded"),
+                        "ms": dt * 1e3, "nnz_per_s": Z / dt, "algorithmic_bytes": algo, "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS,
+                        "key_bytes": A.debug_last_key_bytes(), "steps": len(dts), "digest_ok": okl}
+            del SA, A
+    except _Skip:
+        pass
+    except Exception as ex:
+        out["cfg_large_322"] = {"error": repr(ex)}
     # ---- flush! of the MT wrapper (genericmtextendablesparsematrixcsc.jl:45-51 = Base.sum(xmatrices, csc)): the 2-D mesh
     # dealt to 16 partition buffers (contiguous chunks of the shuffled cell order), each filled by esp_append_elements, then
     # ONE esp_flush_sum into the handle that keeps the CSC -- device-resident; `plugin_ms`: the same through

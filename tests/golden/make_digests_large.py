@@ -60,8 +60,9 @@ def main():
                     kept[ln.split()[0]] = ln.strip()
     lines = []
     # BASELINE config 2 at full size (the bench configuration: rand_mode 1, seed 0x5EED0002, updateindex! style) and
-    # two smaller cubes
-    for n in (128, 192, 256):
+    # two smaller cubes; 322^3: 33 key bits below the planned prefix (the FINE partition: 4-byte keys above 32 bits, unsharded and as
+    # a one-rank shard -- bench.py's cfg_large_322)
+    for n in (128, 192, 256, 322):
         if not (want("fd_%d_m1" % n) or want("cfg3_%d" % n)):
             continue
         O = orc.fdrand(n, n, n, rand_mode=1, seed=0x5EED0002, style=orc.KIND_UPDATE)
