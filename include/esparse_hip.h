@@ -461,7 +461,8 @@ typedef enum {
                                         kernel reads them -- never the fused form that forms them from the sorted item records  */
     ESP_PATH_NO_FINE_PARTITION = 41, /* more than 32 key bits below the planned prefix (a stencil above 256^3): never the FINE partition
                                         (up to 4 more prefix bits, so that 4-byte keys serve, with the bucket kernel taking 2 .. 16
-                                        neighbouring buckets as one segment): packed 8-byte keys as before round 6              */
+                                        neighbouring buckets as one segment): packed 8-byte keys as before round 6 -- for a
+                                        shard's producer too (its own range: 2^fb buckets per digit of the exchange plan)      */
     ESP_PATH_NO_PLAN_REUSE = 31      /* esp_append_device / esp_commit of one kind on an empty buffer always count their columns
                                         (never the run lists of the previous, identical-looking batch)                      */
 } esp_debug_path;
