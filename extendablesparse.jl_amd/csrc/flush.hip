@@ -279,7 +279,7 @@ int32_t flush_local(esp_handle *h, const Sorted &st, int mode, i64 *Zn_out) {
                                                : st.p32_piece >= 0 ? (st.all_update && !generic ? 5 : 4)
                                                                    : (st.all_update && !generic ? 3 : 0))
                                             : st.key_bytes != 4 ? 0 : (st.kind == ESP_UPDATE && !generic ? 2 : 1);
-            h->last_fold_update = keys >= 2 ? 1 : 0;
+            h->last_fold_update = (keys == 2 || keys == 3 || keys == 5 || keys == 7) ? 1 : 0;  // (local.hpp: UPD)
             // the longest column run: what the handle's last flush met, or -- no history -- the pending entries per column (a
             // P1 mesh in 2-D: 24, in 3-D: 120; a wrong guess costs that one flush the radix tier)
             const double longest = h->seen_maxrun > 0 ? (double)h->seen_maxrun : (double)h->count / (double)std::max<i64>(col_end - col_begin, 1);

@@ -2783,12 +2783,13 @@ def test_group_api_partitioned_exchange(esp, orc, world, deal):
         assert h == [("partitioned", 7)] * 3, h
 
 
-@pytest.mark.parametrize("force", [0, 41])
-def test_group_api_fine_partition_two_ranks(esp, force):
+@pytest.mark.parametrize("force,kind", [(0, UPDATE), (0, RAW), (41, UPDATE)])
+def test_group_api_fine_partition_two_ranks(esp, force, kind):
     """Two ranks (threads, one GPU) whose shards leave more than 32 key bits below the plan's prefix (322 x 322 x 162 nodes): from the
     second assembly on the producers cut every digit of the plan in two or four buckets, their own ranges hold 4-byte keys, the neighbour's packed
     keys are narrowed by the bucket kernel (boundary segments: two pieces) -- what an 8-GPU run of 512^3 does with 35 bits.  No
-    CPU oracle at this size: the stitched CSC must be the unsharded handle's, bit for bit; hook 41 (no fine partition): packed keys."""
+    CPU oracle at this size: the stitched CSC must be the unsharded handle's, bit for bit; hook 41 (no fine partition): packed keys;
+    rawupdateindex! calls (kind RAW): the bucket kernel's generic fold over pieces of which one holds 4-byte keys (KEYS 4)."""
     from threaddist import ThreadComm, run_ranks
     world, nx, ny, n = 2, 322, 322, 81      # (a shard just above 2^23 columns, 25 row bits: 33 or 34 bits below the plan's prefix)
     nzg = n * world
@@ -2796,7 +2797,7 @@ def test_group_api_fine_partition_two_ranks(esp, force):
     nodes = nx * ny * n
     R = esp.ExtendableSparseMatrix(N, N)
     for seed in (77, 78, 79):            # (three assemblies onto the same matrix, like the ranks below)
-        R.generate_fdrand(nx, ny, nzg, seed=seed, rand_mode=1)
+        R.generate_fdrand(nx, ny, nzg, seed=seed, rand_mode=1, kind=kind)
         R.flush()
     want = gu.digest(*hip_arrays(R))
     want_nnz = R.nnz()
@@ -2810,9 +2811,10 @@ def test_group_api_fine_partition_two_ranks(esp, force):
         holder["A"] = A
         A.local.debug_force_path(force)
         for rnd, seed in enumerate((77, 78, 79)):
-            A.local.generate_fdrand_range(nx, ny, nzg, rank * nodes, (rank + 1) * nodes, seed=seed, rand_mode=1)
+            A.local.generate_fdrand_range(nx, ny, nzg, rank * nodes, (rank + 1) * nodes, seed=seed, rand_mode=1, kind=kind)
             A.flush()
             assert A.last_exchange == "partitioned" and A.local.debug_last_partition() == 7
+            assert bool(A.local.debug_last_fold_update()) == (kind == UPDATE)
             if rnd > 0:
                 assert A.local.debug_last_shard_source() == 2
                 assert A.local.debug_last_key_bytes() == (4 if force == 0 else 8), (rnd, A.local.debug_last_key_bytes())
