@@ -269,9 +269,19 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
     class _Skip(Exception):
         pass
 
+    # Python's cyclic collector stays off inside the timed loops (what `timeit` does): a full collection of a process that has
+    # torch loaded pauses EVERY thread for 50 - 80 ms, and the one the interpreter schedules a few hundred allocations into a run
+    # fell into the 10 - 20 timed rounds of cfg_mt_sum in about every other process -- 4.75 ms rounds with one of 55 - 85 ms,
+    # i.e. a mean of 7 - 11 ms (NOTES/round6.md section 10; the driver's round-5 record of this line: 23.6 ms against 6.7).
+    # Every config starts with an explicit collection instead; reference counting frees everything the loops drop.
+    import gc
+    gc.collect()
+    gc.disable()
+
     def want(name):
         if only and name not in only.split(","):
             raise _Skip()
+        gc.collect()
 
     def stages(tm, reps):
         return {k: round(v[0] / reps, 3) for k, v in tm.items() if isinstance(v, tuple) and v[0] > 0}
@@ -751,6 +761,7 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
             # which path served (2 = the folds as ONE launch over the buffers' item records; 0 = every buffer's own flush), how many
             # neighbouring segments the combine flush joined, and where the time went (host wall-clock, ms, mean of the timed rounds)
             "lazy_items": min(lazy), "sum_join": min(join), "fills_ms": 1e3 * sum(fills) / len(fills),
+            "fills_ms_steps": [round(1e3 * x, 2) for x in fills], "ms_steps": [round(1e3 * x, 2) for x in dts],
             "folds_ms": sum(folds) / len(folds), "combine_ms": sum(combine) / len(combine),
             "plugin_fresh_ms": tp[0] * 1e3, "plugin_same_pattern_ms": min(tp[1:]) * 1e3, "plugin_free_previous_result_ms": max(tfree) * 1e3}
         pool.shutdown()
@@ -808,6 +819,7 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
         pass
     except Exception as ex:
         out["cfg_mt_sum_per_entry"] = {"error": repr(ex)}
+    gc.enable()
     return out
 
 
@@ -875,6 +887,32 @@ def consumer_lines(esp, torch, A, N, Z, reps=5):
     out["eliminate_dirichlet"] = {"ms": timed(lambda: d.ck(d.lib.esp_eliminate_dirichlet(d.h, vp(mk), 1)), 2), "marked": int(mk.sum().item())}
     del x, r, inv, idg, mk
     return out
+
+
+def warm_page_cache():
+    """Reads every file this process has mapped (the ROCm runtime, torch, the library): on a FRESH box the first GPU process pays
+    its page faults from a cold page cache in the middle of timed steps -- stalls of 5 .. 70 ms in some rounds of cfg_mt_sum's
+    16-thread fills, gone in every later process (NOTES/round6.md section 10).  Untimed, like the warm-up steps.  Returns bytes read."""
+    seen, total = set(), 0
+    try:
+        with open("/proc/self/maps") as f:
+            for ln in f:
+                parts = ln.split(None, 5)
+                if len(parts) == 6 and parts[5].startswith("/") and ".so" in parts[5]:
+                    seen.add(parts[5].strip())
+    except OSError:
+        return 0
+    for path in sorted(seen):
+        try:
+            with open(path, "rb", buffering=0) as f:
+                while True:
+                    b = f.read(1 << 24)
+                    if not b:
+                        break
+                    total += len(b)
+        except OSError:
+            pass
+    return total
 
 
 def summary_of(out):
@@ -1027,11 +1065,16 @@ def main():
         step()
     barrier()
     A.timing(clear=True)
+    # (no cyclic collection inside the timed region -- see extra_configs; every step of the region runs, nothing is skipped)
+    import gc
+    gc.collect()
+    gc.disable()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
     sent = SA.sent_off_rank if SA is not None and getattr(SA, "sent_off_rank", None) is not None else 0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
