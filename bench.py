@@ -771,8 +771,8 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
     except Exception as ex:
         out["cfg_mt_sum"] = {"error": repr(ex)}
     # ---- ... and its per-entry form (test/femtools.jl:88-107: every task calls updateindex! / rawupdateindex! with its tid): 16 buffers
-    # of 2 10^6 calls each, mixed kinds -- not element batches: esp_flush_sum's general path, every buffer's own fold (side by side on
-    # the library's host pool since round 6), their entries gathered, one routed flush.  Timed: the flush! alone (the per-entry
+    # of 2 10^6 calls each, mixed kinds -- not element batches: esp_flush_sum's general path -- the buffers' folds as ONE flush of a
+    # scratch matrix with their occupied column ranges side by side (round 6), its entries gathered, one routed flush.  Timed: the flush! alone (the per-entry
     # appends are the host loop's).
     try:
         want("cfg_mt_sum")
@@ -810,7 +810,7 @@ def extra_configs(esp, torch, local, n_cfg3, fem2d, fem3d, steps=3):
         algo = 16.0 * Ein + 2 * 16.0 * Z + 16.0 * Z + 8.0 * (n5 + 1)   # (pending entries read, the folds written and read, the CSC written)
         out["cfg_mt_sum_per_entry"] = {
             "workload": "%d partition buffers of %d per-entry updateindex! / rawupdateindex! calls each (mixed kinds, a band of columns per tid), "
-                        "flush! = ONE esp_flush_sum: general path (every buffer's own fold, side by side on the host pool; gather; one routed "
+                        "flush! = ONE esp_flush_sum: general path (the buffers' folds as one flush of a scratch matrix; gather; one routed "
                         "flush) -- the flush! alone is timed" % (p5, len(streams[0][0])),
             "ms": dt * 1e3, "nnz_per_s": Z / dt, "final_nnz": Z, "algorithmic_bytes": algo, "frac_of_hbm_peak": algo / dt / 1e9 / HBM_PEAK_GBS,
             "steps": len(dts), "digest_ok": okp}

@@ -106,6 +106,7 @@ SIGNATURES = {
     "esp_debug_last_lazy_items": (i32, [vp, P(i32)]),
     "esp_debug_last_sum_join": (i32, [vp, P(i32)]),
     "esp_debug_last_sum_ms": (i32, [vp, P(C.c_double), P(C.c_double)]),
+    "esp_debug_last_sum_batched": (i32, [vp, P(C.c_int32)]),
     "esp_debug_last_sum_plan_bits": (i32, [vp, P(i32), P(i32)]),
     "esp_debug_last_rebuild": (i32, [vp, P(i32)]),
     "esp_group_unique_id": (i32, [vp]),

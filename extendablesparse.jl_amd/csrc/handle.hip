@@ -112,7 +112,7 @@ void release(DevBuf &b) {
 void release_all(esp_handle *h) {
     for (DevBuf *b : {&h->keys, &h->vals, &h->keys2, &h->vals2, &h->hist, &h->segs, &h->colend, &h->newkey,
                       &h->newval, &h->heads, &h->misc, &h->colptr, &h->colptr2, &h->rowval, &h->nzval, &h->rowval2,
-                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->tseg, &h->ttile, &h->runbuf, &h->chunkbuf, &h->parttab, &h->piecetab, &h->asmwork, &h->csr_rowptr, &h->csr_perm, &h->csr_col, &h->csr_tmp, &h->csr_val, &h->mul_x, &h->mul_r, &h->lazy_hold, &h->elemplan.sorted, &h->elemplan.cellrec, &h->elemplan.segtab, &h->stage.d_rows, &h->stage.d_cols, &h->stage.d_vals, &h->stage.d_kinds, &h->bulk.d_rows, &h->bulk.d_cols, &h->bulk.d_vals, &h->bulk.d_kinds})
+                      &h->nzval2, &h->seg[0], &h->seg[1], &h->tilef[0], &h->tilef[1], &h->segcnt, &h->segout, &h->tseg, &h->ttile, &h->runbuf, &h->chunkbuf, &h->parttab, &h->piecetab, &h->asmwork, &h->sumrange, &h->csr_rowptr, &h->csr_perm, &h->csr_col, &h->csr_tmp, &h->csr_val, &h->mul_x, &h->mul_r, &h->lazy_hold, &h->elemplan.sorted, &h->elemplan.cellrec, &h->elemplan.segtab, &h->stage.d_rows, &h->stage.d_cols, &h->stage.d_vals, &h->stage.d_kinds, &h->bulk.d_rows, &h->bulk.d_cols, &h->bulk.d_vals, &h->bulk.d_kinds})
         release(*b);
     for (esp_handle::StageArea *sa : {&h->stage, &h->bulk}) {
         if (sa->rows) (void)hipHostFree(sa->rows);
@@ -271,6 +271,10 @@ extern "C" int32_t esp_destroy(esp_handle *h) {
     if (!h) return ESP_OK;
     (void)hipSetDevice(h->device);
     (void)hipStreamSynchronize(h->stream);
+    if (h->sumtmp) {
+        (void)esp_destroy(h->sumtmp);
+        h->sumtmp = nullptr;
+    }
     release_all(h);
 #ifdef ESP_EXPERIMENTS
     esp_exp_check_graveyard();
@@ -301,6 +305,10 @@ extern "C" int32_t esp_release_buffers(esp_handle *h) {
     (void)hipSetDevice(h->device);
     HIPCK(h, hipStreamSynchronize(h->stream));
     timing_collect(h);
+    if (h->sumtmp) {  // (the scratch matrix of esp_flush_sum's batched folds)
+        (void)esp_destroy(h->sumtmp);
+        h->sumtmp = nullptr;
+    }
     release_all(h);
     h->cap = 0;
     h->count = 0;

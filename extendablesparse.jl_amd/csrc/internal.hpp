@@ -284,6 +284,11 @@ struct esp_handle {
     i64 part_total = 0, part_maxlen = 0, part_own_lo = 0;
     int part_fb = 0;              // the own range came from a producer's FINE partition: 2^part_fb buckets of seg[1] per digit
     DevBuf parttab, piecetab;
+    // esp_flush_sum's general path: the buffers' folds as ONE flush of a scratch handle with p n columns (buffer k's entries in the
+    // columns [k n, (k + 1) n)); made on first use, destroyed with this handle
+    esp_handle *sumtmp = nullptr;
+    DevBuf sumrange;                       // ... the buffers' column ranges (device side of one round trip)
+    int last_sum_batched = 0;              // the last esp_flush_sum folded its buffers in one flush of sumtmp
     DevBuf asmwork;                        // esp_shard_assemble's kernel: ticket | summary | per-workgroup partial results (zeroed once)
     unsigned long long *pin_asm = nullptr;  // ... and the pinned block its last workgroup writes the results to
     unsigned long long asm_seq = 0;

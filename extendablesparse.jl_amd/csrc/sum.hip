@@ -18,6 +18,103 @@ __global__ __launch_bounds__(256) void csc_as_coo_k(const i64 *__restrict__ colp
         vals[e] = nzval[e];
     }
 }
+// the buffers of a batched fold: where their packed keys / values lie, how many, where they go in the scratch matrix; a kernel
+// over all of them takes 4096 entries per workgroup (blk[j] = first workgroup of buffer j)
+struct BufTab {
+    const u64 *keys[64];
+    const double *vals[64];
+    i64 count[64], at[64];
+    u64 shift[64];
+    u32 blk[65];
+    int q;
+};
+__device__ __forceinline__ int buf_of_block(const BufTab &b, u32 blk) {
+    int j = 0;
+#pragma unroll
+    for (int step = 32; step; step >>= 1)
+        if (j + step < b.q && b.blk[j + step] <= blk) j += step;
+    return j;
+}
+// smallest / largest column (0-based) among every buffer's packed keys: out[2 j] = min, out[2 j + 1] = max (initialised to ~0 / 0)
+__global__ __launch_bounds__(256) void col_range_k(BufTab b, int colshift, unsigned long long *__restrict__ out_all) {
+    __shared__ u64 smin[4], smax[4];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int jb = buf_of_block(b, blockIdx.x);
+    const u64 *keys = b.keys[jb];
+    const i64 count = b.count[jb], first = (i64)(blockIdx.x - b.blk[jb]) * 4096;
+    unsigned long long *out = out_all + 2 * jb;
+    u64 lo = ~0ull, hi = 0ull;
+    for (i64 i = first + t; i < min(count, first + 4096); i += 256) {
+        const u64 c = keys[i] >> colshift;
+        lo = c < lo ? c : lo;
+        hi = c > hi ? c : hi;
+    }
+#pragma unroll
+    for (int o = 32; o; o >>= 1) {
+        const u64 a = (u64)__shfl_xor((long long)lo, o, 64), b = (u64)__shfl_xor((long long)hi, o, 64);
+        lo = a < lo ? a : lo;
+        hi = b > hi ? b : hi;
+    }
+    if (lane == 0) smin[w] = lo, smax[w] = hi;
+    __syncthreads();
+    if (t == 0) {
+        for (int i = 1; i < 4; i++) {
+            lo = smin[i] < lo ? smin[i] : lo;
+            hi = smax[i] > hi ? smax[i] : hi;
+        }
+        atomicMin(&out[0], (unsigned long long)lo);
+        atomicMax(&out[1], (unsigned long long)hi);
+    }
+}
+// the scratch matrix of the batched folds back into COO entries of the buffers' matrix: its column c lies in block j =
+// the last one with off[j] <= c, and is column c - off[j] + cmin[j] there
+struct BlockTab {
+    i64 off[65];
+    i64 cmin[64];
+    int q;
+};
+__global__ __launch_bounds__(256) void blocks_as_coo_k(const i64 *__restrict__ colptr, const i64 *__restrict__ rowval, const double *__restrict__ nzval,
+                                                       i64 nv, KeyLayout L, BlockTab tab, u64 *__restrict__ keys, double *__restrict__ vals) {
+    // entry-parallel (coalesced reads and stores): a workgroup takes 256 columns, their colptr slice in LDS, every entry finds its
+    // column by a binary search there (csc_keys_k's scheme)
+    __shared__ i64 cp[257];
+    const int t = threadIdx.x;
+    const i64 c0 = (i64)blockIdx.x * 256;
+    for (int q = t; q <= 256; q += 256) cp[q] = colptr[min(c0 + q, nv)] - 1;
+    __syncthreads();
+    const i64 e0 = cp[0], e1 = cp[256];
+    for (i64 e = e0 + t; e < e1; e += 256) {
+        int lo = 0, hi = 256;  // invariant cp[lo] <= e < cp[hi]
+#pragma unroll
+        for (int step = 0; step < 8; step++) {
+            const int mid = (lo + hi) >> 1;
+            if (cp[mid] <= e)
+                lo = mid;
+            else
+                hi = mid;
+        }
+        const i64 c = c0 + lo;
+        int j = 0;
+#pragma unroll
+        for (int step = 32; step; step >>= 1)
+            if (j + step < tab.q && tab.off[j + step] <= c) j += step;
+        keys[e] = esp_pack(L, rowval[e], c - tab.off[j] + tab.cmin[j] + 1, ESP_COO);
+        vals[e] = nzval[e];
+    }
+}
+// a buffer's pending entries (packed keys) into the scratch matrix of the batched folds: the same entries, their columns moved by
+// `shift` (as it sits in a packed key; modulo 2^64) into the buffer's block of columns
+__global__ __launch_bounds__(256) void shift_columns_k(BufTab b, u64 *__restrict__ keys_out, double *__restrict__ vals_out) {
+    const int jb = buf_of_block(b, blockIdx.x);
+    const u64 *keys_in = b.keys[jb];
+    const double *vals_in = b.vals[jb];
+    const i64 count = b.count[jb], first = (i64)(blockIdx.x - b.blk[jb]) * 4096, at = b.at[jb];
+    const u64 shift = b.shift[jb];
+    for (i64 i = first + threadIdx.x; i < min(count, first + 4096); i += 256) {
+        keys_out[at + i] = keys_in[i] + shift;
+        vals_out[at + i] = vals_in[i];
+    }
+}
 
 // ---- the buffers' folds as ONE launch (every buffer holds an element batch as sorted items: esp_handle::LazyItems) ----------
 // flags[k S + s] = 1 when segment s of buffer k holds items
@@ -281,6 +378,135 @@ static int32_t flush_sum_items(esp_handle *dst, esp_handle *const *xs, int p, in
     return ESP_OK;
 }
 
+// Steps 1 + 2 as ONE flush (round 6): the non-empty buffers' pending entries go -- packed keys -- into a scratch handle
+// (esp_handle::sumtmp) whose columns are the buffers' OCCUPIED column ranges side by side (buffer k's columns cmin_k .. cmax_k at
+// off_k ..: no column is shared, and a buffer that fills a band of the matrix takes a band's worth of columns -- the plan sees dense
+// columns, where the buffer's own flush planned for its whole, nearly empty key window and met thousands of columns per segment, the
+// bucket kernel's slowest tier).  The scratch handle's flush folds every buffer by itself in one partition + one bucket-kernel pass;
+// its CSC, read column after column, is the same list of folded entries in the same order that q flushes and q gathers produced.
+// *used = false: not applicable (one buffer, windows / shards / test hooks on a buffer, too many key bits) -- the caller folds one by one.
+static int32_t sum_batched_folds(esp_handle *dst, esp_handle *const *xs, int p, i64 *folded, bool *used) {
+    *used = false;
+    std::vector<int> idx;
+    i64 total = 0;
+    for (int k = 0; k < p; k++)
+        if (xs[k]->count != 0) {
+            const esp_handle *x = xs[k];
+            if (windowed(x) || x->shard_user || x->part_assembled || x->force_path != ESP_PATH_AUTO) return ESP_OK;
+            idx.push_back(k);
+            total += x->count;
+        }
+    const int q = (int)idx.size();
+    if (q < 2 || q > 64 || dst->force_path != ESP_PATH_AUTO || total >= 0xFFFFFFF0ll) return ESP_OK;
+    // the buffers' packed keys where they can be read, and their column ranges (one launch each, one round trip for all)
+    CK(ensure(dst, dst->misc, 256));
+    DevBuf &rb_ = dst->sumrange;
+    CK(ensure(dst, rb_, sizeof(unsigned long long) * 128));
+    std::vector<unsigned long long> init(128);
+    for (int j = 0; j < 64; j++) init[(size_t)2 * j] = ~0ull, init[(size_t)2 * j + 1] = 0ull;
+    HIPCK(dst, hipMemcpyAsync(rb_.p, init.data(), sizeof(unsigned long long) * 128, hipMemcpyHostToDevice, dst->stream));
+    const int colshift = dst->L.rb + ESP_TAG_BITS;
+    BufTab bt;
+    memset(&bt, 0, sizeof bt);
+    bt.q = q;
+    i64 blocks = 0;
+    for (int j = 0; j < q; j++) {
+        esp_handle *x = xs[(size_t)idx[(size_t)j]];
+        int32_t rc = pending_materialize(x);
+        if (rc == ESP_OK) rc = settle_offset(x);
+        if (rc != ESP_OK) {
+            dst->err = x->err;
+            return rc;
+        }
+        HIPCK(dst, hipStreamSynchronize(x->stream));  // (the buffer's appends may still be on their way)
+        bt.keys[j] = (const u64 *)x->keys.p;
+        bt.vals[j] = (const double *)x->vals.p;
+        bt.count[j] = x->count;
+        bt.blk[j] = (u32)blocks;
+        blocks += grid_for(x->count, 4096);
+    }
+    bt.blk[q] = (u32)blocks;
+    hipLaunchKernelGGL(col_range_k, dim3((unsigned)blocks), dim3(256), 0, dst->stream, bt, colshift, (unsigned long long *)rb_.p);
+    std::vector<unsigned long long> rng(128);
+    HIPCK(dst, hipMemcpyAsync(rng.data(), rb_.p, sizeof(unsigned long long) * 128, hipMemcpyDeviceToHost, dst->stream));
+    HIPCK(dst, hipStreamSynchronize(dst->stream));
+    BlockTab tab;
+    memset(&tab, 0, sizeof tab);
+    tab.q = q;
+    i64 nv = 0;
+    for (int j = 0; j < q; j++) {
+        const i64 c0 = (i64)rng[(size_t)2 * j], c1 = (i64)rng[(size_t)2 * j + 1];
+        if (c0 < 0 || c1 >= dst->n || c0 > c1) return ESP_OK;  // (a key outside the matrix: the buffer's own flush reports it)
+        tab.off[j] = nv;
+        tab.cmin[j] = c0;
+        nv += c1 - c0 + 1;
+    }
+    tab.off[q] = nv;
+    {
+        int cb = 1;
+        while (cb < 62 && ((i64)1 << cb) < nv + nv / 4) cb++;
+        if (dst->L.rb + cb > 62) return ESP_OK;  // (esp_create would refuse: more than 62 key bits)
+    }
+    // the scratch handle: at least nv columns (kept while nv stays between a quarter of its columns and all of them)
+    esp_handle *t = dst->sumtmp;
+    if (t && (t->m != dst->m || t->n < nv || t->n / 4 > nv)) {
+        (void)esp_destroy(t);
+        dst->sumtmp = t = nullptr;
+    }
+    if (!t) {
+        if (esp_create(dst->m, nv + nv / 4, dst->device, total, &t) != ESP_OK) return ESP_OK;
+        dst->sumtmp = t;
+    }
+    if (t->L.rb != dst->L.rb) return ESP_OK;
+    auto fail_t = [&](int32_t rc) {
+        dst->err = t->err;
+        (void)esp_reset(t);
+        return rc;
+    };
+    {
+        int32_t rc = esp_reset(t);
+        if (rc == ESP_OK) rc = esp_set_column_window(t, 1, nv);
+        if (rc == ESP_OK) rc = reserve_append(t, total);
+        if (rc != ESP_OK) return fail_t(rc);
+    }
+    i64 at = 0;
+    for (int j = 0; j < q; j++) {
+        esp_handle *x = xs[(size_t)idx[(size_t)j]];
+        bt.shift[j] = (u64)(tab.off[j] - tab.cmin[j]) << colshift;  // (modulo 2^64: a block may move down as well as up)
+        bt.at[j] = at;
+        if (x->kind_uniform >= 0 && x->kind_noted == x->count) note_kind(t, x->kind_uniform, x->count);
+        t->count += x->count;
+        at += x->count;
+    }
+    {
+        Span sp(dst, ESP_ST_APPEND);
+        hipLaunchKernelGGL(shift_columns_k, dim3((unsigned)blocks), dim3(256), 0, t->stream, bt, (u64 *)t->keys.p, (double *)t->vals.p);
+        sp.add(1);
+    }
+    HIPCK(dst, hipGetLastError());
+    pending_changed(t);
+    int64_t z = 0;
+    {
+        const int32_t rc = esp_flush(t, ESP_FLUSH_ROUTED, &z, nullptr);
+        if (rc != ESP_OK) return fail_t(rc);
+    }
+    if (z > 0) {
+        CK(reserve_append(dst, z));
+        HIPCK(dst, hipStreamSynchronize(t->stream));
+        Span sp(dst, ESP_ST_APPEND);
+        hipLaunchKernelGGL(blocks_as_coo_k, dim3(grid_for(nv, 256)), dim3(256), 0, dst->stream, (const i64 *)t->colptr.p, (const i64 *)t->rowval.p,
+                           (const double *)t->nzval.p, nv, dst->L, tab, (u64 *)dst->keys.p + dst->count, (double *)dst->vals.p + dst->count);
+        sp.add(1);
+        HIPCK(dst, hipGetLastError());
+        note_kind(dst, ESP_COO, z);
+        dst->count += z;
+        pending_changed(dst);
+    }
+    *folded = z;
+    *used = true;
+    return ESP_OK;
+}
+
 // Base.sum(xmatrices, csc) (sparsematrixdilnkc.jl:397-435; flush! of GenericMTExtendableSparseMatrixCSC,
 // genericmtextendablesparsematrixcsc.jl:45-51).  The reference lists the CSC's entries, then every buffer's -- each buffer
 // holds ONE value per position, the fold of the calls it received -- and hands the triplets to sparse!(I, J, V, m, n, +):
@@ -327,6 +553,13 @@ extern "C" int32_t esp_flush_sum(esp_handle *dst, esp_handle *const *xs, int32_t
         // launches and two or three host round trips each overlap well: 16 buffers of 2 10^6 entries 8.8 -> 6.6 ms, of 2 10^5
         // entries 3.8 -> 1.7 ms (tools/r6_sum_threads.py).  (Rounds 4 / 5 had taken the threads away: what looked like a hazard of
         // concurrent flushes was the bucket kernel's missing barrier.)
+        bool batched = false;
+        CK(sum_batched_folds(dst, xs, p, &folded, &batched));
+        dst->last_sum_batched = batched ? 1 : 0;
+        if (batched) {
+            t_b = t_c = now();
+            return esp_flush(dst, ESP_FLUSH_ROUTED, new_nnz, pattern_changed);
+        }
         {
             std::vector<int> idx;
             for (int k = 0; k < p; k++)
@@ -391,6 +624,7 @@ extern "C" int32_t esp_flush_sum(esp_handle *dst, esp_handle *const *xs, int32_t
         dst->err = msg;
     }
     for (int k = 0; k < p; k++) (void)esp_reset(xs[k]);
+    if (dst->sumtmp) (void)esp_reset(dst->sumtmp);  // (its CSC was read by dst's stream, which is idle now)
     return rc;
 }
 
@@ -401,6 +635,11 @@ extern "C" int32_t esp_debug_last_sum_plan_bits(const esp_handle *h, int32_t *pb
     if (!h || !pb_min || !pb_max) return ESP_ERR_INVALID;
     *pb_min = h->last_sum_plan_bits[0];
     *pb_max = h->last_sum_plan_bits[1];
+    return ESP_OK;
+}
+extern "C" int32_t esp_debug_last_sum_batched(const esp_handle *h, int32_t *batched) {
+    if (!h || !batched) return ESP_ERR_INVALID;
+    *batched = h->last_sum_batched;
     return ESP_OK;
 }
 extern "C" int32_t esp_debug_last_sum_ms(const esp_handle *h, double *folds_ms, double *combine_ms) {

@@ -26,9 +26,10 @@
  *     use included (genericmtextendablesparsematrixcsc.jl:87-99: one buffer per task;
  *     tests/test_concurrent_handles.py; the corruption rounds 4 and 5 saw here was a
  *     missing barrier inside the bucket kernel, NOTES/round6.md section 1).  The library
- *     starts no threads of its own on the flush path, with one exception: esp_flush_sum folds
- *     buffers that are not element batches side by side on its host-copy pool (at most eight
- *     threads with the caller's; ESP_HOST_THREADS caps it);
+ *     starts no threads of its own on the flush path, with one exception: when esp_flush_sum
+ *     cannot fold its buffers in one flush (esp_debug_last_sum_batched 0: a column window or a
+ *     test hook on a buffer) it folds them one by one, side by side on its host-copy pool (at
+ *     most eight threads with the caller's; ESP_HOST_THREADS caps it);
  *   - element types: Float64 values, Int64 indices (the reference's default
  *     ExtendableSparseMatrix{Float64,Int64}); other Tv/Ti stay on the CPU path.
  */
@@ -515,6 +516,10 @@ int32_t esp_debug_last_sum_join(const esp_handle *h, int32_t *segments);
  * every buffer's own flush) | everything behind them (gather, combine flush, its completion) -- what a bench line reports beside
  * esp_debug_last_lazy_items / _sum_join so that a slow run can be told from a run that took the other path */
 int32_t esp_debug_last_sum_ms(const esp_handle *h, double *folds_ms, double *combine_ms);
+/* 1 when the destination's last esp_flush_sum folded its buffers -- not element batches with one plan: per-entry calls, mixed kinds,
+ * anything -- in ONE flush of a scratch matrix with p n columns (buffer k in the columns [k n, (k + 1) n): no column is shared, every
+ * buffer is folded by itself) instead of one flush per buffer; 0: one by one (a single buffer, a window or test hook on a buffer) */
+int32_t esp_debug_last_sum_batched(const esp_handle *h, int32_t *batched);
 /* the smallest / largest number of prefix bits the buffers of the destination's last joint esp_flush_sum (last_lazy_items 2) had planned
  * for their item partitions: every handle plans from its own history, the joint path takes the coarsest plan (test hook) */
 int32_t esp_debug_last_sum_plan_bits(const esp_handle *h, int32_t *pb_min, int32_t *pb_max);

@@ -476,6 +476,62 @@ def test_flush_sum_and_values_only_transfers(esp, orc):
     assert r2.colptr is r1.colptr
 
 
+@pytest.mark.parametrize("shape", ["bands", "everywhere"])
+def test_flush_sum_batched_and_one_by_one(esp, orc, shape):
+    """esp_flush_sum over buffers of per-entry calls (not element batches): the folds as ONE flush of a scratch matrix whose columns
+    are the buffers' occupied column ranges side by side (round 6) against every buffer's own flush (a test hook on the destination
+    switches the batched form off) against the oracle's successive csc + buffer.  Buffers in bands of columns that overlap their
+    neighbours' / spread over the whole matrix, SET / UPDATE / RAWUPDATE calls, repeated positions, explicit zeros, an empty buffer,
+    a stored matrix that some calls hit; two rounds (the second over the scratch handle kept from the first)."""
+    import ctypes as C
+    rng = np.random.default_rng(61)
+    m, n, p = 5000, 60000, 7
+    O = orc.CSC(m, n)
+    homes = [esp.SparseMatrixHIPCOO(m, n), esp.SparseMatrixHIPCOO(m, n)]
+    homes[1]._d.ck(homes[1]._d.lib.esp_debug_force_path(homes[1]._d.h, 31))     # (any hook on the destination: one by one)
+    cscs = [esp.SparseMatrixCSC(m, n), esp.SparseMatrixCSC(m, n)]
+    for rnd in range(2):
+        lnks, streams = [], []
+        for t in range(p):
+            L = orc.SparseMatrixLNK(m, n)
+            lnks.append(L)
+            if t == 3:
+                streams.append(None)                      # an empty buffer
+                continue
+            cnt = 30000 + 1000 * t
+            if shape == "bands":
+                lo, hi = 1 + t * n // p - 500 * (t > 0), (t + 1) * n // p + 500 * (t + 1 < p)
+                J = np.sort(rng.integers(lo, hi + 1, cnt))
+            else:
+                J = rng.integers(1, n + 1, cnt)
+            I = rng.integers(1, 40, cnt) + (J % (m - 50))     # (few rows per column: repeated positions)
+            V = np.where(rng.random(cnt) < 0.05, 0.0, rng.standard_normal(cnt))
+            K = rng.choice(np.array([0, 1, 2], np.uint8), cnt, p=[0.1, 0.6, 0.3])
+            streams.append((I, J, V, K))
+            for k, i, j, v in zip(K.tolist(), I.tolist(), J.tolist(), V.tolist()):
+                if k == 0:
+                    L[i, j] = v
+                elif k == 1:
+                    L.updateindex(orc.OP_ADD, v, i, j)
+                else:
+                    L.rawupdateindex(orc.OP_ADD, v, i, j)
+        for L in lnks:
+            if L.nnz() > 0:
+                O = L + O
+        for which, home in enumerate(homes):
+            xs = [esp.SparseMatrixHIPCOO(m, n) for _ in range(p)]
+            for x, st in zip(xs, streams):
+                if st is not None:
+                    x.append(0, st[0], st[1], st[2], kinds=st[3])
+            cscs[which] = esp.SparseMatrixHIPCOO.sum(xs, cscs[which], home=home)
+            flag = C.c_int32(-1)
+            home._d.ck(home._d.lib.esp_debug_last_sum_batched(home._d.h, C.byref(flag)))
+            assert flag.value == (1 if which == 0 else 0), (which, flag.value)
+            assert_csc_equal(cscs[which].arrays(), O.arrays(), "round %d %s" % (rnd, "batched" if which == 0 else "one by one"))
+            for x in xs:
+                x.close() if hasattr(x, "close") else None
+
+
 def test_device_consumer_hand_off_and_external_stream(esp, orc):
     """esp_csc_device (the hand-off to consumers that stay on the GPU), esp_get_nzval and esp_set_stream: an assembly on a
     caller-made stream, the device CSC read straight from the pointers the library hands out."""

@@ -51,3 +51,20 @@ for name, fn in (("classes", step_py), ("c-abi", step_c), ("classes", step_py), 
         fn()
     A.synchronize()
     print("%-8s %.4f ms per step" % (name, (time.perf_counter() - t0) / steps * 1e3))
+
+
+# where the host's time goes inside one step (the GPU idles from the end of a flush until the next PART launch starts)
+import statistics  # noqa: E402
+
+tr, tg, tf = [], [], []
+for _ in range(steps):
+    a0 = time.perf_counter()
+    lib.esp_reset(h)
+    a1 = time.perf_counter()
+    lib.esp_generate_fdrand(h, n, n, n, 0x5EED0002, 1, esp.ESP_UPDATE)
+    a2 = time.perf_counter()
+    lib.esp_flush(h, esp.ESP_FLUSH_ROUTED, zr, cr)
+    a3 = time.perf_counter()
+    tr.append(a1 - a0), tg.append(a2 - a1), tf.append(a3 - a2)
+print("host time per call (median us): esp_reset %.1f  esp_generate_fdrand %.1f  esp_flush %.1f" % (
+    statistics.median(tr) * 1e6, statistics.median(tg) * 1e6, statistics.median(tf) * 1e6))
