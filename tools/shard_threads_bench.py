@@ -55,6 +55,9 @@ def body(rank, dist):
         A.synchronize()
         dist.barrier()
         out.append((time.perf_counter() - t0, SA.last_exchange, A.debug_last_partition(), SA.sent_off_rank))
+    # (how the last flush's own range was held: shard_source 2 = the producer partitioned by (owner, digit) itself; key bytes 4 = its
+    # own range as 4-byte keys -- above 32 key bits below the plan's prefix through the FINE partition, round 6)
+    out.append(("source", A.debug_last_shard_source(), "key_bytes", A.debug_last_key_bytes()))
     return out, SA.nnz()
 
 
@@ -62,6 +65,6 @@ res = run_ranks(W, body)
 if comm.errors:
     raise SystemExit("transport errors: %r" % (comm.errors[:3],))
 for r, (o, nnz) in enumerate(res):
-    print("rank", r, [(round(t * 1e3, 2), ex, part, sent) for (t, ex, part, sent) in o], "global nnz", nnz)
+    print("rank", r, [(round(t * 1e3, 2), ex, part, sent) for (t, ex, part, sent) in o[:-1]], o[-1], "global nnz", nnz)
 assert all(nnz == Z_total for (_, nnz) in res), (Z_total, [nnz for (_, nnz) in res])
 print("ok (%s): global nnz" % deal, Z_total, "=", W, "ranks x", n, "^3 nodes")
