@@ -3,7 +3,8 @@
 patterns, stream orders (sorted / clustered / shuffled), multi-flush sequences, both flush modes --
 every result compared bit for bit with the CPU oracle.  usage: tests/fuzz_parity.py [seconds] [seed]   (test infrastructure: it runs the CPU oracle)
 ESP_FUZZ_FOCUS=k32: shapes and batches that reach the 4-byte keys / UPDATE-only fold of the bucket kernel;
-ESP_FUZZ_FOCUS=elements: only the element-level append (esp_append_elements) and Base.sum (esp_flush_sum) cases."""
+ESP_FUZZ_FOCUS=elements: only the element-level append (esp_append_elements) and Base.sum (esp_flush_sum) cases;
+ESP_FUZZ_FOCUS=sum: only Base.sum over buffers of per-entry calls (esp_flush_sum's general path)."""
 import os
 import sys
 import time
@@ -263,8 +264,73 @@ def elements_case():
     return True
 
 
+def sum_case():
+    """Base.sum over p buffers of per-entry calls (sparsematrixdilnkc.jl:397-435; esp_flush_sum's general path: the folds as ONE
+    flush of a scratch matrix, round 6): buffers in bands of columns that overlap / spread over the whole matrix / one of them
+    empty / tall matrices, SET / UPDATE / RAWUPDATE, repeated positions, zeros; two rounds onto the same stored matrix, the
+    second with hits; now and then a test hook on the destination (the one-by-one form)."""
+    import ctypes as C
+    p = int(rng.choice([2, 3, 5, 9]))
+    n = int(rng.choice([40, 3000, 250000, 3000000]))
+    m = int(rng.choice([7, 900, 10 ** 6, 2 ** 33]))
+    home = esp.SparseMatrixHIPCOO(m, n)
+    one_by_one = rng.random() < 0.2
+    if one_by_one:
+        home._d.ck(home._d.lib.esp_debug_force_path(home._d.h, 31))
+    csc = esp.SparseMatrixCSC(m, n)
+    Oc = orc.CSC(m, n)
+    shape = str(rng.choice(["bands", "spread", "same"]))
+    for rnd in range(2):
+        xs = [esp.SparseMatrixHIPCOO(m, n) for _ in range(p)]
+        nonempty = 0
+        for t in range(p):
+            cnt = int(rng.choice([0, 3, 400, 20000, 120000]))
+            L = orc.SparseMatrixLNK(m, n)
+            if cnt:
+                nonempty += 1
+                if shape == "bands":
+                    w = max(1, n // p)
+                    lo = max(1, 1 + t * w - int(rng.integers(0, w // 2 + 1)))
+                    hi = min(n, (t + 1) * w + int(rng.integers(0, w // 2 + 1)))
+                elif shape == "same":
+                    lo, hi = max(1, n // 3), max(1, n // 3) + min(n - max(1, n // 3), 50)
+                else:
+                    lo, hi = 1, n
+                J = rng.integers(lo, hi + 1, cnt)
+                if rng.random() < 0.6:
+                    J = np.sort(J)
+                I = np.minimum(m, 1 + (J * 7 + rng.integers(0, 6, cnt)) % min(m, 10 ** 6))
+                V = np.where(rng.random(cnt) < 0.05, 0.0, rng.standard_normal(cnt))
+                K = rng.choice(np.array([0, 1, 2], np.uint8), cnt, p=[0.1, 0.6, 0.3])
+                xs[t].append(0, I, J, V, kinds=K)
+                for k, i, j, v in zip(K.tolist(), I.tolist(), J.tolist(), V.tolist()):
+                    if k == 0:
+                        L[i, j] = v
+                    elif k == 1:
+                        L.updateindex(orc.OP_ADD, v, i, j)
+                    else:
+                        L.rawupdateindex(orc.OP_ADD, v, i, j)
+            if L.nnz() > 0:
+                Oc = L + Oc
+        csc = esp.SparseMatrixHIPCOO.sum(xs, csc, home=home)
+        flag = C.c_int32(-1)
+        home._d.lib.esp_debug_last_sum_batched(home._d.h, C.byref(flag))
+        try:
+            assert_csc_equal(csc.arrays(), Oc.arrays())
+        except AssertionError:
+            print("MISMATCH sum case", dict(p=p, m=m, n=n, shape=shape, rnd=rnd, one_by_one=one_by_one, batched=flag.value, case=cases))
+            raise
+        key = ("sum", shape, flag.value if nonempty else -1)
+        paths[key] = paths.get(key, 0) + 1
+    return True
+
+
 max_cases = int(os.environ.get("ESP_FUZZ_MAXCASES", "0"))
 while time.time() < t_end and (max_cases == 0 or cases < max_cases):
+    if (rng.random() < 0.08 or os.environ.get("ESP_FUZZ_FOCUS") == "sum") and os.environ.get("ESP_FUZZ_FOCUS") not in ("k32", "elements"):
+        if sum_case():
+            cases += 1
+        continue
     if (rng.random() < 0.12 or os.environ.get("ESP_FUZZ_FOCUS") == "elements") and os.environ.get("ESP_FUZZ_FOCUS") != "k32":
         if elements_case():
             cases += 1
