@@ -317,6 +317,7 @@ extern "C" int32_t esp_release_buffers(esp_handle *h) {
     h->rawplan.valid = false;
     h->genplan.valid = false;
     h->elemplan.valid = false;
+    h->shard_offsets.plan_id = 0;  // (the counts it vouches for lived in parttab)
     pending_changed(h);
     h->csc_valid = false;
     h->ones_pending = false;
