@@ -953,8 +953,8 @@ def summary_of(out):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--n", type=int, default=int(os.environ.get("ESP_BENCH_N", "256")))
     ap.add_argument("--cpu-sample-n", type=int, default=int(os.environ.get("ESP_BENCH_CPU_N", "256")))
     ap.add_argument("--cpu-mt-n", type=int, default=int(os.environ.get("ESP_BENCH_CPU_MT_N", "192")))
